@@ -1,0 +1,289 @@
+/* seqdex.h — C ABI of libseqdex_hip.so: the MI355X-native replacement for the two
+ * third-party engines on the BlockAssemblyGraspSim hot path of sequential-dexterity/SeqDex.
+ *
+ *   SIM  (sdx_*) : what the task calls on Isaac Gym's tensor API          (SURVEY.md §8(b) seam 2)
+ *   TASK (sdx_*) : the reference-owned per-step tensor code, fused on GPU  (§8(a) rows T1-T9)
+ *   PPO  (sdxp_*): what rl_games' A2CAgent does per epoch                 (§8(a) rows R1-R9)
+ *
+ * Citations are file:line under /root/reference/dexteroushandenvs/:
+ *   GS = tasks/block_assembly/allegro_hand_block_assembly_grasp_sim.py
+ *   BT = tasks/hand_base/base_task.py     VR = tasks/hand_base/vec_task_rlgames.py
+ *   PS = policy_sequencing/policy_seq_runner.py   RC = utils/rl_games_custom.py
+ *   YG = cfg/lego/ppo_continuous_grasp.yaml
+ *
+ * Conventions: every function returns 0 on success or a negative sdx_status; no exceptions cross the
+ * boundary; handles are opaque; every buffer returned by *_tensor() is device memory owned by the
+ * library, stable until *_destroy(); all device work is enqueued on the caller's hipStream_t (passed as
+ * void* so that this header needs no HIP include) and is stream-ordered with no hidden synchronisation
+ * unless the function's comment says "blocking".  One host thread per handle.  Quaternions are xyzw.
+ */
+#ifndef SEQDEX_H
+#define SEQDEX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDX_ABI_VERSION 1
+
+/* ---- fixed scene dimensions of BlockAssemblyGraspSim (GS:523-1058) ---- */
+#define SDX_NLINK 24        /* robot bodies after collapse_fixed_joints (GS:543); body 0 is the fixed base  */
+#define SDX_NDOF 23         /* 7 arm + 16 hand revolute DOF (GS:561, 580-590)                               */
+#define SDX_MAX_RBOX 32     /* robot collision boxes                                                         */
+#define SDX_NBRICK 132      /* 72 free (GS:717-746) + 60 fixed floor bricks (GS:748-808)                     */
+#define SDX_NFREE 72
+#define SDX_NBRICK_TYPES 8  /* GS:706                                                                        */
+#define SDX_MAX_STATIC 8    /* table, 5 bin walls, merged brick floor, base plate                            */
+#define SDX_ACTORS 142      /* hand, object, goal, table, 5 bin boxes, 132 bricks, base plate                */
+#define SDX_BODIES 165      /* 24 hand links + one body per other actor                                      */
+#define SDX_ACTOR_BRICK0 9  /* first brick actor inside an env                                               */
+#define SDX_BODY_BRICK0 32  /* first brick rigid body inside an env                                          */
+#define SDX_NUM_OBS 396     /* 132 x 3 stacked frames (GS:207-209)                                           */
+#define SDX_NUM_STATES 564  /* 188 x 3 (GS:204-210)                                                          */
+#define SDX_NUM_ACTIONS 23  /* GS:211                                                                        */
+#define SDX_OBS_FRAME 132
+#define SDX_STATE_FRAME 188
+#define SDX_TV_PARAMS 42562 /* GraspInsertTValue 4-256-128-64-2 weights+biases (terminal_value_function.py:30-46) */
+
+typedef enum {
+  SDX_OK = 0,
+  SDX_ERR_INVALID = -1,     /* bad argument / null pointer / bad id                     */
+  SDX_ERR_HIP = -2,         /* a HIP runtime call failed; see sdx_last_error()          */
+  SDX_ERR_NO_DEVICE = -3,   /* no gfx950 device visible: the product path has NO CPU fallback */
+  SDX_ERR_STATE = -4,       /* call order violated (e.g. step before initial states)    */
+  SDX_ERR_NOMEM = -5
+} sdx_status;
+
+typedef enum { SDX_F32 = 0, SDX_I64 = 1, SDX_I32 = 2, SDX_U8 = 3 } sdx_dtype;
+
+/* Tensor ids for sdx_tensor().  Shapes use N = num_envs. */
+typedef enum {
+  SDX_T_ROOT = 0,        /* f32 [N*142,13]  acquire_actor_root_state_tensor      GS:237,321              */
+  SDX_T_DOF = 1,         /* f32 [N*23,2]    acquire_dof_state_tensor             GS:238,313-316          */
+  SDX_T_RB = 2,          /* f32 [N,165,13]  acquire_rigid_body_state_tensor      GS:239,318              */
+  SDX_T_CONTACT = 3,     /* f32 [N,165*3]   acquire_net_contact_force_tensor     GS:240,322              */
+  SDX_T_JAC_EEF = 4,     /* f32 [N,6,7]     jacobian_tensor[:, 7-1, :, :7]       GS:241,1601             */
+  SDX_T_TARGETS = 5,     /* f32 [N,23]      cur_targets == PD targets            GS:329,1638             */
+  SDX_T_PREV_TARGETS = 6,/* f32 [N,23]      prev_targets                         GS:328,1636             */
+  SDX_T_OBS = 7,         /* f32 [N,396]     task.obs_buf (unclamped)             BT:57, GS:1299-1332     */
+  SDX_T_STATES = 8,      /* f32 [N,564]     task.states_buf (unclamped)          BT:59, GS:1220-1280     */
+  SDX_T_OBS_CLAMPED = 9, /* f32 [N,396]     clamp(obs_buf,+-5) as VR:171 returns                         */
+  SDX_T_STATES_CLAMPED = 10, /* f32 [N,564] clamp(states_buf,+-5) as VR:172 returns                      */
+  SDX_T_REW = 11,        /* f32 [N]         task.rew_buf                         BT:61, GS:1061          */
+  SDX_T_RESET = 12,      /* i64 [N]         task.reset_buf (initialised to 1)    BT:63                   */
+  SDX_T_PROGRESS = 13,   /* i64 [N]         task.progress_buf                    BT:65                   */
+  SDX_T_RANDOMIZE = 14,  /* i64 [N]         task.randomize_buf                   BT:67, GS:1642          */
+  SDX_T_ACTIONS = 15,    /* f32 [N,23]      task.actions (clamped copy)          GS:1570, VR:166         */
+  SDX_T_INIT_POS = 16,   /* f32 [N,3]       segmentation_target_init_pos         GS:453,1547             */
+  SDX_T_INIT_ROT = 17,   /* f32 [N,4]       segmentation_target_init_rot         GS:454,1548             */
+  SDX_T_SUCCESSES = 18,  /* f32 [N]         successes                            GS:337,1552             */
+  SDX_T_META_REW = 19,   /* f32 [N]         meta_rew_buf                         GS:367,1069,1553        */
+  SDX_T_CONS_SUCCESSES = 20, /* f32 [1]     consecutive_successes                GS:338,1771-1774        */
+  SDX_T_FINGER_DIST = 21,/* f32 [N]         arm_hand_finger_dist                 GS:1164-1165            */
+  SDX_T_TVALUE = 22,     /* f32 [N]         tvalue                               GS:1200-1201            */
+  SDX_T_ARM_CONTACTS = 23,/* f32 [N,6]      contacts (bodies 1..6 >= 0.1 N)      GS:1159-1162            */
+  SDX_T_STUDENT_OBS = 24,/* f32 [N,30]      extras["student_obs_buf"]            GS:458                  */
+  SDX_T_SUCCESS_BUF = 25,/* i64 [N]         extras["success_buf"]                GS:459                  */
+  SDX_T_PILE_CHOICE = 26,/* i32 [N]         saved-pile index drawn at the last reset of each env  GS:1510 */
+  SDX_T_NCONTACTS = 27,  /* i32 [N]         contact points generated in the last substep (diagnostic)    */
+  SDX_T_COUNT = 28
+} sdx_tensor_id;
+
+/* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the
+ * reference's URDF/STL/OBJ assets and shipped as seqdex_amd/scene_data/grasp_sim_scene.json. */
+typedef struct {
+  int32_t abi_version;                 /* = SDX_ABI_VERSION */
+  /* robot kinematic tree */
+  float base_pos[3];                   /* GS:624-626 */
+  float base_quat[4];
+  int32_t parent[SDX_NLINK];           /* -1 for body 0 */
+  float joint_pos[SDX_NLINK][3];       /* joint frame origin in the parent body frame */
+  float joint_quat[SDX_NLINK][4];      /* joint frame rotation in the parent body frame */
+  float joint_axis[SDX_NLINK][3];      /* revolute axis in the child frame */
+  float lower[SDX_NDOF], upper[SDX_NDOF];
+  float kp[SDX_NDOF], kd[SDX_NDOF], effort[SDX_NDOF], vel_limit[SDX_NDOF], armature[SDX_NDOF]; /* GS:580-590 */
+  float link_mass[SDX_NLINK];
+  float link_com[SDX_NLINK][3];        /* body frame */
+  float link_inertia[SDX_NLINK][6];    /* about COM, body frame: xx yy zz xy xz yz */
+  int32_t n_rbox;
+  int32_t rbox_link[SDX_MAX_RBOX];
+  float rbox_center[SDX_MAX_RBOX][3];
+  float rbox_quat[SDX_MAX_RBOX][4];
+  float rbox_half[SDX_MAX_RBOX][3];
+  /* bricks */
+  float brick_half[SDX_NBRICK_TYPES][3];
+  float brick_center[SDX_NBRICK_TYPES][3];   /* box centre in the brick's mesh frame */
+  float brick_mass[SDX_NBRICK_TYPES];
+  float brick_inertia[SDX_NBRICK_TYPES][3];  /* principal, about the box centre */
+  int32_t brick_type[SDX_NBRICK];
+  /* static boxes (world frame, axis aligned) */
+  int32_t n_static;
+  float static_center[SDX_MAX_STATIC][3];
+  float static_half[SDX_MAX_STATIC][3];
+  /* default actor states for everything that is not a brick (written into ROOT at create) */
+  float object_init_state[13];         /* GS:687-689,927-929 */
+  float goal_reset_pos[3];             /* goal_init_state + goal_displacement, GS:694-700,1348 */
+  float static_actor_pos[6][3];        /* table + 5 bin walls, actor slots 3..8 */
+  float base_plate_pos[3];             /* GS:838 */
+  float fixed_brick_pos[SDX_NBRICK - SDX_NFREE][3];
+  float free_spawn_pos[SDX_NFREE][3];  /* GS:737-742 */
+  float free_spawn_quat[4];
+  /* task constants */
+  int32_t hand_base_body;              /* 7, GS:355 */
+  int32_t fingertip_body[4];           /* link_3.0, link_7.0, link_11.0, link_15.0: ff, mf, rf, th  GS:183-186 */
+  float camera_offset_quat[4];         /* GS:887-888 */
+  float camera_offset_pos[3];          /* GS:889 */
+  float arm_prepare_pose[7];           /* GS:267 */
+  float finger_reset_unscaled[16];     /* GS:1531 */
+  float insert_pose_a[7], insert_pose_b[7]; /* GS:278,281 */
+  float max_episode_length;            /* 150, EG:6 */
+  float act_moving_average;            /* 1.0, EG:16 */
+  float av_factor;                     /* 0.1, GS:151 */
+  float clip_obs, clip_actions;        /* 5, 1: VR:18 */
+  /* simulation parameters (CF:188, EG:155-167) and our solver constants */
+  float dt;
+  int32_t substeps;
+  int32_t solver_iters;
+  float contact_offset;
+  float gravity[3];
+  float friction;
+  float baumgarte;                     /* position-error feedback factor  */
+  float max_depenetration_vel;
+  float jacobi_relax;                  /* relaxation on the mass-split Jacobi update */
+} sdx_scene_desc;
+
+typedef struct sdx_sim* sdx_handle;
+
+/* Scene build: replaces create_sim/add_ground/load_asset/create_env/create_actor/prepare_sim
+ * (GS:505-1058, BT:83-84).  Blocking.  Fails with SDX_ERR_NO_DEVICE when no GPU is present. */
+int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t device, uint64_t seed, sdx_handle* out);
+int sdx_destroy(sdx_handle h);
+
+/* acquire_*_tensor + gymtorch.wrap_tensor (GS:237-241,313-322) and the BaseTask buffers (BT:57-68). */
+int sdx_tensor(sdx_handle h, int32_t id, void** dev_ptr, int64_t shape[4], int32_t* ndim, int32_t* dtype);
+
+/* Saved pile states: replaces pickle.load(".../saved_searching_ternimal_states_good_mo_tvalue.pkl")
+ * (GS:412-413): host float32 [8, K, 132, 13].  Blocking copy to HBM. */
+int sdx_load_initial_states(sdx_handle h, const float* piles_host, int32_t K);
+
+/* GraspInsertTValue parameters (GS:417-419): host float32[SDX_TV_PARAMS] packed as
+ * W1[256,4] b1[256] W2[128,256] b2[128] W3[64,128] b3[64] W4[2,64] b4[2].  Blocking. */
+int sdx_set_tvalue_weights(sdx_handle h, const float* params_host, int32_t n);
+
+/* BaseTask.step(actions) (BT:130-150) fused: pre_physics_step (GS:1555-1638, device-side masked reset
+ * instead of reset_buf.nonzero()) -> simulate x controlFreqInv (BT:138-140) -> post_physics_step
+ * (GS:1640-1658).  actions: device f32 [N,23], clamped to +-clip_actions inside (VR:166). */
+int sdx_step(sdx_handle h, const float* actions_dev, void* stream);
+
+/* The three stages of sdx_step as separate entry points (used by the parity tests and by callers that keep
+ * reference-style task code on top of the simulator). */
+int sdx_pre_physics(sdx_handle h, const float* actions_dev, void* stream);   /* GS:1555-1638 */
+int sdx_simulate(sdx_handle h, void* stream);                                /* BT:140 + refresh_* GS:1091-1095 */
+int sdx_post_physics(sdx_handle h, void* stream);                            /* GS:1640-1645 */
+
+/* compute_observations() only (GS:1090-1218): obs/states frames + stacking, no progress++/reward. */
+int sdx_compute_observations(sdx_handle h, void* stream);
+
+/* reset_idx(env_ids) (GS:1361-1553) for envs with env_mask_dev[i] != 0 (device u8 [N]).
+ * pile_choice_dev: device i32 [N] saved-pile index per env, or NULL to draw it from the counter RNG
+ * (the reference uses python random.sample, GS:1510). */
+int sdx_reset_idx(sdx_handle h, const uint8_t* env_mask_dev, const int32_t* pile_choice_dev, void* stream);
+
+/* refresh_rigid_body_state / jacobian after the caller overwrote DOF/ROOT through the tensor views
+ * (set_dof_state_tensor_indexed / set_actor_root_state_tensor_indexed, GS:1514,1543): recomputes FK,
+ * link velocities and the end-effector Jacobian from SDX_T_DOF. */
+int sdx_refresh_kinematics(sdx_handle h, void* stream);
+
+int sdx_num_envs(sdx_handle h);
+const char* sdx_last_error(sdx_handle h);   /* never NULL; h may be NULL for create-time errors */
+
+/* ======================================================================================= PPO */
+
+typedef struct {
+  int32_t num_actors;        /* N envs (TR:81-85 injects num_actors)                     */
+  int32_t horizon;           /* 8    YG:49 */
+  int32_t minibatch;         /* 4    YG:50 (must divide horizon*num_actors)              */
+  int32_t mini_epochs;       /* 5    YG:51 */
+  int32_t cv_minibatch;      /* 4    YG:75 */
+  int32_t cv_mini_epochs;    /* 5    YG:76 */
+  int32_t obs_dim;           /* 396 */
+  int32_t state_dim;         /* 564 */
+  int32_t act_dim;           /* 23  */
+  int32_t units[3];          /* 1024, 512, 256   YG:23 */
+  float gamma, tau;          /* 0.99, 0.95  YG:35-36 */
+  float lr, cv_lr;           /* 3e-4 YG:38, 1e-3 YG:77 */
+  float e_clip;              /* 0.1  YG:46 */
+  float grad_norm;           /* 1.0  YG:42 */
+  float critic_coef;         /* 1    YG:52 */
+  float entropy_coef;        /* 0    YG:43 */
+  float bounds_loss_coef;    /* 1e-3 YG:63 */
+  float kl_threshold;        /* 0.02 YG:54 */
+  int32_t clip_value;        /* 1    YG:47 */
+  int32_t truncate_grads;    /* 1    YG:44 */
+  int32_t normalize_advantage; /* 1  YG:34 */
+  int32_t cv_normalize_input;  /* 1  YG:82 */
+  int32_t adaptive_lr;       /* 1: lr_schedule adaptive, schedule_type legacy (YG:53, PS:306-312) */
+  int32_t world_size;        /* data-parallel ranks; gradients are averaged by the CALLER (RCCL) between
+                                sdxp_backward_* and sdxp_apply_* when world_size > 1 */
+} sdxp_config;
+
+typedef enum {
+  SDXP_T_AC_PARAMS = 0,      /* f32 [P_ac]   actor MLP | mu | logstd | critic MLP | value  (flat)   */
+  SDXP_T_AC_GRADS = 1,       /* f32 [P_ac]   flat gradient: the buffer RCCL all-reduces             */
+  SDXP_T_CV_PARAMS = 2,      /* f32 [P_cv]   central value MLP (flat)                               */
+  SDXP_T_CV_GRADS = 3,       /* f32 [P_cv]                                                          */
+  SDXP_T_MB_OBS = 4,         /* f32 [H,N,obs]     experience_buffer 'obses'   PS:346                */
+  SDXP_T_MB_STATES = 5,      /* f32 [H,N,state]   'states'                    PS:352                */
+  SDXP_T_MB_ACTIONS = 6,     /* f32 [H,N,act]                                                       */
+  SDXP_T_MB_MUS = 7,         /* f32 [H,N,act]                                                       */
+  SDXP_T_MB_SIGMAS = 8,      /* f32 [H,N,act]                                                       */
+  SDXP_T_MB_NEGLOGP = 9,     /* f32 [H,N]                                                           */
+  SDXP_T_MB_VALUES = 10,     /* f32 [H,N]                                                           */
+  SDXP_T_MB_REWARDS = 11,    /* f32 [H,N]                                                           */
+  SDXP_T_MB_DONES = 12,      /* f32 [H,N]         dones stored BEFORE the step, PS:347              */
+  SDXP_T_RETURNS = 13,       /* f32 [N*H]   env-major after swap_and_flatten01, PS:338-339          */
+  SDXP_T_ADVANTAGES = 14,    /* f32 [N*H]   normalised, RC:1645-1651                                */
+  SDXP_T_CV_RMS_MEAN = 15,   /* f32 [state] running mean (f64 on the host side of rl_games)         */
+  SDXP_T_CV_RMS_VAR = 16,    /* f32 [state]                                                         */
+  SDXP_T_STATS = 17,         /* f32 [16]    a_loss,c_loss,b_loss,entropy,kl,lr,... of the last update */
+  SDXP_T_LAST_VALUES = 18,   /* f32 [N]                                                             */
+  SDXP_T_AC_ADAM_M = 19, SDXP_T_AC_ADAM_V = 20, SDXP_T_CV_ADAM_M = 21, SDXP_T_CV_ADAM_V = 22,
+  SDXP_T_COUNT = 23
+} sdxp_tensor_id;
+
+typedef struct sdxp_agent* sdxp_handle;
+
+/* A2CAgent.__init__ + network build (R1,R2): torch-default Linear init (kaiming_uniform a=sqrt5) drawn from a
+ * counter RNG under `seed`, biases zero, logstd zero (YG:8-29, App. C).  Blocking. */
+int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed, sdxp_handle* out);
+int sdxp_destroy(sdxp_handle h);
+int sdxp_tensor(sdxp_handle h, int32_t id, void** dev_ptr, int64_t shape[4], int32_t* ndim, int32_t* dtype);
+int64_t sdxp_param_count(sdxp_handle h, int32_t which /*0 actor-critic, 1 central value*/);
+
+/* get_action_values (RC:1697-1723): actor forward, a = mu + sigma*eps (eps from the counter RNG, or from
+ * eps_dev f32 [N,act] when non-NULL), neglogp (RC:2114-2126), central value on states; stores row t of the
+ * experience buffer (PS:345-352): obs, states, actions, mus, sigmas, neglogp, values, dones_dev (f32 or NULL=0).
+ * actions_out_dev f32 [N,act] receives the sampled (unclamped) actions. */
+int sdxp_act(sdxp_handle h, int32_t t, const float* obs_dev, const float* states_dev, const float* dones_dev,
+             const float* eps_dev, float* actions_out_dev, void* stream);
+/* post_step (PS:355-359): rewards row t (reward_shaper scale 1, YG:32-33). */
+int sdxp_store_rewards(sdxp_handle h, int32_t t, const float* rew_dev, void* stream);
+/* play_steps tail (PS:329-339) + prepare_dataset (RC:1639-1651): last_values = V(states), GAE (R5), returns,
+ * flatten env-major, advantage normalisation with unbiased std (R6); updates the CV running mean/std. */
+int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const float* last_dones_dev, void* stream);
+/* train_central_value + the actor-critic minibatch loop of train_epoch (PS:294-326, RC:1339-1365): all
+ * mini-epochs, contiguous unshuffled minibatches, loss R7, grad-norm clip, Adam, legacy adaptive LR after
+ * every minibatch (R8).  Single-rank fast path: everything stays on the device. */
+int sdxp_update(sdxp_handle h, void* stream);
+/* Multi-rank path, one minibatch at a time so that the caller can all-reduce SDXP_T_*_GRADS in between:
+ * which = 0 actor-critic, 1 central value; mb = minibatch index within the epoch. */
+int sdxp_backward(sdxp_handle h, int32_t which, int32_t mb, void* stream);
+int sdxp_apply(sdxp_handle h, int32_t which, float kl_allreduced_or_nan, void* stream);
+const char* sdxp_last_error(sdxp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQDEX_H */

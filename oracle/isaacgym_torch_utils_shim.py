@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE ONLY (oracle/): our own restatement of the eleven public
+`isaacgym.torch_utils` helpers the reference task imports with
+`from isaacgym.torch_utils import *` (reference GS:36).
+
+Isaac Gym is a closed binary that is absent from /root/reference, so the reference
+task module cannot be imported without *something* registered under the module name
+`isaacgym.torch_utils`.  This file is that something.  It is registered by
+oracle/gen_golden.py (in the build container only) before importing the reference
+module to generate tests/golden/*.npz.  The formulas are public math, written from
+the definitions (quaternions are xyzw, Hamilton product); they are unit-tested on
+closed forms in tests/test_oracle_math.py.
+
+Nothing in the product path (seqdex_amd/) imports this file.
+"""
+from typing import Tuple
+
+import numpy as np
+import torch
+
+
+def to_torch(x, dtype=torch.float, device='cpu', requires_grad=False):
+    return torch.tensor(x, dtype=dtype, device=device, requires_grad=requires_grad)
+
+
+@torch.jit.script
+def normalize(x, eps: float = 1e-9):
+    return x / x.norm(p=2, dim=-1).clamp(min=eps, max=None).unsqueeze(-1)
+
+
+@torch.jit.script
+def quat_mul(a, b):
+    shape = a.shape
+    a = a.reshape(-1, 4)
+    b = b.reshape(-1, 4)
+    x1, y1, z1, w1 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    x2, y2, z2, w2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    ww = (z1 + x1) * (x2 + y2)
+    yy = (w1 - y1) * (w2 + z2)
+    zz = (w1 + y1) * (w2 - z2)
+    xx = ww + yy + zz
+    qq = 0.5 * (xx + (z1 - x1) * (x2 - y2))
+    w = qq - ww + (z1 - y1) * (y2 - z2)
+    x = qq - xx + (x1 + w1) * (x2 + w2)
+    y = qq - yy + (w1 - x1) * (y2 + z2)
+    z = qq - zz + (z1 + y1) * (w2 - x2)
+    return torch.stack([x, y, z, w], dim=-1).view(shape)
+
+
+@torch.jit.script
+def quat_conjugate(a):
+    shape = a.shape
+    a = a.reshape(-1, 4)
+    return torch.cat((-a[:, :3], a[:, -1:]), dim=-1).view(shape)
+
+
+@torch.jit.script
+def quat_apply(a, b):
+    shape = b.shape
+    a = a.reshape(-1, 4)
+    b = b.reshape(-1, 3)
+    xyz = a[:, :3]
+    t = xyz.cross(b, dim=-1) * 2
+    return (b + a[:, 3:] * t + xyz.cross(t, dim=-1)).view(shape)
+
+
+@torch.jit.script
+def quat_unit(a):
+    return normalize(a)
+
+
+@torch.jit.script
+def quat_from_angle_axis(angle, axis):
+    theta = (angle / 2).unsqueeze(-1)
+    xyz = normalize(axis) * theta.sin()
+    w = theta.cos()
+    return quat_unit(torch.cat([xyz, w], dim=-1))
+
+
+@torch.jit.script
+def tf_inverse(q, t):
+    q_inv = quat_conjugate(q)
+    return q_inv, -quat_apply(q_inv, t)
+
+
+@torch.jit.script
+def tf_combine(q1, t1, q2, t2):
+    return quat_mul(q1, q2), quat_apply(q1, t2) + t1
+
+
+@torch.jit.script
+def scale(x, lower, upper):
+    return 0.5 * (x + 1.0) * (upper - lower) + lower
+
+
+@torch.jit.script
+def unscale(x, lower, upper):
+    return (2.0 * x - upper - lower) / (upper - lower)
+
+
+@torch.jit.script
+def tensor_clamp(t, min_t, max_t):
+    return torch.max(torch.min(t, max_t), min_t)
+
+
+def torch_rand_float(lower, upper, shape, device):
+    # type: (float, float, Tuple[int, int], str) -> Tensor
+    return (upper - lower) * torch.rand(*shape, device=device) + lower

@@ -1,0 +1,131 @@
+"""Scene constants of BlockAssemblyGraspSim.
+
+`load_scene()` reads the compact table produced by tools/compile_scene.py from the reference's asset
+files (seqdex_amd/scene_data/grasp_sim_scene.json) and exposes it both as python attributes and as
+the `sdx_scene_desc` C struct (include/seqdex.h) that sdx_create() takes.  This replaces the scene
+construction of the reference's `_create_envs` (GS:523-1058) and `parse_sim_params` (CF:185-217).
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+from . import _abi
+
+_DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scene_data", "grasp_sim_scene.json")
+
+
+class Scene:
+    def __init__(self, raw):
+        self.raw = raw
+        rb = raw["robot"]
+        bodies = rb["bodies"]
+        assert len(bodies) == _abi.NLINK
+        self.base_pos, self.base_quat = rb["base_pos"], rb["base_quat"]
+        self.parent = [b["parent"] for b in bodies]
+        self.link_names = [b["name"] for b in bodies]
+        self.lower = np.array([bodies[i + 1]["lower"] for i in range(23)], dtype=np.float32)
+        self.upper = np.array([bodies[i + 1]["upper"] for i in range(23)], dtype=np.float32)
+        self.hand_base_body = rb["hand_base_body"]
+        self.fingertip_bodies = rb["fingertip_bodies"]            # ff, mf, rf, th (GS:183-186)
+        self.camera_offset_quat = raw["camera_offset_quat"]
+        self.camera_offset_pos = raw["camera_offset_pos"]
+        op = raw["vestigial_object_pos"]
+        yaw = 1.571                                                # GS:689 from_euler_zyx(0,0,1.571)
+        self.object_init_state = [op[0], op[1], op[2], 0.0, 0.0, math.sin(yaw / 2), math.cos(yaw / 2)] + [0.0] * 6
+        # goal_states[:, 0:3] = goal_init_state = object_init_state with z-0.02 (GS:1040-1042), + displacement (GS:1348)
+        self.goal_reset_pos = [op[0] - 0.2, op[1] - 0.06, op[2] - 0.02 - 10.12]
+        self.brick_types = raw["brick_types"]
+        self.statics = raw["statics"]
+        self.arm_prepare_pose = [0.0, -0.49826458111314524, -0.01990020486871322, -2.4732269941140346,
+                                 -0.01307073642274261, 2.00396583422025, 1.5480939705504309]     # GS:267
+        self.finger_reset_unscaled = [0, 0, -1, 0.5, 1, 0, -1, 0.5, 0, 0, -1, 0.5, 0, 0, -1, 0.5]  # GS:1531
+        self.insert_pose_a = [-0.1560, -0.2140, -0.2795, -2.1806, -0.0681, 1.9730, 1.1735]       # GS:278
+        self.insert_pose_b = [-0.1800, -0.1604, -0.2770, -2.2674, -0.0533, 2.1049, 1.1696]       # GS:281
+        # brick type of each of the 132 bricks: 9 layers x 8 types, then the 60 fixed floor bricks
+        self.brick_type = [i % 8 for i in range(_abi.NFREE)] + [fb["type"] for fb in raw["fixed_bricks"]]
+        self.sim = dict(raw["sim"])
+        # solver constants of our own physics definition
+        self.solver = dict(friction=1.0, baumgarte=0.2, max_depenetration_vel=1.0, jacobi_relax=1.0, armature=0.0)
+
+    # ------------------------------------------------------------------ helpers used by tests / task
+    def seg_index(self, env_i):
+        """actor index (inside the env) of env i's target brick: brick i%8 with {3,4,7}->0 (GS:962-965)."""
+        b = env_i % 8
+        return _abi.ACTOR_BRICK0 + (0 if b in (3, 4, 7) else b)
+
+    def to_desc(self, **overrides):
+        d = _abi.SceneDesc()
+        raw, rb = self.raw, self.raw["robot"]
+        d.abi_version = _abi.SDX_ABI_VERSION
+        d.base_pos[:] = self.base_pos
+        d.base_quat[:] = self.base_quat
+        for i, b in enumerate(rb["bodies"]):
+            d.parent[i] = b["parent"]
+            d.joint_pos[i][:] = b.get("joint_pos", [0, 0, 0])
+            d.joint_quat[i][:] = b.get("joint_quat", [0, 0, 0, 1])
+            d.joint_axis[i][:] = b.get("axis", [0, 0, 1])
+            d.link_mass[i] = b["mass"]
+            d.link_com[i][:] = b["com"]
+            I = b["inertia"]
+            d.link_inertia[i][:] = [I[0][0], I[1][1], I[2][2], I[0][1], I[0][2], I[1][2]]
+        for j in range(23):
+            dj = rb["dof"][j]
+            d.lower[j], d.upper[j] = float(self.lower[j]), float(self.upper[j])
+            d.kp[j], d.kd[j], d.effort[j], d.vel_limit[j] = dj["kp"], dj["kd"], dj["effort"], dj["vel_limit"]
+            d.armature[j] = self.solver["armature"]
+        k = 0
+        for i, b in enumerate(rb["bodies"]):
+            for bx in b["boxes"]:
+                assert k < _abi.MAX_RBOX
+                d.rbox_link[k] = i
+                d.rbox_center[k][:] = bx["center"]
+                d.rbox_quat[k][:] = bx["quat"]
+                d.rbox_half[k][:] = bx["half"]
+                k += 1
+        d.n_rbox = k
+        for t, bt in enumerate(self.brick_types):
+            d.brick_half[t][:] = bt["half"]
+            d.brick_center[t][:] = bt["center"]
+            d.brick_mass[t] = bt["mass"]
+            d.brick_inertia[t][:] = bt["inertia_diag"]
+        d.brick_type[:] = self.brick_type
+        d.n_static = len(self.statics)
+        assert d.n_static <= _abi.MAX_STATIC
+        for s, st in enumerate(self.statics):
+            d.static_center[s][:] = st["center"]
+            d.static_half[s][:] = st["half"]
+        d.object_init_state[:] = self.object_init_state
+        d.goal_reset_pos[:] = self.goal_reset_pos
+        for s in range(6):                      # table + 5 bin walls are the first six statics
+            d.static_actor_pos[s][:] = self.statics[s]["center"]
+        d.base_plate_pos[:] = raw["base_plate_pos"]
+        for i, fb in enumerate(raw["fixed_bricks"]):
+            d.fixed_brick_pos[i][:] = fb["pos"]
+        for i, fs in enumerate(raw["free_spawn"]):
+            d.free_spawn_pos[i][:] = fs["pos"]
+        d.free_spawn_quat[:] = raw["free_spawn"][0]["quat"]
+        d.hand_base_body = self.hand_base_body
+        d.fingertip_body[:] = self.fingertip_bodies
+        d.camera_offset_quat[:] = self.camera_offset_quat
+        d.camera_offset_pos[:] = self.camera_offset_pos
+        d.arm_prepare_pose[:] = self.arm_prepare_pose
+        d.finger_reset_unscaled[:] = self.finger_reset_unscaled
+        d.insert_pose_a[:] = self.insert_pose_a
+        d.insert_pose_b[:] = self.insert_pose_b
+        d.max_episode_length, d.act_moving_average, d.av_factor = 150.0, 1.0, 0.1
+        d.clip_obs, d.clip_actions = 5.0, 1.0
+        d.dt, d.substeps, d.solver_iters = self.sim["dt"], self.sim["substeps"], self.sim["pos_iters"]
+        d.contact_offset = self.sim["contact_offset"]
+        d.gravity[:] = self.sim["gravity"]
+        d.friction, d.baumgarte = self.solver["friction"], self.solver["baumgarte"]
+        d.max_depenetration_vel, d.jacobi_relax = self.solver["max_depenetration_vel"], self.solver["jacobi_relax"]
+        for k_, v in overrides.items():
+            setattr(d, k_, v)
+        return d
+
+
+def load_scene(path=None):
+    with open(path or _DEFAULT) as f:
+        return Scene(json.load(f))
