@@ -1,0 +1,651 @@
+/* TEST INFRASTRUCTURE ONLY (oracle/): plain-C, scalar, sequential restatement of the per-env physics step
+ * that seqdex_amd/csrc/sdx_physics.hip runs one wavefront per env (DESIGN.md §3 "SDX-1 physics").
+ *
+ * PARITY UNPINNED: the reference's physics lives in Isaac Gym / PhysX (closed binary, absent from
+ * /root/reference; call sites BT:138-144 gym.simulate/fetch_results, GS:1091-1095 refresh_*, parameters
+ * CF:185-217 + cfg/allegro_hand_block_assembly_grasp_sim.yaml:155-167, scene GS:523-1058).  There is no
+ * reference-side test or golden vector for it, so this file DEFINES the step (from the scene constants
+ * A0/A1 of SURVEY.md §8(a)) and is pinned only by the known-answer tests we author in
+ * tests/test_physics_oracle.py (free fall, resting contact, PD response, FK/Jacobian finite differences).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this code.
+ *
+ * Algorithm per env and per substep h = dt/substeps  (P1..P5 of SURVEY.md §8(a)):
+ *   A  forward kinematics of the 24-body tree, link twists
+ *   B  joint-space inertia M(q) (composite sums), H = M + diag(armature + h kd + h^2 kp), Hinv
+ *   C  implicit PD drive (P1):  qd += Hinv h clamp(kp(q*-q) - (kd + h kp) qd, +-effort);  bricks: v += h g
+ *   D  contacts (P3): boxes only; sample points of one box against the analytic SDF of the other,
+ *      both directions, <= 4 contacts per pair, kept when separation < contact_offset
+ *   E  solve (P4): `solver_iters` mass-split Jacobi iterations on accumulated impulses, normal +
+ *      2 friction rows, robot side in reduced coordinates (qd = qd* + Hinv J^T lambda)
+ *   F  integrate (P5): semi-implicit Euler, joint limit / velocity clamps, quaternion renormalisation
+ * then once per step: FK for outputs, end-effector Jacobian, net contact force of the last substep.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/seqdex.h"
+
+#define NL SDX_NLINK
+#define ND SDX_NDOF
+#define NF SDX_NFREE
+#ifndef SDXO_MAXC
+#define SDXO_MAXC 1280
+#endif
+#define NSAMP 28
+#define BODY_STATIC 255
+
+typedef float real;
+
+/* ---------------------------------------------------------------- small math */
+typedef struct { real x, y, z; } v3;
+typedef struct { real x, y, z, w; } q4;
+
+static v3 V(real x, real y, real z) { v3 r = {x, y, z}; return r; }
+static v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static v3 vscale(v3 a, real s) { return V(a.x * s, a.y * s, a.z * s); }
+static real vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static q4 qmul(q4 a, q4 b) {
+  q4 r;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  return r;
+}
+static q4 qconj(q4 a) { q4 r = {-a.x, -a.y, -a.z, a.w}; return r; }
+static v3 qrot(q4 q, v3 v) { /* v + w t + u x t, t = 2 u x v */
+  v3 u = V(q.x, q.y, q.z);
+  v3 t = vscale(vcross(u, v), 2.0f);
+  return vadd(vadd(v, vscale(t, q.w)), vcross(u, t));
+}
+static q4 qnormalize(q4 a) {
+  real n = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  q4 r = {a.x * n, a.y * n, a.z * n, a.w * n};
+  return r;
+}
+static q4 qaxis(v3 ax, real ang) {
+  real s = sinf(0.5f * ang), c = cosf(0.5f * ang);
+  q4 r = {ax.x * s, ax.y * s, ax.z * s, c};
+  return r;
+}
+static v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
+static q4 ld4(const float* p) { q4 r = {p[0], p[1], p[2], p[3]}; return r; }
+static void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+static void st4(float* p, q4 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; }
+
+/* sample points of a box in units of its half extents: 8 corners, 12 edge midpoints, 8 quarter points on the
+ * x-parallel edges.  Corners come first: selection is "first k in table order" (DESIGN.md §3.D). */
+static const real SAMP[NSAMP][3] = {
+    {-1, -1, -1}, {1, -1, -1}, {-1, 1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1},
+    {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
+    {-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0},
+    {-0.5f, -1, -1}, {0.5f, -1, -1}, {-0.5f, 1, -1}, {0.5f, 1, -1}, {-0.5f, -1, 1}, {0.5f, -1, 1}, {-0.5f, 1, 1}, {0.5f, 1, 1}};
+
+/* ---------------------------------------------------------------- per-env working state */
+typedef struct {
+  /* robot */
+  real q[ND], qd[ND], tgt[ND];
+  q4 lq[NL];           /* link orientation */
+  v3 lp[NL];           /* link frame origin (= joint anchor) */
+  v3 la[NL];           /* joint axis, world */
+  v3 lc[NL];           /* link COM, world */
+  v3 lv[NL], lw[NL];   /* link origin linear velocity, angular velocity */
+  unsigned anc[NL];    /* bit j set: dof j (link j+1) is on the path base -> this link */
+  real H[ND][ND], Hinv[ND][ND];
+  real qd_star[ND], Q[ND];
+  /* bricks (COM frame) */
+  v3 bp[NF], bv[NF], bw[NF];
+  q4 bq[NF];
+  v3 dv[NF], dw[NF];
+  int bcount[NF];
+  int rcount;          /* contacts touching the robot */
+  /* collision boxes of the robot in world */
+  v3 rc[SDX_MAX_RBOX];
+  q4 rq[SDX_MAX_RBOX];
+  /* contacts */
+  int nc;
+  unsigned char ca[SDXO_MAXC], cb[SDXO_MAXC]; /* body ids: 0..71 brick, 72+k robot link k, 255 static */
+  v3 cn[SDXO_MAXC], cp[SDXO_MAXC];
+  real csep[SDXO_MAXC];
+  real lam[SDXO_MAXC][3], w[SDXO_MAXC][2][3]; /* w[c][side][row]: un-split inverse effective mass */
+  unsigned char active[SDXO_MAXC];
+  int overflow;
+} env_t;
+
+typedef struct { v3 c; q4 q; v3 h; } box_t;
+
+/* ---------------------------------------------------------------- A: forward kinematics */
+static void fk(const sdx_scene_desc* sc, env_t* e) {
+  e->lq[0] = ld4(sc->base_quat);
+  e->lp[0] = ld3(sc->base_pos);
+  e->la[0] = V(0, 0, 1);
+  e->lv[0] = e->lw[0] = V(0, 0, 0);
+  e->anc[0] = 0;
+  e->lc[0] = vadd(e->lp[0], qrot(e->lq[0], ld3(sc->link_com[0])));
+  for (int k = 1; k < NL; ++k) { /* parents precede children (depth-first order) */
+    int p = sc->parent[k];
+    q4 qj = qmul(e->lq[p], ld4(sc->joint_quat[k]));
+    v3 ax = ld3(sc->joint_axis[k]);
+    e->lq[k] = qnormalize(qmul(qj, qaxis(ax, e->q[k - 1])));
+    e->lp[k] = vadd(e->lp[p], qrot(e->lq[p], ld3(sc->joint_pos[k])));
+    e->la[k] = qrot(qj, ax);
+    e->lc[k] = vadd(e->lp[k], qrot(e->lq[k], ld3(sc->link_com[k])));
+    e->lw[k] = vadd(e->lw[p], vscale(e->la[k], e->qd[k - 1]));
+    e->lv[k] = vadd(e->lv[p], vcross(e->lw[p], vsub(e->lp[k], e->lp[p])));
+    e->anc[k] = e->anc[p] | (1u << (k - 1));
+  }
+  for (int r = 0; r < sc->n_rbox; ++r) {
+    int k = sc->rbox_link[r];
+    e->rc[r] = vadd(e->lp[k], qrot(e->lq[k], ld3(sc->rbox_center[r])));
+    e->rq[r] = qmul(e->lq[k], ld4(sc->rbox_quat[r]));
+  }
+}
+
+/* world inertia times vector: R diag-full(I) R^T x, I given as xx yy zz xy xz yz in body frame */
+static v3 inertia_mul(q4 q, const float* I, v3 x) {
+  v3 l = qrot(qconj(q), x);
+  v3 m = V(I[0] * l.x + I[3] * l.y + I[4] * l.z, I[3] * l.x + I[1] * l.y + I[5] * l.z, I[4] * l.x + I[5] * l.y + I[2] * l.z);
+  return qrot(q, m);
+}
+
+/* ---------------------------------------------------------------- B: joint-space inertia and its inverse */
+static void mass_matrix(const sdx_scene_desc* sc, env_t* e, real h) {
+  for (int i = 0; i < ND; ++i)
+    for (int j = 0; j <= i; ++j) {
+      real s = 0;
+      for (int k = 1; k < NL; ++k) {
+        if (!((e->anc[k] >> i) & 1u) || !((e->anc[k] >> j) & 1u)) continue;
+        v3 ai = e->la[i + 1], aj = e->la[j + 1];
+        v3 li = vcross(ai, vsub(e->lc[k], e->lp[i + 1]));
+        v3 lj = vcross(aj, vsub(e->lc[k], e->lp[j + 1]));
+        s += sc->link_mass[k] * vdot(li, lj) + vdot(ai, inertia_mul(e->lq[k], sc->link_inertia[k], aj));
+      }
+      e->H[i][j] = e->H[j][i] = s;
+    }
+  for (int i = 0; i < ND; ++i) e->H[i][i] += sc->armature[i] + h * sc->kd[i] + h * h * sc->kp[i];
+  /* Cholesky H = L L^T (in a scratch copy), then Hinv = L^-T L^-1 */
+  real L[ND][ND], Li[ND][ND];
+  memset(L, 0, sizeof(L));
+  memset(Li, 0, sizeof(Li));
+  for (int j = 0; j < ND; ++j) {
+    real d = e->H[j][j];
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    d = sqrtf(d);
+    L[j][j] = d;
+    for (int i = j + 1; i < ND; ++i) {
+      real s = e->H[i][j];
+      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+      L[i][j] = s / d;
+    }
+  }
+  for (int c = 0; c < ND; ++c) /* Li = L^-1, column by column (forward substitution) */
+    for (int i = c; i < ND; ++i) {
+      real s = (i == c) ? 1.0f : 0.0f;
+      for (int k = c; k < i; ++k) s -= L[i][k] * Li[k][c];
+      Li[i][c] = s / L[i][i];
+    }
+  for (int i = 0; i < ND; ++i)
+    for (int j = 0; j <= i; ++j) {
+      real s = 0;
+      for (int k = i; k < ND; ++k) s += Li[k][i] * Li[k][j];
+      e->Hinv[i][j] = e->Hinv[j][i] = s;
+    }
+}
+
+/* ---------------------------------------------------------------- D: box / box sampled-SDF contacts */
+/* signed distance of point p (box frame) to box with half extents h; *g = outward unit gradient (box frame) */
+static real box_sdf(v3 p, v3 h, v3* g) {
+  v3 a = V(fabsf(p.x), fabsf(p.y), fabsf(p.z));
+  v3 d = vsub(a, h);
+  v3 s = V(p.x < 0 ? -1.0f : 1.0f, p.y < 0 ? -1.0f : 1.0f, p.z < 0 ? -1.0f : 1.0f);
+  real mx = fmaxf(d.x, fmaxf(d.y, d.z));
+  if (mx <= 0) { /* inside: nearest face */
+    if (d.x >= d.y && d.x >= d.z) *g = V(s.x, 0, 0);
+    else if (d.y >= d.z) *g = V(0, s.y, 0);
+    else *g = V(0, 0, s.z);
+    return mx;
+  }
+  v3 o = V(fmaxf(d.x, 0), fmaxf(d.y, 0), fmaxf(d.z, 0));
+  real len = sqrtf(vdot(o, o));
+  *g = V(s.x * o.x / len, s.y * o.y / len, s.z * o.z / len);
+  return len;
+}
+
+static void add_contact(env_t* e, int a, int b, v3 p, v3 n, real sep) {
+  if (e->nc >= SDXO_MAXC) { e->overflow++; return; }
+  int c = e->nc++;
+  e->ca[c] = (unsigned char)a;
+  e->cb[c] = (unsigned char)b;
+  e->cp[c] = p;
+  e->cn[c] = n;
+  e->csep[c] = sep;
+}
+
+/* samples of A against the SDF of B: fills up to 4 candidate sample indices (table order), returns count (<=4).
+ * A's sample l (A frame) in B's frame: t + qrel l with t = qB^-1 (cA - cB), qrel = qB^-1 qA. */
+static int sample_dir(const box_t* A, const box_t* B, real offset, int idx[4]) {
+  int cnt = 0;
+  q4 qbi = qconj(B->q);
+  v3 t = qrot(qbi, vsub(A->c, B->c));
+  q4 qrel = qmul(qbi, A->q);
+  for (int s = 0; s < NSAMP && cnt < 4; ++s) {
+    v3 l = V(A->h.x * SAMP[s][0], A->h.y * SAMP[s][1], A->h.z * SAMP[s][2]);
+    v3 pb = vadd(t, qrot(qrel, l));
+    v3 g;
+    if (box_sdf(pb, B->h, &g) < offset) idx[cnt++] = s;
+  }
+  return cnt;
+}
+
+static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb, const int idx[4], int k) {
+  q4 qbi = qconj(B->q);
+  v3 t = qrot(qbi, vsub(A->c, B->c));
+  q4 qrel = qmul(qbi, A->q);
+  for (int i = 0; i < k; ++i) {
+    int s = idx[i];
+    v3 l = V(A->h.x * SAMP[s][0], A->h.y * SAMP[s][1], A->h.z * SAMP[s][2]);
+    v3 pb = vadd(t, qrot(qrel, l));
+    v3 g;
+    real sd = box_sdf(pb, B->h, &g);
+    v3 n = qrot(B->q, g); /* out of B, towards A */
+    v3 pw = vadd(B->c, qrot(B->q, pb));
+    add_contact(e, ida, idb, vsub(pw, vscale(n, 0.5f * sd)), n, sd);
+  }
+}
+
+/* pair of boxes; bstatic != 0: B is a static box (only A's samples are tested) */
+static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int idb, int bstatic, real offset) {
+  int i1[4], i2[4];
+  int c1 = sample_dir(A, B, offset, i1);
+  int c2 = bstatic ? 0 : sample_dir(B, A, offset, i2);
+  int m2 = c2 < 2 ? c2 : 2;
+  int k1 = c1 < 4 - m2 ? c1 : 4 - m2;
+  int k2 = c2 < 4 - k1 ? c2 : 4 - k1;
+  emit_dir(e, A, B, ida, idb, i1, k1);
+  if (k2 > 0) emit_dir(e, B, A, idb, ida, i2, k2);
+}
+
+static real box_radius(v3 h) { return sqrtf(vdot(h, h)); }
+
+static void collide(const sdx_scene_desc* sc, env_t* e) {
+  const real off = sc->contact_offset;
+  e->nc = 0;
+  box_t bb[NF];
+  real br[NF];
+  for (int i = 0; i < NF; ++i) {
+    int t = sc->brick_type[i];
+    bb[i].c = e->bp[i];
+    bb[i].q = e->bq[i];
+    bb[i].h = ld3(sc->brick_half[t]);
+    br[i] = box_radius(bb[i].h);
+  }
+  /* (1) brick vs static */
+  for (int i = 0; i < NF; ++i)
+    for (int s = 0; s < sc->n_static; ++s) {
+      box_t S = {ld3(sc->static_center[s]), {0, 0, 0, 1}, ld3(sc->static_half[s])};
+      v3 g;
+      if (box_sdf(vsub(bb[i].c, S.c), S.h, &g) > br[i] + off) continue;
+      collide_pair(e, &bb[i], &S, i, BODY_STATIC, 1, off);
+    }
+  /* (2) brick vs brick */
+  for (int i = 0; i < NF; ++i)
+    for (int j = i + 1; j < NF; ++j) {
+      v3 d = vsub(bb[i].c, bb[j].c);
+      real rr = br[i] + br[j] + off;
+      if (vdot(d, d) > rr * rr) continue;
+      collide_pair(e, &bb[i], &bb[j], i, j, 0, off);
+    }
+  /* (3) robot box vs brick, (4) robot box vs static */
+  for (int r = 0; r < sc->n_rbox; ++r) {
+    int k = sc->rbox_link[r];
+    if (k == 0) continue; /* the fixed base never generates contacts */
+    box_t R = {e->rc[r], e->rq[r], ld3(sc->rbox_half[r])};
+    real rr0 = box_radius(R.h);
+    for (int i = 0; i < NF; ++i) {
+      v3 d = vsub(R.c, bb[i].c);
+      real rr = rr0 + br[i] + off;
+      if (vdot(d, d) > rr * rr) continue;
+      collide_pair(e, &R, &bb[i], NF + k, i, 0, off);
+    }
+    for (int s = 0; s < sc->n_static; ++s) {
+      box_t S = {ld3(sc->static_center[s]), {0, 0, 0, 1}, ld3(sc->static_half[s])};
+      v3 g;
+      if (box_sdf(vsub(R.c, S.c), S.h, &g) > rr0 + off) continue;
+      collide_pair(e, &R, &S, NF + k, BODY_STATIC, 1, off);
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- E: solver */
+static void tangents(v3 n, v3* t1, v3* t2) {
+  v3 a = fabsf(n.x) < 0.57735f ? V(1, 0, 0) : V(0, 1, 0);
+  v3 t = vcross(n, a);
+  t = vscale(t, 1.0f / sqrtf(vdot(t, t)));
+  *t1 = t;
+  *t2 = vcross(n, t);
+}
+
+/* velocity of body `id` at world point p */
+static v3 point_vel(const env_t* e, int id, v3 p) {
+  if (id == BODY_STATIC) return V(0, 0, 0);
+  if (id < NF) return vadd(e->bv[id], vcross(e->bw[id], vsub(p, e->bp[id])));
+  int k = id - NF;
+  return vadd(e->lv[k], vcross(e->lw[k], vsub(p, e->lp[k])));
+}
+
+/* robot Jacobian row for link k, point p, direction d: J[j] = (a_j x (p - p_j)) . d for dofs j on the path */
+static void robot_jrow(const env_t* e, int k, v3 p, v3 d, real J[ND]) {
+  for (int j = 0; j < ND; ++j)
+    J[j] = ((e->anc[k] >> j) & 1u) ? vdot(vcross(e->la[j + 1], vsub(p, e->lp[j + 1])), d) : 0.0f;
+}
+
+static real brick_w(const sdx_scene_desc* sc, const env_t* e, int i, v3 p, v3 d) {
+  int t = sc->brick_type[i];
+  v3 rxd = vcross(vsub(p, e->bp[i]), d);
+  v3 l = qrot(qconj(e->bq[i]), rxd);
+  const float* I = sc->brick_inertia[t];
+  return 1.0f / sc->brick_mass[t] + l.x * l.x / I[0] + l.y * l.y / I[1] + l.z * l.z / I[2];
+}
+
+static real robot_w(const env_t* e, int k, v3 p, v3 d) {
+  real J[ND], s = 0;
+  robot_jrow(e, k, p, d, J);
+  for (int i = 0; i < ND; ++i) {
+    if (J[i] == 0.0f) continue;
+    real t = 0;
+    for (int j = 0; j < ND; ++j) t += e->Hinv[i][j] * J[j];
+    s += J[i] * t;
+  }
+  return s;
+}
+
+static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
+  const real mu = sc->friction;
+  /* base (un-split) inverse effective masses per row and side */
+  for (int c = 0; c < e->nc; ++c) {
+    v3 t1, t2, dir[3];
+    tangents(e->cn[c], &t1, &t2);
+    dir[0] = e->cn[c]; dir[1] = t1; dir[2] = t2;
+    int ids[2] = {e->ca[c], e->cb[c]};
+    for (int r = 0; r < 3; ++r) {
+      for (int s = 0; s < 2; ++s) {
+        int id = ids[s];
+        real w = 0;
+        if (id == BODY_STATIC) w = 0;
+        else if (id < NF) w = brick_w(sc, e, id, e->cp[c], dir[r]);
+        else w = robot_w(e, id - NF, e->cp[c], dir[r]);
+        e->w[c][s][r] = w;
+      }
+      e->lam[c][r] = 0;
+    }
+  }
+  for (int j = 0; j < ND; ++j) e->qd_star[j] = e->qd[j];
+  for (int it = 0; it < sc->solver_iters; ++it) {
+    /* pass 1: active set and per-body active-contact counts (mass splitting over ACTIVE contacts only) */
+    for (int i = 0; i < NF; ++i) e->bcount[i] = 0;
+    e->rcount = 0;
+    for (int c = 0; c < e->nc; ++c) {
+      int a = e->ca[c], b = e->cb[c];
+      v3 p = e->cp[c], n = e->cn[c];
+      v3 vr = vsub(point_vel(e, a, p), point_vel(e, b, p));
+      real sep = e->csep[c];
+      real target = sep > 0 ? -sep / h : fminf(sc->baumgarte * (-sep) / h, sc->max_depenetration_vel);
+      int act = (e->lam[c][0] > 0) || (vdot(vr, n) < target);
+      e->active[c] = (unsigned char)act;
+      if (!act) continue;
+      if (a < NF) e->bcount[a]++; else if (a != BODY_STATIC) e->rcount++;
+      if (b < NF) e->bcount[b]++; else if (b != BODY_STATIC) e->rcount++;
+    }
+    for (int i = 0; i < NF; ++i) e->dv[i] = e->dw[i] = V(0, 0, 0);
+    real dQ[ND];
+    for (int j = 0; j < ND; ++j) dQ[j] = 0;
+    /* pass 2: Jacobi update of the accumulated impulses from the same velocity snapshot */
+    for (int c = 0; c < e->nc; ++c) {
+      if (!e->active[c]) continue;
+      int a = e->ca[c], b = e->cb[c];
+      v3 p = e->cp[c], n = e->cn[c], t1, t2;
+      tangents(n, &t1, &t2);
+      real na = a == BODY_STATIC ? 0.0f : (a < NF ? (real)e->bcount[a] : (real)e->rcount);
+      real nb = b == BODY_STATIC ? 0.0f : (b < NF ? (real)e->bcount[b] : (real)e->rcount);
+      v3 vr = vsub(point_vel(e, a, p), point_vel(e, b, p));
+      real sep = e->csep[c];
+      real target = sep > 0 ? -sep / h : fminf(sc->baumgarte * (-sep) / h, sc->max_depenetration_vel);
+      real dl[3];
+      real w0 = na * e->w[c][0][0] + nb * e->w[c][1][0];
+      real w1 = na * e->w[c][0][1] + nb * e->w[c][1][1];
+      real w2 = na * e->w[c][0][2] + nb * e->w[c][1][2];
+      real ln = fmaxf(0.0f, e->lam[c][0] - sc->jacobi_relax * (vdot(vr, n) - target) / w0);
+      dl[0] = ln - e->lam[c][0];
+      e->lam[c][0] = ln;
+      real lim = mu * ln;
+      real l1 = e->lam[c][1] - sc->jacobi_relax * vdot(vr, t1) / w1;
+      l1 = fminf(lim, fmaxf(-lim, l1));
+      dl[1] = l1 - e->lam[c][1];
+      e->lam[c][1] = l1;
+      real l2 = e->lam[c][2] - sc->jacobi_relax * vdot(vr, t2) / w2;
+      l2 = fminf(lim, fmaxf(-lim, l2));
+      dl[2] = l2 - e->lam[c][2];
+      e->lam[c][2] = l2;
+      v3 P = vadd(vadd(vscale(n, dl[0]), vscale(t1, dl[1])), vscale(t2, dl[2])); /* impulse on A; -P on B */
+      int ids[2] = {a, b};
+      for (int s = 0; s < 2; ++s) {
+        int id = ids[s];
+        v3 Ps = s == 0 ? P : vscale(P, -1.0f);
+        if (id == BODY_STATIC) continue;
+        if (id < NF) {
+          int t = sc->brick_type[id];
+          e->dv[id] = vadd(e->dv[id], vscale(Ps, 1.0f / sc->brick_mass[t]));
+          v3 l = qrot(qconj(e->bq[id]), vcross(vsub(p, e->bp[id]), Ps));
+          const float* I = sc->brick_inertia[t];
+          e->dw[id] = vadd(e->dw[id], qrot(e->bq[id], V(l.x / I[0], l.y / I[1], l.z / I[2])));
+        } else {
+          int k = id - NF;
+          for (int j = 0; j < ND; ++j)
+            if ((e->anc[k] >> j) & 1u) dQ[j] += vdot(vcross(e->la[j + 1], vsub(p, e->lp[j + 1])), Ps);
+        }
+      }
+    }
+    for (int i = 0; i < NF; ++i) {
+      e->bv[i] = vadd(e->bv[i], e->dv[i]);
+      e->bw[i] = vadd(e->bw[i], e->dw[i]);
+    }
+    for (int j = 0; j < ND; ++j) e->Q[j] += dQ[j];
+    for (int i = 0; i < ND; ++i) {
+      real s = e->qd_star[i];
+      for (int j = 0; j < ND; ++j) s += e->Hinv[i][j] * e->Q[j];
+      e->qd[i] = s;
+    }
+    /* link twists for the next iteration */
+    for (int k = 1; k < NL; ++k) {
+      int p = sc->parent[k];
+      e->lw[k] = vadd(e->lw[p], vscale(e->la[k], e->qd[k - 1]));
+      e->lv[k] = vadd(e->lv[p], vcross(e->lw[p], vsub(e->lp[k], e->lp[p])));
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- one env, one step */
+static void load_env(const sdx_scene_desc* sc, env_t* e, const float* root, const float* dof, const float* targets) {
+  for (int j = 0; j < ND; ++j) {
+    e->q[j] = dof[2 * j];
+    e->qd[j] = dof[2 * j + 1];
+    e->tgt[j] = targets[j];
+  }
+  for (int i = 0; i < NF; ++i) {
+    const float* s = root + (SDX_ACTOR_BRICK0 + i) * 13;
+    e->bq[i] = qnormalize(ld4(s + 3));
+    e->bp[i] = vadd(ld3(s), qrot(e->bq[i], ld3(sc->brick_center[sc->brick_type[i]])));
+    e->bv[i] = ld3(s + 7); /* COM velocity = origin velocity + w x (R c); the stored root velocity is the COM's */
+    e->bw[i] = ld3(s + 10);
+  }
+}
+
+static void substep(const sdx_scene_desc* sc, env_t* e, real h) {
+  fk(sc, e);
+  mass_matrix(sc, e, h);
+  real tau[ND];
+  for (int j = 0; j < ND; ++j) {
+    real t = sc->kp[j] * (e->tgt[j] - e->q[j]) - (sc->kd[j] + h * sc->kp[j]) * e->qd[j];
+    tau[j] = fminf(sc->effort[j], fmaxf(-sc->effort[j], t));
+  }
+  for (int i = 0; i < ND; ++i) {
+    real s = 0;
+    for (int j = 0; j < ND; ++j) s += e->Hinv[i][j] * tau[j];
+    e->qd[i] += h * s;
+  }
+  for (int j = 0; j < ND; ++j) e->Q[j] = 0;
+  for (int k = 1; k < NL; ++k) { /* twists with the new qd */
+    int p = sc->parent[k];
+    e->lw[k] = vadd(e->lw[p], vscale(e->la[k], e->qd[k - 1]));
+    e->lv[k] = vadd(e->lv[p], vcross(e->lw[p], vsub(e->lp[k], e->lp[p])));
+  }
+  v3 g = ld3(sc->gravity);
+  for (int i = 0; i < NF; ++i) e->bv[i] = vadd(e->bv[i], vscale(g, h));
+  collide(sc, e);
+  solve(sc, e, h);
+  for (int j = 0; j < ND; ++j) {
+    real v = fminf(sc->vel_limit[j], fmaxf(-sc->vel_limit[j], e->qd[j]));
+    real qn = e->q[j] + h * v;
+    if (qn < sc->lower[j]) { qn = sc->lower[j]; v = fmaxf(v, 0.0f); }
+    if (qn > sc->upper[j]) { qn = sc->upper[j]; v = fminf(v, 0.0f); }
+    e->q[j] = qn;
+    e->qd[j] = v;
+  }
+  for (int i = 0; i < NF; ++i) {
+    e->bp[i] = vadd(e->bp[i], vscale(e->bv[i], h));
+    q4 wq = {e->bw[i].x, e->bw[i].y, e->bw[i].z, 0};
+    q4 dq = qmul(wq, e->bq[i]);
+    q4 nq = {e->bq[i].x + 0.5f * h * dq.x, e->bq[i].y + 0.5f * h * dq.y, e->bq[i].z + 0.5f * h * dq.z,
+             e->bq[i].w + 0.5f * h * dq.w};
+    e->bq[i] = qnormalize(nq);
+  }
+}
+
+static void store_env(const sdx_scene_desc* sc, env_t* e, real h, float* root, float* dof, float* rb, float* contact,
+                      float* jac, int* ncontacts) {
+  fk(sc, e);
+  for (int j = 0; j < ND; ++j) {
+    dof[2 * j] = e->q[j];
+    dof[2 * j + 1] = e->qd[j];
+  }
+  for (int k = 0; k < NL; ++k) {
+    float* s = rb + k * 13;
+    st3(s, e->lp[k]);
+    st4(s + 3, e->lq[k]);
+    st3(s + 7, e->lv[k]);
+    st3(s + 10, e->lw[k]);
+  }
+  for (int i = 0; i < NF; ++i) {
+    float* s = root + (SDX_ACTOR_BRICK0 + i) * 13;
+    st3(s, vsub(e->bp[i], qrot(e->bq[i], ld3(sc->brick_center[sc->brick_type[i]]))));
+    st4(s + 3, e->bq[i]);
+    st3(s + 7, e->bv[i]);
+    st3(s + 10, e->bw[i]);
+    memcpy(rb + (SDX_BODY_BRICK0 + i) * 13, s, 13 * sizeof(float));
+  }
+  /* end-effector Jacobian of body hand_base_body at its frame origin, arm dofs 0..6 (GS:1601) */
+  int ee = sc->hand_base_body;
+  for (int j = 0; j < 7; ++j) {
+    v3 lin = vcross(e->la[j + 1], vsub(e->lp[ee], e->lp[j + 1]));
+    v3 ang = e->la[j + 1];
+    jac[0 * 7 + j] = lin.x; jac[1 * 7 + j] = lin.y; jac[2 * 7 + j] = lin.z;
+    jac[3 * 7 + j] = ang.x; jac[4 * 7 + j] = ang.y; jac[5 * 7 + j] = ang.z;
+  }
+  /* net contact force on robot bodies from the last substep's impulses (GS:1094,1159-1162 read bodies 1..6) */
+  for (int k = 0; k < NL; ++k) contact[k * 3] = contact[k * 3 + 1] = contact[k * 3 + 2] = 0;
+  for (int c = 0; c < e->nc; ++c) {
+    v3 t1, t2;
+    tangents(e->cn[c], &t1, &t2);
+    v3 P = vadd(vadd(vscale(e->cn[c], e->lam[c][0]), vscale(t1, e->lam[c][1])), vscale(t2, e->lam[c][2]));
+    P = vscale(P, 1.0f / h);
+    int a = e->ca[c], b = e->cb[c];
+    if (a >= NF && a != BODY_STATIC) { float* f = contact + (a - NF) * 3; f[0] += P.x; f[1] += P.y; f[2] += P.z; }
+    if (b >= NF && b != BODY_STATIC) { float* f = contact + (b - NF) * 3; f[0] -= P.x; f[1] -= P.y; f[2] -= P.z; }
+  }
+  if (ncontacts) *ncontacts = e->nc;
+}
+
+/* ---------------------------------------------------------------- exported entry points (ctypes) */
+
+/* gym.simulate + refresh_* for N envs.  root [N,142,13], dof [N,23,2], targets [N,23], rb [N,165,13],
+ * contact [N,165,3], jac [N,6,7], ncontacts [N] (may be NULL). */
+void sdxo_simulate(const sdx_scene_desc* sc, int N, float* root, float* dof, const float* targets, float* rb,
+                   float* contact, float* jac, int* ncontacts) {
+  real h = sc->dt / (real)sc->substeps;
+  /* envs are independent (collision groups = env id, GS:907-968): OpenMP over envs; thread count = OMP_NUM_THREADS */
+#pragma omp parallel
+  {
+    env_t* e = (env_t*)malloc(sizeof(env_t));
+#pragma omp for schedule(dynamic, 4)
+    for (int n = 0; n < N; ++n) {
+      float* r = root + (size_t)n * SDX_ACTORS * 13;
+      float* d = dof + (size_t)n * ND * 2;
+      e->overflow = 0;
+      load_env(sc, e, r, d, targets + (size_t)n * ND);
+      for (int s = 0; s < sc->substeps; ++s) substep(sc, e, h);
+      store_env(sc, e, h, r, d, rb + (size_t)n * SDX_BODIES * 13, contact + (size_t)n * SDX_BODIES * 3,
+                jac + (size_t)n * 42, ncontacts ? ncontacts + n : NULL);
+    }
+    free(e);
+  }
+}
+
+/* kinematics only (sdx_refresh_kinematics): rb links + jac from dof */
+void sdxo_kinematics(const sdx_scene_desc* sc, int N, const float* dof, float* rb, float* jac) {
+  env_t* e = (env_t*)calloc(1, sizeof(env_t));
+  for (int n = 0; n < N; ++n) {
+    const float* d = dof + (size_t)n * ND * 2;
+    for (int j = 0; j < ND; ++j) { e->q[j] = d[2 * j]; e->qd[j] = d[2 * j + 1]; }
+    fk(sc, e);
+    float* r = rb + (size_t)n * SDX_BODIES * 13;
+    for (int k = 0; k < NL; ++k) {
+      st3(r + k * 13, e->lp[k]); st4(r + k * 13 + 3, e->lq[k]); st3(r + k * 13 + 7, e->lv[k]); st3(r + k * 13 + 10, e->lw[k]);
+    }
+    float* J = jac + (size_t)n * 42;
+    int ee = sc->hand_base_body;
+    for (int j = 0; j < 7; ++j) {
+      v3 lin = vcross(e->la[j + 1], vsub(e->lp[ee], e->lp[j + 1]));
+      J[j] = lin.x; J[7 + j] = lin.y; J[14 + j] = lin.z;
+      J[21 + j] = e->la[j + 1].x; J[28 + j] = e->la[j + 1].y; J[35 + j] = e->la[j + 1].z;
+    }
+  }
+  free(e);
+}
+
+/* debug: joint-space inertia H (with implicit PD terms for substep h) of one configuration, [23,23] */
+void sdxo_mass_matrix(const sdx_scene_desc* sc, const float* q, float h, float* H_out, float* Hinv_out) {
+  env_t* e = (env_t*)calloc(1, sizeof(env_t));
+  for (int j = 0; j < ND; ++j) e->q[j] = q[j];
+  fk(sc, e);
+  mass_matrix(sc, e, h);
+  memcpy(H_out, e->H, sizeof(e->H));
+  memcpy(Hinv_out, e->Hinv, sizeof(e->Hinv));
+  free(e);
+}
+
+/* debug: contact list of one env after loading its state (no stepping): returns count; out [MAXC,9] =
+ * (a, b, px, py, pz, nx, ny, nz, sep) */
+int sdxo_contacts(const sdx_scene_desc* sc, const float* root_env, const float* dof_env, float* out, int cap) {
+  env_t* e = (env_t*)calloc(1, sizeof(env_t));
+  float tg[ND] = {0};
+  load_env(sc, e, root_env, dof_env, tg);
+  fk(sc, e);
+  collide(sc, e);
+  int n = e->nc < cap ? e->nc : cap;
+  for (int c = 0; c < n; ++c) {
+    float* o = out + c * 9;
+    o[0] = e->ca[c]; o[1] = e->cb[c];
+    o[2] = e->cp[c].x; o[3] = e->cp[c].y; o[4] = e->cp[c].z;
+    o[5] = e->cn[c].x; o[6] = e->cn[c].y; o[7] = e->cn[c].z;
+    o[8] = e->csep[c];
+  }
+  int total = e->nc + e->overflow;
+  free(e);
+  return total;
+}
+
+int sdxo_max_contacts(void) { return SDXO_MAXC; }

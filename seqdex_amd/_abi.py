@@ -101,6 +101,9 @@ def load_library():
     lib.sdx_num_envs.argtypes = [vp]
     lib.sdx_last_error.argtypes = [vp]
     lib.sdx_last_error.restype = C.c_char_p
+    missing = [n for n in SDX_EXPORTS if not hasattr(lib, n)]
+    if missing:
+        raise RuntimeError("libseqdex_hip.so is stale, missing %s; rebuild with __graft_entry__.build()" % missing)
     lib.sdxp_create.argtypes = [C.POINTER(PPOConfig), i32, C.c_uint64, C.POINTER(vp)]
     lib.sdxp_destroy.argtypes = [vp]
     lib.sdxp_tensor.argtypes = [vp, i32, C.POINTER(vp), i64p, i32p, i32p]

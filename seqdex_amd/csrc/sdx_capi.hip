@@ -1,0 +1,331 @@
+// sdx_capi.hip — host side of the sdx_* C ABI declared in include/seqdex.h (simulator + task seam).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdx_common.h"
+
+extern "C" {
+void sdxk_pre_physics(const SdxConst*, const SdxBuf*, const float*, const uint8_t*, const int32_t*, int, hipStream_t);
+void sdxk_post_physics(const SdxConst*, const SdxBuf*, int, hipStream_t);
+void sdxk_physics(const SdxConst*, const SdxBuf*, hipStream_t);
+void sdxk_kinematics(const SdxConst*, const SdxBuf*, hipStream_t);
+}
+
+struct sdx_sim {
+  int device = 0;
+  SdxConst* d_const = nullptr;
+  SdxConst h_const;
+  SdxBuf buf;
+  std::vector<void*> allocs;
+  struct TensorInfo { void* ptr; int64_t shape[4]; int ndim; int dtype; } tinfo[SDX_T_COUNT];
+  bool has_piles = false;
+  std::string err;
+};
+
+static thread_local std::string g_create_err = "";
+
+#define HIPCHK(h, call)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (call);                                                                          \
+    if (_e != hipSuccess) {                                                                          \
+      char _b[512];                                                                                  \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      if (h) (h)->err = _b; else g_create_err = _b;                                                  \
+      return SDX_ERR_HIP;                                                                            \
+    }                                                                                                \
+  } while (0)
+
+template <typename T>
+static int dalloc(sdx_sim* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) { h->err = std::string("hipMalloc failed: ") + hipGetErrorString(e); return SDX_ERR_NOMEM; }
+  e = hipMemset(q, 0, count * sizeof(T));
+  if (e != hipSuccess) { h->err = std::string("hipMemset failed: ") + hipGetErrorString(e); return SDX_ERR_HIP; }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return SDX_OK;
+}
+
+static void set_tensor(sdx_sim* h, int id, void* p, int dtype, std::initializer_list<int64_t> shape) {
+  auto& t = h->tinfo[id];
+  t.ptr = p;
+  t.dtype = dtype;
+  t.ndim = (int)shape.size();
+  int i = 0;
+  for (auto s : shape) t.shape[i++] = s;
+  for (; i < 4; ++i) t.shape[i] = 1;
+}
+
+static void qrot_host(const float q[4], const float v[3], float out[3]) {
+  float u[3] = {q[0], q[1], q[2]};
+  float t[3] = {2 * (u[1] * v[2] - u[2] * v[1]), 2 * (u[2] * v[0] - u[0] * v[2]), 2 * (u[0] * v[1] - u[1] * v[0])};
+  out[0] = v[0] + q[3] * t[0] + (u[1] * t[2] - u[2] * t[1]);
+  out[1] = v[1] + q[3] * t[1] + (u[2] * t[0] - u[0] * t[2]);
+  out[2] = v[2] + q[3] * t[2] + (u[0] * t[1] - u[1] * t[0]);
+}
+
+extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t device, uint64_t seed, sdx_handle* out) {
+  if (!scene || !out || num_envs <= 0) { g_create_err = "sdx_create: bad argument"; return SDX_ERR_INVALID; }
+  if (scene->abi_version != SDX_ABI_VERSION) { g_create_err = "sdx_create: scene.abi_version mismatch"; return SDX_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_err = "sdx_create: no HIP device visible; libseqdex_hip has no CPU fallback";
+    return SDX_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { g_create_err = "sdx_create: bad device index"; return SDX_ERR_INVALID; }
+  sdx_sim* h = new sdx_sim();
+  h->device = device;
+  sdx_sim* none = nullptr;
+  (void)none;
+  HIPCHK(h, hipSetDevice(device));
+  const int N = num_envs;
+  // ---- constants + derived tables
+  SdxConst& K = h->h_const;
+  memset(&K, 0, sizeof(K));
+  K.sc = *scene;
+  K.max_depth = 0;
+  for (int k = 0; k < SDX_NLINK; ++k) {
+    const int p = scene->parent[k];
+    K.anc[k] = (k == 0) ? 0u : (K.anc[p] | (1u << (k - 1)));
+    K.depth[k] = (k == 0) ? 0 : K.depth[p] + 1;
+    if (K.depth[k] > K.max_depth) K.max_depth = K.depth[k];
+  }
+  for (int t = 0; t < SDX_NBRICK_TYPES; ++t) {
+    const float* hh = scene->brick_half[t];
+    K.brick_radius[t] = sqrtf(hh[0] * hh[0] + hh[1] * hh[1] + hh[2] * hh[2]);
+  }
+  for (int r = 0; r < scene->n_rbox; ++r) {
+    const float* hh = scene->rbox_half[r];
+    K.rbox_radius[r] = sqrtf(hh[0] * hh[0] + hh[1] * hh[1] + hh[2] * hh[2]);
+  }
+  for (int j = 0; j < SDX_NDOF; ++j) {
+    if (j < 7) K.hand_reset_pose[j] = scene->arm_prepare_pose[j];
+    else K.hand_reset_pose[j] = 0.5f * (scene->finger_reset_unscaled[j - 7] + 1.0f) * (scene->upper[j] - scene->lower[j]) + scene->lower[j];
+  }
+  int rc;
+  if ((rc = dalloc(h, &h->d_const, 1)) != SDX_OK) { g_create_err = h->err; delete h; return rc; }
+  HIPCHK(h, hipMemcpy(h->d_const, &K, sizeof(K), hipMemcpyHostToDevice));
+
+  // ---- buffers
+  SdxBuf& B = h->buf;
+  memset(&B, 0, sizeof(B));
+  B.N = N;
+  B.K = 1;
+  B.seed = seed;
+#define ALLOC(field, count) if ((rc = dalloc(h, &B.field, (size_t)(count))) != SDX_OK) { g_create_err = h->err; sdx_destroy(h); return rc; }
+  ALLOC(root, (size_t)N * SDX_ACTORS * 13);
+  ALLOC(dof, (size_t)N * SDX_NDOF * 2);
+  ALLOC(rb, (size_t)N * SDX_BODIES * 13);
+  ALLOC(contact, (size_t)N * SDX_BODIES * 3);
+  ALLOC(jac, (size_t)N * 42);
+  ALLOC(targets, (size_t)N * SDX_NDOF);
+  ALLOC(prev_targets, (size_t)N * SDX_NDOF);
+  ALLOC(obs, (size_t)N * SDX_NUM_OBS);
+  ALLOC(states, (size_t)N * SDX_NUM_STATES);
+  ALLOC(obs_c, (size_t)N * SDX_NUM_OBS);
+  ALLOC(states_c, (size_t)N * SDX_NUM_STATES);
+  ALLOC(rew, N);
+  ALLOC(reset, N);
+  ALLOC(progress, N);
+  ALLOC(randomize, N);
+  ALLOC(actions, (size_t)N * SDX_NDOF);
+  ALLOC(init_pos, (size_t)N * 3);
+  ALLOC(init_rot, (size_t)N * 4);
+  ALLOC(successes, N);
+  ALLOC(meta_rew, N);
+  ALLOC(cons, 1);
+  ALLOC(finger_dist, N);
+  ALLOC(tvalue, N);
+  ALLOC(arm_contacts, (size_t)N * 6);
+  ALLOC(student_obs, (size_t)N * 30);
+  ALLOC(success_buf, N);
+  ALLOC(pile_choice, N);
+  ALLOC(ncontacts, N);
+  ALLOC(piles, (size_t)8 * SDX_NBRICK * 13);
+  ALLOC(tv_w, SDX_TV_PARAMS);
+  ALLOC(cam_rot, (size_t)N * 4);
+  ALLOC(cscratch, (size_t)N * SDX_CFIELDS * SDX_MAXC);
+  ALLOC(stat, 4);
+  ALLOC(step_count, 1);
+#undef ALLOC
+  set_tensor(h, SDX_T_ROOT, B.root, SDX_F32, {(int64_t)N * SDX_ACTORS, 13});
+  set_tensor(h, SDX_T_DOF, B.dof, SDX_F32, {(int64_t)N * SDX_NDOF, 2});
+  set_tensor(h, SDX_T_RB, B.rb, SDX_F32, {N, SDX_BODIES, 13});
+  set_tensor(h, SDX_T_CONTACT, B.contact, SDX_F32, {N, SDX_BODIES * 3});
+  set_tensor(h, SDX_T_JAC_EEF, B.jac, SDX_F32, {N, 6, 7});
+  set_tensor(h, SDX_T_TARGETS, B.targets, SDX_F32, {N, SDX_NDOF});
+  set_tensor(h, SDX_T_PREV_TARGETS, B.prev_targets, SDX_F32, {N, SDX_NDOF});
+  set_tensor(h, SDX_T_OBS, B.obs, SDX_F32, {N, SDX_NUM_OBS});
+  set_tensor(h, SDX_T_STATES, B.states, SDX_F32, {N, SDX_NUM_STATES});
+  set_tensor(h, SDX_T_OBS_CLAMPED, B.obs_c, SDX_F32, {N, SDX_NUM_OBS});
+  set_tensor(h, SDX_T_STATES_CLAMPED, B.states_c, SDX_F32, {N, SDX_NUM_STATES});
+  set_tensor(h, SDX_T_REW, B.rew, SDX_F32, {N});
+  set_tensor(h, SDX_T_RESET, B.reset, SDX_I64, {N});
+  set_tensor(h, SDX_T_PROGRESS, B.progress, SDX_I64, {N});
+  set_tensor(h, SDX_T_RANDOMIZE, B.randomize, SDX_I64, {N});
+  set_tensor(h, SDX_T_ACTIONS, B.actions, SDX_F32, {N, SDX_NDOF});
+  set_tensor(h, SDX_T_INIT_POS, B.init_pos, SDX_F32, {N, 3});
+  set_tensor(h, SDX_T_INIT_ROT, B.init_rot, SDX_F32, {N, 4});
+  set_tensor(h, SDX_T_SUCCESSES, B.successes, SDX_F32, {N});
+  set_tensor(h, SDX_T_META_REW, B.meta_rew, SDX_F32, {N});
+  set_tensor(h, SDX_T_CONS_SUCCESSES, B.cons, SDX_F32, {1});
+  set_tensor(h, SDX_T_FINGER_DIST, B.finger_dist, SDX_F32, {N});
+  set_tensor(h, SDX_T_TVALUE, B.tvalue, SDX_F32, {N});
+  set_tensor(h, SDX_T_ARM_CONTACTS, B.arm_contacts, SDX_F32, {N, 6});
+  set_tensor(h, SDX_T_STUDENT_OBS, B.student_obs, SDX_F32, {N, 30});
+  set_tensor(h, SDX_T_SUCCESS_BUF, B.success_buf, SDX_I64, {N});
+  set_tensor(h, SDX_T_PILE_CHOICE, B.pile_choice, SDX_I32, {N});
+  set_tensor(h, SDX_T_NCONTACTS, B.ncontacts, SDX_I32, {N});
+
+  // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
+  std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);
+  std::vector<float> pile0((size_t)SDX_NBRICK * 13, 0.0f);
+  for (int i = 0; i < SDX_NBRICK; ++i) {
+    float* s = &pile0[(size_t)i * 13];
+    if (i < SDX_NFREE) {
+      memcpy(s, scene->free_spawn_pos[i], 12);
+      memcpy(s + 3, scene->free_spawn_quat, 16);
+    } else {
+      memcpy(s, scene->fixed_brick_pos[i - SDX_NFREE], 12);
+      s[6] = 1.0f;
+    }
+  }
+  for (int e = 0; e < N; ++e) {
+    float* r = &root[(size_t)e * SDX_ACTORS * 13];
+    for (int a = 0; a < SDX_ACTORS; ++a) r[a * 13 + 6] = 1.0f;
+    memcpy(r, scene->base_pos, 12);
+    memcpy(r + 3, scene->base_quat, 16);
+    memcpy(r + 13, scene->object_init_state, 13 * 4);
+    memcpy(r + 26, scene->goal_reset_pos, 12);
+    for (int s = 0; s < 6; ++s) memcpy(r + (3 + s) * 13, scene->static_actor_pos[s], 12);
+    memcpy(r + SDX_ACTOR_BRICK0 * 13, pile0.data(), pile0.size() * 4);
+    memcpy(r + 141 * 13, scene->base_plate_pos, 12);
+    float* b = &rbv[(size_t)e * SDX_BODIES * 13];
+    for (int a = 1; a < SDX_ACTORS; ++a) memcpy(b + (SDX_NLINK + a - 1) * 13, r + a * 13, 13 * 4);
+  }
+  HIPCHK(h, hipMemcpy(B.root, root.data(), root.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(B.rb, rbv.data(), rbv.size() * 4, hipMemcpyHostToDevice));
+  {  // default saved piles: K=1, the spawn lattice for every type group (replaced by sdx_load_initial_states)
+    std::vector<float> p8;
+    for (int t = 0; t < 8; ++t) p8.insert(p8.end(), pile0.begin(), pile0.end());
+    HIPCHK(h, hipMemcpy(B.piles, p8.data(), p8.size() * 4, hipMemcpyHostToDevice));
+  }
+  {
+    std::vector<int64_t> ones(N, 1);  // reset_buf = ONES: every env resets on the first step (BT:63)
+    HIPCHK(h, hipMemcpy(B.reset, ones.data(), (size_t)N * 8, hipMemcpyHostToDevice));
+  }
+  sdxk_kinematics(h->d_const, &h->buf, 0);  // first refresh (GS:243-246)
+  HIPCHK(h, hipDeviceSynchronize());
+  *out = h;
+  return SDX_OK;
+}
+
+extern "C" int sdx_destroy(sdx_handle h) {
+  if (!h) return SDX_ERR_INVALID;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  for (void* p : h->allocs) hipFree(p);
+  delete h;
+  return SDX_OK;
+}
+
+extern "C" int sdx_tensor(sdx_handle h, int32_t id, void** dev_ptr, int64_t shape[4], int32_t* ndim, int32_t* dtype) {
+  if (!h) return SDX_ERR_INVALID;
+  if (id < 0 || id >= SDX_T_COUNT || !dev_ptr || !shape || !ndim || !dtype) { h->err = "sdx_tensor: bad argument"; return SDX_ERR_INVALID; }
+  const auto& t = h->tinfo[id];
+  *dev_ptr = t.ptr;
+  for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  *ndim = t.ndim;
+  *dtype = t.dtype;
+  return SDX_OK;
+}
+
+extern "C" int sdx_load_initial_states(sdx_handle h, const float* piles_host, int32_t K) {
+  if (!h) return SDX_ERR_INVALID;
+  if (!piles_host || K <= 0) { h->err = "sdx_load_initial_states: bad argument"; return SDX_ERR_INVALID; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  float* p = nullptr;
+  const size_t count = (size_t)8 * K * SDX_NBRICK * 13;
+  int rc = dalloc(h, &p, count);
+  if (rc != SDX_OK) return rc;
+  HIPCHK(h, hipMemcpy(p, piles_host, count * 4, hipMemcpyHostToDevice));
+  h->buf.piles = p;  // the previous table stays allocated until destroy (cheap, avoids a free under a live stream)
+  h->buf.K = K;
+  h->has_piles = true;
+  return SDX_OK;
+}
+
+extern "C" int sdx_set_tvalue_weights(sdx_handle h, const float* w, int32_t n) {
+  if (!h) return SDX_ERR_INVALID;
+  if (!w || n != SDX_TV_PARAMS) { h->err = "sdx_set_tvalue_weights: expected SDX_TV_PARAMS floats"; return SDX_ERR_INVALID; }
+  // host layout (torch): W[out][in] then b; device layout: W^T[in][out] then b
+  std::vector<float> t(SDX_TV_PARAMS);
+  const int dims[5] = {4, 256, 128, 64, 2};
+  size_t o = 0;
+  for (int l = 0; l < 4; ++l) {
+    const int in = dims[l], out = dims[l + 1];
+    for (int i = 0; i < in; ++i)
+      for (int j = 0; j < out; ++j) t[o + (size_t)i * out + j] = w[o + (size_t)j * in + i];
+    o += (size_t)in * out;
+    for (int j = 0; j < out; ++j) t[o + j] = w[o + j];
+    o += out;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(h->buf.tv_w, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  return SDX_OK;
+}
+
+static int check_launch(sdx_handle h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); return SDX_ERR_HIP; }
+  return SDX_OK;
+}
+
+extern "C" int sdx_pre_physics(sdx_handle h, const float* actions_dev, void* stream) {
+  if (!h || !actions_dev) return SDX_ERR_INVALID;
+  sdxk_pre_physics(h->d_const, &h->buf, actions_dev, nullptr, nullptr, 1 | 4, (hipStream_t)stream);
+  return check_launch(h, "sdx_pre_physics");
+}
+extern "C" int sdx_simulate(sdx_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  sdxk_physics(h->d_const, &h->buf, (hipStream_t)stream);
+  return check_launch(h, "sdx_simulate");
+}
+extern "C" int sdx_post_physics(sdx_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  sdxk_post_physics(h->d_const, &h->buf, 1, (hipStream_t)stream);
+  return check_launch(h, "sdx_post_physics");
+}
+extern "C" int sdx_compute_observations(sdx_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  sdxk_post_physics(h->d_const, &h->buf, 0, (hipStream_t)stream);
+  return check_launch(h, "sdx_compute_observations");
+}
+extern "C" int sdx_step(sdx_handle h, const float* actions_dev, void* stream) {
+  if (!h || !actions_dev) return SDX_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  sdxk_pre_physics(h->d_const, &h->buf, actions_dev, nullptr, nullptr, 1 | 4, st);
+  sdxk_physics(h->d_const, &h->buf, st);   // controlFrequencyInv = 1 (EG:18)
+  sdxk_post_physics(h->d_const, &h->buf, 1, st);
+  return check_launch(h, "sdx_step");
+}
+extern "C" int sdx_reset_idx(sdx_handle h, const uint8_t* env_mask_dev, const int32_t* pile_choice_dev, void* stream) {
+  if (!h || !env_mask_dev) return SDX_ERR_INVALID;
+  sdxk_pre_physics(h->d_const, &h->buf, nullptr, env_mask_dev, pile_choice_dev, 2, (hipStream_t)stream);
+  return check_launch(h, "sdx_reset_idx");
+}
+extern "C" int sdx_refresh_kinematics(sdx_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  sdxk_kinematics(h->d_const, &h->buf, (hipStream_t)stream);
+  return check_launch(h, "sdx_refresh_kinematics");
+}
+extern "C" int sdx_num_envs(sdx_handle h) { return h ? h->buf.N : SDX_ERR_INVALID; }
+extern "C" const char* sdx_last_error(sdx_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }

@@ -1,0 +1,100 @@
+// sdx_common.h — device-side constants, buffer table and small math for libseqdex_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/seqdex.h"
+
+#define SDX_WAVE 64
+#define SDX_MAXC 1280        // contact points per env (global scratch, SoA)
+#define SDX_MAXP 1024        // candidate box pairs per env (LDS)
+#define SDX_CFIELDS 17       // ab, p3, n3, sep, lam3, wA3, wB3
+#define SDX_NSAMP 28
+#define SDX_BODY_STATIC 255
+
+// scene constants + derived tables, one copy in HBM (read through the scalar / vector caches)
+struct SdxConst {
+  sdx_scene_desc sc;
+  uint32_t anc[SDX_NLINK];       // bit j: dof j lies on the path base -> link
+  int32_t depth[SDX_NLINK];
+  int32_t max_depth;
+  float brick_radius[SDX_NBRICK_TYPES];
+  float rbox_radius[SDX_MAX_RBOX];
+  float hand_reset_pose[SDX_NDOF];  // arm prepare pose + scale(finger_reset_unscaled)   GS:1526-1536
+};
+
+struct SdxBuf {
+  int32_t N;
+  int32_t K;               // saved piles per brick type
+  uint64_t seed;
+  float *root, *dof, *rb, *contact, *jac, *targets, *prev_targets;
+  float *obs, *states, *obs_c, *states_c, *rew;
+  int64_t *reset, *progress, *randomize;
+  float *actions, *init_pos, *init_rot, *successes, *meta_rew, *cons;
+  float *finger_dist, *tvalue, *arm_contacts, *student_obs;
+  int64_t* success_buf;
+  int32_t *pile_choice, *ncontacts;
+  float* piles;            // [8,K,132,13]
+  float* tv_w;             // packed + transposed T-value weights
+  float* cam_rot;          // [N,4] camera-frame target quaternion (input of the T-value MLP)
+  float* cscratch;         // [N, SDX_CFIELDS, SDX_MAXC]
+  float* stat;             // [2][2] double-buffered (num_resets, finished successes) for cons_successes
+  uint32_t* step_count;    // device counter, incremented by the post-physics kernel
+};
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+__device__ __forceinline__ f3 F3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+  return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ f4 qmul(f4 a, f4 b) {
+  f4 r;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  return r;
+}
+__device__ __forceinline__ f4 qconj(f4 a) { f4 r = {-a.x, -a.y, -a.z, a.w}; return r; }
+// quat_apply of isaacgym.torch_utils: v + w t + u x t, t = 2 u x v
+__device__ __forceinline__ f3 qrot(f4 q, f3 v) {
+  f3 u = F3(q.x, q.y, q.z);
+  f3 t = cross(u, v) * 2.0f;
+  return v + t * q.w + cross(u, t);
+}
+__device__ __forceinline__ f4 qnormalize(f4 a) {
+  float n = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  f4 r = {a.x * n, a.y * n, a.z * n, a.w * n};
+  return r;
+}
+__device__ __forceinline__ f4 qaxis(f3 ax, float ang) {
+  float s, c;
+  sincosf(0.5f * ang, &s, &c);
+  f4 r = {ax.x * s, ax.y * s, ax.z * s, c};
+  return r;
+}
+__device__ __forceinline__ f3 ld3(const float* p) { return F3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f4 ld4(const float* p) { f4 r = {p[0], p[1], p[2], p[3]}; return r; }
+__device__ __forceinline__ void st3(float* p, f3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ void st4(float* p, f4 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+// target brick actor index inside the env: brick (i % 8) with {3,4,7} -> 0   (GS:962-965,974-975)
+__device__ __forceinline__ int seg_actor(int env) {
+  int b = env & 7;
+  return SDX_ACTOR_BRICK0 + ((b == 3 || b == 4 || b == 7) ? 0 : b);
+}
+
+// counter-based RNG (splitmix-style hash of (seed, stream, counter)); documented in DESIGN.md §6
+__device__ __forceinline__ uint64_t sdx_hash(uint64_t seed, uint64_t a, uint64_t b) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xBF58476D1CE4E5B9ull * (b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}

@@ -1,0 +1,444 @@
+// sdx_task.hip — the reference-owned per-step tensor code of BlockAssemblyGraspSim as HIP kernels,
+// one wavefront (64 lanes) per env.  SURVEY.md §8(a) rows T2-T9; reference GS = tasks/block_assembly/
+// allegro_hand_block_assembly_grasp_sim.py, VR = tasks/hand_base/vec_task_rlgames.py.
+//
+//   k_pre_physics   GS:1555-1638 pre_physics_step: device-side masked reset_idx (GS:1361-1553, no
+//                   reset_buf.nonzero() host sync), action -> joint targets incl. the 6x6 damped-least-
+//                   squares IK solve (control_ik GS:1796-1804)
+//   k_post_physics  GS:1640-1645 post_physics_step: progress++, compute_observations (GS:1090-1218,
+//                   1299-1332, 1220-1280) with 3-frame stacking, compute_hand_reward (GS:1706-1776),
+//                   +-5 clamped copies (VR:171-172)
+//   k_tvalue        GraspInsertTValue MLP 4-256-128-64-2, ELU on every layer (terminal_value_function.py:30-46),
+//                   sigmoid(.)[:,1] (GS:1200-1201), batched over envs
+//
+// HBM-bound by design: every per-env row is loaded once with lane-strided (coalesced) accesses into LDS,
+// derived quantities are computed once per wave, rows are written back lane-strided.
+#include "sdx_common.h"
+
+// ------------------------------------------------------------------------------------------------ K1 + K2
+// flags: bit0 reset envs with reset_buf != 0; bit1 reset envs with ext_mask != 0; bit2 compute targets
+__global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __restrict__ C, SdxBuf B,
+                                                          const float* __restrict__ actions_in,
+                                                          const uint8_t* __restrict__ ext_mask,
+                                                          const int32_t* __restrict__ ext_choice, int flags) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const sdx_scene_desc& sc = C->sc;
+  __shared__ float s_J[42];
+
+  bool do_reset = false;
+  if (flags & 1) do_reset = B.reset[e] != 0;
+  if (flags & 2) do_reset = do_reset || (ext_mask[e] != 0);
+  float* root_e = B.root + (size_t)e * SDX_ACTORS * 13;
+
+  if (do_reset) {  // wave-uniform branch
+    int choice;
+    if (ext_choice) choice = ext_choice[e];
+    else choice = (int)(sdx_hash(B.seed, (uint64_t)e, (uint64_t)B.step_count[0]) % (uint64_t)B.K);
+    // restore the 132 bricks from a saved pile state of this env's brick-type group (GS:1507-1513), zero velocities
+    const float* src = B.piles + ((size_t)(e & 7) * B.K + choice) * SDX_NBRICK * 13;
+    float* dst = root_e + SDX_ACTOR_BRICK0 * 13;
+    for (int i = lane; i < SDX_NBRICK * 13; i += SDX_WAVE) {
+      float v = src[i];
+      dst[i] = (i % 13 >= 7) ? 0.0f : v;
+    }
+    if (lane < 13) root_e[1 * 13 + lane] = sc.object_init_state[lane];           // GS:1475-1482
+    if (lane < 3) root_e[2 * 13 + lane] = sc.goal_reset_pos[lane];               // GS:1348
+    if (lane >= 7 && lane < 13) root_e[2 * 13 + lane] = 0.0f;                    // GS:1350
+    if (lane < SDX_NDOF) {
+      float hp = C->hand_reset_pose[lane];
+      B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 0] = hp;                         // GS:1526,1531
+      B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 1] = 0.0f;                       // GS:1529
+      B.prev_targets[(size_t)e * SDX_NDOF + lane] = hp;                          // GS:1527,1533
+      B.targets[(size_t)e * SDX_NDOF + lane] = hp;                               // GS:1528,1535
+    }
+    const int seg = seg_actor(e) - SDX_ACTOR_BRICK0;
+    if (lane < 3) B.init_pos[e * 3 + lane] = src[seg * 13 + lane];               // GS:1547
+    if (lane < 4) B.init_rot[e * 4 + lane] = src[seg * 13 + 3 + lane];           // GS:1548
+    if (lane == 0) {
+      B.progress[e] = 0;                                                          // GS:1550-1553
+      B.reset[e] = 0;
+      B.successes[e] = 0.0f;
+      B.meta_rew[e] = 0.0f;
+      B.pile_choice[e] = choice;
+    }
+    __syncthreads();
+  }
+  if (!(flags & 4)) return;
+
+  // ---- action -> targets (GS:1570-1638); actions are clamped to +-clip_actions first (VR:166)
+  float a = 0.0f;
+  if (lane < SDX_NDOF) {
+    a = clampf(actions_in[(size_t)e * SDX_NDOF + lane], -sc.clip_actions, sc.clip_actions);
+    B.actions[(size_t)e * SDX_NDOF + lane] = a;                                   // GS:1570
+  }
+  if (lane < 42) s_J[lane] = B.jac[(size_t)e * 42 + lane];
+  const long prog = (long)B.progress[e];
+  const bool m0 = prog > 75, m1 = prog > 100, m2 = prog > 125;                    // GS:1590-1592
+  __syncthreads();
+  // dpose (GS:1594-1600), every lane computes it (uniform)
+  float dp[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float ak = __shfl(a, k, SDX_WAVE);
+    dp[k] = ak * (k < 3 ? 0.64f : 0.2f);
+  }
+  if (m0) {
+    const float hz = B.rb[((size_t)e * SDX_BODIES + sc.hand_base_body) * 13 + 2];
+    dp[2] = 0.2f + 0.22f + (B.init_pos[e * 3 + 2] - hz);                          // GS:1596
+    dp[0] = 0.0f;
+    dp[1] = 0.0f;
+  }
+  // A = J J^T + 0.05^2 I (6x6 SPD), Cholesky solve A y = dpose (control_ik, GS:1796-1804)
+  float A[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      float s = (r == c) ? 0.05f * 0.05f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) s += s_J[r * 7 + k] * s_J[c * 7 + k];
+      A[r][c] = s;
+    }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    d = sqrtf(d);
+    A[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float s = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
+      A[i][j] = s / d;
+    }
+  }
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = dp[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= A[i][k] * y[k];
+    y[i] = s / A[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= A[k][i] * y[k];
+    y[i] = s / A[i][i];
+  }
+  if (lane < SDX_NDOF) {
+    const float lo = sc.lower[lane], hi = sc.upper[lane];
+    const float prev = B.prev_targets[(size_t)e * SDX_NDOF + lane];
+    float cur;
+    if (lane >= 7) {
+      cur = 0.5f * (a + 1.0f) * (hi - lo) + lo;                                   // scale(), GS:1585-1587
+      cur = sc.act_moving_average * cur + (1.0f - sc.act_moving_average) * prev;  // GS:1588-1589
+      if (m0) cur = prev;                                                         // GS:1606
+    } else {
+      float u = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) u += s_J[r * 7 + lane] * y[r];
+      cur = B.dof[((size_t)e * SDX_NDOF + lane) * 2] + u;                         // GS:1602
+      if (m1) cur = sc.insert_pose_a[lane];                                       // GS:1604
+      if (m2) cur = sc.insert_pose_b[lane];                                       // GS:1605
+    }
+    cur = fmaxf(fminf(cur, hi), lo);                                              // tensor_clamp GS:1633-1635
+    B.targets[(size_t)e * SDX_NDOF + lane] = cur;
+    B.prev_targets[(size_t)e * SDX_NDOF + lane] = cur;                            // GS:1636
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K6
+// flags: bit0 = post_physics_step (progress++, reward, resets); otherwise compute_observations only
+__global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __restrict__ C, SdxBuf B, int flags) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const sdx_scene_desc& sc = C->sc;
+  __shared__ float s_in[5 * 13 + 13 + 7 + 46 + 18 + 23 + 7];   // hb, ff, mf, rf, th | target | base | dof | cf | act | init
+  __shared__ float s_o[SDX_OBS_FRAME];
+  __shared__ float s_s[SDX_STATE_FRAME];
+  float* s_hb = s_in;
+  float* s_ff = s_in + 13;
+  float* s_mf = s_in + 26;
+  float* s_rf = s_in + 39;
+  float* s_th = s_in + 52;
+  float* s_tg = s_in + 65;
+  float* s_base = s_in + 78;
+  float* s_dof = s_in + 85;
+  float* s_cf = s_in + 131;
+  float* s_act = s_in + 149;
+  float* s_init = s_in + 172;
+
+  long prog = (long)B.progress[e];
+  if (flags & 1) {
+    prog += 1;                                                                    // GS:1641
+    if (lane == 0) {
+      B.progress[e] = prog;
+      B.randomize[e] += 1;                                                        // GS:1642
+    }
+  }
+  const float* rb_e = B.rb + (size_t)e * SDX_BODIES * 13;
+  const float* root_e = B.root + (size_t)e * SDX_ACTORS * 13;
+  {  // gathers (GS:1097-1152): 5 rigid-body rows, the target brick's root row, robot base pose, dof, contacts
+    for (int i = lane; i < 65; i += SDX_WAVE) {
+      int which = i / 13, c = i % 13;
+      int body = which == 0 ? sc.hand_base_body : sc.fingertip_body[which - 1];
+      s_in[i] = rb_e[body * 13 + c];
+    }
+    if (lane < 13) s_tg[lane] = root_e[seg_actor(e) * 13 + lane];
+    if (lane < 7) s_base[lane] = root_e[lane];
+    if (lane < 46) s_dof[lane] = B.dof[(size_t)e * 46 + lane];
+    if (lane < 18) s_cf[lane] = B.contact[(size_t)e * SDX_BODIES * 3 + 3 + lane];  // bodies 1..6, GS:1032-1033,1159-1160
+    if (lane < 23) s_act[lane] = B.actions[(size_t)e * 23 + lane];
+    if (lane < 3) s_init[lane] = B.init_pos[e * 3 + lane];
+    if (lane >= 3 && lane < 7) s_init[lane] = B.init_rot[e * 4 + lane - 3];
+  }
+  __syncthreads();
+
+  // ---- derived quantities, computed by every lane (wave-uniform, no divergence)
+  const f3 off = F3(0.0f, 0.0f, 0.04f);                                           // GS:1154-1157
+  const f3 tpos = ld3(s_tg);
+  const f4 trot = ld4(s_tg + 3);
+  const f3 hpos = ld3(s_hb);
+  const f4 hrot = ld4(s_hb + 3);
+  const f3 ffp = ld3(s_ff) + qrot(ld4(s_ff + 3), off);
+  const f3 mfp = ld3(s_mf) + qrot(ld4(s_mf + 3), off);
+  const f3 rfp = ld3(s_rf) + qrot(ld4(s_rf + 3), off);
+  const f3 thp = ld3(s_th) + qrot(ld4(s_th + 3), off);
+  const f3 dff = tpos - ffp, dmf = tpos - mfp, drf = tpos - rfp, dth = tpos - thp;
+  const float nff = sqrtf(dot(dff, dff)), nmf = sqrtf(dot(dmf, dmf)), nrf = sqrtf(dot(drf, drf)),
+              nth = sqrtf(dot(dth, dth));
+  const float finger_dist = nff + nmf + nrf + nth;                                // GS:1164-1165
+  // hand pose in the robot-base frame (GS:1172-1173)
+  const f4 qbi = qconj(ld4(s_base + 3));
+  const f3 pbi = qrot(qbi, ld3(s_base)) * -1.0f;
+  const f4 hv_rot = qmul(qbi, hrot);
+  const f3 hv_pos = qrot(qbi, hpos) + pbi;
+  // wrist camera frame = link7 o (q_off, p_off); target pose in that frame (GS:1176-1182)
+  const f4 qc = qmul(hrot, ld4(sc.camera_offset_quat));
+  const f3 pc = qrot(hrot, ld3(sc.camera_offset_pos)) + hpos;
+  const f4 qci = qconj(qc);
+  const f3 pci = qrot(qci, pc) * -1.0f;
+  const f4 ct_rot = qmul(qci, trot);
+  const f3 ct_pos = qrot(qci, tpos) + pci;
+  const f4 hq_rel = qmul(hrot, qconj(trot));                                      // GS:1263
+
+  // ---- frames in LDS: bulk copies lane-parallel, derived values by lane 0
+  if (lane < 16) {
+    const int j = 7 + lane;
+    const float lo = sc.lower[j], hi = sc.upper[j];
+    s_o[lane] = (2.0f * s_dof[2 * j] - hi - lo) / (hi - lo);                      // unscale, GS:1300-1302
+    s_o[30 + lane] = 0.2f * s_dof[2 * j + 1];                                     // GS:1310
+  }
+  if (lane < 13) {
+    s_o[46 + lane] = s_ff[lane];                                                  // GS:1312-1315 (ff, rf, mf, th)
+    s_o[59 + lane] = s_rf[lane];
+    s_o[72 + lane] = s_mf[lane];
+    s_o[85 + lane] = s_th[lane];
+    s_o[98 + lane] = s_tg[lane];                                                  // GS:1317
+  }
+  if (lane < 7) {
+    s_o[111 + lane] = s_hb[lane];                                                 // GS:1319-1320
+    s_o[118 + lane] = s_init[lane];                                               // GS:1322-1323
+    s_s[81 + lane] = s_hb[lane];                                                  // GS:1232
+    s_s[88 + lane] = s_tg[lane];                                                  // GS:1234
+  }
+  if (lane < 23) {
+    const float lo = sc.lower[lane], hi = sc.upper[lane];
+    s_s[lane] = (2.0f * s_dof[2 * lane] - hi - lo) / (hi - lo);                   // GS:1221-1223
+    s_s[23 + lane] = 0.2f * s_dof[2 * lane + 1];                                  // GS:1224
+    s_s[58 + lane] = s_act[lane];                                                 // GS:1231
+  }
+  if (lane < 6) s_s[95 + lane] = s_hb[7 + lane];                                  // GS:1236-1237
+  if (lane < 40) {                                                                // GS:1239-1253: ff, mf, rf, th (rot, linvel, angvel)
+    const int f = lane / 10, c = lane % 10;
+    s_s[101 + lane] = s_in[13 * (f + 1) + 3 + c];
+  }
+  if (lane < 6) s_s[142 + lane] = s_tg[7 + lane];                                 // GS:1255-1256
+  if (lane == 0) {
+    st3(s_o + 16, hv_pos);  st4(s_o + 19, hv_rot);                                // GS:1304-1305
+    st3(s_o + 23, ct_pos);  st4(s_o + 26, ct_rot);                                // GS:1307-1308
+    st3(s_o + 125, tpos - ld3(s_init));                                           // GS:1325
+    st3(s_o + 128, hpos - tpos);                                                  // GS:1326
+    s_o[131] = 0.0f;
+    st3(s_s + 46, ffp); st3(s_s + 49, rfp); st3(s_s + 52, mfp); st3(s_s + 55, thp);   // GS:1226-1229
+    s_s[141] = 0.0f;
+    st3(s_s + 148, ld3(s_init));                                                  // GS:1258
+    st3(s_s + 151, tpos - ld3(s_init));                                           // GS:1259
+    st3(s_s + 154, hpos - tpos);                                                  // GS:1262
+    st4(s_s + 157, hq_rel);
+    st3(s_s + 161, dff); st3(s_s + 164, drf); st3(s_s + 167, dmf); st3(s_s + 170, dth);   // GS:1265-1268
+    s_s[173] = finger_dist;                                                       // GS:1270
+    st3(s_s + 174, ct_pos); st4(s_s + 177, ct_rot);                               // GS:1272-1276
+    st3(s_s + 181, ct_pos); st4(s_s + 184, ct_rot);
+    st4(B.cam_rot + (size_t)e * 4, ct_rot);
+    B.finger_dist[e] = finger_dist;
+  }
+  if (lane < 6) {                                                                 // GS:1159-1162
+    const f3 f = ld3(s_cf + 3 * lane);
+    B.arm_contacts[(size_t)e * 6 + lane] = sqrtf(dot(f, f)) >= 0.1f ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+
+  // ---- 3-frame stacking (GS:1330-1332, 1278-1280): new = [frame, old[0:w], old[w:2w]]; rows are read fully
+  // before they are written (one wave owns the row), then written lane-strided together with the clamped copies
+  {
+    float* o = B.obs + (size_t)e * SDX_NUM_OBS;
+    float* oc = B.obs_c + (size_t)e * SDX_NUM_OBS;
+    float hist[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int c = lane + r * SDX_WAVE;
+      hist[r] = (c < 2 * SDX_OBS_FRAME) ? o[c] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int c = lane + r * SDX_WAVE;
+      if (c < 2 * SDX_OBS_FRAME) {
+        o[SDX_OBS_FRAME + c] = hist[r];
+        oc[SDX_OBS_FRAME + c] = clampf(hist[r], -sc.clip_obs, sc.clip_obs);
+      }
+    }
+    for (int c = lane; c < SDX_OBS_FRAME; c += SDX_WAVE) {
+      const float v = s_o[c];
+      o[c] = v;
+      oc[c] = clampf(v, -sc.clip_obs, sc.clip_obs);
+    }
+    float* s = B.states + (size_t)e * SDX_NUM_STATES;
+    float* stc = B.states_c + (size_t)e * SDX_NUM_STATES;
+    float hs[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int c = lane + r * SDX_WAVE;
+      hs[r] = (c < 2 * SDX_STATE_FRAME) ? s[c] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int c = lane + r * SDX_WAVE;
+      if (c < 2 * SDX_STATE_FRAME) {
+        s[SDX_STATE_FRAME + c] = hs[r];
+        stc[SDX_STATE_FRAME + c] = clampf(hs[r], -sc.clip_obs, sc.clip_obs);
+      }
+    }
+    for (int c = lane; c < SDX_STATE_FRAME; c += SDX_WAVE) {
+      const float v = s_s[c];
+      s[c] = v;
+      stc[c] = clampf(v, -sc.clip_obs, sc.clip_obs);
+    }
+  }
+  if (!(flags & 1)) return;
+
+  // ---- compute_hand_reward (GS:1706-1776)
+  if (lane == 0) {
+    const float d = nff + nmf + nrf + 3.0f * nth;                                 // GS:1740-1741
+    long resets = (long)B.reset[e];                                               // GS:1727 (d <= -1 never holds)
+    const bool timed_out = (float)prog >= sc.max_episode_length - 1.0f;           // GS:1729
+    if (timed_out) resets = 1;
+    const float dist_rew = expf(-2.0f * fmaxf(d - 0.5f, 0.0f)) * 0.1f;            // GS:1742
+    float up = clampf(tpos.z - s_init[2], 0.0f, 0.2f) * 100.0f;                   // GS:1744
+    up = fminf(d < 0.5f ? up : 0.0f, 20.0f);                                      // GS:1745
+    const float reward = dist_rew + up;                                           // GS:1751
+    if (prog >= 75 && d >= 0.6f) resets = 1;                                      // GS:1754-1755
+    B.rew[e] = reward;
+    B.reset[e] = resets;
+    B.meta_rew[e] += reward;                                                      // GS:1069
+    if (resets) {                                                                 // GS:1771-1772 (summed by k_tvalue block 0)
+      const int par = (int)(B.step_count[0] & 1u);
+      atomicAdd(&B.stat[par * 2 + 0], 1.0f);
+      atomicAdd(&B.stat[par * 2 + 1], B.successes[e]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ T-value MLP
+// tv_w layout (device, transposed for coalesced neuron-major reads): W1T[4][256] b1[256] W2T[256][128] b2[128]
+// W3T[128][64] b3[64] W4T[64][2] b4[2].  One block = 16 envs x 256 threads.
+#define TV_ENVS 16
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
+
+__global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
+  __shared__ float s_x[TV_ENVS][4];
+  __shared__ float s_h1[TV_ENVS][256];
+  __shared__ float s_h2[TV_ENVS][128];
+  __shared__ float s_h3[TV_ENVS][64];
+  const int t = threadIdx.x, e0 = blockIdx.x * TV_ENVS;
+  const float* W1 = B.tv_w;
+  const float* b1 = W1 + 4 * 256;
+  const float* W2 = b1 + 256;
+  const float* b2 = W2 + 256 * 128;
+  const float* W3 = b2 + 128;
+  const float* b3 = W3 + 128 * 64;
+  const float* W4 = b3 + 64;
+  const float* b4 = W4 + 64 * 2;
+  if (t < TV_ENVS * 4) {
+    const int e = e0 + t / 4;
+    s_x[t / 4][t % 4] = e < B.N ? B.cam_rot[(size_t)e * 4 + (t % 4)] : 0.0f;
+  }
+  __syncthreads();
+  {  // layer 1: thread = neuron, all 16 envs
+    float w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = W1[k * 256 + t];
+    const float b = b1[t];
+#pragma unroll
+    for (int e = 0; e < TV_ENVS; ++e)
+      s_h1[e][t] = elu1(b + w[0] * s_x[e][0] + w[1] * s_x[e][1] + w[2] * s_x[e][2] + w[3] * s_x[e][3]);
+  }
+  __syncthreads();
+  {  // layer 2: neuron = t % 128, env half = t / 128
+    const int n = t & 127, eh = (t >> 7) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = b2[n];
+    for (int k = 0; k < 256; ++k) {
+      const float w = W2[k * 128 + n];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += w * s_h1[eh + e][k];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_h2[eh + e][n] = elu1(acc[e]);
+  }
+  __syncthreads();
+  {  // layer 3: neuron = t % 64, env quarter = t / 64
+    const int n = t & 63, eq = (t >> 6) * 4;
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = b3[n];
+    for (int k = 0; k < 128; ++k) {
+      const float w = W3[k * 64 + n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += w * s_h2[eq + e][k];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_h3[eq + e][n] = elu1(acc[e]);
+  }
+  __syncthreads();
+  if (t < TV_ENVS) {  // layer 4, output 1 only feeds the sigmoid (GS:1201)
+    float y = b4[1];
+    for (int k = 0; k < 64; ++k) y += W4[k * 2 + 1] * s_h3[t][k];
+    y = elu1(y);
+    if (e0 + t < B.N) B.tvalue[e0 + t] = 1.0f / (1.0f + expf(-y));
+  }
+  if (finalize_stats && blockIdx.x == 0 && t == 0) {
+    // cons_successes EMA (GS:1771-1774) from the per-step sums gathered by k_post_physics
+    const uint32_t step = B.step_count[0];
+    const int par = (int)(step & 1u);
+    const float num_resets = B.stat[par * 2 + 0], fin = B.stat[par * 2 + 1];
+    if (num_resets > 0.0f) B.cons[0] = 0.1f * fin / num_resets + 0.9f * B.cons[0];
+    B.stat[par * 2 + 0] = 0.0f;
+    B.stat[par * 2 + 1] = 0.0f;
+    B.step_count[0] = step + 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host launchers
+extern "C" void sdxk_pre_physics(const SdxConst* C, const SdxBuf* B, const float* actions, const uint8_t* mask,
+                                 const int32_t* choice, int flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_pre_physics, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, actions, mask, choice, flags);
+}
+extern "C" void sdxk_post_physics(const SdxConst* C, const SdxBuf* B, int flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_post_physics, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, flags);
+  hipLaunchKernelGGL(k_tvalue, dim3((B->N + TV_ENVS - 1) / TV_ENVS), dim3(256), 0, st, *B, flags & 1);
+}

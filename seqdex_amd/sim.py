@@ -1,0 +1,139 @@
+"""Thin Python binding of the sdx_* C ABI (include/seqdex.h): owns a handle and exposes the library-owned
+device buffers as zero-copy torch tensors — the equivalent of `gymtorch.wrap_tensor(gym.acquire_*_tensor(sim))`
+(GS:237-241,313-322).  torch is plumbing here (device pointers, streams); all arithmetic is in libseqdex_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from .scene import load_scene
+
+_TORCH_DTYPE = {0: (torch.float32, "<f4"), 1: (torch.int64, "<i8"), 2: (torch.int32, "<i4"), 3: (torch.uint8, "|u1")}
+
+
+class _DevArray:
+    """minimal __cuda_array_interface__ carrier so torch can alias a raw device pointer (ROCm uses the same protocol)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def wrap_device_pointer(ptr, shape, dtype_code, device):
+    tdt, typestr = _TORCH_DTYPE[dtype_code]
+    t = torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+    assert t.data_ptr() == ptr and t.dtype == tdt
+    return t
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class SdxError(RuntimeError):
+    pass
+
+
+class SdxSim:
+    """One simulator+task instance on one GPU (one process per GPU; envs shard across ranks)."""
+
+    def __init__(self, num_envs, device="cuda:0", seed=22, scene=None, **desc_overrides):
+        if not torch.cuda.is_available():
+            raise SdxError("seqdex_amd needs a ROCm GPU (gfx950); there is no CPU fallback for the product path")
+        self.lib = _abi.load_library()
+        self.scene = scene or load_scene()
+        self.device = torch.device(device)
+        self.num_envs = int(num_envs)
+        self._desc = self.scene.to_desc(**desc_overrides)
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        rc = self.lib.sdx_create(C.byref(self._desc), self.num_envs, idx, C.c_uint64(seed), C.byref(h))
+        if rc != 0:
+            raise SdxError("sdx_create failed (%d): %s" % (rc, self.lib.sdx_last_error(None).decode()))
+        self.h = h
+        self._tensors = {}
+        for name, tid in _abi.T.items():
+            self._tensors[name] = self._wrap(tid)
+
+    def _wrap(self, tid):
+        ptr, shape, ndim, dt = C.c_void_p(), (C.c_int64 * 4)(), C.c_int32(), C.c_int32()
+        self._check(self.lib.sdx_tensor(self.h, tid, C.byref(ptr), shape, C.byref(ndim), C.byref(dt)))
+        return wrap_device_pointer(ptr.value, [shape[i] for i in range(ndim.value)], dt.value, self.device)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SdxError("libseqdex_hip error %d: %s" % (rc, self.lib.sdx_last_error(self.h).decode()))
+
+    def tensor(self, name):
+        return self._tensors[name]
+
+    def __getattr__(self, name):
+        t = self.__dict__.get("_tensors", {})
+        if name.upper() in t:
+            return t[name.upper()]
+        raise AttributeError(name)
+
+    # ------------------------------------------------------------------ C ABI calls
+    def load_initial_states(self, piles):
+        piles = np.ascontiguousarray(piles, dtype=np.float32)
+        assert piles.ndim == 4 and piles.shape[0] == 8 and piles.shape[2:] == (132, 13), piles.shape
+        self._check(self.lib.sdx_load_initial_states(self.h, piles.ctypes.data_as(C.c_void_p), piles.shape[1]))
+
+    def set_tvalue_weights(self, state_dict_or_flat):
+        if isinstance(state_dict_or_flat, dict):
+            parts = []
+            for n in ["linear1", "linear2", "linear3", "output_layer"]:
+                parts.append(np.asarray(state_dict_or_flat[n + ".weight" if n + ".weight" in state_dict_or_flat
+                                                           else n + "_weight"], dtype=np.float32).ravel())
+                parts.append(np.asarray(state_dict_or_flat[n + ".bias" if n + ".bias" in state_dict_or_flat
+                                                           else n + "_bias"], dtype=np.float32).ravel())
+            flat = np.concatenate(parts)
+        else:
+            flat = np.ascontiguousarray(state_dict_or_flat, dtype=np.float32)
+        assert flat.size == _abi.TV_PARAMS
+        self._check(self.lib.sdx_set_tvalue_weights(self.h, flat.ctypes.data_as(C.c_void_p), flat.size))
+
+    def _act_ptr(self, actions):
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        assert actions.shape == (self.num_envs, _abi.NUM_ACTIONS)
+        return C.c_void_p(actions.data_ptr())
+
+    def step(self, actions):
+        self._check(self.lib.sdx_step(self.h, self._act_ptr(actions), _stream_ptr(self.device)))
+
+    def pre_physics(self, actions):
+        self._check(self.lib.sdx_pre_physics(self.h, self._act_ptr(actions), _stream_ptr(self.device)))
+
+    def simulate(self):
+        self._check(self.lib.sdx_simulate(self.h, _stream_ptr(self.device)))
+
+    def post_physics(self):
+        self._check(self.lib.sdx_post_physics(self.h, _stream_ptr(self.device)))
+
+    def compute_observations(self):
+        self._check(self.lib.sdx_compute_observations(self.h, _stream_ptr(self.device)))
+
+    def refresh_kinematics(self):
+        self._check(self.lib.sdx_refresh_kinematics(self.h, _stream_ptr(self.device)))
+
+    def reset_idx(self, env_mask, pile_choice=None):
+        assert env_mask.is_cuda and env_mask.dtype == torch.uint8 and env_mask.numel() == self.num_envs
+        pc = C.c_void_p(0)
+        if pile_choice is not None:
+            assert pile_choice.is_cuda and pile_choice.dtype == torch.int32 and pile_choice.numel() == self.num_envs
+            pc = C.c_void_p(pile_choice.data_ptr())
+        self._check(self.lib.sdx_reset_idx(self.h, C.c_void_p(env_mask.data_ptr()), pc, _stream_ptr(self.device)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self._tensors.clear()
+            self.lib.sdx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

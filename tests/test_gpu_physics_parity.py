@@ -1,0 +1,111 @@
+"""-m gpu: the HIP physics kernel (one wavefront per env) against oracle/physics_oracle.c, the plain-C CPU
+restatement of the same step (PARITY UNPINNED vs PhysX - see the oracle header).  Teacher forcing: both sides
+start every compared step from the same state.  SURVEY.md §8(a) rows P1-P5."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import physics_oracle as po  # noqa: E402
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def state(golden_dir):
+    return np.load(os.path.join(golden_dir, "P1_settled_state.npz"))
+
+
+def test_kinematics_and_jacobian(scene):
+    from seqdex_amd.sim import SdxSim
+    n = 256
+    s = SdxSim(n)
+    try:
+        rng = np.random.default_rng(0)
+        lo, hi = scene.lower, scene.upper
+        dof = np.stack([lo + (hi - lo) * rng.uniform(size=(n, 23)), rng.normal(size=(n, 23))], -1).astype(np.float32)
+        s.DOF.copy_(_dev(dof.reshape(-1, 2)))
+        s.refresh_kinematics()
+        torch.cuda.synchronize()
+        rb, jac = po.kinematics(s._desc, dof)
+        np.testing.assert_allclose(s.RB.cpu().numpy()[:, :24], rb[:, :24], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(s.JAC_EEF.cpu().numpy(), jac, rtol=2e-5, atol=2e-5)
+    finally:
+        s.close()
+
+
+def _one_step(s, root, dof, targets):
+    n = root.shape[0]
+    s.ROOT.copy_(_dev(root.reshape(-1, 13)))
+    s.DOF.copy_(_dev(dof.reshape(-1, 2)))
+    s.TARGETS.copy_(_dev(targets))
+    s.simulate()
+    torch.cuda.synchronize()
+    return (s.ROOT.cpu().numpy().reshape(n, 142, 13), s.DOF.cpu().numpy().reshape(n, 23, 2), s.RB.cpu().numpy(),
+            s.CONTACT.cpu().numpy().reshape(n, 165, 3), s.JAC_EEF.cpu().numpy(), s.NCONTACTS.cpu().numpy())
+
+
+def test_one_step_teacher_forcing(state, scene):
+    """same start state, one simulate() on each side.  Contact-rich piles amplify fp32 rounding through the
+    discrete contact set, so the bar is: identical contact counts, robot state to 1e-4, brick poses to 2e-5 m,
+    brick velocities to 2e-3 m/s for >= 99% of the bricks."""
+    from seqdex_amd.sim import SdxSim
+    n = state["root"].shape[0]
+    s = SdxSim(n)
+    try:
+        root, dof = state["root"].copy(), state["dof"].copy()
+        for it in range(3):
+            g_root, g_dof, g_rb, g_contact, g_jac, g_nc = _one_step(s, root, dof, state["targets"])
+            o_root, o_dof = root.copy(), dof.copy()
+            o_rb, o_contact, o_jac, o_nc = po.simulate(s._desc, o_root, o_dof, state["targets"])
+            np.testing.assert_array_equal(g_nc, o_nc)
+            np.testing.assert_allclose(g_dof, o_dof, rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(g_rb[:, :24], o_rb[:, :24], rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(g_jac, o_jac, rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(g_root[:, 9:81, 0:7], o_root[:, 9:81, 0:7], atol=2e-5)
+            dv = np.abs(g_root[:, 9:81, 7:13] - o_root[:, 9:81, 7:13]).max(-1)
+            assert (dv < 2e-3).mean() >= 0.99, float((dv < 2e-3).mean())
+            np.testing.assert_allclose(g_contact[:, :24], o_contact[:, :24], rtol=5e-3, atol=5e-2)
+            np.testing.assert_array_equal(g_root[:, 81:141], root[:, 81:141])     # fixed bricks untouched
+            root, dof = o_root, o_dof                                              # teacher forcing
+    finally:
+        s.close()
+
+
+def test_free_fall_and_invariants(scene):
+    """a single brick row dropped from the spawn lattice: free fall is exact semi-implicit Euler until contact;
+    afterwards nothing tunnels through the floor slab and the robot holds its targets."""
+    from seqdex_amd.sim import SdxSim
+    n = 64
+    s = SdxSim(n)
+    try:
+        root0 = s.ROOT.cpu().numpy().reshape(n, 142, 13).copy()
+        pose = np.concatenate([np.array(scene.arm_prepare_pose, np.float32),
+                               0.5 * (np.array(scene.finger_reset_unscaled, np.float32) + 1)
+                               * (scene.upper[7:] - scene.lower[7:]) + scene.lower[7:]]).astype(np.float32)
+        dof = np.zeros((n, 23, 2), np.float32); dof[:, :, 0] = pose
+        s.DOF.copy_(_dev(dof.reshape(-1, 2)))
+        s.TARGETS.copy_(_dev(np.tile(pose, (n, 1))))
+        s.simulate()
+        torch.cuda.synchronize()
+        r1 = s.ROOT.cpu().numpy().reshape(n, 142, 13)
+        top = 9 + 64  # bricks of the highest spawn layer are in free fall during the first step
+        h, g = 1.0 / 120.0, -9.81
+        np.testing.assert_allclose(r1[:, top:top + 8, 9], 2 * h * g, rtol=1e-5)
+        np.testing.assert_allclose(r1[:, top:top + 8, 2] - root0[:, top:top + 8, 2], h * h * g * 3, rtol=1e-4, atol=1e-6)
+        for _ in range(150):
+            s.simulate()
+        torch.cuda.synchronize()
+        r = s.ROOT.cpu().numpy().reshape(n, 142, 13)
+        assert np.isfinite(r).all()
+        assert r[:, 9:81, 2].min() > 0.60                      # nothing below the bin bottom
+        assert np.abs(r[:, 9:81, 0] - 0.25).max() < 0.31 and np.abs(r[:, 9:81, 1] - 0.19).max() < 0.22   # inside the bin
+        assert np.abs(s.DOF.cpu().numpy().reshape(n, 23, 2)[:, :, 0] - pose).max() < 2e-3
+        assert np.linalg.norm(r[:, 9:81, 7:10], axis=-1).mean() < 0.02
+    finally:
+        s.close()
