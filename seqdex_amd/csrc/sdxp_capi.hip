@@ -1,16 +1,326 @@
-// sdxp_capi.hip — PPO side of the C ABI (placeholder while the kernels are being written)
+// sdxp_capi.hip — host side of the sdxp_* C ABI (include/seqdex.h): the rl_games A2CAgent inner loops.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
 #include "sdx_common.h"
-struct sdxp_agent { int dummy; };
+#include "sdxp_types.h"
+
 extern "C" {
-int sdxp_create(const sdxp_config*, int32_t, uint64_t, sdxp_handle*) { return SDX_ERR_STATE; }
-int sdxp_destroy(sdxp_handle) { return SDX_ERR_STATE; }
-int sdxp_tensor(sdxp_handle, int32_t, void**, int64_t*, int32_t*, int32_t*) { return SDX_ERR_STATE; }
-int64_t sdxp_param_count(sdxp_handle, int32_t) { return 0; }
-int sdxp_act(sdxp_handle, int32_t, const float*, const float*, const float*, const float*, float*, void*) { return SDX_ERR_STATE; }
-int sdxp_store_rewards(sdxp_handle, int32_t, const float*, void*) { return SDX_ERR_STATE; }
-int sdxp_finish_rollout(sdxp_handle, const float*, const float*, void*) { return SDX_ERR_STATE; }
-int sdxp_update(sdxp_handle, void*) { return SDX_ERR_STATE; }
-int sdxp_backward(sdxp_handle, int32_t, int32_t, void*) { return SDX_ERR_STATE; }
-int sdxp_apply(sdxp_handle, int32_t, float, void*) { return SDX_ERR_STATE; }
-const char* sdxp_last_error(sdxp_handle) { return "PPO kernels not built yet"; }
+void sdxpk_linear(const float*, const float*, const float*, float*, int, int, int, int, const double*, const double*, hipStream_t);
+void sdxpk_act_heads(const SdxpDev*, int, const float*, const float*, const float*, const float*, float*, uint64_t, hipStream_t);
+void sdxpk_store_rewards(const SdxpDev*, int, const float*, hipStream_t);
+void sdxpk_value_head(const SdxpDev*, float*, hipStream_t);
+void sdxpk_gae(const SdxpDev*, const float*, const float*, hipStream_t);
+int sdxpk_update_step(const SdxpDev*, int, hipStream_t);
+int sdxpk_update_begin(const SdxpDev*, int, hipStream_t);
+int sdxpk_update_flush_layers(const SdxpDev*, int, hipStream_t);
 }
+
+struct sdxp_agent {
+  int device = 0;
+  sdxp_config cfg;
+  SdxpDev D;
+  std::vector<void*> allocs;
+  struct TensorInfo { void* ptr; int64_t shape[4]; int ndim; int dtype; } tinfo[SDXP_T_COUNT];
+  float* stats_dev = nullptr;
+  uint64_t act_counter = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_chunk = 0;
+  std::string err;
+};
+
+static thread_local std::string gp_create_err = "";
+
+#define PCHK(h, call)                                                                                  \
+  do {                                                                                                 \
+    hipError_t _e = (call);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      char _b[512];                                                                                    \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      if (h) (h)->err = _b; else gp_create_err = _b;                                                   \
+      return SDX_ERR_HIP;                                                                              \
+    }                                                                                                  \
+  } while (0)
+
+template <typename T>
+static int palloc(sdxp_agent* h, T** p, size_t count) {
+  void* q = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) { h->err = std::string("hipMalloc failed: ") + hipGetErrorString(e); return SDX_ERR_NOMEM; }
+  e = hipMemset(q, 0, count * sizeof(T));
+  if (e != hipSuccess) { h->err = std::string("hipMemset failed: ") + hipGetErrorString(e); return SDX_ERR_HIP; }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return SDX_OK;
+}
+
+static void pset(sdxp_agent* h, int id, void* p, int dtype, std::initializer_list<int64_t> shape) {
+  auto& t = h->tinfo[id];
+  t.ptr = p; t.dtype = dtype; t.ndim = (int)shape.size();
+  int i = 0;
+  for (auto s : shape) t.shape[i++] = s;
+  for (; i < 4; ++i) t.shape[i] = 1;
+}
+
+// torch.nn.Linear default init: kaiming_uniform_(a=sqrt(5)) -> U(-1/sqrt(fan_in), 1/sqrt(fan_in)); rl_games then
+// zeroes every bias (App. C).  Host-side, seeded.
+static void init_linear(std::vector<float>& p, size_t woff, int out, int in, std::mt19937_64& rng) {
+  const float bound = 1.0f / std::sqrt((float)in);
+  std::uniform_real_distribution<float> U(-bound, bound);
+  for (size_t i = 0; i < (size_t)out * in; ++i) p[woff + i] = U(rng);
+}
+
+extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed, sdxp_handle* out) {
+  if (!cfg || !out) { gp_create_err = "sdxp_create: bad argument"; return SDX_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    gp_create_err = "sdxp_create: no HIP device visible; libseqdex_hip has no CPU fallback";
+    return SDX_ERR_NO_DEVICE;
+  }
+  const int B = cfg->horizon * cfg->num_actors;
+  if (cfg->minibatch <= 0 || B % cfg->minibatch != 0) { gp_create_err = "sdxp_create: batch_size % minibatch_size != 0"; return SDX_ERR_INVALID; }
+  if (cfg->minibatch != cfg->cv_minibatch || cfg->mini_epochs != cfg->cv_mini_epochs) {
+    gp_create_err = "sdxp_create: the fused update needs equal minibatch_size / mini_epochs for actor-critic and central value";
+    return SDX_ERR_INVALID;
+  }
+  if (cfg->units[2] > 256 || cfg->act_dim > 32 || cfg->obs_dim % 4 || cfg->state_dim % 4) {
+    gp_create_err = "sdxp_create: unsupported network shape"; return SDX_ERR_INVALID;
+  }
+  sdxp_agent* h = new sdxp_agent();
+  h->device = device;
+  h->cfg = *cfg;
+  PCHK(h, hipSetDevice(device));
+  SdxpDev& D = h->D;
+  memset(&D, 0, sizeof(D));
+  D.N = cfg->num_actors; D.horizon = cfg->horizon; D.obs_dim = cfg->obs_dim; D.state_dim = cfg->state_dim;
+  D.act_dim = cfg->act_dim;
+  for (int i = 0; i < 3; ++i) D.units[i] = cfg->units[i];
+  D.num_minibatches = B / cfg->minibatch;
+  D.rows_per_wave = 1;
+  D.bsplit = 8;
+  D.clip_value = cfg->clip_value; D.truncate_grads = cfg->truncate_grads; D.normalize_advantage = cfg->normalize_advantage;
+  D.cv_normalize_input = cfg->cv_normalize_input; D.adaptive_lr = cfg->adaptive_lr;
+  D.gamma = cfg->gamma; D.tau = cfg->tau; D.e_clip = cfg->e_clip; D.grad_norm = cfg->grad_norm;
+  D.critic_coef = cfg->critic_coef; D.entropy_coef = cfg->entropy_coef; D.bounds_coef = cfg->bounds_loss_coef;
+  D.kl_threshold = cfg->kl_threshold; D.seed = seed;
+  // ---- flat parameter layouts
+  {
+    size_t o = 0;
+    int in = cfg->obs_dim;
+    for (int l = 0; l < 3; ++l) { D.off.a_w[l] = o; o += (size_t)cfg->units[l] * in; D.off.a_b[l] = o; o += cfg->units[l]; in = cfg->units[l]; }
+    D.off.mu_w = o; o += (size_t)cfg->act_dim * in; D.off.mu_b = o; o += cfg->act_dim;
+    D.off.logstd = o; o += cfg->act_dim;
+    in = cfg->obs_dim;
+    for (int l = 0; l < 3; ++l) { D.off.c_w[l] = o; o += (size_t)cfg->units[l] * in; D.off.c_b[l] = o; o += cfg->units[l]; in = cfg->units[l]; }
+    D.off.v_w = o; o += in; D.off.v_b = o; o += 1;
+    D.off.total = o;
+    o = 0; in = cfg->state_dim;
+    for (int l = 0; l < 3; ++l) { D.coff.w[l] = o; o += (size_t)cfg->units[l] * in; D.coff.b[l] = o; o += cfg->units[l]; in = cfg->units[l]; }
+    D.coff.v_w = o; o += in; D.coff.v_b = o; o += 1;
+    D.coff.total = o;
+  }
+  int rc;
+#define PAL(ptr, count) if ((rc = palloc(h, &(ptr), (size_t)(count))) != SDX_OK) { gp_create_err = h->err; sdxp_destroy(h); return rc; }
+  PAL(D.ac, D.off.total); PAL(D.ac_g, D.off.total); PAL(D.ac_m, D.off.total); PAL(D.ac_v, D.off.total);
+  PAL(D.cv, D.coff.total); PAL(D.cv_g, D.coff.total); PAL(D.cv_m, D.coff.total); PAL(D.cv_v, D.coff.total);
+  const size_t N = D.N, H = D.horizon, R = N * H;
+  for (int l = 0; l < 3; ++l) { PAL(D.h_a[l], N * cfg->units[l]); PAL(D.h_v[l], N * cfg->units[l]); }
+  PAL(D.mb_obs, R * cfg->obs_dim); PAL(D.mb_states, R * cfg->state_dim); PAL(D.mb_actions, R * cfg->act_dim);
+  PAL(D.mb_mus, R * cfg->act_dim); PAL(D.mb_sigmas, R * cfg->act_dim); PAL(D.mb_neglogp, R); PAL(D.mb_values, R);
+  PAL(D.mb_rewards, R); PAL(D.mb_dones, R); PAL(D.returns, R); PAL(D.adv, R); PAL(D.last_values, N);
+  PAL(D.rms_mean, cfg->state_dim); PAL(D.rms_var, cfg->state_dim);
+  const int MB = cfg->minibatch;
+  for (int net = 0; net < 3; ++net) {
+    const int in0 = net == 2 ? cfg->state_dim : cfg->obs_dim;
+    PAL(D.x[net][0], (size_t)2 * MB * in0);
+    for (int l = 0; l < 3; ++l) {
+      PAL(D.x[net][l + 1], (size_t)2 * MB * cfg->units[l]);
+      PAL(D.dy[net][l], (size_t)2 * MB * cfg->units[l]);
+      if (l < 2) PAL(D.dxacc[net][l], (size_t)2 * MB * cfg->units[l]);
+    }
+  }
+  PAL(D.dhead, (size_t)2 * MB * 34); PAL(D.dlogstd, 64); PAL(D.ctrl, 1); PAL(h->stats_dev, 16);
+#undef PAL
+  // ---- parameter init
+  {
+    std::mt19937_64 rng(seed * 0x9E3779B97F4A7C15ull + 12345);
+    std::vector<float> p(D.off.total, 0.0f), c(D.coff.total, 0.0f);
+    int in = cfg->obs_dim;
+    for (int l = 0; l < 3; ++l) { init_linear(p, D.off.a_w[l], cfg->units[l], in, rng); in = cfg->units[l]; }
+    init_linear(p, D.off.mu_w, cfg->act_dim, in, rng);
+    in = cfg->obs_dim;
+    for (int l = 0; l < 3; ++l) { init_linear(p, D.off.c_w[l], cfg->units[l], in, rng); in = cfg->units[l]; }
+    init_linear(p, D.off.v_w, 1, in, rng);
+    in = cfg->state_dim;
+    for (int l = 0; l < 3; ++l) { init_linear(c, D.coff.w[l], cfg->units[l], in, rng); in = cfg->units[l]; }
+    init_linear(c, D.coff.v_w, 1, in, rng);
+    PCHK(h, hipMemcpy(D.ac, p.data(), p.size() * 4, hipMemcpyHostToDevice));
+    PCHK(h, hipMemcpy(D.cv, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+    std::vector<double> ones(cfg->state_dim, 1.0);
+    PCHK(h, hipMemcpy(D.rms_var, ones.data(), ones.size() * 8, hipMemcpyHostToDevice));
+    SdxpCtrl ctl;
+    memset(&ctl, 0, sizeof(ctl));
+    ctl.ac_lr = cfg->lr; ctl.cv_lr = cfg->cv_lr; ctl.ac_gscale = 1.0f; ctl.cv_gscale = 1.0f;
+    ctl.ac_bc1 = ctl.ac_bc2 = ctl.cv_bc1 = ctl.cv_bc2 = 1.0f;
+    ctl.rms_count = 1.0;
+    PCHK(h, hipMemcpy(D.ctrl, &ctl, sizeof(ctl), hipMemcpyHostToDevice));
+  }
+  pset(h, SDXP_T_AC_PARAMS, D.ac, SDX_F32, {(int64_t)D.off.total});
+  pset(h, SDXP_T_AC_GRADS, D.ac_g, SDX_F32, {(int64_t)D.off.total});
+  pset(h, SDXP_T_CV_PARAMS, D.cv, SDX_F32, {(int64_t)D.coff.total});
+  pset(h, SDXP_T_CV_GRADS, D.cv_g, SDX_F32, {(int64_t)D.coff.total});
+  pset(h, SDXP_T_MB_OBS, D.mb_obs, SDX_F32, {(int64_t)N, (int64_t)H, cfg->obs_dim});
+  pset(h, SDXP_T_MB_STATES, D.mb_states, SDX_F32, {(int64_t)N, (int64_t)H, cfg->state_dim});
+  pset(h, SDXP_T_MB_ACTIONS, D.mb_actions, SDX_F32, {(int64_t)N, (int64_t)H, cfg->act_dim});
+  pset(h, SDXP_T_MB_MUS, D.mb_mus, SDX_F32, {(int64_t)N, (int64_t)H, cfg->act_dim});
+  pset(h, SDXP_T_MB_SIGMAS, D.mb_sigmas, SDX_F32, {(int64_t)N, (int64_t)H, cfg->act_dim});
+  pset(h, SDXP_T_MB_NEGLOGP, D.mb_neglogp, SDX_F32, {(int64_t)N, (int64_t)H});
+  pset(h, SDXP_T_MB_VALUES, D.mb_values, SDX_F32, {(int64_t)N, (int64_t)H});
+  pset(h, SDXP_T_MB_REWARDS, D.mb_rewards, SDX_F32, {(int64_t)N, (int64_t)H});
+  pset(h, SDXP_T_MB_DONES, D.mb_dones, SDX_F32, {(int64_t)N, (int64_t)H});
+  pset(h, SDXP_T_RETURNS, D.returns, SDX_F32, {(int64_t)R});
+  pset(h, SDXP_T_ADVANTAGES, D.adv, SDX_F32, {(int64_t)R});
+  pset(h, SDXP_T_CV_RMS_MEAN, D.rms_mean, 4 /*f64*/, {cfg->state_dim});
+  pset(h, SDXP_T_CV_RMS_VAR, D.rms_var, 4, {cfg->state_dim});
+  pset(h, SDXP_T_STATS, D.ctrl, SDX_F32, {(int64_t)(sizeof(SdxpCtrl) / 4)});
+  pset(h, SDXP_T_LAST_VALUES, D.last_values, SDX_F32, {(int64_t)N});
+  pset(h, SDXP_T_AC_ADAM_M, D.ac_m, SDX_F32, {(int64_t)D.off.total});
+  pset(h, SDXP_T_AC_ADAM_V, D.ac_v, SDX_F32, {(int64_t)D.off.total});
+  pset(h, SDXP_T_CV_ADAM_M, D.cv_m, SDX_F32, {(int64_t)D.coff.total});
+  pset(h, SDXP_T_CV_ADAM_V, D.cv_v, SDX_F32, {(int64_t)D.coff.total});
+  *out = h;
+  return SDX_OK;
+}
+
+extern "C" int sdxp_destroy(sdxp_handle h) {
+  if (!h) return SDX_ERR_INVALID;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return SDX_OK;
+}
+
+extern "C" int sdxp_tensor(sdxp_handle h, int32_t id, void** dev_ptr, int64_t shape[4], int32_t* ndim, int32_t* dtype) {
+  if (!h) return SDX_ERR_INVALID;
+  if (id < 0 || id >= SDXP_T_COUNT || !dev_ptr || !shape || !ndim || !dtype) { h->err = "sdxp_tensor: bad argument"; return SDX_ERR_INVALID; }
+  const auto& t = h->tinfo[id];
+  *dev_ptr = t.ptr;
+  for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  *ndim = t.ndim;
+  *dtype = t.dtype;
+  return SDX_OK;
+}
+
+extern "C" int64_t sdxp_param_count(sdxp_handle h, int32_t which) {
+  if (!h) return -1;
+  return which == 0 ? (int64_t)h->D.off.total : (int64_t)h->D.coff.total;
+}
+
+static int plaunch_ok(sdxp_handle h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { h->err = std::string(what) + ": " + hipGetErrorString(e); return SDX_ERR_HIP; }
+  return SDX_OK;
+}
+
+// trunk forward of `net` (0 actor, 2 central value) over M rows into the h_* activation buffers
+static void trunk_forward(sdxp_agent* h, int net, const float* x, int M, hipStream_t st) {
+  const SdxpDev& D = h->D;
+  const float* P = net == 2 ? D.cv : D.ac;
+  float* const* hb = net == 2 ? D.h_v : D.h_a;
+  int in = net == 2 ? D.state_dim : D.obs_dim;
+  const float* cur = x;
+  for (int l = 0; l < 3; ++l) {
+    const size_t wo = net == 0 ? D.off.a_w[l] : D.coff.w[l], bo = net == 0 ? D.off.a_b[l] : D.coff.b[l];
+    const bool norm = (net == 2 && l == 0 && D.cv_normalize_input);
+    sdxpk_linear(cur, P + wo, P + bo, hb[l], M, D.units[l], in, 1, norm ? D.rms_mean : nullptr, norm ? D.rms_var : nullptr, st);
+    cur = hb[l];
+    in = D.units[l];
+  }
+}
+
+extern "C" int sdxp_act(sdxp_handle h, int32_t t, const float* obs_dev, const float* states_dev, const float* dones_dev,
+                        const float* eps_dev, float* actions_out_dev, void* stream) {
+  if (!h || !obs_dev || !states_dev || !actions_out_dev || t < 0 || t >= h->D.horizon) { if (h) h->err = "sdxp_act: bad argument"; return SDX_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  trunk_forward(h, 0, obs_dev, h->D.N, st);
+  trunk_forward(h, 2, states_dev, h->D.N, st);
+  sdxpk_act_heads(&h->D, t, obs_dev, states_dev, dones_dev, eps_dev, actions_out_dev, h->act_counter++, st);
+  return plaunch_ok(h, "sdxp_act");
+}
+
+extern "C" int sdxp_store_rewards(sdxp_handle h, int32_t t, const float* rew_dev, void* stream) {
+  if (!h || !rew_dev || t < 0 || t >= h->D.horizon) return SDX_ERR_INVALID;
+  sdxpk_store_rewards(&h->D, t, rew_dev, (hipStream_t)stream);
+  return plaunch_ok(h, "sdxp_store_rewards");
+}
+
+extern "C" int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const float* last_dones_dev, void* stream) {
+  if (!h || !last_states_dev) return SDX_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  trunk_forward(h, 2, last_states_dev, h->D.N, st);
+  sdxpk_value_head(&h->D, h->D.last_values, st);
+  sdxpk_gae(&h->D, h->D.last_values, last_dones_dev, st);
+  return plaunch_ok(h, "sdxp_finish_rollout");
+}
+
+__global__ void k_ctrl_begin_epoch(SdxpCtrl* c) {
+  c->mb_index = 0; c->mini_epoch = 0; c->n_mb = 0;
+  c->sum_a_loss = c->sum_c_loss = c->sum_b_loss = c->sum_kl = c->sum_cv_loss = c->sum_entropy = 0.0f;
+  for (int i = 0; i < 8; ++i) c->acc[i] = 0.0f;
+}
+
+extern "C" int sdxp_update(sdxp_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int MB = h->cfg.minibatch;
+  if (MB != 2 && MB != 4 && MB != 8) {
+    h->err = "sdxp_update: the fused rank-MB path supports minibatch_size 2/4/8 (as shipped: 4)";
+    return SDX_ERR_INVALID;
+  }
+  const long total = (long)h->cfg.mini_epochs * h->D.num_minibatches;
+  hipLaunchKernelGGL(k_ctrl_begin_epoch, dim3(1), dim3(1), 0, st, h->D.ctrl);
+  sdxpk_update_begin(&h->D, MB, st);
+  // a chunk of optimiser steps is captured once into a hipGraph (no step-dependent kernel arguments: all state
+  // lives in the device control block) and replayed; the remainder is launched eagerly
+  const int chunk = 32;
+  long done = 0;
+  if (total >= chunk) {
+    if (!h->graph_exec) {
+      hipStream_t cs;
+      PCHK(h, hipStreamCreate(&cs));
+      PCHK(h, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < chunk; ++i) sdxpk_update_step(&h->D, MB, cs);
+      PCHK(h, hipStreamEndCapture(cs, &h->graph));
+      PCHK(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+      PCHK(h, hipStreamDestroy(cs));
+      h->graph_chunk = chunk;
+    }
+    for (; done + chunk <= total; done += chunk) PCHK(h, hipGraphLaunch(h->graph_exec, st));
+  }
+  for (; done < total; ++done) sdxpk_update_step(&h->D, MB, st);
+  sdxpk_update_flush_layers(&h->D, MB, st);
+  return plaunch_ok(h, "sdxp_update");
+}
+
+extern "C" int sdxp_backward(sdxp_handle h, int32_t, int32_t, void*) {
+  if (!h) return SDX_ERR_INVALID;
+  h->err = "sdxp_backward: explicit-gradient (multi-rank all-reduce) path is not built in this round";
+  return SDX_ERR_STATE;
+}
+extern "C" int sdxp_apply(sdxp_handle h, int32_t, float, void*) {
+  if (!h) return SDX_ERR_INVALID;
+  h->err = "sdxp_apply: explicit-gradient (multi-rank all-reduce) path is not built in this round";
+  return SDX_ERR_STATE;
+}
+extern "C" const char* sdxp_last_error(sdxp_handle h) { return h ? h->err.c_str() : gp_create_err.c_str(); }

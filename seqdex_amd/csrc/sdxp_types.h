@@ -1,0 +1,51 @@
+// sdxp_types.h — device-side tables of the PPO engine (shared by sdxp_kernels.hip and sdxp_capi.hip)
+#pragma once
+#include <stdint.h>
+
+struct SdxpOff {   // offsets (in floats) into the flat actor-critic parameter buffer, torch layout W[out][in]
+  size_t a_w[3], a_b[3], mu_w, mu_b, logstd, c_w[3], c_b[3], v_w, v_b, total;
+};
+struct SdxpCOff {  // central-value network
+  size_t w[3], b[3], v_w, v_b, total;
+};
+
+// control block living in HBM, advanced by the CTRL kernel (no host round trips inside an epoch)
+struct SdxpCtrl {
+  int32_t step;          // optimiser steps issued so far (parity selects the factor buffers)
+  int32_t mb_index;      // minibatch currently staged
+  int32_t mini_epoch;
+  int32_t ac_pending, cv_pending;
+  int32_t ac_t, cv_t;    // Adam step counters
+  int32_t n_mb;
+  float ac_lr, cv_lr, ac_lr_applied, cv_lr_applied;
+  float ac_gscale, cv_gscale, ac_gnorm, cv_gnorm;
+  float ac_bc1, ac_bc2, cv_bc1, cv_bc2;
+  float last_kl;
+  float sum_a_loss, sum_c_loss, sum_b_loss, sum_kl, sum_cv_loss, sum_entropy;
+  float acc[8];          // per-minibatch sums written by the HEAD kernel: [1]a [2]c [3]b [4]kl [5]cv [6]entropy
+  double rms_count;
+};
+
+struct SdxpDev {
+  int32_t N, horizon, obs_dim, state_dim, act_dim, units[3];
+  int32_t num_minibatches, rows_per_wave, bsplit;
+  int32_t clip_value, truncate_grads, normalize_advantage, cv_normalize_input, adaptive_lr;
+  float gamma, tau, e_clip, grad_norm, critic_coef, entropy_coef, bounds_coef, kl_threshold;
+  uint64_t seed;
+  SdxpOff off;
+  SdxpCOff coff;
+  float *ac, *ac_g, *ac_m, *ac_v, *cv, *cv_g, *cv_m, *cv_v;
+  // rollout activations [N, units[l]] of the actor / (unused critic) / central value trunks
+  float *h_a[3], *h_v[3];
+  // experience buffer, env-major rows r = env*horizon + t (== swap_and_flatten01 order, PS:338-339)
+  float *mb_obs, *mb_states, *mb_actions, *mb_mus, *mb_sigmas, *mb_neglogp, *mb_values, *mb_rewards, *mb_dones;
+  float *returns, *adv, *last_values;
+  double *rms_mean, *rms_var;
+  // small-minibatch update: rank-MB factors, double buffered by step parity
+  float* x[3][4];        // x[net][l]: [2][MB][K_l] input of trunk layer l (l=3: input of the head = output of layer 2)
+  float* dy[3][3];       // dy[net][l]: [2][MB][N_l]
+  float* dxacc[3][2];    // dxacc[net][l]: [2][MB][N_l] split-N accumulators of the backward kernel
+  float* dhead;          // [2][MB][34]: dmu (cols 0..act_dim-1), dV critic (32), dV central value (33)
+  float* dlogstd;        // [2][32]
+  SdxpCtrl* ctrl;
+};

@@ -1,0 +1,116 @@
+"""Python binding of the sdxp_* C ABI (include/seqdex.h): the PPO inner loops of rl_games' A2CAgent on the GPU.
+torch is plumbing (pointers, streams); arithmetic is in libseqdex_hip.so (seqdex_amd/csrc/sdxp_kernels.hip)."""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from .sim import SdxError, _stream_ptr, wrap_device_pointer
+
+
+class Ctrl(C.Structure):
+    """host mirror of SdxpCtrl (csrc/sdxp_types.h)"""
+    _fields_ = [("step", C.c_int32), ("mb_index", C.c_int32), ("mini_epoch", C.c_int32), ("ac_pending", C.c_int32),
+                ("cv_pending", C.c_int32), ("ac_t", C.c_int32), ("cv_t", C.c_int32), ("n_mb", C.c_int32),
+                ("ac_lr", C.c_float), ("cv_lr", C.c_float), ("ac_lr_applied", C.c_float), ("cv_lr_applied", C.c_float),
+                ("ac_gscale", C.c_float), ("cv_gscale", C.c_float), ("ac_gnorm", C.c_float), ("cv_gnorm", C.c_float),
+                ("ac_bc1", C.c_float), ("ac_bc2", C.c_float), ("cv_bc1", C.c_float), ("cv_bc2", C.c_float),
+                ("last_kl", C.c_float), ("sum_a_loss", C.c_float), ("sum_c_loss", C.c_float), ("sum_b_loss", C.c_float),
+                ("sum_kl", C.c_float), ("sum_cv_loss", C.c_float), ("sum_entropy", C.c_float), ("acc", C.c_float * 8),
+                ("rms_count", C.c_double)]
+
+
+def make_config(num_actors, params=None, world_size=1):
+    """sdxp_config from the `params.config` block of cfg/lego/ppo_continuous_grasp.yaml (YG) + network units."""
+    p = params or {}
+    cfgd = p.get("config", {})
+    cv = cfgd.get("central_value_config", {})
+    units = p.get("network", {}).get("mlp", {}).get("units", [1024, 512, 256])
+    c = _abi.PPOConfig()
+    c.num_actors = num_actors
+    c.horizon = cfgd.get("horizon_length", 8)
+    c.minibatch = cfgd.get("minibatch_size", 4)
+    c.mini_epochs = cfgd.get("mini_epochs", 5)
+    c.cv_minibatch = cv.get("minibatch_size", c.minibatch)
+    c.cv_mini_epochs = cv.get("mini_epochs", c.mini_epochs)
+    c.obs_dim, c.state_dim, c.act_dim = _abi.NUM_OBS, _abi.NUM_STATES, _abi.NUM_ACTIONS
+    c.units[:] = units
+    c.gamma, c.tau = cfgd.get("gamma", 0.99), cfgd.get("tau", 0.95)
+    c.lr, c.cv_lr = float(cfgd.get("learning_rate", 3e-4)), float(cv.get("learning_rate", 1e-3))
+    c.e_clip, c.grad_norm = cfgd.get("e_clip", 0.1), cfgd.get("grad_norm", 1.0)
+    c.critic_coef, c.entropy_coef = cfgd.get("critic_coef", 1.0), cfgd.get("entropy_coef", 0.0)
+    c.bounds_loss_coef = cfgd.get("bounds_loss_coef", 1e-3)
+    c.kl_threshold = cfgd.get("kl_threshold", 0.02)
+    c.clip_value = int(bool(cfgd.get("clip_value", True)))
+    c.truncate_grads = int(bool(cfgd.get("truncate_grads", True)))
+    c.normalize_advantage = int(bool(cfgd.get("normalize_advantage", True)))
+    c.cv_normalize_input = int(bool(cv.get("normalize_input", True)))
+    c.adaptive_lr = int(cfgd.get("lr_schedule", "adaptive") == "adaptive")
+    c.world_size = world_size
+    return c
+
+
+class SdxPPO:
+    def __init__(self, num_actors, params=None, device="cuda:0", seed=22, config=None, world_size=1):
+        if not torch.cuda.is_available():
+            raise SdxError("seqdex_amd needs a ROCm GPU (gfx950); there is no CPU fallback for the product path")
+        self.lib = _abi.load_library()
+        self.device = torch.device(device)
+        self.cfg = config or make_config(num_actors, params, world_size)
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        rc = self.lib.sdxp_create(C.byref(self.cfg), idx, C.c_uint64(seed), C.byref(h))
+        if rc != 0:
+            raise SdxError("sdxp_create failed (%d): %s" % (rc, self.lib.sdxp_last_error(None).decode()))
+        self.h = h
+        self.t = {}
+        for name, tid in _abi.TP.items():
+            ptr, shape, ndim, dt = C.c_void_p(), (C.c_int64 * 4)(), C.c_int32(), C.c_int32()
+            self._check(self.lib.sdxp_tensor(self.h, tid, C.byref(ptr), shape, C.byref(ndim), C.byref(dt)))
+            self.t[name] = wrap_device_pointer(ptr.value, [shape[i] for i in range(ndim.value)], dt.value, self.device)
+        self.num_actors, self.horizon = self.cfg.num_actors, self.cfg.horizon
+        self.actions = torch.zeros(num_actors, self.cfg.act_dim, device=self.device)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SdxError("libseqdex_hip (ppo) error %d: %s" % (rc, self.lib.sdxp_last_error(self.h).decode()))
+
+    @staticmethod
+    def _p(t):
+        if t is None:
+            return C.c_void_p(0)
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+
+    def act(self, t, obs, states, dones=None, eps=None):
+        self._check(self.lib.sdxp_act(self.h, t, self._p(obs), self._p(states), self._p(dones), self._p(eps),
+                                      self._p(self.actions), _stream_ptr(self.device)))
+        return self.actions
+
+    def store_rewards(self, t, rew):
+        self._check(self.lib.sdxp_store_rewards(self.h, t, self._p(rew), _stream_ptr(self.device)))
+
+    def finish_rollout(self, last_states, last_dones=None):
+        self._check(self.lib.sdxp_finish_rollout(self.h, self._p(last_states), self._p(last_dones), _stream_ptr(self.device)))
+
+    def update(self):
+        self._check(self.lib.sdxp_update(self.h, _stream_ptr(self.device)))
+
+    def ctrl(self):
+        raw = self.t["STATS"].cpu().numpy().tobytes()
+        return Ctrl.from_buffer_copy(raw[:C.sizeof(Ctrl)])
+
+    def param_count(self, which=0):
+        return int(self.lib.sdxp_param_count(self.h, which))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.t.clear()
+            self.lib.sdxp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -10,7 +10,8 @@ import torch
 from . import _abi
 from .scene import load_scene
 
-_TORCH_DTYPE = {0: (torch.float32, "<f4"), 1: (torch.int64, "<i8"), 2: (torch.int32, "<i4"), 3: (torch.uint8, "|u1")}
+_TORCH_DTYPE = {0: (torch.float32, "<f4"), 1: (torch.int64, "<i8"), 2: (torch.int32, "<i4"), 3: (torch.uint8, "|u1"),
+                4: (torch.float64, "<f8")}
 
 
 class _DevArray:

@@ -1,0 +1,125 @@
+"""-m gpu: the HIP PPO kernels (through the sdxp_* C ABI) against oracle/ppo_oracle.py, a plain-PyTorch autograd
+restatement of the rl_games arithmetic (PARITY UNPINNED vs rl_games itself - see the oracle header).
+SURVEY.md §8(a) rows R1-R9."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle.ppo_oracle import DEFAULT_CFG, PPOOracle  # noqa: E402
+
+
+def make_pair(n, seed=3, **over):
+    from seqdex_amd import _abi
+    from seqdex_amd.ppo import SdxPPO, make_config
+    cfg = make_config(n)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    agent = SdxPPO(n, config=cfg, seed=seed)
+    oc = dict(DEFAULT_CFG)
+    oc.update(minibatch=cfg.minibatch, mini_epochs=cfg.mini_epochs, lr=cfg.lr, cv_lr=cfg.cv_lr,
+              adaptive_lr=bool(cfg.adaptive_lr))
+    orc = PPOOracle(oc, seed=0)
+    orc.load_flat(agent.t["AC_PARAMS"].cpu(), agent.t["CV_PARAMS"].cpu())
+    return agent, orc
+
+
+def test_param_layout_and_init():
+    agent, orc = make_pair(16)
+    try:
+        assert agent.param_count(0) == 2131503 and agent.param_count(1) == 1234945
+        np.testing.assert_array_equal(orc.ac_flat().numpy(), agent.t["AC_PARAMS"].cpu().numpy())
+        p = agent.t["AC_PARAMS"].cpu().numpy()
+        w1 = p[:1024 * 396]
+        assert abs(np.abs(w1).max() - 1 / np.sqrt(396)) < 2e-3                              # U(-1/sqrt(fan_in), +)
+        assert (p[1024 * 396:1024 * 396 + 1024] == 0).all()                                 # biases zeroed
+    finally:
+        agent.close()
+
+
+def rollout(agent, orc, n, g, steps=8):
+    """drive both sides with the same synthetic observations and the same noise; returns the oracle-side dataset"""
+    H = steps
+    obs_l, st_l, eps_l, rew_l, done_l = [], [], [], [], []
+    buf = dict(actions=[], mus=[], sigmas=[], neglogp=[], values=[])
+    for t in range(H):
+        obs = torch.randn(n, 396, generator=g).clamp(-5, 5)
+        st = torch.randn(n, 564, generator=g).clamp(-5, 5) * 2
+        eps = torch.randn(n, 23, generator=g)
+        dones = (torch.rand(n, generator=g) < 0.15).float()
+        rew = torch.rand(n, generator=g)
+        a = agent.act(t, obs.cuda(), st.cuda(), dones.cuda(), eps.cuda())
+        agent.store_rewards(t, rew.cuda())
+        r = orc.act(obs, st, eps)
+        np.testing.assert_allclose(a.cpu().numpy(), r["actions"].numpy(), rtol=2e-4, atol=2e-4)
+        for k in buf:
+            buf[k].append(r[k])
+        obs_l.append(obs); st_l.append(st); eps_l.append(eps); rew_l.append(rew); done_l.append(dones)
+    last_st = torch.randn(n, 564, generator=g)
+    last_done = (torch.rand(n, generator=g) < 0.15).float()
+    agent.finish_rollout(last_st.cuda(), last_done.cuda())
+    torch.cuda.synchronize()
+    values = torch.stack(buf["values"])
+    adv, ret = orc.gae(torch.stack(rew_l), values, torch.stack(done_l), orc.values(last_st), last_done)
+    flat = lambda x: torch.stack(x).transpose(0, 1).reshape(n * H, *x[0].shape[1:]).contiguous()   # swap_and_flatten01
+    ds = dict(obs=flat(obs_l), states=flat(st_l), actions=flat(buf["actions"]), mus=flat(buf["mus"]).clone(),
+              sigmas=flat(buf["sigmas"]).clone(), neglogp=flat(buf["neglogp"]), values=flat(buf["values"]),
+              returns=ret.transpose(0, 1).reshape(-1).contiguous())
+    return ds
+
+
+def test_rollout_gae_and_dataset():
+    n = 64
+    agent, orc = make_pair(n)
+    try:
+        g = torch.Generator().manual_seed(1)
+        ds = rollout(agent, orc, n, g)
+        T = agent.t
+        np.testing.assert_allclose(T["MB_NEGLOGP"].cpu().numpy().reshape(-1), ds["neglogp"].numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(T["MB_VALUES"].cpu().numpy().reshape(-1), ds["values"].numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(T["MB_MUS"].cpu().numpy().reshape(-1, 23), ds["mus"].numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_array_equal(T["MB_OBS"].cpu().numpy().reshape(-1, 396), ds["obs"].numpy())
+        np.testing.assert_allclose(T["RETURNS"].cpu().numpy(), ds["returns"].numpy(), rtol=2e-4, atol=2e-4)
+        adv = ds["returns"] - ds["values"]
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        np.testing.assert_allclose(T["ADVANTAGES"].cpu().numpy(), adv.numpy(), rtol=2e-3, atol=2e-3)
+    finally:
+        agent.close()
+
+
+@pytest.mark.parametrize("adaptive", [0, 1])
+def test_update_matches_autograd_adam(adaptive):
+    """full update phase (5 mini-epochs x 32 minibatches of 4, three networks): parameters, Adam moments, running
+    mean/std, LR schedule and loss statistics against torch.autograd + torch.optim.Adam + clip_grad_norm_."""
+    n = 16
+    agent, orc = make_pair(n, adaptive_lr=adaptive)
+    try:
+        g = torch.Generator().manual_seed(2)
+        ds = rollout(agent, orc, n, g)
+        agent.update()
+        torch.cuda.synchronize()
+        st = orc.update(ds)
+        c = agent.ctrl()
+        nsteps = 5 * (n * 8 // 4)
+        assert c.n_mb == nsteps and c.ac_t == nsteps and c.ac_pending == 0
+        # statistics (means over all minibatches)
+        np.testing.assert_allclose(c.sum_a_loss / nsteps, np.mean(st["a"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_c_loss / nsteps, np.mean(st["c"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_cv_loss / nsteps, np.mean(st["cv"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_kl / nsteps, np.mean(st["kl"]), rtol=5e-3, atol=1e-5)
+        np.testing.assert_allclose(c.ac_lr, orc.lr, rtol=1e-6)
+        np.testing.assert_allclose(c.ac_gnorm, st["gnorm"][-1], rtol=2e-3)
+        np.testing.assert_allclose(c.cv_gnorm, st["cv_gnorm"][-1], rtol=2e-3)
+        # parameters after 160 optimiser steps per network
+        ac = agent.t["AC_PARAMS"].cpu().numpy(); cv = agent.t["CV_PARAMS"].cpu().numpy()
+        oa = orc.ac_flat().numpy(); ocv = orc.cv_flat().numpy()
+        assert np.abs(ac - oa).max() < 2e-4, np.abs(ac - oa).max()
+        assert np.abs(cv - ocv).max() < 5e-4, np.abs(cv - ocv).max()
+        np.testing.assert_allclose(agent.t["CV_RMS_MEAN"].cpu().numpy(), orc.rms.mean.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(agent.t["CV_RMS_VAR"].cpu().numpy(), orc.rms.var.numpy(), rtol=1e-5, atol=1e-7)
+        assert abs(c.rms_count - float(orc.rms.count)) < 1e-9
+        # update_mu_sigma wrote the new mus back into the dataset
+        np.testing.assert_allclose(agent.t["MB_MUS"].cpu().numpy().reshape(-1, 23), ds["mus"].numpy(), rtol=1e-3, atol=1e-3)
+    finally:
+        agent.close()

@@ -135,7 +135,7 @@ def test_reset_idx_golden(sim16, golden_dir):
     got = s.ROOT.cpu().numpy().reshape(n, 142, 13)
     np.testing.assert_array_equal(got[:, 9:141], ra[:, 9:141])          # bricks: exact copy of the saved pile
     m = mask.astype(bool)
-    np.testing.assert_allclose(got[m, 2, 0:3], ra[m, 2, 0:3], atol=1e-5)
+    np.testing.assert_allclose(got[m, 2, 0:3], np.tile(np.array(s.scene.goal_reset_pos, np.float32), (m.sum(), 1)), atol=1e-5)  # GS:1345-1348 with the scene's own goal_init_state
     np.testing.assert_array_equal(got[~m], f["root_before"].reshape(n, 142, 13)[~m])
     np.testing.assert_allclose(s.DOF.cpu().numpy(), f["dof_after"], atol=1e-6)
     np.testing.assert_allclose(s.PREV_TARGETS.cpu().numpy(), f["prev_after"], atol=1e-6)
