@@ -56,7 +56,7 @@ typedef enum {
   SDX_ERR_NOMEM = -5
 } sdx_status;
 
-typedef enum { SDX_F32 = 0, SDX_I64 = 1, SDX_I32 = 2, SDX_U8 = 3 } sdx_dtype;
+typedef enum { SDX_F32 = 0, SDX_I64 = 1, SDX_I32 = 2, SDX_U8 = 3, SDX_F64 = 4 } sdx_dtype;
 
 /* Tensor ids for sdx_tensor().  Shapes use N = num_envs. */
 typedef enum {
@@ -234,20 +234,21 @@ typedef enum {
   SDXP_T_AC_GRADS = 1,       /* f32 [P_ac]   flat gradient: the buffer RCCL all-reduces             */
   SDXP_T_CV_PARAMS = 2,      /* f32 [P_cv]   central value MLP (flat)                               */
   SDXP_T_CV_GRADS = 3,       /* f32 [P_cv]                                                          */
-  SDXP_T_MB_OBS = 4,         /* f32 [H,N,obs]     experience_buffer 'obses'   PS:346                */
-  SDXP_T_MB_STATES = 5,      /* f32 [H,N,state]   'states'                    PS:352                */
-  SDXP_T_MB_ACTIONS = 6,     /* f32 [H,N,act]                                                       */
-  SDXP_T_MB_MUS = 7,         /* f32 [H,N,act]                                                       */
-  SDXP_T_MB_SIGMAS = 8,      /* f32 [H,N,act]                                                       */
-  SDXP_T_MB_NEGLOGP = 9,     /* f32 [H,N]                                                           */
-  SDXP_T_MB_VALUES = 10,     /* f32 [H,N]                                                           */
-  SDXP_T_MB_REWARDS = 11,    /* f32 [H,N]                                                           */
-  SDXP_T_MB_DONES = 12,      /* f32 [H,N]         dones stored BEFORE the step, PS:347              */
+  /* experience buffer, stored env-major [N,H,...] == swap_and_flatten01 order (PS:338-339) */
+  SDXP_T_MB_OBS = 4,         /* f32 [N,H,obs]     experience_buffer 'obses'   PS:346                */
+  SDXP_T_MB_STATES = 5,      /* f32 [N,H,state]   'states'                    PS:352                */
+  SDXP_T_MB_ACTIONS = 6,     /* f32 [N,H,act]                                                       */
+  SDXP_T_MB_MUS = 7,         /* f32 [N,H,act]     overwritten by update_mu_sigma (RC:1358)          */
+  SDXP_T_MB_SIGMAS = 8,      /* f32 [N,H,act]                                                       */
+  SDXP_T_MB_NEGLOGP = 9,     /* f32 [N,H]                                                           */
+  SDXP_T_MB_VALUES = 10,     /* f32 [N,H]                                                           */
+  SDXP_T_MB_REWARDS = 11,    /* f32 [N,H]                                                           */
+  SDXP_T_MB_DONES = 12,      /* f32 [N,H]         dones stored BEFORE the step, PS:347              */
   SDXP_T_RETURNS = 13,       /* f32 [N*H]   env-major after swap_and_flatten01, PS:338-339          */
   SDXP_T_ADVANTAGES = 14,    /* f32 [N*H]   normalised, RC:1645-1651                                */
-  SDXP_T_CV_RMS_MEAN = 15,   /* f32 [state] running mean (f64 on the host side of rl_games)         */
-  SDXP_T_CV_RMS_VAR = 16,    /* f32 [state]                                                         */
-  SDXP_T_STATS = 17,         /* f32 [16]    a_loss,c_loss,b_loss,entropy,kl,lr,... of the last update */
+  SDXP_T_CV_RMS_MEAN = 15,   /* f64 [state] running mean of the central-value input normalisation   */
+  SDXP_T_CV_RMS_VAR = 16,    /* f64 [state]                                                         */
+  SDXP_T_STATS = 17,         /* raw control block (struct SdxpCtrl, csrc/sdxp_types.h) as f32 words  */
   SDXP_T_LAST_VALUES = 18,   /* f32 [N]                                                             */
   SDXP_T_AC_ADAM_M = 19, SDXP_T_AC_ADAM_V = 20, SDXP_T_CV_ADAM_M = 21, SDXP_T_CV_ADAM_V = 22,
   SDXP_T_COUNT = 23
@@ -264,15 +265,17 @@ int64_t sdxp_param_count(sdxp_handle h, int32_t which /*0 actor-critic, 1 centra
 
 /* get_action_values (RC:1697-1723): actor forward, a = mu + sigma*eps (eps from the counter RNG, or from
  * eps_dev f32 [N,act] when non-NULL), neglogp (RC:2114-2126), central value on states; stores row t of the
- * experience buffer (PS:345-352): obs, states, actions, mus, sigmas, neglogp, values, dones_dev (f32 or NULL=0).
+ * experience buffer (PS:345-352): obs, states, actions, mus, sigmas, neglogp, values, dones_dev (the task's i64
+ * reset_buf as returned by the PREVIOUS env step, PS:347; NULL = 0).
  * actions_out_dev f32 [N,act] receives the sampled (unclamped) actions. */
-int sdxp_act(sdxp_handle h, int32_t t, const float* obs_dev, const float* states_dev, const float* dones_dev,
+int sdxp_act(sdxp_handle h, int32_t t, const float* obs_dev, const float* states_dev, const int64_t* dones_dev,
              const float* eps_dev, float* actions_out_dev, void* stream);
-/* post_step (PS:355-359): rewards row t (reward_shaper scale 1, YG:32-33). */
-int sdxp_store_rewards(sdxp_handle h, int32_t t, const float* rew_dev, void* stream);
+/* post_step (PS:355-373): rewards row t (reward_shaper scale 1, YG:32-33) + episode statistics
+ * (current_rewards/current_lengths, game_rewards/game_lengths) from the i64 dones returned by THIS env step. */
+int sdxp_store_rewards(sdxp_handle h, int32_t t, const float* rew_dev, const int64_t* dones_after_dev, void* stream);
 /* play_steps tail (PS:329-339) + prepare_dataset (RC:1639-1651): last_values = V(states), GAE (R5), returns,
  * flatten env-major, advantage normalisation with unbiased std (R6); updates the CV running mean/std. */
-int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const float* last_dones_dev, void* stream);
+int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const int64_t* last_dones_dev, void* stream);
 /* train_central_value + the actor-critic minibatch loop of train_epoch (PS:294-326, RC:1339-1365): all
  * mini-epochs, contiguous unshuffled minibatches, loss R7, grad-norm clip, Adam, legacy adaptive LR after
  * every minibatch (R8).  Single-rank fast path: everything stays on the device. */

@@ -110,7 +110,7 @@ def load_library():
     lib.sdxp_param_count.argtypes = [vp, i32]
     lib.sdxp_param_count.restype = C.c_int64
     lib.sdxp_act.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
-    lib.sdxp_store_rewards.argtypes = [vp, i32, vp, vp]
+    lib.sdxp_store_rewards.argtypes = [vp, i32, vp, vp, vp]
     lib.sdxp_finish_rollout.argtypes = [vp, vp, vp, vp]
     lib.sdxp_update.argtypes = [vp, vp]
     lib.sdxp_backward.argtypes = [vp, i32, i32, vp]

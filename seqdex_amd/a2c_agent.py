@@ -1,0 +1,182 @@
+"""`A2CAgent` with the surface rl_games' `rl_games.algos_torch.a2c_continuous.A2CAgent` offers to its callers
+(train_rlgames.py:88-94 via Runner; policy_sequencing/policy_seq_runner.py:90-129,193-373 touches the attributes):
+train_epoch() returning the 11-tuple, play_steps(), env_reset()/env_step(), update_epoch(), set_eval()/set_train(),
+save()/restore(), obs/dones/frame/epoch_num/last_lr/batch_size/...  The loops themselves run in libseqdex_hip.so
+(seqdex_amd/ppo.py); this class is orchestration + timing + (for world_size > 1) the RCCL exchange."""
+import os
+import time
+
+import torch
+
+from .ppo import SdxPPO, make_config
+
+
+class _Meter:
+    """AverageMeter stand-in for game_rewards / game_lengths (PS:372-373): epoch means from device-side sums."""
+
+    def __init__(self):
+        self.current_size, self.mean = 0, 0.0
+
+    def update_from(self, total, count):
+        if count > 0:
+            self.mean, self.current_size = total / count, int(count)
+
+    def get_mean(self):
+        return [self.mean]
+
+
+class A2CAgent:
+    def __init__(self, base_name, params):
+        self.base_name = base_name
+        self.params = params
+        self.config = cfg = params["config"]
+        self.vec_env = cfg["vec_env"]                                  # injected like TR:84
+        self.env_info = cfg.get("env_info") or self.vec_env.get_env_info()
+        self.num_actors = cfg["num_actors"]
+        self.num_agents = self.env_info.get("agents", 1)
+        self.horizon_length = cfg.get("horizon_length", 8)
+        self.mini_epochs_num = cfg.get("mini_epochs", 5)
+        self.minibatch_size = cfg.get("minibatch_size", 4)
+        self.batch_size = self.horizon_length * self.num_actors * self.num_agents
+        assert self.batch_size % self.minibatch_size == 0
+        self.max_epochs = cfg.get("max_epochs", 100000)
+        self.name = cfg.get("name", "allegro")
+        self.ppo_device = self.vec_env.rl_device
+        self.rank = int(os.environ.get("RANK", "0")) if cfg.get("multi_gpu", False) else 0
+        self.rank_size = int(os.environ.get("WORLD_SIZE", "1")) if cfg.get("multi_gpu", False) else 1
+        self.multi_gpu = self.rank_size > 1
+        seed = int(cfg.get("seed", 22)) + self.rank                    # per-rank seed = seed + rank (App. C)
+        self.ppo = SdxPPO(self.num_actors, params=params, device=self.ppo_device, seed=seed, world_size=self.rank_size)
+        self.has_central_value = True
+        self.is_tensor_obses = True
+        self.frame, self.epoch_num = 0, 0
+        self.last_lr = float(cfg.get("learning_rate", 3e-4))
+        self.entropy_coef = cfg.get("entropy_coef", 0.0)
+        self.game_rewards, self.game_lengths = _Meter(), _Meter()
+        self.last_mean_rewards = -100500
+        self.obs, self.dones = None, None
+        self.curr_frames = self.batch_size
+        self.experience_buffer = type("ExperienceBuffer", (), {})()
+        t = self.ppo.t
+        self.experience_buffer.tensor_dict = {   # env-major [N,H,...] views (== swap_and_flatten01 layout)
+            "obses": t["MB_OBS"], "states": t["MB_STATES"], "actions": t["MB_ACTIONS"], "mus": t["MB_MUS"],
+            "sigmas": t["MB_SIGMAS"], "neglogpacs": t["MB_NEGLOGP"], "values": t["MB_VALUES"],
+            "rewards": t["MB_REWARDS"], "dones": t["MB_DONES"]}
+        self._ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    for _ in range(self.horizon_length)]
+        if self.multi_gpu:
+            self._broadcast_parameters()
+
+    # ------------------------------------------------------------------ multi-GPU (RCCL over xGMI)
+    def _broadcast_parameters(self):
+        import torch.distributed as dist
+        for k in ("AC_PARAMS", "CV_PARAMS"):
+            dist.broadcast(self.ppo.t[k], 0)
+
+    # ------------------------------------------------------------------ rl_games-shaped API
+    def set_eval(self):
+        pass
+
+    def set_train(self):
+        pass
+
+    def init_tensors(self):
+        pass
+
+    def update_epoch(self):
+        self.epoch_num += 1
+        return self.epoch_num
+
+    def env_reset(self):
+        return self.vec_env.reset()
+
+    def env_step(self, actions):
+        obs, rew, dones, infos = self.vec_env.step(actions)
+        return obs, rew.unsqueeze(1), dones, infos
+
+    def get_action_values(self, obs, t=0):
+        a = self.ppo.act(t, obs["obs"], obs["states"], self.dones)
+        return {"actions": a}
+
+    def play_steps(self):
+        """PS:220-275 / RC:1394-1483: horizon loop; every call below is asynchronous on the current stream."""
+        if self.obs is None:
+            self.obs = self.env_reset()
+            self.dones = self.vec_env.task.reset_buf
+        task = self.vec_env.task
+        for n in range(self.horizon_length):
+            a = self.ppo.act(n, self.obs["obs"], self.obs["states"], self.dones)
+            self._ev[n][0].record()
+            self.obs, rew, self.dones, infos = self.vec_env.step(a)
+            self._ev[n][1].record()
+            self.ppo.store_rewards(n, task.rew_buf, self.dones)
+        self.ppo.finish_rollout(self.obs["states"], self.dones)
+        return {"played_frames": self.batch_size}
+
+    def train_epoch(self):
+        """rl_games train_epoch (mirrored at PS:193-218, RC:1306-1392).  Returns
+        (step_time, play_time, update_time, total_time, a_losses, c_losses, b_losses, entropies, kls, last_lr, lr_mul)."""
+        torch.cuda.synchronize()
+        play_time_start = time.time()
+        self.play_steps()
+        torch.cuda.synchronize()
+        play_time_end = time.time()
+        step_time = sum(a.elapsed_time(b) for a, b in self._ev) * 1e-3
+        update_time_start = time.time()
+        if self.multi_gpu:
+            self._update_multi_gpu()
+        else:
+            self.ppo.update()
+        torch.cuda.synchronize()
+        update_time_end = time.time()
+        c = self.ppo.ctrl()
+        n = max(c.n_mb, 1)
+        self.last_lr = c.ac_lr
+        self.game_rewards.update_from(c.games_sum_rew, c.games_cnt)
+        self.game_lengths.update_from(c.games_sum_len, c.games_cnt)
+        tt = lambda v: [torch.tensor(v)]
+        return (step_time, play_time_end - play_time_start, update_time_end - update_time_start,
+                update_time_end - play_time_start, tt(c.sum_a_loss / n), tt(c.sum_c_loss / n), tt(c.sum_b_loss / n),
+                tt(c.sum_entropy / n), tt(c.sum_kl / n), self.last_lr, 1.0)
+
+    def _update_multi_gpu(self):
+        raise NotImplementedError("replaced below")
+
+    def train(self):
+        """rl_games A2CBase.train(): epoch loop + the fps line that IS the metric (PS:136-140)."""
+        total_time = 0.0
+        while True:
+            epoch_num = self.update_epoch()
+            step_time, play_time, update_time, sum_time, a_l, c_l, b_l, ent, kls, last_lr, lr_mul = self.train_epoch()
+            total_time += sum_time
+            curr_frames = self.curr_frames * self.rank_size
+            self.frame += curr_frames
+            if self.rank == 0:
+                fps_step = curr_frames / max(step_time, 1e-6)
+                fps_step_inference = curr_frames / play_time
+                fps_total = curr_frames / sum_time
+                print(f"fps step: {fps_step:.0f} fps step and policy inference: {fps_step_inference:.0f} "
+                      f"fps total: {fps_total:.0f} epoch: {epoch_num}/{self.max_epochs}")
+            if epoch_num >= self.max_epochs:
+                return self.game_rewards.get_mean()[0], epoch_num
+
+    # ------------------------------------------------------------------ checkpoints (rl_games .pth-shaped dict)
+    def get_full_state_weights(self):
+        t = self.ppo.t
+        return {"model": {"ac_flat": t["AC_PARAMS"].cpu(), "cv_flat": t["CV_PARAMS"].cpu()},
+                "optimizer": {"ac_m": t["AC_ADAM_M"].cpu(), "ac_v": t["AC_ADAM_V"].cpu(), "cv_m": t["CV_ADAM_M"].cpu(),
+                              "cv_v": t["CV_ADAM_V"].cpu()},
+                "running_mean_std": {"mean": t["CV_RMS_MEAN"].cpu(), "var": t["CV_RMS_VAR"].cpu()},
+                "epoch": self.epoch_num, "frame": self.frame, "last_mean_rewards": self.last_mean_rewards}
+
+    def save(self, fn):
+        torch.save(self.get_full_state_weights(), fn + ".pth")
+
+    def restore(self, fn):
+        ck = torch.load(fn, map_location="cpu")
+        t = self.ppo.t
+        t["AC_PARAMS"].copy_(ck["model"]["ac_flat"]); t["CV_PARAMS"].copy_(ck["model"]["cv_flat"])
+        t["AC_ADAM_M"].copy_(ck["optimizer"]["ac_m"]); t["AC_ADAM_V"].copy_(ck["optimizer"]["ac_v"])
+        t["CV_ADAM_M"].copy_(ck["optimizer"]["cv_m"]); t["CV_ADAM_V"].copy_(ck["optimizer"]["cv_v"])
+        t["CV_RMS_MEAN"].copy_(ck["running_mean_std"]["mean"]); t["CV_RMS_VAR"].copy_(ck["running_mean_std"]["var"])
+        self.epoch_num, self.frame = ck.get("epoch", 0), ck.get("frame", 0)

@@ -13,10 +13,10 @@
 
 extern "C" {
 void sdxpk_linear(const float*, const float*, const float*, float*, int, int, int, int, const double*, const double*, hipStream_t);
-void sdxpk_act_heads(const SdxpDev*, int, const float*, const float*, const float*, const float*, float*, uint64_t, hipStream_t);
-void sdxpk_store_rewards(const SdxpDev*, int, const float*, hipStream_t);
+void sdxpk_act_heads(const SdxpDev*, int, const float*, const float*, const int64_t*, const float*, float*, uint64_t, hipStream_t);
+void sdxpk_store_rewards(const SdxpDev*, int, const float*, const int64_t*, hipStream_t);
 void sdxpk_value_head(const SdxpDev*, float*, hipStream_t);
-void sdxpk_gae(const SdxpDev*, const float*, const float*, hipStream_t);
+void sdxpk_gae(const SdxpDev*, const float*, const int64_t*, hipStream_t);
 int sdxpk_update_step(const SdxpDev*, int, hipStream_t);
 int sdxpk_update_begin(const SdxpDev*, int, hipStream_t);
 int sdxpk_update_flush_layers(const SdxpDev*, int, hipStream_t);
@@ -136,6 +136,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   PAL(D.mb_obs, R * cfg->obs_dim); PAL(D.mb_states, R * cfg->state_dim); PAL(D.mb_actions, R * cfg->act_dim);
   PAL(D.mb_mus, R * cfg->act_dim); PAL(D.mb_sigmas, R * cfg->act_dim); PAL(D.mb_neglogp, R); PAL(D.mb_values, R);
   PAL(D.mb_rewards, R); PAL(D.mb_dones, R); PAL(D.returns, R); PAL(D.adv, R); PAL(D.last_values, N);
+  PAL(D.cur_rew, N); PAL(D.cur_len, N);
   PAL(D.rms_mean, cfg->state_dim); PAL(D.rms_var, cfg->state_dim);
   const int MB = cfg->minibatch;
   for (int net = 0; net < 3; ++net) {
@@ -188,8 +189,8 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   pset(h, SDXP_T_MB_DONES, D.mb_dones, SDX_F32, {(int64_t)N, (int64_t)H});
   pset(h, SDXP_T_RETURNS, D.returns, SDX_F32, {(int64_t)R});
   pset(h, SDXP_T_ADVANTAGES, D.adv, SDX_F32, {(int64_t)R});
-  pset(h, SDXP_T_CV_RMS_MEAN, D.rms_mean, 4 /*f64*/, {cfg->state_dim});
-  pset(h, SDXP_T_CV_RMS_VAR, D.rms_var, 4, {cfg->state_dim});
+  pset(h, SDXP_T_CV_RMS_MEAN, D.rms_mean, SDX_F64, {cfg->state_dim});
+  pset(h, SDXP_T_CV_RMS_VAR, D.rms_var, SDX_F64, {cfg->state_dim});
   pset(h, SDXP_T_STATS, D.ctrl, SDX_F32, {(int64_t)(sizeof(SdxpCtrl) / 4)});
   pset(h, SDXP_T_LAST_VALUES, D.last_values, SDX_F32, {(int64_t)N});
   pset(h, SDXP_T_AC_ADAM_M, D.ac_m, SDX_F32, {(int64_t)D.off.total});
@@ -233,6 +234,13 @@ static int plaunch_ok(sdxp_handle h, const char* what) {
   return SDX_OK;
 }
 
+__global__ void k_ctrl_begin_epoch(SdxpCtrl* c) {
+  c->mb_index = 0; c->mini_epoch = 0; c->n_mb = 0;
+  c->sum_a_loss = c->sum_c_loss = c->sum_b_loss = c->sum_kl = c->sum_cv_loss = c->sum_entropy = 0.0f;
+  for (int i = 0; i < 8; ++i) c->acc[i] = 0.0f;
+}
+__global__ void k_ctrl_begin_rollout(SdxpCtrl* c) { c->games_sum_rew = c->games_sum_len = c->games_cnt = 0.0f; }
+
 // trunk forward of `net` (0 actor, 2 central value) over M rows into the h_* activation buffers
 static void trunk_forward(sdxp_agent* h, int net, const float* x, int M, hipStream_t st) {
   const SdxpDev& D = h->D;
@@ -249,35 +257,30 @@ static void trunk_forward(sdxp_agent* h, int net, const float* x, int M, hipStre
   }
 }
 
-extern "C" int sdxp_act(sdxp_handle h, int32_t t, const float* obs_dev, const float* states_dev, const float* dones_dev,
+extern "C" int sdxp_act(sdxp_handle h, int32_t t, const float* obs_dev, const float* states_dev, const int64_t* dones_dev,
                         const float* eps_dev, float* actions_out_dev, void* stream) {
   if (!h || !obs_dev || !states_dev || !actions_out_dev || t < 0 || t >= h->D.horizon) { if (h) h->err = "sdxp_act: bad argument"; return SDX_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
+  if (t == 0) hipLaunchKernelGGL(k_ctrl_begin_rollout, dim3(1), dim3(1), 0, st, h->D.ctrl);
   trunk_forward(h, 0, obs_dev, h->D.N, st);
   trunk_forward(h, 2, states_dev, h->D.N, st);
   sdxpk_act_heads(&h->D, t, obs_dev, states_dev, dones_dev, eps_dev, actions_out_dev, h->act_counter++, st);
   return plaunch_ok(h, "sdxp_act");
 }
 
-extern "C" int sdxp_store_rewards(sdxp_handle h, int32_t t, const float* rew_dev, void* stream) {
+extern "C" int sdxp_store_rewards(sdxp_handle h, int32_t t, const float* rew_dev, const int64_t* dones_after_dev, void* stream) {
   if (!h || !rew_dev || t < 0 || t >= h->D.horizon) return SDX_ERR_INVALID;
-  sdxpk_store_rewards(&h->D, t, rew_dev, (hipStream_t)stream);
+  sdxpk_store_rewards(&h->D, t, rew_dev, dones_after_dev, (hipStream_t)stream);
   return plaunch_ok(h, "sdxp_store_rewards");
 }
 
-extern "C" int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const float* last_dones_dev, void* stream) {
+extern "C" int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const int64_t* last_dones_dev, void* stream) {
   if (!h || !last_states_dev) return SDX_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   trunk_forward(h, 2, last_states_dev, h->D.N, st);
   sdxpk_value_head(&h->D, h->D.last_values, st);
   sdxpk_gae(&h->D, h->D.last_values, last_dones_dev, st);
   return plaunch_ok(h, "sdxp_finish_rollout");
-}
-
-__global__ void k_ctrl_begin_epoch(SdxpCtrl* c) {
-  c->mb_index = 0; c->mini_epoch = 0; c->n_mb = 0;
-  c->sum_a_loss = c->sum_c_loss = c->sum_b_loss = c->sum_kl = c->sum_cv_loss = c->sum_entropy = 0.0f;
-  for (int i = 0; i < 8; ++i) c->acc[i] = 0.0f;
 }
 
 extern "C" int sdxp_update(sdxp_handle h, void* stream) {

@@ -94,7 +94,7 @@ __device__ __forceinline__ float randn(uint64_t seed, uint64_t a, uint64_t b) {
 // rollout heads: one wave per env.  mu = h3a Wmu^T + b; V = h3v Wv^T + b (central value); a = mu + sigma eps;
 // neglogp (RC:2114-2126); writes row (env, t) of the env-major experience buffer (PS:345-352).
 __global__ __launch_bounds__(64) void k_act_heads(SdxpDev D, int t, const float* __restrict__ obs,
-                                                  const float* __restrict__ states, const float* __restrict__ dones,
+                                                  const float* __restrict__ states, const int64_t* __restrict__ dones,
                                                   const float* __restrict__ eps_in, float* __restrict__ actions_out,
                                                   uint64_t counter) {
   const int e = blockIdx.x, lane = threadIdx.x;
@@ -131,15 +131,27 @@ __global__ __launch_bounds__(64) void k_act_heads(SdxpDev D, int t, const float*
   if (lane == 0) {
     D.mb_neglogp[row] = nlp;
     D.mb_values[row] = v;
-    D.mb_dones[row] = dones ? dones[e] : 0.0f;
+    D.mb_dones[row] = (dones && dones[e] != 0) ? 1.0f : 0.0f;
   }
   for (int i = lane; i < D.obs_dim; i += 64) D.mb_obs[row * D.obs_dim + i] = obs[(size_t)e * D.obs_dim + i];
   for (int i = lane; i < D.state_dim; i += 64) D.mb_states[row * D.state_dim + i] = states[(size_t)e * D.state_dim + i];
 }
 
-__global__ void k_store_rewards(SdxpDev D, int t, const float* __restrict__ rew) {
+__global__ void k_store_rewards(SdxpDev D, int t, const float* __restrict__ rew, const int64_t* __restrict__ dones_after) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < D.N) D.mb_rewards[(size_t)e * D.horizon + t] = rew[e];   // reward_shaper scale 1 (YG:32-33)
+  if (e >= D.N) return;
+  const float r = rew[e];
+  D.mb_rewards[(size_t)e * D.horizon + t] = r;   // reward_shaper scale 1 (YG:32-33)
+  // episode statistics (PS:361-373): current_rewards/current_lengths, game_rewards/game_lengths on done
+  const float cr = D.cur_rew[e] + r, cl = D.cur_len[e] + 1.0f;
+  const bool done = dones_after && dones_after[e] != 0;
+  if (done) {
+    atomicAdd(&D.ctrl->games_sum_rew, cr);
+    atomicAdd(&D.ctrl->games_sum_len, cl);
+    atomicAdd(&D.ctrl->games_cnt, 1.0f);
+  }
+  D.cur_rew[e] = done ? 0.0f : cr;
+  D.cur_len[e] = done ? 0.0f : cl;
 }
 
 // last value head only (get_values, RC:1725-1752)
@@ -152,14 +164,14 @@ __global__ __launch_bounds__(64) void k_value_head(SdxpDev D, float* __restrict_
 }
 
 // GAE (discount_values, PS:331-336) + returns, thread per env, env-major rows
-__global__ void k_gae(SdxpDev D, const float* __restrict__ last_values, const float* __restrict__ last_dones) {
+__global__ void k_gae(SdxpDev D, const float* __restrict__ last_values, const int64_t* __restrict__ last_dones) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= D.N) return;
   const int H = D.horizon;
   float lastgae = 0.0f;
   for (int t = H - 1; t >= 0; --t) {
     float nonterminal, nextv;
-    if (t == H - 1) { nonterminal = 1.0f - (last_dones ? last_dones[e] : 0.0f); nextv = last_values[e]; }
+    if (t == H - 1) { nonterminal = (last_dones && last_dones[e] != 0) ? 0.0f : 1.0f; nextv = last_values[e]; }
     else { nonterminal = 1.0f - D.mb_dones[(size_t)e * H + t + 1]; nextv = D.mb_values[(size_t)e * H + t + 1]; }
     const float v = D.mb_values[(size_t)e * H + t];
     const float delta = D.mb_rewards[(size_t)e * H + t] + D.gamma * nextv * nonterminal - v;
@@ -707,17 +719,17 @@ extern "C" void sdxpk_linear(const float* X, const float* W, const float* b, flo
   dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT);
   hipLaunchKernelGGL(k_linear_mfma, grid, dim3(256), 0, st, X, W, b, Y, M, N, K, elu_flag, nmean, nvar);
 }
-extern "C" void sdxpk_act_heads(const SdxpDev* D, int t, const float* obs, const float* states, const float* dones,
+extern "C" void sdxpk_act_heads(const SdxpDev* D, int t, const float* obs, const float* states, const int64_t* dones,
                                 const float* eps, float* actions_out, uint64_t counter, hipStream_t st) {
   hipLaunchKernelGGL(k_act_heads, dim3(D->N), dim3(64), 0, st, *D, t, obs, states, dones, eps, actions_out, counter);
 }
-extern "C" void sdxpk_store_rewards(const SdxpDev* D, int t, const float* rew, hipStream_t st) {
-  hipLaunchKernelGGL(k_store_rewards, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, t, rew);
+extern "C" void sdxpk_store_rewards(const SdxpDev* D, int t, const float* rew, const int64_t* dones_after, hipStream_t st) {
+  hipLaunchKernelGGL(k_store_rewards, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, t, rew, dones_after);
 }
 extern "C" void sdxpk_value_head(const SdxpDev* D, float* out, hipStream_t st) {
   hipLaunchKernelGGL(k_value_head, dim3(D->N), dim3(64), 0, st, *D, out);
 }
-extern "C" void sdxpk_gae(const SdxpDev* D, const float* last_values, const float* last_dones, hipStream_t st) {
+extern "C" void sdxpk_gae(const SdxpDev* D, const float* last_values, const int64_t* last_dones, hipStream_t st) {
   hipLaunchKernelGGL(k_gae, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, last_values, last_dones);
   if (D->normalize_advantage) hipLaunchKernelGGL(k_adv_norm, dim3(1), dim3(1024), 0, st, *D);
 }

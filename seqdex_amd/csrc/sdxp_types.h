@@ -23,6 +23,7 @@ struct SdxpCtrl {
   float last_kl;
   float sum_a_loss, sum_c_loss, sum_b_loss, sum_kl, sum_cv_loss, sum_entropy;
   float acc[8];          // per-minibatch sums written by the HEAD kernel: [1]a [2]c [3]b [4]kl [5]cv [6]entropy
+  float games_sum_rew, games_sum_len, games_cnt, pad0;
   double rms_count;
 };
 
@@ -39,7 +40,7 @@ struct SdxpDev {
   float *h_a[3], *h_v[3];
   // experience buffer, env-major rows r = env*horizon + t (== swap_and_flatten01 order, PS:338-339)
   float *mb_obs, *mb_states, *mb_actions, *mb_mus, *mb_sigmas, *mb_neglogp, *mb_values, *mb_rewards, *mb_dones;
-  float *returns, *adv, *last_values;
+  float *returns, *adv, *last_values, *cur_rew, *cur_len;
   double *rms_mean, *rms_var;
   // small-minibatch update: rank-MB factors, double buffered by step parity
   float* x[3][4];        // x[net][l]: [2][MB][K_l] input of trunk layer l (l=3: input of the head = output of layer 2)

@@ -17,6 +17,7 @@ class Ctrl(C.Structure):
                 ("ac_bc1", C.c_float), ("ac_bc2", C.c_float), ("cv_bc1", C.c_float), ("cv_bc2", C.c_float),
                 ("last_kl", C.c_float), ("sum_a_loss", C.c_float), ("sum_c_loss", C.c_float), ("sum_b_loss", C.c_float),
                 ("sum_kl", C.c_float), ("sum_cv_loss", C.c_float), ("sum_entropy", C.c_float), ("acc", C.c_float * 8),
+                ("games_sum_rew", C.c_float), ("games_sum_len", C.c_float), ("games_cnt", C.c_float), ("pad0", C.c_float),
                 ("rms_count", C.c_double)]
 
 
@@ -76,22 +77,24 @@ class SdxPPO:
             raise SdxError("libseqdex_hip (ppo) error %d: %s" % (rc, self.lib.sdxp_last_error(self.h).decode()))
 
     @staticmethod
-    def _p(t):
+    def _p(t, dtype=torch.float32):
         if t is None:
             return C.c_void_p(0)
-        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.dtype, dtype)
         return C.c_void_p(t.data_ptr())
 
     def act(self, t, obs, states, dones=None, eps=None):
-        self._check(self.lib.sdxp_act(self.h, t, self._p(obs), self._p(states), self._p(dones), self._p(eps),
+        self._check(self.lib.sdxp_act(self.h, t, self._p(obs), self._p(states), self._p(dones, torch.int64), self._p(eps),
                                       self._p(self.actions), _stream_ptr(self.device)))
         return self.actions
 
-    def store_rewards(self, t, rew):
-        self._check(self.lib.sdxp_store_rewards(self.h, t, self._p(rew), _stream_ptr(self.device)))
+    def store_rewards(self, t, rew, dones_after=None):
+        self._check(self.lib.sdxp_store_rewards(self.h, t, self._p(rew), self._p(dones_after, torch.int64),
+                                                _stream_ptr(self.device)))
 
     def finish_rollout(self, last_states, last_dones=None):
-        self._check(self.lib.sdxp_finish_rollout(self.h, self._p(last_states), self._p(last_dones), _stream_ptr(self.device)))
+        self._check(self.lib.sdxp_finish_rollout(self.h, self._p(last_states), self._p(last_dones, torch.int64),
+                                                 _stream_ptr(self.device)))
 
     def update(self):
         self._check(self.lib.sdxp_update(self.h, _stream_ptr(self.device)))

@@ -47,21 +47,21 @@ def rollout(agent, orc, n, g, steps=8):
         obs = torch.randn(n, 396, generator=g).clamp(-5, 5)
         st = torch.randn(n, 564, generator=g).clamp(-5, 5) * 2
         eps = torch.randn(n, 23, generator=g)
-        dones = (torch.rand(n, generator=g) < 0.15).float()
+        dones = (torch.rand(n, generator=g) < 0.15).long()
         rew = torch.rand(n, generator=g)
         a = agent.act(t, obs.cuda(), st.cuda(), dones.cuda(), eps.cuda())
-        agent.store_rewards(t, rew.cuda())
+        agent.store_rewards(t, rew.cuda(), dones.cuda())
         r = orc.act(obs, st, eps)
         np.testing.assert_allclose(a.cpu().numpy(), r["actions"].numpy(), rtol=2e-4, atol=2e-4)
         for k in buf:
             buf[k].append(r[k])
-        obs_l.append(obs); st_l.append(st); eps_l.append(eps); rew_l.append(rew); done_l.append(dones)
+        obs_l.append(obs); st_l.append(st); eps_l.append(eps); rew_l.append(rew); done_l.append(dones.float())
     last_st = torch.randn(n, 564, generator=g)
-    last_done = (torch.rand(n, generator=g) < 0.15).float()
+    last_done = (torch.rand(n, generator=g) < 0.15).long()
     agent.finish_rollout(last_st.cuda(), last_done.cuda())
     torch.cuda.synchronize()
     values = torch.stack(buf["values"])
-    adv, ret = orc.gae(torch.stack(rew_l), values, torch.stack(done_l), orc.values(last_st), last_done)
+    adv, ret = orc.gae(torch.stack(rew_l), values, torch.stack(done_l), orc.values(last_st), last_done.float())
     flat = lambda x: torch.stack(x).transpose(0, 1).reshape(n * H, *x[0].shape[1:]).contiguous()   # swap_and_flatten01
     ds = dict(obs=flat(obs_l), states=flat(st_l), actions=flat(buf["actions"]), mus=flat(buf["mus"]).clone(),
               sigmas=flat(buf["sigmas"]).clone(), neglogp=flat(buf["neglogp"]), values=flat(buf["values"]),

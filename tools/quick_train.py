@@ -1,0 +1,19 @@
+import sys, time, yaml, torch
+sys.path.insert(0,'.')
+from seqdex_amd.tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
+from seqdex_amd.vec_task_rlgames import RLgamesVecTaskPython
+from seqdex_amd.a2c_agent import A2CAgent
+n=int(sys.argv[1]) if len(sys.argv)>1 else 1024
+cfg=yaml.safe_load(open('seqdex_amd/cfg/allegro_hand_block_assembly_grasp_sim.yaml')); cfg['env']['numEnvs']=n
+tr=yaml.safe_load(open('seqdex_amd/cfg/lego/ppo_continuous_grasp.yaml'))
+t0=time.time()
+task=BlockAssemblyGraspSim(cfg, device_type='cuda', device_id=0, headless=True, piles_per_type=4)
+print('task create s', time.time()-t0)
+env=RLgamesVecTaskPython(task,'cuda:0')
+tr['params']['config'].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22)
+agent=A2CAgent('run', tr['params'])
+for ep in range(4):
+    r=agent.train_epoch()
+    print('epoch',ep,'step %.4f play %.4f update %.4f total %.4f'%r[:4], 'a %.4f c %.4f kl %.5f lr %.2e'%(r[4][0],r[5][0],r[8][0],r[9]),
+          'fps_step %.0f fps_total %.0f'%(n*8/r[0], n*8/r[3]), 'games', agent.game_rewards.get_mean(), agent.game_lengths.get_mean())
+print('nc mean', task.sim.NCONTACTS.float().mean().item(), 'rew mean', task.rew_buf.mean().item())
