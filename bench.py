@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the BlockAssemblyGraspSim rollout + PPO hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one rl_games epoch of the hot path over one batch of synthetic input: horizon_length (8) vectorised env
+steps of num_envs (1024) envs per GPU (policy inference + physics + obs/reward) followed by the complete PPO update
+with the SHIPPED hyper-parameters (minibatch_size 4, 5 mini-epochs, central value; cfg/lego/ppo_continuous_grasp.yaml).
+value = total env-steps of all ranks / max-over-ranks wall time of exactly K steps = rl_games' "fps total" (PS:136-140).
+Rank 0 prints ONE JSON line; see DESIGN.md §7 for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_ENV_STEP = 18496     # algorithmic HBM bytes per env-step of the sim+task path
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--num-envs", type=int, default=1024, help="envs per GPU (config[1]: 1024)")
+    ap.add_argument("--minibatch", type=int, default=None, help="override minibatch_size (labelled variant, not the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-envs", type=int, default=64)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=6)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, scene_desc, root0, dof0, targets0):
+    """oracle/physics_oracle.c (plain-C port of the same env physics step, OpenMP over envs) timed on the host cores
+    on a bounded sample: `cpu_baseline_envs` envs x `cpu_baseline_steps` steps starting from settled piles."""
+    import numpy as np
+    from oracle import physics_oracle as po
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    n = min(args.cpu_baseline_envs, root0.shape[0])
+    root, dof, tg = root0[:n].copy(), dof0[:n].copy(), targets0[:n].copy()
+    po.simulate(scene_desc, root, dof, tg)            # warm-up (also builds the .so if needed)
+    t = time.time()
+    for _ in range(args.cpu_baseline_steps):
+        po.simulate(scene_desc, root, dof, tg)
+    dt = time.time() - t
+    return {"value": n * args.cpu_baseline_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d physics steps (oracle/physics_oracle.c, OpenMP over envs, %d threads); sim step only, "
+                      "no PPO" % (n, args.cpu_baseline_steps, cores)}
+
+
+def main():
+    args = parse()
+    import torch
+    import yaml
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+
+    from seqdex_amd.a2c_agent import A2CAgent
+    from seqdex_amd.tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
+    from seqdex_amd.vec_task_rlgames import RLgamesVecTaskPython
+
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd/cfg/allegro_hand_block_assembly_grasp_sim.yaml")))
+    train = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd/cfg/lego/ppo_continuous_grasp.yaml")))
+    n = args.num_envs
+    cfg["env"]["numEnvs"] = n
+    if args.minibatch:
+        train["params"]["config"]["minibatch_size"] = args.minibatch
+        train["params"]["config"]["central_value_config"]["minibatch_size"] = args.minibatch
+    seed = 22 + rank
+    task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=local_rank, headless=True, seed=seed, piles_per_type=8)
+    env = RLgamesVecTaskPython(task, "cuda:%d" % local_rank)
+    pc = train["params"]["config"]
+    pc.update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22, multi_gpu=world > 1)
+    agent = A2CAgent("run", train["params"])
+    horizon = agent.horizon_length
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        agent.train_epoch()
+    barrier()
+    t0 = time.time()
+    step_t = play_t = upd_t = 0.0
+    for _ in range(args.steps):
+        r = agent.train_epoch()
+        step_t += r[0]; play_t += r[1]; upd_t += r[2]
+    barrier()
+    dt = time.time() - t0
+    tmax = torch.tensor([dt], device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    frames = n * horizon * args.steps * world
+    value = frames / dt
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    # ---- roofline of the dominant rollout kernel (k_physics): HIP events on the stream the kernel is launched on
+    sim = task.sim
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        sim.simulate()
+    e0.record()
+    for _ in range(reps):
+        sim.simulate()
+    e1.record()
+    torch.cuda.synchronize()
+    phys_ms = e0.elapsed_time(e1) / reps
+    phys_bytes = BYTES_PER_ENV_STEP * n
+    roof_phys = {"kernel": "k_physics", "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes, "traffic": None}
+    roof_phys["frac"] = roof_phys["achieved"] / HBM_PEAK_GBS
+    # ---- roofline of the update phase: one optimiser step streams w,m,v in and out once for all three networks
+    p_ac, p_cv = agent.ppo.param_count(0), agent.ppo.param_count(1)
+    nsteps = agent.mini_epochs_num * (n * horizon // agent.minibatch_size)
+    upd_bytes_step = 6 * 4 * (p_ac + p_cv)
+    upd_ms_step = upd_t / args.steps / nsteps * 1e3
+    roof_upd = {"kernel": "k_layer/k_head/k_back/k_ctrl (one optimiser step, 3 networks)", "bound": "hbm",
+                "achieved": upd_bytes_step / (upd_ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "avg_step_ms": upd_ms_step, "algorithmic_bytes_per_step": upd_bytes_step, "traffic": None}
+    roof_upd["frac"] = roof_upd["achieved"] / HBM_PEAK_GBS
+    dominant = roof_upd if upd_t > step_t else roof_phys
+    out = {
+        "metric": "env-steps/sec BlockAssemblyGraspSim num_envs=%d/GPU" % n, "value": value, "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BlockAssemblyGraspSim num_envs=%d per GPU, fp32, PPO MLP policy [1024,512,256], horizon 8, "
+                               "minibatch_size %d, mini_epochs 5, central value (configs[1])" % (n, agent.minibatch_size),
+                   "step": "one rl_games epoch = 8 env steps x num_envs + full PPO update", "global_envs": n * world,
+                   "piles": "synthetic settled piles, 8 per brick-type group", "policy": "random init, seed 22+rank"},
+        "fps_step": n * horizon * args.steps / step_t, "fps_step_and_inference": n * horizon * args.steps / play_t,
+        "fps_total_rank0": n * horizon * args.steps / (play_t + upd_t),
+        "update_ms_per_epoch": upd_t / args.steps * 1e3, "rollout_ms_per_epoch": play_t / args.steps * 1e3,
+        "roofline": {"bound": dominant["bound"], "achieved": dominant["achieved"], "peak": dominant["peak"],
+                     "unit": "GB/s", "frac": dominant["frac"], "traffic": None, "kernel": dominant["kernel"]},
+        "roofline_physics": roof_phys, "roofline_update": roof_upd,
+    }
+    if not args.no_cpu_baseline:
+        try:
+            root = sim.ROOT.view(n, 142, 13).cpu().numpy().copy()
+            dof = sim.DOF.view(n, 23, 2).cpu().numpy().copy()
+            tg = sim.TARGETS.cpu().numpy().copy()
+            out["cpu_baseline"] = cpu_baseline(args, sim._desc, root, dof, tg)
+        except Exception as ex:   # the checker is optional for the measurement itself
+            out["cpu_baseline"] = {"value": None, "error": str(ex)}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

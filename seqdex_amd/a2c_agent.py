@@ -140,7 +140,22 @@ class A2CAgent:
                 tt(c.sum_entropy / n), tt(c.sum_kl / n), self.last_lr, 1.0)
 
     def _update_multi_gpu(self):
-        raise NotImplementedError("replaced below")
+        """world_size > 1: per optimiser step the flat gradients (8.5 MB actor-critic + 4.9 MB central value, fp32) and
+        the scalar KL are summed over ranks with RCCL (torch.distributed backend "nccl") on the current stream; the
+        division by world_size, clip_grad_norm_, Adam and the LR rule run in sdxp_apply (rl_games multi-GPU semantics,
+        SURVEY.md App. C; PS:308-310)."""
+        import torch.distributed as dist
+        ppo = self.ppo
+        g_ac, g_cv, kl = ppo.t["AC_GRADS"], ppo.t["CV_GRADS"], ppo.kl_view()
+        ppo.backward(0, -1)
+        for _ in range(self.mini_epochs_num):
+            for mb in range(self.batch_size // self.minibatch_size):
+                ppo.backward(0, mb)
+                dist.all_reduce(g_ac)
+                dist.all_reduce(g_cv)
+                dist.all_reduce(kl)
+                ppo.apply(0)
+                ppo.apply(1)
 
     def train(self):
         """rl_games A2CBase.train(): epoch loop + the fps line that IS the metric (PS:136-140)."""

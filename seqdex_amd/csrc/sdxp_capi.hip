@@ -20,6 +20,8 @@ void sdxpk_gae(const SdxpDev*, const float*, const int64_t*, hipStream_t);
 int sdxpk_update_step(const SdxpDev*, int, hipStream_t);
 int sdxpk_update_begin(const SdxpDev*, int, hipStream_t);
 int sdxpk_update_flush_layers(const SdxpDev*, int, hipStream_t);
+int sdxpk_backward_explicit(const SdxpDev*, int, hipStream_t);
+void sdxpk_apply_explicit(const SdxpDev*, int, float, int, hipStream_t);
 }
 
 struct sdxp_agent {
@@ -172,6 +174,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     ctl.ac_lr = cfg->lr; ctl.cv_lr = cfg->cv_lr; ctl.ac_gscale = 1.0f; ctl.cv_gscale = 1.0f;
     ctl.ac_bc1 = ctl.ac_bc2 = ctl.cv_bc1 = ctl.cv_bc2 = 1.0f;
     ctl.rms_count = 1.0;
+    ctl.world = cfg->world_size > 0 ? cfg->world_size : 1;
     PCHK(h, hipMemcpy(D.ctrl, &ctl, sizeof(ctl), hipMemcpyHostToDevice));
   }
   pset(h, SDXP_T_AC_PARAMS, D.ac, SDX_F32, {(int64_t)D.off.total});
@@ -316,14 +319,30 @@ extern "C" int sdxp_update(sdxp_handle h, void* stream) {
   return plaunch_ok(h, "sdxp_update");
 }
 
-extern "C" int sdxp_backward(sdxp_handle h, int32_t, int32_t, void*) {
+// Multi-rank path.  which: 0 = runs forward/backward of ALL THREE networks for minibatch `mb` and materialises both flat
+// gradients (the networks advance in the same launches); 1 = no-op kept for symmetry with sdxp_apply.  mb == -1 begins an
+// epoch's update phase (resets the control block, stages minibatch 0); otherwise minibatches must come in order.
+extern "C" int sdxp_backward(sdxp_handle h, int32_t which, int32_t mb, void* stream) {
   if (!h) return SDX_ERR_INVALID;
-  h->err = "sdxp_backward: explicit-gradient (multi-rank all-reduce) path is not built in this round";
-  return SDX_ERR_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  const int MB = h->cfg.minibatch;
+  if (MB != 2 && MB != 4 && MB != 8) { h->err = "sdxp_backward: minibatch_size must be 2/4/8"; return SDX_ERR_INVALID; }
+  if (which == 1) return SDX_OK;
+  if (mb < 0) {
+    hipLaunchKernelGGL(k_ctrl_begin_epoch, dim3(1), dim3(1), 0, st, h->D.ctrl);
+    sdxpk_update_begin(&h->D, MB, st);
+    return plaunch_ok(h, "sdxp_backward(begin)");
+  }
+  if (mb >= h->D.num_minibatches) { h->err = "sdxp_backward: minibatch index out of range"; return SDX_ERR_INVALID; }
+  sdxpk_backward_explicit(&h->D, MB, st);
+  return plaunch_ok(h, "sdxp_backward");
 }
-extern "C" int sdxp_apply(sdxp_handle h, int32_t, float, void*) {
-  if (!h) return SDX_ERR_INVALID;
-  h->err = "sdxp_apply: explicit-gradient (multi-rank all-reduce) path is not built in this round";
-  return SDX_ERR_STATE;
+// clip_grad_norm_ + Adam on the (caller-all-reduced, SUM) flat gradient of network `which`; gradients are divided by
+// world_size here.  kl: rank-averaged KL for the legacy LR schedule, or NaN to use SdxpCtrl.last_kl that the caller
+// all-reduced in place (SUM) through the SDXP_T_STATS view.
+extern "C" int sdxp_apply(sdxp_handle h, int32_t which, float kl, void* stream) {
+  if (!h || which < 0 || which > 1) return SDX_ERR_INVALID;
+  sdxpk_apply_explicit(&h->D, which, kl, h->cfg.world_size > 0 ? h->cfg.world_size : 1, (hipStream_t)stream);
+  return plaunch_ok(h, "sdxp_apply");
 }
 extern "C" const char* sdxp_last_error(sdxp_handle h) { return h ? h->err.c_str() : gp_create_err.c_str(); }

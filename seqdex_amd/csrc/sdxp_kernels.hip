@@ -651,14 +651,16 @@ __global__ __launch_bounds__(256) void k_ctrl(SdxpDev D, int advance) {
       ctl->ac_bc1 = 1.0f - powf(0.9f, (float)ctl->ac_t); ctl->ac_bc2 = 1.0f - powf(0.999f, (float)ctl->ac_t);
       ctl->cv_bc1 = 1.0f - powf(0.9f, (float)ctl->cv_t); ctl->cv_bc2 = 1.0f - powf(0.999f, (float)ctl->cv_t);
       ctl->ac_lr_applied = ctl->ac_lr; ctl->cv_lr_applied = ctl->cv_lr;
-      ctl->ac_pending = 1; ctl->cv_pending = 1;
+      const bool explicit_mode = (advance & 8) != 0;   // multi-rank: Adam/LR happen in sdxp_apply after the all-reduce
+      if (explicit_mode) { ctl->ac_t -= 1; ctl->cv_t -= 1; ctl->gn2_ac = 0.0f; ctl->gn2_cv = 0.0f; }
+      ctl->ac_pending = explicit_mode ? 0 : 1; ctl->cv_pending = explicit_mode ? 0 : 1;
       // statistics (means over the minibatch) + legacy adaptive LR from this minibatch's KL (PS:306-312)
       const float invM = 1.0f / (float)MB;
       const float kl = ctl->acc[4] * invM;
       ctl->sum_a_loss += ctl->acc[1] * invM; ctl->sum_c_loss += ctl->acc[2] * invM; ctl->sum_b_loss += ctl->acc[3] * invM;
       ctl->sum_kl += kl; ctl->sum_cv_loss += ctl->acc[5] * invM; ctl->sum_entropy += ctl->acc[6] * invM;
       ctl->n_mb += 1; ctl->last_kl = kl;
-      if (D.adaptive_lr) {
+      if (D.adaptive_lr && !explicit_mode) {
         if (kl > 2.0f * D.kl_threshold) ctl->ac_lr = fmaxf(ctl->ac_lr / 1.5f, 1e-6f);
         if (kl < 0.5f * D.kl_threshold) ctl->ac_lr = fminf(ctl->ac_lr * 1.5f, 1e-2f);
       }
@@ -788,4 +790,129 @@ extern "C" int sdxpk_update_flush_layers(const SdxpDev* D, int mb_size, hipStrea
     case 8: launch_flush<8>(D, st); return 0;
     default: return -1;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ explicit gradients
+// world_size > 1: the minibatch gradient is materialised into the flat *_GRADS buffers (same layout as the
+// parameters) so that the caller can all-reduce it with RCCL; then sq-norm, clip and Adam run elementwise.
+template <int MB>
+__global__ __launch_bounds__(256) void k_grad_layer(SdxpDev D, int l) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int par = D.ctrl->step & 1, Nl = D.units[l];
+  const int blocks_per_net = (Nl + 3) / 4;
+  const int net = blockIdx.x / blocks_per_net, n = (blockIdx.x % blocks_per_net) * 4 + wave;
+  const int K = (l == 0) ? (net == 2 ? D.state_dim : D.obs_dim) : D.units[l - 1];
+  float* G = net == 2 ? D.cv_g : D.ac_g;
+  const size_t woff = net == 0 ? D.off.a_w[l] : net == 1 ? D.off.c_w[l] : D.coff.w[l];
+  const size_t boff = net == 0 ? D.off.a_b[l] : net == 1 ? D.off.c_b[l] : D.coff.b[l];
+  const float* gx = D.x[net][l] + (size_t)par * MB * K;
+  for (int i = tid; i < MB * K; i += 256) sm[i] = gx[i];
+  __syncthreads();
+  if (n >= Nl) return;
+  const float* dy = D.dy[net][l] + (size_t)par * MB * Nl;
+  float dyn[MB], sb = 0.0f;
+#pragma unroll
+  for (int s = 0; s < MB; ++s) { dyn[s] = dy[s * Nl + n]; sb += dyn[s]; }
+  for (int k = lane; k < K; k += 64) {
+    float g = 0.0f;
+#pragma unroll
+    for (int s = 0; s < MB; ++s) g += dyn[s] * sm[s * K + k];
+    G[woff + (size_t)n * K + k] = g;
+  }
+  if (lane == 0) G[boff + n] = sb;
+}
+template <int MB>
+__global__ __launch_bounds__(256) void k_grad_heads(SdxpDev D) {
+  const int tid = threadIdx.x, par = D.ctrl->step & 1, U = D.units[2], A = D.act_dim;
+  const float* dh = D.dhead + (size_t)par * MB * 34;
+  for (int i = tid; i < (A + 2) * U; i += 256) {
+    const int row = i / U, k = i % U;
+    const int net = row < A ? 0 : (row == A ? 1 : 2);
+    const float* h = D.x[net][3] + (size_t)par * MB * U;
+    float g = 0.0f;
+    for (int s = 0; s < MB; ++s) g += (row < A ? dh[s * 34 + row] : dh[s * 34 + 32 + (row - A)]) * h[s * U + k];
+    if (row < A) D.ac_g[D.off.mu_w + (size_t)row * U + k] = g;
+    else if (row == A) D.ac_g[D.off.v_w + k] = g;
+    else D.cv_g[D.coff.v_w + k] = g;
+  }
+  if (tid < A + 2) {
+    float g = 0.0f;
+    for (int s = 0; s < MB; ++s) g += tid < A ? dh[s * 34 + tid] : dh[s * 34 + 32 + (tid - A)];
+    if (tid < A) D.ac_g[D.off.mu_b + tid] = g;
+    else if (tid == A) D.ac_g[D.off.v_b] = g;
+    else D.cv_g[D.coff.v_b] = g;
+  }
+  if (tid < A) D.ac_g[D.off.logstd + tid] = D.dlogstd[(size_t)par * 32 + tid];
+}
+__global__ __launch_bounds__(256) void k_sqnorm(const float* __restrict__ g, size_t n, float scale, float* out) {
+  float s = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float v = g[i] * scale; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+__global__ __launch_bounds__(256) void k_adam_explicit(SdxpDev D, int which) {
+  const SdxpCtrl* ctl = D.ctrl;
+  const size_t n = which ? D.coff.total : D.off.total;
+  float* P = which ? D.cv : D.ac; float* M = which ? D.cv_m : D.ac_m; float* V = which ? D.cv_v : D.ac_v;
+  const float* G = which ? D.cv_g : D.ac_g;
+  const float inv_w = 1.0f / (float)ctl->world;
+  const float norm = sqrtf(which ? ctl->gn2_cv : ctl->gn2_ac);
+  const float clip = D.truncate_grads ? fminf(1.0f, D.grad_norm / (norm + 1e-6f)) : 1.0f;
+  const int t = (which ? ctl->cv_t : ctl->ac_t) + 1;
+  const float bc1 = 1.0f - powf(0.9f, (float)t), bc2 = 1.0f - powf(0.999f, (float)t);
+  const float lr = which ? ctl->cv_lr : ctl->ac_lr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float g = G[i] * inv_w * clip;
+    const float m = 0.9f * M[i] + 0.1f * g, v = 0.999f * V[i] + 0.001f * g * g;
+    M[i] = m; V[i] = v;
+    P[i] -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
+  }
+}
+__global__ void k_apply_fin(SdxpDev D, int which, float kl_host) {
+  SdxpCtrl* ctl = D.ctrl;
+  if (which) { ctl->cv_t += 1; ctl->cv_gnorm = sqrtf(ctl->gn2_cv); return; }
+  ctl->ac_t += 1; ctl->ac_gnorm = sqrtf(ctl->gn2_ac);
+  const float kl = (kl_host == kl_host) ? kl_host : ctl->last_kl / (float)ctl->world;   // NaN -> device value, all-reduced in place
+  if (D.adaptive_lr) {   // legacy schedule after every minibatch, on the rank-averaged KL (PS:306-312)
+    if (kl > 2.0f * D.kl_threshold) ctl->ac_lr = fmaxf(ctl->ac_lr / 1.5f, 1e-6f);
+    if (kl < 0.5f * D.kl_threshold) ctl->ac_lr = fminf(ctl->ac_lr * 1.5f, 1e-2f);
+  }
+}
+template <int MB>
+static void launch_backward_explicit(const SdxpDev* D, hipStream_t st) {
+  const int rpb = 4 * D->rows_per_wave;
+  for (int l = 0; l < 3; ++l) {
+    const int Nl = D->units[l];
+    const int Kmax = l == 0 ? (D->state_dim > D->obs_dim ? D->state_dim : D->obs_dim) : D->units[l - 1];
+    hipLaunchKernelGGL(k_layer<MB>, dim3(3 * ((Nl + rpb - 1) / rpb)), dim3(256), (size_t)2 * MB * Kmax * sizeof(float), st, *D, l);
+  }
+  hipLaunchKernelGGL(k_head<MB>, dim3(1), dim3(256), 0, st, *D, 0);
+  for (int l = 1; l >= 0; --l) {
+    const int K = D->units[l];
+    hipLaunchKernelGGL(k_back<MB>, dim3(3 * ((K + 255) / 256) * D->bsplit), dim3(256), 0, st, *D, l);
+    hipLaunchKernelGGL(k_back_fin<MB>, dim3((3 * MB * K + 255) / 256), dim3(256), 0, st, *D, l);
+  }
+  for (int l = 0; l < 3; ++l) {
+    const int Nl = D->units[l];
+    const int Kmax = l == 0 ? (D->state_dim > D->obs_dim ? D->state_dim : D->obs_dim) : D->units[l - 1];
+    hipLaunchKernelGGL(k_grad_layer<MB>, dim3(3 * ((Nl + 3) / 4)), dim3(256), (size_t)MB * Kmax * sizeof(float), st, *D, l);
+  }
+  hipLaunchKernelGGL(k_grad_heads<MB>, dim3(1), dim3(256), 0, st, *D);
+  hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(256), 0, st, *D, 1 | 2 | 8);
+}
+extern "C" int sdxpk_backward_explicit(const SdxpDev* D, int mb_size, hipStream_t st) {
+  switch (mb_size) {
+    case 2: launch_backward_explicit<2>(D, st); return 0;
+    case 4: launch_backward_explicit<4>(D, st); return 0;
+    case 8: launch_backward_explicit<8>(D, st); return 0;
+    default: return -1;
+  }
+}
+extern "C" void sdxpk_apply_explicit(const SdxpDev* D, int which, float kl, int world, hipStream_t st) {
+  const size_t n = which ? D->coff.total : D->off.total;
+  float* acc = which ? &D->ctrl->gn2_cv : &D->ctrl->gn2_ac;
+  hipLaunchKernelGGL(k_sqnorm, dim3(512), dim3(256), 0, st, which ? D->cv_g : D->ac_g, n, 1.0f / (float)world, acc);
+  hipLaunchKernelGGL(k_adam_explicit, dim3(1024), dim3(256), 0, st, *D, which);
+  hipLaunchKernelGGL(k_apply_fin, dim3(1), dim3(1), 0, st, *D, which, kl);
 }

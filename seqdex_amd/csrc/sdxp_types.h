@@ -24,6 +24,8 @@ struct SdxpCtrl {
   float sum_a_loss, sum_c_loss, sum_b_loss, sum_kl, sum_cv_loss, sum_entropy;
   float acc[8];          // per-minibatch sums written by the HEAD kernel: [1]a [2]c [3]b [4]kl [5]cv [6]entropy
   float games_sum_rew, games_sum_len, games_cnt, pad0;
+  float gn2_ac, gn2_cv;  // explicit-gradient path: sum of squares of the (all-reduced) flat gradients
+  int32_t world, pad1;
   double rms_count;
 };
 

@@ -18,6 +18,7 @@ class Ctrl(C.Structure):
                 ("last_kl", C.c_float), ("sum_a_loss", C.c_float), ("sum_c_loss", C.c_float), ("sum_b_loss", C.c_float),
                 ("sum_kl", C.c_float), ("sum_cv_loss", C.c_float), ("sum_entropy", C.c_float), ("acc", C.c_float * 8),
                 ("games_sum_rew", C.c_float), ("games_sum_len", C.c_float), ("games_cnt", C.c_float), ("pad0", C.c_float),
+                ("gn2_ac", C.c_float), ("gn2_cv", C.c_float), ("world", C.c_int32), ("pad1", C.c_int32),
                 ("rms_count", C.c_double)]
 
 
@@ -98,6 +99,18 @@ class SdxPPO:
 
     def update(self):
         self._check(self.lib.sdxp_update(self.h, _stream_ptr(self.device)))
+
+    # ---- explicit-gradient path for world_size > 1 (gradients all-reduced by the caller between the two calls)
+    def backward(self, which, mb):
+        self._check(self.lib.sdxp_backward(self.h, which, mb, _stream_ptr(self.device)))
+
+    def apply(self, which, kl=float("nan")):
+        self._check(self.lib.sdxp_apply(self.h, which, C.c_float(kl), _stream_ptr(self.device)))
+
+    def kl_view(self):
+        """1-element f32 view of SdxpCtrl.last_kl inside the STATS tensor (for the scalar KL all-reduce, PS:308-310)"""
+        off = Ctrl.last_kl.offset // 4
+        return self.t["STATS"][off:off + 1]
 
     def ctrl(self):
         raw = self.t["STATS"].cpu().numpy().tobytes()

@@ -1,0 +1,78 @@
+"""world_size-2 `gloo` test (CPU) of the multi-rank orchestration in seqdex_amd/a2c_agent.py: per optimiser step the
+flat gradients and the scalar KL are summed over ranks between sdxp_backward and sdxp_apply, parameters are broadcast
+from rank 0 at start, and envs/seed shard as rank-local (seed + rank).  The HIP calls are replaced by a CPU stand-in
+with the same method names (the kernels themselves are covered by -m gpu tests)."""
+import os
+import socket
+
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+
+class FakePPO:
+    """CPU stand-in for seqdex_amd.ppo.SdxPPO: 'gradient' of a rank = (rank+1) * (step+1); apply does SGD-like update
+    with the averaged gradient so that every rank must end with identical parameters iff the all-reduce happened."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.step = rank, world, 0
+        self.t = {"AC_GRADS": torch.zeros(10), "CV_GRADS": torch.zeros(6), "AC_PARAMS": torch.full((10,), float(rank)),
+                  "CV_PARAMS": torch.full((6,), float(rank))}
+        self._kl = torch.zeros(1)
+        self.applied = []
+
+    def kl_view(self):
+        return self._kl
+
+    def backward(self, which, mb):
+        if mb < 0:
+            self.step = 0
+            return
+        self.t["AC_GRADS"].fill_((self.rank + 1.0) * (self.step + 1))
+        self.t["CV_GRADS"].fill_((self.rank + 1.0) * 2.0)
+        self._kl.fill_(0.01 * (self.rank + 1))
+
+    def apply(self, which, kl=float("nan")):
+        g = self.t["CV_GRADS" if which else "AC_GRADS"] / self.world
+        self.t["CV_PARAMS" if which else "AC_PARAMS"].sub_(0.1 * g)
+        if which == 0:
+            self.applied.append((float(g[0]), float(self._kl[0]) / self.world))
+            self.step += 1
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from seqdex_amd.a2c_agent import A2CAgent
+    ag = A2CAgent.__new__(A2CAgent)          # orchestration only: no GPU objects
+    ag.ppo = FakePPO(rank, world)
+    ag.mini_epochs_num, ag.batch_size, ag.minibatch_size = 2, 12, 4
+    ag.rank, ag.rank_size, ag.multi_gpu = rank, world, True
+    ag._broadcast_parameters()
+    p0 = ag.ppo.t["AC_PARAMS"].clone()
+    ag._update_multi_gpu()
+    out.put((rank, p0.tolist(), ag.ppo.t["AC_PARAMS"].tolist(), ag.ppo.t["CV_PARAMS"].tolist(), ag.ppo.applied))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_and_broadcast_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, p0a, a0, c0, ap0), (r1, p0b, a1, c1, ap1) = res
+    assert p0a == p0b == [0.0] * 10                      # parameters broadcast from rank 0
+    assert a0 == a1 and c0 == c1                         # identical after the all-reduced updates
+    # 6 optimiser steps; averaged gradient of step k = (1+2)/2 * (k+1); averaged KL = 0.015
+    assert len(ap0) == 6
+    for k, (g, kl) in enumerate(ap0):
+        assert abs(g - 1.5 * (k + 1)) < 1e-6 and abs(kl - 0.015) < 1e-7
+    assert abs(a0[0] - (0.0 - 0.1 * 1.5 * sum(range(1, 7)))) < 1e-5

@@ -123,3 +123,35 @@ def test_update_matches_autograd_adam(adaptive):
         np.testing.assert_allclose(agent.t["MB_MUS"].cpu().numpy().reshape(-1, 23), ds["mus"].numpy(), rtol=1e-3, atol=1e-3)
     finally:
         agent.close()
+
+
+def test_explicit_gradient_path_equals_fused_path():
+    """world_size 1: sdxp_backward / sdxp_apply (materialised flat gradients, the multi-rank path minus the all-reduce)
+    must land on the same parameters as the fused rank-MB lazy-Adam path of sdxp_update."""
+    n = 16
+    a1, orc = make_pair(n, seed=5)
+    a2, _ = make_pair(n, seed=5)
+    try:
+        np.testing.assert_array_equal(a1.t["AC_PARAMS"].cpu().numpy(), a2.t["AC_PARAMS"].cpu().numpy())
+        for ag in (a1, a2):
+            g = torch.Generator().manual_seed(4)
+            rollout(ag, orc, n, g)
+        a1.update()
+        a2.backward(0, -1)
+        for ep in range(5):
+            for mb in range(n * 8 // 4):
+                a2.backward(0, mb)
+                a2.apply(0)
+                a2.apply(1)
+        torch.cuda.synchronize()
+        c1, c2 = a1.ctrl(), a2.ctrl()
+        assert c1.ac_t == c2.ac_t == 160 and c2.ac_pending == 0
+        np.testing.assert_allclose(c1.ac_lr, c2.ac_lr, rtol=1e-6)
+        d_ac = np.abs(a1.t["AC_PARAMS"].cpu().numpy() - a2.t["AC_PARAMS"].cpu().numpy()).max()
+        d_cv = np.abs(a1.t["CV_PARAMS"].cpu().numpy() - a2.t["CV_PARAMS"].cpu().numpy()).max()
+        assert d_ac < 2e-5 and d_cv < 5e-5, (d_ac, d_cv)
+        # the flat gradient buffer holds the last minibatch's gradient: finite and non-zero
+        g_ac = a2.t["AC_GRADS"].cpu().numpy()
+        assert np.isfinite(g_ac).all() and np.abs(g_ac).max() > 0
+    finally:
+        a1.close(); a2.close()

@@ -1,0 +1,127 @@
+"""Known-answer tests that pin oracle/physics_oracle.c (the plain-C definition of the physics step; PARITY UNPINNED vs
+PhysX).  Closed forms: free fall, resting contact, implicit-PD step response, FK/Jacobian by finite differences,
+joint-space inertia = kinetic-energy Hessian, momentum exchange of a 2-body impact."""
+import numpy as np
+import pytest
+
+from oracle import physics_oracle as po
+
+
+@pytest.fixture(scope="module")
+def desc(scene):
+    return scene.to_desc()
+
+
+def base_state(scene, n=1):
+    root = np.zeros((n, 142, 13), np.float32)
+    root[:, :, 6] = 1
+    # park every free brick far apart in the air (no contacts), fixed bricks at their places
+    for i in range(72):
+        root[:, 9 + i, 0:3] = [5.0 + 0.3 * (i % 9), 5.0 + 0.3 * (i // 9), 3.0]
+    for i, fb in enumerate(scene.raw["fixed_bricks"]):
+        root[:, 81 + i, 0:3] = fb["pos"]
+    lo, hi = scene.lower, scene.upper
+    pose = np.concatenate([np.array(scene.arm_prepare_pose, np.float32), 0.5 * (lo[7:] + hi[7:])]).astype(np.float32)
+    dof = np.zeros((n, 23, 2), np.float32)
+    dof[:, :, 0] = pose
+    return root, dof, np.tile(pose, (n, 1)).astype(np.float32)
+
+
+def test_free_fall_is_semi_implicit_euler(scene, desc):
+    root, dof, tg = base_state(scene)
+    z0 = root[0, 9, 2]
+    for k in range(1, 4):
+        po.simulate(desc, root, dof, tg)
+        h, g, m = 1 / 120.0, -9.81, 2 * k
+        np.testing.assert_allclose(root[0, 9, 9], m * h * g, rtol=1e-5)
+        np.testing.assert_allclose(root[0, 9, 2] - z0, h * h * g * m * (m + 1) / 2, rtol=2e-4)
+    assert abs(root[0, 9, 7]) < 1e-7 and abs(root[0, 9, 10]) < 1e-7
+
+
+def test_brick_rests_on_floor(scene, desc):
+    root, dof, tg = base_state(scene)
+    t0 = scene.brick_types[0]
+    floor_top = scene.statics[6]["center"][2] + scene.statics[6]["half"][2]
+    rest_z = floor_top + t0["half"][2] - t0["center"][2]
+    root[0, 9, 0:3] = [0.25, 0.19, rest_z + 0.004]
+    for _ in range(120):
+        rb, contact, jac, nc = po.simulate(desc, root, dof, tg)
+    assert abs(root[0, 9, 2] - rest_z) < 1.5e-3                      # penetration well below contact_offset
+    assert np.linalg.norm(root[0, 9, 7:13]) < 5e-3                   # at rest
+    assert abs(root[0, 9, 0] - 0.25) < 2e-3 and abs(root[0, 9, 1] - 0.19) < 2e-3   # no drift
+
+
+def test_implicit_pd_step_response(scene, desc):
+    """fingers-only target step: monotone, no overshoot beyond 5%, settles to the target; arm holds still."""
+    root, dof, tg = base_state(scene)
+    tg2 = tg.copy()
+    tg2[0, 8] += 0.4
+    q = []
+    for _ in range(60):
+        po.simulate(desc, root, dof, tg2)
+        q.append(dof[0, 8, 0])
+    q = np.array(q)
+    assert abs(q[-1] - tg2[0, 8]) < 2e-3
+    assert q.max() < tg2[0, 8] + 0.05 * 0.4
+    assert np.abs(dof[0, :7, 0] - tg[0, :7]).max() < 2e-3
+
+
+def test_fk_jacobian_finite_difference(scene, desc):
+    rng = np.random.default_rng(0)
+    lo, hi = scene.lower, scene.upper
+    q = (lo + (hi - lo) * rng.uniform(0.2, 0.8, 23)).astype(np.float32)
+    dof = np.zeros((1, 23, 2), np.float32)
+    dof[0, :, 0] = q
+    rb0, jac = po.kinematics(desc, dof)
+    eps = 1e-3
+    for j in range(7):
+        d = dof.copy(); d[0, j, 0] += eps
+        rbp, _ = po.kinematics(desc, d)
+        d[0, j, 0] -= 2 * eps
+        rbm, _ = po.kinematics(desc, d)
+        lin = (rbp[0, 7, 0:3] - rbm[0, 7, 0:3]) / (2 * eps)
+        np.testing.assert_allclose(jac[0, 0:3, j], lin, atol=2e-3)
+    # link velocities are J qd
+    qd = rng.normal(size=23).astype(np.float32)
+    dof[0, :, 1] = qd
+    rb, jac = po.kinematics(desc, dof)
+    np.testing.assert_allclose(rb[0, 7, 7:10], jac[0, 0:3] @ qd[:7], atol=1e-4)
+    np.testing.assert_allclose(rb[0, 7, 10:13], jac[0, 3:6] @ qd[:7], atol=1e-4)
+    # base link is the fixed robot base, fingertip bodies follow the tree
+    np.testing.assert_allclose(rb[0, 0, 0:3], scene.base_pos, atol=1e-6)
+
+
+def test_mass_matrix_is_kinetic_energy_hessian(scene, desc):
+    rng = np.random.default_rng(1)
+    lo, hi = scene.lower, scene.upper
+    q = (lo + (hi - lo) * rng.uniform(0.2, 0.8, 23)).astype(np.float32)
+    H, Hinv = po.mass_matrix(desc, q, 0.0)          # h = 0: pure M(q) (+ armature 0)
+    np.testing.assert_allclose(H, H.T, atol=1e-6)
+    assert np.linalg.eigvalsh(H.astype(np.float64)).min() > 0
+    np.testing.assert_allclose(H.astype(np.float64) @ Hinv.astype(np.float64), np.eye(23), atol=5e-3)
+    # T = 1/2 qd^T M qd must equal sum over links of 1/2 m |v_com|^2 + 1/2 w^T I w
+    qd = rng.normal(size=23).astype(np.float32)
+    dof = np.zeros((1, 23, 2), np.float32); dof[0, :, 0] = q; dof[0, :, 1] = qd
+    rb, _ = po.kinematics(desc, dof)
+    T = 0.0
+    from oracle.task_oracle import quat_apply
+    for k, b in enumerate(scene.raw["robot"]["bodies"]):
+        quat, w, v0, p = rb[0, k, 3:7], rb[0, k, 10:13].astype(np.float64), rb[0, k, 7:10].astype(np.float64), rb[0, k, 0:3]
+        com = quat_apply(quat[None], np.array([b["com"]], np.float32))[0].astype(np.float64)
+        v = v0 + np.cross(w, com)
+        R = np.stack([quat_apply(quat[None], np.eye(3, dtype=np.float32)[i:i + 1])[0] for i in range(3)], 1).astype(np.float64)
+        Iw = R @ np.array(b["inertia"]) @ R.T
+        T += 0.5 * b["mass"] * v @ v + 0.5 * w @ Iw @ w
+    np.testing.assert_allclose(0.5 * qd @ H.astype(np.float64) @ qd, T, rtol=2e-4)
+
+
+def test_contact_generation_face_on_face(scene, desc):
+    root, dof, tg = base_state(scene)
+    t0 = scene.brick_types[0]
+    floor_top = scene.statics[6]["center"][2] + scene.statics[6]["half"][2]
+    root[0, 9, 0:3] = [0.25, 0.19, floor_top + t0["half"][2] - t0["center"][2] - 0.0005]
+    c, total = po.contacts(desc, root[0], dof[0])
+    assert total == 4                                         # the four bottom corners, corners come first
+    np.testing.assert_allclose(c[:, 5:8], [[0, 0, 1]] * 4, atol=1e-6)    # normals out of the floor slab
+    np.testing.assert_allclose(c[:, 8], -0.0005, atol=2e-6)
+    assert set(c[:, 1].astype(int)) == {255} and set(c[:, 0].astype(int)) == {0}
