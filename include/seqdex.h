@@ -251,7 +251,8 @@ typedef enum {
   SDXP_T_STATS = 17,         /* raw control block (struct SdxpCtrl, csrc/sdxp_types.h) as f32 words  */
   SDXP_T_LAST_VALUES = 18,   /* f32 [N]                                                             */
   SDXP_T_AC_ADAM_M = 19, SDXP_T_AC_ADAM_V = 20, SDXP_T_CV_ADAM_M = 21, SDXP_T_CV_ADAM_V = 22,
-  SDXP_T_COUNT = 23
+  SDXP_T_DEBUG = 23,         /* i64 [64]    phase time stamps of the last HEAD / CTRL kernels (profiling aid)      */
+  SDXP_T_COUNT = 24
 } sdxp_tensor_id;
 
 typedef struct sdxp_agent* sdxp_handle;

@@ -39,6 +39,7 @@ struct sdxp_agent {
 };
 
 static thread_local std::string gp_create_err = "";
+static_assert(sizeof(SdxpCtrl) == 2544, "keep seqdex_amd/ppo.py::Ctrl in sync with SdxpCtrl");
 
 #define PCHK(h, call)                                                                                  \
   do {                                                                                                 \
@@ -93,7 +94,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     gp_create_err = "sdxp_create: the fused update needs equal minibatch_size / mini_epochs for actor-critic and central value";
     return SDX_ERR_INVALID;
   }
-  if (cfg->units[2] > 256 || cfg->act_dim > 32 || cfg->obs_dim % 4 || cfg->state_dim % 4) {
+  if (cfg->units[2] != 256 || cfg->units[0] % 4 || cfg->units[1] % 4 || cfg->act_dim > 32 || cfg->obs_dim % 4 || cfg->state_dim % 4) {
     gp_create_err = "sdxp_create: unsupported network shape"; return SDX_ERR_INVALID;
   }
   sdxp_agent* h = new sdxp_agent();
@@ -142,15 +143,14 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   PAL(D.rms_mean, cfg->state_dim); PAL(D.rms_var, cfg->state_dim);
   const int MB = cfg->minibatch;
   for (int net = 0; net < 3; ++net) {
-    const int in0 = net == 2 ? cfg->state_dim : cfg->obs_dim;
-    PAL(D.x[net][0], (size_t)2 * MB * in0);
     for (int l = 0; l < 3; ++l) {
       PAL(D.x[net][l + 1], (size_t)2 * MB * cfg->units[l]);
-      PAL(D.dy[net][l], (size_t)2 * MB * cfg->units[l]);
       if (l < 2) PAL(D.dxacc[net][l], (size_t)2 * MB * cfg->units[l]);
     }
+    PAL(D.dy2[net], (size_t)2 * MB * cfg->units[2]);
   }
-  PAL(D.dhead, (size_t)2 * MB * 34); PAL(D.dlogstd, 64); PAL(D.ctrl, 1); PAL(h->stats_dev, 16);
+  PAL(D.cvx0, R * cfg->state_dim); PAL(D.cvx1, R * cfg->state_dim);
+  PAL(D.dbg, 64); PAL(D.dhead, (size_t)2 * MB * 34); PAL(D.dlogstd, 64); PAL(D.ctrl, 1); PAL(h->stats_dev, 16);
 #undef PAL
   // ---- parameter init
   {
@@ -174,6 +174,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     ctl.ac_lr = cfg->lr; ctl.cv_lr = cfg->cv_lr; ctl.ac_gscale = 1.0f; ctl.cv_gscale = 1.0f;
     ctl.ac_bc1 = ctl.ac_bc2 = ctl.cv_bc1 = ctl.cv_bc2 = 1.0f;
     ctl.rms_count = 1.0;
+    ctl.ac_b1pow = ctl.ac_b2pow = ctl.cv_b1pow = ctl.cv_b2pow = 1.0;
     ctl.world = cfg->world_size > 0 ? cfg->world_size : 1;
     PCHK(h, hipMemcpy(D.ctrl, &ctl, sizeof(ctl), hipMemcpyHostToDevice));
   }
@@ -196,6 +197,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   pset(h, SDXP_T_CV_RMS_VAR, D.rms_var, SDX_F64, {cfg->state_dim});
   pset(h, SDXP_T_STATS, D.ctrl, SDX_F32, {(int64_t)(sizeof(SdxpCtrl) / 4)});
   pset(h, SDXP_T_LAST_VALUES, D.last_values, SDX_F32, {(int64_t)N});
+  pset(h, SDXP_T_DEBUG, D.dbg, SDX_I64, {64});
   pset(h, SDXP_T_AC_ADAM_M, D.ac_m, SDX_F32, {(int64_t)D.off.total});
   pset(h, SDXP_T_AC_ADAM_V, D.ac_v, SDX_F32, {(int64_t)D.off.total});
   pset(h, SDXP_T_CV_ADAM_M, D.cv_m, SDX_F32, {(int64_t)D.coff.total});
@@ -238,7 +240,7 @@ static int plaunch_ok(sdxp_handle h, const char* what) {
 }
 
 __global__ void k_ctrl_begin_epoch(SdxpCtrl* c) {
-  c->mb_index = 0; c->mini_epoch = 0; c->n_mb = 0;
+  c->mb_index = 0; c->mini_epoch = 0; c->n_mb = 0; c->prev_mb = 0; c->prev_mini_epoch = 0;
   c->sum_a_loss = c->sum_c_loss = c->sum_b_loss = c->sum_kl = c->sum_cv_loss = c->sum_entropy = 0.0f;
   for (int i = 0; i < 8; ++i) c->acc[i] = 0.0f;
 }

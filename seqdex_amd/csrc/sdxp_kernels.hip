@@ -16,15 +16,29 @@
 // Per optimiser step: L1, L2, L3, HEAD(+loss +backward of the heads), B3, B2, CTRL = 7 launches for all three nets.
 #include "sdx_common.h"
 #include "sdxp_types.h"
+#include <cstddef>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expm1f(x); }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// wave64 sum with DPP cross-lane moves (VALU rate) instead of ds_bpermute-based __shfl_xor butterflies: quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror give every lane its 16-lane row sum; row_bcast15 / row_bcast31 fold the four rows
+// into lane 63, which is broadcast with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  return v + __builtin_bit_cast(float, r);
 }
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);   // row_mirror
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float lane0(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
 // ------------------------------------------------------------------------------------------------ rollout GEMM
 // Y[M,N] = act(X[M,K] W[N,K]^T + b[N]); act = ELU when elu_flag.  X may be normalised on the fly with (mean, rstd)
@@ -206,25 +220,90 @@ __global__ __launch_bounds__(1024) void k_adv_norm(SdxpDev D) {
 }
 
 // ------------------------------------------------------------------------------------------------ small-minibatch update
-// network ids: 0 actor trunk, 1 critic trunk, 2 central-value trunk.  Per net and layer l (0..2):
-//   x[net][l][par][MB][K_l]   layer input of the minibatch with parity `par` (l=0: obs / normalised states)
-//   dy[net][l][par][MB][N_l]  dLoss/d(pre-activation) of layer l
-// Head layers (mu, value, cv value) live in the HEAD kernel.
+// network ids: 0 actor trunk, 1 critic trunk, 2 central-value trunk.
+//   x[net][l] (l=1..3)   [2][MB][units[l-1]]  ELU output of trunk layer l-1 == input of layer l (l=3: head input),
+//                        double buffered by optimiser-step parity.  Layer-0 inputs are read straight from the dataset
+//                        (obs rows; pre-normalised central-value rows, see k_cv_prenorm).
+//   dy2[net]             [2][MB][units[2]]    dLoss/d(pre-activation) of trunk layer 2 (written by the HEAD kernel)
+//   dxacc[net][l] l=0,1  [2][MB][units[l]]    dLoss/d(OUTPUT) of trunk layer l, accumulated with atomics by the B kernels;
+//                        consumers multiply by elu'(output) on the fly: dY_l = dxacc_l * elu'(x[l+1]).
+#define MAXG 64   // MB*MB for MB <= 8
+#define STAMP(i) do { if (threadIdx.x == 0) D.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
-// L-kernel: lazy Adam of the previous minibatch + forward of the current one for trunk layer `l` of all nets.
-// grid = ceil(total_rows / ROWS_PER_BLOCK); block = 256 threads = 4 waves, wave per weight row.
+__device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }
+
 template <int MB>
+__device__ __forceinline__ const float* layer_input(const SdxpDev& D, const SdxpCtrl* ctl, int net, int l, bool cur) {
+  const int par = ctl->step & 1;
+  if (l > 0) return D.x[net][l] + (size_t)(cur ? par : par ^ 1) * MB * D.units[l - 1];
+  const int mb = cur ? ctl->mb_index : ctl->prev_mb;
+  const int me = cur ? ctl->mini_epoch : ctl->prev_mini_epoch;
+  if (net == 2) return (me == 0 ? D.cvx0 : D.cvx1) + (size_t)mb * MB * D.state_dim;
+  return D.mb_obs + (size_t)mb * MB * D.obs_dim;
+}
+// dLoss/d(pre-activation) of trunk layer l, sample s, neuron n, for step parity `par`
+template <int MB>
+__device__ __forceinline__ float dy_at(const SdxpDev& D, int net, int l, int par, int s, int n) {
+  const int Nl = D.units[l];
+  if (l == 2) return D.dy2[net][(size_t)par * MB * Nl + s * Nl + n];
+  return D.dxacc[net][l][(size_t)par * MB * Nl + s * Nl + n] * elu_grad_from_out(D.x[net][l + 1][(size_t)par * MB * Nl + s * Nl + n]);
+}
+
+// block-wide symmetric Gram of MB vectors of length K living in LDS (v[s*K+k]); result (MB*MB floats) to out (global)
+template <int MB>
+__device__ void block_gram(const float* v, int K, float* out, float* s_scr /*>= MB*MB floats of LDS*/) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float g[MB][MB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) g[a][b] = 0.0f;
+  for (int k = tid; k < K; k += nt) {
+    float x[MB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a) x[a] = v[a * K + k];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) g[a][b] += x[a] * x[b];
+  }
+  if (tid < MB * MB) s_scr[tid] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const float r = wave_sum(g[a][b]);
+      if ((tid & 63) == 0) atomicAdd(&s_scr[a * MB + b], r);
+    }
+  __syncthreads();
+  if (tid < MB * MB) { const int a = tid / MB, b = tid % MB; out[tid] = a >= b ? s_scr[a * MB + b] : s_scr[b * MB + a]; }
+}
+
+// Adam step of one parameter (torch.optim.Adam, betas 0.9/0.999, eps 1e-8, bias corrections bc1/bc2 precomputed)
+__device__ __forceinline__ float adam1(float w, float g, float& m, float& v, float lr_bc1, float isq_bc2) {
+  m = 0.9f * m + 0.1f * g;
+  v = 0.999f * v + 0.001f * g * g;
+  return w - lr_bc1 * m / (sqrtf(v) * isq_bc2 + 1e-8f);
+}
+
+// L-kernel: lazy Adam of the previous minibatch + forward of the current one for trunk layer `l` of all three nets.
+// block = 256 threads = 4 waves; a wave owns RPW consecutive weight rows; lanes run along K with float4 accesses.
+// All global loads of a wave (RPW rows x KI float4 columns x {w,m,v}) are issued before any arithmetic so that the
+// kernel is bandwidth- rather than latency-bound.
+template <int MB, int RPW, int KI>
 __global__ __launch_bounds__(256) void k_layer(SdxpDev D, int l) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float s_scr[MAXG];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const SdxpCtrl* ctl = D.ctrl;
-  const int par = ctl->step & 1;                 // parity of the CURRENT minibatch
+  SdxpCtrl* ctl = D.ctrl;
+  const int par = ctl->step & 1;
   const int Nl = D.units[l];
-  // which net does this block serve?  rows of (actor, critic, cv) are laid out consecutively
-  const int rows_per_block = 4 * D.rows_per_wave;
+  constexpr int rows_per_block = 4 * RPW;
   const int blocks_per_net = (Nl + rows_per_block - 1) / rows_per_block;
   const int net = blockIdx.x / blocks_per_net, blk = blockIdx.x % blocks_per_net;
   const int K = (l == 0) ? (net == 2 ? D.state_dim : D.obs_dim) : D.units[l - 1];
+  const int K4 = K >> 2;
   const bool pend = (net == 2 ? ctl->cv_pending : ctl->ac_pending) != 0;
   float* P = net == 2 ? D.cv : D.ac;
   float* Mo = net == 2 ? D.cv_m : D.ac_m;
@@ -234,77 +313,117 @@ __global__ __launch_bounds__(256) void k_layer(SdxpDev D, int l) {
   const float lr = net == 2 ? ctl->cv_lr_applied : ctl->ac_lr_applied;
   const float gs = net == 2 ? ctl->cv_gscale : ctl->ac_gscale;          // grad clip scale of the pending step
   const float bc1 = net == 2 ? ctl->cv_bc1 : ctl->ac_bc1, bc2 = net == 2 ? ctl->cv_bc2 : ctl->ac_bc2;
+  const float lr_bc1 = lr / bc1, isq_bc2 = 1.0f / sqrtf(bc2);
+  const int n0 = blk * rows_per_block + wave * RPW;
+  // ---- issue this wave's weight / moment loads first
+  float4 w[RPW][KI], m[RPW][KI], v[RPW][KI];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int k4 = lane + 64 * i, n = n0 + r;
+      if (k4 < K4 && n < Nl) {
+        const size_t o = woff + (size_t)n * K;
+        w[r][i] = reinterpret_cast<const float4*>(P + o)[k4];
+        if (pend) { m[r][i] = reinterpret_cast<const float4*>(Mo + o)[k4]; v[r][i] = reinterpret_cast<const float4*>(Vo + o)[k4]; }
+      } else w[r][i] = make_float4(0, 0, 0, 0);
+    }
+  float dyn[RPW][MB], bias[RPW], bm[RPW], bv[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int n = n0 + r;
+    bias[r] = n < Nl ? P[boff + n] : 0.0f;
+    bm[r] = (pend && n < Nl) ? Mo[boff + n] : 0.0f;
+    bv[r] = (pend && n < Nl) ? Vo[boff + n] : 0.0f;
+#pragma unroll
+    for (int s = 0; s < MB; ++s) dyn[r][s] = (pend && n < Nl) ? dy_at<MB>(D, net, l, par ^ 1, s, n) * gs : 0.0f;
+  }
+  // ---- stage the rank-MB factors of the inputs
   float* xc = sm;                 // [MB][K] current input
   float* xp = sm + MB * K;        // [MB][K] previous input (factor of the pending gradient)
-  const float* gx_c = D.x[net][l] + (size_t)par * MB * K;
-  const float* gx_p = D.x[net][l] + (size_t)(par ^ 1) * MB * K;
-  for (int i = tid; i < MB * K; i += 256) { xc[i] = gx_c[i]; xp[i] = gx_p[i]; }
+  {
+    const float4* gc = reinterpret_cast<const float4*>(layer_input<MB>(D, ctl, net, l, true));
+    const float4* gp = reinterpret_cast<const float4*>(layer_input<MB>(D, ctl, net, l, false));
+    float4* c4 = reinterpret_cast<float4*>(xc);
+    float4* p4 = reinterpret_cast<float4*>(xp);
+    for (int i = tid; i < MB * K4; i += 256) { c4[i] = gc[i]; if (pend) p4[i] = gp[i]; }
+  }
   __syncthreads();
-  const float* dyp = D.dy[net][l] + (size_t)(par ^ 1) * MB * Nl;
-  float* xn = D.x[net][l + 1] + (size_t)par * MB * Nl;    // output = next layer's input
-  for (int rr = 0; rr < D.rows_per_wave; ++rr) {
-    const int n = blk * rows_per_block + wave * D.rows_per_wave + rr;
-    if (n >= Nl) break;
-    float dyn[MB];
+  if (blk == 0) block_gram<MB>(xc, K, ctl->gx[net][l], s_scr);   // Gram of this layer's input, for the grad norm
+  float* xn = D.x[net][l + 1] + (size_t)par * MB * Nl;            // output = next layer's input
 #pragma unroll
-    for (int s = 0; s < MB; ++s) dyn[s] = pend ? dyp[s * Nl + n] * gs : 0.0f;
+  for (int r = 0; r < RPW; ++r) {
+    const int n = n0 + r;
     float acc[MB];
 #pragma unroll
     for (int s = 0; s < MB; ++s) acc[s] = 0.0f;
-    float* wrow = P + woff + (size_t)n * K;
-    float* mrow = Mo + woff + (size_t)n * K;
-    float* vrow = Vo + woff + (size_t)n * K;
-    for (int k = lane; k < K; k += 64) {
-      float w = wrow[k];
-      if (pend) {
-        float g = 0.0f;
 #pragma unroll
-        for (int s = 0; s < MB; ++s) g += dyn[s] * xp[s * K + k];
-        const float m = 0.9f * mrow[k] + 0.1f * g;
-        const float v = 0.999f * vrow[k] + 0.001f * g * g;
-        mrow[k] = m; vrow[k] = v;
-        w -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
-        wrow[k] = w;
+    for (int i = 0; i < KI; ++i) {
+      const int k4 = lane + 64 * i;
+      if (k4 < K4 && n < Nl) {
+        float4 ww = w[r][i];
+        if (pend) {
+          float4 mm = m[r][i], vv = v[r][i];
+          float4 g = make_float4(0, 0, 0, 0);
+#pragma unroll
+          for (int s = 0; s < MB; ++s) {
+            const float4 x = reinterpret_cast<const float4*>(xp + s * K)[k4];
+            g.x += dyn[r][s] * x.x; g.y += dyn[r][s] * x.y; g.z += dyn[r][s] * x.z; g.w += dyn[r][s] * x.w;
+          }
+          ww.x = adam1(ww.x, g.x, mm.x, vv.x, lr_bc1, isq_bc2); ww.y = adam1(ww.y, g.y, mm.y, vv.y, lr_bc1, isq_bc2);
+          ww.z = adam1(ww.z, g.z, mm.z, vv.z, lr_bc1, isq_bc2); ww.w = adam1(ww.w, g.w, mm.w, vv.w, lr_bc1, isq_bc2);
+          const size_t o = woff + (size_t)n * K;
+          reinterpret_cast<float4*>(Mo + o)[k4] = mm; reinterpret_cast<float4*>(Vo + o)[k4] = vv;
+          reinterpret_cast<float4*>(P + o)[k4] = ww;
+        }
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          const float4 x = reinterpret_cast<const float4*>(xc + s * K)[k4];
+          acc[s] += ww.x * x.x + ww.y * x.y + ww.z * x.z + ww.w * x.w;
+        }
       }
-#pragma unroll
-      for (int s = 0; s < MB; ++s) acc[s] += w * xc[s * K + k];
     }
-    float bias = P[boff + n];
-    if (pend && lane == 0) {
+    float b = bias[r];
+    if (pend && n < Nl) {
       float g = 0.0f;
 #pragma unroll
-      for (int s = 0; s < MB; ++s) g += dyn[s];
-      const float m = 0.9f * Mo[boff + n] + 0.1f * g;
-      const float v = 0.999f * Vo[boff + n] + 0.001f * g * g;
-      Mo[boff + n] = m; Vo[boff + n] = v;
-      bias -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
-      P[boff + n] = bias;
+      for (int s = 0; s < MB; ++s) g += dyn[r][s];
+      float mm = bm[r], vv = bv[r];
+      b = adam1(b, g, mm, vv, lr_bc1, isq_bc2);
+      if (lane == 0) { Mo[boff + n] = mm; Vo[boff + n] = vv; P[boff + n] = b; }
     }
-    bias = __shfl(bias, 0, 64);
 #pragma unroll
     for (int s = 0; s < MB; ++s) {
-      const float y = wave_sum(acc[s]) + bias;
-      if (lane == 0) xn[s * Nl + n] = elu(y);
+      const float y = wave_sum(acc[s]) + b;
+      if (lane == 0 && n < Nl) xn[s * Nl + n] = elu(y);
     }
   }
 }
 
-// HEAD kernel (one block): lazy Adam of the head parameters, head forward, PPO losses (R7), gradients of the
-// heads' pre-activations, backward through the heads into dY of trunk layer 2, KL + statistics, mu/sigma
-// write-back (dataset.update_mu_sigma, RC:1358).  flush != 0: only the lazy Adam part (end of an epoch).
+// HEAD kernel (one block of 1024 threads): lazy Adam of the head parameters, head forward, PPO losses (R7), gradients
+// of the heads' pre-activations, backward through the heads into dY of trunk layer 2, KL + statistics, mu/sigma
+// write-back (dataset.update_mu_sigma, RC:1358), and the gradient-norm contributions of the heads and of layer 2.
+// flush != 0: only the lazy Adam part (end of an epoch).
 template <int MB>
-__global__ __launch_bounds__(256) void k_head(SdxpDev D, int flush) {
-  __shared__ float s_h[3][MB][256];
-  __shared__ float s_hp[3][MB][256];
-  __shared__ float s_mu[MB][32], s_dmu[MB][32], s_dmu_p[MB][32], s_z[MB][32];
-  __shared__ float s_v[2][MB], s_dv[2][MB], s_dv_p[2][MB], s_gnlp[MB];
-  __shared__ float s_stat[MB][8];
+__global__ __launch_bounds__(1024) void k_head(SdxpDev D, int flush) {
+  __shared__ float s_h[3][MB][256];      // head inputs of the current minibatch
+  __shared__ float s_hp[3][MB][256];     // ... of the previous one (factor of the pending gradient)
+  __shared__ float s_w[26][256];         // head weight rows after the lazy Adam (23 mu rows, critic V, central V)
+  __shared__ float s_dy2[3][MB][256];
+  __shared__ float s_mu[MB][32], s_dmu[MB][32], s_dmu_p[MB][32], s_z[MB][32], s_act[MB][32], s_omu[MB][32], s_osg[MB][32];
+  __shared__ float s_v[2][MB], s_dv[2][MB], s_dv_p[2][MB], s_gnlp[MB], s_ls[32];
+  __shared__ float s_stat[MB][8], s_gh[3][MAXG], s_gd[3][MAXG], s_n2[3], s_n2p[3], s_dls[32], s_term[3 * MAXG], s_bterm[32];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  SdxpCtrl* ctl = D.ctrl;
+  __shared__ SdxpCtrl s_ctl;               // read-mostly snapshot of the control block
+  SdxpCtrl* gctl = D.ctrl;
+  for (int i = tid; i < (int)(sizeof(SdxpCtrl) / 4); i += 1024) reinterpret_cast<uint32_t*>(&s_ctl)[i] = reinterpret_cast<const uint32_t*>(gctl)[i];
+  __syncthreads();
+  const SdxpCtrl* ctl = &s_ctl;
+  STAMP(0);
   const int par = ctl->step & 1, U = D.units[2], A = D.act_dim;
-  const int mb = ctl->mb_index;
+  const size_t r0 = (size_t)ctl->mb_index * MB;   // first dataset row of this minibatch: contiguous, unshuffled (App. C)
   const bool apend = ctl->ac_pending != 0, cpend = ctl->cv_pending != 0;
-  for (int i = tid; i < 3 * MB * U; i += 256) {
+  for (int i = tid; i < 3 * MB * U; i += 1024) {
     const int net = i / (MB * U), r = i % (MB * U);
     s_h[net][r / U][r % U] = D.x[net][3][(size_t)par * MB * U + r];
     s_hp[net][r / U][r % U] = D.x[net][3][(size_t)(par ^ 1) * MB * U + r];
@@ -312,105 +431,145 @@ __global__ __launch_bounds__(256) void k_head(SdxpDev D, int flush) {
   if (tid < MB * 32) {
     const int s = tid / 32, a = tid % 32;
     s_dmu_p[s][a] = (a < A) ? D.dhead[(size_t)(par ^ 1) * MB * 34 + s * 34 + a] : 0.0f;
+    s_act[s][a] = (a < A) ? D.mb_actions[(r0 + s) * A + a] : 0.0f;
+    s_omu[s][a] = (a < A) ? D.mb_mus[(r0 + s) * A + a] : 0.0f;
+    s_osg[s][a] = (a < A) ? D.mb_sigmas[(r0 + s) * A + a] : 1.0f;
   }
   if (tid < 2 * MB) s_dv_p[tid / MB][tid % MB] = D.dhead[(size_t)(par ^ 1) * MB * 34 + (tid % MB) * 34 + 32 + tid / MB];
+  if (tid < 3) s_n2[tid] = 0.0f;
   __syncthreads();
-  // ---- lazy Adam + forward of the head rows: rows 0..A-1 = mu, row A = critic value, row A+1 = central value
-  for (int row = wave; row < A + 2; row += 4) {
-    const int net = row < A ? 0 : (row == A ? 1 : 2);
-    float* P = net == 2 ? D.cv : D.ac;
-    float* Mo = net == 2 ? D.cv_m : D.ac_m;
-    float* Vo = net == 2 ? D.cv_v : D.ac_v;
-    const size_t woff = row < A ? D.off.mu_w + (size_t)row * U : (row == A ? D.off.v_w : D.coff.v_w);
-    const size_t boff = row < A ? D.off.mu_b + row : (row == A ? D.off.v_b : D.coff.v_b);
-    const bool pend = net == 2 ? cpend : apend;
-    const float lr = net == 2 ? ctl->cv_lr_applied : ctl->ac_lr_applied;
-    const float gs = net == 2 ? ctl->cv_gscale : ctl->ac_gscale;
-    const float bc1 = net == 2 ? ctl->cv_bc1 : ctl->ac_bc1, bc2 = net == 2 ? ctl->cv_bc2 : ctl->ac_bc2;
-    float dyn[MB], acc[MB];
+  STAMP(1);
+  // ---- lazy Adam + forward of the head rows: rows 0..A-1 = mu, row A = critic value, row A+1 = central value.
+  // U = 256: one float4 per lane and row; both rows of a wave are loaded before any arithmetic.
+  {
+    const float ac_lr_bc1 = ctl->ac_lr_applied / ctl->ac_bc1, ac_isq = 1.0f / sqrtf(ctl->ac_bc2), ac_gs = ctl->ac_gscale;
+    const float cv_lr_bc1 = ctl->cv_lr_applied / ctl->cv_bc1, cv_isq = 1.0f / sqrtf(ctl->cv_bc2), cv_gs = ctl->cv_gscale;
+    float4 w[2], m[2], v[2];
+    float bias[2], bm[2], bv[2];
 #pragma unroll
-    for (int s = 0; s < MB; ++s) {
-      dyn[s] = pend ? gs * (row < A ? s_dmu_p[s][row] : s_dv_p[row - A][s]) : 0.0f;
-      acc[s] = 0.0f;
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave + 16 * j;
+      w[j] = make_float4(0, 0, 0, 0); m[j] = w[j]; v[j] = w[j]; bias[j] = bm[j] = bv[j] = 0.0f;
+      if (row < A + 2) {
+        const int net = row < A ? 0 : (row == A ? 1 : 2);
+        const float* P = net == 2 ? D.cv : D.ac;
+        const float* Mo = net == 2 ? D.cv_m : D.ac_m;
+        const float* Vo = net == 2 ? D.cv_v : D.ac_v;
+        const size_t woff = row < A ? D.off.mu_w + (size_t)row * U : (row == A ? D.off.v_w : D.coff.v_w);
+        const size_t boff = row < A ? D.off.mu_b + row : (row == A ? D.off.v_b : D.coff.v_b);
+        const bool pend = net == 2 ? cpend : apend;
+        w[j] = reinterpret_cast<const float4*>(P + woff)[lane];
+        bias[j] = P[boff];
+        if (pend) {
+          m[j] = reinterpret_cast<const float4*>(Mo + woff)[lane]; v[j] = reinterpret_cast<const float4*>(Vo + woff)[lane];
+          bm[j] = Mo[boff]; bv[j] = Vo[boff];
+        }
+      }
     }
-    for (int k = lane; k < U; k += 64) {
-      float w = P[woff + k];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave + 16 * j;
+      if (row >= A + 2) continue;
+      const int net = row < A ? 0 : (row == A ? 1 : 2);
+      float* P = net == 2 ? D.cv : D.ac;
+      float* Mo = net == 2 ? D.cv_m : D.ac_m;
+      float* Vo = net == 2 ? D.cv_v : D.ac_v;
+      const size_t woff = row < A ? D.off.mu_w + (size_t)row * U : (row == A ? D.off.v_w : D.coff.v_w);
+      const size_t boff = row < A ? D.off.mu_b + row : (row == A ? D.off.v_b : D.coff.v_b);
+      const bool pend = net == 2 ? cpend : apend;
+      const float lr_bc1 = net == 2 ? cv_lr_bc1 : ac_lr_bc1, isq_bc2 = net == 2 ? cv_isq : ac_isq;
+      const float gs = net == 2 ? cv_gs : ac_gs;
+      float dyn[MB], acc[MB];
+#pragma unroll
+      for (int s = 0; s < MB; ++s) dyn[s] = pend ? gs * (row < A ? s_dmu_p[s][row] : s_dv_p[row - A][s]) : 0.0f;
+      float4 ww = w[j];
+      const int k = 4 * lane;
+      if (pend) {
+        float4 g = make_float4(0, 0, 0, 0), mm = m[j], vv = v[j];
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          g.x += dyn[s] * s_hp[net][s][k]; g.y += dyn[s] * s_hp[net][s][k + 1];
+          g.z += dyn[s] * s_hp[net][s][k + 2]; g.w += dyn[s] * s_hp[net][s][k + 3];
+        }
+        ww.x = adam1(ww.x, g.x, mm.x, vv.x, lr_bc1, isq_bc2); ww.y = adam1(ww.y, g.y, mm.y, vv.y, lr_bc1, isq_bc2);
+        ww.z = adam1(ww.z, g.z, mm.z, vv.z, lr_bc1, isq_bc2); ww.w = adam1(ww.w, g.w, mm.w, vv.w, lr_bc1, isq_bc2);
+        reinterpret_cast<float4*>(Mo + woff)[lane] = mm; reinterpret_cast<float4*>(Vo + woff)[lane] = vv;
+        reinterpret_cast<float4*>(P + woff)[lane] = ww;
+      }
+      s_w[row][k] = ww.x; s_w[row][k + 1] = ww.y; s_w[row][k + 2] = ww.z; s_w[row][k + 3] = ww.w;
+#pragma unroll
+      for (int s = 0; s < MB; ++s)
+        acc[s] = ww.x * s_h[net][s][k] + ww.y * s_h[net][s][k + 1] + ww.z * s_h[net][s][k + 2] + ww.w * s_h[net][s][k + 3];
+      float b = bias[j];
       if (pend) {
         float g = 0.0f;
 #pragma unroll
-        for (int s = 0; s < MB; ++s) g += dyn[s] * s_hp[net][s][k];
-        const float m = 0.9f * Mo[woff + k] + 0.1f * g;
-        const float v = 0.999f * Vo[woff + k] + 0.001f * g * g;
-        Mo[woff + k] = m; Vo[woff + k] = v;
-        w -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
-        P[woff + k] = w;
+        for (int s = 0; s < MB; ++s) g += dyn[s];
+        float mm = bm[j], vv = bv[j];
+        b = adam1(b, g, mm, vv, lr_bc1, isq_bc2);
+        if (lane == 0) { Mo[boff] = mm; Vo[boff] = vv; P[boff] = b; }
       }
 #pragma unroll
-      for (int s = 0; s < MB; ++s) acc[s] += w * s_h[net][s][k];
-    }
-    float bias = P[boff];
-    if (pend && lane == 0) {
-      float g = 0.0f;
-#pragma unroll
-      for (int s = 0; s < MB; ++s) g += dyn[s];
-      const float m = 0.9f * Mo[boff] + 0.1f * g;
-      const float v = 0.999f * Vo[boff] + 0.001f * g * g;
-      Mo[boff] = m; Vo[boff] = v;
-      bias -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
-      P[boff] = bias;
-    }
-    bias = __shfl(bias, 0, 64);
-#pragma unroll
-    for (int s = 0; s < MB; ++s) {
-      const float y = wave_sum(acc[s]) + bias;
-      if (lane == 0) { if (row < A) s_mu[s][row] = y; else s_v[row - A][s] = y; }
+      for (int s = 0; s < MB; ++s) {
+        const float y = wave_sum(acc[s]) + b;
+        if (lane == 0) { if (row < A) s_mu[s][row] = y; else s_v[row - A][s] = y; }
+      }
     }
   }
-  if (tid < A && apend) {   // logstd parameter (fixed_sigma: a free Parameter, YG:18-21)
-    const float g = D.dlogstd[(size_t)(par ^ 1) * 32 + tid] * ctl->ac_gscale;
-    const size_t o = D.off.logstd + tid;
-    const float m = 0.9f * D.ac_m[o] + 0.1f * g;
-    const float v = 0.999f * D.ac_v[o] + 0.001f * g * g;
-    D.ac_m[o] = m; D.ac_v[o] = v;
-    D.ac[o] -= (ctl->ac_lr_applied / ctl->ac_bc1) * m / (sqrtf(v) / sqrtf(ctl->ac_bc2) + 1e-8f);
+  if (tid >= 512 && tid < 512 + 32) {   // logstd parameter (fixed_sigma: a free Parameter, YG:18-21)
+    const int a = tid - 512;
+    float ls = 0.0f;
+    if (a < A) {
+      const size_t o = D.off.logstd + a;
+      ls = D.ac[o];
+      if (apend) {
+        const float g = D.dlogstd[(size_t)(par ^ 1) * 32 + a] * ctl->ac_gscale;
+        float m = D.ac_m[o], v = D.ac_v[o];
+        ls = adam1(ls, g, m, v, ctl->ac_lr_applied / ctl->ac_bc1, 1.0f / sqrtf(ctl->ac_bc2));
+        D.ac_m[o] = m; D.ac_v[o] = v; D.ac[o] = ls;
+      }
+    }
+    s_ls[a] = ls;
   }
   __syncthreads();
   if (flush) {
-    if (tid == 0) { ctl->ac_pending = 0; ctl->cv_pending = 0; }
+    if (tid == 0) { gctl->ac_pending = 0; gctl->cv_pending = 0; }
     return;
   }
-  const size_t r0 = (size_t)mb * MB;   // first dataset row of this minibatch: contiguous, unshuffled (App. C)
   const float invM = 1.0f / (float)MB;
-  // ---- per (sample, action) terms
+  STAMP(2);
   if (tid < MB * 32) {
     const int s = tid / 32, a = tid % 32;
-    float z = 0.0f;
-    if (a < A) {
-      const float sg = expf(D.ac[D.off.logstd + a]);
-      z = (D.mb_actions[(r0 + s) * A + a] - s_mu[s][a]) / sg;
-    }
-    s_z[s][a] = z;
+    s_z[s][a] = (a < A) ? (s_act[s][a] - s_mu[s][a]) / expf(s_ls[a]) : 0.0f;
   }
   __syncthreads();
-  // ---- per-sample scalars: one thread per sample (A = 23 terms each)
-  if (tid < MB) {
-    const int s = tid;
-    float nlp = 0.5f * 1.8378770664093453f * (float)A, kl = 0.0f, bl = 0.0f, ent = 0.0f;
-    for (int a = 0; a < A; ++a) {
-      const float ls = D.ac[D.off.logstd + a], sg = expf(ls), mu = s_mu[s][a];
-      nlp += 0.5f * s_z[s][a] * s_z[s][a] + ls;                                                  // RC:2114-2126
-      const float omu = D.mb_mus[(r0 + s) * A + a], osg = D.mb_sigmas[(r0 + s) * A + a];
-      kl += logf(osg / sg + 1e-5f) + (sg * sg + (omu - mu) * (omu - mu)) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
+  // ---- per-sample scalars: lanes (s, a) reduce over the 32-lane half-wave of sample s
+  float r_nlp = 0.0f, r_kl = 0.0f, r_bl = 0.0f, r_ent = 0.0f;
+  if (tid < MB * 32) {
+    const int s = tid / 32, a = tid % 32;
+    if (a < A) {
+      const float ls = s_ls[a], sg = expf(ls), mu = s_mu[s][a];
+      r_nlp = 0.5f * s_z[s][a] * s_z[s][a] + ls;                                                  // RC:2114-2126
+      const float omu = s_omu[s][a], osg = s_osg[s][a];
+      r_kl = logf(osg / sg + 1e-5f) + (sg * sg + (omu - mu) * (omu - mu)) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
       const float hi = fmaxf(mu - 1.1f, 0.0f), lo = fminf(mu + 1.1f, 0.0f);
-      bl += hi * hi + lo * lo;
-      ent += 0.5f + 0.5f * 1.8378770664093453f + ls;
+      r_bl = hi * hi + lo * lo;
+      r_ent = 0.5f + 0.5f * 1.8378770664093453f + ls;
     }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      r_nlp += __shfl_xor(r_nlp, o, 64); r_kl += __shfl_xor(r_kl, o, 64);
+      r_bl += __shfl_xor(r_bl, o, 64); r_ent += __shfl_xor(r_ent, o, 64);
+    }
+  }
+  if (tid < MB * 32 && (tid % 32) == 0) {
+    const int s = tid / 32;
+    const float nlp = r_nlp + 0.5f * 1.8378770664093453f * (float)A, kl = r_kl, bl = r_bl, ent = r_ent;
     const float adv = D.adv[r0 + s];
     const float ratio = expf(D.mb_neglogp[r0 + s] - nlp);
     const float L1 = -adv * ratio, L2 = -adv * clampf(ratio, 1.0f - D.e_clip, 1.0f + D.e_clip);   // RC:1813
-    // d max(L1,L2)/d nlp: L1' = adv*ratio; L2' = adv*ratio inside the clip range, else 0; ties share the same value
     const bool inr = ratio >= 1.0f - D.e_clip && ratio <= 1.0f + D.e_clip;
-    s_gnlp[s] = (L1 > L2 || inr) ? adv * ratio : 0.0f;
+    s_gnlp[s] = (L1 > L2 || inr) ? adv * ratio : 0.0f;     // d max(L1,L2)/d nlp (L2 is constant outside the clip range)
     const float R = D.returns[r0 + s], vo = D.mb_values[r0 + s];
     float closs[2];
     for (int j = 0; j < 2; ++j) {                                                                 // RC:1818-1822
@@ -421,8 +580,7 @@ __global__ __launch_bounds__(256) void k_head(SdxpDev D, int flush) {
       if (D.clip_value) {
         closs[j] = fmaxf(c1, c2);
         const bool inv = fabsf(v - vo) <= D.e_clip;
-        d = (c1 > c2 || inv) ? 2.0f * (v - R) : 0.0f;   // outside the clip range v_clipped is constant
-        if (c2 > c1 && inv) d = 2.0f * (vc - R);
+        d = (c1 > c2 || inv) ? 2.0f * (v - R) : 0.0f;      // outside the clip range v_clipped is constant
       } else { closs[j] = c1; d = 2.0f * (v - R); }
       s_dv[j][s] = (j == 0 ? 0.5f * D.critic_coef : 1.0f) * d * invM;
     }
@@ -434,7 +592,7 @@ __global__ __launch_bounds__(256) void k_head(SdxpDev D, int flush) {
     const int s = tid / 32, a = tid % 32;
     float dmu = 0.0f;
     if (a < A) {
-      const float ls = D.ac[D.off.logstd + a], sg = expf(ls), mu = s_mu[s][a];
+      const float sg = expf(s_ls[a]), mu = s_mu[s][a];
       const float hi = fmaxf(mu - 1.1f, 0.0f), lo = fminf(mu + 1.1f, 0.0f);
       dmu = s_gnlp[s] * (-(s_z[s][a] / sg)) * invM + D.bounds_coef * (2.0f * hi + 2.0f * lo) * invM;
       D.mb_mus[(r0 + s) * A + a] = mu;                                                            // RC:1358
@@ -444,36 +602,98 @@ __global__ __launch_bounds__(256) void k_head(SdxpDev D, int flush) {
     D.dhead[(size_t)par * MB * 34 + s * 34 + a] = dmu;
     if (a < 2) D.dhead[(size_t)par * MB * 34 + s * 34 + 32 + a] = s_dv[a][s];
   }
-  if (tid < A) {
-    float g = 0.0f;
-    for (int s = 0; s < MB; ++s) g += s_gnlp[s] * (1.0f - s_z[s][tid] * s_z[s][tid]) * invM;
-    D.dlogstd[(size_t)par * 32 + tid] = g;
+  if (tid >= 512 && tid < 512 + A) {
+    const int a = tid - 512;
+    float dls = 0.0f;
+    for (int s = 0; s < MB; ++s) dls += s_gnlp[s] * (1.0f - s_z[s][a] * s_z[s][a]) * invM;
+    D.dlogstd[(size_t)par * 32 + a] = dls;
+    s_dls[a] = dls;
   }
   if (tid == 0) {
     for (int j = 1; j <= 6; ++j) {
       float t = 0.0f;
       for (int s = 0; s < MB; ++s) t += s_stat[s][j];
-      ctl->acc[j] = t;
+      gctl->acc[j] = t;
     }
   }
   __syncthreads();
+  STAMP(3);
   // ---- backward through the heads: dY2[net][s][k] = (sum_rows dhead * W_head[row][k]) * elu'(h[net][s][k])
-  for (int i = tid; i < 3 * MB * U; i += 256) {
+  for (int i = tid; i < 3 * MB * U; i += 1024) {
     const int net = i / (MB * U), s = (i / U) % MB, k = i % U;
     float d = 0.0f;
-    if (net == 0) { for (int a = 0; a < A; ++a) d += s_dmu[s][a] * D.ac[D.off.mu_w + (size_t)a * U + k]; }
-    else if (net == 1) d = s_dv[0][s] * D.ac[D.off.v_w + k];
-    else d = s_dv[1][s] * D.cv[D.coff.v_w + k];
-    const float h = s_h[net][s][k];
-    D.dy[net][2][(size_t)par * MB * U + s * U + k] = d * (h > 0.0f ? 1.0f : h + 1.0f);
+    if (net == 0) { for (int a = 0; a < A; ++a) d += s_dmu[s][a] * s_w[a][k]; }
+    else d = s_dv[net - 1][s] * s_w[A + net - 1][k];
+    const float v = d * elu_grad_from_out(s_h[net][s][k]);
+    s_dy2[net][s][k] = v;
+    D.dy2[net][(size_t)par * MB * U + s * U + k] = v;
   }
+  __syncthreads();
+  STAMP(4);
+  // ---- gradient-norm pieces available here: heads (dhead x h) and trunk layer 2 (dy2 x x[net][2], Gram from k_layer).
+  // Six Gram matrices (h and dy2 of the three nets, K = 256): one wave each, 4 elements per lane, DPP reductions,
+  // results written by lane 0 (no atomics).  Waves 6..8 do the bias-gradient norms of layer 2.
+  if (wave < 6) {
+    const int net = wave % 3;
+    const float* v = wave < 3 ? &s_h[net][0][0] : &s_dy2[net][0][0];
+    float* out = wave < 3 ? s_gh[net] : s_gd[net];
+    float x[MB][4];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[a][j] = v[a * 256 + lane + 64 * j];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 <= a; ++b2) {
+        const float r = wave_sum(x[a][0] * x[b2][0] + x[a][1] * x[b2][1] + x[a][2] * x[b2][2] + x[a][3] * x[b2][3]);
+        if (lane == 0) { out[a * MB + b2] = r; out[b2 * MB + a] = r; }
+      }
+  } else if (wave < 9) {
+    const int net = wave - 6;
+    float bs = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sb = 0.0f;
+#pragma unroll
+      for (int s2 = 0; s2 < MB; ++s2) sb += s_dy2[net][s2][lane + 64 * j];
+      bs += sb * sb;
+    }
+    bs = wave_sum(bs);
+    if (lane == 0) s_n2[net] = bs;
+  }
+  __syncthreads();
+  // n2 of heads + layer 2: thread (net, a, b) forms one term, 3 threads add them up
+  if (tid < 3 * MB * MB) {
+    const int net = tid / (MB * MB), a = (tid / MB) % MB, b2 = tid % MB;
+    float dd = 0.0f;
+    if (net == 0) { for (int j = 0; j < A; ++j) dd += s_dmu[a][j] * s_dmu[b2][j]; }
+    else dd = s_dv[net - 1][a] * s_dv[net - 1][b2];
+    s_term[tid] = dd * s_gh[net][a * MB + b2] + s_gd[net][a * MB + b2] * ctl->gx[net][2][a * MB + b2];
+  } else if (tid >= 256 && tid < 256 + 32) {   // head bias gradients (mu biases, the two value biases) and logstd
+    const int j = tid - 256;
+    float t = 0.0f;
+    if (j < A) { float sb = 0; for (int a = 0; a < MB; ++a) sb += s_dmu[a][j]; t = sb * sb + s_dls[j] * s_dls[j]; }
+    s_bterm[j] = t;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const int net = tid;
+    float n2 = 0.0f;
+    for (int i = 0; i < MB * MB; ++i) n2 += s_term[net * MB * MB + i];
+    if (net == 0) { for (int j = 0; j < A; ++j) n2 += s_bterm[j]; }
+    else { float sb = 0; for (int a = 0; a < MB; ++a) sb += s_dv[net - 1][a]; n2 += sb * sb; }
+    s_n2p[net] = n2;
+  }
+  __syncthreads();
+  if (tid < 3) gctl->n2_part[tid] = s_n2p[tid] + s_n2[tid];
+  STAMP(5);
 }
 
-// B-kernel: backward of trunk layer l+1 into layer l of all nets:
-//   dY_l[s][k] = (sum_n dY_{l+1}[s][n] W_{l+1}[n][k]) * elu'(h_l[s][k]),  thread per k, block per (net, k-chunk, n-split)
-// partial sums over the n-splits are accumulated with atomics into a zeroed buffer; elu' is applied by the consumer.
+// B-kernel: backward of trunk layer l+1 into dxacc of layer l for all nets:
+//   dxacc_l[s][k] += sum_{n in split} dY_{l+1}[s][n] W_{l+1}[n][k]; thread per k, block per (net, k-chunk, n-split).
 template <int MB>
-__global__ __launch_bounds__(256) void k_back(SdxpDev D, int l) {   // l = layer whose dY is produced (1 or 0)
+__global__ __launch_bounds__(256) void k_back(SdxpDev D, int l) {   // l = layer whose output gradient is produced (1 or 0)
   const SdxpCtrl* ctl = D.ctrl;
   const int par = ctl->step & 1;
   const int Nn = D.units[l + 1], K = D.units[l];
@@ -481,23 +701,22 @@ __global__ __launch_bounds__(256) void k_back(SdxpDev D, int l) {   // l = layer
   const int per_net = kchunks * splits;
   const int net = blockIdx.x / per_net, rem = blockIdx.x % per_net, kc = rem / splits, sp = rem % splits;
   const int k = kc * 256 + threadIdx.x;
-  __shared__ float s_dy[MB][128];
+  __shared__ float s_dy[MB][64];
   const int n_per = (Nn + splits - 1) / splits, n0 = sp * n_per, n1 = min(Nn, n0 + n_per);
   const float* P = net == 2 ? D.cv : D.ac;
   const size_t woff = net == 0 ? D.off.a_w[l + 1] : net == 1 ? D.off.c_w[l + 1] : D.coff.w[l + 1];
-  const float* dyn = D.dy[net][l + 1] + (size_t)par * MB * Nn;
   float acc[MB];
 #pragma unroll
   for (int s = 0; s < MB; ++s) acc[s] = 0.0f;
-  for (int nb = n0; nb < n1; nb += 128) {
+  for (int nb = n0; nb < n1; nb += 64) {
     __syncthreads();
-    for (int i = threadIdx.x; i < MB * 128; i += 256) {
-      const int s = i / 128, n = nb + (i % 128);
-      s_dy[s][i % 128] = n < n1 ? dyn[s * Nn + n] : 0.0f;
+    for (int i = threadIdx.x; i < MB * 64; i += 256) {
+      const int s = i / 64, n = nb + (i % 64);
+      s_dy[s][i % 64] = n < n1 ? dy_at<MB>(D, net, l + 1, par, s, n) : 0.0f;
     }
     __syncthreads();
     if (k < K) {
-      const int cnt = min(128, n1 - nb);
+      const int cnt = min(64, n1 - nb);
       for (int j = 0; j < cnt; ++j) {
         const float w = P[woff + (size_t)(nb + j) * K + k];
 #pragma unroll
@@ -512,284 +731,172 @@ __global__ __launch_bounds__(256) void k_back(SdxpDev D, int l) {   // l = layer
   }
 }
 
-// elu' + move: dY_l = dxacc_l * elu'(h_l); also zero dxacc of the other parity for the next step
+// CTRL kernel (one block of 1024 threads): finishes the gradient norms (layers 0 and 1 from dxacc*elu' and the stored
+// input Grams; layer 2 + heads from k_head), clip scales, Adam bias corrections, legacy adaptive LR (PS:306-312),
+// statistics, advances the minibatch cursor and clears the other parity's dxacc.
+// advance bits: 1 = a minibatch was just back-propagated; 2 = move the cursor; 8 = explicit-gradient (multi-rank) mode.
 template <int MB>
-__global__ void k_back_fin(SdxpDev D, int l) {
-  const SdxpCtrl* ctl = D.ctrl;
-  const int par = ctl->step & 1, K = D.units[l];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 3 * MB * K) return;
-  const int net = i / (MB * K), r = i % (MB * K);
-  const float h = D.x[net][l + 1][(size_t)par * MB * K + r];
-  float* acc = D.dxacc[net][l] + (size_t)par * MB * K;
-  D.dy[net][l][(size_t)par * MB * K + r] = acc[r] * (h > 0.0f ? 1.0f : h + 1.0f);
-  acc[r] = 0.0f;
-}
-
-// CTRL kernel (one block): gradient norms from the Gram matrices of the rank-MB factors, clip scale, Adam bias
-// corrections, legacy adaptive LR (PS:306-312), statistics, central-value running mean/std of the NEXT minibatch and
-// staging of the next minibatch's layer-0 inputs.
-template <int MB>
-__global__ __launch_bounds__(256) void k_ctrl(SdxpDev D, int advance) {
-  __shared__ float s_g[3][MB][MB];   // accumulated sum_{layers} (dY_s.dY_s')(X_s.X_s') per optimiser group (ac uses [0]+[1])
+__global__ __launch_bounds__(1024) void k_ctrl(SdxpDev D, int advance) {
+  __shared__ float s_gd[3][2][MAXG];
   __shared__ float s_b[3];
-  __shared__ float s_tmp[2][MB][MB];
-  SdxpCtrl* ctl = D.ctrl;
-  const int tid = threadIdx.x, par = ctl->step & 1, A = D.act_dim, U = D.units[2];
-  if (tid < 3 * MB * MB) (&s_g[0][0][0])[tid] = 0.0f;
+  __shared__ float s_part[16][MAXG + 1];
+  __shared__ SdxpCtrl s_ctl;               // snapshot: the single-thread bookkeeping below runs on LDS, not on HBM
+  SdxpCtrl* gctl = D.ctrl;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (int)(sizeof(SdxpCtrl) / 4); i += 1024) reinterpret_cast<uint32_t*>(&s_ctl)[i] = reinterpret_cast<const uint32_t*>(gctl)[i];
+  if (tid < 3 * 2 * MAXG) (&s_gd[0][0][0])[tid] = 0.0f;
   if (tid < 3) s_b[tid] = 0.0f;
   __syncthreads();
+  SdxpCtrl* ctl = &s_ctl;
+  const int par = ctl->step & 1;
+  if (threadIdx.x == 0) D.dbg[8] = (long long)__builtin_readcyclecounter();
   if (advance & 1) {
-    // ---- gradient norm of the minibatch that was just back-propagated (parity `par`)
-    for (int net = 0; net < 3; ++net) {
-      for (int l = 0; l < 3; ++l) {
-        const int Nl = D.units[l];
-        const int K = (l == 0) ? (net == 2 ? D.state_dim : D.obs_dim) : D.units[l - 1];
-        const float* dy = D.dy[net][l] + (size_t)par * MB * Nl;
-        const float* x = D.x[net][l] + (size_t)par * MB * K;
-        // Gram matrices with all 256 threads: each thread strides over the vector, then block reduce via atomics
-        float gd[MB][MB], gx[MB][MB], bs = 0.0f;
+    // (net, l) groups of dY vectors: l = 0 groups (units[0] long) get 3 waves each, l = 1 groups 2 waves each; a wave
+    // accumulates lane-wise over its 64-neuron chunks and reduces ONCE (11 DPP sums), partials go to LDS.
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < 15) {
+      const int l = wave < 9 ? 0 : 1;
+      const int net = wave < 9 ? wave / 3 : (wave - 9) / 2;
+      const int sub = wave < 9 ? wave % 3 : (wave - 9) % 2, nsub = wave < 9 ? 3 : 2;
+      const int C = D.units[l] / 64;
+      float g[MB][MB], bs = 0.0f;
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < MB; ++b2) g[a][b2] = 0.0f;
+      for (int c = sub; c < C; c += nsub) {
+        const int n = c * 64 + lane;
+        float v[MB], sb = 0.0f;
+#pragma unroll
+        for (int a = 0; a < MB; ++a) { v[a] = dy_at<MB>(D, net, l, par, a, n); sb += v[a]; }
+        bs += sb * sb;
 #pragma unroll
         for (int a = 0; a < MB; ++a)
 #pragma unroll
-          for (int b = 0; b < MB; ++b) { gd[a][b] = 0.0f; gx[a][b] = 0.0f; }
-        for (int n = tid; n < Nl; n += 256) {
-          float v[MB], sb = 0.0f;
-#pragma unroll
-          for (int a = 0; a < MB; ++a) { v[a] = dy[a * Nl + n]; sb += v[a]; }
-          bs += sb * sb;
-#pragma unroll
-          for (int a = 0; a < MB; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) gd[a][b] += v[a] * v[b];
-        }
-        for (int k = tid; k < K; k += 256) {
-          float v[MB];
-#pragma unroll
-          for (int a = 0; a < MB; ++a) v[a] = x[a * K + k];
-#pragma unroll
-          for (int a = 0; a < MB; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) gx[a][b] += v[a] * v[b];
-        }
-        if (tid < 2 * MB * MB) (&s_tmp[0][0][0])[tid] = 0.0f;
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < MB; ++a)
-#pragma unroll
-          for (int b = 0; b <= a; ++b) {
-            const float r1 = wave_sum(gd[a][b]), r2 = wave_sum(gx[a][b]);
-            if ((tid & 63) == 0) { atomicAdd(&s_tmp[0][a][b], r1); atomicAdd(&s_tmp[1][a][b], r2); }
-          }
-        const float rb = wave_sum(bs);
-        if ((tid & 63) == 0) atomicAdd(&s_b[net], rb);
-        __syncthreads();
-        if (tid < MB * MB) {
-          const int a = tid / MB, b = tid % MB;
-          const float d = a >= b ? s_tmp[0][a][b] : s_tmp[0][b][a];
-          const float xx = a >= b ? s_tmp[1][a][b] : s_tmp[1][b][a];
-          s_g[net][a][b] += d * xx;
-        }
-        __syncthreads();
+          for (int b2 = 0; b2 <= a; ++b2) g[a][b2] += v[a] * v[b2];
       }
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 <= a; ++b2) {
+          const float r = wave_sum(g[a][b2]);
+          if (lane == 0) { s_part[wave][a * MB + b2] = r; s_part[wave][b2 * MB + a] = r; }
+        }
+      const float rb = wave_sum(bs);
+      if (lane == 0) s_part[wave][MAXG] = rb;
     }
-    // heads: factors are dhead (MB x 34) and h = x[net][3] (MB x U); h Gram in parallel, the rest is tiny
-    __shared__ float s_hh[3][MB][MB];
-    if (tid < 3 * MB * MB) (&s_hh[0][0][0])[tid] = 0.0f;
     __syncthreads();
-    for (int net = 0; net < 3; ++net) {
-      const float* h = D.x[net][3] + (size_t)par * MB * U;
-      float gx[MB][MB];
-#pragma unroll
-      for (int a = 0; a < MB; ++a)
-#pragma unroll
-        for (int b = 0; b < MB; ++b) gx[a][b] = 0.0f;
-      for (int k = tid; k < U; k += 256) {
-        float v[MB];
-#pragma unroll
-        for (int a = 0; a < MB; ++a) v[a] = h[a * U + k];
-#pragma unroll
-        for (int a = 0; a < MB; ++a)
-#pragma unroll
-          for (int b = 0; b <= a; ++b) gx[a][b] += v[a] * v[b];
-      }
-#pragma unroll
-      for (int a = 0; a < MB; ++a)
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-          const float r = wave_sum(gx[a][b]);
-          if ((tid & 63) == 0) { atomicAdd(&s_hh[net][a][b], r); if (a != b) atomicAdd(&s_hh[net][b][a], r); }
-        }
+    if (threadIdx.x == 0) D.dbg[9] = (long long)__builtin_readcyclecounter();
+    // n2[net] = n2_part[net] + sum_l sum_ab Gd[net][l][ab] * Gx[net][l][ab] + bias terms: thread (net, l, ab)
+    if (tid < 3 * 2 * MB * MB) {
+      const int net = tid / (2 * MB * MB), l = (tid / (MB * MB)) % 2, ab = tid % (MB * MB);
+      float gd = 0.0f;
+      if (l == 0) { for (int w = 0; w < 3; ++w) gd += s_part[net * 3 + w][ab]; }
+      else { for (int w = 0; w < 2; ++w) gd += s_part[9 + net * 2 + w][ab]; }
+      s_gd[net][l][ab] = gd * ctl->gx[net][l][ab];
     }
     __syncthreads();
     if (tid == 0) {
-      float n2[3] = {0, 0, 0};
+      float n2[3];
       for (int net = 0; net < 3; ++net) {
-        float s = 0.0f;
-        for (int a = 0; a < MB; ++a) for (int b = 0; b < MB; ++b) s += s_g[net][a][b];
-        n2[net] = s + s_b[net];
+        float s = ctl->n2_part[net];
+        for (int w = 0; w < 3; ++w) s += s_part[net * 3 + w][MAXG];
+        for (int w = 0; w < 2; ++w) s += s_part[9 + net * 2 + w][MAXG];
+        for (int l = 0; l < 2; ++l)
+          for (int i = 0; i < MB * MB; ++i) s += s_gd[net][l][i];
+        n2[net] = s;
       }
-      const float* dh = D.dhead + (size_t)par * MB * 34;
-      for (int net = 0; net < 3; ++net) {
-        for (int a = 0; a < MB; ++a)
-          for (int b = 0; b < MB; ++b) {
-            float dd = 0.0f;
-            if (net == 0) { for (int j = 0; j < A; ++j) dd += dh[a * 34 + j] * dh[b * 34 + j]; }
-            else dd = dh[a * 34 + 32 + (net - 1)] * dh[b * 34 + 32 + (net - 1)];
-            n2[net] += dd * s_hh[net][a][b];
-          }
-        if (net == 0) { for (int j = 0; j < A; ++j) { float sb = 0; for (int a = 0; a < MB; ++a) sb += dh[a * 34 + j]; n2[0] += sb * sb; } }
-        else { float sb = 0; for (int a = 0; a < MB; ++a) sb += dh[a * 34 + 32 + (net - 1)]; n2[net] += sb * sb; }
-      }
-      for (int j = 0; j < A; ++j) { const float g = D.dlogstd[(size_t)par * 32 + j]; n2[0] += g * g; }
       const float ac_norm = sqrtf(n2[0] + n2[1]), cv_norm = sqrtf(n2[2]);
       ctl->ac_gnorm = ac_norm; ctl->cv_gnorm = cv_norm;
       ctl->ac_gscale = D.truncate_grads ? fminf(1.0f, D.grad_norm / (ac_norm + 1e-6f)) : 1.0f;   // clip_grad_norm_
       ctl->cv_gscale = D.truncate_grads ? fminf(1.0f, D.grad_norm / (cv_norm + 1e-6f)) : 1.0f;
-      // Adam step counters / bias corrections of the step that is now pending
-      ctl->ac_t += 1; ctl->cv_t += 1;
-      ctl->ac_bc1 = 1.0f - powf(0.9f, (float)ctl->ac_t); ctl->ac_bc2 = 1.0f - powf(0.999f, (float)ctl->ac_t);
-      ctl->cv_bc1 = 1.0f - powf(0.9f, (float)ctl->cv_t); ctl->cv_bc2 = 1.0f - powf(0.999f, (float)ctl->cv_t);
-      ctl->ac_lr_applied = ctl->ac_lr; ctl->cv_lr_applied = ctl->cv_lr;
       const bool explicit_mode = (advance & 8) != 0;   // multi-rank: Adam/LR happen in sdxp_apply after the all-reduce
-      if (explicit_mode) { ctl->ac_t -= 1; ctl->cv_t -= 1; ctl->gn2_ac = 0.0f; ctl->gn2_cv = 0.0f; }
-      ctl->ac_pending = explicit_mode ? 0 : 1; ctl->cv_pending = explicit_mode ? 0 : 1;
-      // statistics (means over the minibatch) + legacy adaptive LR from this minibatch's KL (PS:306-312)
+      if (!explicit_mode) {
+        ctl->ac_t += 1; ctl->cv_t += 1;
+        ctl->ac_b1pow *= 0.9; ctl->ac_b2pow *= 0.999; ctl->cv_b1pow *= 0.9; ctl->cv_b2pow *= 0.999;
+        ctl->ac_bc1 = (float)(1.0 - ctl->ac_b1pow); ctl->ac_bc2 = (float)(1.0 - ctl->ac_b2pow);
+        ctl->cv_bc1 = (float)(1.0 - ctl->cv_b1pow); ctl->cv_bc2 = (float)(1.0 - ctl->cv_b2pow);
+        ctl->ac_lr_applied = ctl->ac_lr; ctl->cv_lr_applied = ctl->cv_lr;
+        ctl->ac_pending = 1; ctl->cv_pending = 1;
+      } else { ctl->gn2_ac = 0.0f; ctl->gn2_cv = 0.0f; ctl->ac_pending = 0; ctl->cv_pending = 0; }
       const float invM = 1.0f / (float)MB;
       const float kl = ctl->acc[4] * invM;
       ctl->sum_a_loss += ctl->acc[1] * invM; ctl->sum_c_loss += ctl->acc[2] * invM; ctl->sum_b_loss += ctl->acc[3] * invM;
       ctl->sum_kl += kl; ctl->sum_cv_loss += ctl->acc[5] * invM; ctl->sum_entropy += ctl->acc[6] * invM;
       ctl->n_mb += 1; ctl->last_kl = kl;
-      if (D.adaptive_lr && !explicit_mode) {
+      if (D.adaptive_lr && !explicit_mode) {   // legacy schedule: after every minibatch (PS:306-312)
         if (kl > 2.0f * D.kl_threshold) ctl->ac_lr = fmaxf(ctl->ac_lr / 1.5f, 1e-6f);
         if (kl < 0.5f * D.kl_threshold) ctl->ac_lr = fminf(ctl->ac_lr * 1.5f, 1e-2f);
       }
-      for (int i = 0; i < 8; ++i) ctl->acc[i] = 0.0f;
     }
     __syncthreads();
   }
+  if (threadIdx.x == 0) D.dbg[10] = (long long)__builtin_readcyclecounter();
   if (advance & 2) {
-    // ---- move on to the next minibatch: parity flips, inputs of layer 0 are staged (obs rows; normalised states)
-    __shared__ int s_next;
     if (tid == 0) {
-      int mbn = ctl->mb_index + ((advance & 1) ? 1 : 0);
-      if (mbn >= D.num_minibatches) { mbn = 0; ctl->mini_epoch += 1; }
-      ctl->mb_index = mbn;
-      ctl->step += (advance & 1) ? 1 : 0;
-      s_next = mbn;
-    }
-    __syncthreads();
-    const int mbn = s_next, np = ctl->step & 1;
-    const size_t r0 = (size_t)mbn * MB;
-    const bool upd_rms = D.cv_normalize_input && ctl->mini_epoch == 0 && (advance & 4) == 0;
-    // running mean/std update with this minibatch's raw states BEFORE normalising it (train mode, App. C)
-    for (int k = tid; k < D.state_dim; k += 256) {
-      double mean = D.rms_mean[k], var = D.rms_var[k];
-      const double cnt = ctl->rms_count;
-      if (upd_rms) {
-        double bm = 0.0, bv = 0.0;
-        for (int s = 0; s < MB; ++s) bm += D.mb_states[(r0 + s) * D.state_dim + k];
-        bm /= MB;
-        for (int s = 0; s < MB; ++s) { const double d = D.mb_states[(r0 + s) * D.state_dim + k] - bm; bv += d * d; }
-        bv = MB > 1 ? bv / (MB - 1) : 0.0;
-        const double delta = bm - mean, tot = cnt + MB;
-        const double m2 = var * cnt + bv * MB + delta * delta * cnt * MB / tot;
-        mean = mean + delta * MB / tot;
-        var = m2 / tot;
-        D.rms_mean[k] = mean; D.rms_var[k] = var;
-      }
-      for (int s = 0; s < MB; ++s) {
-        float x = D.mb_states[(r0 + s) * D.state_dim + k];
-        if (D.cv_normalize_input) x = clampf((x - (float)mean) / sqrtf((float)var + 1e-5f), -5.0f, 5.0f);
-        D.x[2][0][(size_t)np * MB * D.state_dim + s * D.state_dim + k] = x;
+      ctl->prev_mb = ctl->mb_index; ctl->prev_mini_epoch = ctl->mini_epoch;
+      if (advance & 1) {
+        int mbn = ctl->mb_index + 1;
+        if (mbn >= D.num_minibatches) { mbn = 0; ctl->mini_epoch += 1; }
+        ctl->mb_index = mbn;
+        ctl->step += 1;
       }
     }
-    for (int i = tid; i < MB * D.obs_dim; i += 256) {
-      const float v = D.mb_obs[r0 * D.obs_dim + i];
-      D.x[0][0][(size_t)np * MB * D.obs_dim + i] = v;
-      D.x[1][0][(size_t)np * MB * D.obs_dim + i] = v;
+    // the split-N accumulators of the parity that the NEXT step will write must start from zero
+    const int npar = (advance & 1) ? (par ^ 1) : par;
+    for (int net = 0; net < 3; ++net)
+      for (int l = 0; l < 2; ++l) {
+        float* a = D.dxacc[net][l] + (size_t)npar * MB * D.units[l];
+        for (int i = tid; i < MB * D.units[l]; i += 1024) a[i] = 0.0f;
+      }
+  }
+  __syncthreads();
+  // write the header of the control block back (the Gram area gx is owned by the L kernels and left untouched)
+  for (int i = tid; i < (int)(offsetof(SdxpCtrl, gx) / 4); i += 1024) reinterpret_cast<uint32_t*>(gctl)[i] = reinterpret_cast<const uint32_t*>(&s_ctl)[i];
+  for (int i = (int)(offsetof(SdxpCtrl, rms_count) / 4) + tid; i < (int)(sizeof(SdxpCtrl) / 4); i += 1024) reinterpret_cast<uint32_t*>(gctl)[i] = reinterpret_cast<const uint32_t*>(&s_ctl)[i];
+  if (threadIdx.x == 0) D.dbg[11] = (long long)__builtin_readcyclecounter();
+}
+
+// central-value input normalisation for the whole epoch, hoisted out of the minibatch loop: thread = feature, sequential
+// over the minibatches exactly like RunningMeanStd in train mode (update with the minibatch, then normalise it) during
+// mini-epoch 0 -> cvx0; statistics frozen afterwards (App. C) -> cvx1 for mini-epochs >= 1.
+template <int MB>
+__global__ void k_cv_prenorm(SdxpDev D) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= D.state_dim) return;
+  const int S = D.state_dim;
+  const size_t R = (size_t)D.N * D.horizon;
+  double mean = D.rms_mean[k], var = D.rms_var[k], cnt = D.ctrl->rms_count;
+  for (int mb = 0; mb < D.num_minibatches; ++mb) {
+    float x[MB];
+#pragma unroll
+    for (int s = 0; s < MB; ++s) x[s] = D.mb_states[((size_t)mb * MB + s) * S + k];
+    if (D.cv_normalize_input) {
+      double bm = 0.0, bv = 0.0;
+#pragma unroll
+      for (int s = 0; s < MB; ++s) bm += x[s];
+      bm /= MB;
+#pragma unroll
+      for (int s = 0; s < MB; ++s) { const double d = x[s] - bm; bv += d * d; }
+      bv = MB > 1 ? bv / (MB - 1) : 0.0;
+      const double delta = bm - mean, tot = cnt + MB;
+      const double m2 = var * cnt + bv * MB + delta * delta * cnt * MB / tot;
+      mean = mean + delta * MB / tot;
+      var = m2 / tot;
+      cnt = tot;
     }
-    __syncthreads();
-    if (tid == 0 && upd_rms) ctl->rms_count += MB;
+    const float fm = (float)mean, rs = sqrtf((float)var + 1e-5f);
+#pragma unroll
+    for (int s = 0; s < MB; ++s)
+      D.cvx0[((size_t)mb * MB + s) * S + k] = D.cv_normalize_input ? clampf((x[s] - fm) / rs, -5.0f, 5.0f) : x[s];
   }
-}
-
-
-// ------------------------------------------------------------------------------------------------ launch helpers
-extern "C" void sdxpk_linear(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int elu_flag,
-                             const double* nmean, const double* nvar, hipStream_t st) {
-  dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT);
-  hipLaunchKernelGGL(k_linear_mfma, grid, dim3(256), 0, st, X, W, b, Y, M, N, K, elu_flag, nmean, nvar);
-}
-extern "C" void sdxpk_act_heads(const SdxpDev* D, int t, const float* obs, const float* states, const int64_t* dones,
-                                const float* eps, float* actions_out, uint64_t counter, hipStream_t st) {
-  hipLaunchKernelGGL(k_act_heads, dim3(D->N), dim3(64), 0, st, *D, t, obs, states, dones, eps, actions_out, counter);
-}
-extern "C" void sdxpk_store_rewards(const SdxpDev* D, int t, const float* rew, const int64_t* dones_after, hipStream_t st) {
-  hipLaunchKernelGGL(k_store_rewards, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, t, rew, dones_after);
-}
-extern "C" void sdxpk_value_head(const SdxpDev* D, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_value_head, dim3(D->N), dim3(64), 0, st, *D, out);
-}
-extern "C" void sdxpk_gae(const SdxpDev* D, const float* last_values, const int64_t* last_dones, hipStream_t st) {
-  hipLaunchKernelGGL(k_gae, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, last_values, last_dones);
-  if (D->normalize_advantage) hipLaunchKernelGGL(k_adv_norm, dim3(1), dim3(1024), 0, st, *D);
-}
-
-template <int MB>
-static void launch_step(const SdxpDev* D, hipStream_t st) {
-  const int rpb = 4 * D->rows_per_wave;
-  for (int l = 0; l < 3; ++l) {
-    const int Nl = D->units[l];
-    const int Kmax = l == 0 ? (D->state_dim > D->obs_dim ? D->state_dim : D->obs_dim) : D->units[l - 1];
-    const int blocks = 3 * ((Nl + rpb - 1) / rpb);
-    hipLaunchKernelGGL(k_layer<MB>, dim3(blocks), dim3(256), (size_t)2 * MB * Kmax * sizeof(float), st, *D, l);
+  D.rms_mean[k] = mean; D.rms_var[k] = var;
+  const float fm = (float)mean, rs = sqrtf((float)var + 1e-5f);
+  for (size_t r = 0; r < R; ++r) {
+    const float x = D.mb_states[r * S + k];
+    D.cvx1[r * S + k] = D.cv_normalize_input ? clampf((x - fm) / rs, -5.0f, 5.0f) : x;
   }
-  hipLaunchKernelGGL(k_head<MB>, dim3(1), dim3(256), 0, st, *D, 0);
-  for (int l = 1; l >= 0; --l) {
-    const int K = D->units[l];
-    const int blocks = 3 * ((K + 255) / 256) * D->bsplit;
-    hipLaunchKernelGGL(k_back<MB>, dim3(blocks), dim3(256), 0, st, *D, l);
-    hipLaunchKernelGGL(k_back_fin<MB>, dim3((3 * MB * K + 255) / 256), dim3(256), 0, st, *D, l);
-  }
-  hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(256), 0, st, *D, 1 | 2);
-}
-extern "C" int sdxpk_update_step(const SdxpDev* D, int mb_size, hipStream_t st) {
-  switch (mb_size) {
-    case 2: launch_step<2>(D, st); return 0;
-    case 4: launch_step<4>(D, st); return 0;
-    case 8: launch_step<8>(D, st); return 0;
-    default: return -1;
-  }
-}
-// stage minibatch 0 (advance = 2: no gradient bookkeeping), bit 2 (=4) suppresses the RMS update
-extern "C" int sdxpk_update_begin(const SdxpDev* D, int mb_size, hipStream_t st) {
-  switch (mb_size) {
-    case 2: hipLaunchKernelGGL(k_ctrl<2>, dim3(1), dim3(256), 0, st, *D, 2); return 0;
-    case 4: hipLaunchKernelGGL(k_ctrl<4>, dim3(1), dim3(256), 0, st, *D, 2); return 0;
-    case 8: hipLaunchKernelGGL(k_ctrl<8>, dim3(1), dim3(256), 0, st, *D, 2); return 0;
-    default: return -1;
-  }
-}
-// flush: apply the last pending optimiser step (the L/HEAD kernels run once more on the last staged minibatch; their
-// forward outputs are discarded)
-template <int MB>
-static void launch_flush(const SdxpDev* D, hipStream_t st) {
-  const int rpb = 4 * D->rows_per_wave;
-  for (int l = 0; l < 3; ++l) {
-    const int Nl = D->units[l];
-    const int Kmax = l == 0 ? (D->state_dim > D->obs_dim ? D->state_dim : D->obs_dim) : D->units[l - 1];
-    hipLaunchKernelGGL(k_layer<MB>, dim3(3 * ((Nl + rpb - 1) / rpb)), dim3(256), (size_t)2 * MB * Kmax * sizeof(float), st, *D, l);
-  }
-  hipLaunchKernelGGL(k_head<MB>, dim3(1), dim3(256), 0, st, *D, 1);
-}
-extern "C" int sdxpk_update_flush_layers(const SdxpDev* D, int mb_size, hipStream_t st) {
-  switch (mb_size) {
-    case 2: launch_flush<2>(D, st); return 0;
-    case 4: launch_flush<4>(D, st); return 0;
-    case 8: launch_flush<8>(D, st); return 0;
-    default: return -1;
-  }
+  if (k == 0 && D.cv_normalize_input) D.ctrl->rms_count = cnt;
 }
 
 // ------------------------------------------------------------------------------------------------ explicit gradients
@@ -799,21 +906,21 @@ template <int MB>
 __global__ __launch_bounds__(256) void k_grad_layer(SdxpDev D, int l) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int par = D.ctrl->step & 1, Nl = D.units[l];
+  const SdxpCtrl* ctl = D.ctrl;
+  const int par = ctl->step & 1, Nl = D.units[l];
   const int blocks_per_net = (Nl + 3) / 4;
   const int net = blockIdx.x / blocks_per_net, n = (blockIdx.x % blocks_per_net) * 4 + wave;
   const int K = (l == 0) ? (net == 2 ? D.state_dim : D.obs_dim) : D.units[l - 1];
   float* G = net == 2 ? D.cv_g : D.ac_g;
   const size_t woff = net == 0 ? D.off.a_w[l] : net == 1 ? D.off.c_w[l] : D.coff.w[l];
   const size_t boff = net == 0 ? D.off.a_b[l] : net == 1 ? D.off.c_b[l] : D.coff.b[l];
-  const float* gx = D.x[net][l] + (size_t)par * MB * K;
+  const float* gx = layer_input<MB>(D, ctl, net, l, true);
   for (int i = tid; i < MB * K; i += 256) sm[i] = gx[i];
   __syncthreads();
   if (n >= Nl) return;
-  const float* dy = D.dy[net][l] + (size_t)par * MB * Nl;
   float dyn[MB], sb = 0.0f;
 #pragma unroll
-  for (int s = 0; s < MB; ++s) { dyn[s] = dy[s * Nl + n]; sb += dyn[s]; }
+  for (int s = 0; s < MB; ++s) { dyn[s] = dy_at<MB>(D, net, l, par, s, n); sb += dyn[s]; }
   for (int k = lane; k < K; k += 64) {
     float g = 0.0f;
 #pragma unroll
@@ -862,52 +969,111 @@ __global__ __launch_bounds__(256) void k_adam_explicit(SdxpDev D, int which) {
   const int t = (which ? ctl->cv_t : ctl->ac_t) + 1;
   const float bc1 = 1.0f - powf(0.9f, (float)t), bc2 = 1.0f - powf(0.999f, (float)t);
   const float lr = which ? ctl->cv_lr : ctl->ac_lr;
+  const float lr_bc1 = lr / bc1, isq_bc2 = 1.0f / sqrtf(bc2);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float g = G[i] * inv_w * clip;
-    const float m = 0.9f * M[i] + 0.1f * g, v = 0.999f * V[i] + 0.001f * g * g;
+    float m = M[i], v = V[i];
+    P[i] = adam1(P[i], G[i] * inv_w * clip, m, v, lr_bc1, isq_bc2);
     M[i] = m; V[i] = v;
-    P[i] -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
   }
 }
 __global__ void k_apply_fin(SdxpDev D, int which, float kl_host) {
   SdxpCtrl* ctl = D.ctrl;
-  if (which) { ctl->cv_t += 1; ctl->cv_gnorm = sqrtf(ctl->gn2_cv); return; }
-  ctl->ac_t += 1; ctl->ac_gnorm = sqrtf(ctl->gn2_ac);
+  if (which) { ctl->cv_t += 1; ctl->cv_b1pow *= 0.9; ctl->cv_b2pow *= 0.999; ctl->cv_gnorm = sqrtf(ctl->gn2_cv); return; }
+  ctl->ac_t += 1; ctl->ac_b1pow *= 0.9; ctl->ac_b2pow *= 0.999; ctl->ac_gnorm = sqrtf(ctl->gn2_ac);
   const float kl = (kl_host == kl_host) ? kl_host : ctl->last_kl / (float)ctl->world;   // NaN -> device value, all-reduced in place
   if (D.adaptive_lr) {   // legacy schedule after every minibatch, on the rank-averaged KL (PS:306-312)
     if (kl > 2.0f * D.kl_threshold) ctl->ac_lr = fmaxf(ctl->ac_lr / 1.5f, 1e-6f);
     if (kl < 0.5f * D.kl_threshold) ctl->ac_lr = fminf(ctl->ac_lr * 1.5f, 1e-2f);
   }
 }
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+extern "C" void sdxpk_linear(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int elu_flag,
+                             const double* nmean, const double* nvar, hipStream_t st) {
+  dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT);
+  hipLaunchKernelGGL(k_linear_mfma, grid, dim3(256), 0, st, X, W, b, Y, M, N, K, elu_flag, nmean, nvar);
+}
+extern "C" void sdxpk_act_heads(const SdxpDev* D, int t, const float* obs, const float* states, const int64_t* dones,
+                                const float* eps, float* actions_out, uint64_t counter, hipStream_t st) {
+  hipLaunchKernelGGL(k_act_heads, dim3(D->N), dim3(64), 0, st, *D, t, obs, states, dones, eps, actions_out, counter);
+}
+extern "C" void sdxpk_store_rewards(const SdxpDev* D, int t, const float* rew, const int64_t* dones_after, hipStream_t st) {
+  hipLaunchKernelGGL(k_store_rewards, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, t, rew, dones_after);
+}
+extern "C" void sdxpk_value_head(const SdxpDev* D, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_value_head, dim3(D->N), dim3(64), 0, st, *D, out);
+}
+extern "C" void sdxpk_gae(const SdxpDev* D, const float* last_values, const int64_t* last_dones, hipStream_t st) {
+  hipLaunchKernelGGL(k_gae, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, last_values, last_dones);
+  if (D->normalize_advantage) hipLaunchKernelGGL(k_adv_norm, dim3(1), dim3(1024), 0, st, *D);
+}
+
+template <int MB, int RPW, int KI>
+static void launch_layer(const SdxpDev* D, int l, int Kmax, hipStream_t st) {
+  const int blocks = 3 * ((D->units[l] + 4 * RPW - 1) / (4 * RPW));
+  hipLaunchKernelGGL((k_layer<MB, RPW, KI>), dim3(blocks), dim3(256), (size_t)2 * MB * Kmax * sizeof(float), st, *D, l);
+}
 template <int MB>
-static void launch_backward_explicit(const SdxpDev* D, hipStream_t st) {
-  const int rpb = 4 * D->rows_per_wave;
+static void launch_layers(const SdxpDev* D, hipStream_t st) {
   for (int l = 0; l < 3; ++l) {
-    const int Nl = D->units[l];
     const int Kmax = l == 0 ? (D->state_dim > D->obs_dim ? D->state_dim : D->obs_dim) : D->units[l - 1];
-    hipLaunchKernelGGL(k_layer<MB>, dim3(3 * ((Nl + rpb - 1) / rpb)), dim3(256), (size_t)2 * MB * Kmax * sizeof(float), st, *D, l);
+    const int ki = (Kmax / 4 + 63) / 64;   // float4 columns per lane
+    const bool two = (3 * D->units[l]) / 4 >= 512;   // 2 rows per wave when there are plenty of rows
+    if (ki <= 1) { if (two) launch_layer<MB, 2, 1>(D, l, Kmax, st); else launch_layer<MB, 1, 1>(D, l, Kmax, st); }
+    else if (ki == 2) { if (two) launch_layer<MB, 2, 2>(D, l, Kmax, st); else launch_layer<MB, 1, 2>(D, l, Kmax, st); }
+    else if (ki == 3) { if (two) launch_layer<MB, 2, 3>(D, l, Kmax, st); else launch_layer<MB, 1, 3>(D, l, Kmax, st); }
+    else { if (two) launch_layer<MB, 2, 4>(D, l, Kmax, st); else launch_layer<MB, 1, 4>(D, l, Kmax, st); }
   }
-  hipLaunchKernelGGL(k_head<MB>, dim3(1), dim3(256), 0, st, *D, 0);
+}
+template <int MB>
+static void launch_fwd_bwd(const SdxpDev* D, hipStream_t st) {
+  launch_layers<MB>(D, st);
+  hipLaunchKernelGGL(k_head<MB>, dim3(1), dim3(1024), 0, st, *D, 0);
   for (int l = 1; l >= 0; --l) {
     const int K = D->units[l];
     hipLaunchKernelGGL(k_back<MB>, dim3(3 * ((K + 255) / 256) * D->bsplit), dim3(256), 0, st, *D, l);
-    hipLaunchKernelGGL(k_back_fin<MB>, dim3((3 * MB * K + 255) / 256), dim3(256), 0, st, *D, l);
   }
+}
+template <int MB>
+static void launch_step(const SdxpDev* D, hipStream_t st) {
+  launch_fwd_bwd<MB>(D, st);
+  hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(1024), 0, st, *D, 1 | 2);
+}
+#define MB_SWITCH(mb, CALL) switch (mb) { case 2: { CALL(2); return 0; } case 4: { CALL(4); return 0; } case 8: { CALL(8); return 0; } default: return -1; }
+extern "C" int sdxpk_update_step(const SdxpDev* D, int mb_size, hipStream_t st) {
+#define C_(M) launch_step<M>(D, st)
+  MB_SWITCH(mb_size, C_)
+#undef C_
+}
+// begin of an epoch's update phase: central-value pre-normalisation for all minibatches + cursor/accumulator reset
+extern "C" int sdxpk_update_begin(const SdxpDev* D, int mb_size, hipStream_t st) {
+#define C_(M) hipLaunchKernelGGL(k_cv_prenorm<M>, dim3((D->state_dim + 63) / 64), dim3(64), 0, st, *D); \
+              hipLaunchKernelGGL(k_ctrl<M>, dim3(1), dim3(1024), 0, st, *D, 2)
+  MB_SWITCH(mb_size, C_)
+#undef C_
+}
+// flush: apply the last pending optimiser step (the L/HEAD kernels run once more on the staged minibatch; their forward
+// outputs are discarded)
+extern "C" int sdxpk_update_flush_layers(const SdxpDev* D, int mb_size, hipStream_t st) {
+#define C_(M) launch_layers<M>(D, st); hipLaunchKernelGGL(k_head<M>, dim3(1), dim3(1024), 0, st, *D, 1)
+  MB_SWITCH(mb_size, C_)
+#undef C_
+}
+template <int MB>
+static void launch_backward_explicit(const SdxpDev* D, hipStream_t st) {
+  launch_fwd_bwd<MB>(D, st);
   for (int l = 0; l < 3; ++l) {
     const int Nl = D->units[l];
     const int Kmax = l == 0 ? (D->state_dim > D->obs_dim ? D->state_dim : D->obs_dim) : D->units[l - 1];
     hipLaunchKernelGGL(k_grad_layer<MB>, dim3(3 * ((Nl + 3) / 4)), dim3(256), (size_t)MB * Kmax * sizeof(float), st, *D, l);
   }
   hipLaunchKernelGGL(k_grad_heads<MB>, dim3(1), dim3(256), 0, st, *D);
-  hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(256), 0, st, *D, 1 | 2 | 8);
+  hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(1024), 0, st, *D, 1 | 2 | 8);
 }
 extern "C" int sdxpk_backward_explicit(const SdxpDev* D, int mb_size, hipStream_t st) {
-  switch (mb_size) {
-    case 2: launch_backward_explicit<2>(D, st); return 0;
-    case 4: launch_backward_explicit<4>(D, st); return 0;
-    case 8: launch_backward_explicit<8>(D, st); return 0;
-    default: return -1;
-  }
+#define C_(M) launch_backward_explicit<M>(D, st)
+  MB_SWITCH(mb_size, C_)
+#undef C_
 }
 extern "C" void sdxpk_apply_explicit(const SdxpDev* D, int which, float kl, int world, hipStream_t st) {
   const size_t n = which ? D->coff.total : D->off.total;

@@ -26,7 +26,11 @@ struct SdxpCtrl {
   float games_sum_rew, games_sum_len, games_cnt, pad0;
   float gn2_ac, gn2_cv;  // explicit-gradient path: sum of squares of the (all-reduced) flat gradients
   int32_t world, pad1;
+  int32_t prev_mb, prev_mini_epoch;
+  float n2_part[4];      // grad-norm^2 contributions of heads + trunk layer 2 per net (written by the HEAD kernel)
+  float gx[3][3][64];    // Gram matrices (MB x MB) of the inputs of trunk layers 0..2 per net (written by the L kernels)
   double rms_count;
+  double ac_b1pow, ac_b2pow, cv_b1pow, cv_b2pow;   // running beta^t of the fused path (bias corrections)
 };
 
 struct SdxpDev {
@@ -45,10 +49,12 @@ struct SdxpDev {
   float *returns, *adv, *last_values, *cur_rew, *cur_len;
   double *rms_mean, *rms_var;
   // small-minibatch update: rank-MB factors, double buffered by step parity
-  float* x[3][4];        // x[net][l]: [2][MB][K_l] input of trunk layer l (l=3: input of the head = output of layer 2)
-  float* dy[3][3];       // dy[net][l]: [2][MB][N_l]
-  float* dxacc[3][2];    // dxacc[net][l]: [2][MB][N_l] split-N accumulators of the backward kernel
+  float* x[3][4];        // x[net][l], l=1..3: [2][MB][units[l-1]] output of trunk layer l-1 (l=3: head input); x[.][0] unused
+  float* dy2[3];         // dy2[net]: [2][MB][units[2]] dLoss/d(pre-activation) of trunk layer 2
+  float* dxacc[3][2];    // dxacc[net][l]: [2][MB][units[l]] dLoss/d(output of layer l), split-N accumulators
+  float *cvx0, *cvx1;    // [N*H, state_dim] normalised central-value inputs (mini-epoch 0 / later mini-epochs)
   float* dhead;          // [2][MB][34]: dmu (cols 0..act_dim-1), dV critic (32), dV central value (33)
   float* dlogstd;        // [2][32]
   SdxpCtrl* ctrl;
+  long long* dbg;        // [64] phase timestamps (s_memtime) written by thread 0 of the single-block kernels
 };
