@@ -88,7 +88,8 @@ typedef enum {
   SDX_T_SUCCESS_BUF = 25,/* i64 [N]         extras["success_buf"]                GS:459                  */
   SDX_T_PILE_CHOICE = 26,/* i32 [N]         saved-pile index drawn at the last reset of each env  GS:1510 */
   SDX_T_NCONTACTS = 27,  /* i32 [N]         contact points generated in the last substep (diagnostic)    */
-  SDX_T_COUNT = 28
+  SDX_T_DEBUG = 28,      /* i64 [64]        phase time stamps (s_memtime) of env 0 in the last k_physics (profiling aid) */
+  SDX_T_COUNT = 29
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the

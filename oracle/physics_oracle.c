@@ -12,7 +12,7 @@
  *
  * Algorithm per env and per substep h = dt/substeps  (P1..P5 of SURVEY.md §8(a)):
  *   A  forward kinematics of the 24-body tree, link twists
- *   B  joint-space inertia M(q) (composite sums), H = M + diag(armature + h kd + h^2 kp), Hinv
+ *   B  joint-space inertia M(q) (composite sums, once per step), H = M + diag(armature + h kd + h^2 kp), Hinv
  *   C  implicit PD drive (P1):  qd += Hinv h clamp(kp(q*-q) - (kd + h kp) qd, +-effort);  bricks: v += h g
  *   D  contacts (P3): boxes only; sample points of one box against the analytic SDF of the other,
  *      both directions, <= 4 contacts per pair, kept when separation < contact_offset
@@ -484,9 +484,9 @@ static void load_env(const sdx_scene_desc* sc, env_t* e, const float* root, cons
   }
 }
 
-static void substep(const sdx_scene_desc* sc, env_t* e, real h) {
+static void substep(const sdx_scene_desc* sc, env_t* e, real h, int first) {
   fk(sc, e);
-  mass_matrix(sc, e, h);
+  if (first) mass_matrix(sc, e, h); /* M(q) is evaluated once per step and frozen over the substeps */
   real tau[ND];
   for (int j = 0; j < ND; ++j) {
     real t = sc->kp[j] * (e->tgt[j] - e->q[j]) - (sc->kd[j] + h * sc->kp[j]) * e->qd[j];
@@ -586,7 +586,7 @@ void sdxo_simulate(const sdx_scene_desc* sc, int N, float* root, float* dof, con
       float* d = dof + (size_t)n * ND * 2;
       e->overflow = 0;
       load_env(sc, e, r, d, targets + (size_t)n * ND);
-      for (int s = 0; s < sc->substeps; ++s) substep(sc, e, h);
+      for (int s = 0; s < sc->substeps; ++s) substep(sc, e, h, s == 0);
       store_env(sc, e, h, r, d, rb + (size_t)n * SDX_BODIES * 13, contact + (size_t)n * SDX_BODIES * 3,
                 jac + (size_t)n * 42, ncontacts ? ncontacts + n : NULL);
     }

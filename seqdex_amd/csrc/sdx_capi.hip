@@ -151,9 +151,10 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(piles, (size_t)8 * SDX_NBRICK * 13);
   ALLOC(tv_w, SDX_TV_PARAMS);
   ALLOC(cam_rot, (size_t)N * 4);
-  ALLOC(cscratch, (size_t)N * SDX_CFIELDS * SDX_MAXC);
+  ALLOC(cscratch, 4);   // (contact rows now live in LDS / registers)
   ALLOC(stat, 4);
   ALLOC(step_count, 1);
+  ALLOC(dbg, 64);
 #undef ALLOC
   set_tensor(h, SDX_T_ROOT, B.root, SDX_F32, {(int64_t)N * SDX_ACTORS, 13});
   set_tensor(h, SDX_T_DOF, B.dof, SDX_F32, {(int64_t)N * SDX_NDOF, 2});
@@ -183,6 +184,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_SUCCESS_BUF, B.success_buf, SDX_I64, {N});
   set_tensor(h, SDX_T_PILE_CHOICE, B.pile_choice, SDX_I32, {N});
   set_tensor(h, SDX_T_NCONTACTS, B.ncontacts, SDX_I32, {N});
+  set_tensor(h, SDX_T_DEBUG, B.dbg, SDX_I64, {64});
 
   // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
   std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);

@@ -40,6 +40,7 @@ struct SdxBuf {
   float* cscratch;         // [N, SDX_CFIELDS, SDX_MAXC]
   float* stat;             // [2][2] double-buffered (num_resets, finished successes) for cons_successes
   uint32_t* step_count;    // device counter, incremented by the post-physics kernel
+  long long* dbg;          // [64] phase time stamps of env 0 (profiling aid)
 };
 
 struct f3 { float x, y, z; };

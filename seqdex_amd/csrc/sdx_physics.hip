@@ -8,12 +8,15 @@
 //   D sampled-SDF box/box contacts (<= 4 per pair)  E active-set mass-split Jacobi on accumulated impulses
 //   F semi-implicit Euler;  then outputs: rigid-body states, end-effector Jacobian, net arm contact forces.
 //
-// Wave-level structure: "lane = link / dof / brick / matrix entry / candidate pair / contact" in turn; every
-// phase is a lane-strided loop separated by workgroup barriers (the workgroup IS one wave, so a barrier is
-// an s_barrier on a single wave plus the LDS fence).
+// Workgroup structure: one workgroup of 4 wavefronts (256 lanes) per env; "lane = link / dof / brick / matrix entry /
+// candidate pair / contact" in turn; every phase is a lane-strided loop separated by workgroup barriers.  Each lane
+// OWNS up to CPT = 5 contact rows (contact c belongs to lane c % 256): their geometry, effective masses and
+// accumulated impulses stay in VGPRs across all solver iterations, so the iteration loop touches only LDS.
 #include "sdx_common.h"
 
-#define NT SDX_WAVE
+#define NT 512
+#define NWAVE (NT / 64)
+#define CPT ((SDX_MAXC + NT - 1) / NT)   // contact rows owned by one lane
 #define NL SDX_NLINK
 #define ND SDX_NDOF
 #define NF SDX_NFREE
@@ -35,11 +38,23 @@ struct PhysLds {
   int rcount, nc, np, overflow;
   float rc[SDX_MAX_RBOX][3], rq[SDX_MAX_RBOX][4];
   uint32_t pairs[SDX_MAXP];
-  float J[ND][NT];
+  int wsum[NWAVE];       // per-wave totals for block-level scans
   float cf[NL][3];
+  int nrobot;            // contact rows touching the robot in this substep
+  float sincos[NL][2];   // sin/cos of half the joint angle, computed for all joints at once
+  // contact staging [8][SDX_MAXC] written by the narrowphase (ab, p3, n3, sep); after the rows are in registers the
+  // same area is reused by the solver for the per-contact impulse P (3) and moment p x P (3)
+  float stage[8][SDX_MAXC];
+  unsigned char act[SDX_MAXC];
+  unsigned short ent[2 * SDX_MAXC];   // CSR entries: contact index | side << 15, grouped by brick, ascending contact index
+  unsigned short ent2[2 * SDX_MAXC];  // unsorted fill order (scratch of the rank pass)
+  int eoff[NF + 1];
+  int efill[NF];
 };
 
 struct Box { f3 c; f4 q; f3 h; };
+#define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && sub == 0) B.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define SSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && dbg) dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ float box_sdf(f3 p, f3 h, f3* g) {
   f3 d = F3(fabsf(p.x) - h.x, fabsf(p.y) - h.y, fabsf(p.z) - h.z);
@@ -109,15 +124,15 @@ __device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off,
   return cnt;
 }
 
-__device__ __forceinline__ void cwrite(float* cs, int c, int a, int b, f3 p, f3 n, float sep) {
-  cs[0 * SDX_MAXC + c] = __int_as_float(a | (b << 8));
-  cs[1 * SDX_MAXC + c] = p.x; cs[2 * SDX_MAXC + c] = p.y; cs[3 * SDX_MAXC + c] = p.z;
-  cs[4 * SDX_MAXC + c] = n.x; cs[5 * SDX_MAXC + c] = n.y; cs[6 * SDX_MAXC + c] = n.z;
-  cs[7 * SDX_MAXC + c] = sep;
+__device__ __forceinline__ void cwrite(float (*cs)[SDX_MAXC], int c, int a, int b, f3 p, f3 n, float sep) {
+  cs[0][c] = __int_as_float(a | (b << 8));
+  cs[1][c] = p.x; cs[2][c] = p.y; cs[3][c] = p.z;
+  cs[4][c] = n.x; cs[5][c] = n.y; cs[6][c] = n.z;
+  cs[7][c] = sep;
 }
 
-__device__ __forceinline__ void emit_dir(const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k, float* cs,
-                                         int base) {
+__device__ __forceinline__ void emit_dir(const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k,
+                                         float (*cs)[SDX_MAXC], int base) {
   const f4 qbi = qconj(B.q);
   const f3 t = qrot(qbi, A.c - B.c);
   const f4 qrel = qmul(qbi, A.q);
@@ -162,6 +177,7 @@ __device__ void fk(const SdxConst* C, PhysLds& S, int tid) {
     st3(S.lw[0], F3(0, 0, 0));
     st3(S.lc[0], ld3(sc.base_pos) + qrot(ld4(sc.base_quat), ld3(sc.link_com[0])));
   }
+  if (tid > 0 && tid < NL) sincosf(0.5f * S.q[tid - 1], &S.sincos[tid][0], &S.sincos[tid][1]);
   __syncthreads();
   for (int d = 1; d <= C->max_depth; ++d) {
     if (tid > 0 && tid < NL && C->depth[tid] == d) {
@@ -170,7 +186,8 @@ __device__ void fk(const SdxConst* C, PhysLds& S, int tid) {
       const f3 pp = ld3(S.lp[p]);
       const f4 qj = qmul(qp, ld4(sc.joint_quat[k]));
       const f3 ax = ld3(sc.joint_axis[k]);
-      const f4 qk = qnormalize(qmul(qj, qaxis(ax, S.q[k - 1])));
+      f4 qa; qa.x = ax.x * S.sincos[k][0]; qa.y = ax.y * S.sincos[k][0]; qa.z = ax.z * S.sincos[k][0]; qa.w = S.sincos[k][1];
+      const f4 qk = qnormalize(qmul(qj, qa));
       const f3 pk = pp + qrot(qp, ld3(sc.joint_pos[k]));
       const f3 ak = qrot(qj, ax);
       const f3 wp = ld3(S.lw[p]);
@@ -262,7 +279,7 @@ __device__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
       s = S.A[tid][j];
       for (int k = 0; k < j; ++k) s -= S.A[tid][k] * S.A[j][k];
     }
-    const float d = sqrtf(__shfl(s, j, NT));
+    const float d = sqrtf(__shfl(s, j, 64));   // rows 0..22 live in wave 0; other waves idle through this loop
     if (tid >= j && tid < ND) S.A[tid][j] = (tid == j) ? d : s / d;
     __syncthreads();
   }
@@ -291,14 +308,48 @@ __device__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
   __syncthreads();
 }
 
+// ---------------------------------------------------------------- block-level exclusive scan helpers (NT = 4 waves)
+// exclusive prefix of a 0/1 flag over the workgroup in thread order; *total = number of set flags.  Two barriers.
+__device__ __forceinline__ int block_scan_flag(PhysLds& S, bool flag, int tid, int* total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint64_t bal = __ballot(flag);
+  if (lane == 0) S.wsum[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVE; ++w) { const int c = S.wsum[w]; if (w < wave) off += c; tot += c; }
+  __syncthreads();
+  *total = tot;
+  return off + __popcll(bal & lt);
+}
+// exclusive prefix of a small count k (0..4)
+__device__ __forceinline__ int block_scan_small(PhysLds& S, int k, int tid, int* total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int pre = 0, wt = 0;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const uint64_t bal = __ballot((k >> b) & 1);
+    pre += __popcll(bal & lt) << b;
+    wt += __popcll(bal) << b;
+  }
+  if (lane == 0) S.wsum[wave] = wt;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVE; ++w) { const int c = S.wsum[w]; if (w < wave) off += c; tot += c; }
+  __syncthreads();
+  *total = tot;
+  return off + pre;
+}
+
 // ---------------------------------------------------------------- D: contacts
-__device__ void collide(const SdxConst* C, PhysLds& S, int tid, float* cs) {
+__device__ void collide(const SdxConst* C, PhysLds& S, int tid) {
+  float (*cs)[SDX_MAXC] = S.stage;
   const sdx_scene_desc& sc = C->sc;
   const float off = sc.contact_offset;
   const int ns = sc.n_static;
-  const uint64_t lt_mask = (tid == 0) ? 0ull : (~0ull >> (64 - tid));
-  if (tid == 0) { S.np = 0; S.nc = 0; S.overflow = 0; }
-  __syncthreads();
   // ---- broadphase: fixed enumeration order (brick/static, brick/brick, then per robot box: bricks, statics)
   const int n1 = NF * ns, n2 = NF * NF, per = NF + ns, n3 = sc.n_rbox * per;
   int np = 0;
@@ -336,16 +387,14 @@ __device__ void collide(const SdxConst* C, PhysLds& S, int tid, float* cs) {
         }
       }
     }
-    const uint64_t bal = __ballot(hit);
-    if (hit) {
-      const int pos = np + __popcll(bal & lt_mask);
-      if (pos < SDX_MAXP) S.pairs[pos] = pr;
-    }
-    np += __popcll(bal);
+    int tot;
+    const int pos = np + block_scan_flag(S, hit, tid, &tot);
+    if (hit && pos < SDX_MAXP) S.pairs[pos] = pr;
+    np += tot;
   }
   if (np > SDX_MAXP) np = SDX_MAXP;
   __syncthreads();
-  // ---- narrowphase: lane = candidate pair; contacts appended in pair order (wave prefix sum of the counts)
+  // ---- narrowphase: lane = candidate pair; contacts appended in pair order (block prefix sum of the counts)
   int nc = 0;
   for (int base = 0; base < np; base += NT) {
     const int pi = base + tid;
@@ -365,15 +414,8 @@ __device__ void collide(const SdxConst* C, PhysLds& S, int tid, float* cs) {
       k1 = c1 < 4 - m2 ? c1 : 4 - m2;
       k2 = c2 < 4 - k1 ? c2 : 4 - k1;
     }
-    const int k = k1 + k2;
-    // exclusive prefix sum of k (0..4) over the wave via three ballots
-    int pre = 0, tot = 0;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const uint64_t bal = __ballot((k >> b) & 1);
-      pre += __popcll(bal & lt_mask) << b;
-      tot += __popcll(bal) << b;
-    }
+    int tot;
+    const int pre = block_scan_small(S, k1 + k2, tid, &tot);
     if (k1 > 0) emit_dir(A, B, ida, idb, p1, k1, cs, nc + pre);
     if (k2 > 0) emit_dir(B, A, idb, ida, p2, k2, cs, nc + pre + k1);
     nc += tot;
@@ -381,167 +423,322 @@ __device__ void collide(const SdxConst* C, PhysLds& S, int tid, float* cs) {
   if (tid == 0) {
     S.overflow = nc > SDX_MAXC ? nc - SDX_MAXC : 0;
     S.nc = nc > SDX_MAXC ? SDX_MAXC : nc;
+    S.np = np;
   }
   __syncthreads();
 }
 
 // ---------------------------------------------------------------- E: solver
-__device__ void solve(const SdxConst* C, PhysLds& S, int tid, float* cs, float h) {
+// contact rows owned by this lane, held in registers for the whole solve
+struct Rows {
+  int a[CPT], b[CPT];
+  f3 p[CPT], n[CPT];
+  float sep[CPT], lam[CPT][3], wA[CPT][3], wB[CPT][3];
+};
+
+// row weight of the robot side: J Hinv J^T with J_j = (a_j x (p - p_j)) . d over the <= 11 dofs on the link's path
+__device__ __attribute__((noinline)) float robot_w(const SdxConst* C, const PhysLds& S, int k, f3 p, f3 d) {
+  float Jp[11];
+  int idx[11];
+  uint32_t m = C->anc[k];
+#pragma unroll
+  for (int q = 0; q < 11; ++q) {
+    if (m) {
+      const int j = __ffs(m) - 1;
+      m &= m - 1;
+      idx[q] = j;
+      Jp[q] = dot(cross(ld3(S.la[j + 1]), p - ld3(S.lp[j + 1])), d);
+    } else { idx[q] = 0; Jp[q] = 0.0f; }
+  }
+  float acc = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 11; ++q) {
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 11; ++r) t += S.A[idx[q]][idx[r]] * Jp[r];
+    acc += Jp[q] * t;
+  }
+  return acc;
+}
+
+__device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last_substep, long long* dbg) {
   const sdx_scene_desc& sc = C->sc;
   const int nc = S.nc;
   const float mu = sc.friction;
-  // un-split inverse effective masses per row and side; zero the accumulated impulses
-  for (int base = 0; base < nc; base += NT) {
-    const int c = base + tid;
-    const bool on = c < nc;
-    int a = SDX_BODY_STATIC, b = SDX_BODY_STATIC;
-    f3 p = F3(0, 0, 0), n = F3(0, 0, 1), t1, t2;
-    if (on) {
-      const int ab = __float_as_int(cs[c]);
-      a = ab & 0xff; b = (ab >> 8) & 0xff;
-      p = F3(cs[1 * SDX_MAXC + c], cs[2 * SDX_MAXC + c], cs[3 * SDX_MAXC + c]);
-      n = F3(cs[4 * SDX_MAXC + c], cs[5 * SDX_MAXC + c], cs[6 * SDX_MAXC + c]);
+  Rows R;
+  SSTAMP(16);
+  // ---- this lane's rows from the LDS staging area into registers
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const int c = tid + q * NT;
+    R.a[q] = SDX_BODY_STATIC; R.b[q] = SDX_BODY_STATIC;
+    R.p[q] = F3(0, 0, 0); R.n[q] = F3(0, 0, 1); R.sep[q] = 1.0f;
+    if (c < nc) {
+      const int ab = __float_as_int(S.stage[0][c]);
+      R.a[q] = ab & 0xff; R.b[q] = (ab >> 8) & 0xff;
+      R.p[q] = F3(S.stage[1][c], S.stage[2][c], S.stage[3][c]);
+      R.n[q] = F3(S.stage[4][c], S.stage[5][c], S.stage[6][c]);
+      R.sep[q] = S.stage[7][c];
     }
-    tangents(n, &t1, &t2);
-    const f3 dir[3] = {n, t1, t2};
-    const int ids[2] = {a, b};
+  }
+  // ---- CSR of contact sides per brick (ascending contact index inside a brick = the oracle's summation order)
+  for (int i = tid; i < NF; i += NT) { S.bcount[i] = 0; S.efill[i] = 0; }
+  if (tid == 0) S.nrobot = 0;
+  __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int id = ids[s];
-      const bool robot = on && id >= NF && id != SDX_BODY_STATIC;
-      const bool any_robot = __any(robot);
+  for (int q = 0; q < CPT; ++q)
+    if (tid + q * NT < nc) {
+      const int a = R.a[q], b = R.b[q];
+      if (a < NF) atomicAdd(&S.bcount[a], 1); else if (a != SDX_BODY_STATIC) atomicAdd(&S.nrobot, 1);
+      if (b < NF) atomicAdd(&S.bcount[b], 1); else if (b != SDX_BODY_STATIC) atomicAdd(&S.nrobot, 1);
+    }
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int i = 0; i < NF; ++i) { S.eoff[i] = o; o += S.bcount[i]; }
+    S.eoff[NF] = o;
+  }
+  __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        float w = 0.0f;
-        if (on && id < NF) w = brick_w(C, S, id, p, dir[r]);
-        if (any_robot) {  // J row staged in LDS (dof-major, lane-minor), then w = J Hinv J^T
-          const int k = robot ? id - NF : 0;
-          const uint32_t m = robot ? C->anc[k] : 0u;
-          for (int j = 0; j < ND; ++j)
-            S.J[j][tid] = ((m >> j) & 1u) ? dot(cross(ld3(S.la[j + 1]), p - ld3(S.lp[j + 1])), dir[r]) : 0.0f;
-          if (robot) {
-            float acc = 0.0f;
-            for (int i = 0; i < ND; ++i) {
-              const float Ji = S.J[i][tid];
-              if (Ji == 0.0f) continue;
-              float t = 0.0f;
-              for (int j = 0; j < ND; ++j) t += S.A[i][j] * S.J[j][tid];
-              acc += Ji * t;
-            }
-            w = acc;
-          }
-        }
-        if (on) cs[(11 + 3 * s + r) * SDX_MAXC + c] = w;
+  for (int q = 0; q < CPT; ++q) {
+    const int c = tid + q * NT;
+    if (c < nc) {
+      const int a = R.a[q], b = R.b[q];
+      if (a < NF) S.ent2[S.eoff[a] + atomicAdd(&S.efill[a], 1)] = (unsigned short)c;
+      if (b < NF) S.ent2[S.eoff[b] + atomicAdd(&S.efill[b], 1)] = (unsigned short)(c | 0x8000);
+    }
+  }
+  __syncthreads();
+  // rank pass: entry -> position = number of entries of the same brick with a smaller contact index (a contact touches
+  // a brick at most once, so indices are distinct) => every brick's list is in ascending contact order, deterministically
+  {
+    const int total = S.eoff[NF];
+    for (int i = tid; i < total; i += NT) {
+      int lo = 0, hi = NF;                       // brick of entry i: largest b with eoff[b] <= i
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.eoff[mid] <= i) lo = mid; else hi = mid; }
+      const int o = S.eoff[lo], n = S.eoff[lo + 1] - o;
+      const unsigned short v = S.ent2[i];
+      const int key = v & 0x7fff;
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (S.ent2[o + j] & 0x7fff) < key;
+      S.ent[o + rank] = v;
+    }
+  }
+  __syncthreads();
+  const bool has_robot = S.nrobot > 0;   // block-uniform (read after the barrier above)
+  // ---- un-split inverse effective masses per row and side; zero accumulated impulses
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const bool on = tid + q * NT < nc;
+    f3 t1, t2;
+    tangents(R.n[q], &t1, &t2);
+    const f3 dir[3] = {R.n[q], t1, t2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float wa = 0.0f, wb = 0.0f;
+      if (on) {
+        const int a = R.a[q], b = R.b[q];
+        if (a < NF) wa = brick_w(C, S, a, R.p[q], dir[r]);
+        else if (a != SDX_BODY_STATIC) wa = robot_w(C, S, a - NF, R.p[q], dir[r]);
+        if (b < NF) wb = brick_w(C, S, b, R.p[q], dir[r]);
+        else if (b != SDX_BODY_STATIC) wb = robot_w(C, S, b - NF, R.p[q], dir[r]);
       }
-    }
-    if (on) {
-      cs[8 * SDX_MAXC + c] = 0.0f; cs[9 * SDX_MAXC + c] = 0.0f; cs[10 * SDX_MAXC + c] = 0.0f;
+      R.wA[q][r] = wa; R.wB[q][r] = wb; R.lam[q][r] = 0.0f;
     }
   }
   if (tid < ND) { S.qds[tid] = S.qd[tid]; }
+  // gather lanes: GL lanes per brick (tid = GL*brick + sub), each caches its slice of the brick's entry list (entries
+  // sub, sub+4, ... up to GE of them) in registers for all iterations
+  constexpr int GE = 8, GL = 4;   // GL lanes per brick, GE cached entries per lane
+  const int gbrick = tid / GL, gsub = tid % GL;
+  const bool glane = gbrick < NF;
+  int gent[GE];
+  int gn = 0, gbeg = 0, gend = 0;
+  if (glane) {
+    gbeg = S.eoff[gbrick]; gend = S.eoff[gbrick + 1];
+#pragma unroll
+    for (int k = 0; k < GE; ++k) {
+      const int i = gbeg + gsub + GL * k;
+      gent[k] = i < gend ? (int)S.ent[i] : -1;
+      if (i < gend) gn = k + 1;
+    }
+  }
   __syncthreads();
+  SSTAMP(17);
+  float (*Pm)[SDX_MAXC] = S.stage;   // rows 0..2: impulse P of the contact (on A), rows 3..5: p x P
 
   for (int it = 0; it < sc.solver_iters; ++it) {
-    for (int i = tid; i < NF; i += NT) {
-      S.bcount[i] = 0;
-      S.dv[i][0] = S.dv[i][1] = S.dv[i][2] = 0.0f;
-      S.dw[i][0] = S.dw[i][1] = S.dw[i][2] = 0.0f;
+    if (it == 1) dbg = nullptr;
+    SSTAMP(18);
+    // pass 1 (lane = contact): relative velocity, active flag
+    f3 vr[CPT];
+    bool act[CPT];
+    int ract = 0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      act[q] = false;
+      vr[q] = F3(0, 0, 0);
+      const int c = tid + q * NT;
+      if (c < nc) {
+        const int a = R.a[q], b = R.b[q];
+        vr[q] = point_vel(S, a, R.p[q]) - point_vel(S, b, R.p[q]);
+        const float sep = R.sep[q];
+        const float target = sep > 0 ? -sep / h : fminf(sc.baumgarte * (-sep) / h, sc.max_depenetration_vel);
+        act[q] = R.lam[q][0] > 0.0f || dot(vr[q], R.n[q]) < target;
+        S.act[c] = act[q] ? 1 : 0;
+        if (act[q]) ract += (a >= NF && a != SDX_BODY_STATIC) + (b >= NF && b != SDX_BODY_STATIC);
+      }
     }
     if (tid < ND) S.dQ[tid] = 0.0f;
     if (tid == 0) S.rcount = 0;
     __syncthreads();
-    // pass 1: active set, per-body counts of ACTIVE contacts
-    for (int base = 0; base < nc; base += NT) {
-      const int c = base + tid;
-      if (c < nc) {
-        const int ab = __float_as_int(cs[c]);
-        const int a = ab & 0xff, b = (ab >> 8) & 0xff;
-        const f3 p = F3(cs[1 * SDX_MAXC + c], cs[2 * SDX_MAXC + c], cs[3 * SDX_MAXC + c]);
-        const f3 n = F3(cs[4 * SDX_MAXC + c], cs[5 * SDX_MAXC + c], cs[6 * SDX_MAXC + c]);
-        const float sep = cs[7 * SDX_MAXC + c];
-        const float lam0 = cs[8 * SDX_MAXC + c];
-        const f3 vr = point_vel(S, a, p) - point_vel(S, b, p);
-        const float target = sep > 0 ? -sep / h : fminf(sc.baumgarte * (-sep) / h, sc.max_depenetration_vel);
-        if (lam0 > 0.0f || dot(vr, n) < target) {
-          if (a < NF) atomicAdd(&S.bcount[a], 1); else if (a != SDX_BODY_STATIC) atomicAdd(&S.rcount, 1);
-          if (b < NF) atomicAdd(&S.bcount[b], 1); else if (b != SDX_BODY_STATIC) atomicAdd(&S.rcount, 1);
-        }
-      }
+    SSTAMP(19);
+    // counts of ACTIVE contacts per brick (4 lanes per brick, quad reduction) and on the robot
+    if (glane) {
+      int n = 0;
+#pragma unroll
+      for (int k = 0; k < GE; ++k) if (k < gn) n += S.act[gent[k] & 0x7fff];
+      for (int i = gbeg + gsub + GL * GE; i < gend; i += GL) n += S.act[S.ent[i] & 0x7fff];
+      n += __shfl_xor(n, 1, 64);
+      n += __shfl_xor(n, 2, 64);
+      if (GL == 8) n += __shfl_xor(n, 4, 64);
+      if (gsub == 0) S.bcount[gbrick] = n;
     }
+    if (has_robot && ract) atomicAdd(&S.rcount, ract);
     __syncthreads();
-    // pass 2: Jacobi update from the same velocity snapshot
-    for (int base = 0; base < nc; base += NT) {
-      const int c = base + tid;
-      if (c < nc) {
-        const int ab = __float_as_int(cs[c]);
-        const int a = ab & 0xff, b = (ab >> 8) & 0xff;
-        const f3 p = F3(cs[1 * SDX_MAXC + c], cs[2 * SDX_MAXC + c], cs[3 * SDX_MAXC + c]);
-        const f3 n = F3(cs[4 * SDX_MAXC + c], cs[5 * SDX_MAXC + c], cs[6 * SDX_MAXC + c]);
-        const float sep = cs[7 * SDX_MAXC + c];
-        float lam0 = cs[8 * SDX_MAXC + c], lam1 = cs[9 * SDX_MAXC + c], lam2 = cs[10 * SDX_MAXC + c];
-        const f3 vr = point_vel(S, a, p) - point_vel(S, b, p);
+    SSTAMP(20);
+    // pass 2 (lane = contact): Jacobi update from the same velocity snapshot; P and p x P to LDS
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const int c = tid + q * NT;
+      f3 P = F3(0, 0, 0);
+      if (act[q]) {
+        const int a = R.a[q], b = R.b[q];
+        const f3 n = R.n[q];
+        const float sep = R.sep[q];
         const float target = sep > 0 ? -sep / h : fminf(sc.baumgarte * (-sep) / h, sc.max_depenetration_vel);
-        const float vn = dot(vr, n);
-        if (lam0 > 0.0f || vn < target) {
-          f3 t1, t2;
-          tangents(n, &t1, &t2);
-          const float na = a == SDX_BODY_STATIC ? 0.0f : (a < NF ? (float)S.bcount[a] : (float)S.rcount);
-          const float nb = b == SDX_BODY_STATIC ? 0.0f : (b < NF ? (float)S.bcount[b] : (float)S.rcount);
-          const float w0 = na * cs[11 * SDX_MAXC + c] + nb * cs[14 * SDX_MAXC + c];
-          const float w1 = na * cs[12 * SDX_MAXC + c] + nb * cs[15 * SDX_MAXC + c];
-          const float w2 = na * cs[13 * SDX_MAXC + c] + nb * cs[16 * SDX_MAXC + c];
-          const float ln = fmaxf(0.0f, lam0 - sc.jacobi_relax * (vn - target) / w0);
-          const float d0 = ln - lam0;
-          const float lim = mu * ln;
-          float l1 = lam1 - sc.jacobi_relax * dot(vr, t1) / w1;
-          l1 = fminf(lim, fmaxf(-lim, l1));
-          const float d1 = l1 - lam1;
-          float l2 = lam2 - sc.jacobi_relax * dot(vr, t2) / w2;
-          l2 = fminf(lim, fmaxf(-lim, l2));
-          const float d2 = l2 - lam2;
-          cs[8 * SDX_MAXC + c] = ln; cs[9 * SDX_MAXC + c] = l1; cs[10 * SDX_MAXC + c] = l2;
-          const f3 P = n * d0 + t1 * d1 + t2 * d2;
+        f3 t1, t2;
+        tangents(n, &t1, &t2);
+        const float na = a == SDX_BODY_STATIC ? 0.0f : (a < NF ? (float)S.bcount[a] : (float)S.rcount);
+        const float nb = b == SDX_BODY_STATIC ? 0.0f : (b < NF ? (float)S.bcount[b] : (float)S.rcount);
+        const float w0 = na * R.wA[q][0] + nb * R.wB[q][0];
+        const float w1 = na * R.wA[q][1] + nb * R.wB[q][1];
+        const float w2 = na * R.wA[q][2] + nb * R.wB[q][2];
+        const float lam0 = R.lam[q][0], lam1 = R.lam[q][1], lam2 = R.lam[q][2];
+        const float ln = fmaxf(0.0f, lam0 - sc.jacobi_relax * (dot(vr[q], n) - target) / w0);
+        const float lim = mu * ln;
+        float l1 = lam1 - sc.jacobi_relax * dot(vr[q], t1) / w1;
+        l1 = fminf(lim, fmaxf(-lim, l1));
+        float l2 = lam2 - sc.jacobi_relax * dot(vr[q], t2) / w2;
+        l2 = fminf(lim, fmaxf(-lim, l2));
+        R.lam[q][0] = ln; R.lam[q][1] = l1; R.lam[q][2] = l2;
+        P = n * (ln - lam0) + t1 * (l1 - lam1) + t2 * (l2 - lam2);
+        if (has_robot) {   // robot side: generalised impulse J^T P (few rows; LDS atomics)
           const int ids[2] = {a, b};
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const int id = ids[s];
-            const f3 Ps = s == 0 ? P : P * -1.0f;
-            if (id == SDX_BODY_STATIC) continue;
-            if (id < NF) {
-              const int t = sc.brick_type[id];
-              const float im = 1.0f / sc.brick_mass[t];
-              atomicAdd(&S.dv[id][0], Ps.x * im); atomicAdd(&S.dv[id][1], Ps.y * im); atomicAdd(&S.dv[id][2], Ps.z * im);
-              const f4 q = ld4(S.bq[id]);
-              const f3 l = qrot(qconj(q), cross(p - ld3(S.bp[id]), Ps));
-              const float* I = sc.brick_inertia[t];
-              const f3 dw = qrot(q, F3(l.x / I[0], l.y / I[1], l.z / I[2]));
-              atomicAdd(&S.dw[id][0], dw.x); atomicAdd(&S.dw[id][1], dw.y); atomicAdd(&S.dw[id][2], dw.z);
-            } else {
+            if (id >= NF && id != SDX_BODY_STATIC) {
+              const f3 Ps = s == 0 ? P : P * -1.0f;
               uint32_t m = C->anc[id - NF];
               while (m) {
                 const int j = __ffs(m) - 1;
                 m &= m - 1;
-                atomicAdd(&S.dQ[j], dot(cross(ld3(S.la[j + 1]), p - ld3(S.lp[j + 1])), Ps));
+                atomicAdd(&S.dQ[j], dot(cross(ld3(S.la[j + 1]), R.p[q] - ld3(S.lp[j + 1])), Ps));
               }
             }
           }
         }
       }
+      if (c < nc) {
+        const f3 M = cross(R.p[q], P);
+        Pm[0][c] = P.x; Pm[1][c] = P.y; Pm[2][c] = P.z;
+        Pm[3][c] = M.x; Pm[4][c] = M.y; Pm[5][c] = M.z;
+      }
     }
     __syncthreads();
-    for (int i = tid; i < NF; i += NT) {
-      S.bv[i][0] += S.dv[i][0]; S.bv[i][1] += S.dv[i][1]; S.bv[i][2] += S.dv[i][2];
-      S.bw[i][0] += S.dw[i][0]; S.bw[i][1] += S.dw[i][1]; S.bw[i][2] += S.dw[i][2];
+    SSTAMP(21);
+    // gather (4 lanes per brick): dv = sum(+-P)/m, dw = Iw^-1 (sum(+-(p x P)) - x x sum(+-P)); each lane sums its
+    // slice in ascending contact order, the four partial sums are combined in a fixed order (deterministic)
+    if (glane) {
+      float acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < GE; ++k)
+        if (k < gn) {
+          const int e = gent[k], c = e & 0x7fff;
+          if (S.act[c]) {
+            const float sg = (e & 0x8000) ? -1.0f : 1.0f;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[r] += Pm[r][c] * sg;
+          }
+        }
+      for (int i = gbeg + gsub + GL * GE; i < gend; i += GL) {
+        const int e = S.ent[i], c = e & 0x7fff;
+        if (S.act[c]) {
+          const float sg = (e & 0x8000) ? -1.0f : 1.0f;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) acc[r] += Pm[r][c] * sg;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        acc[r] += __shfl_xor(acc[r], 1, 64);
+        acc[r] += __shfl_xor(acc[r], 2, 64);
+        if (GL == 8) acc[r] += __shfl_xor(acc[r], 4, 64);
+      }
+      if (gsub == 0) {
+        const f3 sp = F3(acc[0], acc[1], acc[2]), sm = F3(acc[3], acc[4], acc[5]);
+        const int t = sc.brick_type[gbrick];
+        const f3 x = ld3(S.bp[gbrick]);
+        const f4 qq = ld4(S.bq[gbrick]);
+        const f3 tau = sm - cross(x, sp);
+        const f3 l = qrot(qconj(qq), tau);
+        const float* I = sc.brick_inertia[t];
+        const f3 dw = qrot(qq, F3(l.x / I[0], l.y / I[1], l.z / I[2]));
+        const float im = 1.0f / sc.brick_mass[t];
+        st3(S.bv[gbrick], ld3(S.bv[gbrick]) + sp * im);
+        st3(S.bw[gbrick], ld3(S.bw[gbrick]) + dw);
+      }
     }
-    if (tid < ND) S.Q[tid] += S.dQ[tid];
+    if (has_robot) {
+      if (tid >= 64 && tid < 64 + ND) S.Q[tid - 64] += S.dQ[tid - 64];
+      __syncthreads();
+      if (tid < ND) {
+        float sacc = S.qds[tid];
+        for (int j = 0; j < ND; ++j) sacc += S.A[tid][j] * S.Q[j];
+        S.qd[tid] = sacc;
+      }
+      __syncthreads();
+      SSTAMP(22);
+      twists(C, S, tid);
+    } else {
+      __syncthreads();
+      SSTAMP(22);
+    }
+    SSTAMP(23);
+  }
+  // net contact force on the robot bodies from the last substep's accumulated impulses (GS:1094; bodies 1..6 are read)
+  if (last_substep) {
+    for (int i = tid; i < NL * 3; i += NT) (&S.cf[0][0])[i] = 0.0f;
     __syncthreads();
-    if (tid < ND) {
-      float s = S.qds[tid];
-      for (int j = 0; j < ND; ++j) s += S.A[tid][j] * S.Q[j];
-      S.qd[tid] = s;
+    if (has_robot) {
+      const float ih = 1.0f / h;
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) {
+        if (tid + q * NT < nc) {
+          const int a = R.a[q], b = R.b[q];
+          const bool ra = a >= NF && a != SDX_BODY_STATIC, rbb = b >= NF && b != SDX_BODY_STATIC;
+          if (ra || rbb) {
+            f3 t1, t2;
+            tangents(R.n[q], &t1, &t2);
+            const f3 P = (R.n[q] * R.lam[q][0] + t1 * R.lam[q][1] + t2 * R.lam[q][2]) * ih;
+            if (ra) { atomicAdd(&S.cf[a - NF][0], P.x); atomicAdd(&S.cf[a - NF][1], P.y); atomicAdd(&S.cf[a - NF][2], P.z); }
+            if (rbb) { atomicAdd(&S.cf[b - NF][0], -P.x); atomicAdd(&S.cf[b - NF][1], -P.y); atomicAdd(&S.cf[b - NF][2], -P.z); }
+          }
+        }
+      }
     }
     __syncthreads();
-    twists(C, S, tid);
   }
 }
 
@@ -568,13 +765,12 @@ __device__ void write_kinematics(const SdxConst* C, PhysLds& S, const SdxBuf& B,
 }
 
 // ---------------------------------------------------------------- the step kernel
-__global__ __launch_bounds__(NT) void k_physics(const SdxConst* __restrict__ C, SdxBuf B) {
+__global__ __launch_bounds__(NT, 2) void k_physics(const SdxConst* __restrict__ C, SdxBuf B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PhysLds& S = *reinterpret_cast<PhysLds*>(smem);
   const int e = blockIdx.x, tid = threadIdx.x;
   const sdx_scene_desc& sc = C->sc;
   float* root_e = B.root + (size_t)e * SDX_ACTORS * 13;
-  float* cs = B.cscratch + (size_t)e * SDX_CFIELDS * SDX_MAXC;
   const float h = sc.dt / (float)sc.substeps;
 
   // ---- load per-env state (coalesced rows) into LDS
@@ -594,8 +790,11 @@ __global__ __launch_bounds__(NT) void k_physics(const SdxConst* __restrict__ C, 
   __syncthreads();
 
   for (int sub = 0; sub < sc.substeps; ++sub) {
+    PSTAMP(0);
     fk(C, S, tid);
-    mass_matrix(C, S, tid, h);
+    PSTAMP(1);
+    if (sub == 0) mass_matrix(C, S, tid, h);   // M(q) is evaluated once per step (frozen over the substeps)
+    PSTAMP(2);
     // C: implicit PD drive (P1) + gravity on the free bricks
     if (tid < ND) {
       const float t = sc.kp[tid] * (S.tgt[tid] - S.q[tid]) - (sc.kd[tid] + h * sc.kp[tid]) * S.qd[tid];
@@ -613,8 +812,11 @@ __global__ __launch_bounds__(NT) void k_physics(const SdxConst* __restrict__ C, 
     }
     __syncthreads();
     twists(C, S, tid);
-    collide(C, S, tid, cs);
-    solve(C, S, tid, cs, h);
+    PSTAMP(3);
+    collide(C, S, tid);
+    PSTAMP(4);
+    solve(C, S, tid, h, sub == sc.substeps - 1, sub == 0 ? B.dbg : nullptr);
+    PSTAMP(5);
     // F: integrate
     if (tid < ND) {
       float v = fminf(sc.vel_limit[tid], fmaxf(-sc.vel_limit[tid], S.qd[tid]));
@@ -635,6 +837,7 @@ __global__ __launch_bounds__(NT) void k_physics(const SdxConst* __restrict__ C, 
       st4(S.bq[i], qnormalize(nq));
     }
     __syncthreads();
+    PSTAMP(6);
   }
 
   // ---- outputs (refresh_* of GS:1091-1095)
@@ -657,25 +860,6 @@ __global__ __launch_bounds__(NT) void k_physics(const SdxConst* __restrict__ C, 
     root_e[SDX_ACTOR_BRICK0 * 13 + i] = v;
     rb_e[SDX_BODY_BRICK0 * 13 + i] = v;
   }
-  // net contact force on the robot bodies from the last substep's impulses (GS:1094; bodies 1..6 are read)
-  for (int i = tid; i < NL * 3; i += NT) (&S.cf[0][0])[i] = 0.0f;
-  __syncthreads();
-  const int nc = S.nc;
-  const float ih = 1.0f / h;
-  for (int c = tid; c < nc; c += NT) {
-    const int ab = __float_as_int(cs[c]);
-    const int a = ab & 0xff, b = (ab >> 8) & 0xff;
-    const bool ra = a >= NF && a != SDX_BODY_STATIC, rbb = b >= NF && b != SDX_BODY_STATIC;
-    if (ra || rbb) {
-      const f3 n = F3(cs[4 * SDX_MAXC + c], cs[5 * SDX_MAXC + c], cs[6 * SDX_MAXC + c]);
-      f3 t1, t2;
-      tangents(n, &t1, &t2);
-      const f3 P = (n * cs[8 * SDX_MAXC + c] + t1 * cs[9 * SDX_MAXC + c] + t2 * cs[10 * SDX_MAXC + c]) * ih;
-      if (ra) { atomicAdd(&S.cf[a - NF][0], P.x); atomicAdd(&S.cf[a - NF][1], P.y); atomicAdd(&S.cf[a - NF][2], P.z); }
-      if (rbb) { atomicAdd(&S.cf[b - NF][0], -P.x); atomicAdd(&S.cf[b - NF][1], -P.y); atomicAdd(&S.cf[b - NF][2], -P.z); }
-    }
-  }
-  __syncthreads();
   for (int i = tid; i < NL * 3; i += NT) B.contact[(size_t)e * SDX_BODIES * 3 + i] = (&S.cf[0][0])[i];
   if (tid == 0) B.ncontacts[e] = S.nc + S.overflow;
 }
@@ -695,9 +879,18 @@ __global__ __launch_bounds__(NT) void k_kinematics(const SdxConst* __restrict__ 
 }
 
 extern "C" size_t sdxk_physics_lds_bytes() { return sizeof(PhysLds); }
+static void ensure_lds_attr() {   // PhysLds exceeds the default 64 KiB dynamic-LDS limit (gfx950 has 160 KiB per CU)
+  static bool done = false;
+  if (done) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_physics), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PhysLds));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_kinematics), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PhysLds));
+  done = true;
+}
 extern "C" void sdxk_physics(const SdxConst* C, const SdxBuf* B, hipStream_t st) {
+  ensure_lds_attr();
   hipLaunchKernelGGL(k_physics, dim3(B->N), dim3(NT), sizeof(PhysLds), st, C, *B);
 }
 extern "C" void sdxk_kinematics(const SdxConst* C, const SdxBuf* B, hipStream_t st) {
+  ensure_lds_attr();
   hipLaunchKernelGGL(k_kinematics, dim3(B->N), dim3(NT), sizeof(PhysLds), st, C, *B);
 }

@@ -16,3 +16,8 @@ print('sim us', tm(lambda: s.simulate()))
 print('post us', tm(lambda: s.post_physics()))
 print('nc', s.NCONTACTS.float().mean().item(), s.NCONTACTS.max().item())
 print('progress', s.PROGRESS[:4].tolist(), 'rew', s.REW[:4].tolist())
+
+import numpy as np
+d=s.DEBUG.cpu().numpy()
+print('k_physics env0 substep0 phase cycles [fk, mass, pd+twists, collide, solve, integrate]:', np.diff(d[:7]), 'np/nc env0', int(s.NCONTACTS[0]))
+print('solve: [load rows, w prep | it0: zero, pass1, pass2, bodyupd+qd, twists]', np.diff(d[16:24]))
