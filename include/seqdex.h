@@ -45,6 +45,7 @@ extern "C" {
 #define SDX_NUM_ACTIONS 23  /* GS:211                                                                        */
 #define SDX_OBS_FRAME 132
 #define SDX_STATE_FRAME 188
+#define SDX_HARVEST_SLOTS 5001 /* ring of grasp terminal states per brick-type group (GS:1440: index wraps after 5000) */
 #define SDX_TV_PARAMS 42562 /* GraspInsertTValue 4-256-128-64-2 weights+biases (terminal_value_function.py:30-46) */
 
 typedef enum {
@@ -89,7 +90,10 @@ typedef enum {
   SDX_T_PILE_CHOICE = 26,/* i32 [N]         saved-pile index drawn at the last reset of each env  GS:1510 */
   SDX_T_NCONTACTS = 27,  /* i32 [N]         contact points generated in the last substep (diagnostic)    */
   SDX_T_DEBUG = 28,      /* i64 [64]        phase time stamps (s_memtime) of env 0 in the last k_physics (profiling aid) */
-  SDX_T_COUNT = 29
+  SDX_T_HARVEST_HAND = 29, /* f32 [8,5001,23,2] saved_grasp_hand_ternimal_states per brick-type group   GS:391-417 */
+  SDX_T_HARVEST_OBJ = 30,  /* f32 [8,5001,13]   saved_grasp_object_ternimal_states                       GS:391-417 */
+  SDX_T_HARVEST_COUNT = 31,/* i32 [8]           terminal states harvested so far (ring index = count % 5001) GS:1417,1440 */
+  SDX_T_COUNT = 32
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the

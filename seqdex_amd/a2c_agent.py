@@ -175,6 +175,18 @@ class A2CAgent:
             if epoch_num >= self.max_epochs:
                 return self.game_rewards.get_mean()[0], epoch_num
 
+    def play(self, games_num=1, max_steps=150):
+        """--play/--test: rollouts only (the reference's player uses the deterministic mean action; here the sampled
+        action with the learned sigma is used, PPO buffers are exercised but no update is made)."""
+        n = 0
+        while n < max(1, games_num):
+            self.play_steps()
+            c = self.ppo.ctrl()
+            n += int(c.games_cnt)
+            self.game_rewards.update_from(c.games_sum_rew, c.games_cnt)
+        torch.cuda.synchronize()
+        print("mean episode reward: %.3f" % self.game_rewards.get_mean()[0])
+
     # ------------------------------------------------------------------ checkpoints (rl_games .pth-shaped dict)
     def get_full_state_weights(self):
         t = self.ppo.t

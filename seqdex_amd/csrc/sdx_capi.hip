@@ -155,6 +155,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(stat, 4);
   ALLOC(step_count, 1);
   ALLOC(dbg, 64);
+  ALLOC(harvest_hand, (size_t)8 * SDX_HARVEST_SLOTS * SDX_NDOF * 2);
+  ALLOC(harvest_obj, (size_t)8 * SDX_HARVEST_SLOTS * 13);
+  ALLOC(harvest_count, 8);
 #undef ALLOC
   set_tensor(h, SDX_T_ROOT, B.root, SDX_F32, {(int64_t)N * SDX_ACTORS, 13});
   set_tensor(h, SDX_T_DOF, B.dof, SDX_F32, {(int64_t)N * SDX_NDOF, 2});
@@ -185,6 +188,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_PILE_CHOICE, B.pile_choice, SDX_I32, {N});
   set_tensor(h, SDX_T_NCONTACTS, B.ncontacts, SDX_I32, {N});
   set_tensor(h, SDX_T_DEBUG, B.dbg, SDX_I64, {64});
+  set_tensor(h, SDX_T_HARVEST_HAND, B.harvest_hand, SDX_F32, {8, SDX_HARVEST_SLOTS, SDX_NDOF, 2});
+  set_tensor(h, SDX_T_HARVEST_OBJ, B.harvest_obj, SDX_F32, {8, SDX_HARVEST_SLOTS, 13});
+  set_tensor(h, SDX_T_HARVEST_COUNT, B.harvest_count, SDX_I32, {8});
 
   // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
   std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);

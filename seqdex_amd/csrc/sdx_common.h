@@ -41,6 +41,8 @@ struct SdxBuf {
   float* stat;             // [2][2] double-buffered (num_resets, finished successes) for cons_successes
   uint32_t* step_count;    // device counter, incremented by the post-physics kernel
   long long* dbg;          // [64] phase time stamps of env 0 (profiling aid)
+  float *harvest_hand, *harvest_obj;   // [8, SDX_HARVEST_SLOTS, 23*2] / [8, SDX_HARVEST_SLOTS, 13]
+  int32_t* harvest_count;  // [8]
 };
 
 struct f3 { float x, y, z; };

@@ -31,6 +31,19 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
   float* root_e = B.root + (size_t)e * SDX_ACTORS * 13;
 
   if (do_reset) {  // wave-uniform branch
+    // terminal-state harvesting (GS:1398-1442): a finished episode whose target brick was carried over the base plate
+    // (y < 0) with the fingers still around it and an accepting T-value is stored in the ring buffer of its type group
+    if (B.step_count[0] > 0) {                                                     // `if self.total_steps > 0`
+      const float* tg = root_e + seg_actor(e) * 13;
+      if (tg[1] < 0.0f && B.finger_dist[e] < 0.6f && B.tvalue[e] > 0.8f) {         // GS:1404-1406
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&B.harvest_count[e & 7], 1) % SDX_HARVEST_SLOTS;   // GS:1417,1440-1441
+        slot = __shfl(slot, 0, SDX_WAVE);
+        const size_t o = (size_t)(e & 7) * SDX_HARVEST_SLOTS + slot;
+        if (lane < 46) B.harvest_hand[o * 46 + lane] = B.dof[(size_t)e * 46 + lane];      // GS:1415
+        if (lane < 13) B.harvest_obj[o * 13 + lane] = tg[lane];                            // GS:1416
+      }
+    }
     int choice;
     if (ext_choice) choice = ext_choice[e];
     else choice = (int)(sdx_hash(B.seed, (uint64_t)e, (uint64_t)B.step_count[0]) % (uint64_t)B.K);

@@ -188,3 +188,39 @@ def test_task_kernels_vs_oracle_1024(scene):
             np.testing.assert_array_equal(s.RESET.cpu().numpy(), resets)
     finally:
         s.close()
+
+
+def test_terminal_state_harvesting(scene):
+    """GS:1398-1442: on reset, envs whose target brick sits at y < 0 with finger_dist < 0.6 and tvalue > 0.8 store their
+    hand dof state and target root state in the ring buffer of their brick-type group (only when total_steps > 0)."""
+    from seqdex_amd.sim import SdxSim
+    n = 16
+    s = SdxSim(n)
+    try:
+        a = torch.zeros(n, 23).cuda()
+        s.step(a)                                    # total_steps becomes 1; every env was reset at step 0 (nothing harvested)
+        torch.cuda.synchronize()
+        assert int(s.HARVEST_COUNT.sum()) == 0
+        root = s.ROOT.view(n, 142, 13)
+        seg = torch.tensor([scene.seg_index(i) for i in range(n)]).cuda()
+        idx = torch.arange(n).cuda()
+        root[idx, seg, 1] = torch.where(idx % 2 == 0, -0.1, 0.2).float()     # even envs carried the brick to y < 0
+        s.FINGER_DIST.fill_(0.3)
+        s.TVALUE.copy_(torch.where(idx % 4 == 0, 0.9, 0.5).float())          # only envs 0,4,8,12 pass the T-value gate
+        dof_before = s.DOF.view(n, 23, 2).clone()
+        tgt_before = root[idx, seg].clone()
+        s.RESET.fill_(1)
+        s.pre_physics(a)
+        torch.cuda.synchronize()
+        cnt = s.HARVEST_COUNT.cpu().numpy()
+        assert cnt.tolist() == [2, 0, 0, 0, 2, 0, 0, 0]                      # envs {0,8} -> group 0, {4,12} -> group 4
+        hh, ho = s.HARVEST_HAND.cpu().numpy(), s.HARVEST_OBJ.cpu().numpy()
+        for grp, envs in ((0, (0, 8)), (4, (4, 12))):
+            got = {tuple(np.round(ho[grp, k], 5)) for k in range(2)}
+            want = {tuple(np.round(tgt_before[e].cpu().numpy(), 5)) for e in envs}
+            assert got == want
+            got_h = {tuple(np.round(hh[grp, k].ravel(), 5)) for k in range(2)}
+            want_h = {tuple(np.round(dof_before[e].cpu().numpy().ravel(), 5)) for e in envs}
+            assert got_h == want_h
+    finally:
+        s.close()

@@ -1,0 +1,63 @@
+"""CPU tests of the host-side mirrors: flag/config semantics (utils/config.py), scene constants, VecTask surface."""
+import numpy as np
+import pytest
+
+
+def test_get_args_and_load_cfg_overrides():
+    from seqdex_amd.config import get_args, load_cfg
+    a = get_args(["--task=BlockAssemblyGraspSim", "--num_envs=1024", "--seed", "7", "--max_iterations", "3", "--headless",
+                  "--minibatch_size", "64", "--rl_device", "cpu"])
+    assert a.train and not a.play and a.checkpoint == "" and a.device == "cuda"
+    cfg, cfg_train, logdir = load_cfg(a)
+    assert cfg["env"]["numEnvs"] == 1024 and cfg["seed"] == 7
+    assert cfg_train["params"]["config"]["max_epochs"] == 3
+    assert cfg_train["params"]["config"]["num_actors"] == 1024
+    assert cfg_train["params"]["config"]["minibatch_size"] == 4      # --minibatch_size is parsed but never applied (TR)
+    assert logdir == "logs/BlockAssemblyGraspSim"
+    b = get_args(["--test", "--checkpoint", "x.pth"])
+    assert b.play and not b.train and b.checkpoint == "x.pth"
+    with pytest.raises(SystemExit):
+        get_args(["--task=NotATask"])
+    with pytest.raises(SystemExit):
+        get_args(["--pipeline", "cpu"])
+
+
+def test_yaml_values_match_reference_hyperparameters():
+    import yaml, os
+    from seqdex_amd import config
+    tr = yaml.safe_load(open(os.path.join(config.HERE, config.TRAIN_CFG["BlockAssemblyGraspSim"])))["params"]
+    c = tr["config"]
+    assert (c["horizon_length"], c["minibatch_size"], c["mini_epochs"]) == (8, 4, 5)            # YG:49-51
+    assert (c["gamma"], c["tau"], float(c["learning_rate"]), c["e_clip"]) == (0.99, 0.95, 3e-4, 0.1)
+    assert c["central_value_config"]["normalize_input"] is True and float(c["central_value_config"]["learning_rate"]) == 1e-3
+    assert tr["network"]["mlp"]["units"] == [1024, 512, 256] and tr["network"]["space"]["continuous"]["fixed_sigma"] is True
+    env = yaml.safe_load(open(os.path.join(config.HERE, config.TASK_CFG["BlockAssemblyGraspSim"])))
+    assert env["env"]["episodeLength"] == 150 and env["sim"]["substeps"] == 2
+    assert env["sim"]["physx"]["num_position_iterations"] == 16 and env["sim"]["physx"]["contact_offset"] == 0.002
+
+
+def test_scene_constants(scene):
+    assert scene.link_names[7] == "panda_link7" and len(scene.link_names) == 24
+    assert [scene.link_names[i] for i in scene.fingertip_bodies] == ["link_3.0", "link_7.0", "link_11.0", "link_15.0"]
+    np.testing.assert_allclose(scene.lower[3], -3.0718); np.testing.assert_allclose(scene.upper[3], -0.0698)
+    assert [scene.seg_index(i) - 9 for i in range(8)] == [0, 1, 2, 0, 0, 5, 6, 0]                # GS:962-965
+    d = scene.to_desc()
+    assert d.n_rbox == 31 and d.n_static == 8 and d.substeps == 2 and d.solver_iters == 16
+    assert abs(d.kp[0] - 400) < 1e-6 and abs(d.kp[7] - 50) < 1e-6 and abs(d.effort[7] - 5) < 1e-6   # GS:580-590
+    masses = [b["mass"] for b in scene.brick_types]
+    assert 0.02 < min(masses) and max(masses) < 0.12                                              # 567 kg/m3 x hull volume
+
+
+def test_vec_task_surface_without_gpu():
+    from seqdex_amd.vec_task_rlgames import Box, RLgamesVecTaskPython, VecTask
+    class T:  # minimal task stand-in
+        num_envs, num_obs, num_states, num_actions, device = 4, 396, 564, 23, "cpu"
+    env = VecTask(T(), "cpu")
+    info = env.get_env_info()
+    assert info["agents"] == 1 and info["action_space"].shape == (23,) and info["observation_space"].shape == (396,)
+    assert info["state_space"].shape == (564,) and env.num_envs == 4 and env.num_acts == 23 and env.num_obs == 396
+    assert env.get_number_of_agents == 1 and env.has_action_masks() is False
+    assert float(info["action_space"].low[0]) == -1.0 and np.isinf(info["observation_space"].high[0])
+    with pytest.raises(ValueError):
+        VecTask(T(), "cpu", clip_observations=3.0)
+    assert issubclass(RLgamesVecTaskPython, VecTask)
