@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -21,6 +22,9 @@ int sdxpk_update_step(const SdxpDev*, int, hipStream_t);
 int sdxpk_update_begin(const SdxpDev*, int, hipStream_t);
 int sdxpk_update_flush_layers(const SdxpDev*, int, hipStream_t);
 int sdxpk_backward_explicit(const SdxpDev*, int, hipStream_t);
+int sdxpk_persist_supported(const SdxpDev*, int, int);
+int sdxpk_update_persistent(const SdxpDev*, int, unsigned*, unsigned*, hipStream_t);
+int sdxpk_prenorm(const SdxpDev*, int, hipStream_t);
 void sdxpk_apply_explicit(const SdxpDev*, int, float, int, hipStream_t);
 }
 
@@ -35,6 +39,9 @@ struct sdxp_agent {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int graph_chunk = 0;
+  bool use_persist = false;      // persistent register-resident update kernel (sdxp_persist.hip)
+  unsigned* bar_dev = nullptr;   // [64] grid-barrier counter (+ fail flag at [32])
+  unsigned* fail_host = nullptr; // pinned mirror of the fail flag, refreshed after every persistent update
   std::string err;
 };
 
@@ -151,6 +158,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   }
   PAL(D.cvx0, R * cfg->state_dim); PAL(D.cvx1, R * cfg->state_dim);
   PAL(D.dbg, 64); PAL(D.dhead, (size_t)2 * MB * 34); PAL(D.dlogstd, 64); PAL(D.ctrl, 1); PAL(h->stats_dev, 16);
+  PAL(h->bar_dev, 64); PAL(D.ll, SDXP_LL_WORDS);
 #undef PAL
   // ---- parameter init
   {
@@ -177,6 +185,14 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     ctl.ac_b1pow = ctl.ac_b2pow = ctl.cv_b1pow = ctl.cv_b2pow = 1.0;
     ctl.world = cfg->world_size > 0 ? cfg->world_size : 1;
     PCHK(h, hipMemcpy(D.ctrl, &ctl, sizeof(ctl), hipMemcpyHostToDevice));
+  }
+  {
+    hipDeviceProp_t prop;
+    PCHK(h, hipGetDeviceProperties(&prop, device));
+    const char* impl = getenv("SDXP_UPDATE_IMPL");   // "persist" (default when supported) | "graph"
+    h->use_persist = sdxpk_persist_supported(&D, cfg->minibatch, prop.multiProcessorCount) && !(impl && std::string(impl) == "graph");
+    PCHK(h, hipHostMalloc((void**)&h->fail_host, sizeof(unsigned), hipHostMallocDefault));
+    *h->fail_host = 0;
   }
   pset(h, SDXP_T_AC_PARAMS, D.ac, SDX_F32, {(int64_t)D.off.total});
   pset(h, SDXP_T_AC_GRADS, D.ac_g, SDX_F32, {(int64_t)D.off.total});
@@ -212,6 +228,7 @@ extern "C" int sdxp_destroy(sdxp_handle h) {
   (void)hipDeviceSynchronize();
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
+  if (h->fail_host) (void)hipHostFree(h->fail_host);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return SDX_OK;
@@ -297,7 +314,20 @@ extern "C" int sdxp_update(sdxp_handle h, void* stream) {
     return SDX_ERR_INVALID;
   }
   const long total = (long)h->cfg.mini_epochs * h->D.num_minibatches;
+  if (h->fail_host && *h->fail_host) {
+    h->use_persist = false;   // a grid barrier of the persistent kernel timed out earlier: fall back for good
+    *h->fail_host = 0;
+    h->err = "sdxp_update: the persistent update kernel timed out at a grid barrier in a previous call (not all 256 "
+             "workgroups were co-resident?); parameters of that epoch are undefined; falling back to the graph path";
+    return SDX_ERR_STATE;
+  }
   hipLaunchKernelGGL(k_ctrl_begin_epoch, dim3(1), dim3(1), 0, st, h->D.ctrl);
+  if (h->use_persist) {
+    sdxpk_prenorm(&h->D, MB, st);
+    if (sdxpk_update_persistent(&h->D, (int)total, h->bar_dev, h->bar_dev + 32, st) != 0) { h->err = "persistent update launch failed"; return SDX_ERR_HIP; }
+    PCHK(h, hipMemcpyAsync(h->fail_host, h->bar_dev + 32, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    return plaunch_ok(h, "sdxp_update(persistent)");
+  }
   sdxpk_update_begin(&h->D, MB, st);
   // a chunk of optimiser steps is captured once into a hipGraph (no step-dependent kernel arguments: all state
   // lives in the device control block) and replayed; the remainder is launched eagerly

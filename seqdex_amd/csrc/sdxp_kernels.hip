@@ -1052,6 +1052,11 @@ extern "C" int sdxpk_update_begin(const SdxpDev* D, int mb_size, hipStream_t st)
   MB_SWITCH(mb_size, C_)
 #undef C_
 }
+extern "C" int sdxpk_prenorm(const SdxpDev* D, int mb_size, hipStream_t st) {
+#define C_(M) hipLaunchKernelGGL(k_cv_prenorm<M>, dim3((D->state_dim + 63) / 64), dim3(64), 0, st, *D)
+  MB_SWITCH(mb_size, C_)
+#undef C_
+}
 // flush: apply the last pending optimiser step (the L/HEAD kernels run once more on the staged minibatch; their forward
 // outputs are discarded)
 extern "C" int sdxpk_update_flush_layers(const SdxpDev* D, int mb_size, hipStream_t st) {

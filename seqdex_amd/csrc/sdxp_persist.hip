@@ -1,0 +1,1059 @@
+// sdxp_persist.hip — the PPO update phase of one epoch (all mini-epochs x minibatches, three networks) as ONE persistent
+// kernel on MI355X: 256 workgroups (one per CU) x 512 threads, every weight and its Adam moments stay in the VGPR file
+// of the CU that owns them for the whole epoch (~180 registers per lane), activations / gradient factors of the current
+// minibatch live in LDS (~140 KiB), and the only inter-CU traffic per optimiser step is the rank-MB factors
+// (x1, x2, x3, dY1, dY0: ~170 KiB read per CU from L2) exchanged across FIVE grid barriers:
+//
+//   A  [norm from Gram matrices -> clip, Adam of every resident parameter]  forward L0 of own rows      -> x1  | barrier
+//   B  stage x1, forward L1 of own rows                                                                 -> x2  | barrier
+//   C  stage x2, forward L2 of own rows                                                                 -> x3  | barrier
+//   D  stage x3, heads + PPO losses (replicated on every CU, bit-identical), backward L2 (column copy)  -> dY1 | barrier
+//   E  stage dY1, backward L1 (column copy)                                                             -> dY0 | barrier
+//
+// Ownership (shipped network 396/564 -> 1024 -> 512 -> 256 -> 23/1, minibatch 4):
+//   W0 rows      : CU g, wave w owns half (w&1) of row 4g+(w>>1) of actor, critic and central value
+//   W1 rows      : wave w owns quarter (w&3) of row 2g+(w>>2) of the three nets     (forward)
+//   W1 columns   : CU g owns columns 4g..4g+3 of the three nets, thread = row       (backward; duplicate copy, same Adam)
+//   W2 rows      : wave w owns eighth w of row g of the three nets                  (forward)
+//   W2 columns   : CU g owns columns 2g, 2g+1: thread = (column, row)               (backward; duplicate copy)
+//   heads        : replicated on every CU, wave w owns rows w, w+8, ... of the 25 head rows
+// Row and column copies receive the same gradient g[n][k] = sum_s dY_s[n] X_s[k] (same operands, same order), so they
+// stay bit-identical without communication.  Arithmetic is the same as the multi-kernel path (sdxp_kernels.hip), which
+// remains the fallback for other shapes and the explicit-gradient multi-rank path.
+#include <cstddef>
+#include <cstdlib>
+
+#include "sdx_common.h"
+#include "sdxp_types.h"
+
+namespace {
+constexpr int MB = 4, OBS = 396, ST = 564, U0 = 1024, U1 = 512, U2 = 256, ACT = 23;
+constexpr int NWG = 256, NTH = 512, NWV = NTH / 64;
+constexpr int H0A = OBS / 2, H0V = ST / 2;   // a layer-0 row is split over two waves: 198 / 282 elements each
+constexpr int I0A = (H0A + 63) / 64;   // 4 elements per lane of half an actor/critic layer-0 row
+constexpr int I0V = (H0V + 63) / 64;   // 5 for half a central-value layer-0 row
+constexpr int HR = 4;                  // head rows per wave (25 rows over 8 waves)
+constexpr int HPC = (ACT + 2) * U2 / NWG;   // head weights whose Adam state one CU owns (25)
+static_assert(HPC * NWG == (ACT + 2) * U2 && U2 == 256, "head ownership split");
+
+__device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expm1f(x); }
+__device__ __forceinline__ float elu_g(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  return v + __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1, 0xF>(v); v = dpp_add<0x4E, 0xF>(v); v = dpp_add<0x141, 0xF>(v); v = dpp_add<0x140, 0xF>(v);
+  v = dpp_add<0x142, 0xA>(v); v = dpp_add<0x143, 0xC>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// Opaque copy of an index.  volatile asm statements keep their program order relative to each other and to sched_barrier,
+// and an LDS load whose address depends on the result cannot be floated above it: this is what keeps the operand loads of
+// Adam element i+1 below the arithmetic of element i.
+// Passing the weight updated by element i as a (fake) input orders element i+1's loads after element i's arithmetic too.
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opaque(int x, float after) { asm volatile("" : "+v"(x) : "v"(after)); return x; }
+__device__ __forceinline__ void adam1(float& w, float g, float& m, float& v, float lr_bc1, float isq_bc2) {
+  m = 0.9f * m + 0.1f * g;
+  v = 0.999f * v + 0.001f * g * g;
+  // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences: the Adam arithmetic of ~45 elements per lane is VALU bound
+  w -= lr_bc1 * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * isq_bc2 + 1e-8f);
+  // one element at a time: without this the scheduler forms all ~45 gradients of the lane first and holds them (and the
+  // half-updated moments) in registers while it interleaves the long sqrt/div chains
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+struct PLds {
+  float obs[MB][OBS];        // layer-0 input of actor/critic (dataset rows)
+  float cvx[MB][ST];         // layer-0 input of the central value (pre-normalised rows)
+  float x1[3][MB][U0];
+  float x2[3][MB][U1];
+  float x3[3][MB][U2];
+  float dy2[3][MB][U2];
+  float dy1[3][MB][U1];
+  // Gram matrices (MB x MB) of the factors of the minibatch currently held: inputs gx[net][layer 0..3], gradients gd[net][layer 0..2]
+  float gx[3][4][16], gd[3][3][16], bsq[3][3];   // bsq: |sum_s dY_s|^2 (bias gradients) per net and trunk layer
+  float part[64 * 4];        // block_sum results
+  float fpart[3 * MB * NWV];  // cross-wave partial dot products of the forward passes
+  float red[4 * NWV][64];    // block_sum: one row per (wave, DPP row)
+  float mu[MB][32], dmu[MB][32], z[MB][32], act[MB][32], omu[MB][32], osg[MB][32];
+  float val[2][MB], dv[2][MB], gnlp[MB], ls[32], dls[32], stat[MB][8];
+  // biases of the owned rows and their Adam moments (one thread each): [0..2] L0 (net), [3..8] L1 (net*2+row), [9..11] L2,
+  // [12..36] heads (replicated), [37..59] logstd (replicated)
+  float bias[64], bias_m[64], bias_v[64], bias_g[64];
+  float dyown[3][MB][8];     // dY of the owned rows: [net][s][0..3] L0 rows (per wave), [4..5] L1 rows, [6] L2 row
+  float scal[16];            // broadcast scalars of the step: 0 ac_gscale 1 cv_gscale 2 ac_lr_bc1 3 ac_isq 4 cv_lr_bc1 5 cv_isq
+  // control state machine, owned by thread 0 of every CU (every CU runs it on identical inputs, so the copies stay identical)
+  struct Ctl {
+    double ac_b1, ac_b2, cv_b1, cv_b2;
+    float ac_lr, ac_lr_applied, cv_lr, sum_a, sum_c, sum_b, sum_kl, sum_cv, sum_ent, last_kl, ac_gn, cv_gn, n2h[3];
+    int ac_t, cv_t;
+  } ctl;
+  int fail;
+  long long tacc[32], tlast;   // phase clock accumulators of CU 0 (SDXP_PERSIST_STAMPS=1)
+};
+
+// ---- (value, tag) exchange words ("LL" protocol): one relaxed 8-byte store at agent scope carries the float and the tag of the
+// optimiser step that produced it; a consumer re-reads until the tag it expects shows up.  No fences, no barriers, no reset:
+// tags only grow, and the data dependencies of the step (x1 -> x2 -> x3 -> dY1 -> dY0 -> next x1) guarantee that a word is not
+// overwritten before every CU has consumed it ("persistent update kernel").
+typedef unsigned long long u64;
+constexpr size_t LL_X1 = 0, LL_X2 = LL_X1 + 3 * MB * U0, LL_X3 = LL_X2 + 3 * MB * U1, LL_DY1 = LL_X3 + 3 * MB * U2,
+                 LL_DY0 = LL_DY1 + 3 * MB * U1, LL_HW = LL_DY0 + 3 * MB * U0, LL_END = LL_HW + (ACT + 2) * U2;
+static_assert(LL_END <= SDXP_LL_WORDS, "exchange buffer too small");
+__device__ __forceinline__ void ll_store(u64* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// gather N words p[i * stride] carrying `tag`; false (and *failflag set) if they do not arrive.  The retry loop is wave-uniform
+// (all lanes reload until every lane has its words), which keeps the loaded values out of divergent-loop phis.
+template <int N>
+__device__ __forceinline__ bool ll_gather(const u64* p, size_t stride, unsigned tag, float (&out)[N], unsigned* failflag) {
+  unsigned spins = 0;
+  for (;;) {
+    u64 w[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = __hip_atomic_load(p + i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ok = ok && (unsigned)(w[i] >> 32) == tag;
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __uint_as_float((unsigned)w[i]);
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 255u) == 0) {
+      const unsigned f = __hip_atomic_load(failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spins > (1u << 22) || __builtin_amdgcn_readfirstlane(f) != 0) {
+        __hip_atomic_store(failflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+// accumulate the 4x4 Gram (lower triangle, 10 terms) and |sum|^2 of (a, b, c, d)
+__device__ __forceinline__ void gram_acc(float* p, float a, float b, float c, float d) {
+  p[0] += a * a; p[1] += b * a; p[2] += b * b; p[3] += c * a; p[4] += c * b; p[5] += c * c;
+  p[6] += d * a; p[7] += d * b; p[8] += d * c; p[9] += d * d;
+  const float sb = a + b + c + d;
+  p[10] += sb * sb;
+}
+__device__ __forceinline__ int tri16(int i) { const int a = i >> 2, b = i & 3, hi = a > b ? a : b, lo = a > b ? b : a; return hi * (hi + 1) / 2 + lo; }
+// sums over each 32-lane half of the wave; valid in lanes 16..31 and 48..63
+__device__ __forceinline__ float half_sum(float v) {
+  v = dpp_add<0xB1, 0xF>(v); v = dpp_add<0x4E, 0xF>(v); v = dpp_add<0x141, 0xF>(v); v = dpp_add<0x140, 0xF>(v);
+  return dpp_add<0x142, 0xA>(v);
+}
+
+// block-wide sums of N per-thread values (N <= 64); result in out[0..N).  Two "halving" butterfly levels (lane pairs keep the even /
+// odd half of the values, so level L costs N / 2^L exchanges instead of N), two more within the 16-lane DPP row, and the 4 rows x 8
+// waves meet in LDS: ~3.5 N VALU ops + N/4 LDS writes per wave instead of 7 N + N masked writes for N independent wave sums.
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xF, BANK, false));
+}
+template <int N>
+__device__ __forceinline__ void block_sum(PLds& S, const float (&v)[N], float* out, int tid, int wave, int lane) {
+  constexpr int N4 = (N + 3) / 4;
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float u1[2 * N4], u2[N4];
+#pragma unroll
+  for (int j = 0; j < 2 * N4; ++j) {
+    const float e = 2 * j < N ? v[2 * j] : 0.0f, o = 2 * j + 1 < N ? v[2 * j + 1] : 0.0f;
+    const float keep = b0 ? o : e, send = b0 ? e : o;
+    u1[j] = keep + dpp_mov<0xB1, 0xF>(0.0f, send);           // partner lane ^ 1
+  }
+#pragma unroll
+  for (int j = 0; j < N4; ++j) {
+    const float keep = b1 ? u1[2 * j + 1] : u1[2 * j], send = b1 ? u1[2 * j] : u1[2 * j + 1];
+    float t = keep + dpp_mov<0x4E, 0xF>(0.0f, send);         // partner lane ^ 2: t = quad sum of value 4 j + (lane & 3)
+    float x = dpp_mov<0x114, 0xA>(0.0f, t);                  // lane ^ 4: row_shr:4 into banks 1,3 ...
+    x = dpp_mov<0x104, 0x5>(x, t);                           // ... row_shl:4 into banks 0,2
+    t += x;
+    t += dpp_mov<0x128, 0xF>(0.0f, t);                       // lane ^ 8 (row_ror:8): sum over the 16-lane row
+    u2[j] = t;
+  }
+  if ((lane & 15) < 4) {
+    float* r = S.red[wave * 4 + (lane >> 4)];
+#pragma unroll
+    for (int j = 0; j < N4; ++j) r[4 * j + (lane & 3)] = u2[j];
+  }
+  __syncthreads();
+  if (tid < N) {
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4 * NWV; ++w) t += S.red[w][tid];
+    out[tid] = t;
+  }
+  __syncthreads();
+}
+
+static_assert(sizeof(PLds) + 512 <= 160 * 1024, "PLds (+ the static logstd bank) must fit the 160 KiB LDS of a gfx950 CU");
+}  // namespace
+
+// dataset-row helpers
+__device__ __forceinline__ const float* obs_rows(const SdxpDev& D, int mb) { return D.mb_obs + (size_t)mb * MB * OBS; }
+__device__ __forceinline__ const float* cvx_rows(const SdxpDev& D, int mb, int mini_epoch) {
+  return (mini_epoch == 0 ? D.cvx0 : D.cvx1) + (size_t)mb * MB * ST;
+}
+
+__global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int total_steps, unsigned* bar, unsigned* failflag, int stamps) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  PLds& S = *reinterpret_cast<PLds*>(smem_raw);
+  // Thread coordinates are re-derived from an opaque copy of threadIdx/blockIdx at the start of every phase (refresh()):
+  // otherwise every LDS address and ownership index of the step loop is hoisted into the loop preheader and the ~150 hoisted
+  // values, on top of the resident weights and moments, push the kernel far over the 256-VGPR budget.
+  int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = blockIdx.x;
+  int r0w, h0, n0, r1w, q1, r1, c2c, c2n, he, hrow, hk;
+  auto refresh = [&]() {
+    int t = threadIdx.x, b = blockIdx.x;
+    asm volatile("" : "+v"(t));
+    asm volatile("" : "+s"(b));
+    tid = t; lane = t & 63; wave = __builtin_amdgcn_readfirstlane(t >> 6); g = b;
+    r0w = wave >> 1; h0 = wave & 1; n0 = 4 * g + r0w;
+    r1w = wave >> 2; q1 = wave & 3; r1 = 2 * g + r1w;
+    c2c = t >> 8; c2n = t & 255;
+    he = HPC * g + t; hrow = he >> 8; hk = he & (U2 - 1);
+  };
+  refresh();
+#define TS(i) if (stamps && g == 0 && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); S.tacc[i] += t_ - S.tlast; S.tlast = t_; }
+  if (tid < 32) S.tacc[tid] = 0;
+  if (tid == 0) S.fail = 0;
+  if (tid == 0) S.tlast = __builtin_amdgcn_s_memtime();
+  const int A = ACT;
+  u64* const LL = D.ll;   // exchange words, layout LL_*: [net][s][unit] per activation / gradient, then the head matrix
+
+  // ------------------------------------------------------------------ resident parameters
+  // layer 0 rows: row n0 = 4g + (wave>>1), half h0 = wave&1 of K; net 0/1: K = OBS, net 2: K = ST
+  float w0a[I0A], m0a[I0A], v0a[I0A], w0c[I0A], m0c[I0A], v0c[I0A], w0v[I0V], m0v[I0V], v0v[I0V];
+  // layer 1 rows: row r1 = 2g + (wave>>2), quarter q1 = wave&3: k = q1*256 + lane + 64 i (i<4), three nets
+  float w1[3][4], m1[3][4], v1[3][4];
+  // layer 1 columns: cols 4g+c, row n = tid
+  float c1[3][4], cm1[3][4], cv1[3][4];
+  // layer 2 rows: row g, eighth = wave: k = wave*64 + lane
+  float w2[3], m2[3], v2[3];
+  // layer 2 columns: col 2g + (tid>>8), row n = tid & 255
+  float c2[3], cm2[3], cv2[3];
+  // heads ((A+2) x U2 = 6400 weights): CU g runs Adam for the HPC flat elements [HPC g, HPC g + HPC) on its first HPC threads and
+  // publishes the new weight in the parameter array; phase D of every CU reads the whole head matrix back through L2.
+  float hw = 0.0f, hm = 0.0f, hv = 0.0f;
+
+  auto P_of = [&](int net) -> float* { return net == 2 ? D.cv : D.ac; };
+  auto M_of = [&](int net) -> float* { return net == 2 ? D.cv_m : D.ac_m; };
+  auto V_of = [&](int net) -> float* { return net == 2 ? D.cv_v : D.ac_v; };
+  auto woff = [&](int net, int l) -> size_t { return net == 0 ? D.off.a_w[l] : net == 1 ? D.off.c_w[l] : D.coff.w[l]; };
+  auto boff = [&](int net, int l) -> size_t { return net == 0 ? D.off.a_b[l] : net == 1 ? D.off.c_b[l] : D.coff.b[l]; };
+  auto head_woff = [&](int row) -> size_t { return row < A ? D.off.mu_w + (size_t)row * U2 : (row == A ? D.off.v_w : D.coff.v_w); };
+  auto head_boff = [&](int row) -> size_t { return row < A ? D.off.mu_b + row : (row == A ? D.off.v_b : D.coff.v_b); };
+  auto head_net = [&](int row) -> int { return row < A ? 0 : (row == A ? 1 : 2); };
+
+#pragma unroll
+  for (int i = 0; i < I0A; ++i) {
+    const int kk = lane + 64 * i, k = h0 * H0A + kk;
+    const bool ok = kk < H0A;
+    const size_t oa = woff(0, 0) + (size_t)n0 * OBS + k, oc = woff(1, 0) + (size_t)n0 * OBS + k;
+    w0a[i] = ok ? D.ac[oa] : 0.0f; m0a[i] = ok ? D.ac_m[oa] : 0.0f; v0a[i] = ok ? D.ac_v[oa] : 0.0f;
+    w0c[i] = ok ? D.ac[oc] : 0.0f; m0c[i] = ok ? D.ac_m[oc] : 0.0f; v0c[i] = ok ? D.ac_v[oc] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < I0V; ++i) {
+    const int kk = lane + 64 * i, k = h0 * H0V + kk;
+    const bool ok = kk < H0V;
+    const size_t o = woff(2, 0) + (size_t)n0 * ST + k;
+    w0v[i] = ok ? D.cv[o] : 0.0f; m0v[i] = ok ? D.cv_m[o] : 0.0f; v0v[i] = ok ? D.cv_v[o] : 0.0f;
+  }
+#pragma unroll
+  for (int net = 0; net < 3; ++net) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t o = woff(net, 1) + (size_t)r1 * U0 + q1 * 256 + lane + 64 * i;
+      w1[net][i] = P_of(net)[o]; m1[net][i] = M_of(net)[o]; v1[net][i] = V_of(net)[o];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t o = woff(net, 1) + (size_t)tid * U0 + 4 * g + c;
+      c1[net][c] = P_of(net)[o]; cm1[net][c] = M_of(net)[o]; cv1[net][c] = V_of(net)[o];
+    }
+    {
+      const size_t o = woff(net, 2) + (size_t)g * U1 + wave * 64 + lane;
+      w2[net] = P_of(net)[o]; m2[net] = M_of(net)[o]; v2[net] = V_of(net)[o];
+    }
+    {
+      const size_t o = woff(net, 2) + (size_t)c2n * U1 + 2 * g + c2c;
+      c2[net] = P_of(net)[o]; cm2[net] = M_of(net)[o]; cv2[net] = V_of(net)[o];
+    }
+  }
+  if (tid < HPC) {
+    const int net = head_net(hrow);
+    const size_t o = head_woff(hrow) + hk;
+    hw = P_of(net)[o]; hm = M_of(net)[o]; hv = V_of(net)[o];
+  }
+  // biases + logstd (LDS, one thread each)
+  if (tid < 64) {
+    float b = 0.0f, bm = 0.0f, bv = 0.0f;
+    int net = -1; size_t o = 0;
+    if (tid < 3) { net = tid; o = boff(net, 0) + 0; }   // placeholder, L0 biases are per wave: handled below
+    (void)net; (void)o;
+    S.bias[tid] = b; S.bias_m[tid] = bm; S.bias_v[tid] = bv; S.bias_g[tid] = 0.0f;
+  }
+  __syncthreads();
+  // bias slot map: L0: slot = net*4 + wave (12 slots, 0..11); L1: 12 + net*2 + row (6 slots); L2: 18 + net (3); heads: 21 + row (25);
+  // logstd: 46 + a (23)  -> 69 slots: enlarge arrays via two passes of 64 threads
+  // (arrays are sized 64: heads + logstd go to a second bank below)
+  __shared__ float s_b2[3][32];     // logstd value, m, v
+  if (tid < 12) {   // bias slot map: L0 net*4 + row (12), L1 12 + net*2 + row (6), L2 18 + net (3), heads 21 + row (25)
+    const int net = tid / 4, w = tid % 4;
+    const size_t o = boff(net, 0) + 4 * g + w;
+    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = M_of(net)[o]; S.bias_v[tid] = V_of(net)[o];
+  } else if (tid < 18) {
+    const int net = (tid - 12) / 2, r = (tid - 12) % 2;
+    const size_t o = boff(net, 1) + 2 * g + r;
+    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = M_of(net)[o]; S.bias_v[tid] = V_of(net)[o];
+  } else if (tid < 21) {
+    const int net = tid - 18;
+    const size_t o = boff(net, 2) + g;
+    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = M_of(net)[o]; S.bias_v[tid] = V_of(net)[o];
+  } else if (tid < 21 + A + 2) {
+    const int row = tid - 21, net = head_net(row);
+    const size_t o = head_boff(row);
+    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = M_of(net)[o]; S.bias_v[tid] = V_of(net)[o];
+  } else if (tid >= 64 && tid < 64 + A) {
+    const int a = tid - 64;
+    const size_t o = D.off.logstd + a;
+    s_b2[0][a] = D.ac[o]; s_b2[1][a] = D.ac_m[o]; s_b2[2][a] = D.ac_v[o];
+  }
+  // replicated control state (every CU runs the same state machine on identical inputs)
+  SdxpCtrl* gctl = D.ctrl;
+  if (tid == 0) {
+    PLds::Ctl& C = S.ctl;
+    C.ac_lr = gctl->ac_lr; C.ac_lr_applied = C.ac_lr; C.cv_lr = gctl->cv_lr; C.ac_t = gctl->ac_t; C.cv_t = gctl->cv_t;
+    C.ac_b1 = gctl->ac_b1pow; C.ac_b2 = gctl->ac_b2pow; C.cv_b1 = gctl->cv_b1pow; C.cv_b2 = gctl->cv_b2pow;
+    C.sum_a = C.sum_c = C.sum_b = C.sum_kl = C.sum_cv = C.sum_ent = C.last_kl = C.ac_gn = C.cv_gn = 0.0f;
+    C.n2h[0] = C.n2h[1] = C.n2h[2] = 0.0f;   // head + logstd contributions to the squared gradient norm of the held minibatch
+  }
+  bool pending = false;
+  __syncthreads();
+
+  for (int step = 0; step <= total_steps; ++step) {
+    __syncthreads();
+    if (S.fail) return;   // an exchange word never arrived (not all CUs resident?): the host sees *failflag and reports it
+    refresh();
+    const bool last = step == total_steps;   // the extra iteration only applies the optimiser step of the final minibatch
+    const int mbi = step % D.num_minibatches, mini_epoch = step / D.num_minibatches;
+    const unsigned tag = (unsigned)step + 1u;   // tag of everything this step produces
+    // prefetch this step's layer-0 inputs (dataset rows mb*MB .. +MB; lane k holds element k of the MB samples): the HBM latency
+    // hides behind the norm / Adam work below
+    float pf_o[MB], pf_c[2][MB];
+    {
+      const float* o = obs_rows(D, last ? 0 : mbi);
+      const float* c = cvx_rows(D, last ? 0 : mbi, last ? 0 : mini_epoch);
+#pragma unroll
+      for (int s = 0; s < MB; ++s) {
+        pf_o[s] = tid < OBS ? o[s * OBS + tid] : 0.0f;
+        pf_c[0][s] = c[s * ST + tid];
+        pf_c[1][s] = tid + NTH < ST ? c[s * ST + tid + NTH] : 0.0f;
+      }
+    }
+    // ================================================================== phase A: gradient norm, Adam of layer 0, forward L0
+    if (pending) {
+      // squared-norm Gram of dY0 (all CUs' columns; produced by the previous step, tag == step)
+      {
+        float p[33];
+#pragma unroll
+        for (int i = 0; i < 33; ++i) p[i] = 0.0f;
+#pragma unroll
+        for (int h = 0; h < U0 / NTH; ++h) {
+          float v[3 * MB];
+          if (!ll_gather<3 * MB>(LL + LL_DY0 + tid + NTH * h, U0, (unsigned)step, v, failflag)) S.fail = 1;
+#pragma unroll
+          for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], v[net * MB], v[net * MB + 1], v[net * MB + 2], v[net * MB + 3]);
+        }
+        block_sum<33>(S, p, S.part, tid, wave, lane);
+        if (tid < 48) S.gd[tid >> 4][0][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+        else if (tid >= 64 && tid < 67) S.bsq[tid - 64][0] = S.part[(tid - 64) * 11 + 10];
+        __syncthreads();
+      }
+      if (wave == 0) {   // control block: |g|^2 = sum over layers of <Gd, Gx> + bias terms (+ heads, kept in n2h), then the step scalars
+        float t = 0.0f;
+        if (lane < 48) {
+          const int net = lane >> 4, i = lane & 15;
+#pragma unroll
+          for (int l = 0; l < 3; ++l) t += S.gd[net][l][i] * S.gx[net][l][i];
+        }
+        t = dpp_add<0xB1, 0xF>(t); t = dpp_add<0x4E, 0xF>(t); t = dpp_add<0x141, 0xF>(t); t = dpp_add<0x140, 0xF>(t);   // 16-lane row sums
+        float n2[3];
+        n2[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0));
+        n2[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 16));
+        n2[2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 32));
+        if (lane == 0) {
+          PLds::Ctl& C = S.ctl;
+#pragma unroll
+          for (int net = 0; net < 3; ++net) n2[net] += C.n2h[net] + S.bsq[net][0] + S.bsq[net][1] + S.bsq[net][2];
+          C.ac_gn = sqrtf(n2[0] + n2[1]); C.cv_gn = sqrtf(n2[2]);
+          S.scal[0] = D.truncate_grads ? fminf(1.0f, D.grad_norm / (C.ac_gn + 1e-6f)) : 1.0f;
+          S.scal[1] = D.truncate_grads ? fminf(1.0f, D.grad_norm / (C.cv_gn + 1e-6f)) : 1.0f;
+          // Adam step counters / bias corrections
+          C.ac_t += 1; C.cv_t += 1;
+          C.ac_b1 *= 0.9; C.ac_b2 *= 0.999; C.cv_b1 *= 0.9; C.cv_b2 *= 0.999;
+          S.scal[2] = C.ac_lr_applied / (float)(1.0 - C.ac_b1); S.scal[3] = 1.0f / sqrtf((float)(1.0 - C.ac_b2));
+          S.scal[4] = C.cv_lr / (float)(1.0 - C.cv_b1); S.scal[5] = 1.0f / sqrtf((float)(1.0 - C.cv_b2));
+        }
+      }
+      __syncthreads();
+      TS(0)
+      const float gs_ac = S.scal[0], gs_cv = S.scal[1];
+      const float ac_lr_bc1 = S.scal[2], ac_isq = S.scal[3], cv_lr_bc1 = S.scal[4], cv_isq = S.scal[5];
+      float dep = 0.0f;   // last weight written by the Adam sequence below (ordering token, see opaque())
+      // ---- layer 0 rows
+      {
+        float da[MB], dc[MB], dvv[MB];
+#pragma unroll
+        for (int s = 0; s < MB; ++s) { da[s] = S.dyown[0][s][r0w] * gs_ac; dc[s] = S.dyown[1][s][r0w] * gs_ac; dvv[s] = S.dyown[2][s][r0w] * gs_cv; }
+#pragma unroll
+        for (int i = 0; i < I0A; ++i) {
+          const int kk = opaque(lane + 64 * i, dep), k = h0 * H0A + kk;
+          if (kk < H0A) {
+            float ga = 0.0f, gc = 0.0f;
+#pragma unroll
+            for (int s = 0; s < MB; ++s) { const float x = S.obs[s][k]; ga += da[s] * x; gc += dc[s] * x; }
+            adam1(w0a[i], ga, m0a[i], v0a[i], ac_lr_bc1, ac_isq); dep = w0a[i];
+            adam1(w0c[i], gc, m0c[i], v0c[i], ac_lr_bc1, ac_isq); dep = w0c[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < I0V; ++i) {
+          const int kk = opaque(lane + 64 * i, dep), k = h0 * H0V + kk;
+          if (kk < H0V) {
+            float gv = 0.0f;
+#pragma unroll
+            for (int s = 0; s < MB; ++s) gv += dvv[s] * S.cvx[s][k];
+            adam1(w0v[i], gv, m0v[i], v0v[i], cv_lr_bc1, cv_isq); dep = w0v[i];
+          }
+        }
+      }
+      if (tid < 12) {   // layer-0 biases (bias gradient = sum_s dY_s[row])
+        const int net = tid / 4;
+        float gg = 0.0f;
+        for (int s = 0; s < MB; ++s) gg += S.dyown[net][s][tid % 4];
+        float b = S.bias[tid], bm = S.bias_m[tid], bv = S.bias_v[tid];
+        adam1(b, gg * (net == 2 ? gs_cv : gs_ac), bm, bv, net == 2 ? cv_lr_bc1 : ac_lr_bc1, net == 2 ? cv_isq : ac_isq);
+        S.bias[tid] = b; S.bias_m[tid] = bm; S.bias_v[tid] = bv;
+      }
+      __syncthreads();   // every wave is done with the old S.obs / S.cvx
+      TS(1)
+    }
+    if (!last) {
+      // ---- this step's layer-0 inputs to LDS, forward L0 of the owned rows (two half-row waves per row, combined through LDS)
+#pragma unroll
+      for (int s = 0; s < MB; ++s) {
+        if (tid < OBS) S.obs[s][tid] = pf_o[s];
+        S.cvx[s][tid] = pf_c[0][s];
+        if (tid + NTH < ST) S.cvx[s][tid + NTH] = pf_c[1][s];
+      }
+      __syncthreads();
+      float pa[MB], pc[MB], pv[MB];
+#pragma unroll
+      for (int s = 0; s < MB; ++s) { pa[s] = 0.0f; pc[s] = 0.0f; pv[s] = 0.0f; }
+#pragma unroll
+      for (int i = 0; i < I0A; ++i) {
+        const int kk = lane + 64 * i, k = h0 * H0A + kk;
+        if (kk < H0A) {
+#pragma unroll
+          for (int s = 0; s < MB; ++s) { const float x = S.obs[s][k]; pa[s] += w0a[i] * x; pc[s] += w0c[i] * x; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < I0V; ++i) {
+        const int kk = lane + 64 * i, k = h0 * H0V + kk;
+        if (kk < H0V) {
+#pragma unroll
+          for (int s = 0; s < MB; ++s) pv[s] += w0v[i] * S.cvx[s][k];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < MB; ++s) {
+        const float ra = wave_sum(pa[s]), rc = wave_sum(pc[s]), rv = wave_sum(pv[s]);
+        if (lane == 0) { S.fpart[(0 * MB + s) * NWV + wave] = ra; S.fpart[(1 * MB + s) * NWV + wave] = rc; S.fpart[(2 * MB + s) * NWV + wave] = rv; }
+      }
+      __syncthreads();
+      if (tid < 3 * MB * 4) {
+        const int net = tid / (MB * 4), s = (tid / 4) % MB, r = tid % 4;
+        const float y = S.fpart[(net * MB + s) * NWV + 2 * r] + S.fpart[(net * MB + s) * NWV + 2 * r + 1] + S.bias[net * 4 + r];
+        ll_store(LL + LL_X1 + (size_t)(net * MB + s) * U0 + 4 * g + r, elu(y), tag);
+      }
+      TS(2)
+      // ---- in the shadow of the x1 exchange: Gram of the layer-0 inputs (from the prefetch registers)
+      float p[22];
+#pragma unroll
+      for (int i = 0; i < 22; ++i) p[i] = 0.0f;
+      gram_acc(&p[0], pf_o[0], pf_o[1], pf_o[2], pf_o[3]);
+      gram_acc(&p[11], pf_c[0][0], pf_c[0][1], pf_c[0][2], pf_c[0][3]);
+      gram_acc(&p[11], pf_c[1][0], pf_c[1][1], pf_c[1][2], pf_c[1][3]);
+      block_sum<22>(S, p, S.part, tid, wave, lane);
+      if (tid < 16) { const float v = S.part[tri16(tid)]; S.gx[0][0][tid] = v; S.gx[1][0][tid] = v; }
+      else if (tid >= 64 && tid < 80) S.gx[2][0][tid - 64] = S.part[11 + tri16(tid - 64)];
+    }
+    refresh();
+    if (pending) {
+      // ---- (shadow of x1) Adam of layer 1: row copy and column copy, operands are last step's S.x1 / S.dy1
+      const float gs_ac = S.scal[0], gs_cv = S.scal[1];
+      const float ac_lr_bc1 = S.scal[2], ac_isq = S.scal[3], cv_lr_bc1 = S.scal[4], cv_isq = S.scal[5];
+      float dep = 0.0f;
+#pragma unroll
+      for (int net = 0; net < 3; ++net) {
+        const float gs = net == 2 ? gs_cv : gs_ac, lrb = net == 2 ? cv_lr_bc1 : ac_lr_bc1, isq = net == 2 ? cv_isq : ac_isq;
+        float d1r[MB], dn1[MB];
+        const int o_r = opaque(r1w, dep), o_t = opaque(tid, dep);
+#pragma unroll
+        for (int s = 0; s < MB; ++s) { d1r[s] = S.dyown[net][s][4 + o_r] * gs; dn1[s] = S.dy1[net][s][o_t] * gs; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = opaque(q1 * 256 + lane + 64 * i, dep);
+          float gg = 0.0f;
+#pragma unroll
+          for (int s = 0; s < MB; ++s) gg += d1r[s] * S.x1[net][s][k];
+          adam1(w1[net][i], gg, m1[net][i], v1[net][i], lrb, isq); dep = w1[net][i];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int k = opaque(4 * g + c, dep);
+          float gg = 0.0f;
+#pragma unroll
+          for (int s = 0; s < MB; ++s) gg += dn1[s] * S.x1[net][s][k];
+          adam1(c1[net][c], gg, cm1[net][c], cv1[net][c], lrb, isq); dep = c1[net][c];
+        }
+      }
+      if (tid >= 12 && tid < 18) {   // layer-1 biases
+        const int net = (tid - 12) / 2;
+        float gg = 0.0f;
+        for (int s = 0; s < MB; ++s) gg += S.dyown[net][s][4 + (tid - 12) % 2];
+        float b = S.bias[tid], bm = S.bias_m[tid], bv = S.bias_v[tid];
+        adam1(b, gg * (net == 2 ? gs_cv : gs_ac), bm, bv, net == 2 ? cv_lr_bc1 : ac_lr_bc1, net == 2 ? cv_isq : ac_isq);
+        S.bias[tid] = b; S.bias_m[tid] = bm; S.bias_v[tid] = bv;
+      }
+    }
+    TS(3)
+    if (!last) {
+      __syncthreads();   // every wave is done with the old S.x1
+      // ================================================================== phase B: gather x1, forward L1
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v[12];
+        const int i0 = tid + NTH * 12 * h;
+        if (!ll_gather<12>(LL + LL_X1 + i0, NTH, tag, v, failflag)) S.fail = 1;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) (&S.x1[0][0][0])[i0 + NTH * j] = v[j];
+      }
+      TS(4)
+      __syncthreads();
+#pragma unroll
+      for (int net = 0; net < 3; ++net) {
+        float q[MB];
+#pragma unroll
+        for (int s = 0; s < MB; ++s) q[s] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = q1 * 256 + lane + 64 * i;
+#pragma unroll
+          for (int s = 0; s < MB; ++s) q[s] += w1[net][i] * S.x1[net][s][k];
+        }
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          const float r = wave_sum(q[s]);
+          if (lane == 0) S.fpart[(net * MB + s) * NWV + wave] = r;
+        }
+      }
+      __syncthreads();
+      if (tid < 3 * MB * 2) {
+        const int net = tid / (MB * 2), s = (tid / 2) % MB, r = tid % 2;
+        const float* q = &S.fpart[(net * MB + s) * NWV + 4 * r];
+        ll_store(LL + LL_X2 + (size_t)(net * MB + s) * U1 + 2 * g + r, elu(q[0] + q[1] + q[2] + q[3] + S.bias[12 + net * 2 + r]), tag);
+      }
+      TS(5)
+      // ---- (shadow of x2) Gram of x1
+      float p[33];
+#pragma unroll
+      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
+#pragma unroll
+      for (int h = 0; h < U0 / NTH; ++h)
+#pragma unroll
+        for (int net = 0; net < 3; ++net) { const int k = tid + NTH * h; gram_acc(&p[net * 11], S.x1[net][0][k], S.x1[net][1][k], S.x1[net][2][k], S.x1[net][3][k]); }
+      block_sum<33>(S, p, S.part, tid, wave, lane);
+      if (tid < 48) S.gx[tid >> 4][1][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+    }
+    refresh();
+    if (pending) {
+      // ---- (shadow of x2) Adam of layer 2 (row and column copies), of this CU's head elements, of the remaining biases and logstd
+      const float gs_ac = S.scal[0], gs_cv = S.scal[1];
+      const float ac_lr_bc1 = S.scal[2], ac_isq = S.scal[3], cv_lr_bc1 = S.scal[4], cv_isq = S.scal[5];
+      float dep = 0.0f;
+#pragma unroll
+      for (int net = 0; net < 3; ++net) {
+        const float gs = net == 2 ? gs_cv : gs_ac, lrb = net == 2 ? cv_lr_bc1 : ac_lr_bc1, isq = net == 2 ? cv_isq : ac_isq;
+        float d2r[MB], dn2[MB];
+        const int o_n = opaque(c2n, dep);
+#pragma unroll
+        for (int s = 0; s < MB; ++s) { d2r[s] = S.dyown[net][s][6] * gs; dn2[s] = S.dy2[net][s][o_n] * gs; }
+        {
+          const int k = opaque(wave * 64 + lane, dep);
+          float gg = 0.0f;
+#pragma unroll
+          for (int s = 0; s < MB; ++s) gg += d2r[s] * S.x2[net][s][k];
+          adam1(w2[net], gg, m2[net], v2[net], lrb, isq); dep = w2[net];
+        }
+        {
+          const int k = opaque(2 * g + c2c, dep);
+          float gg = 0.0f;
+#pragma unroll
+          for (int s = 0; s < MB; ++s) gg += dn2[s] * S.x2[net][s][k];
+          adam1(c2[net], gg, cm2[net], cv2[net], lrb, isq); dep = c2[net];
+        }
+      }
+      // heads: this CU's HPC elements; the new weight is published for phase D of every CU (tag == step)
+      if (tid < HPC) {
+        const int net = head_net(hrow);
+        const float gs = net == 2 ? gs_cv : gs_ac, lrb = net == 2 ? cv_lr_bc1 : ac_lr_bc1, isq = net == 2 ? cv_isq : ac_isq;
+        float gg = 0.0f;
+#pragma unroll
+        for (int s = 0; s < MB; ++s) gg += (hrow < A ? S.dmu[s][hrow] : S.dv[hrow - A][s]) * gs * S.x3[net][s][hk];
+        adam1(hw, gg, hm, hv, lrb, isq);
+        ll_store(LL + LL_HW + he, hw, (unsigned)step);
+      }
+      if (tid >= 18 && tid < 21 + A + 2) {   // layer-2 and head biases
+        int net; float gg = 0.0f;
+        if (tid < 21) { net = tid - 18; for (int s = 0; s < MB; ++s) gg += S.dyown[net][s][6]; }
+        else { const int row = tid - 21; net = head_net(row); for (int s = 0; s < MB; ++s) gg += row < A ? S.dmu[s][row] : S.dv[row - A][s]; }
+        float b = S.bias[tid], bm = S.bias_m[tid], bv = S.bias_v[tid];
+        adam1(b, gg * (net == 2 ? gs_cv : gs_ac), bm, bv, net == 2 ? cv_lr_bc1 : ac_lr_bc1, net == 2 ? cv_isq : ac_isq);
+        S.bias[tid] = b; S.bias_m[tid] = bm; S.bias_v[tid] = bv;
+      } else if (tid >= 64 && tid < 64 + A) {   // logstd
+        const int a = tid - 64;
+        float b = s_b2[0][a], bm = s_b2[1][a], bv = s_b2[2][a];
+        adam1(b, S.dls[a] * gs_ac, bm, bv, ac_lr_bc1, ac_isq);
+        s_b2[0][a] = b; s_b2[1][a] = bm; s_b2[2][a] = bv;
+      }
+    }
+    TS(6)
+    if (last) break;
+    __syncthreads();   // every wave is done with the old S.x2 / S.x3 / S.dy2 / S.dmu / S.dv
+    // ================================================================== phase C: gather x2, forward L2
+    const size_t r0 = (size_t)mbi * MB;
+    float pf_act = 0.0f, pf_omu = 0.0f, pf_osg = 1.0f;   // this minibatch's actions and old (mu, sigma): needed in phase D
+    float pf_adv = 0.0f, pf_nlp = 0.0f, pf_ret = 0.0f, pf_val = 0.0f;   // per-sample scalars, held by the lane that forms the sample's losses
+    if (tid < MB * 32 && (tid % 32) == 31) {
+      const size_t i = r0 + tid / 32;
+      pf_adv = D.adv[i]; pf_nlp = D.mb_neglogp[i]; pf_ret = D.returns[i]; pf_val = D.mb_values[i];
+    }
+    if (tid < MB * 32 && (tid % 32) < A) {
+      const size_t i = (r0 + tid / 32) * A + tid % 32;
+      pf_act = D.mb_actions[i];
+      // (mu, sigma) were rewritten by CU 0 one mini-epoch ago (update_mu_sigma): agent-scope accesses keep them coherent across XCDs
+      pf_omu = __hip_atomic_load(&D.mb_mus[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pf_osg = __hip_atomic_load(&D.mb_sigmas[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    {
+      float v[12];
+      if (!ll_gather<12>(LL + LL_X2 + tid, NTH, tag, v, failflag)) S.fail = 1;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) (&S.x2[0][0][0])[tid + NTH * j] = v[j];
+    }
+    TS(7)
+    __syncthreads();
+#pragma unroll
+    for (int net = 0; net < 3; ++net) {
+      const int k = wave * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < MB; ++s) {
+        const float r = wave_sum(w2[net] * S.x2[net][s][k]);
+        if (lane == 0) S.fpart[(net * MB + s) * NWV + wave] = r;
+      }
+    }
+    __syncthreads();
+    if (tid < 3 * MB) {
+      const int net = tid / MB, s = tid % MB;
+      const float* q = &S.fpart[(net * MB + s) * NWV];
+      float y = S.bias[18 + net];
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) y += q[w];
+      ll_store(LL + LL_X3 + (size_t)(net * MB + s) * U2 + g, elu(y), tag);
+    }
+    TS(8)
+    {   // ---- (shadow of x3) Gram of x2
+      float p[33];
+#pragma unroll
+      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
+#pragma unroll
+      for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.x2[net][0][tid], S.x2[net][1][tid], S.x2[net][2][tid], S.x2[net][3][tid]);
+      block_sum<33>(S, p, S.part, tid, wave, lane);
+      if (tid < 48) S.gx[tid >> 4][2][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+    }
+    if (tid < MB * 32) { S.act[tid / 32][tid % 32] = pf_act; S.omu[tid / 32][tid % 32] = pf_omu; S.osg[tid / 32][tid % 32] = pf_osg; }
+    if (tid >= 128 && tid < 128 + 32) S.ls[tid - 128] = (tid - 128 < A) ? s_b2[0][tid - 128] : 0.0f;
+    TS(9)
+    refresh();
+    // ================================================================== phase D: gather x3 and the heads, losses, backward to dY1
+    float wh[HR][4];   // this wave's head rows for the forward (row = wave + 8 j, columns 4 lane .. 4 lane + 3)
+    float wc[13];      // this lane's head column for the backward (column c2n, rows 13 c2c .. 13 c2c + 12)
+#pragma unroll
+    for (int j = 0; j < HR; ++j) {
+      const int row = wave + 8 * j;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wh[j][e] = 0.0f;
+      if (row < A + 2) {
+        if (step == 0) {
+          const float* hp = P_of(head_net(row)) + head_woff(row) + 4 * lane;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wh[j][e] = hp[e];
+        } else if (!ll_gather<4>(LL + LL_HW + (size_t)row * U2 + 4 * lane, 1, (unsigned)step, wh[j], failflag)) S.fail = 1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 13; ++j) wc[j] = 0.0f;
+    if (step == 0) {
+#pragma unroll
+      for (int j = 0; j < 13; ++j) { const int row = 13 * c2c + j; if (row < A + 2) wc[j] = P_of(head_net(row))[head_woff(row) + c2n]; }
+    } else if (c2c == 0) {
+      if (!ll_gather<13>(LL + LL_HW + c2n, U2, (unsigned)step, wc, failflag)) S.fail = 1;
+    } else {
+      float t[12];
+      if (!ll_gather<12>(LL + LL_HW + (size_t)13 * U2 + c2n, U2, (unsigned)step, t, failflag)) S.fail = 1;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) wc[j] = t[j];
+    }
+    {
+      float v[6];
+      if (!ll_gather<6>(LL + LL_X3 + tid, NTH, tag, v, failflag)) S.fail = 1;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) (&S.x3[0][0][0])[tid + NTH * j] = v[j];
+    }
+    TS(10)
+    __syncthreads();
+    // head forward: wave per row
+#pragma unroll
+    for (int j = 0; j < HR; ++j) {
+      const int row = wave + 8 * j;
+      if (row < A + 2) {
+        const int net = head_net(row);
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          float q = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q += wh[j][e] * S.x3[net][s][4 * lane + e];
+          const float y = wave_sum(q) + S.bias[21 + row];
+          if (lane == 0) { if (row < A) S.mu[s][row] = y; else S.val[row - A][s] = y; }
+        }
+      }
+    }
+    __syncthreads();
+    TS(11)
+    const float invM = 1.0f / (float)MB;
+    if (tid < MB * 32) {
+      const int s = tid / 32, a = tid % 32;
+      S.z[s][a] = (a < A) ? (S.act[s][a] - S.mu[s][a]) / expf(S.ls[a]) : 0.0f;
+    }
+    __syncthreads();
+    {
+      float r_nlp = 0.0f, r_kl = 0.0f, r_bl = 0.0f, r_ent = 0.0f;
+      if (tid < MB * 32) {
+        const int s = tid / 32, a = tid % 32;
+        if (a < A) {
+          const float ls = S.ls[a], sg = expf(ls), mu = S.mu[s][a];
+          r_nlp = 0.5f * S.z[s][a] * S.z[s][a] + ls;
+          const float omu = S.omu[s][a], osg = S.osg[s][a];
+          r_kl = logf(osg / sg + 1e-5f) + (sg * sg + (omu - mu) * (omu - mu)) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
+          const float hi = fmaxf(mu - 1.1f, 0.0f), lo = fminf(mu + 1.1f, 0.0f);
+          r_bl = hi * hi + lo * lo;
+          r_ent = 0.5f + 0.5f * 1.8378770664093453f + ls;
+        }
+      }
+      r_nlp = half_sum(r_nlp); r_kl = half_sum(r_kl); r_bl = half_sum(r_bl); r_ent = half_sum(r_ent);
+      if (tid < MB * 32 && (tid % 32) == 31) {
+        const int s = tid / 32;
+        const float nlp = r_nlp + 0.5f * 1.8378770664093453f * (float)A;
+        const float adv = pf_adv;
+        const float ratio = expf(pf_nlp - nlp);
+        const float L1 = -adv * ratio, L2 = -adv * clampf(ratio, 1.0f - D.e_clip, 1.0f + D.e_clip);
+        const bool inr = ratio >= 1.0f - D.e_clip && ratio <= 1.0f + D.e_clip;
+        S.gnlp[s] = (L1 > L2 || inr) ? adv * ratio : 0.0f;
+        const float R = pf_ret, vo = pf_val;
+        float closs[2];
+        for (int j = 0; j < 2; ++j) {
+          const float v = S.val[j][s];
+          const float vc = vo + clampf(v - vo, -D.e_clip, D.e_clip);
+          const float c1v = (v - R) * (v - R), c2v = (vc - R) * (vc - R);
+          float d;
+          if (D.clip_value) {
+            closs[j] = fmaxf(c1v, c2v);
+            const bool inv = fabsf(v - vo) <= D.e_clip;
+            d = (c1v > c2v || inv) ? 2.0f * (v - R) : 0.0f;
+          } else { closs[j] = c1v; d = 2.0f * (v - R); }
+          S.dv[j][s] = (j == 0 ? 0.5f * D.critic_coef : 1.0f) * d * invM;
+        }
+        S.stat[s][1] = fmaxf(L1, L2); S.stat[s][2] = closs[0]; S.stat[s][3] = r_bl; S.stat[s][4] = r_kl;
+        S.stat[s][5] = closs[1]; S.stat[s][6] = r_ent;
+      }
+    }
+    __syncthreads();
+    if (tid < MB * 32) {
+      const int s = tid / 32, a = tid % 32;
+      float dmu = 0.0f;
+      if (a < A) {
+        const float sg = expf(S.ls[a]), mu = S.mu[s][a];
+        const float hi = fmaxf(mu - 1.1f, 0.0f), lo = fminf(mu + 1.1f, 0.0f);
+        dmu = S.gnlp[s] * (-(S.z[s][a] / sg)) * invM + D.bounds_coef * (2.0f * hi + 2.0f * lo) * invM;
+        if (g == 0) { __hip_atomic_store(&D.mb_mus[(r0 + s) * A + a], mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&D.mb_sigmas[(r0 + s) * A + a], sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // update_mu_sigma (RC:1358)
+      }
+      S.dmu[s][a] = dmu;
+    }
+    if (tid >= 128 && tid < 128 + 32) {
+      const int a = tid - 128;
+      float dls = 0.0f;
+      if (a < A) for (int s = 0; s < MB; ++s) dls += S.gnlp[s] * (1.0f - S.z[s][a] * S.z[s][a]) * invM;
+      S.dls[a] = dls;
+    }
+    __syncthreads();
+    TS(12)
+    // backward through the heads: lane (column k, row half) forms its part of dX3[.][k], the halves meet in LDS; elu' applied here
+    {
+      const int k = c2n;
+      float a0[MB], a1[MB], a2[MB];
+#pragma unroll
+      for (int s = 0; s < MB; ++s) { a0[s] = 0.0f; a1[s] = 0.0f; a2[s] = 0.0f; }
+      if (c2c == 0) {
+#pragma unroll
+        for (int j = 0; j < 13; ++j)
+#pragma unroll
+          for (int s = 0; s < MB; ++s) a0[s] += S.dmu[s][j] * wc[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < A - 13; ++j)
+#pragma unroll
+          for (int s = 0; s < MB; ++s) a0[s] += S.dmu[s][13 + j] * wc[j];
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          a1[s] = S.dv[0][s] * wc[A - 13]; a2[s] = S.dv[1][s] * wc[A - 12];
+          S.dy2[0][s][k] = a0[s];
+          S.dy2[1][s][k] = a1[s] * elu_g(S.x3[1][s][k]);
+          S.dy2[2][s][k] = a2[s] * elu_g(S.x3[2][s][k]);
+        }
+      }
+      __syncthreads();
+      if (c2c == 0) {
+#pragma unroll
+        for (int s = 0; s < MB; ++s) S.dy2[0][s][k] = (S.dy2[0][s][k] + a0[s]) * elu_g(S.x3[0][s][k]);
+      }
+      __syncthreads();
+    }
+    TS(13)
+    // backward L2 with the column copy: dY1[net][s][2g+c] = (sum_n dY2[net][s][n] W2[n][2g+c]) * elu'(x2[net][s][2g+c])
+    {
+      float p[24];
+#pragma unroll
+      for (int net = 0; net < 3; ++net)
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          const float v = S.dy2[net][s][c2n] * c2[net];
+          p[(net * MB + s) * 2 + 0] = c2c == 0 ? v : 0.0f;
+          p[(net * MB + s) * 2 + 1] = c2c == 1 ? v : 0.0f;
+        }
+      block_sum<24>(S, p, S.part, tid, wave, lane);
+      if (tid < 24) {
+        const int net = tid / 8, s = (tid / 2) % MB, c = tid % 2;
+        const float v = S.part[tid] * elu_g(S.x2[net][s][2 * g + c]);
+        ll_store(LL + LL_DY1 + (size_t)(net * MB + s) * U1 + 2 * g + c, v, tag);
+        S.dyown[net][s][4 + c] = v;
+      }
+    }
+    TS(14)
+    // ---- (shadow of dY1) loss statistics + LR rule, Grams of x3 and dY2, head / logstd terms of the squared gradient norm
+    if (tid == 0) {
+      PLds::Ctl& C = S.ctl;
+      float t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+      for (int s = 0; s < MB; ++s) { t1 += S.stat[s][1]; t2 += S.stat[s][2]; t3 += S.stat[s][3]; t4 += S.stat[s][4]; t5 += S.stat[s][5]; t6 += S.stat[s][6]; }
+      const float kl = t4 * invM;
+      C.sum_a += t1 * invM; C.sum_c += t2 * invM; C.sum_b += t3 * invM; C.sum_kl += kl; C.sum_cv += t5 * invM; C.sum_ent += t6 * invM;
+      C.last_kl = kl;
+      C.ac_lr_applied = C.ac_lr;   // the optimiser step of THIS minibatch uses the current lr; the schedule moves it afterwards
+      if (D.adaptive_lr) {         // legacy schedule: after every minibatch (PS:306-312)
+        if (kl > 2.0f * D.kl_threshold) C.ac_lr = fmaxf(C.ac_lr / 1.5f, 1e-6f);
+        if (kl < 0.5f * D.kl_threshold) C.ac_lr = fminf(C.ac_lr * 1.5f, 1e-2f);
+      }
+    }
+    {
+      float p[33];
+#pragma unroll
+      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
+      if (tid < U2) {
+#pragma unroll
+        for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.x3[net][0][tid], S.x3[net][1][tid], S.x3[net][2][tid], S.x3[net][3][tid]);
+      }
+      block_sum<33>(S, p, S.part, tid, wave, lane);
+      if (tid < 48) S.gx[tid >> 4][3][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+#pragma unroll
+      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
+      if (tid < U2) {
+#pragma unroll
+        for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.dy2[net][0][tid], S.dy2[net][1][tid], S.dy2[net][2][tid], S.dy2[net][3][tid]);
+      }
+      block_sum<33>(S, p, S.part, tid, wave, lane);
+      if (tid < 48) S.gd[tid >> 4][2][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+      else if (tid >= 64 && tid < 67) S.bsq[tid - 64][2] = S.part[(tid - 64) * 11 + 10];
+      else if (tid >= 128 && tid < 128 + 3 * MB) { const int net = (tid - 128) / MB, s = (tid - 128) % MB; S.dyown[net][s][6] = S.dy2[net][s][g]; }
+      __syncthreads();
+    }
+    // squared-norm contributions of the heads and logstd
+    {
+      // thread (net, a, b) forms one Gram product; reduce through LDS
+      if (tid < 48) {
+        const int net = tid / 16, a = (tid / 4) % 4, b = tid % 4;
+        float dd = 0.0f;
+        if (net == 0) { for (int j = 0; j < A; ++j) dd += S.dmu[a][j] * S.dmu[b][j]; }
+        else dd = S.dv[net - 1][a] * S.dv[net - 1][b];
+        S.part[tid] = dd * S.gx[net][3][a * 4 + b];
+      } else if (tid >= 64 && tid < 64 + 32) {
+        const int j = tid - 64;
+        float t = 0.0f;
+        if (j < A) { float sb = 0; for (int a = 0; a < MB; ++a) sb += S.dmu[a][j]; t = sb * sb + S.dls[j] * S.dls[j]; }
+        S.part[tid] = t;
+      }
+      __syncthreads();
+      if (tid < 3) {
+        const int net = tid;
+        float acc = 0.0f;
+        for (int i = 0; i < 16; ++i) acc += S.part[net * 16 + i];
+        if (net == 0) { for (int j = 0; j < A; ++j) acc += S.part[64 + j]; }
+        else { float sb = 0; for (int a = 0; a < MB; ++a) sb += S.dv[net - 1][a]; acc += sb * sb; }
+        S.ctl.n2h[net] = acc;
+      }
+      __syncthreads();
+    }
+    TS(15)
+    refresh();
+    // ================================================================== phase E: gather dY1, backward L1
+    {
+      float v[12];
+      if (!ll_gather<12>(LL + LL_DY1 + tid, NTH, tag, v, failflag)) S.fail = 1;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) (&S.dy1[0][0][0])[tid + NTH * j] = v[j];
+    }
+    TS(16)
+    __syncthreads();
+    {
+      float p[48];
+#pragma unroll
+      for (int net = 0; net < 3; ++net)
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          const float d = S.dy1[net][s][tid];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) p[(net * MB + s) * 4 + c] = d * c1[net][c];
+        }
+      block_sum<48>(S, p, S.part, tid, wave, lane);
+      if (tid < 48) {
+        const int net = tid / 16, s = (tid / 4) % MB, c = tid % 4;
+        const float v = S.part[tid] * elu_g(S.x1[net][s][4 * g + c]);
+        ll_store(LL + LL_DY0 + (size_t)(net * MB + s) * U0 + 4 * g + c, v, tag);
+        S.dyown[net][s][c] = v;
+      }
+    }
+    TS(17)
+    {   // ---- (shadow of dY0) Gram of dY1
+      float p[33];
+#pragma unroll
+      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
+#pragma unroll
+      for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.dy1[net][0][tid], S.dy1[net][1][tid], S.dy1[net][2][tid], S.dy1[net][3][tid]);
+      block_sum<33>(S, p, S.part, tid, wave, lane);
+      if (tid < 48) S.gd[tid >> 4][1][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+      else if (tid >= 64 && tid < 67) S.bsq[tid - 64][1] = S.part[(tid - 64) * 11 + 10];
+    }
+    TS(18)
+    pending = true;
+  }
+
+  if (stamps && g == 0 && tid < 32) D.dbg[tid] = S.tacc[tid];
+  // ------------------------------------------------------------------ epilogue: resident parameters back to HBM
+  refresh();
+#pragma unroll
+  for (int i = 0; i < I0A; ++i) {
+    const int kk = lane + 64 * i, k = h0 * H0A + kk;
+    if (kk < H0A) {
+      const size_t oa = woff(0, 0) + (size_t)n0 * OBS + k, oc = woff(1, 0) + (size_t)n0 * OBS + k;
+      D.ac[oa] = w0a[i]; D.ac_m[oa] = m0a[i]; D.ac_v[oa] = v0a[i];
+      D.ac[oc] = w0c[i]; D.ac_m[oc] = m0c[i]; D.ac_v[oc] = v0c[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < I0V; ++i) {
+    const int kk = lane + 64 * i, k = h0 * H0V + kk;
+    if (kk < H0V) { const size_t o = woff(2, 0) + (size_t)n0 * ST + k; D.cv[o] = w0v[i]; D.cv_m[o] = m0v[i]; D.cv_v[o] = v0v[i]; }
+  }
+#pragma unroll
+  for (int net = 0; net < 3; ++net) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t o = woff(net, 1) + (size_t)r1 * U0 + q1 * 256 + lane + 64 * i;
+      P_of(net)[o] = w1[net][i]; M_of(net)[o] = m1[net][i]; V_of(net)[o] = v1[net][i];
+    }
+    {
+      const size_t o = woff(net, 2) + (size_t)g * U1 + wave * 64 + lane;
+      P_of(net)[o] = w2[net]; M_of(net)[o] = m2[net]; V_of(net)[o] = v2[net];
+    }
+  }
+  if (tid < HPC) {
+    const int net = head_net(hrow);
+    const size_t o = head_woff(hrow) + hk;
+    P_of(net)[o] = hw; M_of(net)[o] = hm; V_of(net)[o] = hv;
+  }
+  if (g == 0) {
+    if (tid >= 21 && tid < 21 + A + 2) {
+      const int row = tid - 21, net = head_net(row);
+      const size_t o = head_boff(row);
+      P_of(net)[o] = S.bias[tid]; M_of(net)[o] = S.bias_m[tid]; V_of(net)[o] = S.bias_v[tid];
+    }
+    if (tid >= 64 && tid < 64 + A) {
+      const int a = tid - 64;
+      const size_t o = D.off.logstd + a;
+      D.ac[o] = s_b2[0][a]; D.ac_m[o] = s_b2[1][a]; D.ac_v[o] = s_b2[2][a];
+    }
+    if (tid == 0) {
+      const PLds::Ctl& C = S.ctl;
+      gctl->ac_lr = C.ac_lr; gctl->ac_t = C.ac_t; gctl->cv_t = C.cv_t;
+      gctl->ac_b1pow = C.ac_b1; gctl->ac_b2pow = C.ac_b2; gctl->cv_b1pow = C.cv_b1; gctl->cv_b2pow = C.cv_b2;
+      gctl->sum_a_loss = C.sum_a; gctl->sum_c_loss = C.sum_c; gctl->sum_b_loss = C.sum_b; gctl->sum_kl = C.sum_kl;
+      gctl->sum_cv_loss = C.sum_cv; gctl->sum_entropy = C.sum_ent; gctl->n_mb = total_steps; gctl->last_kl = C.last_kl;
+      gctl->ac_gnorm = C.ac_gn; gctl->cv_gnorm = C.cv_gn; gctl->ac_pending = 0; gctl->cv_pending = 0;
+      gctl->mb_index = 0; gctl->mini_epoch = total_steps / D.num_minibatches;
+    }
+  }
+  if (tid < 12) {
+    const int net = tid / 4, w = tid % 4;
+    const size_t o = boff(net, 0) + 4 * g + w;
+    P_of(net)[o] = S.bias[tid]; M_of(net)[o] = S.bias_m[tid]; V_of(net)[o] = S.bias_v[tid];
+  } else if (tid < 18) {
+    const int net = (tid - 12) / 2, r = (tid - 12) % 2;
+    const size_t o = boff(net, 1) + 2 * g + r;
+    P_of(net)[o] = S.bias[tid]; M_of(net)[o] = S.bias_m[tid]; V_of(net)[o] = S.bias_v[tid];
+  } else if (tid < 21) {
+    const int net = tid - 18;
+    const size_t o = boff(net, 2) + g;
+    P_of(net)[o] = S.bias[tid]; M_of(net)[o] = S.bias_m[tid]; V_of(net)[o] = S.bias_v[tid];
+  }
+}
+
+extern "C" size_t sdxpk_persist_lds_bytes() { return sizeof(PLds); }
+extern "C" int sdxpk_persist_supported(const SdxpDev* D, int minibatch, int n_cus) {
+  return minibatch == MB && D->obs_dim == OBS && D->state_dim == ST && D->units[0] == U0 && D->units[1] == U1 &&
+         D->units[2] == U2 && D->act_dim == ACT && n_cus >= NWG;
+}
+extern "C" int sdxpk_update_persistent(const SdxpDev* D, int total_steps, unsigned* bar, unsigned* failflag, hipStream_t st) {
+  static bool attr = false;
+  static const int stamps = (getenv("SDXP_PERSIST_STAMPS") && getenv("SDXP_PERSIST_STAMPS")[0] == '1') ? 1 : 0;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_persistent), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(PLds)) != hipSuccess) return -1;
+    attr = true;
+  }
+  if (hipMemsetAsync(bar, 0, 256, st) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_update_persistent, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, total_steps, bar, failflag, stamps);
+  return 0;
+}

@@ -33,6 +33,8 @@ struct SdxpCtrl {
   double ac_b1pow, ac_b2pow, cv_b1pow, cv_b2pow;   // running beta^t of the fused path (bias corrections)
 };
 
+#define SDXP_LL_WORDS 65536
+
 struct SdxpDev {
   int32_t N, horizon, obs_dim, state_dim, act_dim, units[3];
   int32_t num_minibatches, rows_per_wave, bsplit;
@@ -57,4 +59,5 @@ struct SdxpDev {
   float* dlogstd;        // [2][32]
   SdxpCtrl* ctrl;
   long long* dbg;        // [64] phase timestamps (s_memtime) written by thread 0 of the single-block kernels
+  unsigned long long* ll; // [SDXP_LL_WORDS] (value, step tag) words exchanged between the CUs of the persistent update kernel
 };

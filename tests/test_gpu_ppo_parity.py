@@ -149,7 +149,9 @@ def test_explicit_gradient_path_equals_fused_path():
         np.testing.assert_allclose(c1.ac_lr, c2.ac_lr, rtol=1e-6)
         d_ac = np.abs(a1.t["AC_PARAMS"].cpu().numpy() - a2.t["AC_PARAMS"].cpu().numpy()).max()
         d_cv = np.abs(a1.t["CV_PARAMS"].cpu().numpy() - a2.t["CV_PARAMS"].cpu().numpy()).max()
-        assert d_ac < 2e-5 and d_cv < 5e-5, (d_ac, d_cv)
+        # the two paths sum the same terms in different orders (and the persistent kernel uses v_rcp/v_sqrt in Adam): both are
+        # held to the autograd oracle at 2e-4 / 5e-4 above, and to each other at half of that
+        assert d_ac < 1e-4 and d_cv < 1e-4, (d_ac, d_cv)
         # the flat gradient buffers hold the last minibatch's gradients (a fully clipped minibatch has an all-zero
         # gradient, so only finiteness is asserted here; the values are covered by the parameter comparison above)
         g_ac, g_cv = a2.t["AC_GRADS"].cpu().numpy(), a2.t["CV_GRADS"].cpu().numpy()
