@@ -22,6 +22,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_ENV_STEP = 18496     # algorithmic HBM bytes per env-step of the sim+task path
+# HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+# separate runs of this same command at the default config; both counters are in KiB; FETCH_SIZE is reported raw - the guide's
+# x2 correction is calibrated for 16 B/lane streaming reads only, the exchange words here are 8 B/lane).  PMC counters cannot
+# be read from inside this process, so `traffic` is quoted from those files and is null for any other configuration.
+PMC_TRAFFIC_BYTES = {("k_update_persistent", 1024): (15711795.9 + 5536986.1) * 1024,     # profiles/r1_bench_pmc_{fetch,write}_v2.csv
+                     ("k_physics", 1024): (1325.4 + 6929.0) * 1024}
 
 
 def parse():
@@ -32,28 +38,57 @@ def parse():
     ap.add_argument("--num-envs", type=int, default=1024, help="envs per GPU (config[1]: 1024)")
     ap.add_argument("--minibatch", type=int, default=None, help="override minibatch_size (labelled variant, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-envs", type=int, default=64)
-    ap.add_argument("--cpu-baseline-steps", type=int, default=6)
+    ap.add_argument("--cpu-baseline-envs", type=int, default=1024)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=16)
+    ap.add_argument("--cpu-baseline-ppo-envs", type=int, default=8, help="PPO leg: envs of the sample dataset (8 x horizon rows)")
     return ap.parse_args()
 
 
-def cpu_baseline(args, scene_desc, root0, dof0, targets0):
-    """oracle/physics_oracle.c (plain-C port of the same env physics step, OpenMP over envs) timed on the host cores
-    on a bounded sample: `cpu_baseline_envs` envs x `cpu_baseline_steps` steps starting from settled piles."""
+def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mini_epochs):
+    """CPU port of the same hot path, timed on the host cores on a bounded sample (reported beside the GPU number, not a target):
+    sim leg  = oracle/physics_oracle.c (plain-C port of the env physics step, OpenMP over envs) on the bench's own settled piles;
+    PPO leg  = oracle/ppo_oracle.py (torch-CPU autograd + Adam, same three networks and hyper-parameters) on a small dataset,
+               scaled to the optimiser steps of one epoch.  value = env-steps/s of sim leg + PPO leg together ("fps total")."""
     import numpy as np
+    import torch
     from oracle import physics_oracle as po
+    from oracle.ppo_oracle import PPOOracle, DEFAULT_CFG
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    n = min(args.cpu_baseline_envs, root0.shape[0])
+    n_full = root0.shape[0]
+    n = min(args.cpu_baseline_envs, n_full)
     root, dof, tg = root0[:n].copy(), dof0[:n].copy(), targets0[:n].copy()
     po.simulate(scene_desc, root, dof, tg)            # warm-up (also builds the .so if needed)
     t = time.time()
     for _ in range(args.cpu_baseline_steps):
         po.simulate(scene_desc, root, dof, tg)
-    dt = time.time() - t
-    return {"value": n * args.cpu_baseline_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d physics steps (oracle/physics_oracle.c, OpenMP over envs, %d threads); sim step only, "
-                      "no PPO" % (n, args.cpu_baseline_steps, cores)}
+    sim_dt = time.time() - t
+    sim_rate = n * args.cpu_baseline_steps / sim_dt
+    # PPO leg (rank-4 minibatches: the torch-CPU step is dispatch/Adam-stream bound, more than ~16 threads only adds fork/join cost)
+    ppo_threads = min(16, cores)
+    torch.set_num_threads(ppo_threads)
+    m = args.cpu_baseline_ppo_envs
+    oc = dict(DEFAULT_CFG)
+    oc.update(minibatch=minibatch, mini_epochs=mini_epochs)
+    orc = PPOOracle(oc, seed=0)
+    g = torch.Generator().manual_seed(0)
+    R = m * horizon
+    ds = dict(obs=torch.randn(R, 396, generator=g), states=torch.randn(R, 564, generator=g), actions=torch.randn(R, 23, generator=g),
+              mus=torch.zeros(R, 23), sigmas=torch.ones(R, 23), neglogp=torch.full((R,), 30.0), values=torch.zeros(R),
+              returns=torch.randn(R, generator=g))
+    t = time.time()
+    orc.update(ds)
+    ppo_dt = time.time() - t
+    ppo_steps = mini_epochs * (R // minibatch)
+    us_per_opt_step = ppo_dt / ppo_steps * 1e6
+    epoch_opt_steps = mini_epochs * (n_full * horizon // minibatch)
+    epoch_s = n_full * horizon / sim_rate + epoch_opt_steps * us_per_opt_step * 1e-6
+    return {"value": n_full * horizon / epoch_s, "unit": "env-steps/s", "cores": cores, "kind": "port", "ppo_threads": ppo_threads,
+            "sim_only_env_steps_per_s": sim_rate, "ppo_us_per_optimiser_step": us_per_opt_step,
+            "sample": "sim: %d envs x %d physics steps of oracle/physics_oracle.c (OpenMP over envs, %d threads), %.1f s; "
+                      "PPO: %d optimiser steps (minibatch %d) of oracle/ppo_oracle.py on torch-CPU (%d threads), %.1f s, scaled to the "
+                      "%d steps of one epoch; no policy inference / obs kernels in the CPU number"
+                      % (n, args.cpu_baseline_steps, cores, sim_dt, ppo_steps, minibatch, torch.get_num_threads(), ppo_dt, epoch_opt_steps)}
 
 
 def main():
@@ -132,16 +167,34 @@ def main():
     phys_ms = e0.elapsed_time(e1) / reps
     phys_bytes = BYTES_PER_ENV_STEP * n
     roof_phys = {"kernel": "k_physics", "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes, "traffic": None}
+                 "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes,
+                 "traffic": PMC_TRAFFIC_BYTES.get(("k_physics", n))}
     roof_phys["frac"] = roof_phys["achieved"] / HBM_PEAK_GBS
-    # ---- roofline of the update phase: one optimiser step streams w,m,v in and out once for all three networks
+    # ---- roofline of the update phase.  Algorithmic bytes: one optimiser step streams w, m, v in and out once for all three
+    # networks (6 x 4 B x params); the persistent kernel runs all optimiser steps of the epoch in ONE launch and keeps w, m, v in
+    # VGPRs, so its real HBM traffic is far below that figure
     p_ac, p_cv = agent.ppo.param_count(0), agent.ppo.param_count(1)
     nsteps = agent.mini_epochs_num * (n * horizon // agent.minibatch_size)
     upd_bytes_step = 6 * 4 * (p_ac + p_cv)
-    upd_ms_step = upd_t / args.steps / nsteps * 1e3
-    roof_upd = {"kernel": "k_layer/k_head/k_back/k_ctrl (one optimiser step, 3 networks)", "bound": "hbm",
-                "achieved": upd_bytes_step / (upd_ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "avg_step_ms": upd_ms_step, "algorithmic_bytes_per_step": upd_bytes_step, "traffic": None}
+    impl = agent.ppo.update_impl() if world == 1 else "explicit"
+    if impl == "persistent":
+        for _ in range(2):      # HIP events on the stream the kernel is launched on (torch's current stream)
+            e0.record()
+            agent.ppo.update()
+            e1.record()
+            torch.cuda.synchronize()
+        upd_launch_ms = e0.elapsed_time(e1)
+        kname, launches = "k_update_persistent (%d optimiser steps, 3 networks, per launch)" % nsteps, 1
+    else:
+        upd_launch_ms = upd_t / args.steps * 1e3
+        kname = ("k_layer/k_head/k_back/k_ctrl hipGraph (per epoch: %d optimiser steps, 3 networks)" % nsteps if impl == "graph" else
+                 "k_grad_layer/k_grad_heads + RCCL all-reduce + k_adam_explicit (per epoch: %d optimiser steps)" % nsteps)
+        launches = nsteps
+    upd_ms_step = upd_launch_ms / nsteps
+    roof_upd = {"kernel": kname, "bound": "hbm", "achieved": upd_bytes_step / (upd_ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "avg_launch_ms": upd_launch_ms, "us_per_optimiser_step": upd_ms_step * 1e3,
+                "algorithmic_bytes_per_launch": upd_bytes_step * nsteps,
+                "traffic": PMC_TRAFFIC_BYTES.get(("k_update_persistent", n)) if impl == "persistent" and args.minibatch is None else None}
     roof_upd["frac"] = roof_upd["achieved"] / HBM_PEAK_GBS
     dominant = roof_upd if upd_t > step_t else roof_phys
     out = {
@@ -156,7 +209,7 @@ def main():
         "fps_total_rank0": n * horizon * args.steps / (play_t + upd_t),
         "update_ms_per_epoch": upd_t / args.steps * 1e3, "rollout_ms_per_epoch": play_t / args.steps * 1e3,
         "roofline": {"bound": dominant["bound"], "achieved": dominant["achieved"], "peak": dominant["peak"],
-                     "unit": "GB/s", "frac": dominant["frac"], "traffic": None, "kernel": dominant["kernel"]},
+                     "unit": "GB/s", "frac": dominant["frac"], "traffic": dominant["traffic"], "kernel": dominant["kernel"]},
         "roofline_physics": roof_phys, "roofline_update": roof_upd,
     }
     if not args.no_cpu_baseline:
@@ -164,7 +217,7 @@ def main():
             root = sim.ROOT.view(n, 142, 13).cpu().numpy().copy()
             dof = sim.DOF.view(n, 23, 2).cpu().numpy().copy()
             tg = sim.TARGETS.cpu().numpy().copy()
-            out["cpu_baseline"] = cpu_baseline(args, sim._desc, root, dof, tg)
+            out["cpu_baseline"] = cpu_baseline(args, sim._desc, root, dof, tg, horizon, agent.minibatch_size, agent.mini_epochs_num)
         except Exception as ex:   # the checker is optional for the measurement itself
             out["cpu_baseline"] = {"value": None, "error": str(ex)}
     print(json.dumps(out))

@@ -286,6 +286,10 @@ int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const int64
  * mini-epochs, contiguous unshuffled minibatches, loss R7, grad-norm clip, Adam, legacy adaptive LR after
  * every minibatch (R8).  Single-rank fast path: everything stays on the device. */
 int sdxp_update(sdxp_handle h, void* stream);
+/* Which implementation sdxp_update runs on this handle: 1 = persistent kernel (one launch per epoch, weights and Adam moments
+ * resident in the VGPR files of 256 CUs; needs the shipped shapes, minibatch_size 4 and a 256-CU device), 0 = hipGraph of the
+ * multi-kernel optimiser step (any minibatch_size in {2,4,8}; forced with SDXP_UPDATE_IMPL=graph). */
+int sdxp_update_impl(sdxp_handle h);
 /* Multi-rank path, one minibatch at a time so that the caller can all-reduce SDXP_T_*_GRADS in between:
  * which = 0 actor-critic, 1 central value; mb = minibatch index within the epoch. */
 int sdxp_backward(sdxp_handle h, int32_t which, int32_t mb, void* stream);

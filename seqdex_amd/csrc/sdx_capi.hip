@@ -237,9 +237,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
 
 extern "C" int sdx_destroy(sdx_handle h) {
   if (!h) return SDX_ERR_INVALID;
-  hipSetDevice(h->device);
-  hipDeviceSynchronize();
-  for (void* p : h->allocs) hipFree(p);
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return SDX_OK;
 }

@@ -377,4 +377,6 @@ extern "C" int sdxp_apply(sdxp_handle h, int32_t which, float kl, void* stream) 
   sdxpk_apply_explicit(&h->D, which, kl, h->cfg.world_size > 0 ? h->cfg.world_size : 1, (hipStream_t)stream);
   return plaunch_ok(h, "sdxp_apply");
 }
+extern "C" int sdxp_update_impl(sdxp_handle h) { return h && h->use_persist ? 1 : 0; }
+
 extern "C" const char* sdxp_last_error(sdxp_handle h) { return h ? h->err.c_str() : gp_create_err.c_str(); }

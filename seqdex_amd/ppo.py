@@ -102,6 +102,10 @@ class SdxPPO:
     def update(self):
         self._check(self.lib.sdxp_update(self.h, _stream_ptr(self.device)))
 
+    def update_impl(self):
+        """'persistent' (one launch per epoch, register-resident weights) or 'graph' (hipGraph of the multi-kernel step)"""
+        return "persistent" if self.lib.sdxp_update_impl(self.h) == 1 else "graph"
+
     # ---- explicit-gradient path for world_size > 1 (gradients all-reduced by the caller between the two calls)
     def backward(self, which, mb):
         self._check(self.lib.sdxp_backward(self.h, which, mb, _stream_ptr(self.device)))

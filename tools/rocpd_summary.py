@@ -1,0 +1,20 @@
+"""Turn rocprofv3's rocpd sqlite outputs (gpurun_out/prof_*/..._results.db) into the small CSV summaries kept under profiles/.
+usage: python tools/rocpd_summary.py stats <db> <out.csv> | pmc <db> <out.csv>"""
+import csv
+import sqlite3
+import sys
+
+mode, db, out = sys.argv[1:4]
+c = sqlite3.connect(db)
+with open(out, "w", newline="") as f:
+    w = csv.writer(f)
+    if mode == "stats":
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+        for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+            w.writerow([name.split("(")[0][:80], calls, "%.1f" % total, "%.2f" % avg, "%.3f" % pct])
+    else:
+        w.writerow(["kernel", "counter", "dispatches", "avg_value", "min_value", "max_value", "avg_duration_us"])
+        q = ("select kernel_name,counter_name,count(*),avg(value),min(value),max(value),avg(duration) from counters_collection "
+             "group by 1,2 order by 4 desc")
+        for name, cn, n, a, lo, hi, d in c.execute(q):
+            w.writerow([name.split("(")[0][:80], cn, n, "%.1f" % a, "%.1f" % lo, "%.1f" % hi, "%.1f" % (d / 1e3)])
