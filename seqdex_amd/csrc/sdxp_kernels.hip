@@ -865,12 +865,22 @@ __global__ void k_cv_prenorm(SdxpDev D) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= D.state_dim) return;
   const int S = D.state_dim;
-  const size_t R = (size_t)D.N * D.horizon;
+  const float* __restrict__ src = D.mb_states;
+  float* __restrict__ dst = D.cvx0;
   double mean = D.rms_mean[k], var = D.rms_var[k], cnt = D.ctrl->rms_count;
+  // the running statistics form a serial chain over the minibatches; the rows of the next minibatch are fetched while the
+  // chain of the current one runs, so that the chain, not the HBM latency, sets the time per minibatch
+  float xn[MB];
+#pragma unroll
+  for (int s = 0; s < MB; ++s) xn[s] = src[(size_t)s * S + k];
   for (int mb = 0; mb < D.num_minibatches; ++mb) {
     float x[MB];
 #pragma unroll
-    for (int s = 0; s < MB; ++s) x[s] = D.mb_states[((size_t)mb * MB + s) * S + k];
+    for (int s = 0; s < MB; ++s) x[s] = xn[s];
+    if (mb + 1 < D.num_minibatches) {
+#pragma unroll
+      for (int s = 0; s < MB; ++s) xn[s] = src[((size_t)(mb + 1) * MB + s) * S + k];
+    }
     if (D.cv_normalize_input) {
       double bm = 0.0, bv = 0.0;
 #pragma unroll
@@ -888,15 +898,21 @@ __global__ void k_cv_prenorm(SdxpDev D) {
     const float fm = (float)mean, rs = sqrtf((float)var + 1e-5f);
 #pragma unroll
     for (int s = 0; s < MB; ++s)
-      D.cvx0[((size_t)mb * MB + s) * S + k] = D.cv_normalize_input ? clampf((x[s] - fm) / rs, -5.0f, 5.0f) : x[s];
+      dst[((size_t)mb * MB + s) * S + k] = D.cv_normalize_input ? clampf((x[s] - fm) / rs, -5.0f, 5.0f) : x[s];
   }
   D.rms_mean[k] = mean; D.rms_var[k] = var;
-  const float fm = (float)mean, rs = sqrtf((float)var + 1e-5f);
-  for (size_t r = 0; r < R; ++r) {
-    const float x = D.mb_states[r * S + k];
-    D.cvx1[r * S + k] = D.cv_normalize_input ? clampf((x - fm) / rs, -5.0f, 5.0f) : x;
-  }
   if (k == 0 && D.cv_normalize_input) D.ctrl->rms_count = cnt;
+}
+// mini-epochs >= 1: statistics frozen at their end-of-mini-epoch-0 values -> cvx1 (one thread per element)
+__global__ __launch_bounds__(256) void k_cv_prenorm_frozen(SdxpDev D) {
+  const int S = D.state_dim;
+  const size_t total = (size_t)D.N * D.horizon * S;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % S);
+    const float x = D.mb_states[i];
+    const float fm = (float)D.rms_mean[k], rs = sqrtf((float)D.rms_var[k] + 1e-5f);
+    D.cvx1[i] = D.cv_normalize_input ? clampf((x - fm) / rs, -5.0f, 5.0f) : x;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ explicit gradients
@@ -1048,12 +1064,14 @@ extern "C" int sdxpk_update_step(const SdxpDev* D, int mb_size, hipStream_t st) 
 // begin of an epoch's update phase: central-value pre-normalisation for all minibatches + cursor/accumulator reset
 extern "C" int sdxpk_update_begin(const SdxpDev* D, int mb_size, hipStream_t st) {
 #define C_(M) hipLaunchKernelGGL(k_cv_prenorm<M>, dim3((D->state_dim + 63) / 64), dim3(64), 0, st, *D); \
+              hipLaunchKernelGGL(k_cv_prenorm_frozen, dim3(1024), dim3(256), 0, st, *D); \
               hipLaunchKernelGGL(k_ctrl<M>, dim3(1), dim3(1024), 0, st, *D, 2)
   MB_SWITCH(mb_size, C_)
 #undef C_
 }
 extern "C" int sdxpk_prenorm(const SdxpDev* D, int mb_size, hipStream_t st) {
-#define C_(M) hipLaunchKernelGGL(k_cv_prenorm<M>, dim3((D->state_dim + 63) / 64), dim3(64), 0, st, *D)
+#define C_(M) hipLaunchKernelGGL(k_cv_prenorm<M>, dim3((D->state_dim + 63) / 64), dim3(64), 0, st, *D); \
+              hipLaunchKernelGGL(k_cv_prenorm_frozen, dim3(1024), dim3(256), 0, st, *D)
   MB_SWITCH(mb_size, C_)
 #undef C_
 }

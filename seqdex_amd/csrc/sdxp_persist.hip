@@ -888,16 +888,6 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
       block_sum<33>(S, p, S.part, tid, wave, lane);
       if (tid < 48) S.gx[tid >> 4][3][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-#pragma unroll
-      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
-      if (tid < U2) {
-#pragma unroll
-        for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.dy2[net][0][tid], S.dy2[net][1][tid], S.dy2[net][2][tid], S.dy2[net][3][tid]);
-      }
-      block_sum<33>(S, p, S.part, tid, wave, lane);
-      if (tid < 48) S.gd[tid >> 4][2][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-      else if (tid >= 64 && tid < 67) S.bsq[tid - 64][2] = S.part[(tid - 64) * 11 + 10];
-      else if (tid >= 128 && tid < 128 + 3 * MB) { const int net = (tid - 128) / MB, s = (tid - 128) % MB; S.dyown[net][s][6] = S.dy2[net][s][g]; }
       __syncthreads();
     }
     // squared-norm contributions of the heads and logstd
@@ -956,7 +946,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
     }
     TS(17)
-    {   // ---- (shadow of dY0) Gram of dY1
+    {   // ---- (shadow of dY0) Grams of dY1 and dY2
       float p[33];
 #pragma unroll
       for (int i = 0; i < 33; ++i) p[i] = 0.0f;
@@ -965,6 +955,17 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       block_sum<33>(S, p, S.part, tid, wave, lane);
       if (tid < 48) S.gd[tid >> 4][1][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
       else if (tid >= 64 && tid < 67) S.bsq[tid - 64][1] = S.part[(tid - 64) * 11 + 10];
+      // ... and of dY2 (moved here from the dY1 shadow to balance the two)
+#pragma unroll
+      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
+      if (tid < U2) {
+#pragma unroll
+        for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.dy2[net][0][tid], S.dy2[net][1][tid], S.dy2[net][2][tid], S.dy2[net][3][tid]);
+      }
+      block_sum<33>(S, p, S.part, tid, wave, lane);
+      if (tid < 48) S.gd[tid >> 4][2][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+      else if (tid >= 64 && tid < 67) S.bsq[tid - 64][2] = S.part[(tid - 64) * 11 + 10];
+      else if (tid >= 128 && tid < 128 + 3 * MB) { const int net = (tid - 128) / MB, s = (tid - 128) % MB; S.dyown[net][s][6] = S.dy2[net][s][g]; }
     }
     TS(18)
     pending = true;
