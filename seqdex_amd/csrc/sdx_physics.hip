@@ -50,6 +50,10 @@ struct PhysLds {
   unsigned short ent2[2 * SDX_MAXC];  // unsorted fill order (scratch of the rank pass)
   int eoff[NF + 1];
   int efill[NF];
+  // robot-side contact sides: contact index | side << 15, ascending (contact, side) order, and the link each one touches
+  unsigned short rent[SDX_MAXC], rent2[SDX_MAXC];
+  unsigned char rlink[SDX_MAXC];
+  int rfill;
 };
 
 struct Box { f3 c; f4 q; f3 h; };
@@ -483,7 +487,7 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
   }
   // ---- CSR of contact sides per brick (ascending contact index inside a brick = the oracle's summation order)
   for (int i = tid; i < NF; i += NT) { S.bcount[i] = 0; S.efill[i] = 0; }
-  if (tid == 0) S.nrobot = 0;
+  if (tid == 0) { S.nrobot = 0; S.rfill = 0; }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < CPT; ++q)
@@ -505,7 +509,9 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
     if (c < nc) {
       const int a = R.a[q], b = R.b[q];
       if (a < NF) S.ent2[S.eoff[a] + atomicAdd(&S.efill[a], 1)] = (unsigned short)c;
+      else if (a != SDX_BODY_STATIC) { const int i = atomicAdd(&S.rfill, 1); if (i < SDX_MAXC) S.rent2[i] = (unsigned short)c; }
       if (b < NF) S.ent2[S.eoff[b] + atomicAdd(&S.efill[b], 1)] = (unsigned short)(c | 0x8000);
+      else if (b != SDX_BODY_STATIC) { const int i = atomicAdd(&S.rfill, 1); if (i < SDX_MAXC) S.rent2[i] = (unsigned short)(c | 0x8000); }
     }
   }
   __syncthreads();
@@ -523,9 +529,21 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
       for (int j = 0; j < n; ++j) rank += (S.ent2[o + j] & 0x7fff) < key;
       S.ent[o + rank] = v;
     }
+    // the same for the robot-side list (one list for the whole robot; key = contact index, then side)
+    const int nr = min(S.nrobot, SDX_MAXC);
+    for (int i = tid; i < nr; i += NT) {
+      const unsigned short v = S.rent2[i];
+      const int key = ((v & 0x7fff) << 1) | (v >> 15);
+      int rank = 0;
+      for (int j = 0; j < nr; ++j) { const unsigned short u = S.rent2[j]; rank += (((u & 0x7fff) << 1) | (u >> 15)) < key; }
+      S.rent[rank] = v;
+      const int ab = __float_as_int(S.stage[0][v & 0x7fff]);
+      S.rlink[rank] = (unsigned char)(((v & 0x8000) ? ((ab >> 8) & 0xff) : (ab & 0xff)) - NF);
+    }
   }
   __syncthreads();
   const bool has_robot = S.nrobot > 0;   // block-uniform (read after the barrier above)
+  const int nrob = min(S.nrobot, SDX_MAXC);
   // ---- un-split inverse effective masses per row and side; zero accumulated impulses
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
@@ -633,22 +651,6 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
         l2 = fminf(lim, fmaxf(-lim, l2));
         R.lam[q][0] = ln; R.lam[q][1] = l1; R.lam[q][2] = l2;
         P = n * (ln - lam0) + t1 * (l1 - lam1) + t2 * (l2 - lam2);
-        if (has_robot) {   // robot side: generalised impulse J^T P (few rows; LDS atomics)
-          const int ids[2] = {a, b};
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int id = ids[s];
-            if (id >= NF && id != SDX_BODY_STATIC) {
-              const f3 Ps = s == 0 ? P : P * -1.0f;
-              uint32_t m = C->anc[id - NF];
-              while (m) {
-                const int j = __ffs(m) - 1;
-                m &= m - 1;
-                atomicAdd(&S.dQ[j], dot(cross(ld3(S.la[j + 1]), R.p[q] - ld3(S.lp[j + 1])), Ps));
-              }
-            }
-          }
-        }
       }
       if (c < nc) {
         const f3 M = cross(R.p[q], P);
@@ -701,7 +703,28 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
       }
     }
     if (has_robot) {
-      if (tid >= 64 && tid < 64 + ND) S.Q[tid - 64] += S.dQ[tid - 64];
+      // robot side: generalised impulse Q_j += sum over the robot's contact sides of a_j . ((p - o_j) x (+-P)) = a_j . (+-(M - o_j x P))
+      // for the dofs j on the path to the touched link; 8 lanes per dof walk the (contact, side)-ordered list with a fixed
+      // stride and combine in a fixed order (deterministic; LDS float atomics are not)
+      constexpr int RL = 8;
+      const int rt = tid - NF * GL;
+      if (rt >= 0 && rt < ND * RL) {
+        const int j = rt / RL, rsub = rt % RL;
+        const f3 aj = ld3(S.la[j + 1]), oj = ld3(S.lp[j + 1]);
+        float acc = 0.0f;
+        for (int i = rsub; i < nrob; i += RL) {
+          const int e = S.rent[i], c = e & 0x7fff;
+          if (S.act[c] && ((C->anc[S.rlink[i]] >> j) & 1u)) {
+            const f3 P = F3(Pm[0][c], Pm[1][c], Pm[2][c]), M = F3(Pm[3][c], Pm[4][c], Pm[5][c]);
+            const float t = dot(aj, M - cross(oj, P));
+            acc += (e & 0x8000) ? -t : t;
+          }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (rsub == 0) S.Q[j] += acc;
+      }
       __syncthreads();
       if (tid < ND) {
         float sacc = S.qds[tid];
@@ -725,17 +748,29 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
       const float ih = 1.0f / h;
 #pragma unroll
       for (int q = 0; q < CPT; ++q) {
-        if (tid + q * NT < nc) {
-          const int a = R.a[q], b = R.b[q];
-          const bool ra = a >= NF && a != SDX_BODY_STATIC, rbb = b >= NF && b != SDX_BODY_STATIC;
-          if (ra || rbb) {
-            f3 t1, t2;
-            tangents(R.n[q], &t1, &t2);
-            const f3 P = (R.n[q] * R.lam[q][0] + t1 * R.lam[q][1] + t2 * R.lam[q][2]) * ih;
-            if (ra) { atomicAdd(&S.cf[a - NF][0], P.x); atomicAdd(&S.cf[a - NF][1], P.y); atomicAdd(&S.cf[a - NF][2], P.z); }
-            if (rbb) { atomicAdd(&S.cf[b - NF][0], -P.x); atomicAdd(&S.cf[b - NF][1], -P.y); atomicAdd(&S.cf[b - NF][2], -P.z); }
+        const int c = tid + q * NT;
+        if (c < nc) {
+          f3 t1, t2;
+          tangents(R.n[q], &t1, &t2);
+          const f3 P = (R.n[q] * R.lam[q][0] + t1 * R.lam[q][1] + t2 * R.lam[q][2]) * ih;
+          Pm[0][c] = P.x; Pm[1][c] = P.y; Pm[2][c] = P.z;
+        }
+      }
+      __syncthreads();
+      constexpr int RL = 8;
+      if (tid < NL * RL) {   // 8 lanes per link over the ordered robot-side list, fixed combination order
+        const int k = tid / RL, rsub = tid % RL;
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        for (int i = rsub; i < nrob; i += RL) {
+          if (S.rlink[i] == k) {
+            const int e = S.rent[i], c = e & 0x7fff;
+            const float sg = (e & 0x8000) ? -1.0f : 1.0f;
+            ax += sg * Pm[0][c]; ay += sg * Pm[1][c]; az += sg * Pm[2][c];
           }
         }
+#pragma unroll
+        for (int o = 1; o < RL; o <<= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
+        if (rsub == 0) { S.cf[k][0] = ax; S.cf[k][1] = ay; S.cf[k][2] = az; }
       }
     }
     __syncthreads();
