@@ -257,7 +257,9 @@ typedef enum {
   SDXP_T_LAST_VALUES = 18,   /* f32 [N]                                                             */
   SDXP_T_AC_ADAM_M = 19, SDXP_T_AC_ADAM_V = 20, SDXP_T_CV_ADAM_M = 21, SDXP_T_CV_ADAM_V = 22,
   SDXP_T_DEBUG = 23,         /* i64 [64]    phase time stamps of the last HEAD / CTRL kernels (profiling aid)      */
-  SDXP_T_COUNT = 24
+  SDXP_T_ALL_GRADS = 24,     /* f32 [..]    one buffer over AC_GRADS | pad | CV_GRADS | pad | KL word | pad (multiples of 64): a
+                              * multi-rank caller all-reduces THIS once per optimiser step and calls sdxp_apply(which, -INFINITY) */
+  SDXP_T_COUNT = 25
 } sdxp_tensor_id;
 
 typedef struct sdxp_agent* sdxp_handle;
@@ -293,6 +295,8 @@ int sdxp_update_impl(sdxp_handle h);
 /* Multi-rank path, one minibatch at a time so that the caller can all-reduce SDXP_T_*_GRADS in between:
  * which = 0 actor-critic, 1 central value; mb = minibatch index within the epoch. */
 int sdxp_backward(sdxp_handle h, int32_t which, int32_t mb, void* stream);
+/* kl: the rank-averaged KL for the LR schedule; NaN = take SdxpCtrl.last_kl that the caller all-reduced (SUM) in place through
+ * SDXP_T_STATS; -INFINITY = take the KL word of SDXP_T_ALL_GRADS that the caller all-reduced (SUM) with the gradients. */
 int sdxp_apply(sdxp_handle h, int32_t which, float kl_allreduced_or_nan, void* stream);
 const char* sdxp_last_error(sdxp_handle h);
 

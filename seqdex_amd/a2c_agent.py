@@ -146,10 +146,21 @@ class A2CAgent:
         SURVEY.md App. C; PS:308-310)."""
         import torch.distributed as dist
         ppo = self.ppo
-        g_ac, g_cv, kl = ppo.t["AC_GRADS"], ppo.t["CV_GRADS"], ppo.kl_view()
+        nmb = self.batch_size // self.minibatch_size
         ppo.backward(0, -1)
+        if "ALL_GRADS" in ppo.t:
+            # one collective per optimiser step: both flat gradients and the KL word share one library-owned buffer
+            g_all = ppo.t["ALL_GRADS"]
+            for _ in range(self.mini_epochs_num):
+                for mb in range(nmb):
+                    ppo.backward(0, mb)
+                    dist.all_reduce(g_all)
+                    ppo.apply(0, float("-inf"))
+                    ppo.apply(1)
+            return
+        g_ac, g_cv, kl = ppo.t["AC_GRADS"], ppo.t["CV_GRADS"], ppo.kl_view()
         for _ in range(self.mini_epochs_num):
-            for mb in range(self.batch_size // self.minibatch_size):
+            for mb in range(nmb):
                 ppo.backward(0, mb)
                 dist.all_reduce(g_ac)
                 dist.all_reduce(g_cv)

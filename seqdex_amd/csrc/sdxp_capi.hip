@@ -139,8 +139,12 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   }
   int rc;
 #define PAL(ptr, count) if ((rc = palloc(h, &(ptr), (size_t)(count))) != SDX_OK) { gp_create_err = h->err; sdxp_destroy(h); return rc; }
-  PAL(D.ac, D.off.total); PAL(D.ac_g, D.off.total); PAL(D.ac_m, D.off.total); PAL(D.ac_v, D.off.total);
-  PAL(D.cv, D.coff.total); PAL(D.cv_g, D.coff.total); PAL(D.cv_m, D.coff.total); PAL(D.cv_v, D.coff.total);
+  PAL(D.ac, D.off.total); PAL(D.ac_m, D.off.total); PAL(D.ac_v, D.off.total);
+  // both flat gradients and the KL word live in ONE allocation so that the multi-rank path needs a single all-reduce per step
+  const size_t g_ac = (D.off.total + 63) / 64 * 64, g_cv = (D.coff.total + 63) / 64 * 64;
+  PAL(D.ac_g, g_ac + g_cv + 64);
+  D.cv_g = D.ac_g + g_ac; D.g_tail = g_ac + g_cv;
+  PAL(D.cv, D.coff.total); PAL(D.cv_m, D.coff.total); PAL(D.cv_v, D.coff.total);
   const size_t N = D.N, H = D.horizon, R = N * H;
   for (int l = 0; l < 3; ++l) { PAL(D.h_a[l], N * cfg->units[l]); PAL(D.h_v[l], N * cfg->units[l]); }
   PAL(D.mb_obs, R * cfg->obs_dim); PAL(D.mb_states, R * cfg->state_dim); PAL(D.mb_actions, R * cfg->act_dim);
@@ -214,6 +218,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   pset(h, SDXP_T_STATS, D.ctrl, SDX_F32, {(int64_t)(sizeof(SdxpCtrl) / 4)});
   pset(h, SDXP_T_LAST_VALUES, D.last_values, SDX_F32, {(int64_t)N});
   pset(h, SDXP_T_DEBUG, D.dbg, SDX_I64, {64});
+  pset(h, SDXP_T_ALL_GRADS, D.ac_g, SDX_F32, {(int64_t)(D.g_tail + 64)});
   pset(h, SDXP_T_AC_ADAM_M, D.ac_m, SDX_F32, {(int64_t)D.off.total});
   pset(h, SDXP_T_AC_ADAM_V, D.ac_v, SDX_F32, {(int64_t)D.off.total});
   pset(h, SDXP_T_CV_ADAM_M, D.cv_m, SDX_F32, {(int64_t)D.coff.total});

@@ -992,11 +992,14 @@ __global__ __launch_bounds__(256) void k_adam_explicit(SdxpDev D, int which) {
     M[i] = m; V[i] = v;
   }
 }
+__global__ void k_publish_kl(SdxpDev D) { D.ac_g[D.g_tail] = D.ctrl->last_kl; }   // this rank's minibatch KL rides with the gradients
 __global__ void k_apply_fin(SdxpDev D, int which, float kl_host) {
   SdxpCtrl* ctl = D.ctrl;
   if (which) { ctl->cv_t += 1; ctl->cv_b1pow *= 0.9; ctl->cv_b2pow *= 0.999; ctl->cv_gnorm = sqrtf(ctl->gn2_cv); return; }
   ctl->ac_t += 1; ctl->ac_b1pow *= 0.9; ctl->ac_b2pow *= 0.999; ctl->ac_gnorm = sqrtf(ctl->gn2_ac);
-  const float kl = (kl_host == kl_host) ? kl_host : ctl->last_kl / (float)ctl->world;   // NaN -> device value, all-reduced in place
+  // NaN -> device value, all-reduced in place; -inf -> the KL word that travelled with the gradients in ALL_GRADS
+  const float kl = (kl_host != kl_host) ? ctl->last_kl / (float)ctl->world
+                 : (kl_host == -INFINITY ? D.ac_g[D.g_tail] / (float)ctl->world : kl_host);
   if (D.adaptive_lr) {   // legacy schedule after every minibatch, on the rank-averaged KL (PS:306-312)
     if (kl > 2.0f * D.kl_threshold) ctl->ac_lr = fmaxf(ctl->ac_lr / 1.5f, 1e-6f);
     if (kl < 0.5f * D.kl_threshold) ctl->ac_lr = fminf(ctl->ac_lr * 1.5f, 1e-2f);
@@ -1092,6 +1095,7 @@ static void launch_backward_explicit(const SdxpDev* D, hipStream_t st) {
   }
   hipLaunchKernelGGL(k_grad_heads<MB>, dim3(1), dim3(256), 0, st, *D);
   hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(1024), 0, st, *D, 1 | 2 | 8);
+  hipLaunchKernelGGL(k_publish_kl, dim3(1), dim3(1), 0, st, *D);
 }
 extern "C" int sdxpk_backward_explicit(const SdxpDev* D, int mb_size, hipStream_t st) {
 #define C_(M) launch_backward_explicit<M>(D, st)

@@ -59,5 +59,6 @@ struct SdxpDev {
   float* dlogstd;        // [2][32]
   SdxpCtrl* ctrl;
   long long* dbg;        // [64] phase timestamps (s_memtime) written by thread 0 of the single-block kernels
+  size_t g_tail;         // ALL_GRADS = [ac_g | pad | cv_g | pad | kl word | pad]: offset (floats, from ac_g) of the kl word
   unsigned long long* ll; // [SDXP_LL_WORDS] (value, step tag) words exchanged between the CUs of the persistent update kernel
 };

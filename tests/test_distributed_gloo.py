@@ -16,11 +16,16 @@ class FakePPO:
     """CPU stand-in for seqdex_amd.ppo.SdxPPO: 'gradient' of a rank = (rank+1) * (step+1); apply does SGD-like update
     with the averaged gradient so that every rank must end with identical parameters iff the all-reduce happened."""
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, fused=False):
         self.rank, self.world, self.step = rank, world, 0
-        self.t = {"AC_GRADS": torch.zeros(10), "CV_GRADS": torch.zeros(6), "AC_PARAMS": torch.full((10,), float(rank)),
+        # fused: the library's layout - both gradients and the KL word in ONE buffer (SDXP_T_ALL_GRADS), views into it
+        allg = torch.zeros(10 + 6 + 1)
+        self.t = {"AC_GRADS": allg[:10], "CV_GRADS": allg[10:16], "AC_PARAMS": torch.full((10,), float(rank)),
                   "CV_PARAMS": torch.full((6,), float(rank))}
-        self._kl = torch.zeros(1)
+        self._kl = allg[16:17] if fused else torch.zeros(1)
+        if fused:
+            self.t["ALL_GRADS"] = allg
+        self.fused = fused
         self.applied = []
 
     def kl_view(self):
@@ -35,6 +40,8 @@ class FakePPO:
         self._kl.fill_(0.01 * (self.rank + 1))
 
     def apply(self, which, kl=float("nan")):
+        if which == 0:
+            assert (kl == float("-inf")) == self.fused      # -inf tells the library to take the KL word of ALL_GRADS
         g = self.t["CV_GRADS" if which else "AC_GRADS"] / self.world
         self.t["CV_PARAMS" if which else "AC_PARAMS"].sub_(0.1 * g)
         if which == 0:
@@ -42,12 +49,12 @@ class FakePPO:
             self.step += 1
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, fused=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from seqdex_amd.a2c_agent import A2CAgent
     ag = A2CAgent.__new__(A2CAgent)          # orchestration only: no GPU objects
-    ag.ppo = FakePPO(rank, world)
+    ag.ppo = FakePPO(rank, world, fused)
     ag.mini_epochs_num, ag.batch_size, ag.minibatch_size = 2, 12, 4
     ag.rank, ag.rank_size, ag.multi_gpu = rank, world, True
     ag._broadcast_parameters()
@@ -57,11 +64,12 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_gradient_allreduce_and_broadcast_world2():
+@pytest.mark.parametrize("fused", [False, True])
+def test_gradient_allreduce_and_broadcast_world2(fused):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fused)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
