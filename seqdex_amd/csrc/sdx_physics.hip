@@ -29,7 +29,7 @@ __constant__ float c_samp[SDX_NSAMP][3] = {
     {-0.5f, -1, -1}, {0.5f, -1, -1}, {-0.5f, 1, -1}, {0.5f, 1, -1}, {-0.5f, -1, 1}, {0.5f, -1, 1}, {-0.5f, 1, 1}, {0.5f, 1, 1}};
 
 struct PhysLds {
-  float q[ND], qd[ND], tgt[ND], qds[ND], Q[ND], dQ[ND], tau[ND];
+  float q[ND], qd[ND], tgt[ND], qds[ND], Q[ND], tau[ND];
   float lq[NL][4], lp[NL][3], la[NL][3], lc[NL][3], lv[NL][3], lw[NL][3], lI[NL][6];
   float A[ND][HP];   // H -> L -> Hinv
   float T[ND][HP];   // L^-1
@@ -607,7 +607,6 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
         if (act[q]) ract += (a >= NF && a != SDX_BODY_STATIC) + (b >= NF && b != SDX_BODY_STATIC);
       }
     }
-    if (tid < ND) S.dQ[tid] = 0.0f;
     if (tid == 0) S.rcount = 0;
     __syncthreads();
     SSTAMP(19);

@@ -1,14 +1,14 @@
 // sdxp_persist.hip — the PPO update phase of one epoch (all mini-epochs x minibatches, three networks) as ONE persistent
-// kernel on MI355X: 256 workgroups (one per CU) x 512 threads, every weight and its Adam moments stay in the VGPR file
-// of the CU that owns them for the whole epoch (~180 registers per lane), activations / gradient factors of the current
-// minibatch live in LDS (~140 KiB), and the only inter-CU traffic per optimiser step is the rank-MB factors
-// (x1, x2, x3, dY1, dY0: ~170 KiB read per CU from L2) exchanged across FIVE grid barriers:
+// kernel on MI355X: 256 workgroups (one per CU) x 512 threads.  Every weight and its Adam moments stay in the VGPR file of the
+// CU that owns them for the whole epoch (~132 resident registers per lane of 241), activations / gradient factors of the
+// current minibatch live in LDS (147 KiB), and the only inter-CU traffic per optimiser step is the rank-MB factors, exchanged
+// as (value, step tag) words - no grid barrier (replaces PS:294-326 / RC:1339-1365 of the reference loop):
 //
-//   A  [norm from Gram matrices -> clip, Adam of every resident parameter]  forward L0 of own rows      -> x1  | barrier
-//   B  stage x1, forward L1 of own rows                                                                 -> x2  | barrier
-//   C  stage x2, forward L2 of own rows                                                                 -> x3  | barrier
-//   D  stage x3, heads + PPO losses (replicated on every CU, bit-identical), backward L2 (column copy)  -> dY1 | barrier
-//   E  stage dY1, backward L1 (column copy)                                                             -> dY0 | barrier
+//   A  dY0 -> Gram -> |g|^2 -> clip scale, Adam of layer 0, forward L0 of own rows                       -> x1  | shadow: Adam L1
+//   B  gather x1, forward L1 of own rows                                                                 -> x2  | shadow: Gram x1, Adam L2/heads/biases
+//   C  gather x2, forward L2 of own row                                                                  -> x3  | shadow: Gram x2
+//   D  gather x3 + heads, PPO losses (replicated on every CU, bit-identical), backward heads and L2      -> dY1 | shadow: stats, LR rule, Gram x3, head norms
+//   E  gather dY1, backward L1 (column copy)                                                             -> dY0 | shadow: Grams dY1, dY2
 //
 // Ownership (shipped network 396/564 -> 1024 -> 512 -> 256 -> 23/1, minibatch 4):
 //   W0 rows      : CU g, wave w owns half (w&1) of row 4g+(w>>1) of actor, critic and central value
@@ -16,10 +16,10 @@
 //   W1 columns   : CU g owns columns 4g..4g+3 of the three nets, thread = row       (backward; duplicate copy, same Adam)
 //   W2 rows      : wave w owns eighth w of row g of the three nets                  (forward)
 //   W2 columns   : CU g owns columns 2g, 2g+1: thread = (column, row)               (backward; duplicate copy)
-//   heads        : replicated on every CU, wave w owns rows w, w+8, ... of the 25 head rows
+//   heads        : CU g runs Adam for 25 of the 6 400 head weights and publishes them; every CU reads the matrix back in phase D
 // Row and column copies receive the same gradient g[n][k] = sum_s dY_s[n] X_s[k] (same operands, same order), so they
-// stay bit-identical without communication.  Arithmetic is the same as the multi-kernel path (sdxp_kernels.hip), which
-// remains the fallback for other shapes and the explicit-gradient multi-rank path.
+// stay bit-identical without communication.  The multi-kernel path (sdxp_kernels.hip) remains the fallback for other shapes
+// and the explicit-gradient multi-rank path.
 #include <cstddef>
 #include <cstdlib>
 
@@ -52,7 +52,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 // and an LDS load whose address depends on the result cannot be floated above it: this is what keeps the operand loads of
 // Adam element i+1 below the arithmetic of element i.
 // Passing the weight updated by element i as a (fake) input orders element i+1's loads after element i's arithmetic too.
-__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int opaque(int x, float after) { asm volatile("" : "+v"(x) : "v"(after)); return x; }
 __device__ __forceinline__ void adam1(float& w, float g, float& m, float& v, float lr_bc1, float isq_bc2) {
   m = 0.9f * m + 0.1f * g;
@@ -79,9 +78,9 @@ struct PLds {
   float red[4 * NWV][64];    // block_sum: one row per (wave, DPP row)
   float mu[MB][32], dmu[MB][32], z[MB][32], act[MB][32], omu[MB][32], osg[MB][32];
   float val[2][MB], dv[2][MB], gnlp[MB], ls[32], dls[32], stat[MB][8];
-  // biases of the owned rows and their Adam moments (one thread each): [0..2] L0 (net), [3..8] L1 (net*2+row), [9..11] L2,
-  // [12..36] heads (replicated), [37..59] logstd (replicated)
-  float bias[64], bias_m[64], bias_v[64], bias_g[64];
+  // biases of the owned rows and their Adam moments, one thread per slot: [0..11] L0 (net*4 + row), [12..17] L1 (12 + net*2 + row),
+  // [18..20] L2 (18 + net), [21..45] heads (21 + row, replicated on every CU); logstd lives in the static bank s_b2
+  float bias[64], bias_m[64], bias_v[64];
   float dyown[3][MB][8];     // dY of the owned rows: [net][s][0..3] L0 rows (per wave), [4..5] L1 rows, [6] L2 row
   float scal[16];            // broadcast scalars of the step: 0 ac_gscale 1 cv_gscale 2 ac_lr_bc1 3 ac_isq 4 cv_lr_bc1 5 cv_isq
   // control state machine, owned by thread 0 of every CU (every CU runs it on identical inputs, so the copies stay identical)
@@ -288,17 +287,6 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     hw = P_of(net)[o]; hm = M_of(net)[o]; hv = V_of(net)[o];
   }
   // biases + logstd (LDS, one thread each)
-  if (tid < 64) {
-    float b = 0.0f, bm = 0.0f, bv = 0.0f;
-    int net = -1; size_t o = 0;
-    if (tid < 3) { net = tid; o = boff(net, 0) + 0; }   // placeholder, L0 biases are per wave: handled below
-    (void)net; (void)o;
-    S.bias[tid] = b; S.bias_m[tid] = bm; S.bias_v[tid] = bv; S.bias_g[tid] = 0.0f;
-  }
-  __syncthreads();
-  // bias slot map: L0: slot = net*4 + wave (12 slots, 0..11); L1: 12 + net*2 + row (6 slots); L2: 18 + net (3); heads: 21 + row (25);
-  // logstd: 46 + a (23)  -> 69 slots: enlarge arrays via two passes of 64 threads
-  // (arrays are sized 64: heads + logstd go to a second bank below)
   __shared__ float s_b2[3][32];     // logstd value, m, v
   if (tid < 12) {   // bias slot map: L0 net*4 + row (12), L1 12 + net*2 + row (6), L2 18 + net (3), heads 21 + row (25)
     const int net = tid / 4, w = tid % 4;
