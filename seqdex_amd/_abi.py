@@ -68,13 +68,14 @@ T = dict(ROOT=0, DOF=1, RB=2, CONTACT=3, JAC_EEF=4, TARGETS=5, PREV_TARGETS=6, O
 TP = dict(AC_PARAMS=0, AC_GRADS=1, CV_PARAMS=2, CV_GRADS=3, MB_OBS=4, MB_STATES=5, MB_ACTIONS=6, MB_MUS=7,
           MB_SIGMAS=8, MB_NEGLOGP=9, MB_VALUES=10, MB_REWARDS=11, MB_DONES=12, RETURNS=13, ADVANTAGES=14,
           CV_RMS_MEAN=15, CV_RMS_VAR=16, STATS=17, LAST_VALUES=18, AC_ADAM_M=19, AC_ADAM_V=20, CV_ADAM_M=21,
-          CV_ADAM_V=22, DEBUG=23, ALL_GRADS=24)
+          CV_ADAM_V=22, DEBUG=23, ALL_GRADS=24, FACTORS=25, FACTORS_ALL=26)
 
 SDX_EXPORTS = ["sdx_create", "sdx_destroy", "sdx_tensor", "sdx_load_initial_states", "sdx_set_tvalue_weights",
                "sdx_step", "sdx_pre_physics", "sdx_simulate", "sdx_post_physics", "sdx_compute_observations",
                "sdx_reset_idx", "sdx_refresh_kinematics", "sdx_num_envs", "sdx_last_error",
                "sdxp_create", "sdxp_destroy", "sdxp_tensor", "sdxp_param_count", "sdxp_act", "sdxp_store_rewards",
-               "sdxp_finish_rollout", "sdxp_update", "sdxp_update_impl", "sdxp_backward", "sdxp_apply", "sdxp_last_error"]
+               "sdxp_finish_rollout", "sdxp_update", "sdxp_update_impl", "sdxp_backward", "sdxp_apply", "sdxp_backward_factors",
+               "sdxp_grads_from_factors", "sdxp_last_error"]
 
 _lib = None
 
@@ -117,6 +118,8 @@ def load_library():
     lib.sdxp_update_impl.argtypes = [vp]
     lib.sdxp_backward.argtypes = [vp, i32, i32, vp]
     lib.sdxp_apply.argtypes = [vp, i32, f32, vp]
+    lib.sdxp_backward_factors.argtypes = [vp, i32, vp]
+    lib.sdxp_grads_from_factors.argtypes = [vp, vp]
     lib.sdxp_last_error.argtypes = [vp]
     lib.sdxp_last_error.restype = C.c_char_p
     for n in SDX_EXPORTS:

@@ -147,6 +147,18 @@ class A2CAgent:
         import torch.distributed as dist
         ppo = self.ppo
         nmb = self.batch_size // self.minibatch_size
+        if "FACTORS" in ppo.t and hasattr(ppo, "backward_factors"):
+            # preferred: all-gather the rank-MB factors (194 KB per rank) and rebuild the summed gradient locally
+            fact, fact_all = ppo.t["FACTORS"], ppo.t["FACTORS_ALL"]
+            ppo.backward_factors(-1)
+            for _ in range(self.mini_epochs_num):
+                for mb in range(nmb):
+                    ppo.backward_factors(mb)
+                    dist.all_gather_into_tensor(fact_all, fact)
+                    ppo.grads_from_factors()
+                    ppo.apply(0, float("-inf"))
+                    ppo.apply(1)
+            return
         ppo.backward(0, -1)
         if "ALL_GRADS" in ppo.t:
             # one collective per optimiser step: both flat gradients and the KL word share one library-owned buffer

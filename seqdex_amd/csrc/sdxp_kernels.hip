@@ -968,11 +968,130 @@ __global__ __launch_bounds__(256) void k_grad_heads(SdxpDev D) {
   }
   if (tid < A) D.ac_g[D.off.logstd + tid] = D.dlogstd[(size_t)par * 32 + tid];
 }
-__global__ __launch_bounds__(256) void k_sqnorm(const float* __restrict__ g, size_t n, float scale, float* out) {
+// ---- multi-rank path, factor exchange: instead of all-reducing 13.4 MB of materialised gradients per optimiser step the ranks
+// all-gather the rank-MB factors (194 KB each) and every rank rebuilds the SUM over ranks of dY^T X locally.
+template <int MB>
+__global__ __launch_bounds__(256) void k_pack_factors(SdxpDev D) {
+  const SdxpCtrl* ctl = D.ctrl;
+  const int par = ctl->step & 1, seg = blockIdx.y;
+  float* F = D.fact;
+  const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+  if (seg < 9) {
+    const int net = seg / 3, l = seg % 3;
+    const int K = (l == 0) ? (net == 2 ? D.state_dim : D.obs_dim) : D.units[l - 1];
+    const float* src = layer_input<MB>(D, ctl, net, l, true);
+    for (int i = t0; i < MB * K; i += stride) F[D.foff.x[net][l] + i] = src[i];
+  } else if (seg < 18) {
+    const int net = (seg - 9) / 3, l = (seg - 9) % 3, Nl = D.units[l];
+    for (int i = t0; i < MB * Nl; i += stride) F[D.foff.dy[net][l] + i] = dy_at<MB>(D, net, l, par, i / Nl, i % Nl);
+  } else if (seg < 21) {
+    const int net = seg - 18, U = D.units[2];
+    const float* src = D.x[net][3] + (size_t)par * MB * U;
+    for (int i = t0; i < MB * U; i += stride) F[D.foff.h[net] + i] = src[i];
+  } else if (seg == 21) {
+    for (int i = t0; i < MB * 34; i += stride) F[D.foff.dh + i] = D.dhead[(size_t)par * MB * 34 + i];
+  } else {
+    for (int i = t0; i < 32; i += stride) F[D.foff.dls + i] = D.dlogstd[(size_t)par * 32 + i];
+  }
+}
+__global__ void k_pack_kl(SdxpDev D) { D.fact[D.foff.kl] = D.ctrl->last_kl; }
+template <int MB>
+__global__ __launch_bounds__(256) void k_grad_layer_w(SdxpDev D, int l) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int Nl = D.units[l];
+  const int blocks_per_net = (Nl + 3) / 4;
+  const int net = blockIdx.x / blocks_per_net, n = (blockIdx.x % blocks_per_net) * 4 + wave;
+  const int K = (l == 0) ? (net == 2 ? D.state_dim : D.obs_dim) : D.units[l - 1];
+  float* G = net == 2 ? D.cv_g : D.ac_g;
+  const size_t woff = net == 0 ? D.off.a_w[l] : net == 1 ? D.off.c_w[l] : D.coff.w[l];
+  const size_t boff = net == 0 ? D.off.a_b[l] : net == 1 ? D.off.c_b[l] : D.coff.b[l];
+  const bool valid = n < Nl;
+  float g[16], sb = 0.0f;   // K <= 1024: 16 columns per lane
+#pragma unroll
+  for (int j = 0; j < 16; ++j) g[j] = 0.0f;
+  for (int r = 0; r < D.world; ++r) {      // ascending rank order on every rank: identical sums everywhere
+    const float* F = D.fact_all + (size_t)r * D.foff.total;
+    const float* gx = F + D.foff.x[net][l];
+    for (int i = tid; i < MB * K; i += 256) sm[i] = gx[i];
+    __syncthreads();
+    if (valid) {
+      float dyn[MB];
+#pragma unroll
+      for (int s = 0; s < MB; ++s) { dyn[s] = F[D.foff.dy[net][l] + s * Nl + n]; sb += dyn[s]; }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = lane + 64 * j;
+        if (k < K) {
+#pragma unroll
+          for (int s = 0; s < MB; ++s) g[j] += dyn[s] * sm[s * K + k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { const int k = lane + 64 * j; if (k < K) G[woff + (size_t)n * K + k] = g[j]; }
+  if (lane == 0) G[boff + n] = sb;
+}
+template <int MB>
+__global__ __launch_bounds__(256) void k_grad_heads_w(SdxpDev D) {
+  const int tid = threadIdx.x, U = D.units[2], A = D.act_dim, W = D.world;
+  const size_t T = D.foff.total;
+  for (int i = tid; i < (A + 2) * U; i += 256) {
+    const int row = i / U, k = i % U;
+    const int net = row < A ? 0 : (row == A ? 1 : 2);
+    float g = 0.0f;
+    for (int r = 0; r < W; ++r) {
+      const float* F = D.fact_all + r * T;
+      const float* dh = F + D.foff.dh;
+      const float* h = F + D.foff.h[net];
+      for (int s = 0; s < MB; ++s) g += (row < A ? dh[s * 34 + row] : dh[s * 34 + 32 + (row - A)]) * h[s * U + k];
+    }
+    if (row < A) D.ac_g[D.off.mu_w + (size_t)row * U + k] = g;
+    else if (row == A) D.ac_g[D.off.v_w + k] = g;
+    else D.cv_g[D.coff.v_w + k] = g;
+  }
+  if (tid < A + 2) {
+    float g = 0.0f;
+    for (int r = 0; r < W; ++r) {
+      const float* dh = D.fact_all + r * T + D.foff.dh;
+      for (int s = 0; s < MB; ++s) g += tid < A ? dh[s * 34 + tid] : dh[s * 34 + 32 + (tid - A)];
+    }
+    if (tid < A) D.ac_g[D.off.mu_b + tid] = g;
+    else if (tid == A) D.ac_g[D.off.v_b] = g;
+    else D.cv_g[D.coff.v_b] = g;
+  }
+  if (tid >= 64 && tid < 64 + A) {
+    float g = 0.0f;
+    for (int r = 0; r < W; ++r) g += D.fact_all[r * T + D.foff.dls + (tid - 64)];
+    D.ac_g[D.off.logstd + (tid - 64)] = g;
+  }
+  if (tid == 128) {   // SUM of the ranks' minibatch KL, where sdxp_apply(0, -INFINITY) looks for it
+    float kl = 0.0f;
+    for (int r = 0; r < W; ++r) kl += D.fact_all[r * T + D.foff.kl];
+    D.ac_g[D.g_tail] = kl;
+  }
+}
+// squared norm of the flat gradient, bit-reproducible (every rank must compute the SAME clip scale from the same gradient, or the
+// replicas drift apart): fixed block -> slice mapping, in-block tree in a fixed order, second stage sums the 512 block partials
+__global__ __launch_bounds__(256) void k_sqnorm(const float* __restrict__ g, size_t n, float scale, float* part) {
+  __shared__ float sw[4];
   float s = 0.0f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float v = g[i] * scale; s += v * v; }
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(512) void k_sqnorm_fin(const float* __restrict__ part, int nparts, float* out) {
+  __shared__ float sw[8];
+  float s = threadIdx.x < nparts ? part[threadIdx.x] : 0.0f;
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = ((sw[0] + sw[1]) + (sw[2] + sw[3])) + ((sw[4] + sw[5]) + (sw[6] + sw[7]));
 }
 __global__ __launch_bounds__(256) void k_adam_explicit(SdxpDev D, int which) {
   const SdxpCtrl* ctl = D.ctrl;
@@ -1102,10 +1221,37 @@ extern "C" int sdxpk_backward_explicit(const SdxpDev* D, int mb_size, hipStream_
   MB_SWITCH(mb_size, C_)
 #undef C_
 }
+template <int MB>
+static void launch_backward_factors(const SdxpDev* D, hipStream_t st) {
+  launch_fwd_bwd<MB>(D, st);
+  hipLaunchKernelGGL(k_pack_factors<MB>, dim3(8, 23), dim3(256), 0, st, *D);
+  hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(1024), 0, st, *D, 1 | 2 | 8);
+  hipLaunchKernelGGL(k_pack_kl, dim3(1), dim3(1), 0, st, *D);
+}
+extern "C" int sdxpk_backward_factors(const SdxpDev* D, int mb_size, hipStream_t st) {
+#define C_(M) launch_backward_factors<M>(D, st)
+  MB_SWITCH(mb_size, C_)
+#undef C_
+}
+template <int MB>
+static void launch_grads_from_factors(const SdxpDev* D, hipStream_t st) {
+  for (int l = 0; l < 3; ++l) {
+    const int Nl = D->units[l];
+    const int Kmax = l == 0 ? (D->state_dim > D->obs_dim ? D->state_dim : D->obs_dim) : D->units[l - 1];
+    hipLaunchKernelGGL(k_grad_layer_w<MB>, dim3(3 * ((Nl + 3) / 4)), dim3(256), (size_t)MB * Kmax * sizeof(float), st, *D, l);
+  }
+  hipLaunchKernelGGL(k_grad_heads_w<MB>, dim3(1), dim3(256), 0, st, *D);
+}
+extern "C" int sdxpk_grads_from_factors(const SdxpDev* D, int mb_size, hipStream_t st) {
+#define C_(M) launch_grads_from_factors<M>(D, st)
+  MB_SWITCH(mb_size, C_)
+#undef C_
+}
 extern "C" void sdxpk_apply_explicit(const SdxpDev* D, int which, float kl, int world, hipStream_t st) {
   const size_t n = which ? D->coff.total : D->off.total;
   float* acc = which ? &D->ctrl->gn2_cv : &D->ctrl->gn2_ac;
-  hipLaunchKernelGGL(k_sqnorm, dim3(512), dim3(256), 0, st, which ? D->cv_g : D->ac_g, n, 1.0f / (float)world, acc);
+  hipLaunchKernelGGL(k_sqnorm, dim3(512), dim3(256), 0, st, which ? D->cv_g : D->ac_g, n, 1.0f / (float)world, D->sqn_part);
+  hipLaunchKernelGGL(k_sqnorm_fin, dim3(1), dim3(512), 0, st, D->sqn_part, 512, acc);
   hipLaunchKernelGGL(k_adam_explicit, dim3(1024), dim3(256), 0, st, *D, which);
   hipLaunchKernelGGL(k_apply_fin, dim3(1), dim3(1), 0, st, *D, which, kl);
 }

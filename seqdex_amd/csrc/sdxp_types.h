@@ -35,6 +35,11 @@ struct SdxpCtrl {
 
 #define SDXP_LL_WORDS 65536
 
+// rank-MB factors of one minibatch packed for the multi-rank exchange (floats): per net the inputs X_l [MB][K_l] and the
+// pre-activation gradients dY_l [MB][N_l] of the three trunk layers, the head inputs [MB][units[2]], the head gradients
+// [MB][34], dlogstd [32] and the minibatch KL
+struct SdxpFactOff { uint32_t x[3][3], dy[3][3], h[3], dh, dls, kl, total; };
+
 struct SdxpDev {
   int32_t N, horizon, obs_dim, state_dim, act_dim, units[3];
   int32_t num_minibatches, rows_per_wave, bsplit;
@@ -59,6 +64,10 @@ struct SdxpDev {
   float* dlogstd;        // [2][32]
   SdxpCtrl* ctrl;
   long long* dbg;        // [64] phase timestamps (s_memtime) written by thread 0 of the single-block kernels
+  SdxpFactOff foff;
+  float *fact, *fact_all; // [foff.total] this rank's factors; [world][foff.total] all ranks' (all-gathered by the caller)
+  int32_t world;
+  float* sqn_part;       // [512] block partials of the deterministic gradient-norm reduction
   size_t g_tail;         // ALL_GRADS = [ac_g | pad | cv_g | pad | kl word | pad]: offset (floats, from ac_g) of the kl word
   unsigned long long* ll; // [SDXP_LL_WORDS] (value, step tag) words exchanged between the CUs of the persistent update kernel
 };

@@ -113,6 +113,14 @@ class SdxPPO:
     def apply(self, which, kl=float("nan")):
         self._check(self.lib.sdxp_apply(self.h, which, C.c_float(kl), _stream_ptr(self.device)))
 
+    def backward_factors(self, mb):
+        """multi-rank, factor exchange: this rank's rank-MB factors of minibatch `mb` -> t["FACTORS"] (mb < 0: begin of the epoch)"""
+        self._check(self.lib.sdxp_backward_factors(self.h, mb, _stream_ptr(self.device)))
+
+    def grads_from_factors(self):
+        """rebuild the SUM over ranks of the minibatch gradients from t["FACTORS_ALL"] (all-gathered by the caller)"""
+        self._check(self.lib.sdxp_grads_from_factors(self.h, _stream_ptr(self.device)))
+
     def kl_view(self):
         """1-element f32 view of SdxpCtrl.last_kl inside the STATS tensor (for the scalar KL all-reduce, PS:308-310)"""
         off = Ctrl.last_kl.offset // 4

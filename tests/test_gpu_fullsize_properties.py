@@ -168,3 +168,59 @@ def test_explicit_path_through_rccl_world1():
     finally:
         a.close(); b.close()
         dist.destroy_process_group()
+
+
+def _filled_agent_w(n, seed, data_seed, world):
+    from seqdex_amd.ppo import SdxPPO, make_config
+    ag = SdxPPO(n, config=make_config(n, world_size=world), seed=seed)
+    g = torch.Generator().manual_seed(data_seed)
+    for t in range(8):
+        obs = torch.randn(n, 396, generator=g).clamp(-5, 5).cuda()
+        st = (torch.randn(n, 564, generator=g) * 2).clamp(-5, 5).cuda()
+        dones = (torch.rand(n, generator=g) < 0.1).long().cuda()
+        ag.act(t, obs, st, dones, torch.randn(n, 23, generator=g).cuda())
+        ag.store_rewards(t, torch.rand(n, generator=g).cuda(), dones)
+    ag.finish_rollout(torch.randn(n, 564, generator=g).cuda(), (torch.rand(n, generator=g) < 0.1).long().cuda())
+    torch.cuda.synchronize()
+    return ag
+
+
+def test_factor_exchange_equals_gradient_allreduce_world2_emulated():
+    """two ranks emulated in one process (same parameters, different datasets, world_size 2): the factor path
+    (all-gather of the rank-MB factors + local rebuild of the summed gradient) must land where the all-reduce of the
+    materialised gradients lands, and both emulated ranks must stay bit-identical to each other."""
+    n, world = 16, 2
+    A1, B1 = _filled_agent_w(n, 5, 4, world), _filled_agent_w(n, 5, 6, world)
+    A2, B2 = _filled_agent_w(n, 5, 4, world), _filled_agent_w(n, 5, 6, world)
+    try:
+        np.testing.assert_array_equal(A1.t["AC_PARAMS"].cpu().numpy(), B2.t["AC_PARAMS"].cpu().numpy())
+        for ag in (A1, B1):
+            ag.backward(0, -1)
+        for ag in (A2, B2):
+            ag.backward_factors(-1)
+        for ep in range(2):
+            for mb in range(n * 8 // 4):
+                A1.backward(0, mb); B1.backward(0, mb)
+                s = A1.t["ALL_GRADS"] + B1.t["ALL_GRADS"]                  # what dist.all_reduce(SUM) leaves on both ranks
+                A1.t["ALL_GRADS"].copy_(s); B1.t["ALL_GRADS"].copy_(s)
+                A2.backward_factors(mb); B2.backward_factors(mb)
+                f = torch.stack([A2.t["FACTORS"], B2.t["FACTORS"]])        # what dist.all_gather_into_tensor leaves
+                A2.t["FACTORS_ALL"].copy_(f); B2.t["FACTORS_ALL"].copy_(f)
+                A2.grads_from_factors(); B2.grads_from_factors()
+                if ep == 0 and mb == 3:
+                    torch.cuda.synchronize()
+                    ga, gf = A1.t["ALL_GRADS"].cpu().numpy(), A2.t["ALL_GRADS"].cpu().numpy()
+                    np.testing.assert_allclose(gf, ga, rtol=1e-4, atol=1e-6)
+                    assert np.abs(ga).max() > 1e-3
+                for ag in (A1, B1, A2, B2):
+                    ag.apply(0, float("-inf")); ag.apply(1)
+        torch.cuda.synchronize()
+        assert A1.ctrl().ac_t == A2.ctrl().ac_t == 2 * (n * 8 // 4)
+        for k in ("AC_PARAMS", "CV_PARAMS"):
+            np.testing.assert_array_equal(A2.t[k].cpu().numpy(), B2.t[k].cpu().numpy(), err_msg=k)      # ranks stay in lock step
+            d = float((A1.t[k] - A2.t[k]).abs().max())
+            assert d < 1e-4, (k, d)
+        np.testing.assert_allclose(A1.ctrl().ac_lr, A2.ctrl().ac_lr, rtol=1e-6)
+    finally:
+        for ag in (A1, B1, A2, B2):
+            ag.close()
