@@ -155,9 +155,7 @@ class A2CAgent:
                 for mb in range(nmb):
                     ppo.backward_factors(mb)
                     dist.all_gather_into_tensor(fact_all, fact)
-                    ppo.grads_from_factors()
-                    ppo.apply(0, float("-inf"))
-                    ppo.apply(1)
+                    ppo.apply_factors()
             return
         ppo.backward(0, -1)
         if "ALL_GRADS" in ppo.t:

@@ -25,6 +25,7 @@ int sdxpk_backward_explicit(const SdxpDev*, int, hipStream_t);
 int sdxpk_persist_supported(const SdxpDev*, int, int);
 int sdxpk_backward_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_grads_from_factors(const SdxpDev*, int, hipStream_t);
+int sdxpk_apply_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_update_persistent(const SdxpDev*, int, unsigned*, unsigned*, hipStream_t);
 int sdxpk_prenorm(const SdxpDev*, int, hipStream_t);
 void sdxpk_apply_explicit(const SdxpDev*, int, float, int, hipStream_t);
@@ -175,7 +176,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     D.foff.dh = o; o += MB * 34; D.foff.dls = o; o += 32; D.foff.kl = o; o += 1;
     D.foff.total = (o + 63) / 64 * 64;
     D.world = cfg->world_size > 0 ? cfg->world_size : 1;
-    PAL(D.fact, D.foff.total); PAL(D.fact_all, (size_t)D.foff.total * D.world); PAL(D.sqn_part, 512);
+    PAL(D.fact, D.foff.total); PAL(D.fact_all, (size_t)D.foff.total * D.world); PAL(D.sqn_part, 1024);
   }
 #undef PAL
   // ---- parameter init
@@ -408,6 +409,12 @@ extern "C" int sdxp_grads_from_factors(sdxp_handle h, void* stream) {
   if (!h) return SDX_ERR_INVALID;
   sdxpk_grads_from_factors(&h->D, h->cfg.minibatch, (hipStream_t)stream);
   return plaunch_ok(h, "sdxp_grads_from_factors");
+}
+// sdxp_grads_from_factors + sdxp_apply(0, -INFINITY) + sdxp_apply(1) in four launches (the multi-rank step is launch-latency bound)
+extern "C" int sdxp_apply_factors(sdxp_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  sdxpk_apply_factors(&h->D, h->cfg.minibatch, (hipStream_t)stream);
+  return plaunch_ok(h, "sdxp_apply_factors");
 }
 // clip_grad_norm_ + Adam on the (caller-all-reduced, SUM) flat gradient of network `which`; gradients are divided by
 // world_size here.  kl: rank-averaged KL for the legacy LR schedule, or NaN to use SdxpCtrl.last_kl that the caller

@@ -821,6 +821,7 @@ __global__ __launch_bounds__(1024) void k_ctrl(SdxpDev D, int advance) {
       } else { ctl->gn2_ac = 0.0f; ctl->gn2_cv = 0.0f; ctl->ac_pending = 0; ctl->cv_pending = 0; }
       const float invM = 1.0f / (float)MB;
       const float kl = ctl->acc[4] * invM;
+      if (explicit_mode) { D.fact[D.foff.kl] = kl; D.ac_g[D.g_tail] = kl; }   // this rank's minibatch KL rides with factors / gradients
       ctl->sum_a_loss += ctl->acc[1] * invM; ctl->sum_c_loss += ctl->acc[2] * invM; ctl->sum_b_loss += ctl->acc[3] * invM;
       ctl->sum_kl += kl; ctl->sum_cv_loss += ctl->acc[5] * invM; ctl->sum_entropy += ctl->acc[6] * invM;
       ctl->n_mb += 1; ctl->last_kl = kl;
@@ -994,14 +995,13 @@ __global__ __launch_bounds__(256) void k_pack_factors(SdxpDev D) {
     for (int i = t0; i < 32; i += stride) F[D.foff.dls + i] = D.dlogstd[(size_t)par * 32 + i];
   }
 }
-__global__ void k_pack_kl(SdxpDev D) { D.fact[D.foff.kl] = D.ctrl->last_kl; }
 template <int MB>
-__global__ __launch_bounds__(256) void k_grad_layer_w(SdxpDev D, int l) {
+__device__ __forceinline__ void grad_layer_w_body(const SdxpDev& D, int l, int bidx) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int Nl = D.units[l];
   const int blocks_per_net = (Nl + 3) / 4;
-  const int net = blockIdx.x / blocks_per_net, n = (blockIdx.x % blocks_per_net) * 4 + wave;
+  const int net = bidx / blocks_per_net, n = (bidx % blocks_per_net) * 4 + wave;
   const int K = (l == 0) ? (net == 2 ? D.state_dim : D.obs_dim) : D.units[l - 1];
   float* G = net == 2 ? D.cv_g : D.ac_g;
   const size_t woff = net == 0 ? D.off.a_w[l] : net == 1 ? D.off.c_w[l] : D.coff.w[l];
@@ -1036,10 +1036,12 @@ __global__ __launch_bounds__(256) void k_grad_layer_w(SdxpDev D, int l) {
   if (lane == 0) G[boff + n] = sb;
 }
 template <int MB>
-__global__ __launch_bounds__(256) void k_grad_heads_w(SdxpDev D) {
+__global__ __launch_bounds__(256) void k_grad_layer_w(SdxpDev D, int l) { grad_layer_w_body<MB>(D, l, blockIdx.x); }
+template <int MB>
+__device__ __forceinline__ void grad_heads_w_body(const SdxpDev& D, int hb, int nhb) {   // block hb of nhb; the last one also does the tails
   const int tid = threadIdx.x, U = D.units[2], A = D.act_dim, W = D.world;
   const size_t T = D.foff.total;
-  for (int i = tid; i < (A + 2) * U; i += 256) {
+  for (int i = hb * 256 + tid; i < (A + 2) * U; i += nhb * 256) {
     const int row = i / U, k = i % U;
     const int net = row < A ? 0 : (row == A ? 1 : 2);
     float g = 0.0f;
@@ -1053,6 +1055,7 @@ __global__ __launch_bounds__(256) void k_grad_heads_w(SdxpDev D) {
     else if (row == A) D.ac_g[D.off.v_w + k] = g;
     else D.cv_g[D.coff.v_w + k] = g;
   }
+  if (hb != nhb - 1) return;
   if (tid < A + 2) {
     float g = 0.0f;
     for (int r = 0; r < W; ++r) {
@@ -1074,6 +1077,8 @@ __global__ __launch_bounds__(256) void k_grad_heads_w(SdxpDev D) {
     D.ac_g[D.g_tail] = kl;
   }
 }
+template <int MB>
+__global__ __launch_bounds__(256) void k_grad_heads_w(SdxpDev D) { grad_heads_w_body<MB>(D, 0, 1); }
 // squared norm of the flat gradient, bit-reproducible (every rank must compute the SAME clip scale from the same gradient, or the
 // replicas drift apart): fixed block -> slice mapping, in-block tree in a fixed order, second stage sums the 512 block partials
 __global__ __launch_bounds__(256) void k_sqnorm(const float* __restrict__ g, size_t n, float scale, float* part) {
@@ -1111,7 +1116,6 @@ __global__ __launch_bounds__(256) void k_adam_explicit(SdxpDev D, int which) {
     M[i] = m; V[i] = v;
   }
 }
-__global__ void k_publish_kl(SdxpDev D) { D.ac_g[D.g_tail] = D.ctrl->last_kl; }   // this rank's minibatch KL rides with the gradients
 __global__ void k_apply_fin(SdxpDev D, int which, float kl_host) {
   SdxpCtrl* ctl = D.ctrl;
   if (which) { ctl->cv_t += 1; ctl->cv_b1pow *= 0.9; ctl->cv_b2pow *= 0.999; ctl->cv_gnorm = sqrtf(ctl->gn2_cv); return; }
@@ -1214,10 +1218,90 @@ static void launch_backward_explicit(const SdxpDev* D, hipStream_t st) {
   }
   hipLaunchKernelGGL(k_grad_heads<MB>, dim3(1), dim3(256), 0, st, *D);
   hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(1024), 0, st, *D, 1 | 2 | 8);
-  hipLaunchKernelGGL(k_publish_kl, dim3(1), dim3(1), 0, st, *D);
 }
 extern "C" int sdxpk_backward_explicit(const SdxpDev* D, int mb_size, hipStream_t st) {
 #define C_(M) launch_backward_explicit<M>(D, st)
+  MB_SWITCH(mb_size, C_)
+#undef C_
+}
+// ---- the factor path's "apply" in four launches: every gradient block of the three layers and the heads at once, the squared
+// norms of both flat gradients, clip + Adam of both networks, the step counters / LR rule
+template <int MB>
+__global__ __launch_bounds__(256) void k_grad_all_w(SdxpDev D) {
+  const int nb0 = 3 * ((D.units[0] + 3) / 4), nb1 = 3 * ((D.units[1] + 3) / 4), nb2 = 3 * ((D.units[2] + 3) / 4);
+  int b = blockIdx.x, l;
+  if (b < nb0) l = 0;
+  else if (b < nb0 + nb1) { l = 1; b -= nb0; }
+  else if (b < nb0 + nb1 + nb2) { l = 2; b -= nb0 + nb1; }
+  else { grad_heads_w_body<MB>(D, b - (nb0 + nb1 + nb2), (int)gridDim.x - (nb0 + nb1 + nb2)); return; }
+  grad_layer_w_body<MB>(D, l, b);
+}
+__global__ __launch_bounds__(256) void k_sqnorm2(SdxpDev D, float scale) {
+  __shared__ float sw[4];
+  const int which = blockIdx.y;
+  const float* g = which ? D.cv_g : D.ac_g;
+  const size_t n = which ? D.coff.total : D.off.total;
+  float s = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float v = g[i] * scale; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) D.sqn_part[which * 512 + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ __launch_bounds__(256) void k_adam2(SdxpDev D) {
+  __shared__ float sw[4];
+  __shared__ float s_n2;
+  SdxpCtrl* ctl = D.ctrl;
+  const int which = blockIdx.y;
+  {   // every block folds the 512 partials in the same fixed order -> the same clip scale everywhere, on every rank
+    float s = D.sqn_part[which * 512 + threadIdx.x] + D.sqn_part[which * 512 + 256 + threadIdx.x];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_n2 = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+      if (blockIdx.x == 0) { if (which) ctl->gn2_cv = s_n2; else ctl->gn2_ac = s_n2; }
+    }
+    __syncthreads();
+  }
+  const size_t n = which ? D.coff.total : D.off.total;
+  float* P = which ? D.cv : D.ac; float* M = which ? D.cv_m : D.ac_m; float* V = which ? D.cv_v : D.ac_v;
+  const float* G = which ? D.cv_g : D.ac_g;
+  const float inv_w = 1.0f / (float)ctl->world;
+  const float norm = sqrtf(s_n2);
+  const float clip = D.truncate_grads ? fminf(1.0f, D.grad_norm / (norm + 1e-6f)) : 1.0f;
+  const int t = (which ? ctl->cv_t : ctl->ac_t) + 1;
+  const float bc1 = 1.0f - powf(0.9f, (float)t), bc2 = 1.0f - powf(0.999f, (float)t);
+  const float lr = which ? ctl->cv_lr : ctl->ac_lr;
+  const float lr_bc1 = lr / bc1, isq_bc2 = 1.0f / sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float m = M[i], v = V[i];
+    P[i] = adam1(P[i], G[i] * inv_w * clip, m, v, lr_bc1, isq_bc2);
+    M[i] = m; V[i] = v;
+  }
+}
+__global__ void k_apply_fin2(SdxpDev D) {
+  SdxpCtrl* ctl = D.ctrl;
+  ctl->cv_t += 1; ctl->cv_b1pow *= 0.9; ctl->cv_b2pow *= 0.999; ctl->cv_gnorm = sqrtf(ctl->gn2_cv);
+  ctl->ac_t += 1; ctl->ac_b1pow *= 0.9; ctl->ac_b2pow *= 0.999; ctl->ac_gnorm = sqrtf(ctl->gn2_ac);
+  const float kl = D.ac_g[D.g_tail] / (float)ctl->world;
+  if (D.adaptive_lr) {   // legacy schedule after every minibatch, on the rank-averaged KL (PS:306-312)
+    if (kl > 2.0f * D.kl_threshold) ctl->ac_lr = fmaxf(ctl->ac_lr / 1.5f, 1e-6f);
+    if (kl < 0.5f * D.kl_threshold) ctl->ac_lr = fminf(ctl->ac_lr * 1.5f, 1e-2f);
+  }
+}
+template <int MB>
+static void launch_apply_factors(const SdxpDev* D, hipStream_t st) {
+  const int nhb = ((D->act_dim + 2) * D->units[2] + 255) / 256 + 1;   // head blocks: one output per thread, + one block for the tails
+  const int nb = 3 * ((D->units[0] + 3) / 4) + 3 * ((D->units[1] + 3) / 4) + 3 * ((D->units[2] + 3) / 4) + nhb;
+  const int Kmax = D->units[0] > D->state_dim ? D->units[0] : D->state_dim;
+  hipLaunchKernelGGL(k_grad_all_w<MB>, dim3(nb), dim3(256), (size_t)MB * Kmax * sizeof(float), st, *D);
+  hipLaunchKernelGGL(k_sqnorm2, dim3(512, 2), dim3(256), 0, st, *D, 1.0f / (float)D->world);
+  hipLaunchKernelGGL(k_adam2, dim3(512, 2), dim3(256), 0, st, *D);
+  hipLaunchKernelGGL(k_apply_fin2, dim3(1), dim3(1), 0, st, *D);
+}
+extern "C" int sdxpk_apply_factors(const SdxpDev* D, int mb_size, hipStream_t st) {
+#define C_(M) launch_apply_factors<M>(D, st)
   MB_SWITCH(mb_size, C_)
 #undef C_
 }
@@ -1226,7 +1310,6 @@ static void launch_backward_factors(const SdxpDev* D, hipStream_t st) {
   launch_fwd_bwd<MB>(D, st);
   hipLaunchKernelGGL(k_pack_factors<MB>, dim3(8, 23), dim3(256), 0, st, *D);
   hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(1024), 0, st, *D, 1 | 2 | 8);
-  hipLaunchKernelGGL(k_pack_kl, dim3(1), dim3(1), 0, st, *D);
 }
 extern "C" int sdxpk_backward_factors(const SdxpDev* D, int mb_size, hipStream_t st) {
 #define C_(M) launch_backward_factors<M>(D, st)

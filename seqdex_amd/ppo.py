@@ -121,6 +121,10 @@ class SdxPPO:
         """rebuild the SUM over ranks of the minibatch gradients from t["FACTORS_ALL"] (all-gathered by the caller)"""
         self._check(self.lib.sdxp_grads_from_factors(self.h, _stream_ptr(self.device)))
 
+    def apply_factors(self):
+        """grads_from_factors() + apply(0, -inf) + apply(1) in four launches"""
+        self._check(self.lib.sdxp_apply_factors(self.h, _stream_ptr(self.device)))
+
     def kl_view(self):
         """1-element f32 view of SdxpCtrl.last_kl inside the STATS tensor (for the scalar KL all-reduce, PS:308-310)"""
         off = Ctrl.last_kl.offset // 4
