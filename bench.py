@@ -103,7 +103,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_multi = os.environ.get("SDX_FORCE_MULTI_RANK") == "1"     # multi-rank update path at world size 1 (validation aid)
+    if force_multi and "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+    if world > 1 or force_multi:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
 
@@ -122,7 +125,7 @@ def main():
     task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=local_rank, headless=True, seed=seed, piles_per_type=8)
     env = RLgamesVecTaskPython(task, "cuda:%d" % local_rank)
     pc = train["params"]["config"]
-    pc.update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22, multi_gpu=world > 1)
+    pc.update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22, multi_gpu=world > 1 or force_multi)
     agent = A2CAgent("run", train["params"])
     horizon = agent.horizon_length
 
@@ -176,7 +179,7 @@ def main():
     p_ac, p_cv = agent.ppo.param_count(0), agent.ppo.param_count(1)
     nsteps = agent.mini_epochs_num * (n * horizon // agent.minibatch_size)
     upd_bytes_step = 6 * 4 * (p_ac + p_cv)
-    impl = agent.ppo.update_impl() if world == 1 else "explicit"
+    impl = agent.ppo.update_impl() if not agent.multi_gpu else "explicit"
     if impl == "persistent":
         for _ in range(2):      # HIP events on the stream the kernel is launched on (torch's current stream)
             e0.record()

@@ -44,7 +44,9 @@ class A2CAgent:
         self.ppo_device = self.vec_env.rl_device
         self.rank = int(os.environ.get("RANK", "0")) if cfg.get("multi_gpu", False) else 0
         self.rank_size = int(os.environ.get("WORLD_SIZE", "1")) if cfg.get("multi_gpu", False) else 1
-        self.multi_gpu = self.rank_size > 1
+        # SDX_FORCE_MULTI_RANK=1: run the multi-rank update path even at world size 1 (degenerate collectives; used to validate and
+        # time that path on a single-GPU box)
+        self.multi_gpu = self.rank_size > 1 or (cfg.get("multi_gpu", False) and os.environ.get("SDX_FORCE_MULTI_RANK") == "1")
         seed = int(cfg.get("seed", 22)) + self.rank                    # per-rank seed = seed + rank (App. C)
         self.ppo = SdxPPO(self.num_actors, params=params, device=self.ppo_device, seed=seed, world_size=self.rank_size)
         self.has_central_value = True
