@@ -31,7 +31,7 @@
 #define ND SDX_NDOF
 #define NF SDX_NFREE
 #ifndef SDXO_MAXC
-#define SDXO_MAXC 1280
+#define SDXO_MAXC 1536
 #endif
 #define NSAMP 28
 #define BODY_STATIC 255

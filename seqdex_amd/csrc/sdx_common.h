@@ -6,7 +6,7 @@
 #include "../../include/seqdex.h"
 
 #define SDX_WAVE 64
-#define SDX_MAXC 1280        // contact points per env (global scratch, SoA)
+#define SDX_MAXC 1536        // contact points per env = 3 rows per lane x 512 lanes of k_physics
 #define SDX_MAXP 1024        // candidate box pairs per env (LDS)
 #define SDX_CFIELDS 17       // ab, p3, n3, sep, lam3, wA3, wB3
 #define SDX_NSAMP 28

@@ -51,7 +51,7 @@ def test_physics_1024_deterministic_env_independent_and_sampled_oracle(golden_di
         for x, y in zip(a, b):                                   # bit-exact run-to-run: no atomics, fixed contact order
             np.testing.assert_array_equal(x, y)
         assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
-        assert a[2].max() < 1280 and a[2].min() > 100            # contact-rich, inside the per-env capacity
+        assert a[2].max() < 1536 and a[2].min() > 100            # contact-rich, inside the per-env capacity
         # envs do not interact: a 64-env simulator fed envs [512, 576) reproduces those rows bit for bit
         s2 = SdxSim(64)
         try:
