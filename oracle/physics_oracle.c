@@ -152,6 +152,32 @@ static v3 inertia_mul(q4 q, const float* I, v3 x) {
   return qrot(q, m);
 }
 
+/* ---------------------------------------------------------------- A2: velocity-product bias torques */
+/* C(q,qd) qd of the fixed-base tree = recursive Newton-Euler with zero joint accelerations (no gravity on the robot, GS:544):
+ * link angular accelerations al, linear accelerations of the link origins ao, then the inertial wrench of every link about
+ * its centre of mass, projected on the joint axes of its ancestors. */
+static void coriolis(const sdx_scene_desc* sc, const env_t* e, real tauc[ND]) {
+  v3 al[NL], ao[NL], F[NL], Nn[NL];
+  al[0] = ao[0] = F[0] = Nn[0] = V(0, 0, 0);
+  for (int k = 1; k < NL; ++k) {
+    int p = sc->parent[k];
+    v3 r = vsub(e->lp[k], e->lp[p]);
+    al[k] = vadd(al[p], vcross(e->lw[p], vscale(e->la[k], e->qd[k - 1])));
+    ao[k] = vadd(ao[p], vadd(vcross(al[p], r), vcross(e->lw[p], vcross(e->lw[p], r))));
+    v3 d = vsub(e->lc[k], e->lp[k]);
+    v3 acom = vadd(ao[k], vadd(vcross(al[k], d), vcross(e->lw[k], vcross(e->lw[k], d))));
+    F[k] = vscale(acom, sc->link_mass[k]);
+    Nn[k] = vadd(inertia_mul(e->lq[k], sc->link_inertia[k], al[k]),
+                 vcross(e->lw[k], inertia_mul(e->lq[k], sc->link_inertia[k], e->lw[k])));
+  }
+  for (int j = 0; j < ND; ++j) {
+    real s = 0;
+    for (int k = 1; k < NL; ++k)
+      if ((e->anc[k] >> j) & 1u) s += vdot(e->la[j + 1], vadd(vcross(vsub(e->lc[k], e->lp[j + 1]), F[k]), Nn[k]));
+    tauc[j] = s;
+  }
+}
+
 /* ---------------------------------------------------------------- B: joint-space inertia and its inverse */
 static void mass_matrix(const sdx_scene_desc* sc, env_t* e, real h) {
   for (int i = 0; i < ND; ++i)
@@ -487,10 +513,11 @@ static void load_env(const sdx_scene_desc* sc, env_t* e, const float* root, cons
 static void substep(const sdx_scene_desc* sc, env_t* e, real h, int first) {
   fk(sc, e);
   if (first) mass_matrix(sc, e, h); /* M(q) is evaluated once per step and frozen over the substeps */
-  real tau[ND];
+  real tau[ND], tauc[ND];
+  coriolis(sc, e, tauc);
   for (int j = 0; j < ND; ++j) {
     real t = sc->kp[j] * (e->tgt[j] - e->q[j]) - (sc->kd[j] + h * sc->kp[j]) * e->qd[j];
-    tau[j] = fminf(sc->effort[j], fmaxf(-sc->effort[j], t));
+    tau[j] = fminf(sc->effort[j], fmaxf(-sc->effort[j], t)) - tauc[j];   /* the effort limit applies to the drive only */
   }
   for (int i = 0; i < ND; ++i) {
     real s = 0;

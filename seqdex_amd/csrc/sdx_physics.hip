@@ -31,6 +31,7 @@ __constant__ float c_samp[SDX_NSAMP][3] = {
 struct PhysLds {
   float q[ND], qd[ND], tgt[ND], qds[ND], Q[ND], tau[ND];
   float lq[NL][4], lp[NL][3], la[NL][3], lc[NL][3], lv[NL][3], lw[NL][3], lI[NL][6];
+  float lal[NL][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
   float A[ND][HP];   // H -> L -> Hinv
   float T[ND][HP];   // L^-1
   float bp[NF][3], bq[NF][4], bv[NF][3], bw[NF][3], dv[NF][3], dw[NF][3];
@@ -171,6 +172,11 @@ __device__ __forceinline__ float brick_w(const SdxConst* C, const PhysLds& S, in
 }
 
 // ---------------------------------------------------------------- A: FK (level-parallel over the tree)
+// world inertia times vector: R I R^T x with I = (xx yy zz xy xz yz) in the link frame
+__device__ __forceinline__ f3 inertia_mul(f4 q, const float* I, f3 x) {
+  const f3 l = qrot(qconj(q), x);
+  return qrot(q, F3(I[0] * l.x + I[3] * l.y + I[4] * l.z, I[3] * l.x + I[1] * l.y + I[5] * l.z, I[4] * l.x + I[5] * l.y + I[2] * l.z));
+}
 __device__ void fk(const SdxConst* C, PhysLds& S, int tid) {
   const sdx_scene_desc& sc = C->sc;
   if (tid == 0) {
@@ -179,6 +185,7 @@ __device__ void fk(const SdxConst* C, PhysLds& S, int tid) {
     st3(S.la[0], F3(0, 0, 1));
     st3(S.lv[0], F3(0, 0, 0));
     st3(S.lw[0], F3(0, 0, 0));
+    st3(S.lal[0], F3(0, 0, 0)); st3(S.lao[0], F3(0, 0, 0)); st3(S.lF[0], F3(0, 0, 0)); st3(S.lN[0], F3(0, 0, 0));
     st3(S.lc[0], ld3(sc.base_pos) + qrot(ld4(sc.base_quat), ld3(sc.link_com[0])));
   }
   if (tid > 0 && tid < NL) sincosf(0.5f * S.q[tid - 1], &S.sincos[tid][0], &S.sincos[tid][1]);
@@ -199,8 +206,19 @@ __device__ void fk(const SdxConst* C, PhysLds& S, int tid) {
       st3(S.lp[k], pk);
       st3(S.la[k], ak);
       st3(S.lc[k], pk + qrot(qk, ld3(sc.link_com[k])));
-      st3(S.lw[k], wp + ak * S.qd[k - 1]);
+      const f3 wk = wp + ak * S.qd[k - 1];
+      st3(S.lw[k], wk);
       st3(S.lv[k], ld3(S.lv[p]) + cross(wp, pk - pp));
+      // velocity-product terms (recursive Newton-Euler at zero joint acceleration, fixed base, no gravity on the robot)
+      const f3 alp = ld3(S.lal[p]), r = pk - pp;
+      const f3 alk = alp + cross(wp, ak * S.qd[k - 1]);
+      const f3 aok = ld3(S.lao[p]) + cross(alp, r) + cross(wp, cross(wp, r));
+      st3(S.lal[k], alk);
+      st3(S.lao[k], aok);
+      const f3 dk = qrot(qk, ld3(sc.link_com[k]));
+      const f3 acom = aok + cross(alk, dk) + cross(wk, cross(wk, dk));
+      st3(S.lF[k], acom * sc.link_mass[k]);
+      st3(S.lN[k], inertia_mul(qk, sc.link_inertia[k], alk) + cross(wk, inertia_mul(qk, sc.link_inertia[k], wk)));
     }
     __syncthreads();
   }
@@ -832,7 +850,12 @@ __global__ __launch_bounds__(NT, 2) void k_physics(const SdxConst* __restrict__ 
     // C: implicit PD drive (P1) + gravity on the free bricks
     if (tid < ND) {
       const float t = sc.kp[tid] * (S.tgt[tid] - S.q[tid]) - (sc.kd[tid] + h * sc.kp[tid]) * S.qd[tid];
-      S.tau[tid] = fminf(sc.effort[tid], fmaxf(-sc.effort[tid], t));
+      // velocity-product bias torque of dof tid: inertial wrenches of the links below it, projected on its axis
+      float tc = 0.0f;
+      const f3 aj = ld3(S.la[tid + 1]), oj = ld3(S.lp[tid + 1]);
+      for (int k = 1; k < NL; ++k)
+        if ((C->anc[k] >> tid) & 1u) tc += dot(aj, cross(ld3(S.lc[k]) - oj, ld3(S.lF[k])) + ld3(S.lN[k]));
+      S.tau[tid] = fminf(sc.effort[tid], fmaxf(-sc.effort[tid], t)) - tc;   // the effort limit applies to the drive only
       S.Q[tid] = 0.0f;
     }
     __syncthreads();

@@ -125,3 +125,30 @@ def test_contact_generation_face_on_face(scene, desc):
     np.testing.assert_allclose(c[:, 5:8], [[0, 0, 1]] * 4, atol=1e-6)    # normals out of the floor slab
     np.testing.assert_allclose(c[:, 8], -0.0005, atol=2e-6)
     assert set(c[:, 1].astype(int)) == {255} and set(c[:, 0].astype(int)) == {0}
+
+
+def test_free_swinging_arm_conserves_kinetic_energy(scene):
+    """known answer for the velocity-product (Coriolis / centrifugal) terms: with the drives switched off and nothing in reach
+    the arm + hand is a conservative system, so T = 1/2 qd^T (M(q) + armature) qd stays constant while q changes by tenths of
+    a radian.  Without C(q,qd)qd the same run gains 87 % in 20 steps; the bar here is the drift of semi-implicit Euler."""
+    d = scene.to_desc()
+    for j in range(23):
+        d.kp[j] = 0.0; d.kd[j] = 0.0; d.vel_limit[j] = 100.0
+    root = np.zeros((1, 142, 13), np.float32); root[..., 6] = 1.0
+    root[:, :, 0] = 50.0 + np.arange(142)[None, :] * 2.0; root[:, :, 2] = 100.0     # bricks and statics out of reach
+    rng = np.random.default_rng(0)
+    q0 = ((scene.lower + scene.upper) / 2).astype(np.float32)
+    dof = np.zeros((1, 23, 2), np.float32); dof[0, :, 0] = q0
+    dof[0, :7, 1] = rng.uniform(-1.5, 1.5, 7); dof[0, 7:, 1] = rng.uniform(-2, 2, 16)
+    tg = np.tile(q0, (1, 1)).astype(np.float32)
+
+    def kinetic(dof):
+        H, _ = po.mass_matrix(d, dof[0, :, 0], 0.0)
+        v = dof[0, :, 1].astype(np.float64)
+        return 0.5 * v @ H.astype(np.float64) @ v
+
+    e0 = kinetic(dof)
+    for _ in range(15):                       # 0.25 s; no joint reaches its limit before step 16 in this draw
+        po.simulate(d, root, dof, tg)
+        assert abs(kinetic(dof) / e0 - 1.0) < 0.02
+    assert np.abs(dof[0, :, 0] - q0).max() > 0.3
