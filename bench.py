@@ -27,7 +27,7 @@ BYTES_PER_ENV_STEP = 18496     # algorithmic HBM bytes per env
 # x2 correction is calibrated for 16 B/lane streaming reads only, the exchange words here are 8 B/lane).  PMC counters cannot
 # be read from inside this process, so `traffic` is quoted from those files and is null for any other configuration.
 PMC_TRAFFIC_BYTES = {("k_update_persistent", 1024): (15711795.9 + 5536986.1) * 1024,     # profiles/r1_bench_pmc_{fetch,write}_v2.csv
-                     ("k_physics", 1024): (1325.4 + 6929.0) * 1024}
+                     ("k_physics", 1024): (3321.1 + 21548.8) * 1024}   # the 40 dispatches with 1024 workgroups (grid 524288) only
 
 
 def parse():
