@@ -294,6 +294,10 @@ int sdxp_update(sdxp_handle h, void* stream);
  * resident in the VGPR files of 256 CUs; needs the shipped shapes, minibatch_size 4 and a 256-CU device), 0 = hipGraph of the
  * multi-kernel optimiser step (any minibatch_size in {2,4,8}; forced with SDXP_UPDATE_IMPL=graph). */
 int sdxp_update_impl(sdxp_handle h);
+/* Waits for the update launched on `stream`.  SDX_OK, or SDX_ERR_STATE when the persistent kernel timed out (its 256 workgroups were
+ * not co-resident): nothing was applied, the inputs it had touched are restored and the handle has switched to the hipGraph
+ * path - call sdxp_update again to repeat the epoch.  Optional after the hipGraph path (always SDX_OK there). */
+int sdxp_update_status(sdxp_handle h, void* stream);
 /* Multi-rank path, one minibatch at a time so that the caller can all-reduce SDXP_T_*_GRADS in between:
  * which = 0 actor-critic, 1 central value; mb = minibatch index within the epoch. */
 int sdxp_backward(sdxp_handle h, int32_t which, int32_t mb, void* stream);

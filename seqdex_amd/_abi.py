@@ -74,7 +74,7 @@ SDX_EXPORTS = ["sdx_create", "sdx_destroy", "sdx_tensor", "sdx_load_initial_stat
                "sdx_step", "sdx_pre_physics", "sdx_simulate", "sdx_post_physics", "sdx_compute_observations",
                "sdx_reset_idx", "sdx_refresh_kinematics", "sdx_num_envs", "sdx_last_error",
                "sdxp_create", "sdxp_destroy", "sdxp_tensor", "sdxp_param_count", "sdxp_act", "sdxp_store_rewards",
-               "sdxp_finish_rollout", "sdxp_update", "sdxp_update_impl", "sdxp_backward", "sdxp_apply", "sdxp_backward_factors",
+               "sdxp_finish_rollout", "sdxp_update", "sdxp_update_impl", "sdxp_update_status", "sdxp_backward", "sdxp_apply", "sdxp_backward_factors",
                "sdxp_grads_from_factors", "sdxp_apply_factors", "sdxp_last_error"]
 
 _lib = None
@@ -116,6 +116,7 @@ def load_library():
     lib.sdxp_finish_rollout.argtypes = [vp, vp, vp, vp]
     lib.sdxp_update.argtypes = [vp, vp]
     lib.sdxp_update_impl.argtypes = [vp]
+    lib.sdxp_update_status.argtypes = [vp, vp]
     lib.sdxp_backward.argtypes = [vp, i32, i32, vp]
     lib.sdxp_apply.argtypes = [vp, i32, f32, vp]
     lib.sdxp_backward_factors.argtypes = [vp, i32, vp]

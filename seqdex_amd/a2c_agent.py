@@ -128,7 +128,7 @@ class A2CAgent:
         if self.multi_gpu:
             self._update_multi_gpu()
         else:
-            self.ppo.update()
+            self.ppo.update_checked()      # waits; falls back to the hipGraph path if the persistent kernel could not run
         torch.cuda.synchronize()
         update_time_end = time.time()
         c = self.ppo.ctrl()

@@ -45,6 +45,11 @@ struct sdxp_agent {
   bool use_persist = false;      // persistent register-resident update kernel (sdxp_persist.hip)
   unsigned* bar_dev = nullptr;   // [64] grid-barrier counter (+ fail flag at [32])
   unsigned* fail_host = nullptr; // pinned mirror of the fail flag, refreshed after every persistent update
+  // what a persistent update touches before it can fail (old mu/sigma rows, running mean/std, control block): saved at the start
+  // of the call so that sdxp_update_status can put it back and the caller can repeat the epoch on the hipGraph path
+  float *mus_bak = nullptr, *sig_bak = nullptr;
+  double* rms_bak = nullptr;
+  SdxpCtrl* ctrl_bak = nullptr;
   std::string err;
 };
 
@@ -166,6 +171,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   PAL(D.cvx0, R * cfg->state_dim); PAL(D.cvx1, R * cfg->state_dim);
   PAL(D.dbg, 64); PAL(D.dhead, (size_t)2 * MB * 34); PAL(D.dlogstd, 64); PAL(D.ctrl, 1); PAL(h->stats_dev, 16);
   PAL(h->bar_dev, 64); PAL(D.ll, SDXP_LL_WORDS);
+  PAL(h->mus_bak, R * cfg->act_dim); PAL(h->sig_bak, R * cfg->act_dim); PAL(h->rms_bak, (size_t)2 * cfg->state_dim); PAL(h->ctrl_bak, 1);
   {   // factor exchange buffers of the multi-rank path
     uint32_t o = 0;
     for (int net = 0; net < 3; ++net)
@@ -339,9 +345,18 @@ extern "C" int sdxp_update(sdxp_handle h, void* stream) {
   if (h->fail_host && *h->fail_host) {
     h->use_persist = false;   // a grid barrier of the persistent kernel timed out earlier: fall back for good
     *h->fail_host = 0;
-    h->err = "sdxp_update: the persistent update kernel timed out at a grid barrier in a previous call (not all 256 "
-             "workgroups were co-resident?); parameters of that epoch are undefined; falling back to the graph path";
+    h->err = "sdxp_update: the persistent update kernel of the previous call timed out waiting for an exchange word (not all 256 "
+             "workgroups co-resident?); that epoch's update was NOT applied (call sdxp_update_status after sdxp_update to catch "
+             "this in time to repeat it); this handle now uses the hipGraph path";
     return SDX_ERR_STATE;
+  }
+  if (h->use_persist) {
+    const size_t ra = (size_t)h->D.N * h->D.horizon * h->D.act_dim * sizeof(float), sd = (size_t)h->D.state_dim * sizeof(double);
+    PCHK(h, hipMemcpyAsync(h->mus_bak, h->D.mb_mus, ra, hipMemcpyDeviceToDevice, st));
+    PCHK(h, hipMemcpyAsync(h->sig_bak, h->D.mb_sigmas, ra, hipMemcpyDeviceToDevice, st));
+    PCHK(h, hipMemcpyAsync(h->rms_bak, h->D.rms_mean, sd, hipMemcpyDeviceToDevice, st));
+    PCHK(h, hipMemcpyAsync(h->rms_bak + h->D.state_dim, h->D.rms_var, sd, hipMemcpyDeviceToDevice, st));
+    PCHK(h, hipMemcpyAsync(h->ctrl_bak, h->D.ctrl, sizeof(SdxpCtrl), hipMemcpyDeviceToDevice, st));
   }
   hipLaunchKernelGGL(k_ctrl_begin_epoch, dim3(1), dim3(1), 0, st, h->D.ctrl);
   if (h->use_persist) {
@@ -423,6 +438,29 @@ extern "C" int sdxp_apply(sdxp_handle h, int32_t which, float kl, void* stream) 
   if (!h || which < 0 || which > 1) return SDX_ERR_INVALID;
   sdxpk_apply_explicit(&h->D, which, kl, h->cfg.world_size > 0 ? h->cfg.world_size : 1, (hipStream_t)stream);
   return plaunch_ok(h, "sdxp_apply");
+}
+// Blocks until the update launched by sdxp_update on `stream` has finished.  SDX_OK, or SDX_ERR_STATE if the persistent kernel gave
+// up (an exchange word never arrived): nothing of that epoch was applied, the inputs it had already touched (old mu/sigma rows,
+// running mean/std, control block) are restored, and the handle is switched to the hipGraph path - calling sdxp_update again
+// repeats the epoch there.
+extern "C" int sdxp_update_status(sdxp_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  PCHK(h, hipStreamSynchronize(st));
+  if (!h->fail_host || !*h->fail_host) return SDX_OK;
+  *h->fail_host = 0;
+  h->use_persist = false;
+  const size_t ra = (size_t)h->D.N * h->D.horizon * h->D.act_dim * sizeof(float), sd = (size_t)h->D.state_dim * sizeof(double);
+  PCHK(h, hipMemsetAsync(h->bar_dev, 0, 256, st));
+  PCHK(h, hipMemcpyAsync(h->D.mb_mus, h->mus_bak, ra, hipMemcpyDeviceToDevice, st));
+  PCHK(h, hipMemcpyAsync(h->D.mb_sigmas, h->sig_bak, ra, hipMemcpyDeviceToDevice, st));
+  PCHK(h, hipMemcpyAsync(h->D.rms_mean, h->rms_bak, sd, hipMemcpyDeviceToDevice, st));
+  PCHK(h, hipMemcpyAsync(h->D.rms_var, h->rms_bak + h->D.state_dim, sd, hipMemcpyDeviceToDevice, st));
+  PCHK(h, hipMemcpyAsync(h->D.ctrl, h->ctrl_bak, sizeof(SdxpCtrl), hipMemcpyDeviceToDevice, st));
+  PCHK(h, hipStreamSynchronize(st));
+  h->err = "sdxp_update: the persistent update kernel timed out waiting for an exchange word (not all 256 workgroups co-resident?); "
+           "nothing was applied, inputs restored; this handle now uses the hipGraph path - call sdxp_update again";
+  return SDX_ERR_STATE;
 }
 extern "C" int sdxp_update_impl(sdxp_handle h) { return h && h->use_persist ? 1 : 0; }
 

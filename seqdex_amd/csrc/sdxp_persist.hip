@@ -122,7 +122,7 @@ __device__ __forceinline__ bool ll_gather(const u64* p, size_t stride, unsigned 
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 255u) == 0) {
       const unsigned f = __hip_atomic_load(failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (spins > (1u << 22) || __builtin_amdgcn_readfirstlane(f) != 0) {
+      if (spins > (1u << 20) || __builtin_amdgcn_readfirstlane(f) != 0) {
         __hip_atomic_store(failflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
@@ -195,7 +195,7 @@ __device__ __forceinline__ const float* cvx_rows(const SdxpDev& D, int mb, int m
   return (mini_epoch == 0 ? D.cvx0 : D.cvx1) + (size_t)mb * MB * ST;
 }
 
-__global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int total_steps, unsigned* bar, unsigned* failflag, int stamps) {
+__global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int total_steps, unsigned* bar, unsigned* failflag, int stamps, int fault) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   PLds& S = *reinterpret_cast<PLds*>(smem_raw);
   // Thread coordinates are re-derived from an opaque copy of threadIdx/blockIdx at the start of every phase (refresh()):
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
   for (int step = 0; step <= total_steps; ++step) {
     __syncthreads();
     if (S.fail) return;   // an exchange word never arrived (not all CUs resident?): the host sees *failflag and reports it
+    if (fault && g == NWG - 1 && step == 3) return;   // SDXP_PERSIST_FAULT=1 (tests): one CU goes silent, the others must time out
     refresh();
     const bool last = step == total_steps;   // the extra iteration only applies the optimiser step of the final minibatch
     const int mbi = step % D.num_minibatches, mini_epoch = step / D.num_minibatches;
@@ -1037,12 +1038,14 @@ extern "C" int sdxpk_persist_supported(const SdxpDev* D, int minibatch, int n_cu
 extern "C" int sdxpk_update_persistent(const SdxpDev* D, int total_steps, unsigned* bar, unsigned* failflag, hipStream_t st) {
   static bool attr = false;
   static const int stamps = (getenv("SDXP_PERSIST_STAMPS") && getenv("SDXP_PERSIST_STAMPS")[0] == '1') ? 1 : 0;
+  const char* fe = getenv("SDXP_PERSIST_FAULT");   // read per call: the failure-path test sets and clears it
+  const int fault = (fe && fe[0] == '1') ? 1 : 0;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_persistent), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sizeof(PLds)) != hipSuccess) return -1;
     attr = true;
   }
   if (hipMemsetAsync(bar, 0, 256, st) != hipSuccess) return -1;
-  hipLaunchKernelGGL(k_update_persistent, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, total_steps, bar, failflag, stamps);
+  hipLaunchKernelGGL(k_update_persistent, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, total_steps, bar, failflag, stamps, fault);
   return 0;
 }

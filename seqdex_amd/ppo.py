@@ -102,6 +102,15 @@ class SdxPPO:
     def update(self):
         self._check(self.lib.sdxp_update(self.h, _stream_ptr(self.device)))
 
+    def update_checked(self):
+        """update() + wait + verdict; if the persistent kernel could not run (its 256 workgroups were not co-resident) the library
+        has restored its inputs and switched to the hipGraph path: repeat the epoch there.  Returns the implementation used."""
+        self.update()
+        if self.lib.sdxp_update_status(self.h, _stream_ptr(self.device)) != 0:
+            self.update()
+            self._check(self.lib.sdxp_update_status(self.h, _stream_ptr(self.device)))
+        return self.update_impl()
+
     def update_impl(self):
         """'persistent' (one launch per epoch, register-resident weights) or 'graph' (hipGraph of the multi-kernel step)"""
         return "persistent" if self.lib.sdxp_update_impl(self.h) == 1 else "graph"

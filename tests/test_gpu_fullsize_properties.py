@@ -229,3 +229,36 @@ def test_factor_exchange_equals_gradient_allreduce_world2_emulated():
     finally:
         for ag in (A1, B1, A2, B2):
             ag.close()
+
+
+def test_persistent_kernel_failure_falls_back_to_graph_path():
+    """fault injection (SDXP_PERSIST_FAULT=1: one CU of the persistent kernel goes silent at step 3): every other CU must time out
+    instead of hanging, nothing of the epoch may be applied, the touched inputs must be restored, and update_checked() must
+    repeat the epoch on the hipGraph path with the same result a graph-only agent gets."""
+    n = 64
+    a = _filled_agent(n, 9)
+    c = _filled_agent(n, 9, impl="graph")
+    try:
+        if a.update_impl() != "persistent":
+            pytest.skip("persistent update kernel not selected on this device")
+        p0 = a.t["AC_PARAMS"].clone(); mus0 = a.t["MB_MUS"].clone(); rms0 = a.t["CV_RMS_MEAN"].clone()
+        os.environ["SDXP_PERSIST_FAULT"] = "1"
+        try:
+            a.update()
+            rc = a.lib.sdxp_update_status(a.h, None)
+        finally:
+            del os.environ["SDXP_PERSIST_FAULT"]
+        assert rc != 0 and b"timed out" in a.lib.sdxp_last_error(a.h)
+        assert a.update_impl() == "graph"
+        np.testing.assert_array_equal(a.t["AC_PARAMS"].cpu().numpy(), p0.cpu().numpy())      # nothing applied
+        np.testing.assert_array_equal(a.t["MB_MUS"].cpu().numpy(), mus0.cpu().numpy())        # inputs restored
+        np.testing.assert_array_equal(a.t["CV_RMS_MEAN"].cpu().numpy(), rms0.cpu().numpy())
+        assert a.update_checked() == "graph"                                                   # the repeat
+        c.update(); torch.cuda.synchronize()
+        assert a.ctrl().ac_t == c.ctrl().ac_t == 5 * (n * 8 // 4)
+        np.testing.assert_allclose(a.ctrl().sum_a_loss, c.ctrl().sum_a_loss, rtol=2e-3, atol=1e-4)
+        move = float((c.t["AC_PARAMS"] - p0).abs().max())
+        assert float((a.t["AC_PARAMS"] - c.t["AC_PARAMS"]).abs().max()) < 0.05 * move
+        np.testing.assert_allclose(a.t["CV_RMS_MEAN"].cpu().numpy(), c.t["CV_RMS_MEAN"].cpu().numpy(), rtol=1e-6, atol=1e-7)
+    finally:
+        a.close(); c.close()
