@@ -158,6 +158,7 @@ class A2CAgent:
                     ppo.backward_factors(mb)
                     dist.all_gather_into_tensor(fact_all, fact)
                     ppo.apply_factors()
+            ppo.update_status()
             return
         ppo.backward(0, -1)
         if "ALL_GRADS" in ppo.t:

@@ -26,7 +26,8 @@ int sdxpk_persist_supported(const SdxpDev*, int, int);
 int sdxpk_backward_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_grads_from_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_apply_factors(const SdxpDev*, int, hipStream_t);
-int sdxpk_update_persistent(const SdxpDev*, int, unsigned*, unsigned*, hipStream_t);
+int sdxpk_update_persistent(const SdxpDev*, int, unsigned, unsigned*, hipStream_t);
+int sdxpk_fwd_bwd_persistent(const SdxpDev*, unsigned, unsigned*, hipStream_t);
 int sdxpk_prenorm(const SdxpDev*, int, hipStream_t);
 void sdxpk_apply_explicit(const SdxpDev*, int, float, int, hipStream_t);
 }
@@ -44,6 +45,9 @@ struct sdxp_agent {
   int graph_chunk = 0;
   bool use_persist = false;      // persistent register-resident update kernel (sdxp_persist.hip)
   unsigned* bar_dev = nullptr;   // [64] grid-barrier counter (+ fail flag at [32])
+  unsigned ll_tag = 0;           // last exchange tag handed to a persistent launch (tags only grow: the buffer is never cleared)
+  bool last_was_step = false;    // the most recent persistent launch was a single forward/backward (no restore possible on failure)
+  bool use_persist_step = false; // multi-rank path: forward/backward of one minibatch as one persistent-style launch
   unsigned* fail_host = nullptr; // pinned mirror of the fail flag, refreshed after every persistent update
   // what a persistent update touches before it can fail (old mu/sigma rows, running mean/std, control block): saved at the start
   // of the call so that sdxp_update_status can put it back and the caller can repeat the epoch on the hipGraph path
@@ -215,7 +219,10 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     hipDeviceProp_t prop;
     PCHK(h, hipGetDeviceProperties(&prop, device));
     const char* impl = getenv("SDXP_UPDATE_IMPL");   // "persist" (default when supported) | "graph"
-    h->use_persist = sdxpk_persist_supported(&D, cfg->minibatch, prop.multiProcessorCount) && !(impl && std::string(impl) == "graph");
+    const bool supported = sdxpk_persist_supported(&D, cfg->minibatch, prop.multiProcessorCount);
+    h->use_persist = supported && !(impl && std::string(impl) == "graph");
+    const char* simpl = getenv("SDXP_STEP_IMPL");   // multi-rank path: "kernels" forces the multi-kernel forward/backward
+    h->use_persist_step = supported && !(simpl && std::string(simpl) == "kernels");
     PCHK(h, hipHostMalloc((void**)&h->fail_host, sizeof(unsigned), hipHostMallocDefault));
     *h->fail_host = 0;
   }
@@ -361,7 +368,10 @@ extern "C" int sdxp_update(sdxp_handle h, void* stream) {
   hipLaunchKernelGGL(k_ctrl_begin_epoch, dim3(1), dim3(1), 0, st, h->D.ctrl);
   if (h->use_persist) {
     sdxpk_prenorm(&h->D, MB, st);
-    if (sdxpk_update_persistent(&h->D, (int)total, h->bar_dev, h->bar_dev + 32, st) != 0) { h->err = "persistent update launch failed"; return SDX_ERR_HIP; }
+    const unsigned tag_base = h->ll_tag;
+    h->ll_tag += (unsigned)total + 2u;
+    h->last_was_step = false;
+    if (sdxpk_update_persistent(&h->D, (int)total, tag_base, h->bar_dev + 32, st) != 0) { h->err = "persistent update launch failed"; return SDX_ERR_HIP; }
     PCHK(h, hipMemcpyAsync(h->fail_host, h->bar_dev + 32, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return plaunch_ok(h, "sdxp_update(persistent)");
   }
@@ -417,6 +427,13 @@ extern "C" int sdxp_backward_factors(sdxp_handle h, int32_t mb, void* stream) {
   if (MB != 2 && MB != 4 && MB != 8) { h->err = "sdxp_backward_factors: minibatch_size must be 2/4/8"; return SDX_ERR_INVALID; }
   if (mb < 0) return sdxp_backward(h, 0, -1, stream);
   if (mb >= h->D.num_minibatches) { h->err = "sdxp_backward_factors: minibatch index out of range"; return SDX_ERR_INVALID; }
+  if (h->use_persist_step) {   // one launch: forward + backward on 256 CUs with tagged-word exchange, factors straight into D.fact
+    const unsigned tag_base = h->ll_tag;
+    h->ll_tag += 3u;
+    h->last_was_step = true;
+    if (sdxpk_fwd_bwd_persistent(&h->D, tag_base, h->bar_dev + 32, st) != 0) { h->err = "persistent forward/backward launch failed"; return SDX_ERR_HIP; }
+    return plaunch_ok(h, "sdxp_backward_factors(persistent)");
+  }
   sdxpk_backward_factors(&h->D, MB, st);
   return plaunch_ok(h, "sdxp_backward_factors");
 }
@@ -447,7 +464,18 @@ extern "C" int sdxp_update_status(sdxp_handle h, void* stream) {
   if (!h) return SDX_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   PCHK(h, hipStreamSynchronize(st));
-  if (!h->fail_host || !*h->fail_host) return SDX_OK;
+  if (!h->fail_host) return SDX_OK;
+  PCHK(h, hipMemcpy(h->fail_host, h->bar_dev + 32, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (!*h->fail_host) return SDX_OK;
+  if (h->last_was_step) {   // multi-rank path: a forward/backward launch gave up; its factors were garbage and may have been applied
+    *h->fail_host = 0;
+    h->use_persist_step = false;
+    PCHK(h, hipMemset(h->bar_dev, 0, 256));
+    h->err = "sdxp_backward_factors: a persistent forward/backward launch timed out waiting for an exchange word (not all 256 "
+             "workgroups co-resident?); at least one optimiser step of this epoch used invalid factors; this handle now uses the "
+             "multi-kernel forward/backward - restore a checkpoint";
+    return SDX_ERR_STATE;
+  }
   *h->fail_host = 0;
   h->use_persist = false;
   const size_t ra = (size_t)h->D.N * h->D.horizon * h->D.act_dim * sizeof(float), sd = (size_t)h->D.state_dim * sizeof(double);

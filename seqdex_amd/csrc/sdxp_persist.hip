@@ -195,7 +195,12 @@ __device__ __forceinline__ const float* cvx_rows(const SdxpDev& D, int mb, int m
   return (mini_epoch == 0 ? D.cvx0 : D.cvx1) + (size_t)mb * MB * ST;
 }
 
-__global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int total_steps, unsigned* bar, unsigned* failflag, int stamps, int fault) {
+// SINGLE = false: the whole update phase of an epoch (above).  SINGLE = true: forward + backward of ONE minibatch (the one the
+// device cursor SdxpCtrl.mb_index points at) with the current parameters; no optimiser state is touched, the rank-MB factors
+// are written to D.fact for the multi-rank exchange and the cursor / loss statistics advance as k_ctrl does in explicit mode.
+template <bool SINGLE>
+__global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int total_steps, unsigned* bar, unsigned* failflag, int stamps, int fault,
+                                                              unsigned tag_base) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   PLds& S = *reinterpret_cast<PLds*>(smem_raw);
   // Thread coordinates are re-derived from an opaque copy of threadIdx/blockIdx at the start of every phase (refresh()):
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
   // publishes the new weight in the parameter array; phase D of every CU reads the whole head matrix back through L2.
   float hw = 0.0f, hm = 0.0f, hv = 0.0f;
 
+  auto ldm = [&](const float* p, size_t o) -> float { return SINGLE ? 0.0f : p[o]; };   // Adam moments: not needed for one forward/backward
   auto P_of = [&](int net) -> float* { return net == 2 ? D.cv : D.ac; };
   auto M_of = [&](int net) -> float* { return net == 2 ? D.cv_m : D.ac_m; };
   auto V_of = [&](int net) -> float* { return net == 2 ? D.cv_v : D.ac_v; };
@@ -250,64 +256,64 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     const int kk = lane + 64 * i, k = h0 * H0A + kk;
     const bool ok = kk < H0A;
     const size_t oa = woff(0, 0) + (size_t)n0 * OBS + k, oc = woff(1, 0) + (size_t)n0 * OBS + k;
-    w0a[i] = ok ? D.ac[oa] : 0.0f; m0a[i] = ok ? D.ac_m[oa] : 0.0f; v0a[i] = ok ? D.ac_v[oa] : 0.0f;
-    w0c[i] = ok ? D.ac[oc] : 0.0f; m0c[i] = ok ? D.ac_m[oc] : 0.0f; v0c[i] = ok ? D.ac_v[oc] : 0.0f;
+    w0a[i] = ok ? D.ac[oa] : 0.0f; m0a[i] = ok ? ldm(D.ac_m, oa) : 0.0f; v0a[i] = ok ? ldm(D.ac_v, oa) : 0.0f;
+    w0c[i] = ok ? D.ac[oc] : 0.0f; m0c[i] = ok ? ldm(D.ac_m, oc) : 0.0f; v0c[i] = ok ? ldm(D.ac_v, oc) : 0.0f;
   }
 #pragma unroll
   for (int i = 0; i < I0V; ++i) {
     const int kk = lane + 64 * i, k = h0 * H0V + kk;
     const bool ok = kk < H0V;
     const size_t o = woff(2, 0) + (size_t)n0 * ST + k;
-    w0v[i] = ok ? D.cv[o] : 0.0f; m0v[i] = ok ? D.cv_m[o] : 0.0f; v0v[i] = ok ? D.cv_v[o] : 0.0f;
+    w0v[i] = ok ? D.cv[o] : 0.0f; m0v[i] = ok ? ldm(D.cv_m, o) : 0.0f; v0v[i] = ok ? ldm(D.cv_v, o) : 0.0f;
   }
 #pragma unroll
   for (int net = 0; net < 3; ++net) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t o = woff(net, 1) + (size_t)r1 * U0 + q1 * 256 + lane + 64 * i;
-      w1[net][i] = P_of(net)[o]; m1[net][i] = M_of(net)[o]; v1[net][i] = V_of(net)[o];
+      w1[net][i] = P_of(net)[o]; m1[net][i] = ldm(M_of(net), o); v1[net][i] = ldm(V_of(net), o);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const size_t o = woff(net, 1) + (size_t)tid * U0 + 4 * g + c;
-      c1[net][c] = P_of(net)[o]; cm1[net][c] = M_of(net)[o]; cv1[net][c] = V_of(net)[o];
+      c1[net][c] = P_of(net)[o]; cm1[net][c] = ldm(M_of(net), o); cv1[net][c] = ldm(V_of(net), o);
     }
     {
       const size_t o = woff(net, 2) + (size_t)g * U1 + wave * 64 + lane;
-      w2[net] = P_of(net)[o]; m2[net] = M_of(net)[o]; v2[net] = V_of(net)[o];
+      w2[net] = P_of(net)[o]; m2[net] = ldm(M_of(net), o); v2[net] = ldm(V_of(net), o);
     }
     {
       const size_t o = woff(net, 2) + (size_t)c2n * U1 + 2 * g + c2c;
-      c2[net] = P_of(net)[o]; cm2[net] = M_of(net)[o]; cv2[net] = V_of(net)[o];
+      c2[net] = P_of(net)[o]; cm2[net] = ldm(M_of(net), o); cv2[net] = ldm(V_of(net), o);
     }
   }
   if (tid < HPC) {
     const int net = head_net(hrow);
     const size_t o = head_woff(hrow) + hk;
-    hw = P_of(net)[o]; hm = M_of(net)[o]; hv = V_of(net)[o];
+    hw = P_of(net)[o]; hm = ldm(M_of(net), o); hv = ldm(V_of(net), o);
   }
   // biases + logstd (LDS, one thread each)
   __shared__ float s_b2[3][32];     // logstd value, m, v
   if (tid < 12) {   // bias slot map: L0 net*4 + row (12), L1 12 + net*2 + row (6), L2 18 + net (3), heads 21 + row (25)
     const int net = tid / 4, w = tid % 4;
     const size_t o = boff(net, 0) + 4 * g + w;
-    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = M_of(net)[o]; S.bias_v[tid] = V_of(net)[o];
+    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = ldm(M_of(net), o); S.bias_v[tid] = ldm(V_of(net), o);
   } else if (tid < 18) {
     const int net = (tid - 12) / 2, r = (tid - 12) % 2;
     const size_t o = boff(net, 1) + 2 * g + r;
-    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = M_of(net)[o]; S.bias_v[tid] = V_of(net)[o];
+    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = ldm(M_of(net), o); S.bias_v[tid] = ldm(V_of(net), o);
   } else if (tid < 21) {
     const int net = tid - 18;
     const size_t o = boff(net, 2) + g;
-    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = M_of(net)[o]; S.bias_v[tid] = V_of(net)[o];
+    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = ldm(M_of(net), o); S.bias_v[tid] = ldm(V_of(net), o);
   } else if (tid < 21 + A + 2) {
     const int row = tid - 21, net = head_net(row);
     const size_t o = head_boff(row);
-    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = M_of(net)[o]; S.bias_v[tid] = V_of(net)[o];
+    S.bias[tid] = P_of(net)[o]; S.bias_m[tid] = ldm(M_of(net), o); S.bias_v[tid] = ldm(V_of(net), o);
   } else if (tid >= 64 && tid < 64 + A) {
     const int a = tid - 64;
     const size_t o = D.off.logstd + a;
-    s_b2[0][a] = D.ac[o]; s_b2[1][a] = D.ac_m[o]; s_b2[2][a] = D.ac_v[o];
+    s_b2[0][a] = D.ac[o]; s_b2[1][a] = ldm(D.ac_m, o); s_b2[2][a] = ldm(D.ac_v, o);
   }
   // replicated control state (every CU runs the same state machine on identical inputs)
   SdxpCtrl* gctl = D.ctrl;
@@ -327,8 +333,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     if (fault && g == NWG - 1 && step == 3) return;   // SDXP_PERSIST_FAULT=1 (tests): one CU goes silent, the others must time out
     refresh();
     const bool last = step == total_steps;   // the extra iteration only applies the optimiser step of the final minibatch
-    const int mbi = step % D.num_minibatches, mini_epoch = step / D.num_minibatches;
-    const unsigned tag = (unsigned)step + 1u;   // tag of everything this step produces
+    const int mbi = SINGLE ? gctl->mb_index : step % D.num_minibatches, mini_epoch = SINGLE ? gctl->mini_epoch : step / D.num_minibatches;
+    // tag of everything this step produces / of what the previous step produced.  tag_base advances from launch to launch (the
+    // exchange buffer is never cleared), so a word left over from an earlier launch can never match
+    const unsigned tag = tag_base + (unsigned)step + 1u, tag_prev = tag_base + (unsigned)step;
     // prefetch this step's layer-0 inputs (dataset rows mb*MB .. +MB; lane k holds element k of the MB samples): the HBM latency
     // hides behind the norm / Adam work below
     float pf_o[MB], pf_c[2][MB];
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 #pragma unroll
         for (int h = 0; h < U0 / NTH; ++h) {
           float v[3 * MB];
-          if (!ll_gather<3 * MB>(LL + LL_DY0 + tid + NTH * h, U0, (unsigned)step, v, failflag)) S.fail = 1;
+          if (!ll_gather<3 * MB>(LL + LL_DY0 + tid + NTH * h, U0, tag_prev, v, failflag)) S.fail = 1;
 #pragma unroll
           for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], v[net * MB], v[net * MB + 1], v[net * MB + 2], v[net * MB + 3]);
         }
@@ -470,6 +478,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         ll_store(LL + LL_X1 + (size_t)(net * MB + s) * U0 + 4 * g + r, elu(y), tag);
       }
       TS(2)
+      if constexpr (!SINGLE) {
       // ---- in the shadow of the x1 exchange: Gram of the layer-0 inputs (from the prefetch registers)
       float p[22];
 #pragma unroll
@@ -480,6 +489,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       block_sum<22>(S, p, S.part, tid, wave, lane);
       if (tid < 16) { const float v = S.part[tri16(tid)]; S.gx[0][0][tid] = v; S.gx[1][0][tid] = v; }
       else if (tid >= 64 && tid < 80) S.gx[2][0][tid - 64] = S.part[11 + tri16(tid - 64)];
+      }
     }
     refresh();
     if (pending) {
@@ -558,6 +568,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         ll_store(LL + LL_X2 + (size_t)(net * MB + s) * U1 + 2 * g + r, elu(q[0] + q[1] + q[2] + q[3] + S.bias[12 + net * 2 + r]), tag);
       }
       TS(5)
+      if constexpr (!SINGLE) {
       // ---- (shadow of x2) Gram of x1
       float p[33];
 #pragma unroll
@@ -568,6 +579,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         for (int net = 0; net < 3; ++net) { const int k = tid + NTH * h; gram_acc(&p[net * 11], S.x1[net][0][k], S.x1[net][1][k], S.x1[net][2][k], S.x1[net][3][k]); }
       block_sum<33>(S, p, S.part, tid, wave, lane);
       if (tid < 48) S.gx[tid >> 4][1][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+      }
     }
     refresh();
     if (pending) {
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 #pragma unroll
         for (int s = 0; s < MB; ++s) gg += (hrow < A ? S.dmu[s][hrow] : S.dv[hrow - A][s]) * gs * S.x3[net][s][hk];
         adam1(hw, gg, hm, hv, lrb, isq);
-        ll_store(LL + LL_HW + he, hw, (unsigned)step);
+        ll_store(LL + LL_HW + he, hw, tag_prev);
       }
       if (tid >= 18 && tid < 21 + A + 2) {   // layer-2 and head biases
         int net; float gg = 0.0f;
@@ -666,6 +678,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       ll_store(LL + LL_X3 + (size_t)(net * MB + s) * U2 + g, elu(y), tag);
     }
     TS(8)
+    if constexpr (!SINGLE)
     {   // ---- (shadow of x3) Gram of x2
       float p[33];
 #pragma unroll
@@ -692,7 +705,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
           const float* hp = P_of(head_net(row)) + head_woff(row) + 4 * lane;
 #pragma unroll
           for (int e = 0; e < 4; ++e) wh[j][e] = hp[e];
-        } else if (!ll_gather<4>(LL + LL_HW + (size_t)row * U2 + 4 * lane, 1, (unsigned)step, wh[j], failflag)) S.fail = 1;
+        } else if (!ll_gather<4>(LL + LL_HW + (size_t)row * U2 + 4 * lane, 1, tag_prev, wh[j], failflag)) S.fail = 1;
       }
     }
 #pragma unroll
@@ -701,10 +714,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 #pragma unroll
       for (int j = 0; j < 13; ++j) { const int row = 13 * c2c + j; if (row < A + 2) wc[j] = P_of(head_net(row))[head_woff(row) + c2n]; }
     } else if (c2c == 0) {
-      if (!ll_gather<13>(LL + LL_HW + c2n, U2, (unsigned)step, wc, failflag)) S.fail = 1;
+      if (!ll_gather<13>(LL + LL_HW + c2n, U2, tag_prev, wc, failflag)) S.fail = 1;
     } else {
       float t[12];
-      if (!ll_gather<12>(LL + LL_HW + (size_t)13 * U2 + c2n, U2, (unsigned)step, t, failflag)) S.fail = 1;
+      if (!ll_gather<12>(LL + LL_HW + (size_t)13 * U2 + c2n, U2, tag_prev, t, failflag)) S.fail = 1;
 #pragma unroll
       for (int j = 0; j < 12; ++j) wc[j] = t[j];
     }
@@ -867,6 +880,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         if (kl < 0.5f * D.kl_threshold) C.ac_lr = fminf(C.ac_lr * 1.5f, 1e-2f);
       }
     }
+    if constexpr (!SINGLE) {
     {
       float p[33];
 #pragma unroll
@@ -905,6 +919,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
       __syncthreads();
     }
+    }
     TS(15)
     refresh();
     // ================================================================== phase E: gather dY1, backward L1
@@ -935,6 +950,46 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
     }
     TS(17)
+    if constexpr (SINGLE) {
+      // ---- hand the minibatch over to the multi-rank exchange: rank-MB factors -> D.fact (layout SdxpFactOff), CU g writes slice g
+      __syncthreads();
+      float* F = D.fact;
+      const int i = g * NTH + tid, stride = NWG * NTH;
+      for (int j = i; j < MB * OBS; j += stride) { const float v = (&S.obs[0][0])[j]; F[D.foff.x[0][0] + j] = v; F[D.foff.x[1][0] + j] = v; }
+      for (int j = i; j < MB * ST; j += stride) F[D.foff.x[2][0] + j] = (&S.cvx[0][0])[j];
+#pragma unroll
+      for (int net = 0; net < 3; ++net) {
+        for (int j = i; j < MB * U0; j += stride) F[D.foff.x[net][1] + j] = (&S.x1[net][0][0])[j];
+        for (int j = i; j < MB * U1; j += stride) { F[D.foff.x[net][2] + j] = (&S.x2[net][0][0])[j]; F[D.foff.dy[net][1] + j] = (&S.dy1[net][0][0])[j]; }
+        for (int j = i; j < MB * U2; j += stride) { F[D.foff.h[net] + j] = (&S.x3[net][0][0])[j]; F[D.foff.dy[net][2] + j] = (&S.dy2[net][0][0])[j]; }
+      }
+      if (i < 3 * MB * U0) {   // dY0: every CU produced four columns of it; the first 24 CUs collect the words
+        float v[1];
+        if (!ll_gather<1>(LL + LL_DY0 + i, 1, tag, v, failflag)) S.fail = 1;
+        F[D.foff.dy[i / (MB * U0)][0] + i % (MB * U0)] = v[0];
+      }
+      if (g == 0) {
+        if (tid < MB * 34) {
+          const int s = tid / 34, c = tid % 34;
+          F[D.foff.dh + tid] = c < A ? S.dmu[s][c] : (c == 32 ? S.dv[0][s] : (c == 33 ? S.dv[1][s] : 0.0f));
+        }
+        if (tid >= 192 && tid < 192 + 32) F[D.foff.dls + tid - 192] = tid - 192 < A ? S.dls[tid - 192] : 0.0f;
+        if (tid == 0) {   // what k_ctrl does after a minibatch in explicit (multi-rank) mode: statistics, KL words, cursor
+          const PLds::Ctl& C = S.ctl;
+          gctl->sum_a_loss += C.sum_a; gctl->sum_c_loss += C.sum_c; gctl->sum_b_loss += C.sum_b; gctl->sum_kl += C.sum_kl;
+          gctl->sum_cv_loss += C.sum_cv; gctl->sum_entropy += C.sum_ent; gctl->n_mb += 1; gctl->last_kl = C.last_kl;
+          gctl->ac_pending = 0; gctl->cv_pending = 0;
+          F[D.foff.kl] = C.last_kl; D.ac_g[D.g_tail] = C.last_kl;
+          gctl->prev_mb = gctl->mb_index; gctl->prev_mini_epoch = gctl->mini_epoch;
+          int mbn = gctl->mb_index + 1;
+          if (mbn >= D.num_minibatches) { mbn = 0; gctl->mini_epoch += 1; }
+          gctl->mb_index = mbn;
+          gctl->step += 1;
+        }
+      }
+      return;
+    }
+    if constexpr (!SINGLE)
     {   // ---- (shadow of dY0) Grams of dY1 and dY2
       float p[33];
 #pragma unroll
@@ -1035,17 +1090,29 @@ extern "C" int sdxpk_persist_supported(const SdxpDev* D, int minibatch, int n_cu
   return minibatch == MB && D->obs_dim == OBS && D->state_dim == ST && D->units[0] == U0 && D->units[1] == U1 &&
          D->units[2] == U2 && D->act_dim == ACT && n_cus >= NWG;
 }
-extern "C" int sdxpk_update_persistent(const SdxpDev* D, int total_steps, unsigned* bar, unsigned* failflag, hipStream_t st) {
+// tag_base: first exchange tag of this launch minus one; the caller advances it by total_steps + 2 per launch
+extern "C" int sdxpk_update_persistent(const SdxpDev* D, int total_steps, unsigned tag_base, unsigned* failflag, hipStream_t st) {
   static bool attr = false;
   static const int stamps = (getenv("SDXP_PERSIST_STAMPS") && getenv("SDXP_PERSIST_STAMPS")[0] == '1') ? 1 : 0;
   const char* fe = getenv("SDXP_PERSIST_FAULT");   // read per call: the failure-path test sets and clears it
   const int fault = (fe && fe[0] == '1') ? 1 : 0;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_persistent), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_persistent<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sizeof(PLds)) != hipSuccess) return -1;
     attr = true;
   }
-  if (hipMemsetAsync(bar, 0, 256, st) != hipSuccess) return -1;
-  hipLaunchKernelGGL(k_update_persistent, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, total_steps, bar, failflag, stamps, fault);
+  if (hipMemsetAsync(failflag, 0, sizeof(unsigned), st) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_update_persistent<false>, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, total_steps, nullptr, failflag, stamps, fault, tag_base);
+  return 0;
+}
+// forward + backward of the minibatch under the device cursor -> D.fact (multi-rank path); the fail flag is sticky (not cleared here)
+extern "C" int sdxpk_fwd_bwd_persistent(const SdxpDev* D, unsigned tag_base, unsigned* failflag, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_persistent<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(PLds)) != hipSuccess) return -1;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_update_persistent<true>, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, 1, nullptr, failflag, 0, 0, tag_base);
   return 0;
 }

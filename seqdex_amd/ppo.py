@@ -111,6 +111,10 @@ class SdxPPO:
             self._check(self.lib.sdxp_update_status(self.h, _stream_ptr(self.device)))
         return self.update_impl()
 
+    def update_status(self):
+        """wait for the launched update / multi-rank steps; raises SdxError if a persistent launch could not run"""
+        self._check(self.lib.sdxp_update_status(self.h, _stream_ptr(self.device)))
+
     def update_impl(self):
         """'persistent' (one launch per epoch, register-resident weights) or 'graph' (hipGraph of the multi-kernel step)"""
         return "persistent" if self.lib.sdxp_update_impl(self.h) == 1 else "graph"

@@ -12,7 +12,7 @@ print('task create s', time.time()-t0)
 env=RLgamesVecTaskPython(task,'cuda:0')
 tr['params']['config'].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22)
 agent=A2CAgent('run', tr['params'])
-for ep in range(4):
+for ep in range(int(sys.argv[2]) if len(sys.argv)>2 else 4):
     r=agent.train_epoch()
     print('epoch',ep,'step %.4f play %.4f update %.4f total %.4f'%r[:4], 'a %.4f c %.4f kl %.5f lr %.2e'%(r[4][0],r[5][0],r[8][0],r[9]),
           'fps_step %.0f fps_total %.0f'%(n*8/r[0], n*8/r[3]), 'games', agent.game_rewards.get_mean(), agent.game_lengths.get_mean())
