@@ -137,6 +137,14 @@ def test_update_1024_persistent_deterministic_and_equal_to_graph_path():
         for k in ("AC_PARAMS", "CV_PARAMS"):
             assert bool(torch.isfinite(a.t[k]).all()) and bool(torch.isfinite(c.t[k]).all())
         np.testing.assert_allclose(a.t["CV_RMS_MEAN"].cpu().numpy(), c.t["CV_RMS_MEAN"].cpu().numpy(), rtol=1e-6, atol=1e-7)
+        # a second epoch on the same handles: the exchange buffer now holds the words of the first launch, which must never be
+        # mistaken for this launch's (tags grow across launches) - any such read would be timing dependent and break the equality
+        snap = {k: a.t[k].clone() for k in ("AC_PARAMS", "CV_PARAMS")}
+        a.update(); b.update()
+        torch.cuda.synchronize()
+        for k in ("AC_PARAMS", "CV_PARAMS", "AC_ADAM_M", "CV_ADAM_V", "MB_MUS"):
+            np.testing.assert_array_equal(a.t[k].cpu().numpy(), b.t[k].cpu().numpy(), err_msg="epoch 2 " + k)
+        assert float((a.t["CV_PARAMS"] - snap["CV_PARAMS"]).abs().max()) > 1e-4
     finally:
         a.close(); b.close(); c.close()
 
