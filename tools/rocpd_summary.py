@@ -13,8 +13,8 @@ with open(out, "w", newline="") as f:
         for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
             w.writerow([name.split("(")[0][:80], calls, "%.1f" % total, "%.2f" % avg, "%.3f" % pct])
     else:
-        w.writerow(["kernel", "counter", "dispatches", "avg_value", "min_value", "max_value", "avg_duration_us"])
-        q = ("select kernel_name,counter_name,count(*),avg(value),min(value),max(value),avg(duration) from counters_collection "
-             "group by 1,2 order by 4 desc")
-        for name, cn, n, a, lo, hi, d in c.execute(q):
-            w.writerow([name.split("(")[0][:80], cn, n, "%.1f" % a, "%.1f" % lo, "%.1f" % hi, "%.1f" % (d / 1e3)])
+        w.writerow(["kernel", "grid_size", "counter", "dispatches", "avg_value", "min_value", "max_value", "avg_duration_us"])
+        q = ("select kernel_name,grid_size,counter_name,count(*),avg(value),min(value),max(value),avg(duration) from counters_collection "
+             "group by 1,2,3 order by 1,2,3")
+        for name, gs, cn, n, a, lo, hi, d in c.execute(q):
+            w.writerow([name.split("(")[0][:80], gs, cn, n, "%.1f" % a, "%.1f" % lo, "%.1f" % hi, "%.1f" % (d / 1e3)])
