@@ -26,8 +26,8 @@ BYTES_PER_ENV_STEP = 18496     # algorithmic HBM bytes per env
 # separate runs of this same command at the default config; both counters are in KiB; FETCH_SIZE is reported raw - the guide's
 # x2 correction is calibrated for 16 B/lane streaming reads only, the exchange words here are 8 B/lane).  PMC counters cannot
 # be read from inside this process, so `traffic` is quoted from those files and is null for any other configuration.
-PMC_TRAFFIC_BYTES = {("k_update_persistent", 1024): (15711795.9 + 5536986.1) * 1024,     # profiles/r1_bench_pmc_{fetch,write}_v2.csv
-                     ("k_physics", 1024): (3321.1 + 21548.8) * 1024}   # the 40 dispatches with 1024 workgroups (grid 524288) only
+PMC_TRAFFIC_BYTES = {("k_update_persistent", 1024): (15700756.4 + 5536964.6) * 1024,     # profiles/r1_bench_pmc_{fetch,write}_v3.csv
+                     ("k_physics", 1024): (2848.9 + 16305.9) * 1024}   # the 40 dispatches with 1024 workgroups (grid 524288) only
 
 
 def parse():
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-envs", type=int, default=1024)
     ap.add_argument("--cpu-baseline-steps", type=int, default=16)
-    ap.add_argument("--cpu-baseline-ppo-envs", type=int, default=8, help="PPO leg: envs of the sample dataset (8 x horizon rows)")
+    ap.add_argument("--cpu-baseline-ppo-envs", type=int, default=128, help="PPO leg: envs of the sample dataset (x horizon rows; 128 -> 1280 optimiser steps, a few seconds)")
     return ap.parse_args()
 
 
