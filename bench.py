@@ -191,7 +191,7 @@ def main():
     else:
         upd_launch_ms = upd_t / args.steps * 1e3
         kname = ("k_layer/k_head/k_back/k_ctrl hipGraph (per epoch: %d optimiser steps, 3 networks)" % nsteps if impl == "graph" else
-                 "k_layer/k_head/k_back + k_pack_factors + RCCL all-gather of the rank-MB factors + k_grad_all_w/k_sqnorm2/k_adam2 "
+                 "k_update_persistent<SINGLE> (forward/backward of one minibatch) + RCCL all-gather of the rank-MB factors + k_grad_all_w/k_sqnorm2/k_adam2 "
                  "(per epoch: %d optimiser steps)" % nsteps)
         launches = nsteps
     upd_ms_step = upd_launch_ms / nsteps
