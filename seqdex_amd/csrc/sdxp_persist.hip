@@ -99,7 +99,8 @@ struct PLds {
 // overwritten before every CU has consumed it ("persistent update kernel").
 typedef unsigned long long u64;
 constexpr size_t LL_X1 = 0, LL_X2 = LL_X1 + 3 * MB * U0, LL_X3 = LL_X2 + 3 * MB * U1, LL_DY1 = LL_X3 + 3 * MB * U2,
-                 LL_DY0 = LL_DY1 + 3 * MB * U1, LL_HW = LL_DY0 + 3 * MB * U0, LL_END = LL_HW + (ACT + 2) * U2;
+                 LL_DY0 = LL_DY1 + 3 * MB * U1, LL_HW = LL_DY0 + 3 * MB * U0, LL_G0 = LL_HW + (ACT + 2) * U2,
+                 LL_END = LL_G0 + 32 * NWG;   // LL_G0: [30 Gram entries (net, lower triangle)][CU]: every CU's share of dY0 dY0^T
 static_assert(LL_END <= SDXP_LL_WORDS, "exchange buffer too small");
 __device__ __forceinline__ void ll_store(u64* p, float v, unsigned tag) {
   __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -352,21 +353,24 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     }
     // ================================================================== phase A: gradient norm, Adam of layer 0, forward L0
     if (pending) {
-      // squared-norm Gram of dY0 (all CUs' columns; produced by the previous step, tag == step)
+      // squared-norm Gram of dY0: every CU published the 4x4 Gram of ITS four columns per net (30 numbers) at the end of the
+      // previous step; thread (entry v, lane c16 of its 16-lane row) adds the shares of CUs c16, c16 + 16, ..., a DPP row reduction does the rest
       {
-        float p[33];
+        const int v = tid >> 4, c16 = tid & 15;
+        float t = 0.0f;
+        if (v < 30) {
+          float w[16];
+          // lane c16 takes CUs c16, c16 + 16, ...: the 16 lanes of a row read 16 consecutive words per load (coalesced)
+          if (!ll_gather<16>(LL + LL_G0 + (size_t)v * NWG + c16, 16, tag_prev, w, failflag)) S.fail = 1;
 #pragma unroll
-        for (int i = 0; i < 33; ++i) p[i] = 0.0f;
-#pragma unroll
-        for (int h = 0; h < U0 / NTH; ++h) {
-          float v[3 * MB];
-          if (!ll_gather<3 * MB>(LL + LL_DY0 + tid + NTH * h, U0, tag_prev, v, failflag)) S.fail = 1;
-#pragma unroll
-          for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], v[net * MB], v[net * MB + 1], v[net * MB + 2], v[net * MB + 3]);
+          for (int j = 0; j < 16; ++j) t += w[j];
         }
-        block_sum<33>(S, p, S.part, tid, wave, lane);
-        if (tid < 48) S.gd[tid >> 4][0][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-        else if (tid >= 64 && tid < 67) S.bsq[tid - 64][0] = S.part[(tid - 64) * 11 + 10];
+        t = dpp_add<0xB1, 0xF>(t); t = dpp_add<0x4E, 0xF>(t); t = dpp_add<0x141, 0xF>(t); t = dpp_add<0x140, 0xF>(t);   // 16-lane row sums
+        if (v < 30 && c16 == 0) {
+          const int net = v / 10, e = v % 10;                     // e = hi (hi + 1) / 2 + lo
+          const int hi = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), lo = e - hi * (hi + 1) / 2;
+          S.gd[net][0][hi * 4 + lo] = t; S.gd[net][0][lo * 4 + hi] = t;
+        }
         __syncthreads();
       }
       if (wave == 0) {   // control block: |g|^2 = sum over layers of <Gd, Gx> + bias terms (+ heads, kept in n2h), then the step scalars
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
           const int net = lane >> 4, i = lane & 15;
 #pragma unroll
           for (int l = 0; l < 3; ++l) t += S.gd[net][l][i] * S.gx[net][l][i];
+          t += S.gd[net][0][i];   // layer-0 bias term |sum_s dY0_s|^2 = sum of all entries of the Gram
         }
         t = dpp_add<0xB1, 0xF>(t); t = dpp_add<0x4E, 0xF>(t); t = dpp_add<0x141, 0xF>(t); t = dpp_add<0x140, 0xF>(t);   // 16-lane row sums
         float n2[3];
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         if (lane == 0) {
           PLds::Ctl& C = S.ctl;
 #pragma unroll
-          for (int net = 0; net < 3; ++net) n2[net] += C.n2h[net] + S.bsq[net][0] + S.bsq[net][1] + S.bsq[net][2];
+          for (int net = 0; net < 3; ++net) n2[net] += C.n2h[net] + S.bsq[net][1] + S.bsq[net][2];
           C.ac_gn = sqrtf(n2[0] + n2[1]); C.cv_gn = sqrtf(n2[2]);
           S.scal[0] = D.truncate_grads ? fminf(1.0f, D.grad_norm / (C.ac_gn + 1e-6f)) : 1.0f;
           S.scal[1] = D.truncate_grads ? fminf(1.0f, D.grad_norm / (C.cv_gn + 1e-6f)) : 1.0f;
@@ -945,8 +950,23 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       if (tid < 48) {
         const int net = tid / 16, s = (tid / 4) % MB, c = tid % 4;
         const float v = S.part[tid] * elu_g(S.x1[net][s][4 * g + c]);
-        ll_store(LL + LL_DY0 + (size_t)(net * MB + s) * U0 + 4 * g + c, v, tag);
+        if constexpr (SINGLE) ll_store(LL + LL_DY0 + (size_t)(net * MB + s) * U0 + 4 * g + c, v, tag);
         S.dyown[net][s][c] = v;
+      }
+      if constexpr (!SINGLE) {
+        // the other CUs need dY0 only for the gradient norm: publish this CU's share of the Gram dY0 dY0^T (its four columns).
+        // Lanes 0..47 of wave 0 wrote dyown above; the same wave reads it back (LDS keeps program order within a wave)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid < 30) {
+          const int net = tid / 10, e = tid % 10;
+          const int hi = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), lo = e - hi * (hi + 1) / 2;
+          float gsum = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) gsum += S.dyown[net][hi][c] * S.dyown[net][lo][c];
+          ll_store(LL + LL_G0 + (size_t)tid * NWG + g, gsum, tag);
+        }
       }
     }
     TS(17)
