@@ -698,7 +698,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     TS(9)
     refresh();
     // ================================================================== phase D: gather x3 and the heads, losses, backward to dY1
-    float wh[HR][4];   // this wave's head rows for the forward (row = wave + 8 j, columns 4 lane .. 4 lane + 3)
+    float wh[HR][4];   // this wave's head rows for the forward (row = wave + 8 j, columns lane + 64 e)
     float wc[13];      // this lane's head column for the backward (column c2n, rows 13 c2c .. 13 c2c + 12)
 #pragma unroll
     for (int j = 0; j < HR; ++j) {
@@ -707,10 +707,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       for (int e = 0; e < 4; ++e) wh[j][e] = 0.0f;
       if (row < A + 2) {
         if (step == 0) {
-          const float* hp = P_of(head_net(row)) + head_woff(row) + 4 * lane;
+          const float* hp = P_of(head_net(row)) + head_woff(row) + lane;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) wh[j][e] = hp[e];
-        } else if (!ll_gather<4>(LL + LL_HW + (size_t)row * U2 + 4 * lane, 1, tag_prev, wh[j], failflag)) S.fail = 1;
+          for (int e = 0; e < 4; ++e) wh[j][e] = hp[64 * e];
+        } else if (!ll_gather<4>(LL + LL_HW + (size_t)row * U2 + lane, 64, tag_prev, wh[j], failflag)) S.fail = 1;   // lane-contiguous words
       }
     }
 #pragma unroll
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         for (int s = 0; s < MB; ++s) {
           float q = 0.0f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) q += wh[j][e] * S.x3[net][s][4 * lane + e];
+          for (int e = 0; e < 4; ++e) q += wh[j][e] * S.x3[net][s][lane + 64 * e];
           const float y = wave_sum(q) + S.bias[21 + row];
           if (lane == 0) { if (row < A) S.mu[s][row] = y; else S.val[row - A][s] = y; }
         }
