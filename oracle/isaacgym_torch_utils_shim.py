@@ -105,3 +105,16 @@ def tensor_clamp(t, min_t, max_t):
 def torch_rand_float(lower, upper, shape, device):
     # type: (float, float, Tuple[int, int], str) -> Tensor
     return (upper - lower) * torch.rand(*shape, device=device) + lower
+
+
+def quat_from_euler_xyz(roll, pitch, yaw):
+    """xyzw quaternion of the intrinsic z-y-x (yaw, pitch, roll) rotation; the standard half-angle product form that
+    isaacgym.torch_utils publishes (used by the Orient/Insert tasks: OR:1440,1669,1740)."""
+    cy, sy = torch.cos(yaw * 0.5), torch.sin(yaw * 0.5)
+    cr, sr = torch.cos(roll * 0.5), torch.sin(roll * 0.5)
+    cp, sp = torch.cos(pitch * 0.5), torch.sin(pitch * 0.5)
+    qw = cy * cr * cp + sy * sr * sp
+    qx = cy * sr * cp - sy * cr * sp
+    qy = cy * cr * sp + sy * sr * cp
+    qz = sy * cr * cp - cy * sr * sp
+    return torch.stack([qx, qy, qz, qw], dim=-1)

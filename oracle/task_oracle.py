@@ -273,3 +273,89 @@ def seg_index_for_env(i):
     """target brick = brick (i % 8) with {3,4,7} -> 0 (GS:962-965,974-975); actor index inside env = 9 + brick."""
     b = i % 8
     return 9 + (0 if b in (3, 4, 7) else b)
+
+
+# =================================================================== BlockAssemblyOrient (configs[2], SURVEY 8(f) rank 1)
+# OR = dexteroushandenvs/tasks/block_assembly/allegro_hand_block_assembly_orient.py.  The scene, the intermediate quantities of
+# compute_observations (OR:1087-1200 == GS:1090-1198) and the asymmetric state frame (OR:1244-1306 == GS:1220-1280) are shared
+# with GraspSim; what differs is restated here and pinned by tests/golden/O*.npz (oracle/gen_golden_orient.py).
+ORIENT_TARGET_EULER = np.array([0.0, 3.1415, 1.571], dtype=F)                                    # OR:477
+
+
+def quat_from_euler_xyz(roll, pitch, yaw):
+    """isaacgym.torch_utils.quat_from_euler_xyz (package absent; published half-angle product form): xyzw."""
+    cy, sy, cr, sr = np.cos(yaw * F(0.5)), np.sin(yaw * F(0.5)), np.cos(roll * F(0.5)), np.sin(roll * F(0.5))
+    cp, sp = np.cos(pitch * F(0.5)), np.sin(pitch * F(0.5))
+    return np.stack([cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp,
+                     cy * cr * cp + sy * sr * sp], axis=-1).astype(F)
+
+
+def orientation_error(desired, current):
+    """OR:1922-1925: vector part of desired * conj(current), sign-flipped into the w >= 0 hemisphere."""
+    q_r = quat_mul(desired, quat_conjugate(current))
+    return (q_r[:, 0:3] * np.sign(q_r[:, 3])[:, None]).astype(F)
+
+
+def orient_pre_physics_targets(actions, q, prev_targets, progress, init_pos, hand_pos, hand_rot, target_pos, J, lower, upper,
+                               target_euler=ORIENT_TARGET_EULER, act_moving_average=1.0):
+    """OR:1720-1778 (after any reset): fingers from the action, arm by damped-least-squares IK that TRACKS the target brick
+    (hand base held 0.22 above and 0.18 behind it, fixed wrist orientation); after step 75 the hand lifts towards
+    z_init + 0.39 and the fingers hold their previous targets."""
+    a = actions.astype(F)
+    N = a.shape[0]
+    cur = np.zeros_like(prev_targets, dtype=F)
+    cur[:, 7:23] = scale(a[:, 7:23], lower[7:23], upper[7:23])                                   # OR:1726-1728
+    cur[:, 7:23] = F(act_moving_average) * cur[:, 7:23] + F(1.0 - act_moving_average) * prev_targets[:, 7:23]
+    m0 = progress > 75                                                                           # OR:1731
+    pos_err = (target_pos - hand_pos).astype(F)                                                  # OR:1734
+    pos_err[:, 2] += F(0.22)                                                                     # OR:1735
+    pos_err[:, 0] -= F(0.18)                                                                     # OR:1736
+    lift = (init_pos[:, 2] - hand_pos[:, 2] + F(0.15) + F(0.24)).astype(F)                       # OR:1737
+    pos_err[m0, 2] = lift[m0]
+    te = np.broadcast_to(np.asarray(target_euler, dtype=F), (N, 3))
+    rot_err = orientation_error(quat_from_euler_xyz(te[:, 0], te[:, 1], te[:, 2]), hand_rot)     # OR:1740-1741
+    cur[:, :7] = q[:, :7] + control_ik(J, np.concatenate([pos_err, rot_err], axis=-1))           # OR:1743-1745
+    cur[m0, 7:23] = prev_targets[m0, 7:23]                                                       # OR:1746
+    return np.maximum(np.minimum(cur, upper), lower).astype(F)                                   # OR:1773-1776
+
+
+def orient_obs_frame(dof, actions, lower, upper):
+    """compute_real_observations OR:1308-1326: 62 numbers - finger joint positions (unscaled), 14 unused zeros, the action
+    minus the unscaled finger positions, the finger action.  NOT stacked: columns 62..185 of obs_buf stay zero in the reference."""
+    q = dof[..., 0]
+    o = np.zeros((q.shape[0], 62), dtype=F)
+    u = unscale(q[:, 7:23], lower[7:23], upper[7:23])
+    o[:, 0:16] = u
+    o[:, 30:46] = actions[:, 7:23] - u
+    o[:, 46:62] = actions[:, 7:23]
+    return o
+
+
+def orient_tvalue_gate(tvalue):
+    """OR:1203: the T-value is thresholded at 0.99 before anything uses it."""
+    return np.where(tvalue > F(0.99), F(1), F(0)).astype(F)
+
+
+def orient_hand_reward(target_pos, target_rot, ff, rf, mf, th, progress, reset_buf, cons_successes, successes,
+                       max_episode_length=150.0, av_factor=0.1, max_consecutive_successes=0, fall_penalty=0.0):
+    """compute_hand_reward OR:1843-1907: exp(-5 (1 - (z_align + 1)/2) - 5 max(d - 0.4, 0)) with d the thumb-weighted fingertip
+    distance (dropped after step 175); reset only on time-out."""
+    nrm = lambda v: np.linalg.norm(v.astype(F), axis=-1).astype(F)
+    N = target_pos.shape[0]
+    d = nrm(target_pos - ff) + nrm(target_pos - mf) + nrm(target_pos - rf) + F(3) * nrm(target_pos - th)   # OR:1853-1854
+    dot1 = quat_apply(target_rot, np.broadcast_to(np.array([0, 0, 1], dtype=F), (N, 3)))[:, 2]             # OR:1856-1859
+    z_align = (np.sign(dot1) * dot1 ** 2).astype(F)
+    resets = np.where(d <= -1, 1, reset_buf)                                                               # OR:1866
+    timed_out = progress >= max_episode_length - 1                                                         # OR:1868-1869
+    resets = np.where(timed_out, 1, resets)
+    d_rew = np.clip(d - F(0.4), 0, None).astype(F)                                                         # OR:1878
+    d_rew = np.where(progress > 175, F(0), d_rew)                                                          # OR:1879
+    z_rew = (F(1) - (z_align + F(1)) / F(2)).astype(F)                                                     # OR:1884
+    reward = np.exp(-(F(5) * z_rew + F(5) * d_rew)).astype(F)                                              # OR:1886
+    if max_consecutive_successes > 0:
+        reward = np.where(timed_out, reward + F(0.5 * fall_penalty), reward)                               # OR:1900-1901
+    num_resets = resets.sum()                                                                              # OR:1903-1906
+    fin = (successes * resets.astype(F)).sum()
+    cons = np.where(num_resets > 0, F(av_factor) * fin / max(num_resets, 1) + F(1.0 - av_factor) * cons_successes,
+                    cons_successes).astype(F)
+    return reward, resets.astype(np.int64), cons, z_align
