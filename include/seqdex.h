@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDX_ABI_VERSION 1
+#define SDX_ABI_VERSION 2
 
 /* ---- fixed scene dimensions of BlockAssemblyGraspSim (GS:523-1058) ---- */
 #define SDX_NLINK 24        /* robot bodies after collapse_fixed_joints (GS:543); body 0 is the fixed base  */
@@ -157,6 +157,10 @@ typedef struct {
   float baumgarte;                     /* position-error feedback factor  */
   float max_depenetration_vel;
   float jacobi_relax;                  /* relaxation on the mass-split Jacobi update */
+  /* which task's per-step tensor code the pre/post-physics kernels run: 0 = BlockAssemblyGraspSim (GS),
+   * 1 = BlockAssemblyOrient (OR = tasks/block_assembly/allegro_hand_block_assembly_orient.py; targets/IK OR:1720-1778) */
+  int32_t task_kind;
+  float target_euler[3];               /* Orient: fixed wrist orientation of the tracking IK, OR:477 */
 } sdx_scene_desc;
 
 typedef struct sdx_sim* sdx_handle;

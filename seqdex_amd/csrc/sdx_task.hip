@@ -90,16 +90,39 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
   __syncthreads();
   // dpose (GS:1594-1600), every lane computes it (uniform)
   float dp[6];
+  const bool orient = sc.task_kind == 1;
+  if (!orient) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    float ak = __shfl(a, k, SDX_WAVE);
-    dp[k] = ak * (k < 3 ? 0.64f : 0.2f);
-  }
-  if (m0) {
-    const float hz = B.rb[((size_t)e * SDX_BODIES + sc.hand_base_body) * 13 + 2];
-    dp[2] = 0.2f + 0.22f + (B.init_pos[e * 3 + 2] - hz);                          // GS:1596
-    dp[0] = 0.0f;
-    dp[1] = 0.0f;
+    for (int k = 0; k < 6; ++k) {
+      float ak = __shfl(a, k, SDX_WAVE);
+      dp[k] = ak * (k < 3 ? 0.64f : 0.2f);
+    }
+    if (m0) {
+      const float hz = B.rb[((size_t)e * SDX_BODIES + sc.hand_base_body) * 13 + 2];
+      dp[2] = 0.2f + 0.22f + (B.init_pos[e * 3 + 2] - hz);                          // GS:1596
+      dp[0] = 0.0f;
+      dp[1] = 0.0f;
+    }
+  } else {
+    // BlockAssemblyOrient, OR:1733-1743: object-centric tracking - the hand base is held 0.22 above / 0.18 behind the target
+    // brick with a fixed wrist orientation; after step 75 it lifts towards z_init + 0.39
+    const float* hb = B.rb + ((size_t)e * SDX_BODIES + sc.hand_base_body) * 13;
+    const float* tg = B.root + ((size_t)e * SDX_ACTORS + seg_actor(e)) * 13;
+    dp[0] = tg[0] - hb[0] - 0.18f;
+    dp[1] = tg[1] - hb[1];
+    dp[2] = tg[2] - hb[2] + 0.22f;
+    if (m0) dp[2] = B.init_pos[e * 3 + 2] - hb[2] + 0.15f + 0.24f;                  // OR:1737
+    // quat_from_euler_xyz(target_euler) (isaacgym.torch_utils; half-angle products), orientation_error OR:1922-1925
+    float sr, cr, sp, cp, sy, cy;
+    sincosf(0.5f * sc.target_euler[0], &sr, &cr);
+    sincosf(0.5f * sc.target_euler[1], &sp, &cp);
+    sincosf(0.5f * sc.target_euler[2], &sy, &cy);
+    f4 qd;
+    qd.x = cy * sr * cp - sy * cr * sp; qd.y = cy * cr * sp + sy * sr * cp; qd.z = sy * cr * cp - cy * sr * sp;
+    qd.w = cy * cr * cp + sy * sr * sp;
+    const f4 qr = qmul(qd, qconj(ld4(hb + 3)));
+    const float sg = qr.w > 0.0f ? 1.0f : (qr.w < 0.0f ? -1.0f : 0.0f);             // torch.sign
+    dp[3] = qr.x * sg; dp[4] = qr.y * sg; dp[5] = qr.z * sg;
   }
   // A = J J^T + 0.05^2 I (6x6 SPD), Cholesky solve A y = dpose (control_ik, GS:1796-1804)
   float A[6][6];
@@ -155,8 +178,8 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
 #pragma unroll
       for (int r = 0; r < 6; ++r) u += s_J[r * 7 + lane] * y[r];
       cur = B.dof[((size_t)e * SDX_NDOF + lane) * 2] + u;                         // GS:1602
-      if (m1) cur = sc.insert_pose_a[lane];                                       // GS:1604
-      if (m2) cur = sc.insert_pose_b[lane];                                       // GS:1605
+      if (m1 && !orient) cur = sc.insert_pose_a[lane];                            // GS:1604
+      if (m2 && !orient) cur = sc.insert_pose_b[lane];                            // GS:1605
     }
     cur = fmaxf(fminf(cur, hi), lo);                                              // tensor_clamp GS:1633-1635
     B.targets[(size_t)e * SDX_NDOF + lane] = cur;

@@ -121,8 +121,13 @@ class Scene:
         d.gravity[:] = self.sim["gravity"]
         d.friction, d.baumgarte = self.solver["friction"], self.solver["baumgarte"]
         d.max_depenetration_vel, d.jacobi_relax = self.solver["max_depenetration_vel"], self.solver["jacobi_relax"]
+        d.task_kind = 0                                   # BlockAssemblyGraspSim; 1 = BlockAssemblyOrient (per-step tensor code only)
+        d.target_euler[:] = [0.0, 3.1415, 1.571]          # OR:477
         for k_, v in overrides.items():
-            setattr(d, k_, v)
+            if hasattr(v, "__len__") and not isinstance(v, (str, bytes)):
+                getattr(d, k_)[:] = list(v)
+            else:
+                setattr(d, k_, v)
         return d
 
 
