@@ -117,6 +117,8 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   SdxBuf& B = h->buf;
   memset(&B, 0, sizeof(B));
   B.N = N;
+  B.task_kind = scene->task_kind;
+  B.obs_w = scene->task_kind == 1 ? 186 : SDX_NUM_OBS;
   B.K = 1;
   B.seed = seed;
 #define ALLOC(field, count) if ((rc = dalloc(h, &B.field, (size_t)(count))) != SDX_OK) { g_create_err = h->err; sdx_destroy(h); return rc; }
@@ -166,9 +168,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_JAC_EEF, B.jac, SDX_F32, {N, 6, 7});
   set_tensor(h, SDX_T_TARGETS, B.targets, SDX_F32, {N, SDX_NDOF});
   set_tensor(h, SDX_T_PREV_TARGETS, B.prev_targets, SDX_F32, {N, SDX_NDOF});
-  set_tensor(h, SDX_T_OBS, B.obs, SDX_F32, {N, SDX_NUM_OBS});
+  set_tensor(h, SDX_T_OBS, B.obs, SDX_F32, {N, B.obs_w});
   set_tensor(h, SDX_T_STATES, B.states, SDX_F32, {N, SDX_NUM_STATES});
-  set_tensor(h, SDX_T_OBS_CLAMPED, B.obs_c, SDX_F32, {N, SDX_NUM_OBS});
+  set_tensor(h, SDX_T_OBS_CLAMPED, B.obs_c, SDX_F32, {N, B.obs_w});
   set_tensor(h, SDX_T_STATES_CLAMPED, B.states_c, SDX_F32, {N, SDX_NUM_STATES});
   set_tensor(h, SDX_T_REW, B.rew, SDX_F32, {N});
   set_tensor(h, SDX_T_RESET, B.reset, SDX_I64, {N});

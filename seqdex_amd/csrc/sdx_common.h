@@ -26,6 +26,8 @@ struct SdxConst {
 struct SdxBuf {
   int32_t N;
   int32_t K;               // saved piles per brick type
+  int32_t obs_w;           // row width of obs / obs_c: 396 (GraspSim, 3 x 132) or 186 (Orient, 62 + 124 never-written zeros)
+  int32_t task_kind;       // copy of sdx_scene_desc.task_kind for kernels that do not take the constants
   uint64_t seed;
   float *root, *dof, *rb, *contact, *jac, *targets, *prev_targets;
   float *obs, *states, *obs_c, *states_c, *rew;

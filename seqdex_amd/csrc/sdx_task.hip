@@ -321,8 +321,19 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
   // ---- 3-frame stacking (GS:1330-1332, 1278-1280): new = [frame, old[0:w], old[w:2w]]; rows are read fully
   // before they are written (one wave owns the row), then written lane-strided together with the clamped copies
   {
-    float* o = B.obs + (size_t)e * SDX_NUM_OBS;
-    float* oc = B.obs_c + (size_t)e * SDX_NUM_OBS;
+    float* o = B.obs + (size_t)e * B.obs_w;
+    float* oc = B.obs_c + (size_t)e * B.obs_w;
+    if (sc.task_kind == 1) {
+      // BlockAssemblyOrient, compute_real_observations OR:1308-1326: 62 numbers, NOT stacked (columns 62..185 are never written)
+      if (lane < 62) {
+        float v = 0.0f;
+        if (lane < 16) v = s_o[lane];                                             // unscaled finger joint positions
+        else if (lane >= 30 && lane < 46) v = s_act[7 + lane - 30] - s_o[lane - 30];   // action - unscaled position, OR:1322-1324
+        else if (lane >= 46) v = s_act[7 + lane - 46];                            // OR:1326
+        o[lane] = v;
+        oc[lane] = clampf(v, -sc.clip_obs, sc.clip_obs);
+      }
+    } else {
     float hist[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
@@ -341,6 +352,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
       const float v = s_o[c];
       o[c] = v;
       oc[c] = clampf(v, -sc.clip_obs, sc.clip_obs);
+    }
     }
     float* s = B.states + (size_t)e * SDX_NUM_STATES;
     float* stc = B.states_c + (size_t)e * SDX_NUM_STATES;
@@ -366,17 +378,27 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
   }
   if (!(flags & 1)) return;
 
-  // ---- compute_hand_reward (GS:1706-1776)
+  // ---- compute_hand_reward (GS:1706-1776 / OR:1843-1907)
   if (lane == 0) {
-    const float d = nff + nmf + nrf + 3.0f * nth;                                 // GS:1740-1741
+    const float d = nff + nmf + nrf + 3.0f * nth;                                 // GS:1740-1741, OR:1853-1854
     long resets = (long)B.reset[e];                                               // GS:1727 (d <= -1 never holds)
     const bool timed_out = (float)prog >= sc.max_episode_length - 1.0f;           // GS:1729
     if (timed_out) resets = 1;
-    const float dist_rew = expf(-2.0f * fmaxf(d - 0.5f, 0.0f)) * 0.1f;            // GS:1742
-    float up = clampf(tpos.z - s_init[2], 0.0f, 0.2f) * 100.0f;                   // GS:1744
-    up = fminf(d < 0.5f ? up : 0.0f, 20.0f);                                      // GS:1745
-    const float reward = dist_rew + up;                                           // GS:1751
-    if (prog >= 75 && d >= 0.6f) resets = 1;                                      // GS:1754-1755
+    float reward;
+    if (sc.task_kind == 1) {
+      // Orient: exp(-5 (1 - (z_align + 1) / 2) - 5 max(d - 0.4, 0)), distance term dropped after step 175; time-out is the only
+      // reset (max_consecutive_successes = 0 in the shipped config, so the fall-penalty term OR:1900-1901 is inactive)
+      const float dot1 = qrot(trot, F3(0.0f, 0.0f, 1.0f)).z;                      // OR:1856-1859
+      const float z_align = (dot1 > 0.0f ? 1.0f : (dot1 < 0.0f ? -1.0f : 0.0f)) * dot1 * dot1;
+      const float d_rew = prog > 175 ? 0.0f : fmaxf(d - 0.4f, 0.0f);              // OR:1878-1879
+      reward = expf(-(5.0f * (1.0f - (z_align + 1.0f) * 0.5f) + 5.0f * d_rew));   // OR:1884-1886
+    } else {
+      const float dist_rew = expf(-2.0f * fmaxf(d - 0.5f, 0.0f)) * 0.1f;          // GS:1742
+      float up = clampf(tpos.z - s_init[2], 0.0f, 0.2f) * 100.0f;                 // GS:1744
+      up = fminf(d < 0.5f ? up : 0.0f, 20.0f);                                    // GS:1745
+      reward = dist_rew + up;                                                     // GS:1751
+      if (prog >= 75 && d >= 0.6f) resets = 1;                                    // GS:1754-1755
+    }
     B.rew[e] = reward;
     B.reset[e] = resets;
     B.meta_rew[e] += reward;                                                      // GS:1069
@@ -455,7 +477,11 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
     float y = b4[1];
     for (int k = 0; k < 64; ++k) y += W4[k * 2 + 1] * s_h3[t][k];
     y = elu1(y);
-    if (e0 + t < B.N) B.tvalue[e0 + t] = 1.0f / (1.0f + expf(-y));
+    if (e0 + t < B.N) {
+      float tvv = 1.0f / (1.0f + expf(-y));
+      if (B.task_kind == 1) tvv = tvv > 0.99f ? 1.0f : 0.0f;                      // Orient gates the T-value at 0.99, OR:1203
+      B.tvalue[e0 + t] = tvv;
+    }
   }
   if (finalize_stats && blockIdx.x == 0 && t == 0) {
     // cons_successes EMA (GS:1771-1774) from the per-step sums gathered by k_post_physics

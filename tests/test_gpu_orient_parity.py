@@ -48,3 +48,54 @@ def test_orient_pre_physics_golden(orient16, golden_dir, scene, phase):
     want = T.orient_pre_physics_targets(f[p + "actions"], f[p + "q"], f[p + "prev_targets"], f[p + "progress"], f[p + "init_pos"],
                                         f[p + "hand_pos"], f[p + "hand_rot"], f[p + "target_pos"], f[p + "J"], f["lower"], f["upper"])
     np.testing.assert_allclose(s.TARGETS.cpu().numpy(), want, rtol=2e-4, atol=1e-4)                       # and the oracle's
+
+
+def test_orient_observations_golden(orient16, golden_dir):
+    f = np.load(os.path.join(golden_dir, "O3_observations.npz"))
+    s = orient16
+    assert tuple(s.OBS.shape) == (16, 186) and tuple(s.STATES.shape) == (16, 564)        # 62 x 3 / 188 x 3 (OR:191-207)
+    s.set_tvalue_weights({k[3:]: f[k] for k in f.files if k.startswith("tv_")})
+    s.OBS.zero_(); s.STATES.zero_()
+    s.INIT_POS.copy_(_dev(f["init_pos"]))
+    s.INIT_ROT.copy_(_dev(f["init_rot"]))
+    for c in range(3):
+        p = "c%d_" % c
+        s.ROOT.copy_(_dev(f[p + "root"]))
+        s.RB.copy_(_dev(f[p + "rb"]))
+        s.DOF.copy_(_dev(f[p + "dof"]).view(-1, 2))
+        s.CONTACT.copy_(_dev(f[p + "contact"]))
+        s.ACTIONS.copy_(_dev(f[p + "actions"]))
+        s.compute_observations()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(s.OBS.cpu().numpy(), f[p + "obs_buf"], rtol=3e-5, atol=3e-5)     # 62 numbers, never stacked
+        np.testing.assert_allclose(s.STATES.cpu().numpy(), f[p + "states_buf"], rtol=3e-5, atol=3e-5)
+        np.testing.assert_array_equal(s.OBS_CLAMPED.cpu().numpy(), np.clip(s.OBS.cpu().numpy(), -5, 5))
+        np.testing.assert_allclose(s.FINGER_DIST.cpu().numpy(), f[p + "finger_dist"], rtol=3e-5, atol=3e-5)
+        np.testing.assert_array_equal(s.TVALUE.cpu().numpy(), f[p + "tvalue"])                     # gated at 0.99 (OR:1203)
+
+
+def test_orient_reward_golden(golden_dir):
+    from seqdex_amd.sim import SdxSim
+    f = np.load(os.path.join(golden_dir, "O5_reward.npz"))
+    m = f["progress"].shape[0]
+    s = SdxSim(m, device="cuda:0", task_kind=1, max_episode_length=float(f["max_episode_length"]))
+    try:
+        root = s.ROOT.view(m, 142, 13)
+        seg = torch.tensor([s.scene.seg_index(i) for i in range(m)]).cuda()
+        ar = torch.arange(m).cuda()
+        root[ar, seg, 0:3] = _dev(f["target_pos"])
+        root[ar, seg, 3:7] = _dev(f["target_rot"])
+        for body, key in zip(s.scene.fingertip_bodies, ["ff", "mf", "rf", "th"]):
+            s.RB[:, body, 0:3] = _dev(f[key] - np.array([0, 0, 0.04], np.float32))
+            s.RB[:, body, 3:7] = torch.tensor([0.0, 0, 0, 1]).cuda()
+        s.PROGRESS.copy_(_dev(f["progress"] - 1))        # post_physics_step increments first
+        s.RESET.copy_(_dev(f["reset_buf"]))
+        s.SUCCESSES.copy_(_dev(f["successes"]))
+        s.CONS_SUCCESSES.copy_(_dev(f["cons_in"]))
+        s.post_physics()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(s.REW.cpu().numpy(), f["reward"], rtol=3e-5, atol=3e-6)
+        np.testing.assert_array_equal(s.RESET.cpu().numpy(), f["resets"])
+        np.testing.assert_allclose(s.CONS_SUCCESSES.cpu().numpy(), f["cons_out"], rtol=1e-6)
+    finally:
+        s.close()
