@@ -161,6 +161,7 @@ typedef struct {
    * 1 = BlockAssemblyOrient (OR = tasks/block_assembly/allegro_hand_block_assembly_orient.py; targets/IK OR:1720-1778) */
   int32_t task_kind;
   float target_euler[3];               /* Orient: fixed wrist orientation of the tracking IK, OR:477 */
+  float seg_mass_scale;                /* mass (and inertia) factor of each env's target brick: 1 (GS:980-981), 50 in Orient (OR:977) */
 } sdx_scene_desc;
 
 typedef struct sdx_sim* sdx_handle;

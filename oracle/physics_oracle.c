@@ -114,6 +114,7 @@ typedef struct {
   real lam[SDXO_MAXC][3], w[SDXO_MAXC][2][3]; /* w[c][side][row]: un-split inverse effective mass */
   unsigned char active[SDXO_MAXC];
   int overflow;
+  int seg_brick; /* this env's target brick: mass and inertia scaled by sc->seg_mass_scale */
 } env_t;
 
 typedef struct { v3 c; q4 q; v3 h; } box_t;
@@ -374,7 +375,8 @@ static real brick_w(const sdx_scene_desc* sc, const env_t* e, int i, v3 p, v3 d)
   v3 rxd = vcross(vsub(p, e->bp[i]), d);
   v3 l = qrot(qconj(e->bq[i]), rxd);
   const float* I = sc->brick_inertia[t];
-  return 1.0f / sc->brick_mass[t] + l.x * l.x / I[0] + l.y * l.y / I[1] + l.z * l.z / I[2];
+  real w = 1.0f / sc->brick_mass[t] + l.x * l.x / I[0] + l.y * l.y / I[1] + l.z * l.z / I[2];
+  return i == e->seg_brick ? w / sc->seg_mass_scale : w;
 }
 
 static real robot_w(const env_t* e, int k, v3 p, v3 d) {
@@ -464,10 +466,11 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
         if (id == BODY_STATIC) continue;
         if (id < NF) {
           int t = sc->brick_type[id];
-          e->dv[id] = vadd(e->dv[id], vscale(Ps, 1.0f / sc->brick_mass[t]));
+          real isc = id == e->seg_brick ? 1.0f / sc->seg_mass_scale : 1.0f;
+          e->dv[id] = vadd(e->dv[id], vscale(Ps, isc / sc->brick_mass[t]));
           v3 l = qrot(qconj(e->bq[id]), vcross(vsub(p, e->bp[id]), Ps));
           const float* I = sc->brick_inertia[t];
-          e->dw[id] = vadd(e->dw[id], qrot(e->bq[id], V(l.x / I[0], l.y / I[1], l.z / I[2])));
+          e->dw[id] = vadd(e->dw[id], vscale(qrot(e->bq[id], V(l.x / I[0], l.y / I[1], l.z / I[2])), isc));
         } else {
           int k = id - NF;
           for (int j = 0; j < ND; ++j)
@@ -495,7 +498,8 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
 }
 
 /* ---------------------------------------------------------------- one env, one step */
-static void load_env(const sdx_scene_desc* sc, env_t* e, const float* root, const float* dof, const float* targets) {
+static void load_env(const sdx_scene_desc* sc, env_t* e, int env_index, const float* root, const float* dof, const float* targets) {
+  { int b = env_index & 7; e->seg_brick = (b == 3 || b == 4 || b == 7) ? 0 : b; } /* GS:962-965,974-975 */
   for (int j = 0; j < ND; ++j) {
     e->q[j] = dof[2 * j];
     e->qd[j] = dof[2 * j + 1];
@@ -612,7 +616,7 @@ void sdxo_simulate(const sdx_scene_desc* sc, int N, float* root, float* dof, con
       float* r = root + (size_t)n * SDX_ACTORS * 13;
       float* d = dof + (size_t)n * ND * 2;
       e->overflow = 0;
-      load_env(sc, e, r, d, targets + (size_t)n * ND);
+      load_env(sc, e, n, r, d, targets + (size_t)n * ND);
       for (int s = 0; s < sc->substeps; ++s) substep(sc, e, h, s == 0);
       store_env(sc, e, h, r, d, rb + (size_t)n * SDX_BODIES * 13, contact + (size_t)n * SDX_BODIES * 3,
                 jac + (size_t)n * 42, ncontacts ? ncontacts + n : NULL);
@@ -659,7 +663,7 @@ void sdxo_mass_matrix(const sdx_scene_desc* sc, const float* q, float h, float* 
 int sdxo_contacts(const sdx_scene_desc* sc, const float* root_env, const float* dof_env, float* out, int cap) {
   env_t* e = (env_t*)calloc(1, sizeof(env_t));
   float tg[ND] = {0};
-  load_env(sc, e, root_env, dof_env, tg);
+  load_env(sc, e, 0, root_env, dof_env, tg);
   fk(sc, e);
   collide(sc, e);
   int n = e->nc < cap ? e->nc : cap;

@@ -44,7 +44,7 @@ class SceneDesc(C.Structure):
         ("clip_obs", f32), ("clip_actions", f32),
         ("dt", f32), ("substeps", i32), ("solver_iters", i32), ("contact_offset", f32), ("gravity", f32 * 3),
         ("friction", f32), ("baumgarte", f32), ("max_depenetration_vel", f32), ("jacobi_relax", f32),
-        ("task_kind", i32), ("target_euler", f32 * 3),
+        ("task_kind", i32), ("target_euler", f32 * 3), ("seg_mass_scale", f32),
     ]
 
 

@@ -15,6 +15,8 @@ void sdxk_pre_physics(const SdxConst*, const SdxBuf*, const float*, const uint8_
 void sdxk_post_physics(const SdxConst*, const SdxBuf*, int, hipStream_t);
 void sdxk_physics(const SdxConst*, const SdxBuf*, hipStream_t);
 void sdxk_kinematics(const SdxConst*, const SdxBuf*, hipStream_t);
+void sdxk_orient_pregrasp(const SdxConst*, const SdxBuf*, const uint8_t*, int, int, hipStream_t);
+void sdxk_orient_post_reset(const SdxConst*, const SdxBuf*, const uint8_t*, hipStream_t);
 }
 
 struct sdx_sim {
@@ -22,6 +24,7 @@ struct sdx_sim {
   SdxConst* d_const = nullptr;
   SdxConst h_const;
   SdxBuf buf;
+  uint8_t* orient_mask = nullptr;   // device copy of the reset flags of an Orient reset event
   std::vector<void*> allocs;
   struct TensorInfo { void* ptr; int64_t shape[4]; int ndim; int dtype; } tinfo[SDX_T_COUNT];
   bool has_piles = false;
@@ -319,9 +322,45 @@ extern "C" int sdx_compute_observations(sdx_handle h, void* stream) {
   sdxk_post_physics(h->d_const, &h->buf, 0, (hipStream_t)stream);
   return check_launch(h, "sdx_compute_observations");
 }
+// BlockAssemblyOrient reset (OR:1390-1695).  Like the reference (reset_buf.nonzero()) this reads the reset flags on the host; a reset
+// event costs 50 (only when steps have been taken) + 2 + 1 + 50 simulator steps of ALL envs, during which the resetting envs' arms
+// are scripted by the tracking IK.  The shipped task only resets on time-out, so all envs reset together every episodeLength steps.
+static int orient_reset_if_needed(sdx_handle h, hipStream_t st) {
+  const int N = h->buf.N;
+  std::vector<int64_t> flags(N);
+  HIPCHK(h, hipMemcpyAsync(flags.data(), h->buf.reset, sizeof(int64_t) * N, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  std::vector<uint8_t> mask(N);
+  int any = 0;
+  for (int i = 0; i < N; ++i) { mask[i] = flags[i] != 0; any |= mask[i]; }
+  if (!any) return SDX_OK;
+  if (!h->orient_mask) { HIPCHK(h, hipMalloc((void**)&h->orient_mask, N)); h->allocs.push_back(h->orient_mask); }
+  HIPCHK(h, hipMemcpyAsync(h->orient_mask, mask.data(), N, hipMemcpyHostToDevice, st));
+  uint32_t steps = 0;
+  HIPCHK(h, hipMemcpyAsync(&steps, h->buf.step_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (steps > 0)
+    for (int i = 0; i < 50; ++i) { sdxk_orient_pregrasp(h->d_const, &h->buf, h->orient_mask, 0, i, st); sdxk_physics(h->d_const, &h->buf, st); }
+  sdxk_pre_physics(h->d_const, &h->buf, nullptr, h->orient_mask, nullptr, 2, st);      // restore piles, hand to the prepare pose, counters
+  sdxk_physics(h->d_const, &h->buf, st);
+  sdxk_physics(h->d_const, &h->buf, st);                                               // OR:1618-1620
+  sdxk_orient_post_reset(h->d_const, &h->buf, h->orient_mask, st);
+  sdxk_physics(h->d_const, &h->buf, st);                                               // OR:1653
+  for (int i = 0; i < 50; ++i) { sdxk_orient_pregrasp(h->d_const, &h->buf, h->orient_mask, 1, i, st); sdxk_physics(h->d_const, &h->buf, st); }
+  return check_launch(h, "sdx_step(orient reset)");
+}
+
 extern "C" int sdx_step(sdx_handle h, const float* actions_dev, void* stream) {
   if (!h || !actions_dev) return SDX_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
+  if (h->h_const.sc.task_kind == 1) {
+    const int rc = orient_reset_if_needed(h, st);
+    if (rc != SDX_OK) return rc;
+    sdxk_pre_physics(h->d_const, &h->buf, actions_dev, nullptr, nullptr, 4, st);
+    sdxk_physics(h->d_const, &h->buf, st);
+    sdxk_post_physics(h->d_const, &h->buf, 1, st);
+    return check_launch(h, "sdx_step");
+  }
   sdxk_pre_physics(h->d_const, &h->buf, actions_dev, nullptr, nullptr, 1 | 4, st);
   sdxk_physics(h->d_const, &h->buf, st);   // controlFrequencyInv = 1 (EG:18)
   sdxk_post_physics(h->d_const, &h->buf, 1, st);

@@ -42,6 +42,7 @@ struct PhysLds {
   int wsum[NWAVE];       // per-wave totals for block-level scans
   float cf[NL][3];
   int nrobot;            // contact rows touching the robot in this substep
+  int seg_brick;         // this env's target brick (its mass and inertia carry sc.seg_mass_scale)
   float sincos[NL][2];   // sin/cos of half the joint angle, computed for all joints at once
   // contact staging [8][SDX_MAXC] written by the narrowphase (ab, p3, n3, sep); after the rows are in registers the
   // same area is reused by the solver for the per-contact impulse P (3) and moment p x P (3)
@@ -168,7 +169,8 @@ __device__ __forceinline__ float brick_w(const SdxConst* C, const PhysLds& S, in
   const f3 rxd = cross(p - ld3(S.bp[i]), d);
   const f3 l = qrot(qconj(ld4(S.bq[i])), rxd);
   const float* I = sc.brick_inertia[t];
-  return 1.0f / sc.brick_mass[t] + l.x * l.x / I[0] + l.y * l.y / I[1] + l.z * l.z / I[2];
+  const float w = 1.0f / sc.brick_mass[t] + l.x * l.x / I[0] + l.y * l.y / I[1] + l.z * l.z / I[2];
+  return i == S.seg_brick ? w / sc.seg_mass_scale : w;
 }
 
 // ---------------------------------------------------------------- A: FK (level-parallel over the tree)
@@ -713,8 +715,9 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
         const f3 tau = sm - cross(x, sp);
         const f3 l = qrot(qconj(qq), tau);
         const float* I = sc.brick_inertia[t];
-        const f3 dw = qrot(qq, F3(l.x / I[0], l.y / I[1], l.z / I[2]));
-        const float im = 1.0f / sc.brick_mass[t];
+        const float isc = gbrick == S.seg_brick ? 1.0f / sc.seg_mass_scale : 1.0f;
+        const f3 dw = qrot(qq, F3(l.x / I[0], l.y / I[1], l.z / I[2])) * isc;
+        const float im = isc / sc.brick_mass[t];
         st3(S.bv[gbrick], ld3(S.bv[gbrick]) + sp * im);
         st3(S.bw[gbrick], ld3(S.bw[gbrick]) + dw);
       }
@@ -826,6 +829,7 @@ __global__ __launch_bounds__(NT, 2) void k_physics(const SdxConst* __restrict__ 
   const float h = sc.dt / (float)sc.substeps;
 
   // ---- load per-env state (coalesced rows) into LDS
+  if (tid == 0) S.seg_brick = seg_actor(e) - SDX_ACTOR_BRICK0;
   if (tid < ND) {
     S.q[tid] = B.dof[((size_t)e * ND + tid) * 2];
     S.qd[tid] = B.dof[((size_t)e * ND + tid) * 2 + 1];

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
   if (do_reset) {  // wave-uniform branch
     // terminal-state harvesting (GS:1398-1442): a finished episode whose target brick was carried over the base plate
     // (y < 0) with the fingers still around it and an accepting T-value is stored in the ring buffer of its type group
-    if (B.step_count[0] > 0) {                                                     // `if self.total_steps > 0`
+    if (B.step_count[0] > 0 && sc.task_kind == 0) {                                // `if self.total_steps > 0`; GraspSim's rule only
       const float* tg = root_e + seg_actor(e) * 13;
       if (tg[1] < 0.0f && B.finger_dist[e] < 0.6f && B.tvalue[e] > 0.8f) {         // GS:1404-1406
         int slot = 0;
@@ -496,6 +496,121 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
 }
 
 // ------------------------------------------------------------------------------------------------ host launchers
+// ------------------------------------------------------------------------------------------------ BlockAssemblyOrient reset
+// The Orient task scripts the arm with the tracking IK of its pre_physics_step while the simulator runs 50 steps, twice per reset:
+//   mode 0 (OR:1427-1461, before the states are restored, only when total_steps > 0): hand base to 0.42 above / 0.18 behind the
+//          target brick's CURRENT position, targets clamped to the joint limits, finger targets = their values at loop entry - 0.01;
+//   mode 1 (OR:1655-1695, after the restore): hand base to 0.22 (+0.2 during the first 20 iterations) above / 0.18 behind the
+//          target brick's INITIAL position, no clamp, fingers at the reset pose.
+// Only envs with mask != 0 receive targets (set_dof_position_target_tensor_indexed with the resetting hands).
+__global__ __launch_bounds__(SDX_WAVE) void k_orient_pregrasp(const SdxConst* __restrict__ C, SdxBuf B, const uint8_t* __restrict__ mask,
+                                                              int mode, int iter) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (!mask[e]) return;
+  const sdx_scene_desc& sc = C->sc;
+  __shared__ float s_J[42];
+  if (lane < 42) s_J[lane] = B.jac[(size_t)e * 42 + lane];
+  __syncthreads();
+  const float* hb = B.rb + ((size_t)e * SDX_BODIES + sc.hand_base_body) * 13;
+  float dp[6];
+  if (mode == 0) {
+    const float* tg = B.root + ((size_t)e * SDX_ACTORS + seg_actor(e)) * 13;
+    dp[0] = tg[0] - hb[0] - 0.18f; dp[1] = tg[1] - hb[1]; dp[2] = tg[2] - hb[2] + 0.42f;          // OR:1436-1438
+  } else {
+    dp[0] = B.init_pos[e * 3 + 0] - hb[0] - 0.18f; dp[1] = B.init_pos[e * 3 + 1] - hb[1];
+    dp[2] = B.init_pos[e * 3 + 2] - hb[2] + 0.22f + (iter < 20 ? 0.2f : 0.0f);                   // OR:1662-1667
+  }
+  float sr, cr, sp, cp, sy, cy;
+  sincosf(0.5f * sc.target_euler[0], &sr, &cr);
+  sincosf(0.5f * sc.target_euler[1], &sp, &cp);
+  sincosf(0.5f * sc.target_euler[2], &sy, &cy);
+  f4 qd;
+  qd.x = cy * sr * cp - sy * cr * sp; qd.y = cy * cr * sp + sy * sr * cp; qd.z = sy * cr * cp - cy * sr * sp;
+  qd.w = cy * cr * cp + sy * sr * sp;
+  const f4 qr = qmul(qd, qconj(ld4(hb + 3)));
+  const float sg = qr.w > 0.0f ? 1.0f : (qr.w < 0.0f ? -1.0f : 0.0f);
+  dp[3] = qr.x * sg; dp[4] = qr.y * sg; dp[5] = qr.z * sg;
+  // control_ik (OR:1927-1935): A = J J^T + 0.05^2 I, Cholesky, y = A^-1 dpose, u = J^T y
+  float A[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      float acc = (r == c) ? 0.05f * 0.05f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc += s_J[r * 7 + k] * s_J[c * 7 + k];
+      A[r][c] = acc;
+    }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    d = sqrtf(d);
+    A[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float acc = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) acc -= A[i][k] * A[j][k];
+      A[i][j] = acc / d;
+    }
+  }
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float acc = dp[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) acc -= A[i][k] * y[k];
+    y[i] = acc / A[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float acc = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) acc -= A[k][i] * y[k];
+    y[i] = acc / A[i][i];
+  }
+  if (lane < SDX_NDOF) {
+    float cur;
+    if (lane < 7) {
+      float u = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) u += s_J[r * 7 + lane] * y[r];
+      cur = B.dof[((size_t)e * SDX_NDOF + lane) * 2] + u;
+      if (mode == 0) cur = fmaxf(fminf(cur, sc.upper[lane]), sc.lower[lane]);                    // OR:1448-1450
+    } else if (mode == 0) {
+      // prev_targets holds the finger targets at loop entry (cur_targets_clone, OR:1429,1452-1453)
+      cur = B.prev_targets[(size_t)e * SDX_NDOF + lane] - 0.01f;
+    } else {
+      cur = C->hand_reset_pose[lane];                                                            // OR:1678-1683
+    }
+    B.targets[(size_t)e * SDX_NDOF + lane] = cur;
+    if (mode == 1 || lane < 7) B.prev_targets[(size_t)e * SDX_NDOF + lane] = cur;               // OR:1685 / OR:1453 keeps the clone
+  }
+}
+// after the restore and two simulator steps (OR:1618-1646): the target brick's settled pose becomes the episode's initial pose and
+// the hand is put back to the prepare pose with zero velocity
+__global__ __launch_bounds__(SDX_WAVE) void k_orient_post_reset(const SdxConst* __restrict__ C, SdxBuf B, const uint8_t* __restrict__ mask) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (!mask[e]) return;
+  const float* tg = B.root + ((size_t)e * SDX_ACTORS + seg_actor(e)) * 13;
+  if (lane < 3) B.init_pos[e * 3 + lane] = tg[lane];                                            // OR:1627
+  if (lane < 4) B.init_rot[e * 4 + lane] = tg[3 + lane];                                        // OR:1628
+  if (lane < SDX_NDOF) {
+    const float hp = C->hand_reset_pose[lane];
+    B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 0] = hp;                                          // OR:1635-1646
+    B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 1] = 0.0f;
+    B.prev_targets[(size_t)e * SDX_NDOF + lane] = hp;
+    B.targets[(size_t)e * SDX_NDOF + lane] = hp;
+  }
+}
+extern "C" void sdxk_orient_pregrasp(const SdxConst* C, const SdxBuf* B, const uint8_t* mask, int mode, int iter, hipStream_t st) {
+  hipLaunchKernelGGL(k_orient_pregrasp, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, mask, mode, iter);
+}
+extern "C" void sdxk_orient_post_reset(const SdxConst* C, const SdxBuf* B, const uint8_t* mask, hipStream_t st) {
+  hipLaunchKernelGGL(k_orient_post_reset, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, mask);
+}
 extern "C" void sdxk_pre_physics(const SdxConst* C, const SdxBuf* B, const float* actions, const uint8_t* mask,
                                  const int32_t* choice, int flags, hipStream_t st) {
   hipLaunchKernelGGL(k_pre_physics, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, actions, mask, choice, flags);

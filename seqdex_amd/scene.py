@@ -123,6 +123,7 @@ class Scene:
         d.max_depenetration_vel, d.jacobi_relax = self.solver["max_depenetration_vel"], self.solver["jacobi_relax"]
         d.task_kind = 0                                   # BlockAssemblyGraspSim; 1 = BlockAssemblyOrient (per-step tensor code only)
         d.target_euler[:] = [0.0, 3.1415, 1.571]          # OR:477
+        d.seg_mass_scale = 1.0                            # GS:980-981 (x1); Orient x50 (OR:977)
         for k_, v in overrides.items():
             if hasattr(v, "__len__") and not isinstance(v, (str, bytes)):
                 getattr(d, k_)[:] = list(v)

@@ -12,6 +12,13 @@ from ..sim import SdxSim
 
 
 class BlockAssemblyGraspSim:
+    TASK_KIND = 0                     # sdx_scene_desc.task_kind
+    ONE_FRAME_NUM_OBS = _abi.OBS_FRAME
+
+    def _scene_overrides(self, scene):
+        """task-specific entries of sdx_scene_desc (hook for the other BlockAssembly* tasks)"""
+        return {}
+
     def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True,
                  agent_index=None, is_multi_agent=False, seed=22, initial_piles=None, piles_per_type=8):
         self.cfg = cfg
@@ -19,11 +26,11 @@ class BlockAssemblyGraspSim:
         self.num_envs = env["numEnvs"]
         self.max_episode_length = env["episodeLength"]                       # GS:147
         self.stack_obs = 3                                                    # GS:189
-        self.one_frame_num_obs, self.one_frame_num_states = _abi.OBS_FRAME, _abi.STATE_FRAME   # GS:207-208
-        cfg["env"]["numObservations"] = _abi.NUM_OBS                          # GS:209-211
+        self.one_frame_num_obs, self.one_frame_num_states = self.ONE_FRAME_NUM_OBS, _abi.STATE_FRAME   # GS:207-208
+        cfg["env"]["numObservations"] = self.ONE_FRAME_NUM_OBS * self.stack_obs   # GS:209-211
         cfg["env"]["numStates"] = _abi.NUM_STATES
         cfg["env"]["numActions"] = _abi.NUM_ACTIONS
-        self.num_obs, self.num_states, self.num_actions = _abi.NUM_OBS, _abi.NUM_STATES, _abi.NUM_ACTIONS
+        self.num_obs, self.num_states, self.num_actions = self.ONE_FRAME_NUM_OBS * self.stack_obs, _abi.NUM_STATES, _abi.NUM_ACTIONS
         self.control_freq_inv = env.get("controlFrequencyInv", 1)
         if device_type not in ("cuda", "GPU"):
             raise RuntimeError("seqdex_amd runs the task on the GPU only (no CPU pipeline; see DESIGN.md §5)")
@@ -40,7 +47,11 @@ class BlockAssemblyGraspSim:
             overrides["contact_offset"] = float(px["contact_offset"])
         overrides["max_episode_length"] = float(self.max_episode_length)
         overrides["act_moving_average"] = float(env.get("actionsMovingAverage", 1.0))
-        self.sim = SdxSim(self.num_envs, device=self.device, seed=seed, **overrides)
+        from ..scene import load_scene
+        scene = load_scene()
+        overrides["task_kind"] = self.TASK_KIND
+        overrides.update(self._scene_overrides(scene))
+        self.sim = SdxSim(self.num_envs, device=self.device, seed=seed, scene=scene, **overrides)
         s = self.sim
         # buffers of BaseTask (BT:57-69) are zero-copy views of library-owned memory
         self.obs_buf, self.states_buf = s.OBS, s.STATES
