@@ -237,6 +237,8 @@ typedef struct {
   int32_t adaptive_lr;       /* 1: lr_schedule adaptive, schedule_type legacy (YG:53, PS:306-312) */
   int32_t world_size;        /* data-parallel ranks; gradients are averaged by the CALLER (RCCL) between
                                 sdxp_backward_* and sdxp_apply_* when world_size > 1 */
+  int32_t obs_cols;          /* columns of the caller's observation rows if fewer than obs_dim (0 = obs_dim): the network input is
+                                zero-padded to obs_dim, which must be a multiple of 4 (BlockAssemblyOrient: 186 -> 188) */
 } sdxp_config;
 
 typedef enum {

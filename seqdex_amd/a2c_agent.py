@@ -48,7 +48,10 @@ class A2CAgent:
         # time that path on a single-GPU box)
         self.multi_gpu = self.rank_size > 1 or (cfg.get("multi_gpu", False) and os.environ.get("SDX_FORCE_MULTI_RANK") == "1")
         seed = int(cfg.get("seed", 22)) + self.rank                    # per-rank seed = seed + rank (App. C)
-        self.ppo = SdxPPO(self.num_actors, params=params, device=self.ppo_device, seed=seed, world_size=self.rank_size)
+        obs_dim = int(self.env_info["observation_space"].shape[0])        # 396 GraspSim, 186 Orient
+        state_dim = int(self.env_info["state_space"].shape[0]) if "state_space" in self.env_info else None
+        self.ppo = SdxPPO(self.num_actors, params=params, device=self.ppo_device, seed=seed, world_size=self.rank_size,
+                          obs_dim=obs_dim, state_dim=state_dim)
         self.has_central_value = True
         self.is_tensor_obses = True
         self.frame, self.epoch_num = 0, 0

@@ -11,8 +11,10 @@ import numpy as np
 import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-TASK_CFG = {"BlockAssemblyGraspSim": "cfg/allegro_hand_block_assembly_grasp_sim.yaml"}                      # CF:63-64
-TRAIN_CFG = {"BlockAssemblyGraspSim": "cfg/lego/ppo_continuous_grasp.yaml"}                                 # TR:44-47
+TASK_CFG = {"BlockAssemblyGraspSim": "cfg/allegro_hand_block_assembly_grasp_sim.yaml",                      # CF:63-64
+            "BlockAssemblyOrient": "cfg/allegro_hand_block_assembly_orient.yaml"}                               # CF:75-76
+TRAIN_CFG = {"BlockAssemblyGraspSim": "cfg/lego/ppo_continuous_grasp.yaml",                                 # TR:44-47
+             "BlockAssemblyOrient": "cfg/lego/ppo_continuous_grasp.yaml"}
 
 
 def get_args(argv=None):

@@ -23,6 +23,7 @@ int sdxpk_update_begin(const SdxpDev*, int, hipStream_t);
 int sdxpk_update_flush_layers(const SdxpDev*, int, hipStream_t);
 int sdxpk_backward_explicit(const SdxpDev*, int, hipStream_t);
 int sdxpk_persist_supported(const SdxpDev*, int, int);
+void sdxpk_pad_obs(const SdxpDev*, const float*, hipStream_t);
 int sdxpk_backward_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_grads_from_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_apply_factors(const SdxpDev*, int, hipStream_t);
@@ -113,6 +114,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     gp_create_err = "sdxp_create: the fused update needs equal minibatch_size / mini_epochs for actor-critic and central value";
     return SDX_ERR_INVALID;
   }
+  if (cfg->obs_cols < 0 || cfg->obs_cols > cfg->obs_dim) { gp_create_err = "sdxp_create: obs_cols must be in [0, obs_dim]"; return SDX_ERR_INVALID; }
   if (cfg->units[2] != 256 || cfg->units[0] % 4 || cfg->units[1] % 4 || cfg->act_dim > 32 || cfg->obs_dim % 4 || cfg->state_dim % 4) {
     gp_create_err = "sdxp_create: unsupported network shape"; return SDX_ERR_INVALID;
   }
@@ -175,6 +177,8 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   PAL(D.cvx0, R * cfg->state_dim); PAL(D.cvx1, R * cfg->state_dim);
   PAL(D.dbg, 64); PAL(D.dhead, (size_t)2 * MB * 34); PAL(D.dlogstd, 64); PAL(D.ctrl, 1); PAL(h->stats_dev, 16);
   PAL(h->bar_dev, 64); PAL(D.ll, SDXP_LL_WORDS);
+  D.obs_cols = cfg->obs_cols > 0 ? cfg->obs_cols : cfg->obs_dim;
+  PAL(D.obs_pad, (size_t)N * cfg->obs_dim);
   PAL(h->mus_bak, R * cfg->act_dim); PAL(h->sig_bak, R * cfg->act_dim); PAL(h->rms_bak, (size_t)2 * cfg->state_dim); PAL(h->ctrl_bak, 1);
   {   // factor exchange buffers of the multi-rank path
     uint32_t o = 0;
@@ -319,6 +323,7 @@ extern "C" int sdxp_act(sdxp_handle h, int32_t t, const float* obs_dev, const fl
   if (!h || !obs_dev || !states_dev || !actions_out_dev || t < 0 || t >= h->D.horizon) { if (h) h->err = "sdxp_act: bad argument"; return SDX_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   if (t == 0) hipLaunchKernelGGL(k_ctrl_begin_rollout, dim3(1), dim3(1), 0, st, h->D.ctrl);
+  if (h->D.obs_cols != h->D.obs_dim) { sdxpk_pad_obs(&h->D, obs_dev, st); obs_dev = h->D.obs_pad; }
   trunk_forward(h, 0, obs_dev, h->D.N, st);
   trunk_forward(h, 2, states_dev, h->D.N, st);
   sdxpk_act_heads(&h->D, t, obs_dev, states_dev, dones_dev, eps_dev, actions_out_dev, h->act_counter++, st);

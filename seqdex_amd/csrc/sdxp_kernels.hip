@@ -1182,6 +1182,17 @@ static void launch_step(const SdxpDev* D, hipStream_t st) {
   hipLaunchKernelGGL(k_ctrl<MB>, dim3(1), dim3(1024), 0, st, *D, 1 | 2);
 }
 #define MB_SWITCH(mb, CALL) switch (mb) { case 2: { CALL(2); return 0; } case 4: { CALL(4); return 0; } case 8: { CALL(8); return 0; } default: return -1; }
+// observation rows narrower than the (4-aligned) network input: zero-padded copy
+__global__ __launch_bounds__(256) void k_pad_obs(SdxpDev D, const float* __restrict__ obs) {
+  const size_t total = (size_t)D.N * D.obs_dim;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % D.obs_dim);
+    D.obs_pad[i] = c < D.obs_cols ? obs[(i / D.obs_dim) * D.obs_cols + c] : 0.0f;
+  }
+}
+extern "C" void sdxpk_pad_obs(const SdxpDev* D, const float* obs, hipStream_t st) {
+  hipLaunchKernelGGL(k_pad_obs, dim3(256), dim3(256), 0, st, *D, obs);
+}
 extern "C" int sdxpk_update_step(const SdxpDev* D, int mb_size, hipStream_t st) {
 #define C_(M) launch_step<M>(D, st)
   MB_SWITCH(mb_size, C_)

@@ -67,6 +67,8 @@ struct SdxpDev {
   SdxpFactOff foff;
   float *fact, *fact_all; // [foff.total] this rank's factors; [world][foff.total] all ranks' (all-gathered by the caller)
   int32_t world;
+  int32_t obs_cols;      // columns of the caller's observation rows (<= obs_dim); obs_pad [N, obs_dim] holds the zero-padded copy
+  float* obs_pad;
   float* sqn_part;       // [512] block partials of the deterministic gradient-norm reduction
   size_t g_tail;         // ALL_GRADS = [ac_g | pad | cv_g | pad | kl word | pad]: offset (floats, from ac_g) of the kl word
   unsigned long long* ll; // [SDXP_LL_WORDS] (value, step tag) words exchanged between the CUs of the persistent update kernel

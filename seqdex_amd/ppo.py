@@ -24,7 +24,7 @@ class Ctrl(C.Structure):
                 ("ac_b1pow", C.c_double), ("ac_b2pow", C.c_double), ("cv_b1pow", C.c_double), ("cv_b2pow", C.c_double)]
 
 
-def make_config(num_actors, params=None, world_size=1):
+def make_config(num_actors, params=None, world_size=1, obs_dim=None, state_dim=None):
     """sdxp_config from the `params.config` block of cfg/lego/ppo_continuous_grasp.yaml (YG) + network units."""
     p = params or {}
     cfgd = p.get("config", {})
@@ -37,7 +37,10 @@ def make_config(num_actors, params=None, world_size=1):
     c.mini_epochs = cfgd.get("mini_epochs", 5)
     c.cv_minibatch = cv.get("minibatch_size", c.minibatch)
     c.cv_mini_epochs = cv.get("mini_epochs", c.mini_epochs)
-    c.obs_dim, c.state_dim, c.act_dim = _abi.NUM_OBS, _abi.NUM_STATES, _abi.NUM_ACTIONS
+    raw_obs = obs_dim or _abi.NUM_OBS
+    c.obs_dim = (raw_obs + 3) // 4 * 4          # the kernels read rows with float4 accesses: network input zero-padded to x4
+    c.obs_cols = raw_obs if raw_obs != c.obs_dim else 0
+    c.state_dim, c.act_dim = state_dim or _abi.NUM_STATES, _abi.NUM_ACTIONS
     c.units[:] = units
     c.gamma, c.tau = cfgd.get("gamma", 0.99), cfgd.get("tau", 0.95)
     c.lr, c.cv_lr = float(cfgd.get("learning_rate", 3e-4)), float(cv.get("learning_rate", 1e-3))
@@ -55,12 +58,12 @@ def make_config(num_actors, params=None, world_size=1):
 
 
 class SdxPPO:
-    def __init__(self, num_actors, params=None, device="cuda:0", seed=22, config=None, world_size=1):
+    def __init__(self, num_actors, params=None, device="cuda:0", seed=22, config=None, world_size=1, obs_dim=None, state_dim=None):
         if not torch.cuda.is_available():
             raise SdxError("seqdex_amd needs a ROCm GPU (gfx950); there is no CPU fallback for the product path")
         self.lib = _abi.load_library()
         self.device = torch.device(device)
-        self.cfg = config or make_config(num_actors, params, world_size)
+        self.cfg = config or make_config(num_actors, params, world_size, obs_dim, state_dim)
         h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         rc = self.lib.sdxp_create(C.byref(self.cfg), idx, C.c_uint64(seed), C.byref(h))
