@@ -27,6 +27,7 @@
 #include "sdxp_types.h"
 
 namespace {
+// OBS is the LARGEST actor/critic input width (GraspSim, 396); narrower inputs (Orient: 188) run with the tail columns masked off
 constexpr int MB = 4, OBS = 396, ST = 564, U0 = 1024, U1 = 512, U2 = 256, ACT = 23;
 constexpr int NWG = 256, NTH = 512, NWV = NTH / 64;
 constexpr int H0A = OBS / 2, H0V = ST / 2;   // a layer-0 row is split over two waves: 198 / 282 elements each
@@ -191,7 +192,7 @@ static_assert(sizeof(PLds) + 512 <= 160 * 1024, "PLds (+ the static logstd bank)
 }  // namespace
 
 // dataset-row helpers
-__device__ __forceinline__ const float* obs_rows(const SdxpDev& D, int mb) { return D.mb_obs + (size_t)mb * MB * OBS; }
+__device__ __forceinline__ const float* obs_rows(const SdxpDev& D, int mb) { return D.mb_obs + (size_t)mb * MB * D.obs_dim; }
 __device__ __forceinline__ const float* cvx_rows(const SdxpDev& D, int mb, int mini_epoch) {
   return (mini_epoch == 0 ? D.cvx0 : D.cvx1) + (size_t)mb * MB * ST;
 }
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 #pragma unroll
   for (int i = 0; i < I0A; ++i) {
     const int kk = lane + 64 * i, k = h0 * H0A + kk;
-    const bool ok = kk < H0A;
-    const size_t oa = woff(0, 0) + (size_t)n0 * OBS + k, oc = woff(1, 0) + (size_t)n0 * OBS + k;
+    const bool ok = kk < H0A && k < D.obs_dim;
+    const size_t oa = woff(0, 0) + (size_t)n0 * D.obs_dim + k, oc = woff(1, 0) + (size_t)n0 * D.obs_dim + k;
     w0a[i] = ok ? D.ac[oa] : 0.0f; m0a[i] = ok ? ldm(D.ac_m, oa) : 0.0f; v0a[i] = ok ? ldm(D.ac_v, oa) : 0.0f;
     w0c[i] = ok ? D.ac[oc] : 0.0f; m0c[i] = ok ? ldm(D.ac_m, oc) : 0.0f; v0c[i] = ok ? ldm(D.ac_v, oc) : 0.0f;
   }
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       const float* c = cvx_rows(D, last ? 0 : mbi, last ? 0 : mini_epoch);
 #pragma unroll
       for (int s = 0; s < MB; ++s) {
-        pf_o[s] = tid < OBS ? o[s * OBS + tid] : 0.0f;
+        pf_o[s] = tid < D.obs_dim ? o[s * D.obs_dim + tid] : 0.0f;
         pf_c[0][s] = c[s * ST + tid];
         pf_c[1][s] = tid + NTH < ST ? c[s * ST + tid + NTH] : 0.0f;
       }
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 #pragma unroll
         for (int i = 0; i < I0A; ++i) {
           const int kk = opaque(lane + 64 * i, dep), k = h0 * H0A + kk;
-          if (kk < H0A) {
+          if (kk < H0A && k < D.obs_dim) {
             float ga = 0.0f, gc = 0.0f;
 #pragma unroll
             for (int s = 0; s < MB; ++s) { const float x = S.obs[s][k]; ga += da[s] * x; gc += dc[s] * x; }
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       // ---- this step's layer-0 inputs to LDS, forward L0 of the owned rows (two half-row waves per row, combined through LDS)
 #pragma unroll
       for (int s = 0; s < MB; ++s) {
-        if (tid < OBS) S.obs[s][tid] = pf_o[s];
+        if (tid < OBS) S.obs[s][tid] = pf_o[s];   // columns past obs_dim hold zeros (pf_o is masked)
         S.cvx[s][tid] = pf_c[0][s];
         if (tid + NTH < ST) S.cvx[s][tid + NTH] = pf_c[1][s];
       }
@@ -975,7 +976,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       __syncthreads();
       float* F = D.fact;
       const int i = g * NTH + tid, stride = NWG * NTH;
-      for (int j = i; j < MB * OBS; j += stride) { const float v = (&S.obs[0][0])[j]; F[D.foff.x[0][0] + j] = v; F[D.foff.x[1][0] + j] = v; }
+      for (int j = i; j < MB * D.obs_dim; j += stride) {
+        const float v = S.obs[j / D.obs_dim][j % D.obs_dim];
+        F[D.foff.x[0][0] + j] = v; F[D.foff.x[1][0] + j] = v;
+      }
       for (int j = i; j < MB * ST; j += stride) F[D.foff.x[2][0] + j] = (&S.cvx[0][0])[j];
 #pragma unroll
       for (int net = 0; net < 3; ++net) {
@@ -1041,8 +1045,8 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 #pragma unroll
   for (int i = 0; i < I0A; ++i) {
     const int kk = lane + 64 * i, k = h0 * H0A + kk;
-    if (kk < H0A) {
-      const size_t oa = woff(0, 0) + (size_t)n0 * OBS + k, oc = woff(1, 0) + (size_t)n0 * OBS + k;
+    if (kk < H0A && k < D.obs_dim) {
+      const size_t oa = woff(0, 0) + (size_t)n0 * D.obs_dim + k, oc = woff(1, 0) + (size_t)n0 * D.obs_dim + k;
       D.ac[oa] = w0a[i]; D.ac_m[oa] = m0a[i]; D.ac_v[oa] = v0a[i];
       D.ac[oc] = w0c[i]; D.ac_m[oc] = m0c[i]; D.ac_v[oc] = v0c[i];
     }
@@ -1107,7 +1111,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 
 extern "C" size_t sdxpk_persist_lds_bytes() { return sizeof(PLds); }
 extern "C" int sdxpk_persist_supported(const SdxpDev* D, int minibatch, int n_cus) {
-  return minibatch == MB && D->obs_dim == OBS && D->state_dim == ST && D->units[0] == U0 && D->units[1] == U1 &&
+  return minibatch == MB && D->obs_dim <= OBS && D->obs_dim % 4 == 0 && D->state_dim == ST && D->units[0] == U0 && D->units[1] == U1 &&
          D->units[2] == U2 && D->act_dim == ACT && n_cus >= NWG;
 }
 // tag_base: first exchange tag of this launch minus one; the caller advances it by total_steps + 2 per launch

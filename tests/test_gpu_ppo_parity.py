@@ -159,3 +159,54 @@ def test_explicit_gradient_path_equals_fused_path():
         np.testing.assert_allclose(c1.cv_gnorm, c2.cv_gnorm, rtol=2e-3)
     finally:
         a1.close(); a2.close()
+
+
+def test_update_with_narrow_padded_observation_186():
+    """BlockAssemblyOrient's 186-wide observation: the library pads the network input to 188 (two dead inputs, sdxp_config.obs_cols);
+    the oracle runs a 188-input network on explicitly zero-padded rows.  Covers sdxp_act's padding and the persistent update kernel
+    with an input narrower than its compiled maximum."""
+    from seqdex_amd.ppo import SdxPPO, make_config
+    n = 16
+    cfg = make_config(n, obs_dim=186)
+    assert cfg.obs_dim == 188 and cfg.obs_cols == 186
+    agent = SdxPPO(n, config=cfg, seed=3)
+    oc = dict(DEFAULT_CFG)
+    oc.update(obs_dim=188, minibatch=cfg.minibatch, mini_epochs=cfg.mini_epochs, lr=cfg.lr, cv_lr=cfg.cv_lr, adaptive_lr=True)
+    orc = PPOOracle(oc, seed=0)
+    orc.load_flat(agent.t["AC_PARAMS"].cpu(), agent.t["CV_PARAMS"].cpu())
+    try:
+        g = torch.Generator().manual_seed(2)
+        H = 8
+        obs_l, st_l, rew_l, done_l = [], [], [], []
+        buf = dict(actions=[], mus=[], sigmas=[], neglogp=[], values=[])
+        for t in range(H):
+            obs = torch.randn(n, 186, generator=g).clamp(-5, 5)
+            obs188 = torch.cat([obs, torch.zeros(n, 2)], dim=1)
+            st = torch.randn(n, 564, generator=g).clamp(-5, 5) * 2
+            eps = torch.randn(n, 23, generator=g)
+            dones = (torch.rand(n, generator=g) < 0.15).long()
+            rew = torch.rand(n, generator=g)
+            a = agent.act(t, obs.cuda(), st.cuda(), dones.cuda(), eps.cuda())
+            agent.store_rewards(t, rew.cuda(), dones.cuda())
+            r = orc.act(obs188, st, eps)
+            np.testing.assert_allclose(a.cpu().numpy(), r["actions"].numpy(), rtol=2e-4, atol=2e-4)
+            for k in buf:
+                buf[k].append(r[k])
+            obs_l.append(obs188); st_l.append(st); rew_l.append(rew); done_l.append(dones.float())
+        last_st = torch.randn(n, 564, generator=g)
+        last_done = (torch.rand(n, generator=g) < 0.15).long()
+        agent.finish_rollout(last_st.cuda(), last_done.cuda())
+        torch.cuda.synchronize()
+        adv, ret = orc.gae(torch.stack(rew_l), torch.stack(buf["values"]), torch.stack(done_l), orc.values(last_st), last_done.float())
+        flat = lambda x: torch.stack(x).transpose(0, 1).reshape(n * H, *x[0].shape[1:]).contiguous()
+        ds = dict(obs=flat(obs_l), states=flat(st_l), actions=flat(buf["actions"]), mus=flat(buf["mus"]).clone(),
+                  sigmas=flat(buf["sigmas"]).clone(), neglogp=flat(buf["neglogp"]), values=flat(buf["values"]),
+                  returns=ret.transpose(0, 1).reshape(-1).contiguous())
+        impl = agent.update_checked()
+        orc.update(ds)
+        ac, cv = agent.t["AC_PARAMS"].cpu().numpy(), agent.t["CV_PARAMS"].cpu().numpy()
+        assert np.abs(ac - orc.ac_flat().numpy()).max() < 2e-4, (impl, np.abs(ac - orc.ac_flat().numpy()).max())
+        assert np.abs(cv - orc.cv_flat().numpy()).max() < 5e-4
+        np.testing.assert_allclose(agent.ctrl().ac_lr, orc.lr, rtol=1e-6)
+    finally:
+        agent.close()
