@@ -359,3 +359,133 @@ def orient_hand_reward(target_pos, target_rot, ff, rf, mf, th, progress, reset_b
     cons = np.where(num_resets > 0, F(av_factor) * fin / max(num_resets, 1) + F(1.0 - av_factor) * cons_successes,
                     cons_successes).astype(F)
     return reward, resets.astype(np.int64), cons, z_align
+
+
+# ================================================================== BlockAssemblyInsertSim (second policy of the chain)
+# IS = dexteroushandenvs/tasks/block_assembly/allegro_hand_block_assembly_insert_sim.py.  Pinned by tests/golden/I*.npz
+# (oracle/gen_golden_insert.py).  The HIP side of this task is not built: oracle groundwork only.
+INSERT_POS_SCALE = 0.64                                                                          # IS:1537
+
+
+def insert_offset_sets(n):
+    """IS:779-812 (use_unseen False): envs whose insertion target is shifted along the base plate's y by one stud pitch (1xn
+    bricks), by one stud in x and y (the 1x1 brick, i % 8 == 5), and the plate-height class i % 3."""
+    i = np.arange(n)
+    return dict(xn=i % 8 != 5, x1=i % 8 == 5, height=i % 3)
+
+
+def insert_extra_target(extra_pos, extra_rot):
+    """IS:1121-1132,1165: the insertion site = root pose of the base plate actor shifted, in the plate's own frame, by
+    0.0375 (1 + i % 3) in z, 0.015 in y (1xn) or 0.015 in x and y (1x1); plus the 180-degree-about-z symmetric orientation."""
+    n = extra_pos.shape[0]
+    s = insert_offset_sets(n)
+    ax = lambda v: quat_apply(extra_rot, np.broadcast_to(np.array(v, dtype=F), (n, 3)))
+    p = extra_pos.astype(F).copy()
+    p = p + ax([0, 0, 1]) * (F(0.0375) * (s["height"] + 1).astype(F))[:, None]
+    p = p + ax([0, 1, 0]) * np.where(s["xn"], F(0.015), F(0))[:, None]
+    p = p + ax([1, 0, 0]) * np.where(s["x1"], F(0.015), F(0))[:, None]
+    p = p + ax([0, 1, 0]) * np.where(s["x1"], F(0.015), F(0))[:, None]
+    sym = quat_mul(extra_rot, np.broadcast_to(np.array([0, 0, 1, 0], dtype=F), (n, 4)))
+    return p.astype(F), sym
+
+
+def insert_pre_physics_targets(actions, q, prev_targets, hand_rot, J, lower, upper, target_euler, act_moving_average=1.0):
+    """IS:1526-1572: fingers from a[7:23]; the arm moves the hand base by a[0:3] * 0.64 with the wrist orientation servoed to
+    target_euler through the damped-least-squares IK.  Returns (targets, rot_err); rot_err feeds the reward's reset rule."""
+    a = actions.astype(F)
+    n = a.shape[0]
+    cur = np.zeros_like(prev_targets, dtype=F)
+    cur[:, 7:23] = scale(a[:, 7:23], lower[7:23], upper[7:23])
+    cur[:, 7:23] = F(act_moving_average) * cur[:, 7:23] + F(1.0 - act_moving_average) * prev_targets[:, 7:23]
+    pos_err = a[:, 0:3] * F(INSERT_POS_SCALE)
+    te = np.broadcast_to(np.asarray(target_euler, dtype=F), (n, 3))
+    rot_err = orientation_error(quat_from_euler_xyz(te[:, 0], te[:, 1], te[:, 2]), hand_rot)
+    cur[:, :7] = q[:, :7] + control_ik(J, np.concatenate([pos_err, rot_err], axis=-1))
+    return np.maximum(np.minimum(cur, upper), lower).astype(F), rot_err
+
+
+def insert_observation_frames(root_env, rb, dof, actions, seg_idx, init_pos, lower, upper, cam_q, cam_p, fingertips, progress,
+                              extra_actor=141, hand_body=7, max_episode_length=125.0):
+    """compute_contact_observations IS:1280-1298 (75 numbers, NOT stacked) and the asymmetric state IS:1220-1278 (188, not
+    stacked): poses are expressed relative to the insertion site instead of the camera."""
+    n = rb.shape[0]
+    ar = np.arange(n)
+    tgt = root_env[ar, seg_idx]
+    tpos, trot = tgt[:, 0:3], tgt[:, 3:7]
+    ext = root_env[:, extra_actor]
+    epos, sym = insert_extra_target(ext[:, 0:3], ext[:, 3:7])
+    erot = ext[:, 3:7]
+    hb = rb[:, hand_body]
+    hpos, hrot = hb[:, 0:3], hb[:, 3:7]
+    ff, mf, rf, th = (rb[:, fingertips[i]] for i in range(4))
+    tip = lambda s: (s[:, 0:3] + quat_apply(s[:, 3:7], np.broadcast_to(FT_OFFSET, (n, 3)))).astype(F)
+    ffp, mfp, rfp, thp = tip(ff), tip(mf), tip(rf), tip(th)
+    nrm = lambda v: np.linalg.norm(v, axis=-1).astype(F)
+    finger_dist = nrm(tpos - ffp) + nrm(tpos - mfp) + nrm(tpos - rfp) + nrm(tpos - thp)          # IS:1180-1181
+    qc, pc = tf_combine(hrot, hpos, np.broadcast_to(cam_q, (n, 4)), np.broadcast_to(cam_p, (n, 3)))
+    qci, pci = tf_inverse(qc, pc)
+    ct_rot, ct_pos = tf_combine(qci, pci, trot, tpos)
+    q, qd = dof[..., 0], dof[..., 1]
+
+    o = np.zeros((n, 75), dtype=F)
+    o[:, 0:16] = unscale(q[:, 7:23], lower[7:23], upper[7:23])
+    o[:, 23:46] = actions
+    o[:, 46:49] = hpos - epos
+    o[:, 49:53] = quat_mul(hrot, quat_conjugate(erot))
+    o[:, 53:56] = hpos - tpos
+    o[:, 56:60] = quat_mul(hrot, quat_conjugate(trot))
+    o[:, 61:64], o[:, 64:68] = epos, erot
+    o[:, 68:71] = tpos - epos
+    o[:, 71:75] = quat_mul(trot, quat_conjugate(erot))
+
+    s = np.zeros((n, 188), dtype=F)
+    s[:, 0:23] = unscale(q, lower, upper)
+    s[:, 23:46] = F(0.2) * qd
+    s[:, 46:49], s[:, 49:52], s[:, 52:55], s[:, 55:58] = ffp, rfp, mfp, thp
+    s[:, 58:81] = actions
+    s[:, 81:88] = hb[:, 0:7]
+    s[:, 88:95] = tgt[:, 0:7]
+    s[:, 95:98], s[:, 98:101] = hb[:, 7:10], hb[:, 10:13]
+    for k, st in enumerate([ff, mf, rf, th]):
+        s[:, 101 + 10 * k:105 + 10 * k] = st[:, 3:7]
+        s[:, 105 + 10 * k:108 + 10 * k] = st[:, 7:10]
+        s[:, 108 + 10 * k:111 + 10 * k] = st[:, 10:13]
+    s[:, 141] = progress.astype(F) / F(max_episode_length)                                       # IS:1255
+    s[:, 142:145], s[:, 145:148] = tgt[:, 7:10], tgt[:, 10:13]
+    s[:, 148:151] = init_pos
+    s[:, 151:154] = tpos - init_pos
+    s[:, 154:157] = hpos - tpos
+    s[:, 157:161] = quat_mul(hrot, quat_conjugate(trot))
+    s[:, 161:164], s[:, 164:167] = tpos - ffp, tpos - rfp
+    s[:, 167:170], s[:, 170:173] = tpos - mfp, tpos - thp
+    s[:, 173] = finger_dist
+    s[:, 174:177], s[:, 177:181] = ct_pos, ct_rot
+    s[:, 181:184], s[:, 184:188] = epos, erot                                                    # IS:1277-1278
+    return o, s, dict(extra_target_pos=epos, symmetry_rot=sym, finger_dist=finger_dist)
+
+
+def insert_hand_reward(target_pos, target_rot, extra_pos, extra_rot, symmetry_rot, rot_err, ff, rf, mf, th, progress, reset_buf,
+                       cons_successes, successes, max_episode_length=125.0, av_factor=0.1, max_consecutive_successes=0,
+                       fall_penalty=0.0):
+    """compute_hand_reward IS:1640-1695: exp(-rot_dist - 20 |brick - site|) (+1 once within 2 cm and 0.2 rad, the site's
+    180-degree twin counting as aligned); reset when the hand lets go (thumb-weighted distance >= 0.6), when the wrist servo error
+    grows (sum rot_err^2 >= 0.03) or on time-out."""
+    nrm = lambda v: np.linalg.norm(v.astype(F), axis=-1).astype(F)
+    d = nrm(target_pos - ff) + nrm(target_pos - mf) + nrm(target_pos - rf) + F(3) * nrm(target_pos - th)   # IS:1650-1651
+    ang = lambda a, b: (F(2) * np.arcsin(np.minimum(nrm(quat_mul(a, quat_conjugate(b))[:, 0:3]), F(1)))).astype(F)
+    rot_dist = np.minimum(ang(target_rot, extra_rot), ang(target_rot, symmetry_rot))             # IS:1656-1660
+    gap = nrm(target_pos - extra_pos)
+    insert_reward = np.exp(-rot_dist - F(20) * gap).astype(F)                                    # IS:1664
+    bonus = np.where((gap < F(0.02)) & (rot_dist < F(0.2)), F(1), F(0))                          # IS:1666-1668
+    resets = np.where(d >= F(0.6), 1, reset_buf)                                                 # IS:1673
+    resets = np.where((rot_err.astype(F) ** 2).sum(-1) >= F(0.03), 1, resets)                    # IS:1675
+    timed_out = progress >= max_episode_length - 1                                               # IS:1677-1678
+    resets = np.where(timed_out, 1, resets)
+    reward = (bonus + insert_reward).astype(F)                                                   # IS:1680
+    if max_consecutive_successes > 0:
+        reward = np.where(timed_out, reward + F(0.5 * fall_penalty), reward)
+    num_resets = resets.sum()
+    fin = (successes * resets.astype(F)).sum()
+    cons = np.where(num_resets > 0, F(av_factor) * fin / max(num_resets, 1) + F(1.0 - av_factor) * cons_successes,
+                    cons_successes).astype(F)
+    return reward, resets.astype(np.int64), cons, rot_dist
