@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDX_ABI_VERSION 2
+#define SDX_ABI_VERSION 3
 
 /* ---- fixed scene dimensions of BlockAssemblyGraspSim (GS:523-1058) ---- */
 #define SDX_NLINK 24        /* robot bodies after collapse_fixed_joints (GS:543); body 0 is the fixed base  */
@@ -93,7 +93,8 @@ typedef enum {
   SDX_T_HARVEST_HAND = 29, /* f32 [8,5001,23,2] saved_grasp_hand_ternimal_states per brick-type group   GS:391-417 */
   SDX_T_HARVEST_OBJ = 30,  /* f32 [8,5001,13]   saved_grasp_object_ternimal_states                       GS:391-417 */
   SDX_T_HARVEST_COUNT = 31,/* i32 [8]           terminal states harvested so far (ring index = count % 5001) GS:1417,1440 */
-  SDX_T_COUNT = 32
+  SDX_T_INSERT_AUX = 32,   /* f32 [N,8]         InsertSim: [0:3] rot_err (IS:1539), [3] |brick - site|, [4] rot_dist (IS:1656-1660) */
+  SDX_T_COUNT = 33
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the
@@ -158,10 +159,18 @@ typedef struct {
   float max_depenetration_vel;
   float jacobi_relax;                  /* relaxation on the mass-split Jacobi update */
   /* which task's per-step tensor code the pre/post-physics kernels run: 0 = BlockAssemblyGraspSim (GS),
-   * 1 = BlockAssemblyOrient (OR = tasks/block_assembly/allegro_hand_block_assembly_orient.py; targets/IK OR:1720-1778) */
+   * 1 = BlockAssemblyOrient (OR = tasks/block_assembly/allegro_hand_block_assembly_orient.py; targets/IK OR:1720-1778),
+   * 2 = BlockAssemblyInsertSim (IS; position action + fixed wrist orientation IS:1526-1572, 75-number observation IS:1280-1298,
+   *     insertion reward IS:1640-1695, reset from harvested grasp states IS:1416-1494) */
   int32_t task_kind;
   float target_euler[3];               /* Orient: fixed wrist orientation of the tracking IK, OR:477 */
   float seg_mass_scale;                /* mass (and inertia) factor of each env's target brick: 1 (GS:980-981), 50 in Orient (OR:977) */
+  /* task_kind 2 = BlockAssemblyInsertSim (IS = tasks/block_assembly/allegro_hand_block_assembly_insert_sim.py): the base plate is
+   * one of 4x4x{1,2,4} chosen by env % 3 (IS:971-977).  Only the z extent of static box `static_var_slot` differs between the
+   * variants; -1 = every env uses static_center/static_half as they are. */
+  int32_t static_var_slot;
+  float static_var_center_z[3];
+  float static_var_half_z[3];
 } sdx_scene_desc;
 
 typedef struct sdx_sim* sdx_handle;

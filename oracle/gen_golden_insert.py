@@ -134,7 +134,9 @@ def i5_reward(ins, g):
     rot = G.rand_quat(g, M)
     extra_rot = rot.clone()
     extra_rot[M // 4:] = G.rand_quat(g, M - M // 4)
-    sym = G.rand_quat(g, M)
+    zq = torch.tensor([0.0, 0.0, 1.0, 0.0]).repeat(M, 1)
+    extra_rot[M // 4:M // 2] = ins.quat_mul(rot, zq)[M // 4:M // 2]                          # plate turned by 180 degrees: the twin counts as aligned
+    sym = ins.quat_mul(extra_rot, zq)                                                        # as compute_observations builds it, IS:1167
     spread = torch.cat([torch.full((M // 2,), 0.03), torch.full((M // 2,), 0.25)])[:, None]
     tips = [tgt + torch.randn(M, 3, generator=g) * spread for _ in range(4)]
     progress = torch.tensor(([3, 74, 123, 124, 125, 60, 10, 90] * (M // 8)), dtype=torch.long)

@@ -114,6 +114,7 @@ typedef struct {
   real lam[SDXO_MAXC][3], w[SDXO_MAXC][2][3]; /* w[c][side][row]: un-split inverse effective mass */
   unsigned char active[SDXO_MAXC];
   int overflow;
+  int env_index;
   int seg_brick; /* this env's target brick: mass and inertia scaled by sc->seg_mass_scale */
 } env_t;
 
@@ -298,6 +299,16 @@ static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int 
 
 static real box_radius(v3 h) { return sqrtf(vdot(h, h)); }
 
+/* static box s as env `env_index` sees it: InsertSim's base plate height depends on env % 3 (sdx_scene_desc.static_var_*) */
+static box_t static_box(const sdx_scene_desc* sc, int s, int env_index) {
+  box_t S = {ld3(sc->static_center[s]), {0, 0, 0, 1}, ld3(sc->static_half[s])};
+  if (s == sc->static_var_slot) {
+    S.c.z = sc->static_var_center_z[env_index % 3];
+    S.h.z = sc->static_var_half_z[env_index % 3];
+  }
+  return S;
+}
+
 static void collide(const sdx_scene_desc* sc, env_t* e) {
   const real off = sc->contact_offset;
   e->nc = 0;
@@ -313,7 +324,7 @@ static void collide(const sdx_scene_desc* sc, env_t* e) {
   /* (1) brick vs static */
   for (int i = 0; i < NF; ++i)
     for (int s = 0; s < sc->n_static; ++s) {
-      box_t S = {ld3(sc->static_center[s]), {0, 0, 0, 1}, ld3(sc->static_half[s])};
+      box_t S = static_box(sc, s, e->env_index);
       v3 g;
       if (box_sdf(vsub(bb[i].c, S.c), S.h, &g) > br[i] + off) continue;
       collide_pair(e, &bb[i], &S, i, BODY_STATIC, 1, off);
@@ -339,7 +350,7 @@ static void collide(const sdx_scene_desc* sc, env_t* e) {
       collide_pair(e, &R, &bb[i], NF + k, i, 0, off);
     }
     for (int s = 0; s < sc->n_static; ++s) {
-      box_t S = {ld3(sc->static_center[s]), {0, 0, 0, 1}, ld3(sc->static_half[s])};
+      box_t S = static_box(sc, s, e->env_index);
       v3 g;
       if (box_sdf(vsub(R.c, S.c), S.h, &g) > rr0 + off) continue;
       collide_pair(e, &R, &S, NF + k, BODY_STATIC, 1, off);
@@ -499,6 +510,7 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
 
 /* ---------------------------------------------------------------- one env, one step */
 static void load_env(const sdx_scene_desc* sc, env_t* e, int env_index, const float* root, const float* dof, const float* targets) {
+  e->env_index = env_index;
   { int b = env_index & 7; e->seg_brick = (b == 3 || b == 4 || b == 7) ? 0 : b; } /* GS:962-965,974-975 */
   for (int j = 0; j < ND; ++j) {
     e->q[j] = dof[2 * j];

@@ -121,7 +121,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   memset(&B, 0, sizeof(B));
   B.N = N;
   B.task_kind = scene->task_kind;
-  B.obs_w = scene->task_kind == 1 ? 186 : SDX_NUM_OBS;
+  B.obs_w = scene->task_kind == 1 ? 186 : (scene->task_kind == 2 ? 75 : SDX_NUM_OBS);
   B.K = 1;
   B.seed = seed;
 #define ALLOC(field, count) if ((rc = dalloc(h, &B.field, (size_t)(count))) != SDX_OK) { g_create_err = h->err; sdx_destroy(h); return rc; }
@@ -163,6 +163,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(harvest_hand, (size_t)8 * SDX_HARVEST_SLOTS * SDX_NDOF * 2);
   ALLOC(harvest_obj, (size_t)8 * SDX_HARVEST_SLOTS * 13);
   ALLOC(harvest_count, 8);
+  ALLOC(insert_aux, (size_t)N * 8);
 #undef ALLOC
   set_tensor(h, SDX_T_ROOT, B.root, SDX_F32, {(int64_t)N * SDX_ACTORS, 13});
   set_tensor(h, SDX_T_DOF, B.dof, SDX_F32, {(int64_t)N * SDX_NDOF, 2});
@@ -196,6 +197,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_HARVEST_HAND, B.harvest_hand, SDX_F32, {8, SDX_HARVEST_SLOTS, SDX_NDOF, 2});
   set_tensor(h, SDX_T_HARVEST_OBJ, B.harvest_obj, SDX_F32, {8, SDX_HARVEST_SLOTS, 13});
   set_tensor(h, SDX_T_HARVEST_COUNT, B.harvest_count, SDX_I32, {8});
+  set_tensor(h, SDX_T_INSERT_AUX, B.insert_aux, SDX_F32, {N, 8});
 
   // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
   std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);

@@ -26,7 +26,7 @@ struct SdxConst {
 struct SdxBuf {
   int32_t N;
   int32_t K;               // saved piles per brick type
-  int32_t obs_w;           // row width of obs / obs_c: 396 (GraspSim, 3 x 132) or 186 (Orient, 62 + 124 never-written zeros)
+  int32_t obs_w;           // row width of obs / obs_c: 396 (GraspSim, 3 x 132), 186 (Orient, 62 + 124 never-written zeros), 75 (InsertSim)
   int32_t task_kind;       // copy of sdx_scene_desc.task_kind for kernels that do not take the constants
   uint64_t seed;
   float *root, *dof, *rb, *contact, *jac, *targets, *prev_targets;
@@ -45,6 +45,7 @@ struct SdxBuf {
   long long* dbg;          // [64] phase time stamps of env 0 (profiling aid)
   float *harvest_hand, *harvest_obj;   // [8, SDX_HARVEST_SLOTS, 23*2] / [8, SDX_HARVEST_SLOTS, 13]
   int32_t* harvest_count;  // [8]
+  float* insert_aux;       // [N,8] InsertSim: 0..2 rot_err of the last pre_physics_step (IS:1539), 3 |brick - site|, 4 rot_dist
 };
 
 struct f3 { float x, y, z; };

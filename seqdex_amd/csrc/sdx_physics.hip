@@ -93,6 +93,16 @@ __device__ __forceinline__ void tangents(f3 n, f3* t1, f3* t2) {
   *t2 = cross(n, t);
 }
 
+// static box s of env blockIdx.x: InsertSim's base plate has one of three heights by env % 3 (sdx_scene_desc.static_var_*)
+__device__ __forceinline__ void static_box(const sdx_scene_desc& sc, int s, f3* c, f3* h) {
+  *c = ld3(sc.static_center[s]);
+  *h = ld3(sc.static_half[s]);
+  if (s == sc.static_var_slot) {
+    const int k = (int)(blockIdx.x % 3u);
+    c->z = sc.static_var_center_z[k];
+    h->z = sc.static_var_half_z[k];
+  }
+}
 // box id: 0..71 brick, 72..103 robot box, 128.. static
 __device__ __forceinline__ Box load_box(const SdxConst* C, const PhysLds& S, int id) {
   const sdx_scene_desc& sc = C->sc;
@@ -104,7 +114,7 @@ __device__ __forceinline__ Box load_box(const SdxConst* C, const PhysLds& S, int
     b.c = ld3(S.rc[r]); b.q = ld4(S.rq[r]); b.h = ld3(sc.rbox_half[r]);
   } else {
     const int s = id - 128;
-    b.c = ld3(sc.static_center[s]); b.q.x = 0; b.q.y = 0; b.q.z = 0; b.q.w = 1; b.h = ld3(sc.static_half[s]);
+    static_box(sc, s, &b.c, &b.h); b.q.x = 0; b.q.y = 0; b.q.z = 0; b.q.w = 1;
   }
   return b;
 }
@@ -384,7 +394,9 @@ __device__ void collide(const SdxConst* C, PhysLds& S, int tid) {
     if (idx < n1) {
       const int i = idx / ns, s = idx % ns;
       const float r = C->brick_radius[sc.brick_type[i]];
-      hit = box_sdf_val(ld3(S.bp[i]) - ld3(sc.static_center[s]), ld3(sc.static_half[s])) <= r + off;
+      f3 stc, sth;
+      static_box(sc, s, &stc, &sth);
+      hit = box_sdf_val(ld3(S.bp[i]) - stc, sth) <= r + off;
       pr = (uint32_t)i | ((uint32_t)(128 + s) << 8);
     } else if (idx < n1 + n2) {
       const int t = idx - n1, i = t / NF, j = t % NF;
@@ -406,7 +418,9 @@ __device__ void collide(const SdxConst* C, PhysLds& S, int tid) {
           pr = (uint32_t)(NF + r) | ((uint32_t)u << 8);
         } else {
           const int s = u - NF;
-          hit = box_sdf_val(rc - ld3(sc.static_center[s]), ld3(sc.static_half[s])) <= rr0 + off;
+          f3 stc, sth;
+          static_box(sc, s, &stc, &sth);
+          hit = box_sdf_val(rc - stc, sth) <= rr0 + off;
           pr = (uint32_t)(NF + r) | ((uint32_t)(128 + s) << 8);
         }
       }

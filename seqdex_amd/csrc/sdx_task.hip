@@ -67,6 +67,41 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
     const int seg = seg_actor(e) - SDX_ACTOR_BRICK0;
     if (lane < 3) B.init_pos[e * 3 + lane] = src[seg * 13 + lane];               // GS:1547
     if (lane < 4) B.init_rot[e * 4 + lane] = src[seg * 13 + 3 + lane];           // GS:1548
+    if (sc.task_kind == 2) {
+      // BlockAssemblyInsertSim reset_idx, IS:1328-1494.  Episode outcome first (IS:1345-1354, from the quantities of the last
+      // compute_observations): inserted = within 2 cm and 0.2 rad of the site or of its 180-degree twin
+      __syncthreads();                                                              // the pile / hand writes above land first
+      float* aux = B.insert_aux + (size_t)e * 8;
+      if (lane == 0 && B.step_count[0] > 0) B.success_buf[e] = (aux[3] < 0.02f && aux[4] < 0.2f) ? 1 : 0;
+      // base plate back to its place with a 0 / 90 degree yaw drawn ONCE per reset event (random.sample([0, 1], 1), IS:1435-1445)
+      const float yaw_half = 0.785f * (float)(sdx_hash(B.seed, 0xA11CEull, (uint64_t)B.step_count[0]) & 1ull);
+      if (lane < 13) {
+        float v = 0.0f;
+        if (lane < 3) v = sc.base_plate_pos[lane];
+        else if (lane == 5) v = sinf(yaw_half);
+        else if (lane == 6) v = cosf(yaw_half);
+        root_e[141 * 13 + lane] = v;
+      }
+      // the target brick and the hand start from a grasp terminal state harvested by BlockAssemblyGraspSim (IS:1449-1456):
+      // random slot of this env's brick-type ring, velocities zeroed, PD targets = the restored joint positions (IS:1478-1479)
+      int cnt = B.harvest_count[e & 7];
+      if (cnt > SDX_HARVEST_SLOTS - 1) cnt = SDX_HARVEST_SLOTS - 1;                // range(0, 5000)
+      if (cnt > 0) {
+        const int slot = (int)(sdx_hash(B.seed ^ 0x5EEDull, (uint64_t)e, (uint64_t)B.step_count[0]) % (uint64_t)cnt);
+        const size_t o = (size_t)(e & 7) * SDX_HARVEST_SLOTS + slot;
+        float* tg = root_e + seg_actor(e) * 13;
+        if (lane < 13) tg[lane] = lane < 7 ? B.harvest_obj[o * 13 + lane] : 0.0f;  // IS:1452,1455
+        if (lane < SDX_NDOF) {
+          const float qh = B.harvest_hand[o * 46 + 2 * lane];                      // IS:1453,1456
+          B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 0] = qh;
+          B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 1] = 0.0f;
+          B.prev_targets[(size_t)e * SDX_NDOF + lane] = qh;
+          B.targets[(size_t)e * SDX_NDOF + lane] = qh;
+        }
+        if (lane < 3) B.init_pos[e * 3 + lane] = B.harvest_obj[o * 13 + lane];      // IS:1485
+        if (lane < 4) B.init_rot[e * 4 + lane] = B.harvest_obj[o * 13 + 3 + lane];  // IS:1486
+      }
+    }
     if (lane == 0) {
       B.progress[e] = 0;                                                          // GS:1550-1553
       B.reset[e] = 0;
@@ -90,8 +125,9 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
   __syncthreads();
   // dpose (GS:1594-1600), every lane computes it (uniform)
   float dp[6];
-  const bool orient = sc.task_kind == 1;
-  if (!orient) {
+  const bool orient = sc.task_kind == 1, insert = sc.task_kind == 2;
+  const bool hold = m0 && !insert;                                                // GraspSim / Orient freeze the fingers after step 75
+  if (!orient && !insert) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       float ak = __shfl(a, k, SDX_WAVE);
@@ -105,13 +141,19 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
     }
   } else {
     // BlockAssemblyOrient, OR:1733-1743: object-centric tracking - the hand base is held 0.22 above / 0.18 behind the target
-    // brick with a fixed wrist orientation; after step 75 it lifts towards z_init + 0.39
+    // brick with a fixed wrist orientation; after step 75 it lifts towards z_init + 0.39.
+    // BlockAssemblyInsertSim, IS:1537-1539: the policy moves the hand base (a[0:3] * 0.64) and the wrist orientation is servoed.
     const float* hb = B.rb + ((size_t)e * SDX_BODIES + sc.hand_base_body) * 13;
     const float* tg = B.root + ((size_t)e * SDX_ACTORS + seg_actor(e)) * 13;
-    dp[0] = tg[0] - hb[0] - 0.18f;
-    dp[1] = tg[1] - hb[1];
-    dp[2] = tg[2] - hb[2] + 0.22f;
-    if (m0) dp[2] = B.init_pos[e * 3 + 2] - hb[2] + 0.15f + 0.24f;                  // OR:1737
+    if (insert) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dp[k] = __shfl(a, k, SDX_WAVE) * 0.64f;
+    } else {
+      dp[0] = tg[0] - hb[0] - 0.18f;
+      dp[1] = tg[1] - hb[1];
+      dp[2] = tg[2] - hb[2] + 0.22f;
+      if (m0) dp[2] = B.init_pos[e * 3 + 2] - hb[2] + 0.15f + 0.24f;                // OR:1737
+    }
     // quat_from_euler_xyz(target_euler) (isaacgym.torch_utils; half-angle products), orientation_error OR:1922-1925
     float sr, cr, sp, cp, sy, cy;
     sincosf(0.5f * sc.target_euler[0], &sr, &cr);
@@ -123,6 +165,10 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
     const f4 qr = qmul(qd, qconj(ld4(hb + 3)));
     const float sg = qr.w > 0.0f ? 1.0f : (qr.w < 0.0f ? -1.0f : 0.0f);             // torch.sign
     dp[3] = qr.x * sg; dp[4] = qr.y * sg; dp[5] = qr.z * sg;
+    if (insert && lane == 0) {                                                      // self.rot_err feeds the reward's reset rule, IS:1539,1675
+      float* aux = B.insert_aux + (size_t)e * 8;
+      aux[0] = dp[3]; aux[1] = dp[4]; aux[2] = dp[5];
+    }
   }
   // A = J J^T + 0.05^2 I (6x6 SPD), Cholesky solve A y = dpose (control_ik, GS:1796-1804)
   float A[6][6];
@@ -172,14 +218,14 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
     if (lane >= 7) {
       cur = 0.5f * (a + 1.0f) * (hi - lo) + lo;                                   // scale(), GS:1585-1587
       cur = sc.act_moving_average * cur + (1.0f - sc.act_moving_average) * prev;  // GS:1588-1589
-      if (m0) cur = prev;                                                         // GS:1606
+      if (hold) cur = prev;                                                       // GS:1606
     } else {
       float u = 0.0f;
 #pragma unroll
       for (int r = 0; r < 6; ++r) u += s_J[r * 7 + lane] * y[r];
       cur = B.dof[((size_t)e * SDX_NDOF + lane) * 2] + u;                         // GS:1602
-      if (m1 && !orient) cur = sc.insert_pose_a[lane];                            // GS:1604
-      if (m2 && !orient) cur = sc.insert_pose_b[lane];                            // GS:1605
+      if (m1 && !orient && !insert) cur = sc.insert_pose_a[lane];                 // GS:1604
+      if (m2 && !orient && !insert) cur = sc.insert_pose_b[lane];                 // GS:1605
     }
     cur = fmaxf(fminf(cur, hi), lo);                                              // tensor_clamp GS:1633-1635
     B.targets[(size_t)e * SDX_NDOF + lane] = cur;
@@ -260,6 +306,28 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
   const f4 ct_rot = qmul(qci, trot);
   const f3 ct_pos = qrot(qci, tpos) + pci;
   const f4 hq_rel = qmul(hrot, qconj(trot));                                      // GS:1263
+  // BlockAssemblyInsertSim: the insertion site = base plate pose shifted in the plate frame by 0.0375 (1 + env % 3) in z and one
+  // stud pitch in y (1xn bricks) or in x and y (the 1x1 brick, env % 8 == 5), IS:779-812,1119-1130; its 180-degree twin IS:1167
+  const bool insert = sc.task_kind == 2;
+  f3 epos = F3(0.0f, 0.0f, 0.0f);
+  f4 erot = {0.0f, 0.0f, 0.0f, 1.0f};
+  float gap = 0.0f, rot_dist = 0.0f;
+  if (insert) {
+    const float* ex = root_e + 141 * 13;
+    erot = ld4(ex + 3);
+    const bool one = (e & 7) == 5;
+    epos = ld3(ex) + qrot(erot, F3(0.0f, 0.0f, 1.0f)) * (0.0375f * (float)(1 + e % 3));
+    if (!one) epos = epos + qrot(erot, F3(0.0f, 1.0f, 0.0f)) * 0.015f;
+    else epos = epos + qrot(erot, F3(1.0f, 0.0f, 0.0f)) * 0.015f + qrot(erot, F3(0.0f, 1.0f, 0.0f)) * 0.015f;
+    const f4 zq = {0.0f, 0.0f, 1.0f, 0.0f};
+    const f4 esym = qmul(erot, zq);
+    const f4 d1 = qmul(trot, qconj(erot)), d2 = qmul(trot, qconj(esym));
+    const float r1 = 2.0f * asinf(fminf(sqrtf(d1.x * d1.x + d1.y * d1.y + d1.z * d1.z), 1.0f));   // IS:1656-1660
+    const float r2 = 2.0f * asinf(fminf(sqrtf(d2.x * d2.x + d2.y * d2.y + d2.z * d2.z), 1.0f));
+    rot_dist = fminf(r1, r2);
+    const f3 dg = tpos - epos;
+    gap = sqrtf(dot(dg, dg));
+  }
 
   // ---- frames in LDS: bulk copies lane-parallel, derived values by lane 0
   if (lane < 16) {
@@ -309,6 +377,18 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
     s_s[173] = finger_dist;                                                       // GS:1270
     st3(s_s + 174, ct_pos); st4(s_s + 177, ct_rot);                               // GS:1272-1276
     st3(s_s + 181, ct_pos); st4(s_s + 184, ct_rot);
+    if (insert) {
+      s_s[141] = (float)prog / sc.max_episode_length;                             // IS:1255
+      st3(s_s + 181, epos); st4(s_s + 184, erot);                                 // IS:1277-1278
+      float* aux = B.insert_aux + (size_t)e * 8;
+      aux[3] = gap; aux[4] = rot_dist;
+      // compute_contact_observations IS:1280-1298, staged behind the GraspSim frame (s_o[0:16] already holds the finger joints)
+      st3(s_o + 46, hpos - epos);  st4(s_o + 49, qmul(hrot, qconj(erot)));
+      st3(s_o + 53, hpos - tpos);  st4(s_o + 56, hq_rel);
+      s_o[60] = 0.0f;
+      st3(s_o + 61, epos);         st4(s_o + 64, erot);
+      st3(s_o + 68, tpos - epos);  st4(s_o + 71, qmul(trot, qconj(erot)));
+    }
     st4(B.cam_rot + (size_t)e * 4, ct_rot);
     B.finger_dist[e] = finger_dist;
   }
@@ -333,6 +413,15 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
         o[lane] = v;
         oc[lane] = clampf(v, -sc.clip_obs, sc.clip_obs);
       }
+    } else if (insert) {
+      // BlockAssemblyInsertSim: 75 numbers, one frame (stack_obs = 1, IS:172); columns 16..22 and 60 are never written
+      for (int c = lane; c < 75; c += SDX_WAVE) {
+        float v = s_o[c];
+        if (c >= 16 && c < 23) v = 0.0f;
+        else if (c >= 23 && c < 46) v = s_act[c - 23];                            // IS:1285
+        o[c] = v;
+        oc[c] = clampf(v, -sc.clip_obs, sc.clip_obs);
+      }
     } else {
     float hist[5];
 #pragma unroll
@@ -356,18 +445,20 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
     }
     float* s = B.states + (size_t)e * SDX_NUM_STATES;
     float* stc = B.states_c + (size_t)e * SDX_NUM_STATES;
-    float hs[6];
+    if (!insert) {                                                                // InsertSim's 188 states are one frame (IS:172,192):
+      float hs[6];                                                                // columns 188.. of its rows stay zero
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int c = lane + r * SDX_WAVE;
-      hs[r] = (c < 2 * SDX_STATE_FRAME) ? s[c] : 0.0f;
-    }
+      for (int r = 0; r < 6; ++r) {
+        const int c = lane + r * SDX_WAVE;
+        hs[r] = (c < 2 * SDX_STATE_FRAME) ? s[c] : 0.0f;
+      }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int c = lane + r * SDX_WAVE;
-      if (c < 2 * SDX_STATE_FRAME) {
-        s[SDX_STATE_FRAME + c] = hs[r];
-        stc[SDX_STATE_FRAME + c] = clampf(hs[r], -sc.clip_obs, sc.clip_obs);
+      for (int r = 0; r < 6; ++r) {
+        const int c = lane + r * SDX_WAVE;
+        if (c < 2 * SDX_STATE_FRAME) {
+          s[SDX_STATE_FRAME + c] = hs[r];
+          stc[SDX_STATE_FRAME + c] = clampf(hs[r], -sc.clip_obs, sc.clip_obs);
+        }
       }
     }
     for (int c = lane; c < SDX_STATE_FRAME; c += SDX_WAVE) {
@@ -385,7 +476,16 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
     const bool timed_out = (float)prog >= sc.max_episode_length - 1.0f;           // GS:1729
     if (timed_out) resets = 1;
     float reward;
-    if (sc.task_kind == 1) {
+    if (insert) {
+      // InsertSim, IS:1640-1695: exp(-rot_dist - 20 |brick - site|) + 1 once seated; reset when the hand lets go, when the wrist
+      // servo error (the rot_err of this step's pre_physics_step) grows, or on time-out
+      const float* aux = B.insert_aux + (size_t)e * 8;
+      reward = expf(-rot_dist - 20.0f * gap) + ((gap < 0.02f && rot_dist < 0.2f) ? 1.0f : 0.0f);   // IS:1664-1668,1680
+      resets = (long)B.reset[e];
+      if (d >= 0.6f) resets = 1;                                                  // IS:1673
+      if (aux[0] * aux[0] + aux[1] * aux[1] + aux[2] * aux[2] >= 0.03f) resets = 1;   // IS:1675
+      if (timed_out) resets = 1;                                                  // IS:1677-1678
+    } else if (sc.task_kind == 1) {
       // Orient: exp(-5 (1 - (z_align + 1) / 2) - 5 max(d - 0.4, 0)), distance term dropped after step 175; time-out is the only
       // reset (max_consecutive_successes = 0 in the shipped config, so the fall-penalty term OR:1900-1901 is inactive)
       const float dot1 = qrot(trot, F3(0.0f, 0.0f, 1.0f)).z;                      // OR:1856-1859

@@ -124,12 +124,31 @@ class Scene:
         d.task_kind = 0                                   # BlockAssemblyGraspSim; 1 = BlockAssemblyOrient (per-step tensor code only)
         d.target_euler[:] = [0.0, 3.1415, 1.571]          # OR:477
         d.seg_mass_scale = 1.0                            # GS:980-981 (x1); Orient x50 (OR:977)
+        d.static_var_slot = -1
         for k_, v in overrides.items():
             if hasattr(v, "__len__") and not isinstance(v, (str, bytes)):
                 getattr(d, k_)[:] = list(v)
             else:
                 setattr(d, k_, v)
+        if d.task_kind == 2:
+            self._place_insert_plates(d)
         return d
+
+    def _place_insert_plates(self, d):
+        """BlockAssemblyInsertSim: the base plate actor sits at (0.25, -0.2, 0.618) (IS:1438-1440; the torch_rand_int(0, 1) offsets
+        are always 0) and is one of 4x4x{1,2,4} by env % 3 (IS:971-977).  The plate is square, so the 0 / 90 degree yaw drawn at each
+        reset (IS:1435-1436) leaves its axis-aligned collision box unchanged; see tools/compile_scene.py for the stud-less body box."""
+        raw = self.raw
+        ps = [i for i, st in enumerate(self.statics) if st["name"] == "base_plate"][0]
+        pos = raw["insert_plate_pos"]
+        d.base_plate_pos[:] = pos
+        p0 = raw["insert_plates"][0]
+        d.static_center[ps][:] = [pos[0] + p0["center"][0], pos[1] + p0["center"][1], pos[2] + p0["center"][2]]
+        d.static_half[ps][:] = p0["half"]
+        d.static_var_slot = ps
+        for k, pl in enumerate(raw["insert_plates"]):
+            d.static_var_center_z[k] = pos[2] + pl["center"][2]
+            d.static_var_half_z[k] = pl["half"][2]
 
 
 def load_scene(path=None):

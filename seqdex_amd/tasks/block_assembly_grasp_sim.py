@@ -14,6 +14,7 @@ from ..sim import SdxSim
 class BlockAssemblyGraspSim:
     TASK_KIND = 0                     # sdx_scene_desc.task_kind
     ONE_FRAME_NUM_OBS = _abi.OBS_FRAME
+    STACK_OBS = 3                     # GS:189
 
     def _scene_overrides(self, scene):
         """task-specific entries of sdx_scene_desc (hook for the other BlockAssembly* tasks)"""
@@ -25,7 +26,7 @@ class BlockAssemblyGraspSim:
         env = cfg["env"]
         self.num_envs = env["numEnvs"]
         self.max_episode_length = env["episodeLength"]                       # GS:147
-        self.stack_obs = 3                                                    # GS:189
+        self.stack_obs = self.STACK_OBS
         self.one_frame_num_obs, self.one_frame_num_states = self.ONE_FRAME_NUM_OBS, _abi.STATE_FRAME   # GS:207-208
         cfg["env"]["numObservations"] = self.ONE_FRAME_NUM_OBS * self.stack_obs   # GS:209-211
         cfg["env"]["numStates"] = _abi.NUM_STATES
@@ -104,6 +105,23 @@ class BlockAssemblyGraspSim:
         mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
         mask[env_ids] = 1
         self.sim.reset_idx(mask)
+
+    # ------------------------------------------------------------------ hand-off to BlockAssemblyInsertSim
+    def grasp_terminal_states(self):
+        """the harvested terminal states in the reference's hand-off layout (GS:391-417,1440-1450): two lists of 8 tensors,
+        object root states [K_t, 1, 13] and hand joint states [K_t, 23, 2] per brick-type group (K_t = filled ring slots)."""
+        s = self.sim
+        cnt = s.HARVEST_COUNT.cpu().numpy()
+        k = np.minimum(cnt, _abi.HARVEST_SLOTS)
+        obj = [s.HARVEST_OBJ[t, :int(k[t])].clone().unsqueeze(1) for t in range(8)]
+        hand = [s.HARVEST_HAND[t, :int(k[t])].clone() for t in range(8)]
+        return obj, hand
+
+    def save_grasp_terminal_states(self, path):
+        """np.savez of grasp_terminal_states(): obj_<t> / hand_<t> arrays (our stand-in for the two pickles of GS:1447-1450)."""
+        obj, hand = self.grasp_terminal_states()
+        np.savez(path, **{"obj_%d" % t: obj[t].cpu().numpy() for t in range(8)},
+                 **{"hand_%d" % t: hand[t].cpu().numpy() for t in range(8)})
 
     def get_states(self):                         # BT:152-153
         return self.states_buf

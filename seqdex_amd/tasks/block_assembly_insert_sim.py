@@ -1,0 +1,118 @@
+"""Host-side mirror of the reference task class `BlockAssemblyInsertSim`
+(tasks/block_assembly/allegro_hand_block_assembly_insert_sim.py:94 = IS; second policy of the grasp -> insert chain, SURVEY.md
+section 8(f) rank 1).  Same robot and table as BlockAssemblyGraspSim; what the task changes and this build reproduces:
+  * action: a[0:3] * 0.64 moves the hand base, the wrist orientation is servoed to a fixed target through the damped-least-squares
+    IK, fingers from a[7:23] (IS:1526-1572);
+  * observation: 75 numbers, one frame, poses relative to the insertion site (IS:1280-1298); asymmetric state of 188 numbers, one frame
+    (IS:1220-1278) - the buffer keeps GraspSim's 564-wide rows, columns 188.. stay zero, so the same update kernel serves all tasks;
+  * reward exp(-rot_dist - 20 |brick - site|) + 1 once seated (the site's 180-degree twin counts), resets when the hand lets go,
+    when the wrist servo error grows, or on time-out (IS:1640-1695); episodeLength 125;
+  * base plate 4x4x{1,2,4} by env % 3 at (0.25, -0.2, 0.618), yaw 0 / 90 degrees drawn per reset event (IS:971-977,1435-1445);
+  * reset: target brick and hand start from a grasp terminal state harvested by BlockAssemblyGraspSim (IS:1449-1456) - pass them
+    with `grasp_states=` (the lists of `BlockAssemblyGraspSim.grasp_terminal_states()`, an .npz of `save_grasp_terminal_states`,
+    or the reference's two pickles); without them kinematic stand-ins are synthesised (hand at GraspSim's last arm waypoint, fingers
+    closed, brick between the fingertips) and the task says so in `grasp_states_source`.
+Not reproduced: stud engagement (box-only contact: the plate is its stud-less body, a seated brick rests on
+it), the 8 parked bricks of IS:706-731 (the settled GraspSim pile stays in the bin instead; neither enters observation or reward),
+HDF5 T-value logging (IS:1392-1410), the replan bookkeeping (IS:1357-1374).
+"""
+import pickle
+
+import numpy as np
+import torch
+
+from .. import _abi
+from .block_assembly_grasp_sim import BlockAssemblyGraspSim
+
+
+class BlockAssemblyInsertSim(BlockAssemblyGraspSim):
+    TASK_KIND = 2
+    ONE_FRAME_NUM_OBS = 75                                                     # IS:175
+    STACK_OBS = 1                                                              # IS:172
+
+    def _scene_overrides(self, scene):
+        return {"target_euler": [0.0, 3.1415, 1.571]}                          # IS:444
+
+    def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True,
+                 agent_index=None, is_multi_agent=False, seed=22, initial_piles=None, piles_per_type=8, grasp_states=None,
+                 synthetic_states_per_type=64):
+        super().__init__(cfg, sim_params, physics_engine, device_type, device_id, headless, agent_index, is_multi_agent, seed,
+                         initial_piles, piles_per_type)
+        self.one_frame_num_states = _abi.STATE_FRAME                           # 188 real columns (IS:190); rows are 564 wide
+        self.insert_aux = self.sim.INSERT_AUX
+        if grasp_states is None:
+            obj, hand = self.synthesize_grasp_states(synthetic_states_per_type, seed)
+            self.grasp_states_source = "synthetic"
+        else:
+            obj, hand = self._read_grasp_states(grasp_states)
+            self.grasp_states_source = "given"
+        self.load_grasp_states(obj, hand)
+
+    # ------------------------------------------------------------------ IS:372-375
+    @staticmethod
+    def _read_grasp_states(src):
+        if isinstance(src, str):
+            z = np.load(src)
+            return [z["obj_%d" % t] for t in range(8)], [z["hand_%d" % t] for t in range(8)]
+        obj, hand = src
+        if isinstance(obj, str):                                               # the reference's two pickle files
+            with open(obj, "rb") as f:
+                obj = pickle.load(f)
+            with open(hand, "rb") as f:
+                hand = pickle.load(f)
+        return obj, hand
+
+    def load_grasp_states(self, obj, hand):
+        """obj: 8 arrays [K_t, 1, 13] (or [K_t, 13]); hand: 8 arrays [K_t, 23, 2]; written into the library's terminal-state rings."""
+        s = self.sim
+        cnt = torch.zeros(8, dtype=torch.int32)
+        for t in range(8):
+            o = torch.as_tensor(np.asarray(obj[t].cpu() if torch.is_tensor(obj[t]) else obj[t]), dtype=torch.float32).reshape(-1, 13)
+            h = torch.as_tensor(np.asarray(hand[t].cpu() if torch.is_tensor(hand[t]) else hand[t]), dtype=torch.float32).reshape(-1, 23, 2)
+            k = min(o.shape[0], h.shape[0], _abi.HARVEST_SLOTS)
+            if k == 0:
+                raise ValueError("BlockAssemblyInsertSim: no grasp terminal states for brick-type group %d" % t)
+            s.HARVEST_OBJ[t, :k] = o[:k].to(self.device)
+            s.HARVEST_HAND[t, :k] = h[:k].to(self.device)
+            cnt[t] = k
+        s.HARVEST_COUNT.copy_(cnt.to(self.device))
+        torch.cuda.synchronize()
+
+    def synthesize_grasp_states(self, k, seed=22):
+        """kinematic stand-ins for harvested grasp states: arm at GraspSim's last waypoint (GS:281) with small joint noise, fingers
+        closed to about half their range, brick at the centroid of the four fingertips with the hand base's orientation.  Uses the
+        library's forward kinematics (sdx_refresh_kinematics); the joint state of the envs is restored afterwards."""
+        s, n = self.sim, self.num_envs
+        g = torch.Generator().manual_seed(seed + 77)
+        lo = torch.as_tensor(s.scene.lower, dtype=torch.float32)
+        hi = torch.as_tensor(s.scene.upper, dtype=torch.float32)
+        saved = s.DOF.clone()
+        obj = [[] for _ in range(8)]
+        hand = [[] for _ in range(8)]
+        tips = list(s.scene.fingertip_bodies)
+        need = 8 * k
+        while sum(len(x) for x in obj) < need:
+            q = torch.zeros(n, 23)
+            q[:, :7] = torch.tensor(s.scene.insert_pose_b) + 0.03 * (torch.rand(n, 7, generator=g) * 2 - 1)
+            q[:, 7:] = lo[7:] + (hi[7:] - lo[7:]) * (0.45 + 0.2 * torch.rand(n, 16, generator=g))
+            q = torch.maximum(torch.minimum(q, hi), lo)
+            dof = torch.zeros(n, 23, 2)
+            dof[:, :, 0] = q
+            s.DOF.copy_(dof.view(-1, 2).to(self.device))
+            s.refresh_kinematics()
+            torch.cuda.synchronize()
+            rb = s.RB.cpu()
+            centre = rb[:, tips, 0:3].mean(dim=1)
+            for e in range(n):
+                t = e % 8
+                if len(obj[t]) >= k:
+                    continue
+                st = torch.zeros(13)
+                st[0:3] = centre[e]
+                st[3:7] = rb[e, s.scene.hand_base_body, 3:7]
+                obj[t].append(st)
+                hand[t].append(dof[e].clone())
+        s.DOF.copy_(saved)
+        s.refresh_kinematics()
+        torch.cuda.synchronize()
+        return [torch.stack(o).unsqueeze(1) for o in obj], [torch.stack(h) for h in hand]

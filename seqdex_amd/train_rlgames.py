@@ -16,6 +16,7 @@ def main(argv=None):
     from .config import get_args, load_cfg, set_seed
     from .tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
     from .tasks.block_assembly_orient import BlockAssemblyOrient
+    from .tasks.block_assembly_insert_sim import BlockAssemblyInsertSim
     from .vec_task_rlgames import RLgamesVecTaskPython
     args = get_args(argv)
     args.algo = "lego"                                                                    # TR:36
@@ -32,7 +33,8 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))       # RCCL over xGMI
     cfg["env"]["test"] = args.play                                                        # TR:68
     set_seed(seed + rank, args.torch_deterministic)                                       # TR:70 (+ rank, App. C)
-    task_cls = {"BlockAssemblyGraspSim": BlockAssemblyGraspSim, "BlockAssemblyOrient": BlockAssemblyOrient}[args.task]   # eval(args.task), PT:162
+    task_cls = {"BlockAssemblyGraspSim": BlockAssemblyGraspSim, "BlockAssemblyOrient": BlockAssemblyOrient,
+                "BlockAssemblyInsertSim": BlockAssemblyInsertSim}[args.task]   # eval(args.task), PT:162
     task = task_cls(cfg, None, None, "cuda", local_rank, True, seed=seed + rank)                   # PT:162-170
     env = RLgamesVecTaskPython(task, args.rl_device)                                      # PT:178
     rl = cfg_train                                                                        # TR:78-85

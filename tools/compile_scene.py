@@ -237,6 +237,24 @@ def compile_bricks():
     return out, plate
 
 
+def compile_insert_plates():
+    """InsertSim's three base plates (IS:750-767, env % 3).  A brick seats with its origin 0.0375 (1 + k) above the plate origin
+    (IS:1123-1125), i.e. its body rests on the plate BODY; the studs that the V-HACD hulls engage are not representable by a box, so
+    the collision box is the body without the stud layer (stud height = the bricks' own: bounding-box top minus the 0.01875 body top)."""
+    stud = None
+    out = []
+    for name in ["4x4x1_real", "4x4x2_real", "4x4x4_real"]:
+        v = load_stl(os.path.join(REF, "blender/assets_for_insertion/origin_obj", name, name + ".stl")) * 0.01
+        lo, hi = v.min(0), v.max(0)
+        if stud is None:
+            stud = float(hi[2] - 0.01875)
+        top = float(hi[2]) - stud
+        out.append({"name": name, "half": [float(hi[0] - lo[0]) / 2, float(hi[1] - lo[1]) / 2, (top - float(lo[2])) / 2],
+                    "center": [float(lo[0] + hi[0]) / 2, float(lo[1] + hi[1]) / 2, (top + float(lo[2])) / 2],
+                    "bbox_lo": lo.tolist(), "bbox_hi": hi.tolist()})
+    return out
+
+
 def main():
     bodies, dof = compile_robot()
     bricks, plate = compile_bricks()
@@ -299,6 +317,7 @@ def main():
         "robot": {"base_pos": [-0.35, 0.0, 0.6], "base_quat": [0, 0, 0, 1], "bodies": bodies, "dof": dof,
                   "hand_base_body": 7, "fingertip_bodies": None, "arm_contact_bodies": [1, 2, 3, 4, 5, 6]},
         "brick_types": bricks, "base_plate": plate, "base_plate_pos": [0.25, -0.19, 0.618],
+        "insert_plates": compile_insert_plates(), "insert_plate_pos": [0.25, -0.2, 0.618],      # IS:1438-1440
         "statics": statics, "fixed_bricks": fixed_bricks, "free_spawn": free_spawn,
         "camera_offset_quat": cam_q, "camera_offset_pos": [0.03, 0.107 - 0.098, 0.067 + 0.107],
         "vestigial_object_pos": [0.0, 0.0, -10.78], "vestigial_goal_pos": [-0.2, -0.06, -10.78 - 10.12 - 0.04],
