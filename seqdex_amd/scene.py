@@ -134,6 +134,8 @@ class Scene:
             self._place_insert_plates(d)
         return d
 
+    INSERT_PLATE_MARGIN = 0.004
+
     def _place_insert_plates(self, d):
         """BlockAssemblyInsertSim: the base plate actor sits at (0.25, -0.2, 0.618) (IS:1438-1440; the torch_rand_int(0, 1) offsets
         are always 0) and is one of 4x4x{1,2,4} by env % 3 (IS:971-977).  The plate is square, so the 0 / 90 degree yaw drawn at each
@@ -144,7 +146,11 @@ class Scene:
         d.base_plate_pos[:] = pos
         p0 = raw["insert_plates"][0]
         d.static_center[ps][:] = [pos[0] + p0["center"][0], pos[1] + p0["center"][1], pos[2] + p0["center"][2]]
-        d.static_half[ps][:] = p0["half"]
+        # bricks that end flush with the plate edge (the 1x4 brick spans it; the 1x3 brick of the env % 8 == 5 rule ends on it) would
+        # touch the plate's SIDE faces with their corner samples and get no vertical support from the sampled box contacts
+        # (DESIGN.md section 3); the body box is widened by 4 mm per side so that those corners land on the top face
+        m = self.INSERT_PLATE_MARGIN
+        d.static_half[ps][:] = [p0["half"][0] + m, p0["half"][1] + m, p0["half"][2]]
         d.static_var_slot = ps
         for k, pl in enumerate(raw["insert_plates"]):
             d.static_var_center_z[k] = pos[2] + pl["center"][2]

@@ -78,20 +78,21 @@ class BlockAssemblyInsertSim(BlockAssemblyGraspSim):
         s.HARVEST_COUNT.copy_(cnt.to(self.device))
         torch.cuda.synchronize()
 
-    def synthesize_grasp_states(self, k, seed=22):
-        """kinematic stand-ins for harvested grasp states: arm at GraspSim's last waypoint (GS:281) with small joint noise, fingers
-        closed to about half their range, brick at the centroid of the four fingertips with the hand base's orientation.  Uses the
-        library's forward kinematics (sdx_refresh_kinematics); the joint state of the envs is restored afterwards."""
+    def synthesize_grasp_states(self, k, seed=22, servo_steps=40):
+        """stand-ins for harvested grasp states: the arm starts at GraspSim's last waypoint (GS:281) with small joint noise and the
+        fingers closed to about half their range; the task's own controller (zero position action: the IK only servoes the wrist to
+        the target orientation, IS:1537-1543) then runs `servo_steps` simulator steps so that the states start episodes with a small
+        wrist error, as states harvested from a trained grasp policy do.  The brick is put at the centroid of the four fingertips with
+        the hand base's orientation.  Only library calls are used (sdx_pre_physics / sdx_simulate); the envs are restored afterwards."""
         s, n = self.sim, self.num_envs
         g = torch.Generator().manual_seed(seed + 77)
         lo = torch.as_tensor(s.scene.lower, dtype=torch.float32)
         hi = torch.as_tensor(s.scene.upper, dtype=torch.float32)
-        saved = s.DOF.clone()
+        saved = [t.clone() for t in (s.DOF, s.RESET, s.TARGETS, s.PREV_TARGETS, s.ROOT)]
         obj = [[] for _ in range(8)]
         hand = [[] for _ in range(8)]
         tips = list(s.scene.fingertip_bodies)
-        need = 8 * k
-        while sum(len(x) for x in obj) < need:
+        while min(len(x) for x in obj) < k:
             q = torch.zeros(n, 23)
             q[:, :7] = torch.tensor(s.scene.insert_pose_b) + 0.03 * (torch.rand(n, 7, generator=g) * 2 - 1)
             q[:, 7:] = lo[7:] + (hi[7:] - lo[7:]) * (0.45 + 0.2 * torch.rand(n, 16, generator=g))
@@ -99,20 +100,32 @@ class BlockAssemblyInsertSim(BlockAssemblyGraspSim):
             dof = torch.zeros(n, 23, 2)
             dof[:, :, 0] = q
             s.DOF.copy_(dof.view(-1, 2).to(self.device))
+            s.TARGETS.copy_(q.to(self.device))
+            s.PREV_TARGETS.copy_(q.to(self.device))
+            s.RESET.zero_()
             s.refresh_kinematics()
+            a = torch.zeros(n, 23)
+            a[:, 7:] = (2 * q[:, 7:] - hi[7:] - lo[7:]) / (hi[7:] - lo[7:])      # unscale: the finger targets stay where they are
+            a = a.to(self.device)
+            for _ in range(servo_steps):
+                s.pre_physics(a)
+                s.simulate()
             torch.cuda.synchronize()
             rb = s.RB.cpu()
+            dof = s.DOF.view(n, 23, 2).cpu().clone()
+            dof[:, :, 1] = 0
             centre = rb[:, tips, 0:3].mean(dim=1)
             for e in range(n):
                 t = e % 8
-                if len(obj[t]) >= k:
+                if len(obj[t]) >= k or not torch.isfinite(dof[e]).all():
                     continue
                 st = torch.zeros(13)
                 st[0:3] = centre[e]
                 st[3:7] = rb[e, s.scene.hand_base_body, 3:7]
                 obj[t].append(st)
                 hand[t].append(dof[e].clone())
-        s.DOF.copy_(saved)
+        for dst, src in zip((s.DOF, s.RESET, s.TARGETS, s.PREV_TARGETS, s.ROOT), saved):
+            dst.copy_(src)
         s.refresh_kinematics()
         torch.cuda.synchronize()
         return [torch.stack(o).unsqueeze(1) for o in obj], [torch.stack(h) for h in hand]

@@ -200,8 +200,6 @@ def test_insert_plate_variants_match_c_oracle_and_seat_the_brick():
         torch.cuda.synchronize()
         r_gpu = s.ROOT.cpu().numpy().reshape(n, 142, 13)
         for e in range(n):
-            if e % 8 == 5:      # the 1x3 brick of these envs gets the 1x1 offset (IS:794-795): one end flush with the plate edge, where
-                continue        # the sampled box contacts lose the end samples and it slowly tips over
             assert abs(r_gpu[e, seg[e], 2] - site[e, 2]) < 0.004, (e, r_gpu[e, seg[e], 2], site[e, 2])
             assert np.abs(r_gpu[e, seg[e], 0:2] - site[e, 0:2]).max() < 0.01
     finally:
@@ -236,6 +234,8 @@ def test_insert_task_end_to_end(scene):
     assert np.isfinite(obs["obs"].cpu().numpy()).all() and np.isfinite(rews).all()
     assert (rews > 0).all() and (rews <= 2.0).all()
     assert resets_seen >= n                                      # every env finished at least one episode (time-out at 124 at the latest)
+    assert resets_seen < 12 * n                                  # ... and episodes are not cut at once: the synthetic states start with
+                                                                 # the wrist near its target orientation and the fingers around the brick
     assert not obs["states"][:, 188:].any()
     r = task.sim.ROOT.cpu().numpy().reshape(n, 142, 13)
     assert np.isfinite(r).all()

@@ -1,5 +1,8 @@
 """CPU tests of the host-side mirrors: flag/config semantics (utils/config.py), scene constants, VecTask surface."""
+import os
+
 import numpy as np
+import yaml
 import pytest
 
 
@@ -61,3 +64,27 @@ def test_vec_task_surface_without_gpu():
     with pytest.raises(ValueError):
         VecTask(T(), "cpu", clip_observations=3.0)
     assert issubclass(RLgamesVecTaskPython, VecTask)
+
+
+def test_insert_sim_scene_desc_places_three_plate_variants(scene):
+    """BlockAssemblyInsertSim (task_kind 2): plate actor at (0.25, -0.2, 0.618) (IS:1438-1440), static box 7 = stud-less plate body
+    whose z extent depends on env % 3 (4x4x{1,2,4}, IS:971-977); a seated brick's origin is exactly at the insertion site."""
+    d = scene.to_desc(task_kind=2)
+    assert d.abi_version == 3 and d.static_var_slot == 7 and d.n_static == 8
+    np.testing.assert_allclose(list(d.base_plate_pos), [0.25, -0.2, 0.618], atol=1e-7)
+    np.testing.assert_allclose(list(d.static_center[7])[:2], [0.25, -0.2], atol=1e-7)
+    assert abs(d.static_half[7][0] - (0.06 + scene.INSERT_PLATE_MARGIN)) < 1e-6
+    for k in range(3):
+        top = d.static_var_center_z[k] + d.static_var_half_z[k]
+        assert abs(top + 0.01875 - (0.618 + 0.0375 * (1 + k))) < 6e-4          # body top + half a brick body = site height
+        assert abs(d.static_var_center_z[k] - d.static_var_half_z[k] - (0.618 - 0.01875)) < 1e-6
+    g = scene.to_desc()                                                       # GraspSim keeps its single plate
+    assert g.static_var_slot == -1 and abs(g.static_center[7][1] + 0.19) < 1e-6
+
+
+def test_launcher_maps_the_three_tasks():
+    from seqdex_amd import config
+    assert set(config.TASK_CFG) == {"BlockAssemblyGraspSim", "BlockAssemblyOrient", "BlockAssemblyInsertSim"}
+    for t, rel in config.TASK_CFG.items():
+        cfg = yaml.safe_load(open(os.path.join(os.path.dirname(config.__file__), rel)))
+        assert cfg["env"]["episodeLength"] == {"BlockAssemblyGraspSim": 150, "BlockAssemblyOrient": 75, "BlockAssemblyInsertSim": 125}[t]

@@ -4,7 +4,13 @@ from seqdex_amd.tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
 from seqdex_amd.vec_task_rlgames import RLgamesVecTaskPython
 from seqdex_amd.a2c_agent import A2CAgent
 n=int(sys.argv[1]) if len(sys.argv)>1 else 1024
-cfg=yaml.safe_load(open('seqdex_amd/cfg/allegro_hand_block_assembly_grasp_sim.yaml')); cfg['env']['numEnvs']=n
+task_name=sys.argv[3] if len(sys.argv)>3 else 'BlockAssemblyGraspSim'
+if task_name=='BlockAssemblyInsertSim':
+    from seqdex_amd.tasks.block_assembly_insert_sim import BlockAssemblyInsertSim as BlockAssemblyGraspSim
+elif task_name=='BlockAssemblyOrient':
+    from seqdex_amd.tasks.block_assembly_orient import BlockAssemblyOrient as BlockAssemblyGraspSim
+from seqdex_amd.config import TASK_CFG
+cfg=yaml.safe_load(open('seqdex_amd/'+TASK_CFG[task_name])); cfg['env']['numEnvs']=n
 tr=yaml.safe_load(open('seqdex_amd/cfg/lego/ppo_continuous_grasp.yaml'))
 t0=time.time()
 task=BlockAssemblyGraspSim(cfg, device_type='cuda', device_id=0, headless=True, piles_per_type=4)
