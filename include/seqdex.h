@@ -308,7 +308,9 @@ int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const int64
 int sdxp_update(sdxp_handle h, void* stream);
 /* Which implementation sdxp_update runs on this handle: 1 = persistent kernel (one launch per epoch, weights and Adam moments
  * resident in the VGPR files of 256 CUs; needs the shipped shapes, minibatch_size 4 and a 256-CU device), 0 = hipGraph of the
- * multi-kernel optimiser step (any minibatch_size in {2,4,8}; forced with SDXP_UPDATE_IMPL=graph). */
+ * multi-kernel optimiser step (any minibatch_size in {2,4,8}; forced with SDXP_UPDATE_IMPL=graph), 2 = GEMM-shaped step for
+ * minibatch_size > 8 (cfg/lego/ppo_continuous_insert.yaml: 4096): fp32-MFMA forward / data-gradient / weight-gradient GEMMs,
+ * explicit flat gradients, clip_grad_norm_ + Adam (sdxp_bigmb.hip). */
 int sdxp_update_impl(sdxp_handle h);
 /* Waits for the update launched on `stream`.  SDX_OK, or SDX_ERR_STATE when the persistent kernel timed out (its 256 workgroups were
  * not co-resident): nothing was applied, the inputs it had touched are restored and the handle has switched to the hipGraph

@@ -152,7 +152,7 @@ class A2CAgent:
         import torch.distributed as dist
         ppo = self.ppo
         nmb = self.batch_size // self.minibatch_size
-        if "FACTORS" in ppo.t and hasattr(ppo, "backward_factors"):
+        if "FACTORS" in ppo.t and hasattr(ppo, "backward_factors") and self.minibatch_size <= 8:
             # preferred: all-gather the rank-MB factors (194 KB per rank) and rebuild the summed gradient locally
             fact, fact_all = ppo.t["FACTORS"], ppo.t["FACTORS_ALL"]
             ppo.backward_factors(-1)
@@ -166,6 +166,7 @@ class A2CAgent:
         ppo.backward(0, -1)
         if "ALL_GRADS" in ppo.t:
             # one collective per optimiser step: both flat gradients and the KL word share one library-owned buffer
+            # (this is also the large-minibatch path: with thousands of samples per step the gradient IS the small object)
             g_all = ppo.t["ALL_GRADS"]
             for _ in range(self.mini_epochs_num):
                 for mb in range(nmb):

@@ -1,0 +1,435 @@
+// sdxp_bigmb.hip — large-minibatch PPO optimiser step (minibatch_size > 8) for gfx950.
+//
+// The reference trains the insert policy with minibatch_size 4096 (cfg/lego/ppo_continuous_insert.yaml:50,75) and BASELINE.md asks
+// for a labelled large-minibatch variant next to the shipped minibatch of 4.  With thousands of samples per step the update is
+// GEMM-shaped, not the rank-MB weight streaming of sdxp_kernels.hip / sdxp_persist.hip: forward Y = ELU(X W^T + b), data gradient
+// dX = (dY W) * ELU'(H), weight gradient G = dY^T X, all three on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// k-ordered fma chain), LDS-tiled 64x64x16 per 256-thread workgroup (4 waves of 32x32).  rl_games' calc_gradients
+// (a2c_continuous.py / RC:1796-1877) + CentralValueTrain.train_net for all three networks of one minibatch:
+//
+//   forward 3 nets x 3 trunk layers (NT GEMM, bias + ELU fused) -> mu head (NT GEMM) + two value heads (row dots)
+//   k_big_head: per-sample PPO losses and their head gradients (same formulas as k_head of sdxp_kernels.hip), block partials
+//   k_big_fin:  statistics, d logstd, KL word, minibatch bookkeeping of the control block
+//   backward: head data gradients, then per net  G_l = dY_l^T X_l (TN GEMM, split over the minibatch rows, partials reduced in a
+//   fixed order: deterministic), b_l = column sums of dY_l, dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1}) (NN GEMM, fused)
+//   -> flat gradients in ac_g / cv_g (parameter layout), then the explicit clip + Adam of sdxp_kernels.hip (k_sqnorm2 / k_adam2).
+//
+// The central-value input normalisation (RunningMeanStd in train mode: update with the minibatch, then normalise it, during
+// mini-epoch 0; frozen afterwards) is hoisted out of the loop as in the small-minibatch path, with column statistics reduced in fp64.
+#include "sdx_common.h"
+#include "sdxp_types.h"
+#include <cstddef>
+#include <cstdint>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TB 64   // output tile
+#define TK 16   // reduction chunk staged through LDS
+
+__device__ __forceinline__ float belu(float x) { return x > 0.0f ? x : expm1f(x); }
+__device__ __forceinline__ float belu_grad_from_out(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }
+
+// four consecutive floats p[0..3] of which the first `valid` exist; one 16-byte load when possible
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int valid) {
+  if (valid >= 4 && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)) return *reinterpret_cast<const float4*>(p);
+  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (valid > 0) v.x = p[0];
+  if (valid > 1) v.y = p[1];
+  if (valid > 2) v.z = p[2];
+  if (valid > 3) v.w = p[3];
+  return v;
+}
+
+struct GemmArgs {
+  const float* A; int lda;      // AT == 0: A[i][k] (k contiguous); AT == 1: stored [k][i] (i contiguous)
+  const float* B; int ldb;      // BT == 0: B stored [j][k] (k contiguous); BT == 1: stored [k][j] (j contiguous)
+  float* C; int ldc;            // C[i][j]; split z writes to C + z * cz
+  size_t cz;
+  int M, N, K, kchunk;          // reduction range of split z: [z * kchunk, min(K, (z + 1) * kchunk))
+  const float* bias;            // EPI 1/2: bias[j]
+  const float* H; int ldh;      // EPI 3: C = acc * ELU'(H[i][j]) with H the layer OUTPUT
+};
+
+// EPI: 0 none, 1 bias + ELU, 2 bias, 3 times ELU'(H)
+template <int AT, int BT, int EPI>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+  __shared__ float As[TB][TK + 1];
+  __shared__ float Bs[TB][TK + 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i0 = blockIdx.y * TB, j0 = blockIdx.x * TB;
+  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;      // k-contiguous sources: row lr, k offset lk
+  const int kr = tid >> 4, li = (tid & 15) * 4;     // transposed sources: k row kr, i/j offset li
+  for (int k0 = kbeg; k0 < kend; k0 += TK) {
+    float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+    if (AT == 0) { if (i0 + lr < g.M && k0 + lk < kend) av = load4(g.A + (size_t)(i0 + lr) * g.lda + k0 + lk, kend - (k0 + lk)); }
+    else         { if (k0 + kr < kend && i0 + li < g.M) av = load4(g.A + (size_t)(k0 + kr) * g.lda + i0 + li, g.M - (i0 + li)); }
+    if (BT == 0) { if (j0 + lr < g.N && k0 + lk < kend) bv = load4(g.B + (size_t)(j0 + lr) * g.ldb + k0 + lk, kend - (k0 + lk)); }
+    else         { if (k0 + kr < kend && j0 + li < g.N) bv = load4(g.B + (size_t)(k0 + kr) * g.ldb + j0 + li, g.N - (j0 + li)); }
+    __syncthreads();
+    if (AT == 0) { As[lr][lk] = av.x; As[lr][lk + 1] = av.y; As[lr][lk + 2] = av.z; As[lr][lk + 3] = av.w; }
+    else         { As[li][kr] = av.x; As[li + 1][kr] = av.y; As[li + 2][kr] = av.z; As[li + 3][kr] = av.w; }
+    if (BT == 0) { Bs[lr][lk] = bv.x; Bs[lr][lk + 1] = bv.y; Bs[lr][lk + 2] = bv.z; Bs[lr][lk + 3] = bv.w; }
+    else         { Bs[li][kr] = bv.x; Bs[li + 1][kr] = bv.y; Bs[li + 2][kr] = bv.z; Bs[li + 3][kr] = bv.w; }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; kk += 2) {
+      const float a = As[wm + (lane & 31)][kk + (lane >> 5)];
+      const float b = Bs[wn + (lane & 31)][kk + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  const int col = j0 + wn + (lane & 31);
+  if (col >= g.N) return;
+  float* C = g.C + (size_t)blockIdx.z * g.cz;
+  const float bias = (EPI == 1 || EPI == 2) ? g.bias[col] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = i0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < g.M) {
+      float v = acc[r] + bias;
+      if (EPI == 1) v = belu(v);
+      if (EPI == 3) v *= belu_grad_from_out(g.H[(size_t)row * g.ldh + col]);
+      C[(size_t)row * g.ldc + col] = v;
+    }
+  }
+}
+
+// column sums of Y[M][N] (ld) over the row range of split blockIdx.y -> out[blockIdx.y * oz + n]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ Y, int ld, int M, int N, int rchunk, float* __restrict__ out, size_t oz) {
+  __shared__ float s[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int rbeg = blockIdx.y * rchunk, rend = min(M, rbeg + rchunk);
+  float a = 0.0f;
+  if (c < N)
+    for (int r = rbeg + rg; r < rend; r += 4) a += Y[(size_t)r * ld + c];
+  s[rg][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rg == 0 && c < N) out[(size_t)blockIdx.y * oz + c] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+// out[i] = sum_z part[z * pz + i] in fixed order
+__global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ part, size_t pz, int S, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float a = 0.0f;
+    for (int z = 0; z < S; ++z) a += part[(size_t)z * pz + i];
+    out[i] = a;
+  }
+}
+
+// value heads: v[m] = H[m] . w + b (wave per row, U = 256: one float4 per lane)
+__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ H, int U, int M, const float* __restrict__ w, const float* __restrict__ b,
+                                                float* __restrict__ v) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float a = 0.0f;
+  for (int k = lane; k < U; k += 64) a += H[(size_t)row * U + k] * w[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) v[row] = a + b[0];
+}
+// dY2[m][k] = dv[m] * w[k] * ELU'(H[m][k])
+__global__ __launch_bounds__(256) void k_vhead_back(const float* __restrict__ dv, const float* __restrict__ w, const float* __restrict__ H, int U,
+                                                    int M, float* __restrict__ dY) {
+  const size_t n = (size_t)M * U;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / U), k = (int)(i % U);
+    dY[i] = dv[m] * w[k] * belu_grad_from_out(H[i]);
+  }
+}
+// value-head weight gradient partials: out[z][k] = sum_{m in split z} dv[m] H[m][k]; out[z][U] = sum dv
+__global__ __launch_bounds__(256) void k_vhead_wgrad(const float* __restrict__ dv, const float* __restrict__ H, int U, int M, int rchunk,
+                                                     float* __restrict__ out, size_t oz) {
+  const int k = threadIdx.x;            // U == 256
+  const int rbeg = blockIdx.x * rchunk, rend = min(M, rbeg + rchunk);
+  float a = 0.0f, sb = 0.0f;
+  for (int m = rbeg; m < rend; ++m) { const float d = dv[m]; a += d * H[(size_t)m * U + k]; sb += d; }
+  out[(size_t)blockIdx.x * oz + k] = a;
+  if (k == 0) out[(size_t)blockIdx.x * oz + U] = sb;
+}
+
+// ------------------------------------------------------------------------------------------------ losses
+// thread = sample s of the minibatch (dataset row r0 + s).  Formulas as k_head of sdxp_kernels.hip (RC:1796-1830, 2114-2126):
+// Gaussian neglogp, clipped surrogate, (clipped) value losses of the critic and the central value, bound loss, KL to the stored
+// mu/sigma.  Writes dmu [MB][24] (column 23 = 0), dv [2][MB], the refreshed mu/sigma rows (RC:1358) and block partials
+// part[block][40]: 0..22 d logstd, 32..37 the six loss sums.
+#define BIGP 40
+__global__ __launch_bounds__(256) void k_big_head(SdxpDev D, size_t r0, int MB, const float* __restrict__ mu, const float* __restrict__ vc,
+                                                  const float* __restrict__ vcv, float* __restrict__ dmu, float* __restrict__ dv,
+                                                  float* __restrict__ part) {
+  __shared__ float s_red[4][BIGP];
+  const int s = blockIdx.x * 256 + threadIdx.x, A = D.act_dim, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = s < MB;
+  const float invM = 1.0f / (float)MB;
+  float nlp = 0.0f, kl = 0.0f, bl = 0.0f, ent = 0.0f, gnlp = 0.0f;
+  float stat[6] = {0, 0, 0, 0, 0, 0};
+  const float* ls_p = D.ac + D.off.logstd;
+  if (live) {
+    const size_t r = r0 + s;
+    for (int a = 0; a < A; ++a) {
+      const float ls = ls_p[a], sg = expf(ls), m = mu[(size_t)s * 24 + a];
+      const float z = (D.mb_actions[r * A + a] - m) / sg;
+      nlp += 0.5f * z * z + ls;
+      const float omu = D.mb_mus[r * A + a], osg = D.mb_sigmas[r * A + a];
+      kl += logf(osg / sg + 1e-5f) + (sg * sg + (omu - m) * (omu - m)) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
+      const float hi = fmaxf(m - 1.1f, 0.0f), lo = fminf(m + 1.1f, 0.0f);
+      bl += hi * hi + lo * lo;
+      ent += 0.5f + 0.5f * 1.8378770664093453f + ls;
+    }
+    nlp += 0.5f * 1.8378770664093453f * (float)A;
+    const float adv = D.adv[r];
+    const float ratio = expf(D.mb_neglogp[r] - nlp);
+    const float L1 = -adv * ratio, L2 = -adv * clampf(ratio, 1.0f - D.e_clip, 1.0f + D.e_clip);
+    const bool inr = ratio >= 1.0f - D.e_clip && ratio <= 1.0f + D.e_clip;
+    gnlp = (L1 > L2 || inr) ? adv * ratio : 0.0f;
+    const float R = D.returns[r], vo = D.mb_values[r];
+    float closs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float v = j == 0 ? vc[s] : vcv[s];
+      const float vcl = vo + clampf(v - vo, -D.e_clip, D.e_clip);
+      const float c1 = (v - R) * (v - R), c2 = (vcl - R) * (vcl - R);
+      float d;
+      if (D.clip_value) {
+        closs[j] = fmaxf(c1, c2);
+        const bool inv = fabsf(v - vo) <= D.e_clip;
+        d = (c1 > c2 || inv) ? 2.0f * (v - R) : 0.0f;
+      } else { closs[j] = c1; d = 2.0f * (v - R); }
+      dv[(size_t)j * MB + s] = (j == 0 ? 0.5f * D.critic_coef : 1.0f) * d * invM;
+    }
+    stat[0] = fmaxf(L1, L2); stat[1] = closs[0]; stat[2] = bl; stat[3] = kl; stat[4] = closs[1]; stat[5] = ent;
+  }
+  // head gradients + d logstd partial sums (one wave reduction per action)
+  for (int a = 0; a < 24; ++a) {
+    float dls = 0.0f;
+    if (live) {
+      float d = 0.0f;
+      if (a < A) {
+        const size_t r = r0 + s;
+        const float ls = ls_p[a], sg = expf(ls), m = mu[(size_t)s * 24 + a];
+        const float z = (D.mb_actions[r * A + a] - m) / sg;
+        const float hi = fmaxf(m - 1.1f, 0.0f), lo = fminf(m + 1.1f, 0.0f);
+        d = gnlp * (-(z / sg)) * invM + D.bounds_coef * (2.0f * hi + 2.0f * lo) * invM;
+        dls = gnlp * (1.0f - z * z) * invM;
+        D.mb_mus[r * A + a] = m;
+        D.mb_sigmas[r * A + a] = sg;
+      }
+      dmu[(size_t)s * 24 + a] = d;
+    }
+    if (a < A) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dls += __shfl_xor(dls, o, 64);
+      if (lane == 0) s_red[wave][a] = dls;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float t = stat[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) s_red[wave][32 + j] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < BIGP) {
+    const int j = threadIdx.x;
+    const bool used = j < A || (j >= 32 && j < 38);
+    part[(size_t)blockIdx.x * BIGP + j] = used ? (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]) : 0.0f;
+  }
+}
+// one block: fold the block partials, write d logstd into the flat gradient, the KL word, the loss sums and advance the minibatch
+// cursor of the control block (what k_ctrl does in explicit mode for the small-minibatch path)
+__global__ __launch_bounds__(64) void k_big_fin(SdxpDev D, int nblocks, int MB, const float* __restrict__ part) {
+  __shared__ float s_t[BIGP];
+  const int j = threadIdx.x;
+  if (j < BIGP) {
+    float t = 0.0f;
+    for (int b = 0; b < nblocks; ++b) t += part[(size_t)b * BIGP + j];
+    s_t[j] = t;
+  }
+  __syncthreads();
+  if (j < D.act_dim) D.ac_g[D.off.logstd + j] = s_t[j] - D.entropy_coef;   // d(-coef * mean entropy)/d logstd = -coef
+  if (j == 0) {
+    SdxpCtrl* ctl = D.ctrl;
+    const float invM = 1.0f / (float)MB;
+    const float kl = s_t[35] * invM;
+    for (int q = 0; q < 6; ++q) ctl->acc[1 + q] = s_t[32 + q];
+    ctl->sum_a_loss += s_t[32] * invM; ctl->sum_c_loss += s_t[33] * invM; ctl->sum_b_loss += s_t[34] * invM;
+    ctl->sum_kl += kl; ctl->sum_cv_loss += s_t[36] * invM; ctl->sum_entropy += s_t[37] * invM;
+    ctl->n_mb += 1; ctl->last_kl = kl;
+    D.ac_g[D.g_tail] = kl;                        // rides with the gradients (multi-rank all-reduce), read by k_apply_fin2
+    ctl->gn2_ac = 0.0f; ctl->gn2_cv = 0.0f; ctl->ac_pending = 0; ctl->cv_pending = 0;
+    ctl->prev_mb = ctl->mb_index; ctl->prev_mini_epoch = ctl->mini_epoch;
+    int mbn = ctl->mb_index + 1;
+    if (mbn >= D.num_minibatches) { mbn = 0; ctl->mini_epoch += 1; }
+    ctl->mb_index = mbn;
+    ctl->step += 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ central-value input statistics
+// partial column sums / sums of squares (fp64) of rows [r0 + z * rchunk, ...) of mb_states
+__global__ __launch_bounds__(256) void k_big_colstats(SdxpDev D, size_t r0, int MB, int rchunk, double* __restrict__ part) {
+  __shared__ double s1[4][64], s2[4][64];
+  const int S = D.state_dim, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int rbeg = blockIdx.y * rchunk, rend = min(MB, rbeg + rchunk);
+  double a = 0.0, q = 0.0;
+  if (c < S)
+    for (int r = rbeg + rg; r < rend; r += 4) { const double x = D.mb_states[(r0 + r) * S + c]; a += x; q += x * x; }
+  s1[rg][threadIdx.x & 63] = a; s2[rg][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (rg == 0 && c < S) {
+    const int t = threadIdx.x;
+    part[((size_t)blockIdx.y * S + c) * 2 + 0] = (s1[0][t] + s1[1][t]) + (s1[2][t] + s1[3][t]);
+    part[((size_t)blockIdx.y * S + c) * 2 + 1] = (s2[0][t] + s2[1][t]) + (s2[2][t] + s2[3][t]);
+  }
+}
+// RunningMeanStd.update with the minibatch statistics (unbiased batch variance, parallel-variance merge), thread = feature
+__global__ __launch_bounds__(256) void k_big_rms_update(SdxpDev D, int MB, int nsplit, const double* __restrict__ part) {
+  const int k = blockIdx.x * 256 + threadIdx.x, S = D.state_dim;
+  if (k >= S) return;
+  double a = 0.0, q = 0.0;
+  for (int z = 0; z < nsplit; ++z) { a += part[((size_t)z * S + k) * 2]; q += part[((size_t)z * S + k) * 2 + 1]; }
+  const double bm = a / MB;
+  double bv = MB > 1 ? (q - MB * bm * bm) / (MB - 1) : 0.0;
+  if (bv < 0.0) bv = 0.0;
+  const double cnt = D.ctrl->rms_count, mean = D.rms_mean[k], var = D.rms_var[k];
+  const double delta = bm - mean, tot = cnt + MB;
+  const double m2 = var * cnt + bv * MB + delta * delta * cnt * MB / tot;
+  D.rms_mean[k] = mean + delta * MB / tot;
+  D.rms_var[k] = m2 / tot;
+}
+__global__ void k_big_rms_count(SdxpDev D, int MB) { D.ctrl->rms_count += (double)MB; }
+// dst rows = clamp((x - mean) / sqrt(var + 1e-5), +-5) of mb_states rows [r0, r0 + rows)
+__global__ __launch_bounds__(256) void k_big_normalise(SdxpDev D, size_t r0, size_t rows, float* __restrict__ dst) {
+  const int S = D.state_dim;
+  const size_t base = r0 * S, total = rows * S;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)((base + i) % S);
+    const float x = D.mb_states[base + i];
+    const float fm = (float)D.rms_mean[k], rs = sqrtf((float)D.rms_var[k] + 1e-5f);
+    dst[base + i] = D.cv_normalize_input ? clampf((x - fm) / rs, -5.0f, 5.0f) : x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct SdxpBigWs {            // device workspace, allocated by sdxp_capi.hip (sizes: sdxpk_big_ws_floats)
+  float* h[3][3];             // trunk outputs  [MB][units[l]]
+  float* dy[3][3];            // dLoss/d(pre-activation) [MB][units[l]]
+  float* mu;                  // [MB][24]
+  float* dmu;                 // [MB][24]
+  float* v;                   // [2][MB] critic / central value
+  float* dv;                  // [2][MB]
+  float* part;                // split partials (max over layers of S * (N*K + N)), also head partials
+  double* dpart;              // [nsplit][state_dim][2]
+  int MB, nsplit;
+};
+
+static int big_splits(int MB) { int s = (MB + 511) / 512; return s < 1 ? 1 : (s > 16 ? 16 : s); }
+
+extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB) {
+  const int S = big_splits(MB);
+  const size_t in0 = D->obs_dim > D->state_dim ? D->obs_dim : D->state_dim;
+  size_t mx = (size_t)D->units[0] * in0 + D->units[0];
+  const size_t l1 = (size_t)D->units[1] * D->units[0] + D->units[1], l2 = (size_t)D->units[2] * D->units[1] + D->units[2];
+  if (l1 > mx) mx = l1;
+  if (l2 > mx) mx = l2;
+  const size_t hp = (size_t)((MB + 255) / 256) * BIGP;
+  const size_t need = (size_t)S * mx;
+  return need > hp ? need : hp;
+}
+extern "C" int sdxpk_big_nsplit(int MB) { return big_splits(MB); }
+
+template <int AT, int BT, int EPI>
+static void gemm(const GemmArgs& g, int splits, hipStream_t st) {
+  dim3 grid((g.N + TB - 1) / TB, (g.M + TB - 1) / TB, splits);
+  hipLaunchKernelGGL((k_gemm<AT, BT, EPI>), grid, dim3(256), 0, st, g);
+}
+
+// central-value inputs of the whole epoch: cvx0 (statistics updated minibatch by minibatch, mini-epoch 0), cvx1 (frozen)
+extern "C" void sdxpk_big_prenorm(const SdxpDev* D, const SdxpBigWs* ws, hipStream_t st) {
+  const int MB = ws->MB, S = D->state_dim, nsplit = ws->nsplit, rchunk = (MB + nsplit - 1) / nsplit;
+  for (int mb = 0; mb < D->num_minibatches; ++mb) {
+    const size_t r0 = (size_t)mb * MB;
+    if (D->cv_normalize_input) {
+      hipLaunchKernelGGL(k_big_colstats, dim3((S + 63) / 64, nsplit), dim3(256), 0, st, *D, r0, MB, rchunk, ws->dpart);
+      hipLaunchKernelGGL(k_big_rms_update, dim3((S + 255) / 256), dim3(256), 0, st, *D, MB, nsplit, ws->dpart);
+      hipLaunchKernelGGL(k_big_rms_count, dim3(1), dim3(1), 0, st, *D, MB);
+    }
+    hipLaunchKernelGGL(k_big_normalise, dim3(1024), dim3(256), 0, st, *D, r0, (size_t)MB, D->cvx0);
+  }
+  hipLaunchKernelGGL(k_big_normalise, dim3(1024), dim3(256), 0, st, *D, (size_t)0, (size_t)D->N * D->horizon, D->cvx1);
+}
+
+// forward + losses + backward of minibatch `mb` (mini-epoch `me`) for all three networks; leaves the flat gradients in ac_g / cv_g,
+// the KL word in ac_g[g_tail] and the control block advanced.  The caller follows with the explicit clip + Adam.
+extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, int me, hipStream_t st) {
+  const SdxpDev& D = *Dp;
+  const int MB = ws->MB, A = D.act_dim, U2 = D.units[2];
+  const size_t r0 = (size_t)mb * MB;
+  const int S = ws->nsplit, rchunk = (MB + S - 1) / S;
+  for (int net = 0; net < 3; ++net) {
+    const float* P = net == 2 ? D.cv : D.ac;
+    const int in0 = net == 2 ? D.state_dim : D.obs_dim;
+    const float* X = net == 2 ? (me == 0 ? D.cvx0 : D.cvx1) + r0 * D.state_dim : D.mb_obs + r0 * D.obs_dim;
+    int in = in0;
+    for (int l = 0; l < 3; ++l) {
+      const size_t wo = net == 0 ? D.off.a_w[l] : (net == 1 ? D.off.c_w[l] : D.coff.w[l]);
+      const size_t bo = net == 0 ? D.off.a_b[l] : (net == 1 ? D.off.c_b[l] : D.coff.b[l]);
+      GemmArgs g = {X, in, P + wo, in, ws->h[net][l], D.units[l], 0, MB, D.units[l], in, in, P + bo, nullptr, 0};
+      gemm<0, 0, 1>(g, 1, st);
+      X = ws->h[net][l];
+      in = D.units[l];
+    }
+  }
+  {  // heads
+    GemmArgs g = {ws->h[0][2], U2, D.ac + D.off.mu_w, U2, ws->mu, 24, 0, MB, A, U2, U2, D.ac + D.off.mu_b, nullptr, 0};
+    gemm<0, 0, 2>(g, 1, st);
+    hipLaunchKernelGGL(k_rowdot, dim3((MB + 3) / 4), dim3(256), 0, st, ws->h[1][2], U2, MB, D.ac + D.off.v_w, D.ac + D.off.v_b, ws->v);
+    hipLaunchKernelGGL(k_rowdot, dim3((MB + 3) / 4), dim3(256), 0, st, ws->h[2][2], U2, MB, D.cv + D.coff.v_w, D.cv + D.coff.v_b, ws->v + MB);
+  }
+  const int hb = (MB + 255) / 256;
+  hipLaunchKernelGGL(k_big_head, dim3(hb), dim3(256), 0, st, D, r0, MB, ws->mu, ws->v, ws->v + MB, ws->dmu, ws->dv, ws->part);
+  hipLaunchKernelGGL(k_big_fin, dim3(1), dim3(64), 0, st, D, hb, MB, ws->part);
+  // ---- head backward: data gradients into dy[net][2], weight gradients into the flat buffers
+  {
+    GemmArgs g = {ws->dmu, 24, D.ac + D.off.mu_w, U2, ws->dy[0][2], U2, 0, MB, U2, A, A, nullptr, ws->h[0][2], U2};
+    gemm<0, 1, 3>(g, 1, st);                                             // dY2 = (dmu Wmu) * ELU'(h3)
+    hipLaunchKernelGGL(k_vhead_back, dim3(512), dim3(256), 0, st, ws->dv, D.ac + D.off.v_w, ws->h[1][2], U2, MB, ws->dy[1][2]);
+    hipLaunchKernelGGL(k_vhead_back, dim3(512), dim3(256), 0, st, ws->dv + MB, D.cv + D.coff.v_w, ws->h[2][2], U2, MB, ws->dy[2][2]);
+    // mu head: G[A][U2] = dmu^T h3, bias = column sums of dmu (A of the 24 columns); contiguous [mu_w | mu_b] in the flat layout
+    const size_t pz = (size_t)A * U2 + A;
+    GemmArgs gw = {ws->dmu, 24, ws->h[0][2], U2, ws->part, U2, pz, A, U2, MB, rchunk, nullptr, nullptr, 0};
+    gemm<1, 1, 0>(gw, S, st);
+    hipLaunchKernelGGL(k_colsum, dim3(1, S), dim3(256), 0, st, ws->dmu, 24, MB, A, rchunk, ws->part + (size_t)A * U2, pz);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(32), dim3(256), 0, st, ws->part, pz, S, pz, D.ac_g + D.off.mu_w);
+    // value heads: [v_w | v_b] contiguous
+    hipLaunchKernelGGL(k_vhead_wgrad, dim3(S), dim3(256), 0, st, ws->dv, ws->h[1][2], U2, MB, rchunk, ws->part, (size_t)U2 + 1);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, ws->part, (size_t)U2 + 1, S, (size_t)U2 + 1, D.ac_g + D.off.v_w);
+    hipLaunchKernelGGL(k_vhead_wgrad, dim3(S), dim3(256), 0, st, ws->dv + MB, ws->h[2][2], U2, MB, rchunk, ws->part, (size_t)U2 + 1);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, ws->part, (size_t)U2 + 1, S, (size_t)U2 + 1, D.cv_g + D.coff.v_w);
+  }
+  // ---- trunk backward
+  for (int net = 0; net < 3; ++net) {
+    const float* P = net == 2 ? D.cv : D.ac;
+    float* G = net == 2 ? D.cv_g : D.ac_g;
+    const int in0 = net == 2 ? D.state_dim : D.obs_dim;
+    const float* X0 = net == 2 ? (me == 0 ? D.cvx0 : D.cvx1) + r0 * D.state_dim : D.mb_obs + r0 * D.obs_dim;
+    for (int l = 2; l >= 0; --l) {
+      const size_t wo = net == 0 ? D.off.a_w[l] : (net == 1 ? D.off.c_w[l] : D.coff.w[l]);
+      const int Nl = D.units[l], Kl = l == 0 ? in0 : D.units[l - 1];
+      const float* Xl = l == 0 ? X0 : ws->h[net][l - 1];
+      const size_t pz = (size_t)Nl * Kl + Nl;                             // [W_l | b_l] contiguous in the flat layout
+      GemmArgs gw = {ws->dy[net][l], Nl, Xl, Kl, ws->part, Kl, pz, Nl, Kl, MB, rchunk, nullptr, nullptr, 0};
+      gemm<1, 1, 0>(gw, S, st);                                           // G_l = dY_l^T X_l
+      hipLaunchKernelGGL(k_colsum, dim3((Nl + 63) / 64, S), dim3(256), 0, st, ws->dy[net][l], Nl, MB, Nl, rchunk, ws->part + (size_t)Nl * Kl, pz);
+      hipLaunchKernelGGL(k_reduce_parts, dim3(512), dim3(256), 0, st, ws->part, pz, S, pz, G + wo);
+      if (l > 0) {
+        GemmArgs gx = {ws->dy[net][l], Nl, P + wo, Kl, ws->dy[net][l - 1], Kl, 0, MB, Kl, Nl, Nl, nullptr, ws->h[net][l - 1], Kl};
+        gemm<0, 1, 3>(gx, 1, st);                                         // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
+      }
+    }
+  }
+}

@@ -33,6 +33,23 @@ int sdxpk_prenorm(const SdxpDev*, int, hipStream_t);
 void sdxpk_apply_explicit(const SdxpDev*, int, float, int, hipStream_t);
 }
 
+struct SdxpBigWs {            // workspace of the large-minibatch update path (sdxp_bigmb.hip)
+  float* h[3][3];
+  float* dy[3][3];
+  float* mu;
+  float* dmu;
+  float* v;
+  float* dv;
+  float* part;
+  double* dpart;
+  int MB, nsplit;
+};
+extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB);
+extern "C" int sdxpk_big_nsplit(int MB);
+extern "C" void sdxpk_big_prenorm(const SdxpDev* D, const SdxpBigWs* ws, hipStream_t st);
+extern "C" void sdxpk_big_step(const SdxpDev* D, const SdxpBigWs* ws, int mb, int me, hipStream_t st);
+extern "C" void sdxpk_apply_flat(const SdxpDev* D, hipStream_t st);
+
 struct sdxp_agent {
   int device = 0;
   sdxp_config cfg;
@@ -55,6 +72,9 @@ struct sdxp_agent {
   float *mus_bak = nullptr, *sig_bak = nullptr;
   double* rms_bak = nullptr;
   SdxpCtrl* ctrl_bak = nullptr;
+  bool big = false;              // minibatch_size > 8: GEMM-shaped update path (sdxp_bigmb.hip)
+  SdxpBigWs bigws;
+  int big_me = 0, big_next = 0;  // multi-rank big path: mini-epoch / expected minibatch of the next sdxp_backward call
   std::string err;
 };
 
@@ -166,7 +186,8 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   PAL(D.mb_rewards, R); PAL(D.mb_dones, R); PAL(D.returns, R); PAL(D.adv, R); PAL(D.last_values, N);
   PAL(D.cur_rew, N); PAL(D.cur_len, N);
   PAL(D.rms_mean, cfg->state_dim); PAL(D.rms_var, cfg->state_dim);
-  const int MB = cfg->minibatch;
+  h->big = cfg->minibatch > 8;
+  const int MB = h->big ? 1 : cfg->minibatch;   // the rank-MB factor buffers below belong to the small-minibatch paths
   for (int net = 0; net < 3; ++net) {
     for (int l = 0; l < 3; ++l) {
       PAL(D.x[net][l + 1], (size_t)2 * MB * cfg->units[l]);
@@ -191,6 +212,17 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     D.foff.total = (o + 63) / 64 * 64;
     D.world = cfg->world_size > 0 ? cfg->world_size : 1;
     PAL(D.fact, D.foff.total); PAL(D.fact_all, (size_t)D.foff.total * D.world); PAL(D.sqn_part, 1024);
+  }
+  if (h->big) {   // activations and pre-activation gradients of one large minibatch, split partials of the weight gradients
+    SdxpBigWs& w = h->bigws;
+    const size_t BM = (size_t)cfg->minibatch;
+    w.MB = cfg->minibatch;
+    w.nsplit = sdxpk_big_nsplit(cfg->minibatch);
+    for (int net = 0; net < 3; ++net)
+      for (int l = 0; l < 3; ++l) { PAL(w.h[net][l], BM * cfg->units[l]); PAL(w.dy[net][l], BM * cfg->units[l]); }
+    PAL(w.mu, BM * 24); PAL(w.dmu, BM * 24); PAL(w.v, 2 * BM); PAL(w.dv, 2 * BM);
+    PAL(w.part, sdxpk_big_part_floats(&D, cfg->minibatch));
+    PAL(w.dpart, (size_t)w.nsplit * cfg->state_dim * 2);
   }
 #undef PAL
   // ---- parameter init
@@ -349,8 +381,18 @@ extern "C" int sdxp_update(sdxp_handle h, void* stream) {
   if (!h) return SDX_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int MB = h->cfg.minibatch;
+  if (h->big) {   // minibatch_size > 8 (ppo_continuous_insert.yaml: 4096): GEMM-shaped step, explicit gradients, clip + Adam
+    hipLaunchKernelGGL(k_ctrl_begin_epoch, dim3(1), dim3(1), 0, st, h->D.ctrl);
+    sdxpk_big_prenorm(&h->D, &h->bigws, st);
+    for (int me = 0; me < h->cfg.mini_epochs; ++me)
+      for (int mb = 0; mb < h->D.num_minibatches; ++mb) {
+        sdxpk_big_step(&h->D, &h->bigws, mb, me, st);
+        sdxpk_apply_flat(&h->D, st);
+      }
+    return plaunch_ok(h, "sdxp_update(large minibatch)");
+  }
   if (MB != 2 && MB != 4 && MB != 8) {
-    h->err = "sdxp_update: the fused rank-MB path supports minibatch_size 2/4/8 (as shipped: 4)";
+    h->err = "sdxp_update: minibatch_size must be 2/4/8 (rank-MB paths) or > 8 (GEMM path)";
     return SDX_ERR_INVALID;
   }
   const long total = (long)h->cfg.mini_epochs * h->D.num_minibatches;
@@ -410,6 +452,20 @@ extern "C" int sdxp_backward(sdxp_handle h, int32_t which, int32_t mb, void* str
   if (!h) return SDX_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int MB = h->cfg.minibatch;
+  if (h->big) {
+    if (which == 1) return SDX_OK;
+    if (mb < 0) {
+      hipLaunchKernelGGL(k_ctrl_begin_epoch, dim3(1), dim3(1), 0, st, h->D.ctrl);
+      sdxpk_big_prenorm(&h->D, &h->bigws, st);
+      h->big_me = 0; h->big_next = 0;
+      return plaunch_ok(h, "sdxp_backward(begin, large minibatch)");
+    }
+    if (mb != h->big_next) { h->err = "sdxp_backward: minibatches must come in order"; return SDX_ERR_INVALID; }
+    sdxpk_big_step(&h->D, &h->bigws, mb, h->big_me, st);
+    h->big_next = mb + 1;
+    if (h->big_next >= h->D.num_minibatches) { h->big_next = 0; h->big_me += 1; }
+    return plaunch_ok(h, "sdxp_backward(large minibatch)");
+  }
   if (MB != 2 && MB != 4 && MB != 8) { h->err = "sdxp_backward: minibatch_size must be 2/4/8"; return SDX_ERR_INVALID; }
   if (which == 1) return SDX_OK;
   if (mb < 0) {
@@ -495,6 +551,6 @@ extern "C" int sdxp_update_status(sdxp_handle h, void* stream) {
            "nothing was applied, inputs restored; this handle now uses the hipGraph path - call sdxp_update again";
   return SDX_ERR_STATE;
 }
-extern "C" int sdxp_update_impl(sdxp_handle h) { return h && h->use_persist ? 1 : 0; }
+extern "C" int sdxp_update_impl(sdxp_handle h) { return !h ? 0 : (h->big ? 2 : (h->use_persist ? 1 : 0)); }
 
 extern "C" const char* sdxp_last_error(sdxp_handle h) { return h ? h->err.c_str() : gp_create_err.c_str(); }

@@ -1311,6 +1311,12 @@ static void launch_apply_factors(const SdxpDev* D, hipStream_t st) {
   hipLaunchKernelGGL(k_adam2, dim3(512, 2), dim3(256), 0, st, *D);
   hipLaunchKernelGGL(k_apply_fin2, dim3(1), dim3(1), 0, st, *D);
 }
+// clip_grad_norm_ + Adam + LR schedule on the flat gradients already sitting in ac_g / cv_g (KL word in ac_g[g_tail])
+extern "C" void sdxpk_apply_flat(const SdxpDev* D, hipStream_t st) {
+  hipLaunchKernelGGL(k_sqnorm2, dim3(512, 2), dim3(256), 0, st, *D, 1.0f / (float)D->world);
+  hipLaunchKernelGGL(k_adam2, dim3(512, 2), dim3(256), 0, st, *D);
+  hipLaunchKernelGGL(k_apply_fin2, dim3(1), dim3(1), 0, st, *D);
+}
 extern "C" int sdxpk_apply_factors(const SdxpDev* D, int mb_size, hipStream_t st) {
 #define C_(M) launch_apply_factors<M>(D, st)
   MB_SWITCH(mb_size, C_)

@@ -119,8 +119,9 @@ class SdxPPO:
         self._check(self.lib.sdxp_update_status(self.h, _stream_ptr(self.device)))
 
     def update_impl(self):
-        """'persistent' (one launch per epoch, register-resident weights) or 'graph' (hipGraph of the multi-kernel step)"""
-        return "persistent" if self.lib.sdxp_update_impl(self.h) == 1 else "graph"
+        """'persistent' (one launch per epoch, register-resident weights), 'graph' (hipGraph of the multi-kernel rank-MB step) or
+        'gemm' (minibatch_size > 8: fp32-MFMA GEMM step with explicit gradients, sdxp_bigmb.hip)"""
+        return {1: "persistent", 2: "gemm"}.get(self.lib.sdxp_update_impl(self.h), "graph")
 
     # ---- explicit-gradient path for world_size > 1 (gradients all-reduced by the caller between the two calls)
     def backward(self, which, mb):

@@ -19,7 +19,7 @@ def make_pair(n, seed=3, **over):
     agent = SdxPPO(n, config=cfg, seed=seed)
     oc = dict(DEFAULT_CFG)
     oc.update(minibatch=cfg.minibatch, mini_epochs=cfg.mini_epochs, lr=cfg.lr, cv_lr=cfg.cv_lr,
-              adaptive_lr=bool(cfg.adaptive_lr))
+              adaptive_lr=bool(cfg.adaptive_lr), critic_coef=cfg.critic_coef)
     orc = PPOOracle(oc, seed=0)
     orc.load_flat(agent.t["AC_PARAMS"].cpu(), agent.t["CV_PARAMS"].cpu())
     return agent, orc
@@ -123,6 +123,66 @@ def test_update_matches_autograd_adam(adaptive):
         np.testing.assert_allclose(agent.t["MB_MUS"].cpu().numpy().reshape(-1, 23), ds["mus"].numpy(), rtol=1e-3, atol=1e-3)
     finally:
         agent.close()
+
+
+@pytest.mark.parametrize("mbsize,critic_coef", [(64, 4.0), (96, 1.0)])
+def test_large_minibatch_update_matches_autograd_adam(mbsize, critic_coef):
+    """minibatch_size > 8 (the insert policy's schedule, cfg/lego/ppo_continuous_insert.yaml: 4096, critic_coef 4) takes the GEMM-shaped
+    step of sdxp_bigmb.hip (fp32 MFMA forward / data-gradient / weight-gradient GEMMs, explicit flat gradients, clip + Adam): the
+    whole update phase against torch.autograd + Adam.  96 does not divide the 64-wide tiles: edge handling."""
+    n = 48
+    agent, orc = make_pair(n, minibatch=mbsize, cv_minibatch=mbsize, critic_coef=critic_coef)
+    try:
+        assert agent.update_impl() == "gemm"
+        g = torch.Generator().manual_seed(7)
+        ds = rollout(agent, orc, n, g)
+        agent.update()
+        torch.cuda.synchronize()
+        st = orc.update(ds)
+        c = agent.ctrl()
+        nsteps = 5 * (n * 8 // mbsize)
+        assert c.n_mb == nsteps and c.ac_t == nsteps and c.cv_t == nsteps and c.mini_epoch == 5 and c.mb_index == 0
+        np.testing.assert_allclose(c.sum_a_loss / nsteps, np.mean(st["a"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_c_loss / nsteps, np.mean(st["c"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_cv_loss / nsteps, np.mean(st["cv"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_kl / nsteps, np.mean(st["kl"]), rtol=5e-3, atol=1e-5)
+        np.testing.assert_allclose(c.ac_lr, orc.lr, rtol=1e-6)
+        np.testing.assert_allclose(c.ac_gnorm, st["gnorm"][-1], rtol=2e-3)
+        np.testing.assert_allclose(c.cv_gnorm, st["cv_gnorm"][-1], rtol=2e-3)
+        ac = agent.t["AC_PARAMS"].cpu().numpy(); cv = agent.t["CV_PARAMS"].cpu().numpy()
+        oa = orc.ac_flat().numpy(); ocv = orc.cv_flat().numpy()
+        assert np.abs(ac - oa).max() < 2e-4, np.abs(ac - oa).max()
+        assert np.abs(cv - ocv).max() < 5e-4, np.abs(cv - ocv).max()
+        np.testing.assert_allclose(agent.t["CV_RMS_MEAN"].cpu().numpy(), orc.rms.mean.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(agent.t["CV_RMS_VAR"].cpu().numpy(), orc.rms.var.numpy(), rtol=1e-5, atol=1e-7)
+        assert abs(c.rms_count - float(orc.rms.count)) < 1e-9
+        np.testing.assert_allclose(agent.t["MB_MUS"].cpu().numpy().reshape(-1, 23), ds["mus"].numpy(), rtol=1e-3, atol=1e-3)
+    finally:
+        agent.close()
+
+
+def test_large_minibatch_explicit_path_equals_update():
+    """sdxp_backward(0, mb) + sdxp_apply_flat-equivalent calls (the multi-rank order of calls at world size 1) == sdxp_update."""
+    n = 32
+    a1, orc = make_pair(n, seed=5, minibatch=64, cv_minibatch=64)
+    a2, _ = make_pair(n, seed=5, minibatch=64, cv_minibatch=64)
+    try:
+        for ag in (a1, a2):
+            g = torch.Generator().manual_seed(4)
+            rollout(ag, orc, n, g)
+        a1.update()
+        a2.backward(0, -1)
+        for me in range(5):
+            for mb in range(n * 8 // 64):
+                a2.backward(0, mb)
+                a2.apply(0, float("-inf"))
+                a2.apply(1, 0.0)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(a2.t["AC_PARAMS"].cpu().numpy(), a1.t["AC_PARAMS"].cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(a2.t["CV_PARAMS"].cpu().numpy(), a1.t["CV_PARAMS"].cpu().numpy(), rtol=0, atol=2e-6)
+        assert a1.ctrl().ac_t == a2.ctrl().ac_t == 5 * (n * 8 // 64)
+    finally:
+        a1.close(); a2.close()
 
 
 def test_explicit_gradient_path_equals_fused_path():
