@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--num-envs", type=int, default=1024, help="envs per GPU (config[1]: 1024)")
     ap.add_argument("--minibatch", type=int, default=None, help="override minibatch_size (labelled variant, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-minibatch", action="store_true", help="skip the labelled large-minibatch variant")
     ap.add_argument("--cpu-baseline-envs", type=int, default=1024)
     ap.add_argument("--cpu-baseline-steps", type=int, default=16)
     ap.add_argument("--cpu-baseline-ppo-envs", type=int, default=128, help="PPO leg: envs of the sample dataset (x horizon rows; 128 -> 1280 optimiser steps, a few seconds)")
@@ -89,6 +90,52 @@ def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mi
                       "PPO: %d optimiser steps (minibatch %d) of oracle/ppo_oracle.py on torch-CPU (%d threads), %.1f s, scaled to the "
                       "%d steps of one epoch; no policy inference / obs kernels in the CPU number"
                       % (n, args.cpu_baseline_steps, cores, sim_dt, ppo_steps, minibatch, torch.get_num_threads(), ppo_dt, epoch_opt_steps)}
+
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def gemm_roofline(agent, n, horizon, upd_ms_per_epoch):
+    """large-minibatch update (sdxp_bigmb.hip): the dominant kernels are the fp32-MFMA GEMMs k_gemm<...>; algorithmic flops of one
+    optimiser step = 6 x minibatch x parameters (forward 2, data gradient 2, weight gradient 2 flops per weight and sample)"""
+    p = agent.ppo.param_count(0) + agent.ppo.param_count(1)
+    nsteps = agent.mini_epochs_num * (n * horizon // agent.minibatch_size)
+    flops_step = 6.0 * agent.minibatch_size * p
+    ms_step = upd_ms_per_epoch / nsteps
+    ach = flops_step / (ms_step * 1e-3) / 1e12
+    return {"kernel": "k_gemm<NT|NN|TN> fp32 MFMA (forward, data gradient, weight gradient of 3 networks; whole optimiser step incl. "
+                      "losses, reductions, clip + Adam in the time)", "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": ms_step, "us_per_optimiser_step": ms_step * 1e3,
+            "algorithmic_flops_per_step": flops_step, "optimiser_steps_per_epoch": nsteps, "traffic": None}
+
+
+def large_minibatch_variant(train, env, n, horizon, args):
+    import copy
+    import torch
+    from seqdex_amd.a2c_agent import A2CAgent
+    tr = copy.deepcopy({k: v for k, v in train["params"].items() if k != "config"})
+    pc = {k: v for k, v in train["params"]["config"].items() if k not in ("vec_env", "env_info")}
+    pc = copy.deepcopy(pc)
+    mbs = n * horizon
+    pc["minibatch_size"] = mbs
+    pc["central_value_config"]["minibatch_size"] = mbs
+    pc.update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22, multi_gpu=False)
+    tr["config"] = pc
+    agent = A2CAgent("run_large_minibatch", tr)
+    for _ in range(args.warmup):
+        agent.train_epoch()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    play_t = upd_t = 0.0
+    for _ in range(args.steps):
+        r = agent.train_epoch()
+        play_t += r[1]; upd_t += r[2]
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    return {"label": "NOT the shipped schedule: minibatch_size %d instead of 4 (BASELINE.md protocol row; the insert policy ships 4096)" % mbs,
+            "minibatch_size": mbs, "value": n * horizon * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3,
+            "update_ms_per_epoch": upd_t / args.steps * 1e3, "rollout_ms_per_epoch": play_t / args.steps * 1e3,
+            "update_impl": agent.ppo.update_impl(), "roofline": gemm_roofline(agent, n, horizon, upd_t / args.steps * 1e3)}
 
 
 def main():
@@ -195,11 +242,14 @@ def main():
                  "(per epoch: %d optimiser steps)" % nsteps)
         launches = nsteps
     upd_ms_step = upd_launch_ms / nsteps
-    roof_upd = {"kernel": kname, "bound": "hbm", "achieved": upd_bytes_step / (upd_ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+    if impl == "gemm":
+        roof_upd = gemm_roofline(agent, n, horizon, upd_launch_ms)
+    else:
+      roof_upd = {"kernel": kname, "bound": "hbm", "achieved": upd_bytes_step / (upd_ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "avg_launch_ms": upd_launch_ms, "us_per_optimiser_step": upd_ms_step * 1e3,
                 "algorithmic_bytes_per_launch": upd_bytes_step * nsteps,
                 "traffic": PMC_TRAFFIC_BYTES.get(("k_update_persistent", n)) if impl == "persistent" and args.minibatch is None else None}
-    roof_upd["frac"] = roof_upd["achieved"] / HBM_PEAK_GBS
+      roof_upd["frac"] = roof_upd["achieved"] / HBM_PEAK_GBS
     dominant = roof_upd if upd_t > step_t else roof_phys
     out = {
         "metric": "env-steps/sec BlockAssemblyGraspSim num_envs=%d/GPU" % n, "value": value, "unit": "env-steps/s",
@@ -213,9 +263,14 @@ def main():
         "fps_total_rank0": n * horizon * args.steps / (play_t + upd_t),
         "update_ms_per_epoch": upd_t / args.steps * 1e3, "rollout_ms_per_epoch": play_t / args.steps * 1e3,
         "roofline": {"bound": dominant["bound"], "achieved": dominant["achieved"], "peak": dominant["peak"],
-                     "unit": "GB/s", "frac": dominant["frac"], "traffic": dominant["traffic"], "kernel": dominant["kernel"]},
+                     "unit": dominant["unit"], "frac": dominant["frac"], "traffic": dominant["traffic"], "kernel": dominant["kernel"]},
         "roofline_physics": roof_phys, "roofline_update": roof_upd,
     }
+    if world == 1 and not force_multi and args.minibatch is None and not args.no_large_minibatch:
+        try:    # BASELINE.md's labelled variant: the same epoch with ONE minibatch of n x horizon samples per mini-epoch
+            out["large_minibatch_variant"] = large_minibatch_variant(train, env, n, horizon, args)
+        except Exception as ex:
+            out["large_minibatch_variant"] = {"value": None, "error": str(ex)}
     if not args.no_cpu_baseline:
         try:
             root = sim.ROOT.view(n, 142, 13).cpu().numpy().copy()

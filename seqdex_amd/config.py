@@ -16,9 +16,7 @@ TASK_CFG = {"BlockAssemblyGraspSim": "cfg/allegro_hand_block_assembly_grasp_sim.
             "BlockAssemblyInsertSim": "cfg/allegro_hand_block_assembly_insert_sim.yaml"}                        # CF:69-70
 TRAIN_CFG = {"BlockAssemblyGraspSim": "cfg/lego/ppo_continuous_grasp.yaml",                                 # TR:44-47
              "BlockAssemblyOrient": "cfg/lego/ppo_continuous_grasp.yaml",
-             # the reference trains the insert policy with ppo_continuous_insert.yaml (TR:48-49: minibatch_size 4096, critic_coef 4);
-             # the update path built here is the minibatch-4 one, so the grasp schedule stands in
-             "BlockAssemblyInsertSim": "cfg/lego/ppo_continuous_grasp.yaml"}
+             "BlockAssemblyInsertSim": "cfg/lego/ppo_continuous_insert.yaml"}                               # TR:48-49
 
 
 def get_args(argv=None):

@@ -4,7 +4,8 @@
 // for a labelled large-minibatch variant next to the shipped minibatch of 4.  With thousands of samples per step the update is
 // GEMM-shaped, not the rank-MB weight streaming of sdxp_kernels.hip / sdxp_persist.hip: forward Y = ELU(X W^T + b), data gradient
 // dX = (dY W) * ELU'(H), weight gradient G = dY^T X, all three on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
-// k-ordered fma chain), LDS-tiled 64x64x16 per 256-thread workgroup (4 waves of 32x32).  rl_games' calc_gradients
+// k-ordered fma chain), LDS-tiled 128x128x32 per 256-thread workgroup (4 waves of 64x64; 64x64x16 for small problems), the
+// same layer of the three networks in one launch.  rl_games' calc_gradients
 // (a2c_continuous.py / RC:1796-1877) + CentralValueTrain.train_net for all three networks of one minibatch:
 //
 //   forward 3 nets x 3 trunk layers (NT GEMM, bias + ELU fused) -> mu head (NT GEMM) + two value heads (row dots)
@@ -24,7 +25,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define TB 64   // output tile
-#define TK 16   // reduction chunk staged through LDS
 
 __device__ __forceinline__ float belu(float x) { return x > 0.0f ? x : expm1f(x); }
 __device__ __forceinline__ float belu_grad_from_out(float h) { return h > 0.0f ? 1.0f : h + 1.0f; }
@@ -48,54 +48,99 @@ struct GemmArgs {
   int M, N, K, kchunk;          // reduction range of split z: [z * kchunk, min(K, (z + 1) * kchunk))
   const float* bias;            // EPI 1/2: bias[j]
   const float* H; int ldh;      // EPI 3: C = acc * ELU'(H[i][j]) with H the layer OUTPUT
+  float* rowsum;                // EPI 4: rowsum[z * cz + i] = sum_k A(i, k) over the split (the bias gradient of a dY^T X product)
 };
 
-// EPI: 0 none, 1 bias + ELU, 2 bias, 3 times ELU'(H)
-template <int AT, int BT, int EPI>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-  __shared__ float As[TB][TK + 1];
-  __shared__ float Bs[TB][TK + 1];
+// EPI: 0 none, 1 bias + ELU, 2 bias, 3 times ELU'(H), 4 none + row sums of A.  WT: waves own (32 WT) x (32 WT) of a (64 WT)^2 tile.
+// The global loads of reduction chunk c+1 are issued before the MFMAs of chunk c (register double buffering).
+// One launch serves up to three independent products (the same layer of the actor, critic and central-value networks):
+// blockIdx.z = problem * splits + split, so that the narrow layers still give every CU several workgroups.
+struct GemmBatch { GemmArgs a[3]; int splits; };
+
+template <int AT, int BT, int EPI, int WT, int KT>
+__global__ __launch_bounds__(256) void k_gemm(GemmBatch gb) {
+  constexpr int T = TB * WT;                        // tile edge
+  constexpr int NV = T * KT / 4 / 256;              // float4 loads per thread and operand per reduction chunk
+  __shared__ float As[T][KT + 1];
+  __shared__ float Bs[T][KT + 1];
+  const GemmArgs& g = gb.a[blockIdx.z / gb.splits];
+  const int zs = blockIdx.z % gb.splits;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i0 = blockIdx.y * TB, j0 = blockIdx.x * TB;
-  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  f32x16 acc;
+  const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
+  if (i0 >= g.M || j0 >= g.N) return;               // the grid covers the largest problem of the batch
+  const int kbeg = zs * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int wm = (wave >> 1) * 32 * WT, wn = (wave & 1) * 32 * WT;
+  f32x16 acc[WT][WT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  const int lr = tid >> 2, lk = (tid & 3) * 4;      // k-contiguous sources: row lr, k offset lk
-  const int kr = tid >> 4, li = (tid & 15) * 4;     // transposed sources: k row kr, i/j offset li
-  for (int k0 = kbeg; k0 < kend; k0 += TK) {
-    float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
-    if (AT == 0) { if (i0 + lr < g.M && k0 + lk < kend) av = load4(g.A + (size_t)(i0 + lr) * g.lda + k0 + lk, kend - (k0 + lk)); }
-    else         { if (k0 + kr < kend && i0 + li < g.M) av = load4(g.A + (size_t)(k0 + kr) * g.lda + i0 + li, g.M - (i0 + li)); }
-    if (BT == 0) { if (j0 + lr < g.N && k0 + lk < kend) bv = load4(g.B + (size_t)(j0 + lr) * g.ldb + k0 + lk, kend - (k0 + lk)); }
-    else         { if (k0 + kr < kend && j0 + li < g.N) bv = load4(g.B + (size_t)(k0 + kr) * g.ldb + j0 + li, g.N - (j0 + li)); }
-    __syncthreads();
-    if (AT == 0) { As[lr][lk] = av.x; As[lr][lk + 1] = av.y; As[lr][lk + 2] = av.z; As[lr][lk + 3] = av.w; }
-    else         { As[li][kr] = av.x; As[li + 1][kr] = av.y; As[li + 2][kr] = av.z; As[li + 3][kr] = av.w; }
-    if (BT == 0) { Bs[lr][lk] = bv.x; Bs[lr][lk + 1] = bv.y; Bs[lr][lk + 2] = bv.z; Bs[lr][lk + 3] = bv.w; }
-    else         { Bs[li][kr] = bv.x; Bs[li + 1][kr] = bv.y; Bs[li + 2][kr] = bv.z; Bs[li + 3][kr] = bv.w; }
+  for (int u = 0; u < WT; ++u)
+#pragma unroll
+    for (int v = 0; v < WT; ++v)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[u][v][i] = 0.0f;
+  // element e = tid + 256 p of a chunk: k-contiguous sources -> (row e / (KT/4), k offset 4 (e % (KT/4)));
+  // transposed sources -> (k row e / (T/4), i/j offset 4 (e % (T/4))): consecutive lanes read consecutive 16-byte pieces
+  float4 av[NV], bv[NV];
+  float rsum = 0.0f;
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int e = tid + 256 * p;
+      av[p] = make_float4(0, 0, 0, 0); bv[p] = make_float4(0, 0, 0, 0);
+      if (AT == 0) { const int r = i0 + e / (KT / 4), k = k0 + 4 * (e % (KT / 4)); if (r < g.M && k < kend) av[p] = load4(g.A + (size_t)r * g.lda + k, kend - k); }
+      else         { const int k = k0 + e / (T / 4), c = i0 + 4 * (e % (T / 4));   if (k < kend && c < g.M) av[p] = load4(g.A + (size_t)k * g.lda + c, g.M - c); }
+      if (BT == 0) { const int r = j0 + e / (KT / 4), k = k0 + 4 * (e % (KT / 4)); if (r < g.N && k < kend) bv[p] = load4(g.B + (size_t)r * g.ldb + k, kend - k); }
+      else         { const int k = k0 + e / (T / 4), c = j0 + 4 * (e % (T / 4));   if (k < kend && c < g.N) bv[p] = load4(g.B + (size_t)k * g.ldb + c, g.N - c); }
+    }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += KT) {
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < TK; kk += 2) {
-      const float a = As[wm + (lane & 31)][kk + (lane >> 5)];
-      const float b = Bs[wn + (lane & 31)][kk + (lane >> 5)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int p = 0; p < NV; ++p) {
+      const int e = tid + 256 * p;
+      if (AT == 0) { float* d = &As[e / (KT / 4)][4 * (e % (KT / 4))]; d[0] = av[p].x; d[1] = av[p].y; d[2] = av[p].z; d[3] = av[p].w; }
+      else         { const int k = e / (T / 4), c = 4 * (e % (T / 4)); As[c][k] = av[p].x; As[c + 1][k] = av[p].y; As[c + 2][k] = av[p].z; As[c + 3][k] = av[p].w; }
+      if (BT == 0) { float* d = &Bs[e / (KT / 4)][4 * (e % (KT / 4))]; d[0] = bv[p].x; d[1] = bv[p].y; d[2] = bv[p].z; d[3] = bv[p].w; }
+      else         { const int k = e / (T / 4), c = 4 * (e % (T / 4)); Bs[c][k] = bv[p].x; Bs[c + 1][k] = bv[p].y; Bs[c + 2][k] = bv[p].z; Bs[c + 3][k] = bv[p].w; }
+    }
+    __syncthreads();
+    if (k0 + KT < kend) fetch(k0 + KT);
+    if (EPI == 4 && blockIdx.x == 0 && tid < T) {
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk) rsum += As[tid][kk];
+    }
+#pragma unroll
+    for (int kk = 0; kk < KT; kk += 2) {
+      float a[WT], b[WT];
+#pragma unroll
+      for (int u = 0; u < WT; ++u) a[u] = As[wm + 32 * u + (lane & 31)][kk + (lane >> 5)];
+#pragma unroll
+      for (int v = 0; v < WT; ++v) b[v] = Bs[wn + 32 * v + (lane & 31)][kk + (lane >> 5)];
+#pragma unroll
+      for (int u = 0; u < WT; ++u)
+#pragma unroll
+        for (int v = 0; v < WT; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[v], acc[u][v], 0, 0, 0);
     }
   }
-  const int col = j0 + wn + (lane & 31);
-  if (col >= g.N) return;
-  float* C = g.C + (size_t)blockIdx.z * g.cz;
-  const float bias = (EPI == 1 || EPI == 2) ? g.bias[col] : 0.0f;
+  if (EPI == 4 && blockIdx.x == 0 && tid < T && i0 + tid < g.M) g.rowsum[(size_t)zs * g.cz + i0 + tid] = rsum;
+  float* C = g.C + (size_t)zs * g.cz;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = i0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < g.M) {
-      float v = acc[r] + bias;
-      if (EPI == 1) v = belu(v);
-      if (EPI == 3) v *= belu_grad_from_out(g.H[(size_t)row * g.ldh + col]);
-      C[(size_t)row * g.ldc + col] = v;
-    }
+  for (int v = 0; v < WT; ++v) {
+    const int col = j0 + wn + 32 * v + (lane & 31);
+    if (col >= g.N) continue;
+    const float bias = (EPI == 1 || EPI == 2) ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < WT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M) {
+          float x = acc[u][v][r] + bias;
+          if (EPI == 1) x = belu(x);
+          if (EPI == 3) x *= belu_grad_from_out(g.H[(size_t)row * g.ldh + col]);
+          C[(size_t)row * g.ldc + col] = x;
+        }
+      }
   }
 }
 
@@ -116,6 +161,18 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const float* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float a = 0.0f;
     for (int z = 0; z < S; ++z) a += part[(size_t)z * pz + i];
+    out[i] = a;
+  }
+}
+struct ReduceBatch { const float* part[3]; size_t pz[3]; size_t n[3]; float* out[3]; int S; };
+__global__ __launch_bounds__(256) void k_reduce_parts3(ReduceBatch rb) {
+  const int q = blockIdx.y;
+  const float* __restrict__ part = rb.part[q];
+  float* __restrict__ out = rb.out[q];
+  const size_t pz = rb.pz[q], n = rb.n[q];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float a = 0.0f;
+    for (int z = 0; z < rb.S; ++z) a += part[(size_t)z * pz + i];
     out[i] = a;
   }
 }
@@ -325,6 +382,7 @@ struct SdxpBigWs {            // device workspace, allocated by sdxp_capi.hip (s
   float* part;                // split partials (max over layers of S * (N*K + N)), also head partials
   double* dpart;              // [nsplit][state_dim][2]
   int MB, nsplit;
+  size_t part_region;         // floats of split partials per network inside `part`
 };
 
 static int big_splits(int MB) { int s = (MB + 511) / 512; return s < 1 ? 1 : (s > 16 ? 16 : s); }
@@ -336,16 +394,30 @@ extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB) {
   const size_t l1 = (size_t)D->units[1] * D->units[0] + D->units[1], l2 = (size_t)D->units[2] * D->units[1] + D->units[2];
   if (l1 > mx) mx = l1;
   if (l2 > mx) mx = l2;
-  const size_t hp = (size_t)((MB + 255) / 256) * BIGP;
+  const size_t hp = (size_t)((MB + 255) / 256) * BIGP + (size_t)2 * ((MB + 63) / 64) * (D->units[2] + 1) + (size_t)S * (32 * (D->units[2] + 1));
   const size_t need = (size_t)S * mx;
-  return need > hp ? need : hp;
+  return need > hp ? need : hp;      // per network; the workspace holds three such regions
 }
 extern "C" int sdxpk_big_nsplit(int MB) { return big_splits(MB); }
 
+// 128 x 128 tiles (each wave 64 x 64: half the LDS and L2 traffic per flop) when they still give every CU a workgroup
 template <int AT, int BT, int EPI>
-static void gemm(const GemmArgs& g, int splits, hipStream_t st) {
-  dim3 grid((g.N + TB - 1) / TB, (g.M + TB - 1) / TB, splits);
-  hipLaunchKernelGGL((k_gemm<AT, BT, EPI>), grid, dim3(256), 0, st, g);
+static void gemm(const GemmArgs* gs, int count, int splits, hipStream_t st) {
+  GemmBatch gb;
+  int Mx = 0, Nx = 0;
+  for (int q = 0; q < 3; ++q) {
+    gb.a[q] = gs[q < count ? q : 0];
+    if (q < count) { Mx = gs[q].M > Mx ? gs[q].M : Mx; Nx = gs[q].N > Nx ? gs[q].N : Nx; }
+  }
+  gb.splits = splits;
+  const long big = (long)((Nx + 127) / 128) * ((Mx + 127) / 128) * splits * count;
+  if (big >= 192) {
+    dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, splits * count);
+    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 32>), grid, dim3(256), 0, st, gb);
+  } else {
+    dim3 grid((Nx + TB - 1) / TB, (Mx + TB - 1) / TB, splits * count);
+    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 1, 16>), grid, dim3(256), 0, st, gb);
+  }
 }
 
 // central-value inputs of the whole epoch: cvx0 (statistics updated minibatch by minibatch, mini-epoch 0), cvx1 (frozen)
@@ -370,23 +442,26 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
   const int MB = ws->MB, A = D.act_dim, U2 = D.units[2];
   const size_t r0 = (size_t)mb * MB;
   const int S = ws->nsplit, rchunk = (MB + S - 1) / S;
-  for (int net = 0; net < 3; ++net) {
-    const float* P = net == 2 ? D.cv : D.ac;
-    const int in0 = net == 2 ? D.state_dim : D.obs_dim;
-    const float* X = net == 2 ? (me == 0 ? D.cvx0 : D.cvx1) + r0 * D.state_dim : D.mb_obs + r0 * D.obs_dim;
-    int in = in0;
-    for (int l = 0; l < 3; ++l) {
-      const size_t wo = net == 0 ? D.off.a_w[l] : (net == 1 ? D.off.c_w[l] : D.coff.w[l]);
-      const size_t bo = net == 0 ? D.off.a_b[l] : (net == 1 ? D.off.c_b[l] : D.coff.b[l]);
-      GemmArgs g = {X, in, P + wo, in, ws->h[net][l], D.units[l], 0, MB, D.units[l], in, in, P + bo, nullptr, 0};
-      gemm<0, 0, 1>(g, 1, st);
-      X = ws->h[net][l];
-      in = D.units[l];
+  const float* P[3] = {D.ac, D.ac, D.cv};
+  float* G[3] = {D.ac_g, D.ac_g, D.cv_g};
+  const int in0[3] = {D.obs_dim, D.obs_dim, D.state_dim};
+  const float* X0[3] = {D.mb_obs + r0 * D.obs_dim, D.mb_obs + r0 * D.obs_dim, (me == 0 ? D.cvx0 : D.cvx1) + r0 * D.state_dim};
+  auto woff = [&](int net, int l) { return net == 0 ? D.off.a_w[l] : (net == 1 ? D.off.c_w[l] : D.coff.w[l]); };
+  auto boff = [&](int net, int l) { return net == 0 ? D.off.a_b[l] : (net == 1 ? D.off.c_b[l] : D.coff.b[l]); };
+  const size_t region = ws->part_region;                                  // floats of split partials per network
+  // ---- forward: layer l of the three networks in one launch
+  for (int l = 0; l < 3; ++l) {
+    GemmArgs g[3];
+    for (int net = 0; net < 3; ++net) {
+      const int in = l == 0 ? in0[net] : D.units[l - 1];
+      const float* X = l == 0 ? X0[net] : ws->h[net][l - 1];
+      g[net] = {X, in, P[net] + woff(net, l), in, ws->h[net][l], D.units[l], 0, MB, D.units[l], in, in, P[net] + boff(net, l), nullptr, 0, nullptr};
     }
+    gemm<0, 0, 1>(g, 3, 1, st);
   }
   {  // heads
-    GemmArgs g = {ws->h[0][2], U2, D.ac + D.off.mu_w, U2, ws->mu, 24, 0, MB, A, U2, U2, D.ac + D.off.mu_b, nullptr, 0};
-    gemm<0, 0, 2>(g, 1, st);
+    GemmArgs g = {ws->h[0][2], U2, D.ac + D.off.mu_w, U2, ws->mu, 24, 0, MB, A, U2, U2, D.ac + D.off.mu_b, nullptr, 0, nullptr};
+    gemm<0, 0, 2>(&g, 1, 1, st);
     hipLaunchKernelGGL(k_rowdot, dim3((MB + 3) / 4), dim3(256), 0, st, ws->h[1][2], U2, MB, D.ac + D.off.v_w, D.ac + D.off.v_b, ws->v);
     hipLaunchKernelGGL(k_rowdot, dim3((MB + 3) / 4), dim3(256), 0, st, ws->h[2][2], U2, MB, D.cv + D.coff.v_w, D.cv + D.coff.v_b, ws->v + MB);
   }
@@ -395,41 +470,46 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
   hipLaunchKernelGGL(k_big_fin, dim3(1), dim3(64), 0, st, D, hb, MB, ws->part);
   // ---- head backward: data gradients into dy[net][2], weight gradients into the flat buffers
   {
-    GemmArgs g = {ws->dmu, 24, D.ac + D.off.mu_w, U2, ws->dy[0][2], U2, 0, MB, U2, A, A, nullptr, ws->h[0][2], U2};
-    gemm<0, 1, 3>(g, 1, st);                                             // dY2 = (dmu Wmu) * ELU'(h3)
+    GemmArgs g = {ws->dmu, 24, D.ac + D.off.mu_w, U2, ws->dy[0][2], U2, 0, MB, U2, A, A, nullptr, ws->h[0][2], U2, nullptr};
+    gemm<0, 1, 3>(&g, 1, 1, st);                                         // dY2 = (dmu Wmu) * ELU'(h3)
     hipLaunchKernelGGL(k_vhead_back, dim3(512), dim3(256), 0, st, ws->dv, D.ac + D.off.v_w, ws->h[1][2], U2, MB, ws->dy[1][2]);
     hipLaunchKernelGGL(k_vhead_back, dim3(512), dim3(256), 0, st, ws->dv + MB, D.cv + D.coff.v_w, ws->h[2][2], U2, MB, ws->dy[2][2]);
-    // mu head: G[A][U2] = dmu^T h3, bias = column sums of dmu (A of the 24 columns); contiguous [mu_w | mu_b] in the flat layout
+    // mu head: G[A][U2] = dmu^T h3, bias = row sums of dmu^T; contiguous [mu_w | mu_b] in the flat layout
     const size_t pz = (size_t)A * U2 + A;
-    GemmArgs gw = {ws->dmu, 24, ws->h[0][2], U2, ws->part, U2, pz, A, U2, MB, rchunk, nullptr, nullptr, 0};
-    gemm<1, 1, 0>(gw, S, st);
-    hipLaunchKernelGGL(k_colsum, dim3(1, S), dim3(256), 0, st, ws->dmu, 24, MB, A, rchunk, ws->part + (size_t)A * U2, pz);
+    GemmArgs gw = {ws->dmu, 24, ws->h[0][2], U2, ws->part, U2, pz, A, U2, MB, rchunk, nullptr, nullptr, 0, ws->part + (size_t)A * U2};
+    gemm<1, 1, 4>(&gw, 1, S, st);
+    // value heads: [v_w | v_b] contiguous; 64-row splits
+    const int VS = (MB + 63) / 64;
+    float* vp0 = ws->part + (size_t)S * pz;
+    float* vp1 = vp0 + (size_t)VS * (U2 + 1);
+    hipLaunchKernelGGL(k_vhead_wgrad, dim3(VS), dim3(256), 0, st, ws->dv, ws->h[1][2], U2, MB, 64, vp0, (size_t)U2 + 1);
+    hipLaunchKernelGGL(k_vhead_wgrad, dim3(VS), dim3(256), 0, st, ws->dv + MB, ws->h[2][2], U2, MB, 64, vp1, (size_t)U2 + 1);
     hipLaunchKernelGGL(k_reduce_parts, dim3(32), dim3(256), 0, st, ws->part, pz, S, pz, D.ac_g + D.off.mu_w);
-    // value heads: [v_w | v_b] contiguous
-    hipLaunchKernelGGL(k_vhead_wgrad, dim3(S), dim3(256), 0, st, ws->dv, ws->h[1][2], U2, MB, rchunk, ws->part, (size_t)U2 + 1);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, ws->part, (size_t)U2 + 1, S, (size_t)U2 + 1, D.ac_g + D.off.v_w);
-    hipLaunchKernelGGL(k_vhead_wgrad, dim3(S), dim3(256), 0, st, ws->dv + MB, ws->h[2][2], U2, MB, rchunk, ws->part, (size_t)U2 + 1);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, ws->part, (size_t)U2 + 1, S, (size_t)U2 + 1, D.cv_g + D.coff.v_w);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, vp0, (size_t)U2 + 1, VS, (size_t)U2 + 1, D.ac_g + D.off.v_w);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, vp1, (size_t)U2 + 1, VS, (size_t)U2 + 1, D.cv_g + D.coff.v_w);
   }
-  // ---- trunk backward
-  for (int net = 0; net < 3; ++net) {
-    const float* P = net == 2 ? D.cv : D.ac;
-    float* G = net == 2 ? D.cv_g : D.ac_g;
-    const int in0 = net == 2 ? D.state_dim : D.obs_dim;
-    const float* X0 = net == 2 ? (me == 0 ? D.cvx0 : D.cvx1) + r0 * D.state_dim : D.mb_obs + r0 * D.obs_dim;
-    for (int l = 2; l >= 0; --l) {
-      const size_t wo = net == 0 ? D.off.a_w[l] : (net == 1 ? D.off.c_w[l] : D.coff.w[l]);
-      const int Nl = D.units[l], Kl = l == 0 ? in0 : D.units[l - 1];
-      const float* Xl = l == 0 ? X0 : ws->h[net][l - 1];
+  // ---- trunk backward, layer by layer for the three networks at once
+  for (int l = 2; l >= 0; --l) {
+    const int Nl = D.units[l];
+    GemmArgs gw[3];
+    ReduceBatch rb;
+    rb.S = S;
+    for (int net = 0; net < 3; ++net) {
+      const int Kl = l == 0 ? in0[net] : D.units[l - 1];
+      const float* Xl = l == 0 ? X0[net] : ws->h[net][l - 1];
       const size_t pz = (size_t)Nl * Kl + Nl;                             // [W_l | b_l] contiguous in the flat layout
-      GemmArgs gw = {ws->dy[net][l], Nl, Xl, Kl, ws->part, Kl, pz, Nl, Kl, MB, rchunk, nullptr, nullptr, 0};
-      gemm<1, 1, 0>(gw, S, st);                                           // G_l = dY_l^T X_l
-      hipLaunchKernelGGL(k_colsum, dim3((Nl + 63) / 64, S), dim3(256), 0, st, ws->dy[net][l], Nl, MB, Nl, rchunk, ws->part + (size_t)Nl * Kl, pz);
-      hipLaunchKernelGGL(k_reduce_parts, dim3(512), dim3(256), 0, st, ws->part, pz, S, pz, G + wo);
-      if (l > 0) {
-        GemmArgs gx = {ws->dy[net][l], Nl, P + wo, Kl, ws->dy[net][l - 1], Kl, 0, MB, Kl, Nl, Nl, nullptr, ws->h[net][l - 1], Kl};
-        gemm<0, 1, 3>(gx, 1, st);                                         // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
-      }
+      float* part = ws->part + (size_t)net * region;
+      gw[net] = {ws->dy[net][l], Nl, Xl, Kl, part, Kl, pz, Nl, Kl, MB, rchunk, nullptr, nullptr, 0, part + (size_t)Nl * Kl};
+      rb.part[net] = part; rb.pz[net] = pz; rb.n[net] = pz; rb.out[net] = G[net] + woff(net, l);
+    }
+    gemm<1, 1, 4>(gw, 3, S, st);                                          // G_l = dY_l^T X_l, b_l = row sums of dY_l^T (fused)
+    hipLaunchKernelGGL(k_reduce_parts3, dim3(256, 3), dim3(256), 0, st, rb);
+    if (l > 0) {
+      GemmArgs gx[3];
+      const int Kl = D.units[l - 1];
+      for (int net = 0; net < 3; ++net)
+        gx[net] = {ws->dy[net][l], Nl, P[net] + woff(net, l), Kl, ws->dy[net][l - 1], Kl, 0, MB, Kl, Nl, Nl, nullptr, ws->h[net][l - 1], Kl, nullptr};
+      gemm<0, 1, 3>(gx, 3, 1, st);                                        // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
     }
   }
 }

@@ -43,6 +43,7 @@ struct SdxpBigWs {            // workspace of the large-minibatch update path (s
   float* part;
   double* dpart;
   int MB, nsplit;
+  size_t part_region;
 };
 extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB);
 extern "C" int sdxpk_big_nsplit(int MB);
@@ -221,7 +222,8 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     for (int net = 0; net < 3; ++net)
       for (int l = 0; l < 3; ++l) { PAL(w.h[net][l], BM * cfg->units[l]); PAL(w.dy[net][l], BM * cfg->units[l]); }
     PAL(w.mu, BM * 24); PAL(w.dmu, BM * 24); PAL(w.v, 2 * BM); PAL(w.dv, 2 * BM);
-    PAL(w.part, sdxpk_big_part_floats(&D, cfg->minibatch));
+    w.part_region = sdxpk_big_part_floats(&D, cfg->minibatch);
+    PAL(w.part, 3 * w.part_region);
     PAL(w.dpart, (size_t)w.nsplit * cfg->state_dim * 2);
   }
 #undef PAL

@@ -9,9 +9,12 @@ if task_name=='BlockAssemblyInsertSim':
     from seqdex_amd.tasks.block_assembly_insert_sim import BlockAssemblyInsertSim as BlockAssemblyGraspSim
 elif task_name=='BlockAssemblyOrient':
     from seqdex_amd.tasks.block_assembly_orient import BlockAssemblyOrient as BlockAssemblyGraspSim
-from seqdex_amd.config import TASK_CFG
+from seqdex_amd.config import TASK_CFG, TRAIN_CFG
 cfg=yaml.safe_load(open('seqdex_amd/'+TASK_CFG[task_name])); cfg['env']['numEnvs']=n
-tr=yaml.safe_load(open('seqdex_amd/cfg/lego/ppo_continuous_grasp.yaml'))
+tr=yaml.safe_load(open('seqdex_amd/'+TRAIN_CFG[task_name]))
+if len(sys.argv)>4:
+    tr['params']['config']['minibatch_size']=int(sys.argv[4]); tr['params']['config']['central_value_config']['minibatch_size']=int(sys.argv[4])
+print('minibatch_size', tr['params']['config']['minibatch_size'])
 t0=time.time()
 task=BlockAssemblyGraspSim(cfg, device_type='cuda', device_id=0, headless=True, piles_per_type=4)
 print('task create s', time.time()-t0)
