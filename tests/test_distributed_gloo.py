@@ -49,13 +49,21 @@ class FakePPO:
             self.step += 1
 
 
-def _worker(rank, world, port, out, fused=False):
+def _worker(rank, world, port, out, fused=False, large=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from seqdex_amd.a2c_agent import A2CAgent
     ag = A2CAgent.__new__(A2CAgent)          # orchestration only: no GPU objects
     ag.ppo = FakePPO(rank, world, fused)
     ag.mini_epochs_num, ag.batch_size, ag.minibatch_size = 2, 12, 4
+    if large:      # minibatch_size > 8 (GEMM update path): the gradient is the small object - even when the library offers the
+        ag.mini_epochs_num, ag.batch_size, ag.minibatch_size = 6, 48, 48       # rank-MB factor tensors they must not be used
+        ag.ppo.t["FACTORS"] = torch.zeros(4)
+        ag.ppo.t["FACTORS_ALL"] = torch.zeros(world, 4)
+
+        def _no_factors(mb):
+            raise AssertionError("factor exchange requested for a large minibatch")
+        ag.ppo.backward_factors = _no_factors
     ag.rank, ag.rank_size, ag.multi_gpu = rank, world, True
     ag._broadcast_parameters()
     p0 = ag.ppo.t["AC_PARAMS"].clone()
@@ -64,12 +72,12 @@ def _worker(rank, world, port, out, fused=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_gradient_allreduce_and_broadcast_world2(fused):
+@pytest.mark.parametrize("fused,large", [(False, False), (True, False), (True, True)])
+def test_gradient_allreduce_and_broadcast_world2(fused, large):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fused)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fused, large)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
