@@ -33,7 +33,6 @@ struct PhysLds {
   float lq[NL][4], lp[NL][3], la[NL][3], lc[NL][3], lv[NL][3], lw[NL][3], lI[NL][6];
   float lal[NL][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
   float A[ND][HP];   // H -> L -> Hinv
-  float T[ND][HP];   // L^-1
   float bp[NF][3], bq[NF][4], bv[NF][3], bw[NF][3], dv[NF][3], dw[NF][3];
   int bcount[NF];
   int rcount, nc, np, overflow;
@@ -49,14 +48,24 @@ struct PhysLds {
   float stage[8][SDX_MAXC];
   unsigned char act[SDX_MAXC];
   unsigned short ent[2 * SDX_MAXC];   // CSR entries: contact index | side << 15, grouped by brick, ascending contact index
-  unsigned short ent2[2 * SDX_MAXC];  // unsorted fill order (scratch of the rank pass)
   int eoff[NF + 1];
   int efill[NF];
   // robot-side contact sides: contact index | side << 15, ascending (contact, side) order, and the link each one touches
-  unsigned short rent[SDX_MAXC], rent2[SDX_MAXC];
+  unsigned short rent[SDX_MAXC];
   unsigned char rlink[SDX_MAXC];
   int rfill;
 };
+
+// Scratch that lives inside the contact staging area while those rows are dead (keeps PhysLds under 80 KiB, the LDS half of what two
+// workgroups per CU would need; the register half does not fit yet: at the 128-VGPR budget of 4 waves/SIMD the solver's contact
+// rows spill 640 B/lane and a launch gets 5 % SLOWER (2.15 vs 2.05 ms at N = 1024), so the kernel stays at 256 VGPRs, 1 workgroup/CU):
+//   L^-1 of the mass-matrix inversion (substep 0, before the narrowphase writes the staging rows)            -> stage[0]
+//   unsorted CSR fill order of the brick sides / robot sides (rank pass; rows 6 (n.z) and 7 (sep) are in registers by then and
+//   the solver reuses only rows 0..5)                                                                        -> stage[6], stage[7]
+#define S_T(S) (reinterpret_cast<float (*)[HP]>(&(S).stage[0][0]))
+#define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).stage[6][0]))
+#define S_RENT2(S) (reinterpret_cast<unsigned short*>(&(S).stage[7][0]))
+static_assert(ND * HP <= SDX_MAXC, "L^-1 must fit one staging row");
 
 struct Box { f3 c; f4 q; f3 h; };
 #define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && sub == 0) B.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -320,11 +329,11 @@ __device__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
   // T = L^-1, lane = column
   if (tid < ND) {
     const int c = tid;
-    for (int i = 0; i < c; ++i) S.T[i][c] = 0.0f;
+    for (int i = 0; i < c; ++i) S_T(S)[i][c] = 0.0f;
     for (int i = c; i < ND; ++i) {
       float s = (i == c) ? 1.0f : 0.0f;
-      for (int k = c; k < i; ++k) s -= S.A[i][k] * S.T[k][c];
-      S.T[i][c] = s / S.A[i][i];
+      for (int k = c; k < i; ++k) s -= S.A[i][k] * S_T(S)[k][c];
+      S_T(S)[i][c] = s / S.A[i][i];
     }
   }
   __syncthreads();
@@ -335,7 +344,7 @@ __device__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
     while (i * (i + 1) / 2 > idx) --i;
     const int j = idx - i * (i + 1) / 2;
     float s = 0.0f;
-    for (int k = i; k < ND; ++k) s += S.T[k][i] * S.T[k][j];
+    for (int k = i; k < ND; ++k) s += S_T(S)[k][i] * S_T(S)[k][j];
     S.A[i][j] = s;
     S.A[j][i] = s;
   }
@@ -542,10 +551,10 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
     const int c = tid + q * NT;
     if (c < nc) {
       const int a = R.a[q], b = R.b[q];
-      if (a < NF) S.ent2[S.eoff[a] + atomicAdd(&S.efill[a], 1)] = (unsigned short)c;
-      else if (a != SDX_BODY_STATIC) { const int i = atomicAdd(&S.rfill, 1); if (i < SDX_MAXC) S.rent2[i] = (unsigned short)c; }
-      if (b < NF) S.ent2[S.eoff[b] + atomicAdd(&S.efill[b], 1)] = (unsigned short)(c | 0x8000);
-      else if (b != SDX_BODY_STATIC) { const int i = atomicAdd(&S.rfill, 1); if (i < SDX_MAXC) S.rent2[i] = (unsigned short)(c | 0x8000); }
+      if (a < NF) S_ENT2(S)[S.eoff[a] + atomicAdd(&S.efill[a], 1)] = (unsigned short)c;
+      else if (a != SDX_BODY_STATIC) { const int i = atomicAdd(&S.rfill, 1); if (i < SDX_MAXC) S_RENT2(S)[i] = (unsigned short)c; }
+      if (b < NF) S_ENT2(S)[S.eoff[b] + atomicAdd(&S.efill[b], 1)] = (unsigned short)(c | 0x8000);
+      else if (b != SDX_BODY_STATIC) { const int i = atomicAdd(&S.rfill, 1); if (i < SDX_MAXC) S_RENT2(S)[i] = (unsigned short)(c | 0x8000); }
     }
   }
   __syncthreads();
@@ -557,19 +566,19 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
       int lo = 0, hi = NF;                       // brick of entry i: largest b with eoff[b] <= i
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.eoff[mid] <= i) lo = mid; else hi = mid; }
       const int o = S.eoff[lo], n = S.eoff[lo + 1] - o;
-      const unsigned short v = S.ent2[i];
+      const unsigned short v = S_ENT2(S)[i];
       const int key = v & 0x7fff;
       int rank = 0;
-      for (int j = 0; j < n; ++j) rank += (S.ent2[o + j] & 0x7fff) < key;
+      for (int j = 0; j < n; ++j) rank += (S_ENT2(S)[o + j] & 0x7fff) < key;
       S.ent[o + rank] = v;
     }
     // the same for the robot-side list (one list for the whole robot; key = contact index, then side)
     const int nr = min(S.nrobot, SDX_MAXC);
     for (int i = tid; i < nr; i += NT) {
-      const unsigned short v = S.rent2[i];
+      const unsigned short v = S_RENT2(S)[i];
       const int key = ((v & 0x7fff) << 1) | (v >> 15);
       int rank = 0;
-      for (int j = 0; j < nr; ++j) { const unsigned short u = S.rent2[j]; rank += (((u & 0x7fff) << 1) | (u >> 15)) < key; }
+      for (int j = 0; j < nr; ++j) { const unsigned short u = S_RENT2(S)[j]; rank += (((u & 0x7fff) << 1) | (u >> 15)) < key; }
       S.rent[rank] = v;
       const int ab = __float_as_int(S.stage[0][v & 0x7fff]);
       S.rlink[rank] = (unsigned char)(((v & 0x8000) ? ((ab >> 8) & 0xff) : (ab & 0xff)) - NF);
