@@ -217,21 +217,45 @@ class A2CAgent:
 
     # ------------------------------------------------------------------ checkpoints (rl_games .pth-shaped dict)
     def get_full_state_weights(self):
-        t = self.ppo.t
-        return {"model": {"ac_flat": t["AC_PARAMS"].cpu(), "cv_flat": t["CV_PARAMS"].cpu()},
+        """rl_games' checkpoint dictionary (A2CBase.get_full_state_weights, 1.5.2 layout as recalled in SURVEY.md App. C): `model` and
+        `assymetric_vf_nets` are named state_dicts (seqdex_amd/rlgames_checkpoint.py); the Adam moments are kept flat under `optimizer`
+        (rl_games stores torch.optim state there, which only another rl_games process could consume)."""
+        from .rlgames_checkpoint import rlgames_from_flat
+        t, c = self.ppo.t, self.ppo.ctrl()
+        cfg = self.ppo.cfg
+        model, vf = rlgames_from_flat(t["AC_PARAMS"], t["CV_PARAMS"], cfg.obs_dim, cfg.state_dim, cfg.act_dim, tuple(cfg.units),
+                                      t["CV_RMS_MEAN"], t["CV_RMS_VAR"], c.rms_count)
+        return {"model": model, "assymetric_vf_nets": vf,
                 "optimizer": {"ac_m": t["AC_ADAM_M"].cpu(), "ac_v": t["AC_ADAM_V"].cpu(), "cv_m": t["CV_ADAM_M"].cpu(),
-                              "cv_v": t["CV_ADAM_V"].cpu()},
-                "running_mean_std": {"mean": t["CV_RMS_MEAN"].cpu(), "var": t["CV_RMS_VAR"].cpu()},
-                "epoch": self.epoch_num, "frame": self.frame, "last_mean_rewards": self.last_mean_rewards}
+                              "cv_v": t["CV_ADAM_V"].cpu(), "ac_t": c.ac_t, "cv_t": c.cv_t},
+                "epoch": self.epoch_num, "frame": self.frame, "last_mean_rewards": self.last_mean_rewards, "env_state": None}
 
     def save(self, fn):
         torch.save(self.get_full_state_weights(), fn + ".pth")
 
     def restore(self, fn):
-        ck = torch.load(fn, map_location="cpu")
+        """loads a checkpoint written by save() or by rl_games itself (`model` / `assymetric_vf_nets` state_dicts; keys matched by
+        suffix, shapes checked; first-layer columns the library pads are zero-filled).  Adam moments are restored when they are ours."""
+        from .rlgames_checkpoint import flat_from_rlgames
+        ck = torch.load(fn, map_location="cpu", weights_only=False)
         t = self.ppo.t
-        t["AC_PARAMS"].copy_(ck["model"]["ac_flat"]); t["CV_PARAMS"].copy_(ck["model"]["cv_flat"])
-        t["AC_ADAM_M"].copy_(ck["optimizer"]["ac_m"]); t["AC_ADAM_V"].copy_(ck["optimizer"]["ac_v"])
-        t["CV_ADAM_M"].copy_(ck["optimizer"]["cv_m"]); t["CV_ADAM_V"].copy_(ck["optimizer"]["cv_v"])
-        t["CV_RMS_MEAN"].copy_(ck["running_mean_std"]["mean"]); t["CV_RMS_VAR"].copy_(ck["running_mean_std"]["var"])
+        cfg = self.ppo.cfg
+        if "ac_flat" in ck.get("model", {}):                         # round-1 layout of this package
+            ac, cv = ck["model"]["ac_flat"], ck["model"]["cv_flat"]
+            rms = (ck["running_mean_std"]["mean"], ck["running_mean_std"]["var"], None)
+        else:
+            obs_cols = cfg.obs_cols if cfg.obs_cols > 0 else None
+            try:
+                ac, cv, rms = flat_from_rlgames(ck["model"], ck["assymetric_vf_nets"], cfg.obs_dim, cfg.state_dim, cfg.act_dim,
+                                                tuple(cfg.units))
+            except ValueError:
+                ac, cv, rms = flat_from_rlgames(ck["model"], ck["assymetric_vf_nets"], cfg.obs_dim, cfg.state_dim, cfg.act_dim,
+                                                tuple(cfg.units), obs_cols=obs_cols, state_cols=getattr(self, "state_cols", None))
+        t["AC_PARAMS"].copy_(ac); t["CV_PARAMS"].copy_(cv)
+        if rms is not None:
+            t["CV_RMS_MEAN"].copy_(rms[0]); t["CV_RMS_VAR"].copy_(rms[1])
+        opt = ck.get("optimizer", {})
+        if isinstance(opt, dict) and "ac_m" in opt:
+            t["AC_ADAM_M"].copy_(opt["ac_m"]); t["AC_ADAM_V"].copy_(opt["ac_v"])
+            t["CV_ADAM_M"].copy_(opt["cv_m"]); t["CV_ADAM_V"].copy_(opt["cv_v"])
         self.epoch_num, self.frame = ck.get("epoch", 0), ck.get("frame", 0)

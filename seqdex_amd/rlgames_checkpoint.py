@@ -1,0 +1,111 @@
+"""rl_games 1.5.2 checkpoint layout <-> the library's flat parameter buffers.
+
+rl_games' `A2CBase.get_full_state_weights()` stores `model` = state_dict of `ModelA2CContinuousLogStd.Network` (network builder
+`actor_critic`, `separate: True`, `fixed_sigma: True`) and, for the central value, `assymetric_vf_nets` = state_dict of
+`CentralValueTrain` (its own `actor_critic` network with `central_value: True` + the input RunningMeanStd).  The flat buffers of
+libseqdex_hip.so use the torch layout W[out][in] in the order of `SdxpOff` / `SdxpCOff` (csrc/sdxp_types.h), so the conversion is
+slicing and naming only.  rl_games is not installed here and the reference ships no checkpoint: the key names below are the
+upstream ones as recalled (PARITY UNPINNED); `flat_from_rlgames` therefore matches keys by suffix and checks every shape.
+"""
+import numpy as np
+import torch
+
+AC_KEYS = [("a2c_network.actor_mlp.%d", 3), ("a2c_network.mu", 1), ("a2c_network.sigma", 0),
+           ("a2c_network.critic_mlp.%d", 3), ("a2c_network.value", 1)]
+
+
+def _layers(in_dim, units):
+    dims, d = [], in_dim
+    for u in units:
+        dims.append((u, d))
+        d = u
+    return dims
+
+
+def rlgames_from_flat(ac_flat, cv_flat, obs_dim, state_dim, act_dim=23, units=(1024, 512, 256), rms_mean=None, rms_var=None,
+                      rms_count=None):
+    """flat actor-critic / central-value parameter vectors -> (model_state_dict, assymetric_vf_nets_state_dict)"""
+    ac, cv = torch.as_tensor(ac_flat).float().cpu(), torch.as_tensor(cv_flat).float().cpu()
+    model, o = {}, 0
+
+    def take(buf, off, shape):
+        n = int(np.prod(shape))
+        return buf[off:off + n].reshape(shape).clone(), off + n
+
+    for i, (out, inn) in enumerate(_layers(obs_dim, units)):          # Sequential(Linear, ELU, ...): Linear at indices 0, 2, 4
+        model["a2c_network.actor_mlp.%d.weight" % (2 * i)], o = take(ac, o, (out, inn))
+        model["a2c_network.actor_mlp.%d.bias" % (2 * i)], o = take(ac, o, (out,))
+    model["a2c_network.mu.weight"], o = take(ac, o, (act_dim, units[-1]))
+    model["a2c_network.mu.bias"], o = take(ac, o, (act_dim,))
+    model["a2c_network.sigma"], o = take(ac, o, (act_dim,))
+    for i, (out, inn) in enumerate(_layers(obs_dim, units)):
+        model["a2c_network.critic_mlp.%d.weight" % (2 * i)], o = take(ac, o, (out, inn))
+        model["a2c_network.critic_mlp.%d.bias" % (2 * i)], o = take(ac, o, (out,))
+    model["a2c_network.value.weight"], o = take(ac, o, (1, units[-1]))
+    model["a2c_network.value.bias"], o = take(ac, o, (1,))
+    assert o == ac.numel(), (o, ac.numel())
+    vf, o = {}, 0
+    for i, (out, inn) in enumerate(_layers(state_dim, units)):
+        vf["model.a2c_network.critic_mlp.%d.weight" % (2 * i)], o = take(cv, o, (out, inn))
+        vf["model.a2c_network.critic_mlp.%d.bias" % (2 * i)], o = take(cv, o, (out,))
+    vf["model.a2c_network.value.weight"], o = take(cv, o, (1, units[-1]))
+    vf["model.a2c_network.value.bias"], o = take(cv, o, (1,))
+    assert o == cv.numel(), (o, cv.numel())
+    if rms_mean is not None:
+        vf["running_mean_std.running_mean"] = torch.as_tensor(rms_mean).double().cpu().clone()
+        vf["running_mean_std.running_var"] = torch.as_tensor(rms_var).double().cpu().clone()
+        vf["running_mean_std.count"] = torch.tensor(float(rms_count if rms_count is not None else 0.0), dtype=torch.float64)
+    return model, vf
+
+
+def _find(sd, suffix, shape):
+    hits = [k for k in sd if k.endswith(suffix)]
+    if len(hits) != 1:
+        raise KeyError("rl_games checkpoint: expected exactly one key ending in %r, found %r" % (suffix, hits))
+    v = torch.as_tensor(sd[hits[0]]).float().cpu()
+    if tuple(v.shape) != tuple(shape):
+        raise ValueError("rl_games checkpoint: %s has shape %s, this network needs %s" % (hits[0], tuple(v.shape), tuple(shape)))
+    return v.reshape(-1)
+
+
+def flat_from_rlgames(model, vf, obs_dim, state_dim, act_dim=23, units=(1024, 512, 256), obs_cols=None, state_cols=None):
+    """(model state_dict, assymetric_vf_nets state_dict) -> (ac_flat, cv_flat, rms or None).  Keys are matched by suffix (DataParallel
+    / wrapper prefixes are ignored).  obs_cols / state_cols: width of the checkpoint's first layers when the library pads its network
+    inputs (Orient 186 -> 188 observation columns, InsertSim 188 -> 564 state columns): the missing input columns get zero weights."""
+    def first(sd, name, out, inn, cols):
+        cols = cols or inn
+        w = _find(sd, name + ".weight", (out, cols)).reshape(out, cols)
+        if cols != inn:
+            w = torch.cat([w, torch.zeros(out, inn - cols)], dim=1)
+        return w.reshape(-1)
+
+    parts = []
+    for trunk, head, hout in (("actor_mlp", "mu", act_dim), ("critic_mlp", "value", 1)):
+        for i, (out, inn) in enumerate(_layers(obs_dim, units)):
+            name = "a2c_network.%s.%d" % (trunk, 2 * i)
+            parts.append(first(model, name, out, inn, obs_cols) if i == 0 else _find(model, name + ".weight", (out, inn)))
+            parts.append(_find(model, name + ".bias", (out,)))
+        parts.append(_find(model, "a2c_network.%s.weight" % head, (hout, units[-1])))
+        parts.append(_find(model, "a2c_network.%s.bias" % head, (hout,)))
+        if head == "mu":
+            parts.append(_find(model, "a2c_network.sigma", (act_dim,)))
+    ac = torch.cat(parts)
+    parts = []
+    for i, (out, inn) in enumerate(_layers(state_dim, units)):
+        name = "a2c_network.critic_mlp.%d" % (2 * i)
+        parts.append(first(vf, name, out, inn, state_cols) if i == 0 else _find(vf, name + ".weight", (out, inn)))
+        parts.append(_find(vf, name + ".bias", (out,)))
+    parts.append(_find(vf, "a2c_network.value.weight", (1, units[-1])))
+    parts.append(_find(vf, "a2c_network.value.bias", (1,)))
+    cv = torch.cat(parts)
+    rms = None
+    mean_keys = [k for k in vf if k.endswith("running_mean_std.running_mean")]
+    if mean_keys:
+        pre = mean_keys[0][:-len("running_mean")]
+        cols = state_cols or state_dim
+        mean, var = torch.zeros(state_dim, dtype=torch.float64), torch.ones(state_dim, dtype=torch.float64)
+        mean[:cols] = torch.as_tensor(vf[pre + "running_mean"]).double().reshape(-1)[:cols]
+        var[:cols] = torch.as_tensor(vf[pre + "running_var"]).double().reshape(-1)[:cols]
+        cnt = float(torch.as_tensor(vf[pre + "count"])) if (pre + "count") in vf else 0.0
+        rms = (mean, var, cnt)
+    return ac, cv, rms

@@ -88,3 +88,30 @@ def test_launcher_maps_the_three_tasks():
     for t, rel in config.TASK_CFG.items():
         cfg = yaml.safe_load(open(os.path.join(os.path.dirname(config.__file__), rel)))
         assert cfg["env"]["episodeLength"] == {"BlockAssemblyGraspSim": 150, "BlockAssemblyOrient": 75, "BlockAssemblyInsertSim": 125}[t]
+
+
+def test_rlgames_checkpoint_layout_round_trip():
+    """flat parameter buffers <-> rl_games 1.5.2 state_dict names: sizes add up to the parameter counts of
+    SURVEY.md section 2b, the round trip is exact, wrapper prefixes are ignored, wrong shapes are refused, and a checkpoint of the
+    reference's 186-wide Orient observation loads into the library's 188-wide (zero-padded) first layer."""
+    import torch
+    from seqdex_amd.rlgames_checkpoint import flat_from_rlgames, rlgames_from_flat
+    g = torch.Generator().manual_seed(0)
+    ac, cv = torch.randn(2131503, generator=g), torch.randn(1234945, generator=g)
+    model, vf = rlgames_from_flat(ac, cv, 396, 564, rms_mean=torch.arange(564.0), rms_var=torch.ones(564) * 2, rms_count=77.0)
+    assert tuple(model["a2c_network.actor_mlp.0.weight"].shape) == (1024, 396) and tuple(model["a2c_network.sigma"].shape) == (23,)
+    assert tuple(model["a2c_network.critic_mlp.4.weight"].shape) == (256, 512) and tuple(model["a2c_network.value.weight"].shape) == (1, 256)
+    assert tuple(vf["model.a2c_network.critic_mlp.0.weight"].shape) == (1024, 564)
+    assert torch.equal(model["a2c_network.actor_mlp.0.weight"].reshape(-1), ac[:1024 * 396])          # torch layout W[out][in], first block
+    wrapped = {"module." + k: v for k, v in model.items()}
+    ac2, cv2, rms = flat_from_rlgames(wrapped, vf, 396, 564)
+    assert torch.equal(ac2, ac) and torch.equal(cv2, cv)
+    assert rms[2] == 77.0 and torch.equal(rms[0], torch.arange(564.0).double())
+    bad = dict(model)
+    bad["a2c_network.mu.weight"] = torch.zeros(22, 256)
+    with pytest.raises(ValueError):
+        flat_from_rlgames(bad, vf, 396, 564)
+    m186, v188 = rlgames_from_flat(torch.randn(2131503 - 2 * 1024 * 210, generator=g), cv, 186, 564)
+    acp, _, _ = flat_from_rlgames(m186, v188, 188, 564, obs_cols=186)
+    w0 = acp[:1024 * 188].reshape(1024, 188)
+    assert torch.equal(w0[:, :186], m186["a2c_network.actor_mlp.0.weight"]) and not w0[:, 186:].any()
