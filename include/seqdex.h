@@ -45,6 +45,7 @@ extern "C" {
 #define SDX_NUM_ACTIONS 23  /* GS:211                                                                        */
 #define SDX_OBS_FRAME 132
 #define SDX_STATE_FRAME 188
+#define SDX_TV_LOG_SLOTS 65536 /* rows of each T-value dataset ring (success / failure)                          */
 #define SDX_HARVEST_SLOTS 5001 /* ring of grasp terminal states per brick-type group (GS:1440: index wraps after 5000) */
 #define SDX_TV_PARAMS 42562 /* GraspInsertTValue 4-256-128-64-2 weights+biases (terminal_value_function.py:30-46) */
 
@@ -94,7 +95,10 @@ typedef enum {
   SDX_T_HARVEST_OBJ = 30,  /* f32 [8,5001,13]   saved_grasp_object_ternimal_states                       GS:391-417 */
   SDX_T_HARVEST_COUNT = 31,/* i32 [8]           terminal states harvested so far (ring index = count % 5001) GS:1417,1440 */
   SDX_T_INSERT_AUX = 32,   /* f32 [N,8]         InsertSim: [0:3] rot_err (IS:1539), [3] |brick - site|, [4] rot_dist (IS:1656-1660) */
-  SDX_T_COUNT = 33
+  SDX_T_TV_SUCCESS = 33,   /* f32 [65536,4]     camera-frame target quaternions of successful episode ends (ring)   GS:1404-1412, IS:1392-1400 */
+  SDX_T_TV_FAILURE = 34,   /* f32 [65536,4]     ... of failed ones                                                  GS:1420-1438, IS:1401-1410 */
+  SDX_T_TV_COUNT = 35,     /* i32 [2]           rows logged so far: [success, failure] (ring index = count % 65536)                      */
+  SDX_T_COUNT = 36
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the
@@ -330,6 +334,36 @@ int sdxp_apply_factors(sdxp_handle h, void* stream);
  * SDXP_T_STATS; -INFINITY = take the KL word of SDXP_T_ALL_GRADS that the caller all-reduced (SUM) with the gradients. */
 int sdxp_apply(sdxp_handle h, int32_t which, float kl_allreduced_or_nan, void* stream);
 const char* sdxp_last_error(sdxp_handle h);
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Transition-value trainer (policy_sequencing/transition_value_trainer.py:127-248 = TT): fits GraspInsertTValue
+ * (terminal_value_function.py:30-46; parameter packing as sdx_set_tvalue_weights) to success / failure camera-frame quaternions.
+ * The datasets are device arrays [n, 4] - e.g. the SDX_T_TV_SUCCESS / SDX_T_TV_FAILURE rings the task kernels fill at episode ends
+ * (the reference writes them to HDF5 groups data/success_dataset, data/failure_dataset: GS:470-480,1404-1432, IS:1392-1410). */
+typedef struct sdxtv_trainer* sdxtv_handle;
+typedef enum {
+  SDXTV_T_PARAMS = 0,    /* f32 [42562]  W1 b1 W2 b2 W3 b3 W4 b4, torch layout W[out][in]                      TT:181      */
+  SDXTV_T_GRADS = 1,     /* f32 [42562]  gradient of the last sdxtv_step                                                    */
+  SDXTV_T_ADAM_M = 2,    /* f32 [42562]                                                                         TT:187      */
+  SDXTV_T_ADAM_V = 3,    /* f32 [42562]                                                                                     */
+  SDXTV_T_BATCH = 4,     /* f32 [B, 4]   t_value_obs_buf: rows [0, B/2) success, [B/2, B) failure                TT:207,213-222 */
+  SDXTV_T_LOSS = 5,      /* f32 [1]      BCEWithLogitsLoss of the last step                                     TT:228      */
+  SDXTV_T_OUTPUT = 6,    /* f32 [B, 2]   predict_success_confident of the last step                             TT:225      */
+  SDXTV_T_COUNT = 7
+} sdxtv_tensor_id;
+int sdxtv_create(int32_t batch /* 1024, TT:190 */, int32_t device, uint64_t seed, sdxtv_handle* out);
+int sdxtv_destroy(sdxtv_handle h);
+int sdxtv_tensor(sdxtv_handle h, int32_t id, void** dev_ptr, int64_t shape[4], int32_t* ndim, int32_t* dtype);
+/* draw a batch (TT:211-222): B/2 random success rows and B/2 random failure rows, + U(-1,1) * 0.05, renormalised -> SDXTV_T_BATCH */
+int sdxtv_sample(sdxtv_handle h, const float* succ_dev, int32_t n_succ, const float* fail_dev, int32_t n_fail, void* stream);
+/* forward, BCEWithLogitsLoss against the one-hot [failure, success] labels, backward, Adam step (TT:225-231) on SDXTV_T_BATCH */
+int sdxtv_step(sdxtv_handle h, float lr /* 1e-3 */, void* stream);
+/* iters x (sdxtv_sample, sdxtv_step): train_rollout (TT:209-231) */
+int sdxtv_train(sdxtv_handle h, const float* succ_dev, int32_t n_succ, const float* fail_dev, int32_t n_fail, int32_t iters, float lr,
+                void* stream);
+/* net(x) for n <= batch rows -> out_dev [n, 2] (validation pass TT:235-246) */
+int sdxtv_predict(sdxtv_handle h, const float* x_dev, int32_t n, float* out_dev, void* stream);
+const char* sdxtv_last_error(sdxtv_handle h);
 
 #ifdef __cplusplus
 }

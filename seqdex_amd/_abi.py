@@ -66,7 +66,7 @@ T = dict(ROOT=0, DOF=1, RB=2, CONTACT=3, JAC_EEF=4, TARGETS=5, PREV_TARGETS=6, O
          STATES_CLAMPED=10, REW=11, RESET=12, PROGRESS=13, RANDOMIZE=14, ACTIONS=15, INIT_POS=16, INIT_ROT=17,
          SUCCESSES=18, META_REW=19, CONS_SUCCESSES=20, FINGER_DIST=21, TVALUE=22, ARM_CONTACTS=23, STUDENT_OBS=24,
          SUCCESS_BUF=25, PILE_CHOICE=26, NCONTACTS=27, DEBUG=28, HARVEST_HAND=29, HARVEST_OBJ=30,
-         HARVEST_COUNT=31, INSERT_AUX=32)
+         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35)
 # sdxp_tensor_id
 TP = dict(AC_PARAMS=0, AC_GRADS=1, CV_PARAMS=2, CV_GRADS=3, MB_OBS=4, MB_STATES=5, MB_ACTIONS=6, MB_MUS=7,
           MB_SIGMAS=8, MB_NEGLOGP=9, MB_VALUES=10, MB_REWARDS=11, MB_DONES=12, RETURNS=13, ADVANTAGES=14,
@@ -78,7 +78,9 @@ SDX_EXPORTS = ["sdx_create", "sdx_destroy", "sdx_tensor", "sdx_load_initial_stat
                "sdx_reset_idx", "sdx_refresh_kinematics", "sdx_num_envs", "sdx_last_error",
                "sdxp_create", "sdxp_destroy", "sdxp_tensor", "sdxp_param_count", "sdxp_act", "sdxp_store_rewards",
                "sdxp_finish_rollout", "sdxp_update", "sdxp_update_impl", "sdxp_update_status", "sdxp_backward", "sdxp_apply", "sdxp_backward_factors",
-               "sdxp_grads_from_factors", "sdxp_apply_factors", "sdxp_last_error"]
+               "sdxp_grads_from_factors", "sdxp_apply_factors", "sdxp_last_error",
+               "sdxtv_create", "sdxtv_destroy", "sdxtv_tensor", "sdxtv_sample", "sdxtv_step", "sdxtv_train", "sdxtv_predict",
+               "sdxtv_last_error"]
 
 _lib = None
 
@@ -117,6 +119,15 @@ def load_library():
     lib.sdxp_act.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     lib.sdxp_store_rewards.argtypes = [vp, i32, vp, vp, vp]
     lib.sdxp_finish_rollout.argtypes = [vp, vp, vp, vp]
+    lib.sdxtv_create.argtypes = [i32, i32, C.c_uint64, C.POINTER(vp)]
+    lib.sdxtv_destroy.argtypes = [vp]
+    lib.sdxtv_tensor.argtypes = [vp, i32, C.POINTER(vp), i64p, i32p, i32p]
+    lib.sdxtv_sample.argtypes = [vp, vp, i32, vp, i32, vp]
+    lib.sdxtv_step.argtypes = [vp, C.c_float, vp]
+    lib.sdxtv_train.argtypes = [vp, vp, i32, vp, i32, i32, C.c_float, vp]
+    lib.sdxtv_predict.argtypes = [vp, vp, i32, vp, vp]
+    lib.sdxtv_last_error.argtypes = [vp]
+    lib.sdxtv_last_error.restype = C.c_char_p
     lib.sdxp_update.argtypes = [vp, vp]
     lib.sdxp_update_impl.argtypes = [vp]
     lib.sdxp_update_status.argtypes = [vp, vp]
@@ -128,7 +139,7 @@ def load_library():
     lib.sdxp_last_error.argtypes = [vp]
     lib.sdxp_last_error.restype = C.c_char_p
     for n in SDX_EXPORTS:
-        if n not in ("sdx_last_error", "sdxp_last_error", "sdxp_param_count"):
+        if n not in ("sdx_last_error", "sdxp_last_error", "sdxp_param_count", "sdxtv_last_error"):
             getattr(lib, n).restype = i32
     _lib = lib
     return lib

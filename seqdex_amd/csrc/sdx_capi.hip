@@ -164,6 +164,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(harvest_obj, (size_t)8 * SDX_HARVEST_SLOTS * 13);
   ALLOC(harvest_count, 8);
   ALLOC(insert_aux, (size_t)N * 8);
+  ALLOC(tv_succ, (size_t)SDX_TV_LOG_SLOTS * 4);
+  ALLOC(tv_fail, (size_t)SDX_TV_LOG_SLOTS * 4);
+  ALLOC(tv_count, 2);
 #undef ALLOC
   set_tensor(h, SDX_T_ROOT, B.root, SDX_F32, {(int64_t)N * SDX_ACTORS, 13});
   set_tensor(h, SDX_T_DOF, B.dof, SDX_F32, {(int64_t)N * SDX_NDOF, 2});
@@ -198,6 +201,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_HARVEST_OBJ, B.harvest_obj, SDX_F32, {8, SDX_HARVEST_SLOTS, 13});
   set_tensor(h, SDX_T_HARVEST_COUNT, B.harvest_count, SDX_I32, {8});
   set_tensor(h, SDX_T_INSERT_AUX, B.insert_aux, SDX_F32, {N, 8});
+  set_tensor(h, SDX_T_TV_SUCCESS, B.tv_succ, SDX_F32, {SDX_TV_LOG_SLOTS, 4});
+  set_tensor(h, SDX_T_TV_FAILURE, B.tv_fail, SDX_F32, {SDX_TV_LOG_SLOTS, 4});
+  set_tensor(h, SDX_T_TV_COUNT, B.tv_count, SDX_I32, {2});
 
   // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
   std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);

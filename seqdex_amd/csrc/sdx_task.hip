@@ -15,6 +15,17 @@
 // derived quantities are computed once per wave, rows are written back lane-strided.
 #include "sdx_common.h"
 
+// T-value datasets (the reference's HDF5 groups data/success_dataset, data/failure_dataset, GS:470-480): the camera-frame
+// quaternion of the target brick (camera_view_segmentation_target_rot of the last compute_observations) of a finished episode goes to
+// the success or the failure ring.  Wave-uniform call; lane 0 claims the slot.
+__device__ __forceinline__ void tv_log(const SdxBuf& B, int e, int lane, bool success) {
+  int slot = 0;
+  if (lane == 0) slot = atomicAdd(&B.tv_count[success ? 0 : 1], 1) % SDX_TV_LOG_SLOTS;
+  slot = __shfl(slot, 0, SDX_WAVE);
+  float* dst = (success ? B.tv_succ : B.tv_fail) + (size_t)slot * 4;
+  if (lane < 4) dst[lane] = B.cam_rot[(size_t)e * 4 + lane];
+}
+
 // ------------------------------------------------------------------------------------------------ K1 + K2
 // flags: bit0 reset envs with reset_buf != 0; bit1 reset envs with ext_mask != 0; bit2 compute targets
 __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __restrict__ C, SdxBuf B,
@@ -35,7 +46,9 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
     // (y < 0) with the fingers still around it and an accepting T-value is stored in the ring buffer of its type group
     if (B.step_count[0] > 0 && sc.task_kind == 0) {                                // `if self.total_steps > 0`; GraspSim's rule only
       const float* tg = root_e + seg_actor(e) * 13;
-      if (tg[1] < 0.0f && B.finger_dist[e] < 0.6f && B.tvalue[e] > 0.8f) {         // GS:1404-1406
+      const bool good = tg[1] < 0.0f && B.finger_dist[e] < 0.6f && B.tvalue[e] > 0.8f;   // GS:1404-1406
+      tv_log(B, e, lane, good);                                                    // the save_hdf5 datasets, GS:1407-1438
+      if (good) {
         int slot = 0;
         if (lane == 0) slot = atomicAdd(&B.harvest_count[e & 7], 1) % SDX_HARVEST_SLOTS;   // GS:1417,1440-1441
         slot = __shfl(slot, 0, SDX_WAVE);
@@ -72,7 +85,11 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
       // compute_observations): inserted = within 2 cm and 0.2 rad of the site or of its 180-degree twin
       __syncthreads();                                                              // the pile / hand writes above land first
       float* aux = B.insert_aux + (size_t)e * 8;
-      if (lane == 0 && B.step_count[0] > 0) B.success_buf[e] = (aux[3] < 0.02f && aux[4] < 0.2f) ? 1 : 0;
+      if (B.step_count[0] > 0) {
+        const bool inserted = aux[3] < 0.02f && aux[4] < 0.2f;
+        if (lane == 0) B.success_buf[e] = inserted ? 1 : 0;
+        tv_log(B, e, lane, inserted);                                               // train_t_value datasets, IS:1392-1410
+      }
       // base plate back to its place with a 0 / 90 degree yaw drawn ONCE per reset event (random.sample([0, 1], 1), IS:1435-1445)
       const float yaw_half = 0.785f * (float)(sdx_hash(B.seed, 0xA11CEull, (uint64_t)B.step_count[0]) & 1ull);
       if (lane < 13) {

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     txt = open(os.path.join(ROOT, "include", "seqdex.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(sdxp?_[a-z_0-9]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(sdx(?:p|tv)?_[a-z_0-9]+)\s*\(", txt)))
 
 
 def test_header_declares_expected_surface():

@@ -272,3 +272,32 @@ def test_persistent_kernel_failure_falls_back_to_graph_path():
         assert abs(a.ctrl().rms_count - c.ctrl().rms_count) < 1e-9          # the running statistics were not double counted
     finally:
         a.close(); c.close()
+
+
+def test_checkpoint_round_trip_in_rlgames_layout(tmp_path):
+    """A2CAgent.save writes rl_games' dictionary (named state_dicts `model` / `assymetric_vf_nets`); restore on a fresh handle brings
+    back parameters, Adam moments and the central-value running statistics bit for bit."""
+    from seqdex_amd.a2c_agent import A2CAgent
+    n = 16
+    a = _filled_agent(n, 5)
+    b = _filled_agent(n, 9)
+    try:
+        a.update()
+        torch.cuda.synchronize()
+        ag = A2CAgent.__new__(A2CAgent)
+        ag.ppo, ag.epoch_num, ag.frame, ag.last_mean_rewards = a, 3, 384, -1.0
+        ag.save(str(tmp_path / "ck"))
+        ck = torch.load(str(tmp_path / "ck.pth"), map_location="cpu", weights_only=False)
+        assert tuple(ck["model"]["a2c_network.mu.weight"].shape) == (23, 256)
+        assert tuple(ck["assymetric_vf_nets"]["model.a2c_network.critic_mlp.0.weight"].shape) == (1024, 564)
+        assert set(ck) >= {"model", "optimizer", "epoch", "frame", "last_mean_rewards", "env_state", "assymetric_vf_nets"}
+        bg = A2CAgent.__new__(A2CAgent)
+        bg.ppo = b
+        assert float((a.t["AC_PARAMS"] - b.t["AC_PARAMS"]).abs().max()) > 1e-3
+        bg.restore(str(tmp_path / "ck.pth"))
+        torch.cuda.synchronize()
+        for k in ("AC_PARAMS", "CV_PARAMS", "AC_ADAM_M", "AC_ADAM_V", "CV_ADAM_M", "CV_ADAM_V", "CV_RMS_MEAN", "CV_RMS_VAR"):
+            np.testing.assert_array_equal(a.t[k].cpu().numpy(), b.t[k].cpu().numpy(), err_msg=k)
+        assert bg.epoch_num == 3 and bg.frame == 384
+    finally:
+        a.close(); b.close()
