@@ -26,8 +26,8 @@ BYTES_PER_ENV_STEP = 18496     # algorithmic HBM bytes per env
 # separate runs of this same command at the default config; both counters are in KiB; FETCH_SIZE is reported raw - the guide's
 # x2 correction is calibrated for 16 B/lane streaming reads only, the exchange words here are 8 B/lane).  PMC counters cannot
 # be read from inside this process, so `traffic` is quoted from those files and is null for any other configuration.
-PMC_TRAFFIC_BYTES = {("k_update_persistent", 1024): (15700756.4 + 5536964.6) * 1024,     # profiles/r1_bench_pmc_{fetch,write}_v3.csv
-                     ("k_physics", 1024): (2848.9 + 16305.9) * 1024}   # the 40 dispatches with 1024 workgroups (grid 524288) only
+PMC_TRAFFIC_BYTES = {("k_update_persistent", 1024): (14343183.0 + 7011506.7) * 1024,     # profiles/r1_bench_pmc_{fetch,write}_v4.csv
+                     ("k_physics", 1024): (2874.8 + 16285.8) * 1024}   # the 57 dispatches with 1024 workgroups (grid 524288) only
 
 
 def parse():
