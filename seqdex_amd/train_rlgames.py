@@ -10,15 +10,15 @@ import os
 import yaml
 
 
-def main(argv=None):
+def build(args, task_kwargs=None, minibatch_size=0):
+    """args (config.get_args) -> (task, env, agent, logdir, rank): everything main() does before agent.train() / agent.play()"""
     import torch
     from .a2c_agent import A2CAgent
-    from .config import get_args, load_cfg, set_seed
+    from .config import load_cfg, set_seed
     from .tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
     from .tasks.block_assembly_orient import BlockAssemblyOrient
     from .tasks.block_assembly_insert_sim import BlockAssemblyInsertSim
     from .vec_task_rlgames import RLgamesVecTaskPython
-    args = get_args(argv)
     args.algo = "lego"                                                                    # TR:36
     args.task_type = "RLgames"                                                            # TR:56
     print("Loading config: ", args.cfg_train)
@@ -35,9 +35,12 @@ def main(argv=None):
     set_seed(seed + rank, args.torch_deterministic)                                       # TR:70 (+ rank, App. C)
     task_cls = {"BlockAssemblyGraspSim": BlockAssemblyGraspSim, "BlockAssemblyOrient": BlockAssemblyOrient,
                 "BlockAssemblyInsertSim": BlockAssemblyInsertSim}[args.task]   # eval(args.task), PT:162
-    task = task_cls(cfg, None, None, "cuda", local_rank, True, seed=seed + rank)                   # PT:162-170
+    task = task_cls(cfg, None, None, "cuda", local_rank, True, seed=seed + rank, **(task_kwargs or {}))   # PT:162-170
     env = RLgamesVecTaskPython(task, args.rl_device)                                      # PT:178
     rl = cfg_train                                                                        # TR:78-85
+    if minibatch_size:     # programmatic override (the reference parses --minibatch_size but never applies it, CF:43)
+        rl["params"]["config"]["minibatch_size"] = minibatch_size
+        rl["params"]["config"]["central_value_config"]["minibatch_size"] = minibatch_size
     rl["params"]["config"]["name"] = args.task
     rl["params"]["config"]["num_actors"] = env.num_environments
     rl["params"]["seed"] = seed
@@ -49,13 +52,20 @@ def main(argv=None):
     agent = A2CAgent("run", rl["params"])                                                 # TR:88-94 (Runner.run -> agent.train)
     if rl["params"].get("load_path"):
         agent.restore(rl["params"]["load_path"])
+    return task, env, agent, logdir, rank
+
+
+def main(argv=None):
+    from .config import get_args
+    args = get_args(argv)
+    task, env, agent, logdir, rank = build(args)
     if args.train:
         agent.train()
         if rank == 0:
             os.makedirs(os.path.join(logdir, "nn"), exist_ok=True)
             agent.save(os.path.join(logdir, "nn", "last_%s_ep_%d" % (args.task, agent.epoch_num)))
     else:
-        agent.play(int(rl["params"]["config"].get("player", {}).get("games_num", 1)))
+        agent.play(int(agent.config.get("player", {}).get("games_num", 1)))
 
 
 if __name__ == "__main__":

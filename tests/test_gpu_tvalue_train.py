@@ -131,3 +131,17 @@ def test_insert_task_logs_tvalue_datasets_and_trainer_consumes_them(scene):
         assert np.isfinite(task.tvalue.cpu().numpy()).all()
     finally:
         tr.close()
+
+
+def test_bi_optimization_outer_loop_one_round(tmp_path, monkeypatch):
+    """one round of the chain's outer loop at toy size: Orient -> GraspSim -> InsertSim forward, then InsertSim again for the
+    transition-value data, the trainer, and GraspSim fine-tuned with the new value; checkpoints in rl_games' layout are written and
+    re-loaded along the way."""
+    from seqdex_amd.scripts import bi_optimization as bo
+    monkeypatch.chdir(tmp_path)
+    paths, tv = bo.block_assembly(rounds=1, num_envs=64, epochs=2, tvalue_rollout=20, insert_minibatch=256)
+    for k in ("orient", "grasp", "insert"):
+        ck = torch.load(paths[k], map_location="cpu", weights_only=False)
+        assert "a2c_network.mu.weight" in ck["model"] and ck["epoch"] == 2
+    assert tv is None or set(tv) == {"linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "linear3.weight", "linear3.bias",
+                                      "output_layer.weight", "output_layer.bias"}
