@@ -45,6 +45,7 @@ extern "C" {
 #define SDX_NUM_ACTIONS 23  /* GS:211                                                                        */
 #define SDX_OBS_FRAME 132
 #define SDX_STATE_FRAME 188
+#define SDX_PILE_HARVEST_SLOTS 512 /* Orient's ring of pile states per brick-type group (the reference keeps 10 000: OR:1485)     */
 #define SDX_TV_LOG_SLOTS 65536 /* rows of each T-value dataset ring (success / failure)                          */
 #define SDX_HARVEST_SLOTS 5001 /* ring of grasp terminal states per brick-type group (GS:1440: index wraps after 5000) */
 #define SDX_TV_PARAMS 42562 /* GraspInsertTValue 4-256-128-64-2 weights+biases (terminal_value_function.py:30-46) */
@@ -98,7 +99,10 @@ typedef enum {
   SDX_T_TV_SUCCESS = 33,   /* f32 [65536,4]     camera-frame target quaternions of successful episode ends (ring)   GS:1404-1412, IS:1392-1400 */
   SDX_T_TV_FAILURE = 34,   /* f32 [65536,4]     ... of failed ones                                                  GS:1420-1438, IS:1401-1410 */
   SDX_T_TV_COUNT = 35,     /* i32 [2]           rows logged so far: [success, failure] (ring index = count % 65536)                      */
-  SDX_T_COUNT = 36
+  SDX_T_PILE_HARVEST = 36, /* f32 [8,S,132,13]  Orient: brick states of finished episodes that left the target brick reachable (ring per
+                            *                    brick-type group; S = 512 for task_kind 1, else 1) = the saved piles GraspSim starts from    OR:1463-1488, GS:412-413 */
+  SDX_T_PILE_HARVEST_COUNT = 37, /* i32 [8]     pile states harvested so far (ring index = count % S)                                    */
+  SDX_T_COUNT = 38
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the

@@ -167,6 +167,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(tv_succ, (size_t)SDX_TV_LOG_SLOTS * 4);
   ALLOC(tv_fail, (size_t)SDX_TV_LOG_SLOTS * 4);
   ALLOC(tv_count, 2);
+  B.pile_slots = scene->task_kind == 1 ? SDX_PILE_HARVEST_SLOTS : 1;
+  ALLOC(pile_harvest, (size_t)8 * B.pile_slots * SDX_NBRICK * 13);
+  ALLOC(pile_harvest_count, 8);
 #undef ALLOC
   set_tensor(h, SDX_T_ROOT, B.root, SDX_F32, {(int64_t)N * SDX_ACTORS, 13});
   set_tensor(h, SDX_T_DOF, B.dof, SDX_F32, {(int64_t)N * SDX_NDOF, 2});
@@ -204,6 +207,8 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_TV_SUCCESS, B.tv_succ, SDX_F32, {SDX_TV_LOG_SLOTS, 4});
   set_tensor(h, SDX_T_TV_FAILURE, B.tv_fail, SDX_F32, {SDX_TV_LOG_SLOTS, 4});
   set_tensor(h, SDX_T_TV_COUNT, B.tv_count, SDX_I32, {2});
+  set_tensor(h, SDX_T_PILE_HARVEST, B.pile_harvest, SDX_F32, {8, B.pile_slots, SDX_NBRICK, 13});
+  set_tensor(h, SDX_T_PILE_HARVEST_COUNT, B.pile_harvest_count, SDX_I32, {8});
 
   // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
   std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);
@@ -349,7 +354,8 @@ static int orient_reset_if_needed(sdx_handle h, hipStream_t st) {
   HIPCHK(h, hipStreamSynchronize(st));
   if (steps > 0)
     for (int i = 0; i < 50; ++i) { sdxk_orient_pregrasp(h->d_const, &h->buf, h->orient_mask, 0, i, st); sdxk_physics(h->d_const, &h->buf, st); }
-  sdxk_pre_physics(h->d_const, &h->buf, nullptr, h->orient_mask, nullptr, 2, st);      // restore piles, hand to the prepare pose, counters
+  if (steps > 0) sdxk_post_physics(h->d_const, &h->buf, 0, st);                        // self.compute_observations() before the harvest, OR:1464-1465
+  sdxk_pre_physics(h->d_const, &h->buf, nullptr, h->orient_mask, nullptr, 2, st);      // harvest, restore piles, hand to the prepare pose, counters
   sdxk_physics(h->d_const, &h->buf, st);
   sdxk_physics(h->d_const, &h->buf, st);                                               // OR:1618-1620
   sdxk_orient_post_reset(h->d_const, &h->buf, h->orient_mask, st);

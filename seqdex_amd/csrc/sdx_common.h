@@ -45,6 +45,9 @@ struct SdxBuf {
   long long* dbg;          // [64] phase time stamps of env 0 (profiling aid)
   float *harvest_hand, *harvest_obj;   // [8, SDX_HARVEST_SLOTS, 23*2] / [8, SDX_HARVEST_SLOTS, 13]
   int32_t* harvest_count;  // [8]
+  float* pile_harvest;     // [8, pile_slots, 132, 13] Orient terminal pile states
+  int32_t* pile_harvest_count;   // [8]
+  int32_t pile_slots;
   float *tv_succ, *tv_fail;   // [SDX_TV_LOG_SLOTS,4] camera-frame target quaternions logged at episode ends (T-value datasets)
   int32_t* tv_count;       // [2] rows logged: success, failure
   float* insert_aux;       // [N,8] InsertSim: 0..2 rot_err of the last pre_physics_step (IS:1539), 3 |brick - site|, 4 rot_dist

@@ -57,6 +57,22 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
         if (lane < 13) B.harvest_obj[o * 13 + lane] = tg[lane];                            // GS:1416
       }
     }
+    // BlockAssemblyOrient, OR:1463-1488: an episode that ends with the hand withdrawn (finger distance > 0.3), the target brick still
+    // in the bin half (0 < y < 0.5) and an accepting T-value hands its WHOLE brick pile on: these are the saved piles that
+    // BlockAssemblyGraspSim starts its episodes from (GS:412-413,1507-1513); the camera-frame quaternion goes to the T-value datasets
+    if (B.step_count[0] > 0 && sc.task_kind == 1) {
+      const float* tg = root_e + seg_actor(e) * 13;
+      const bool good = B.finger_dist[e] > 0.3f && tg[1] > 0.0f && tg[1] < 0.5f && B.tvalue[e] > 0.6f;   // OR:1468-1470
+      tv_log(B, e, lane, good);
+      if (good) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&B.pile_harvest_count[e & 7], 1) % B.pile_slots;          // OR:1483-1486
+        slot = __shfl(slot, 0, SDX_WAVE);
+        float* dst = B.pile_harvest + ((size_t)(e & 7) * B.pile_slots + slot) * SDX_NBRICK * 13;
+        const float* srcb = root_e + SDX_ACTOR_BRICK0 * 13;
+        for (int i = lane; i < SDX_NBRICK * 13; i += SDX_WAVE) dst[i] = srcb[i];
+      }
+    }
     int choice;
     if (ext_choice) choice = ext_choice[e];
     else choice = (int)(sdx_hash(B.seed, (uint64_t)e, (uint64_t)B.step_count[0]) % (uint64_t)B.K);

@@ -69,9 +69,12 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
     paths = {}
     for i in range(rounds):
         # ---- forward initialisation (bi_optimization.py:115-118)
-        paths["orient"], _ = main_rlgames("BlockAssemblyOrient", num_envs, max_iterations=epochs, policy_path=paths.get("orient", ""))
+        paths["orient"], orient = main_rlgames("BlockAssemblyOrient", num_envs, max_iterations=epochs, policy_path=paths.get("orient", ""),
+                                               keep=True)
+        piles = orient.pile_terminal_states()                                             # hand-off OR:1483-1510 -> GS:412-413
+        orient.sim.close()
         paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, max_iterations=epochs, policy_path=paths.get("grasp", ""),
-                                             tvalue_state=tv, keep=True)
+                                             tvalue_state=tv, keep=True, task_kwargs={"initial_piles": piles})
         cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
         grasp_states = grasp.grasp_terminal_states() if cnt.min() > 0 else None          # hand-off GS:1447-1450 -> IS:372-375
         grasp.sim.close()

@@ -78,6 +78,8 @@ class SdxSim:
 
     # ------------------------------------------------------------------ C ABI calls
     def load_initial_states(self, piles):
+        if torch.is_tensor(piles):
+            piles = piles.detach().cpu().numpy()
         piles = np.ascontiguousarray(piles, dtype=np.float32)
         assert piles.ndim == 4 and piles.shape[0] == 8 and piles.shape[2:] == (132, 13), piles.shape
         self._check(self.lib.sdx_load_initial_states(self.h, piles.ctypes.data_as(C.c_void_p), piles.shape[1]))

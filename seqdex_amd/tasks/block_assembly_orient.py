@@ -8,8 +8,10 @@ Same robot, bin and brick pile as BlockAssemblyGraspSim; what the Orient task ch
   * reward exp(-5 (1 - (z_align + 1)/2) - 5 max(d - 0.4, 0)), reset on time-out only (OR:1843-1907), episodeLength 75;
   * finger drives kp 20 / effort 0.7 (OR:596-597), target brick 50 x heavier (OR:977);
   * reset with the two scripted 50-step pre-grasp phases (OR:1427-1461, 1655-1695) - inside sdx_step, on the device.
-Not reproduced: the terminal-state harvesting of this task (OR:1463-1515, 8 x 11 024 x 108 x 13 floats), the
-36-brick floor of this scene (the GraspSim slab is used), the density 2000 of the fixed bricks (they are static here anyway).
+  * terminal-state harvesting (OR:1463-1488): finished episodes that leave the target brick reachable hand their whole brick pile on
+    (`pile_terminal_states()` -> `BlockAssemblyGraspSim(initial_piles=...)`), ring of 512 per brick-type group (reference: 10 000).
+Not reproduced: the 36-brick floor of this scene (the GraspSim slab is used), the density 2000 of the fixed
+bricks (they are static here anyway).
 """
 from .. import _abi
 from .block_assembly_grasp_sim import BlockAssemblyGraspSim
@@ -25,3 +27,12 @@ class BlockAssemblyOrient(BlockAssemblyGraspSim):
         for j in range(7, 23):                                                 # OR:595-597
             kp[j], effort[j] = 20.0, 0.7
         return {"kp": kp, "effort": effort, "seg_mass_scale": 50.0, "target_euler": [0.0, 3.1415, 1.571]}
+
+    def pile_terminal_states(self):
+        """[8, K, 132, 13] pile states harvested so far (K = the smallest fill over the 8 brick-type groups; None while one is empty):
+        the reference's saved_searching_ternimal_states list (OR:1483-1510), the format BlockAssemblyGraspSim loads (GS:412-413)."""
+        import numpy as np
+        s = self.sim
+        cnt = np.minimum(s.PILE_HARVEST_COUNT.cpu().numpy(), s.PILE_HARVEST.shape[1])
+        k = int(cnt.min())
+        return s.PILE_HARVEST[:, :k].clone() if k > 0 else None

@@ -136,3 +136,48 @@ def test_orient_task_end_to_end_with_scripted_reset(scene):
     r = task.sim.ROOT.cpu().numpy().reshape(n, 142, 13)
     assert r[:, 9:81, 2].min() > 0.55 and np.isfinite(r).all()
     assert 0.0 < float(rew.mean()) <= 1.0                        # exp(-...) reward
+
+
+def test_orient_harvests_pile_states_for_grasp_sim(scene):
+    """OR:1463-1488: at a reset event (after the first one) every env whose episode ended with the hand withdrawn, the target brick in
+    the bin half and an accepting T-value stores its whole brick pile in the ring of its brick-type group and logs a T-value success;
+    the others log failures.  The harvested piles are what BlockAssemblyGraspSim starts from (GS:412-413)."""
+    import yaml
+    from seqdex_amd import _abi
+    from seqdex_amd.tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
+    from seqdex_amd.tasks.block_assembly_orient import BlockAssemblyOrient
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root_dir, "seqdex_amd/cfg/allegro_hand_block_assembly_orient.yaml")))
+    n = 16
+    cfg["env"]["numEnvs"] = n
+    task = BlockAssemblyOrient(cfg, device_type="cuda", device_id=0, headless=True, seed=4, piles_per_type=2)
+    flat = np.zeros(_abi.TV_PARAMS, np.float32)
+    flat[-1] = 20.0                                   # output_layer.bias[1]: sigmoid(elu(20)) = 1 -> the 0.99 gate accepts every state
+    task.sim.set_tvalue_weights(flat)
+    assert task.pile_terminal_states() is None
+    g = torch.Generator().manual_seed(0)
+    for t in range(77):                               # episode length 75: one time-out of all envs, its reset event runs in step 76
+        task.step(((torch.rand(n, 23, generator=g) * 2 - 1) * 0.1).cuda())
+    torch.cuda.synchronize()
+    tvc = task.sim.TV_COUNT.cpu().numpy()
+    pc = task.sim.PILE_HARVEST_COUNT.cpu().numpy()
+    assert tvc.sum() == n and pc.sum() == tvc[0] and tvc[0] >= n // 2, (tvc, pc)
+    piles = task.pile_terminal_states()
+    assert piles is not None and tuple(piles.shape[2:]) == (132, 13)
+    p = piles.cpu().numpy()
+    assert np.isfinite(p).all()
+    for grp in range(8):
+        seg = scene.seg_index(grp) - 9
+        y = p[grp, :, seg, 1]
+        assert ((y > 0) & (y < 0.5)).all()            # the harvest rule on the target brick of that group
+    np.testing.assert_allclose(np.linalg.norm(p[..., 3:7], axis=-1), 1.0, atol=1e-4)
+    # hand-off: a GraspSim instance starts its episodes from these piles
+    gcfg = yaml.safe_load(open(os.path.join(root_dir, "seqdex_amd/cfg/allegro_hand_block_assembly_grasp_sim.yaml")))
+    gcfg["env"]["numEnvs"] = n
+    gs = BlockAssemblyGraspSim(gcfg, device_type="cuda", device_id=0, headless=True, seed=1, initial_piles=piles)
+    gs.step(torch.zeros(n, 23).cuda())
+    torch.cuda.synchronize()
+    r = gs.sim.ROOT.view(n, 142, 13).cpu().numpy()
+    ch = gs.sim.PILE_CHOICE.cpu().numpy()
+    for e in range(n):                                # positions after one simulator step from the chosen harvested pile
+        assert np.abs(r[e, 9:81, 0:3] - p[e % 8, ch[e], 0:72, 0:3]).max() < 0.02
