@@ -103,14 +103,20 @@ class A2CAgent:
         a = self.ppo.act(t, obs["obs"], obs["states"], self.dones)
         return {"actions": a}
 
-    def play_steps(self):
-        """PS:220-275 / RC:1394-1483: horizon loop; every call below is asynchronous on the current stream."""
+    def play_steps(self, deterministic=False):
+        """PS:220-275 / RC:1394-1483: horizon loop; every call below is asynchronous on the current stream.  deterministic: zero noise
+        into the Gaussian head, i.e. the mean action (rl_games' player with `deterministic: True`, YG:69)."""
         if self.obs is None:
             self.obs = self.env_reset()
             self.dones = self.vec_env.task.reset_buf
         task = self.vec_env.task
+        eps = None
+        if deterministic:
+            if getattr(self, "_zero_eps", None) is None:
+                self._zero_eps = torch.zeros(self.num_actors, self.ppo.cfg.act_dim, device=self.ppo.device)
+            eps = self._zero_eps
         for n in range(self.horizon_length):
-            a = self.ppo.act(n, self.obs["obs"], self.obs["states"], self.dones)
+            a = self.ppo.act(n, self.obs["obs"], self.obs["states"], self.dones, eps)
             self._ev[n][0].record()
             self.obs, rew, self.dones, infos = self.vec_env.step(a)
             self._ev[n][1].record()
@@ -203,17 +209,23 @@ class A2CAgent:
             if epoch_num >= self.max_epochs:
                 return self.game_rewards.get_mean()[0], epoch_num
 
-    def play(self, games_num=1, max_steps=150):
-        """--play/--test: rollouts only (the reference's player uses the deterministic mean action; here the sampled
-        action with the learned sigma is used, PPO buffers are exercised but no update is made)."""
-        n = 0
+    def play(self, games_num=1, max_steps=150, deterministic=None):
+        """--play/--test: rollouts only, no update.  The action is the policy mean when the YAML's player block says
+        `deterministic: True` (as shipped, YG:69), else sampled with the learned sigma."""
+        if deterministic is None:
+            deterministic = bool(self.config.get("player", {}).get("deterministic", True)) if hasattr(self, "config") else True
+        n, rew, length = 0, 0.0, 0.0
         while n < max(1, games_num):
-            self.play_steps()
+            self.play_steps(deterministic)
             c = self.ppo.ctrl()
             n += int(c.games_cnt)
-            self.game_rewards.update_from(c.games_sum_rew, c.games_cnt)
+            rew += c.games_sum_rew
+            length += c.games_sum_len
+            self.game_rewards.update_from(rew, n)            # means over every game finished during this play() call
+            self.game_lengths.update_from(length, n)
         torch.cuda.synchronize()
-        print("mean episode reward: %.3f" % self.game_rewards.get_mean()[0])
+        print("mean episode reward: %.3f  mean episode length: %.1f  (%d games)" % (self.game_rewards.get_mean()[0],
+                                                                                   self.game_lengths.get_mean()[0], n))
 
     # ------------------------------------------------------------------ checkpoints (rl_games .pth-shaped dict)
     def get_full_state_weights(self):

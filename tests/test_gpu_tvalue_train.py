@@ -143,5 +143,10 @@ def test_bi_optimization_outer_loop_one_round(tmp_path, monkeypatch):
     for k in ("orient", "grasp", "insert"):
         ck = torch.load(paths[k], map_location="cpu", weights_only=False)
         assert "a2c_network.mu.weight" in ck["model"] and ck["epoch"] == 2
+    from seqdex_amd.scripts import evaluation as ev
+    res = ev.block_assembly(paths["orient"], paths["grasp"], paths["insert"], num_envs=64, games=64, insert_minibatch=256)
+    assert set(res) == {"BlockAssemblyOrient", "BlockAssemblyGraspSim", "BlockAssemblyInsertSim"}
+    assert all(np.isfinite(v["reward"]) and v["length"] > 0 for v in res.values()), res
+    assert 0.0 <= res["BlockAssemblyInsertSim"]["insert_success_rate"] <= 1.0
     assert tv is None or set(tv) == {"linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "linear3.weight", "linear3.bias",
                                       "output_layer.weight", "output_layer.bias"}
