@@ -15,6 +15,64 @@
 // derived quantities are computed once per wave, rows are written back lane-strided.
 #include "sdx_common.h"
 
+// orientation_error(quat_from_euler_xyz(euler), current) (OR:1922-1925; quat_from_euler_xyz of isaacgym.torch_utils: half-angle
+// products): vector part of desired * conj(current), flipped into the w >= 0 hemisphere
+__device__ __forceinline__ f3 wrist_error(const float* euler, f4 current) {
+  float sr, cr, sp, cp, sy, cy;
+  sincosf(0.5f * euler[0], &sr, &cr);
+  sincosf(0.5f * euler[1], &sp, &cp);
+  sincosf(0.5f * euler[2], &sy, &cy);
+  f4 qd;
+  qd.x = cy * sr * cp - sy * cr * sp; qd.y = cy * cr * sp + sy * sr * cp; qd.z = sy * cr * cp - cy * sr * sp;
+  qd.w = cy * cr * cp + sy * sr * sp;
+  const f4 qr = qmul(qd, qconj(current));
+  const float sg = qr.w > 0.0f ? 1.0f : (qr.w < 0.0f ? -1.0f : 0.0f);             // torch.sign
+  return F3(qr.x * sg, qr.y * sg, qr.z * sg);
+}
+// control_ik (GS:1796-1804 / OR:1927-1935): y = (J J^T + 0.05^2 I)^-1 dpose by a 6x6 Cholesky solve; the caller forms u = J^T y.
+// J: [6][7] row-major in LDS; every lane computes the same y (wave-uniform).
+__device__ __forceinline__ void control_ik_solve(const float* J, const float* dp, float* y) {
+  float A[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      float s = (r == c) ? 0.05f * 0.05f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) s += J[r * 7 + k] * J[c * 7 + k];
+      A[r][c] = s;
+    }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    d = sqrtf(d);
+    A[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float s = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
+      A[i][j] = s / d;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = dp[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= A[i][k] * y[k];
+    y[i] = s / A[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= A[k][i] * y[k];
+    y[i] = s / A[i][i];
+  }
+}
+
 // T-value datasets (the reference's HDF5 groups data/success_dataset, data/failure_dataset, GS:470-480): the camera-frame
 // quaternion of the target brick (camera_view_segmentation_target_rot of the last compute_observations) of a finished episode goes to
 // the success or the failure ring.  Wave-uniform call; lane 0 claims the slot.
@@ -187,63 +245,15 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
       dp[2] = tg[2] - hb[2] + 0.22f;
       if (m0) dp[2] = B.init_pos[e * 3 + 2] - hb[2] + 0.15f + 0.24f;                // OR:1737
     }
-    // quat_from_euler_xyz(target_euler) (isaacgym.torch_utils; half-angle products), orientation_error OR:1922-1925
-    float sr, cr, sp, cp, sy, cy;
-    sincosf(0.5f * sc.target_euler[0], &sr, &cr);
-    sincosf(0.5f * sc.target_euler[1], &sp, &cp);
-    sincosf(0.5f * sc.target_euler[2], &sy, &cy);
-    f4 qd;
-    qd.x = cy * sr * cp - sy * cr * sp; qd.y = cy * cr * sp + sy * sr * cp; qd.z = sy * cr * cp - cy * sr * sp;
-    qd.w = cy * cr * cp + sy * sr * sp;
-    const f4 qr = qmul(qd, qconj(ld4(hb + 3)));
-    const float sg = qr.w > 0.0f ? 1.0f : (qr.w < 0.0f ? -1.0f : 0.0f);             // torch.sign
-    dp[3] = qr.x * sg; dp[4] = qr.y * sg; dp[5] = qr.z * sg;
+    const f3 re = wrist_error(sc.target_euler, ld4(hb + 3));                        // OR:1740-1741, IS:1538-1539
+    dp[3] = re.x; dp[4] = re.y; dp[5] = re.z;
     if (insert && lane == 0) {                                                      // self.rot_err feeds the reward's reset rule, IS:1539,1675
       float* aux = B.insert_aux + (size_t)e * 8;
       aux[0] = dp[3]; aux[1] = dp[4]; aux[2] = dp[5];
     }
   }
-  // A = J J^T + 0.05^2 I (6x6 SPD), Cholesky solve A y = dpose (control_ik, GS:1796-1804)
-  float A[6][6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c <= r; ++c) {
-      float s = (r == c) ? 0.05f * 0.05f : 0.0f;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) s += s_J[r * 7 + k] * s_J[c * 7 + k];
-      A[r][c] = s;
-    }
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    float d = A[j][j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
-    d = sqrtf(d);
-    A[j][j] = d;
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      float s = A[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
-      A[i][j] = s / d;
-    }
-  }
   float y[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float s = dp[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) s -= A[i][k] * y[k];
-    y[i] = s / A[i][i];
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
-    float s = y[i];
-#pragma unroll
-    for (int k = i + 1; k < 6; ++k) s -= A[k][i] * y[k];
-    y[i] = s / A[i][i];
-  }
+  control_ik_solve(s_J, dp, y);                                                   // GS:1796-1804
   if (lane < SDX_NDOF) {
     const float lo = sc.lower[lane], hi = sc.upper[lane];
     const float prev = B.prev_targets[(size_t)e * SDX_NDOF + lane];
@@ -653,57 +663,10 @@ __global__ __launch_bounds__(SDX_WAVE) void k_orient_pregrasp(const SdxConst* __
     dp[0] = B.init_pos[e * 3 + 0] - hb[0] - 0.18f; dp[1] = B.init_pos[e * 3 + 1] - hb[1];
     dp[2] = B.init_pos[e * 3 + 2] - hb[2] + 0.22f + (iter < 20 ? 0.2f : 0.0f);                   // OR:1662-1667
   }
-  float sr, cr, sp, cp, sy, cy;
-  sincosf(0.5f * sc.target_euler[0], &sr, &cr);
-  sincosf(0.5f * sc.target_euler[1], &sp, &cp);
-  sincosf(0.5f * sc.target_euler[2], &sy, &cy);
-  f4 qd;
-  qd.x = cy * sr * cp - sy * cr * sp; qd.y = cy * cr * sp + sy * sr * cp; qd.z = sy * cr * cp - cy * sr * sp;
-  qd.w = cy * cr * cp + sy * sr * sp;
-  const f4 qr = qmul(qd, qconj(ld4(hb + 3)));
-  const float sg = qr.w > 0.0f ? 1.0f : (qr.w < 0.0f ? -1.0f : 0.0f);
-  dp[3] = qr.x * sg; dp[4] = qr.y * sg; dp[5] = qr.z * sg;
-  // control_ik (OR:1927-1935): A = J J^T + 0.05^2 I, Cholesky, y = A^-1 dpose, u = J^T y
-  float A[6][6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c <= r; ++c) {
-      float acc = (r == c) ? 0.05f * 0.05f : 0.0f;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) acc += s_J[r * 7 + k] * s_J[c * 7 + k];
-      A[r][c] = acc;
-    }
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    float d = A[j][j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
-    d = sqrtf(d);
-    A[j][j] = d;
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      float acc = A[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) acc -= A[i][k] * A[j][k];
-      A[i][j] = acc / d;
-    }
-  }
+  const f3 re = wrist_error(sc.target_euler, ld4(hb + 3));
+  dp[3] = re.x; dp[4] = re.y; dp[5] = re.z;
   float y[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float acc = dp[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) acc -= A[i][k] * y[k];
-    y[i] = acc / A[i][i];
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
-    float acc = y[i];
-#pragma unroll
-    for (int k = i + 1; k < 6; ++k) acc -= A[k][i] * y[k];
-    y[i] = acc / A[i][i];
-  }
+  control_ik_solve(s_J, dp, y);                                                                  // OR:1927-1935
   if (lane < SDX_NDOF) {
     float cur;
     if (lane < 7) {
