@@ -489,3 +489,105 @@ def insert_hand_reward(target_pos, target_rot, extra_pos, extra_rot, symmetry_ro
     cons = np.where(num_resets > 0, F(av_factor) * fin / max(num_resets, 1) + F(1.0 - av_factor) * cons_successes,
                     cons_successes).astype(F)
     return reward, resets.astype(np.int64), cons, rot_dist
+
+
+# ================================================================== BlockAssemblySearch (first policy of the chain) - pure functions
+# SE = dexteroushandenvs/tasks/block_assembly/allegro_hand_block_assembly_search.py.  Pinned by tests/golden/S*.npz
+# (oracle/gen_golden_search.py).  The task itself is NOT built (segmentation rasteriser, its reset with 60 settle steps and the
+# hand-position history are missing): this is the oracle a later round's kernels will be checked against.
+SEARCH_EULER = np.array([0.0, 3.14, 1.57], dtype=F)                                              # SE:1569
+SEARCH_SUCCESS_PIXELS = np.array([20, 20, 15, 20, 20, 30, 30, 20])                               # SE:1289
+
+
+def search_pre_physics_targets(actions, q, prev_targets, hand_pos, hand_rot, target_pos, J, lower, upper, act_moving_average=0.6):
+    """SE:1557-1596: fingers = moving average of the scaled action, clamped; arm by the IK that keeps the hand base 0.24 above and
+    0.18 behind the target brick with the wrist at quat_from_euler_xyz(0, 3.14, 1.57); everything clamped to the joint limits."""
+    a = actions.astype(F)
+    n = a.shape[0]
+    cur = np.zeros_like(prev_targets, dtype=F)
+    f = scale(a[:, 7:23], lower[7:23], upper[7:23])
+    f = F(act_moving_average) * f + F(1.0 - act_moving_average) * prev_targets[:, 7:23]
+    cur[:, 7:23] = np.maximum(np.minimum(f, upper[7:23]), lower[7:23])
+    pos_err = (target_pos - hand_pos).astype(F)
+    pos_err[:, 2] += F(0.24)
+    pos_err[:, 0] -= F(0.18)
+    te = np.broadcast_to(SEARCH_EULER, (n, 3))
+    rot_err = orientation_error(quat_from_euler_xyz(te[:, 0], te[:, 1], te[:, 2]), hand_rot)
+    cur[:, :7] = q[:, :7] + control_ik(J, np.concatenate([pos_err, rot_err], axis=-1))
+    return np.maximum(np.minimum(cur, upper), lower).astype(F)
+
+
+def segmentation_pixel_stats(seg, ids):
+    """SE:1232-1241: pixels of the target's segmentation id in the [H, W] image: count and the truncated mean row / column (0, 0
+    when the target is not visible)."""
+    n = seg.shape[0]
+    cx, cy, num = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for i in range(n):
+        rows, cols = np.nonzero(seg[i] == ids[i])
+        num[i] = rows.size
+        if rows.size:
+            cx[i], cy[i] = int(rows.astype(np.float32).mean()), int(cols.astype(np.float32).mean())
+    return cx, cy, num
+
+
+def search_obs_frame(dof, actions, lower, upper):
+    """compute_contact_observations SE:1220-1230: the same 62 numbers as Orient's compute_real_observations"""
+    return orient_obs_frame(dof, actions, lower, upper)
+
+
+def search_state_frame(dof, actions, lower, upper, a):
+    """compute_contact_asymmetric_observations SE:1168-1218 (175 numbers used of the 188-wide frame); `a` maps the attribute names the
+    reference reads (fingertip positions, hand base pose, target pose, eight hand-position history means, pixel statistics, twists)."""
+    n = dof.shape[0]
+    q, qd = dof[..., 0], dof[..., 1]
+    s = np.zeros((n, 188), dtype=F)
+    s[:, 0:23] = unscale(q, lower, upper)
+    s[:, 23:46] = F(0.2) * qd
+    s[:, 46:49], s[:, 49:52], s[:, 52:55], s[:, 55:58] = a["arm_hand_ff_pos"], a["arm_hand_rf_pos"], a["arm_hand_mf_pos"], a["arm_hand_th_pos"]
+    s[:, 58:81] = actions
+    s[:, 81:88] = a["hand_base_pose"]
+    s[:, 88:95] = a["segmentation_target_pose"]
+    for k in range(8):
+        s[:, 96 + 3 * k:99 + 3 * k] = a["hand_pos_history_%d" % k]
+    s[:, 120] = a["center_x"].reshape(-1) / F(128)
+    s[:, 121] = a["center_y"].reshape(-1) / F(128)
+    s[:, 122] = a["point_num"].reshape(-1) / F(100)
+    s[:, 123:126], s[:, 126:129] = a["hand_base_linvel"], a["hand_base_angvel"]
+    for k, f in enumerate(("ff", "mf", "rf", "th")):
+        s[:, 129 + 10 * k:133 + 10 * k] = a["arm_hand_%s_rot" % f]
+        s[:, 133 + 10 * k:136 + 10 * k] = a["arm_hand_%s_linvel" % f]
+        s[:, 136 + 10 * k:139 + 10 * k] = a["arm_hand_%s_angvel" % f]
+    s[:, 169:172], s[:, 172:175] = a["segmentation_target_linvel"], a["segmentation_target_angvel"]
+    return s
+
+
+def search_hand_reward(target_pos, init_pos, ff, rf, mf, th, progress, reset_buf, cons_successes, successes, arm_contacts, actions,
+                       max_episode_length=75.0, av_factor=0.1):
+    """compute_hand_reward SE:1660-1711: min(-0.2 d, -0.06) - arm contacts - 0.005 |a|^2 + lift term; the camera-derived emergence reward
+    and the heap-movement count are computed by the task but do NOT enter the reward; reset on time-out only."""
+    nrm = lambda v: np.linalg.norm(v.astype(F), axis=-1).astype(F)
+    d = nrm(target_pos - ff) + nrm(target_pos - mf) + nrm(target_pos - rf) + nrm(target_pos - th)          # SE:1669-1670 (no thumb weight)
+    dist_rew = np.minimum(F(-0.2) * d, F(-0.06))                                                           # SE:1671
+    action_penalty = (actions.astype(F) ** 2).sum(-1) * F(0.005)
+    dlt = (target_pos - init_pos).astype(F)
+    up = (np.clip(dlt[:, 2], 0, 0.1) * F(1000) - np.clip(dlt[:, 0], 0, 0.1) * F(1000) - np.clip(dlt[:, 1], 0, 0.1) * F(1000)).astype(F)
+    reward = (dist_rew - arm_contacts.sum(-1) - action_penalty + up).astype(F)                             # SE:1685
+    resets = np.where(d <= -1, 1, reset_buf)
+    resets = np.where(progress >= max_episode_length - 1, 1, resets)                                       # SE:1699-1700
+    num_resets = resets.sum()
+    fin = (successes * resets.astype(F)).sum()
+    cons = np.where(num_resets > 0, F(av_factor) * fin / max(num_resets, 1) + F(1.0 - av_factor) * cons_successes,
+                    cons_successes).astype(F)
+    return reward, resets.astype(np.int64), cons, up
+
+
+def search_emergence_reward(seg, ids, last_pixels):
+    """SE:1640-1646: 5 x the change of the target's visible pixel count"""
+    pix = np.array([(seg[i] == ids[i]).sum() for i in range(seg.shape[0])], dtype=F)
+    return pix, (pix - last_pixels) * F(5)
+
+
+def search_heap_movement(brick_pos):
+    """SE:1648-1652: number of bricks thrown out of the bin region (|x - 1| > 0.25 and |y| > 0.35 in the env frame)"""
+    out = (np.abs(brick_pos[:, :, 0] - 1) > 0.25) & (np.abs(brick_pos[:, :, 1]) > 0.35)
+    return out.sum(axis=1).astype(F)

@@ -1,0 +1,52 @@
+"""CPU: numpy restatement of the pure per-step tensor code of BlockAssemblySearch (oracle/task_oracle.py, SE:*) against the golden vectors
+that oracle/gen_golden_search.py captured from the reference's own functions (tests/golden/S*.npz).  The Search TASK is not built
+(it needs a segmentation rasteriser); this pins the oracle for the round that builds it."""
+import os
+
+import numpy as np
+
+from oracle import task_oracle as T
+
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def test_search_pre_physics_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "S2_pre_physics.npz"))
+    np.testing.assert_allclose(g["euler"], T.SEARCH_EULER)
+    cur = T.search_pre_physics_targets(g["actions"], g["q"], g["prev_targets"], g["hand_pos"], g["hand_rot"], g["target_pos"], g["J"],
+                                       g["lower"], g["upper"])
+    np.testing.assert_allclose(cur, g["cur_targets"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(cur, g["sim_targets"], rtol=1e-4, atol=1e-4)
+
+
+def test_search_observations_and_pixel_statistics_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "S3_observations.npz"))
+    cx, cy, num = T.segmentation_pixel_stats(g["seg"], g["ids"])
+    np.testing.assert_array_equal(num, g["point_num"].reshape(-1))
+    np.testing.assert_array_equal(cx, g["center_x"].reshape(-1))
+    np.testing.assert_array_equal(cy, g["center_y"].reshape(-1))
+    assert num[3] == 0 and cx[3] == 0 and (num > 0).sum() >= 10
+    obs = np.zeros_like(g["obs_buf"])
+    obs[:, :62] = T.search_obs_frame(g["dof"], g["actions"], g["lower"], g["upper"])
+    np.testing.assert_allclose(obs, g["obs_buf"], **TOL)
+    a = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    a.update(center_x=g["center_x"], center_y=g["center_y"], point_num=g["point_num"])
+    s = T.search_state_frame(g["dof"], g["actions"], g["lower"], g["upper"], a)
+    np.testing.assert_allclose(s, g["states_buf"][:, :188], **TOL)
+    assert not g["states_buf"][:, 188:].any() and not s[:, 95].any() and not s[:, 175:].any()
+
+
+def test_search_reward_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "S5_reward.npz"))
+    rew, resets, cons, up = T.search_hand_reward(g["target_pos"], g["init_pos"], g["ff"], g["rf"], g["mf"], g["th"], g["progress"],
+                                                 g["reset_buf"], g["cons_in"], g["successes"], g["arm_contacts"], g["actions"],
+                                                 float(g["max_episode_length"]))
+    np.testing.assert_allclose(rew, g["reward"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(resets, g["resets"])
+    np.testing.assert_allclose(cons, g["cons_out"], **TOL)
+    np.testing.assert_allclose(g["emergence_after"], g["emergence_in"] * up / 10, rtol=1e-4, atol=1e-4)   # scaled in place, never used
+    pix, em = T.search_emergence_reward(g["em_seg"], g["em_ids"], g["em_last"])
+    np.testing.assert_array_equal(pix, g["em_pixel"])
+    np.testing.assert_allclose(em, g["em_reward"], **TOL)
+    np.testing.assert_array_equal(T.search_heap_movement(g["heap_pos"]), g["heap_penalty"])
+    assert g["heap_penalty"].max() > 0
