@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDX_ABI_VERSION 3
+#define SDX_ABI_VERSION 4
 
 /* ---- fixed scene dimensions of BlockAssemblyGraspSim (GS:523-1058) ---- */
 #define SDX_NLINK 24        /* robot bodies after collapse_fixed_joints (GS:543); body 0 is the fixed base  */
@@ -59,7 +59,7 @@ typedef enum {
   SDX_ERR_NOMEM = -5
 } sdx_status;
 
-typedef enum { SDX_F32 = 0, SDX_I64 = 1, SDX_I32 = 2, SDX_U8 = 3, SDX_F64 = 4 } sdx_dtype;
+typedef enum { SDX_F32 = 0, SDX_I64 = 1, SDX_I32 = 2, SDX_U8 = 3, SDX_F64 = 4, SDX_I16 = 5 } sdx_dtype;
 
 /* Tensor ids for sdx_tensor().  Shapes use N = num_envs. */
 typedef enum {
@@ -102,7 +102,10 @@ typedef enum {
   SDX_T_PILE_HARVEST = 36, /* f32 [8,S,132,13]  Orient: brick states of finished episodes that left the target brick reachable (ring per
                             *                    brick-type group; S = 512 for task_kind 1, else 1) = the saved piles GraspSim starts from    OR:1463-1488, GS:412-413 */
   SDX_T_PILE_HARVEST_COUNT = 37, /* i32 [8]     pile states harvested so far (ring index = count % S)                                    */
-  SDX_T_COUNT = 38
+  SDX_T_SEG_IMAGE = 38,    /* i16 [N,128,128]   Search: segmentation image of the last render (0 = background / robot / bin, i+1 = brick i)  SE:877 */
+  SDX_T_SEG_PIXELS = 39,   /* f32 [N,4]         Search: target pixel count, centroid row, centroid column, count of the render before   SE:1232-1241 */
+  SDX_T_EMERGENCE = 40,    /* f32 [N]           Search: extras["emergence_reward"] = 5 x change of the pixel count                    SE:1640-1646 */
+  SDX_T_COUNT = 41
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the
@@ -179,6 +182,11 @@ typedef struct {
   int32_t static_var_slot;
   float static_var_center_z[3];
   float static_var_half_z[3];
+  /* task_kind 3 = BlockAssemblySearch (SE = tasks/block_assembly/allegro_hand_block_assembly_search.py): the fixed segmentation camera
+   * (128 x 128; set_camera_location SE:875; Isaac Gym's default horizontal field of view 90 degrees) */
+  float seg_cam_pos[3];
+  float seg_cam_target[3];
+  float seg_cam_hfov_deg;
 } sdx_scene_desc;
 
 typedef struct sdx_sim* sdx_handle;
@@ -221,6 +229,9 @@ int sdx_reset_idx(sdx_handle h, const uint8_t* env_mask_dev, const int32_t* pile
 /* refresh_rigid_body_state / jacobian after the caller overwrote DOF/ROOT through the tensor views
  * (set_dof_state_tensor_indexed / set_actor_root_state_tensor_indexed, GS:1514,1543): recomputes FK,
  * link velocities and the end-effector Jacobian from SDX_T_DOF. */
+/* Search: render the segmentation camera of every env from the current ROOT / RB states -> SDX_T_SEG_IMAGE, SDX_T_SEG_PIXELS,
+ * SDX_T_EMERGENCE (gym.render_all_camera_sensors + the pixel statistics of SE:1232-1241,1640-1646).  task_kind 3 only. */
+int sdx_render_segmentation(sdx_handle h, void* stream);
 int sdx_refresh_kinematics(sdx_handle h, void* stream);
 
 int sdx_num_envs(sdx_handle h);

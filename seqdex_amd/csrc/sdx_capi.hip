@@ -15,6 +15,7 @@ void sdxk_pre_physics(const SdxConst*, const SdxBuf*, const float*, const uint8_
 void sdxk_post_physics(const SdxConst*, const SdxBuf*, int, hipStream_t);
 void sdxk_physics(const SdxConst*, const SdxBuf*, hipStream_t);
 void sdxk_kinematics(const SdxConst*, const SdxBuf*, hipStream_t);
+extern "C" void sdxk_seg_camera(const SdxConst*, const SdxBuf*, hipStream_t);
 void sdxk_orient_pregrasp(const SdxConst*, const SdxBuf*, const uint8_t*, int, int, hipStream_t);
 void sdxk_orient_post_reset(const SdxConst*, const SdxBuf*, const uint8_t*, hipStream_t);
 }
@@ -170,6 +171,10 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   B.pile_slots = scene->task_kind == 1 ? SDX_PILE_HARVEST_SLOTS : 1;
   ALLOC(pile_harvest, (size_t)8 * B.pile_slots * SDX_NBRICK * 13);
   ALLOC(pile_harvest_count, 8);
+  ALLOC(seg_stats, (size_t)N * 4);
+  ALLOC(seg_image, scene->task_kind == 3 ? (size_t)N * 128 * 128 : 1);
+  ALLOC(seg_pix, (size_t)N * 4);
+  ALLOC(emergence, N);
 #undef ALLOC
   set_tensor(h, SDX_T_ROOT, B.root, SDX_F32, {(int64_t)N * SDX_ACTORS, 13});
   set_tensor(h, SDX_T_DOF, B.dof, SDX_F32, {(int64_t)N * SDX_NDOF, 2});
@@ -209,6 +214,10 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_TV_COUNT, B.tv_count, SDX_I32, {2});
   set_tensor(h, SDX_T_PILE_HARVEST, B.pile_harvest, SDX_F32, {8, B.pile_slots, SDX_NBRICK, 13});
   set_tensor(h, SDX_T_PILE_HARVEST_COUNT, B.pile_harvest_count, SDX_I32, {8});
+  if (scene->task_kind == 3) set_tensor(h, SDX_T_SEG_IMAGE, B.seg_image, SDX_I16, {N, 128, 128});
+  else set_tensor(h, SDX_T_SEG_IMAGE, B.seg_image, SDX_I16, {1, 1, 1});   // placeholder: the camera belongs to Search
+  set_tensor(h, SDX_T_SEG_PIXELS, B.seg_pix, SDX_F32, {N, 4});
+  set_tensor(h, SDX_T_EMERGENCE, B.emergence, SDX_F32, {N});
 
   // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
   std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);
@@ -384,6 +393,12 @@ extern "C" int sdx_reset_idx(sdx_handle h, const uint8_t* env_mask_dev, const in
   if (!h || !env_mask_dev) return SDX_ERR_INVALID;
   sdxk_pre_physics(h->d_const, &h->buf, nullptr, env_mask_dev, pile_choice_dev, 2, (hipStream_t)stream);
   return check_launch(h, "sdx_reset_idx");
+}
+extern "C" int sdx_render_segmentation(sdx_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  if (h->h_const.sc.task_kind != 3) { h->err = "sdx_render_segmentation: the segmentation camera belongs to BlockAssemblySearch (task_kind 3)"; return SDX_ERR_STATE; }
+  sdxk_seg_camera(h->d_const, &h->buf, (hipStream_t)stream);
+  return check_launch(h, "sdx_render_segmentation");
 }
 extern "C" int sdx_refresh_kinematics(sdx_handle h, void* stream) {
   if (!h) return SDX_ERR_INVALID;

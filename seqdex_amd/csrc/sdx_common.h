@@ -45,6 +45,10 @@ struct SdxBuf {
   long long* dbg;          // [64] phase time stamps of env 0 (profiling aid)
   float *harvest_hand, *harvest_obj;   // [8, SDX_HARVEST_SLOTS, 23*2] / [8, SDX_HARVEST_SLOTS, 13]
   int32_t* harvest_count;  // [8]
+  int32_t* seg_stats;      // [N,4] Search camera: accumulators (count, sum rows, sum cols)
+  int16_t* seg_image;      // [N,128,128] or nullptr
+  float* seg_pix;          // [N,4] count, centroid row, centroid col, previous count
+  float* emergence;        // [N]
   float* pile_harvest;     // [8, pile_slots, 132, 13] Orient terminal pile states
   int32_t* pile_harvest_count;   // [8]
   int32_t pile_slots;

@@ -125,6 +125,9 @@ class Scene:
         d.target_euler[:] = [0.0, 3.1415, 1.571]          # OR:477
         d.seg_mass_scale = 1.0                            # GS:980-981 (x1); Orient x50 (OR:977)
         d.static_var_slot = -1
+        d.seg_cam_pos[:] = [0.35, 0.19, 1.0]              # gym.set_camera_location(camera, env, Vec3(0.35, 0.19, 1.0), Vec3(0.2, 0.19, 0)), SE:875
+        d.seg_cam_target[:] = [0.2, 0.19, 0.0]
+        d.seg_cam_hfov_deg = 90.0                         # gymapi.CameraProperties default horizontal_fov
         for k_, v in overrides.items():
             if hasattr(v, "__len__") and not isinstance(v, (str, bytes)):
                 getattr(d, k_)[:] = list(v)

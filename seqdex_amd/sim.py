@@ -11,7 +11,7 @@ from . import _abi
 from .scene import load_scene
 
 _TORCH_DTYPE = {0: (torch.float32, "<f4"), 1: (torch.int64, "<i8"), 2: (torch.int32, "<i4"), 3: (torch.uint8, "|u1"),
-                4: (torch.float64, "<f8")}
+                4: (torch.float64, "<f8"), 5: (torch.int16, "<i2")}
 
 
 class _DevArray:
@@ -117,6 +117,10 @@ class SdxSim:
 
     def compute_observations(self):
         self._check(self.lib.sdx_compute_observations(self.h, _stream_ptr(self.device)))
+
+    def render_segmentation(self):
+        """BlockAssemblySearch: gym.render_all_camera_sensors + pixel statistics -> SEG_IMAGE, SEG_PIXELS, EMERGENCE"""
+        self._check(self.lib.sdx_render_segmentation(self.h, _stream_ptr(self.device)))
 
     def refresh_kinematics(self):
         self._check(self.lib.sdx_refresh_kinematics(self.h, _stream_ptr(self.device)))
