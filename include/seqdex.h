@@ -172,7 +172,9 @@ typedef struct {
   /* which task's per-step tensor code the pre/post-physics kernels run: 0 = BlockAssemblyGraspSim (GS),
    * 1 = BlockAssemblyOrient (OR = tasks/block_assembly/allegro_hand_block_assembly_orient.py; targets/IK OR:1720-1778),
    * 2 = BlockAssemblyInsertSim (IS; position action + fixed wrist orientation IS:1526-1572, 75-number observation IS:1280-1298,
-   *     insertion reward IS:1640-1695, reset from harvested grasp states IS:1416-1494) */
+   *     insertion reward IS:1640-1695, reset from harvested grasp states IS:1416-1494),
+   * 3 = BlockAssemblySearch (SE; tracking IK 0.24 above the target SE:1565-1575, 62-number observation SE:1220-1230, its own asymmetric
+   *     state SE:1168-1218, reward SE:1660-1711, reset with 60 settling steps and a segmentation render SE:1274-1538) */
   int32_t task_kind;
   float target_euler[3];               /* Orient: fixed wrist orientation of the tracking IK, OR:477 */
   float seg_mass_scale;                /* mass (and inertia) factor of each env's target brick: 1 (GS:980-981), 50 in Orient (OR:977) */
@@ -187,6 +189,8 @@ typedef struct {
   float seg_cam_pos[3];
   float seg_cam_target[3];
   float seg_cam_hfov_deg;
+  float search_default_arm[7];         /* arm_hand_default_dof_pos[:7]: hand parked out of the camera's view, SE:203 */
+  float search_finger_pose[16];        /* finger joints (radians) of the default AND the prepare pose, SE:205-206,220-222 */
 } sdx_scene_desc;
 
 typedef struct sdx_sim* sdx_handle;

@@ -48,6 +48,7 @@ class SceneDesc(C.Structure):
         ("task_kind", i32), ("target_euler", f32 * 3), ("seg_mass_scale", f32),
         ("static_var_slot", i32), ("static_var_center_z", f32 * 3), ("static_var_half_z", f32 * 3),
         ("seg_cam_pos", f32 * 3), ("seg_cam_target", f32 * 3), ("seg_cam_hfov_deg", f32),
+        ("search_default_arm", f32 * 7), ("search_finger_pose", f32 * 16),
     ]
 
 

@@ -13,10 +13,12 @@ import yaml
 HERE = os.path.dirname(os.path.abspath(__file__))
 TASK_CFG = {"BlockAssemblyGraspSim": "cfg/allegro_hand_block_assembly_grasp_sim.yaml",                      # CF:63-64
             "BlockAssemblyOrient": "cfg/allegro_hand_block_assembly_orient.yaml",                               # CF:75-76
-            "BlockAssemblyInsertSim": "cfg/allegro_hand_block_assembly_insert_sim.yaml"}                        # CF:69-70
+            "BlockAssemblyInsertSim": "cfg/allegro_hand_block_assembly_insert_sim.yaml",                        # CF:69-70
+            "BlockAssemblySearch": "cfg/allegro_hand_block_assembly_search.yaml"}                               # CF:72-73
 TRAIN_CFG = {"BlockAssemblyGraspSim": "cfg/lego/ppo_continuous_grasp.yaml",                                 # TR:44-47
              "BlockAssemblyOrient": "cfg/lego/ppo_continuous_grasp.yaml",
-             "BlockAssemblyInsertSim": "cfg/lego/ppo_continuous_insert.yaml"}                               # TR:48-49
+             "BlockAssemblyInsertSim": "cfg/lego/ppo_continuous_insert.yaml",                               # TR:48-49
+             "BlockAssemblySearch": "cfg/lego/ppo_continuous_grasp.yaml"}                                   # TR:45-47
 
 
 def get_args(argv=None):

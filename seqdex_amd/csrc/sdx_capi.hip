@@ -122,7 +122,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   memset(&B, 0, sizeof(B));
   B.N = N;
   B.task_kind = scene->task_kind;
-  B.obs_w = scene->task_kind == 1 ? 186 : (scene->task_kind == 2 ? 75 : SDX_NUM_OBS);
+  B.obs_w = (scene->task_kind == 1 || scene->task_kind == 3) ? 186 : (scene->task_kind == 2 ? 75 : SDX_NUM_OBS);
   B.K = 1;
   B.seed = seed;
 #define ALLOC(field, count) if ((rc = dalloc(h, &B.field, (size_t)(count))) != SDX_OK) { g_create_err = h->err; sdx_destroy(h); return rc; }
@@ -373,9 +373,49 @@ static int orient_reset_if_needed(sdx_handle h, hipStream_t st) {
   return check_launch(h, "sdx_step(orient reset)");
 }
 
+extern "C" void sdxk_search_set_hand(const SdxConst*, const SdxBuf*, const uint8_t*, int, hipStream_t);
+
+// BlockAssemblySearch: reset_idx + post_reset (SE:1274-1538) for the envs whose reset flag is set (read on the host, as
+// reset_buf.nonzero() does): outcome / harvest / lattice restore on the device, 60 settling steps of all envs, a segmentation render
+// (emergence bookkeeping), hand to the prepare pose.  *progress0 = progress_buf[0] before this step (the end-of-episode render keys
+// on it, SE:992).
+static int search_reset_if_needed(sdx_handle h, hipStream_t st, int64_t* progress0) {
+  const int N = h->buf.N;
+  std::vector<int64_t> flags(N);
+  HIPCHK(h, hipMemcpyAsync(flags.data(), h->buf.reset, sizeof(int64_t) * N, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(progress0, h->buf.progress, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  std::vector<uint8_t> mask(N);
+  int any = 0;
+  for (int i = 0; i < N; ++i) { mask[i] = flags[i] != 0; any |= mask[i]; }
+  if (!any) return SDX_OK;
+  if (!h->orient_mask) { HIPCHK(h, hipMalloc((void**)&h->orient_mask, N)); h->allocs.push_back(h->orient_mask); }
+  HIPCHK(h, hipMemcpyAsync(h->orient_mask, mask.data(), N, hipMemcpyHostToDevice, st));
+  sdxk_pre_physics(h->d_const, &h->buf, nullptr, h->orient_mask, nullptr, 2, st);      // outcome, harvest, lattice + noise, target drop, default pose
+  for (int i = 0; i < 60; ++i) sdxk_physics(h->d_const, &h->buf, st);                  // SE:1437-1439
+  sdxk_seg_camera(h->d_const, &h->buf, st);                                            // SE:1444-1455
+  sdxk_search_set_hand(h->d_const, &h->buf, h->orient_mask, 0, st);                    // SE:1482-1495
+  if (mask[0]) *progress0 = 0;
+  return check_launch(h, "sdx_step(search reset)");
+}
+
 extern "C" int sdx_step(sdx_handle h, const float* actions_dev, void* stream) {
   if (!h || !actions_dev) return SDX_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
+  if (h->h_const.sc.task_kind == 3) {
+    int64_t p0 = 0;
+    const int rc = search_reset_if_needed(h, st, &p0);
+    if (rc != SDX_OK) return rc;
+    sdxk_pre_physics(h->d_const, &h->buf, actions_dev, nullptr, nullptr, 4, st);
+    sdxk_physics(h->d_const, &h->buf, st);
+    if ((float)(p0 + 1) >= h->h_const.sc.max_episode_length - 1.0f) {                  // SE:992-1019: park the hand, one more step, render
+      sdxk_search_set_hand(h->d_const, &h->buf, nullptr, 1, st);
+      sdxk_physics(h->d_const, &h->buf, st);
+      sdxk_seg_camera(h->d_const, &h->buf, st);
+    }
+    sdxk_post_physics(h->d_const, &h->buf, 1, st);
+    return check_launch(h, "sdx_step");
+  }
   if (h->h_const.sc.task_kind == 1) {
     const int rc = orient_reset_if_needed(h, st);
     if (rc != SDX_OK) return rc;

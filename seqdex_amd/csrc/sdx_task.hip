@@ -131,6 +131,22 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
         for (int i = lane; i < SDX_NBRICK * 13; i += SDX_WAVE) dst[i] = srcb[i];
       }
     }
+    // BlockAssemblySearch, SE:1289,1306-1343: the episode succeeded when enough pixels of the target brick are visible to the fixed
+    // camera (threshold by brick type); successes hand their whole pile on (the saved piles BlockAssemblyOrient starts from)
+    if (B.step_count[0] > 0 && sc.task_kind == 3) {
+      const int thr[8] = {20, 20, 15, 20, 20, 30, 30, 20};
+      const bool good = B.seg_pix[(size_t)e * 4] > (float)thr[e & 7];
+      tv_log(B, e, lane, good);
+      if (lane == 0) B.success_buf[e] = good ? 1 : 0;
+      if (good) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&B.pile_harvest_count[e & 7], 1) % B.pile_slots;          // SE:1323-1328
+        slot = __shfl(slot, 0, SDX_WAVE);
+        float* dst = B.pile_harvest + ((size_t)(e & 7) * B.pile_slots + slot) * SDX_NBRICK * 13;
+        const float* srcb = root_e + SDX_ACTOR_BRICK0 * 13;
+        for (int i = lane; i < SDX_NBRICK * 13; i += SDX_WAVE) dst[i] = srcb[i];
+      }
+    }
     int choice;
     if (ext_choice) choice = ext_choice[e];
     else choice = (int)(sdx_hash(B.seed, (uint64_t)e, (uint64_t)B.step_count[0]) % (uint64_t)B.K);
@@ -154,6 +170,30 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
     const int seg = seg_actor(e) - SDX_ACTOR_BRICK0;
     if (lane < 3) B.init_pos[e * 3 + lane] = src[seg * 13 + lane];               // GS:1547
     if (lane < 4) B.init_rot[e * 4 + lane] = src[seg * 13 + 3 + lane];           // GS:1548
+    if (sc.task_kind == 3) {
+      // BlockAssemblySearch reset_idx, SE:1367-1421: bricks back on the spawn lattice (the saved "pile" of this task) with +-0.02 of
+      // x / y noise on the free ones, the target brick dropped from z = 0.9 at a random spot over the bin, hand parked at its
+      // default pose; the host then lets the pile settle for 60 steps (post_reset)
+      __syncthreads();
+      float* bricks = root_e + SDX_ACTOR_BRICK0 * 13;
+      for (int i = lane; i < SDX_NFREE * 2; i += SDX_WAVE) {
+        const uint64_t hsh = sdx_hash(B.seed ^ 0x5EA7ull, (uint64_t)e * 1024 + i, (uint64_t)B.step_count[0]);
+        const float uni = (float)((hsh >> 40) & 0xFFFFFFull) * (2.0f / 16777216.0f) - 1.0f;
+        bricks[(i >> 1) * 13 + (i & 1)] += uni * 0.02f;                               // SE:1395-1396
+      }
+      __syncthreads();
+      const uint64_t hr = sdx_hash(B.seed ^ 0x7A96ull, (uint64_t)e, (uint64_t)B.step_count[0]);
+      const float r = (float)((hr >> 40) & 0xFFFFFFull) * (2.0f / 16777216.0f) - 1.0f;   // ONE draw moves x and y together, SE:1399-1400
+      float* tg = root_e + seg_actor(e) * 13;
+      if (lane == 0) { tg[0] = 0.25f + r * 0.2f; tg[1] = 0.19f + r * 0.15f; tg[2] = 0.9f; }
+      if (lane < SDX_NDOF) {
+        const float qh = lane < 7 ? sc.search_default_arm[lane] : sc.search_finger_pose[lane - 7];   // SE:1416-1421
+        B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 0] = qh;
+        B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 1] = 0.0f;
+        B.prev_targets[(size_t)e * SDX_NDOF + lane] = qh;
+        B.targets[(size_t)e * SDX_NDOF + lane] = qh;
+      }
+    }
     if (sc.task_kind == 2) {
       // BlockAssemblyInsertSim reset_idx, IS:1328-1494.  Episode outcome first (IS:1345-1354, from the quantities of the last
       // compute_observations): inserted = within 2 cm and 0.2 rad of the site or of its 180-degree twin
@@ -216,8 +256,9 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
   __syncthreads();
   // dpose (GS:1594-1600), every lane computes it (uniform)
   float dp[6];
-  const bool orient = sc.task_kind == 1, insert = sc.task_kind == 2;
-  const bool hold = m0 && !insert;                                                // GraspSim / Orient freeze the fingers after step 75
+  const bool search = sc.task_kind == 3;
+  const bool orient = sc.task_kind == 1 || search, insert = sc.task_kind == 2;    // Search drives the arm like Orient (tracking IK)
+  const bool hold = m0 && !insert && !search;                                     // GraspSim / Orient freeze the fingers after step 75
   if (!orient && !insert) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -242,8 +283,8 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
     } else {
       dp[0] = tg[0] - hb[0] - 0.18f;
       dp[1] = tg[1] - hb[1];
-      dp[2] = tg[2] - hb[2] + 0.22f;
-      if (m0) dp[2] = B.init_pos[e * 3 + 2] - hb[2] + 0.15f + 0.24f;                // OR:1737
+      dp[2] = tg[2] - hb[2] + (search ? 0.24f : 0.22f);                             // SE:1566 / OR:1735
+      if (m0 && !search) dp[2] = B.init_pos[e * 3 + 2] - hb[2] + 0.15f + 0.24f;     // OR:1737
     }
     const f3 re = wrist_error(sc.target_euler, ld4(hb + 3));                        // OR:1740-1741, IS:1538-1539
     dp[3] = re.x; dp[4] = re.y; dp[5] = re.z;
@@ -446,8 +487,9 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
   {
     float* o = B.obs + (size_t)e * B.obs_w;
     float* oc = B.obs_c + (size_t)e * B.obs_w;
-    if (sc.task_kind == 1) {
-      // BlockAssemblyOrient, compute_real_observations OR:1308-1326: 62 numbers, NOT stacked (columns 62..185 are never written)
+    if (sc.task_kind == 1 || sc.task_kind == 3) {
+      // BlockAssemblyOrient, compute_real_observations OR:1308-1326 (= Search's compute_contact_observations SE:1220-1230): 62 numbers,
+      // NOT stacked (columns 62..185 are never written)
       if (lane < 62) {
         float v = 0.0f;
         if (lane < 16) v = s_o[lane];                                             // unscaled finger joint positions
@@ -488,7 +530,33 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
     }
     float* s = B.states + (size_t)e * SDX_NUM_STATES;
     float* stc = B.states_c + (size_t)e * SDX_NUM_STATES;
-    if (!insert) {                                                                // InsertSim's 188 states are one frame (IS:172,192):
+    const bool search = sc.task_kind == 3;
+    if (search) {
+      // Search's own asymmetric frame, SE:1168-1218, built from the GraspSim frame staged above: joints, fingertips, actions, hand and
+      // target poses stay where they are; the eight hand-position history means are zero (they are only ever computed from a zeroed
+      // buffer, SE:1458-1466), then the pixel statistics, the hand twist, the fingertip (rot, linvel, angvel) blocks, the target twist
+      __syncthreads();
+      float keep[3] = {0.0f, 0.0f, 0.0f};
+      for (int r = 0; r < 3; ++r) { const int c = lane + r * SDX_WAVE; if (c < SDX_STATE_FRAME) keep[r] = s_s[c]; }
+      __syncthreads();
+      for (int r = 0; r < 3; ++r) {
+        const int c = lane + r * SDX_WAVE;
+        if (c >= 95 && c < SDX_STATE_FRAME) s_s[c] = 0.0f;
+      }
+      __syncthreads();
+      for (int r = 0; r < 3; ++r) {                                                 // old column -> new column
+        const int c = lane + r * SDX_WAVE;
+        if (c >= 95 && c < 101) s_s[c + 28] = keep[r];                              // hand twist 95:101 -> 123:129
+        else if (c >= 101 && c < 141) s_s[c + 28] = keep[r];                        // fingertips 101:141 -> 129:169
+        else if (c >= 142 && c < 148) s_s[c + 27] = keep[r];                        // target twist 142:148 -> 169:175
+      }
+      if (lane == 0) {
+        const float* px = B.seg_pix + (size_t)e * 4;
+        s_s[120] = px[1] / 128.0f; s_s[121] = px[2] / 128.0f; s_s[122] = px[0] / 100.0f;   // SE:1192-1194
+      }
+      __syncthreads();
+    }
+    if (!insert && !search) {                                                     // InsertSim's / Search's 188 states are one frame:
       float hs[6];                                                                // columns 188.. of its rows stay zero
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
@@ -519,7 +587,17 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
     const bool timed_out = (float)prog >= sc.max_episode_length - 1.0f;           // GS:1729
     if (timed_out) resets = 1;
     float reward;
-    if (insert) {
+    if (sc.task_kind == 3) {
+      // Search, SE:1660-1711: min(-0.2 d, -0.06) - arm contacts - 0.005 |a|^2 + lift term (unweighted fingertip distance); the camera's
+      // emergence reward does not enter; time-out is the only reset
+      const float d4 = nff + nmf + nrf + nth;
+      float asq = 0.0f, ac = 0.0f;
+      for (int j = 0; j < SDX_NDOF; ++j) asq += s_act[j] * s_act[j];
+      for (int j = 0; j < 6; ++j) { const f3 f = ld3(s_cf + 3 * j); ac += sqrtf(dot(f, f)) >= 0.1f ? 1.0f : 0.0f; }
+      const float up = clampf(tpos.z - s_init[2], 0.0f, 0.1f) * 1000.0f - clampf(tpos.x - s_init[0], 0.0f, 0.1f) * 1000.0f -
+                       clampf(tpos.y - s_init[1], 0.0f, 0.1f) * 1000.0f;
+      reward = fminf(-0.2f * d4, -0.06f) - ac - asq * 0.005f + up;
+    } else if (insert) {
       // InsertSim, IS:1640-1695: exp(-rot_dist - 20 |brick - site|) + 1 once seated; reset when the hand lets go, when the wrist
       // servo error (the rot_err of this step's pre_physics_step) grows, or on time-out
       const float* aux = B.insert_aux + (size_t)e * 8;
@@ -700,6 +778,32 @@ __global__ __launch_bounds__(SDX_WAVE) void k_orient_post_reset(const SdxConst* 
     B.prev_targets[(size_t)e * SDX_NDOF + lane] = hp;
     B.targets[(size_t)e * SDX_NDOF + lane] = hp;
   }
+}
+// ------------------------------------------------------------------------------------------------ BlockAssemblySearch helpers
+// mode 0 (SE:1482-1493, end of post_reset, masked envs): hand to the prepare pose (joint state set directly, zero velocity), PD targets
+//         there too, and the settled pose of the target brick becomes the episode's initial pose;
+// mode 1 (SE:992-1003, last step of an episode, all envs): hand parked at the default pose so that it does not hide the pile from
+//         the camera; the caller then simulates one step and renders
+__global__ __launch_bounds__(SDX_WAVE) void k_search_set_hand(const SdxConst* __restrict__ C, SdxBuf B, const uint8_t* __restrict__ mask, int mode) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[e]) return;
+  const sdx_scene_desc& sc = C->sc;
+  if (lane < SDX_NDOF) {
+    const float arm = mode == 0 ? sc.arm_prepare_pose[lane < 7 ? lane : 0] : sc.search_default_arm[lane < 7 ? lane : 0];
+    const float qh = lane < 7 ? arm : sc.search_finger_pose[lane - 7];
+    B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 0] = qh;
+    B.dof[((size_t)e * SDX_NDOF + lane) * 2 + 1] = 0.0f;
+    B.prev_targets[(size_t)e * SDX_NDOF + lane] = qh;
+    B.targets[(size_t)e * SDX_NDOF + lane] = qh;
+  }
+  if (mode == 0) {
+    const float* tg = B.root + ((size_t)e * SDX_ACTORS + seg_actor(e)) * 13;
+    if (lane < 3) B.init_pos[e * 3 + lane] = tg[lane];                                          // SE:1494
+    if (lane < 4) B.init_rot[e * 4 + lane] = tg[3 + lane];                                      // SE:1495
+  }
+}
+extern "C" void sdxk_search_set_hand(const SdxConst* C, const SdxBuf* B, const uint8_t* mask, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_search_set_hand, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, mask, mode);
 }
 extern "C" void sdxk_orient_pregrasp(const SdxConst* C, const SdxBuf* B, const uint8_t* mask, int mode, int iter, hipStream_t st) {
   hipLaunchKernelGGL(k_orient_pregrasp, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, mask, mode, iter);

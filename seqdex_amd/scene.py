@@ -128,6 +128,8 @@ class Scene:
         d.seg_cam_pos[:] = [0.35, 0.19, 1.0]              # gym.set_camera_location(camera, env, Vec3(0.35, 0.19, 1.0), Vec3(0.2, 0.19, 0)), SE:875
         d.seg_cam_target[:] = [0.2, 0.19, 0.0]
         d.seg_cam_hfov_deg = 90.0                         # gymapi.CameraProperties default horizontal_fov
+        d.search_default_arm[:] = [0.9467, -0.5708, -2.4997, -2.3102, -0.7739, 2.6616, 0.6497]     # SE:203
+        d.search_finger_pose[:] = [0.0, -0.174, 0.785, 0.785] * 4                                 # SE:205-206,220-222
         for k_, v in overrides.items():
             if hasattr(v, "__len__") and not isinstance(v, (str, bytes)):
                 getattr(d, k_)[:] = list(v)

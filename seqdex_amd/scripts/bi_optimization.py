@@ -4,8 +4,7 @@
     backward fine-tuning   : run the LAST policy again to collect success / failure data, fit the transition value on it, give it to
                              the policy before it and fine-tune that one, and so on towards the front of the chain
 
-for the tasks this build has: BlockAssemblyOrient -> BlockAssemblyGraspSim -> BlockAssemblyInsertSim (BlockAssemblySearch needs the
-camera rasteriser and is not built).  Where the reference hands data over through files (pickles of terminal states, an HDF5 file of
+for the chain BlockAssemblySearch -> BlockAssemblyOrient -> BlockAssemblyGraspSim -> BlockAssemblyInsertSim.  Where the reference hands data over through files (pickles of terminal states, an HDF5 file of
 quaternions, .pth checkpoints), the stages here hand over device tensors of the same content; checkpoints are still written.
 
     python -m seqdex_amd.scripts.bi_optimization --tasks BlockAssembly [--rounds 10] [--epochs N] [--tvalue_rollout 10000]
@@ -69,8 +68,12 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
     paths = {}
     for i in range(rounds):
         # ---- forward initialisation (bi_optimization.py:115-118)
+        paths["search"], search = main_rlgames("BlockAssemblySearch", min(num_envs, 128), max_iterations=epochs,
+                                               policy_path=paths.get("search", ""), keep=True)
+        dug = search.pile_terminal_states()                                               # hand-off SE:1323-1353 -> Orient's saved piles
+        search.sim.close()
         paths["orient"], orient = main_rlgames("BlockAssemblyOrient", num_envs, max_iterations=epochs, policy_path=paths.get("orient", ""),
-                                               keep=True)
+                                               keep=True, task_kwargs={"initial_piles": dug})
         piles = orient.pile_terminal_states()                                             # hand-off OR:1483-1510 -> GS:412-413
         orient.sim.close()
         paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, max_iterations=epochs, policy_path=paths.get("grasp", ""),

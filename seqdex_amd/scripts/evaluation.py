@@ -1,7 +1,6 @@
 """Sequential --play evaluation of the policy chain, after the reference's scripts/evaluation.py:36-119: every sub-policy is restored
 from its checkpoint and played (mean action, no update) on its own task, in chain order, each stage starting from what the stage
-before produced (Orient's harvested piles -> GraspSim; GraspSim's grasp terminal states -> InsertSim).  Tasks built here:
-BlockAssemblyOrient, BlockAssemblyGraspSim, BlockAssemblyInsertSim.  Checkpoints: files written by A2CAgent.save (rl_games' layout) or
+before produced (Search's dug-out piles -> Orient; Orient's harvested piles -> GraspSim; GraspSim's grasp terminal states -> InsertSim).  Checkpoints: files written by A2CAgent.save (rl_games' layout) or
 by rl_games itself.
 
     python -m seqdex_amd.scripts.evaluation --tasks BlockAssembly --orient ck1.pth --grasp ck2.pth --insert ck3.pth [--games 512]
@@ -29,9 +28,17 @@ def main_rlgames(task, num_envs, play=True, use_t_value=False, policy_path="", g
     return rew, length, task_obj
 
 
-def block_assembly(orient_path, grasp_path, insert_path, num_envs=512, games=0, insert_minibatch=0):
+def block_assembly(orient_path, grasp_path, insert_path, num_envs=512, games=0, insert_minibatch=0, search_path=None):
     out = {}
-    r, l, orient = main_rlgames("BlockAssemblyOrient", num_envs, use_t_value=True, policy_path=orient_path, games=games)
+    dug = None
+    if search_path is not None:
+        r, l, search = main_rlgames("BlockAssemblySearch", min(num_envs, 128), use_t_value=True, policy_path=search_path, games=games)
+        dug = search.pile_terminal_states()
+        out["BlockAssemblySearch"] = dict(reward=r, length=l, search_success_rate=float(search.extras["success_buf"].float().mean()),
+                                          piles_handed_on=0 if dug is None else int(dug.shape[1]))
+        search.sim.close()
+    r, l, orient = main_rlgames("BlockAssemblyOrient", num_envs, use_t_value=True, policy_path=orient_path, games=games,
+                                task_kwargs={"initial_piles": dug})
     piles = orient.pile_terminal_states()
     out["BlockAssemblyOrient"] = dict(reward=r, length=l, piles_handed_on=0 if piles is None else int(piles.shape[1]))
     orient.sim.close()
@@ -54,6 +61,7 @@ def block_assembly(orient_path, grasp_path, insert_path, num_envs=512, games=0, 
 if __name__ == "__main__":
     p = argparse.ArgumentParser()
     p.add_argument("--tasks", type=str, default="BlockAssembly")
+    p.add_argument("--search", type=str, default=None)
     p.add_argument("--orient", type=str, default="")
     p.add_argument("--grasp", type=str, default="")
     p.add_argument("--insert", type=str, default="")
@@ -62,4 +70,4 @@ if __name__ == "__main__":
     a = p.parse_args()
     if a.tasks != "BlockAssembly":
         raise Exception("Unrecognized task!")
-    block_assembly(a.orient, a.grasp, a.insert, a.num_envs, a.games)
+    block_assembly(a.orient, a.grasp, a.insert, a.num_envs, a.games, search_path=a.search)

@@ -18,6 +18,7 @@ def build(args, task_kwargs=None, minibatch_size=0):
     from .tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
     from .tasks.block_assembly_orient import BlockAssemblyOrient
     from .tasks.block_assembly_insert_sim import BlockAssemblyInsertSim
+    from .tasks.block_assembly_search import BlockAssemblySearch
     from .vec_task_rlgames import RLgamesVecTaskPython
     args.algo = "lego"                                                                    # TR:36
     args.task_type = "RLgames"                                                            # TR:56
@@ -34,7 +35,7 @@ def build(args, task_kwargs=None, minibatch_size=0):
     cfg["env"]["test"] = args.play                                                        # TR:68
     set_seed(seed + rank, args.torch_deterministic)                                       # TR:70 (+ rank, App. C)
     task_cls = {"BlockAssemblyGraspSim": BlockAssemblyGraspSim, "BlockAssemblyOrient": BlockAssemblyOrient,
-                "BlockAssemblyInsertSim": BlockAssemblyInsertSim}[args.task]   # eval(args.task), PT:162
+                "BlockAssemblyInsertSim": BlockAssemblyInsertSim, "BlockAssemblySearch": BlockAssemblySearch}[args.task]   # eval(args.task), PT:162
     task = task_cls(cfg, None, None, "cuda", local_rank, True, seed=seed + rank, **(task_kwargs or {}))   # PT:162-170
     env = RLgamesVecTaskPython(task, args.rl_device)                                      # PT:178
     rl = cfg_train                                                                        # TR:78-85

@@ -54,3 +54,146 @@ def test_segmentation_camera_matches_numpy_ray_caster(scene):
         assert not s.EMERGENCE.cpu().numpy().any()                                           # nothing moved: no emergence
     finally:
         s.close()
+
+
+@pytest.fixture(scope="module")
+def search16():
+    from seqdex_amd.sim import SdxSim
+    s = SdxSim(16, device="cuda:0", seed=22, task_kind=3, max_episode_length=75.0, act_moving_average=0.6, target_euler=[0.0, 3.14, 1.57])
+    yield s
+    s.close()
+
+
+def test_search_pre_physics_golden(search16, golden_dir, scene):
+    f = np.load(os.path.join(golden_dir, "S2_pre_physics.npz"))
+    s, n = search16, 16
+    s.RESET.zero_()
+    dof = torch.zeros(n, 23, 2)
+    dof[:, :, 0] = torch.as_tensor(f["q"])
+    s.DOF.copy_(dof.view(-1, 2).cuda())
+    s.PREV_TARGETS.copy_(_dev(f["prev_targets"]))
+    s.PROGRESS.fill_(80)                                   # past Orient's step-75 lift: Search has none
+    s.RB[:, 7, 0:3] = _dev(f["hand_pos"])
+    s.RB[:, 7, 3:7] = _dev(f["hand_rot"])
+    root = s.ROOT.view(n, 142, 13)
+    for e in range(n):
+        root[e, scene.seg_index(e), 0:3] = _dev(f["target_pos"][e])
+    s.JAC_EEF.copy_(_dev(f["J"]))
+    s.pre_physics(_dev(f["actions"]))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(s.TARGETS.cpu().numpy(), f["cur_targets"], rtol=2e-4, atol=1e-4)      # the reference's numbers
+    want = T.search_pre_physics_targets(f["actions"], f["q"], f["prev_targets"], f["hand_pos"], f["hand_rot"], f["target_pos"], f["J"],
+                                        f["lower"], f["upper"])
+    np.testing.assert_allclose(s.TARGETS.cpu().numpy(), want, rtol=2e-4, atol=1e-4)
+
+
+def test_search_observation_and_state_layout(search16, golden_dir, scene):
+    """62-number observation and Search's own asymmetric frame (SE:1168-1218) against the numpy oracle (itself pinned to the reference
+    on CPU), with the attribute values the reference would read derived from the same rigid-body / root / joint states."""
+    f = np.load(os.path.join(golden_dir, "F3_observations.npz"))     # GraspSim's state fixtures serve as inputs
+    s, n = search16, 16
+    s.OBS.zero_(); s.STATES.zero_()
+    s.ROOT.copy_(_dev(f["c0_root"])); s.RB.copy_(_dev(f["c0_rb"])); s.DOF.copy_(_dev(f["c0_dof"]).view(-1, 2))
+    s.CONTACT.copy_(_dev(f["c0_contact"])); s.ACTIONS.copy_(_dev(f["c0_actions"]))
+    pix = torch.zeros(n, 4)
+    pix[:, 0] = torch.arange(n) * 7.0
+    pix[:, 1] = torch.arange(n) + 20.0
+    pix[:, 2] = 100.0 - torch.arange(n)
+    s.SEG_PIXELS.copy_(pix.cuda())
+    s.compute_observations()
+    torch.cuda.synchronize()
+    root = f["c0_root"].reshape(n, 142, 13)
+    rb, dof, act = f["c0_rb"], f["c0_dof"], f["c0_actions"]
+    obs = np.zeros((n, 186), np.float32)
+    obs[:, :62] = T.search_obs_frame(dof, act, f["lower"], f["upper"])
+    np.testing.assert_allclose(s.OBS.cpu().numpy(), obs, rtol=3e-5, atol=3e-5)
+    tgt = root[np.arange(n), f["seg_index_in_env"]]
+    tip = lambda b: (rb[:, b, 0:3] + T.quat_apply(rb[:, b, 3:7], np.broadcast_to(T.FT_OFFSET, (n, 3)))).astype(np.float32)
+    ft = scene.fingertip_bodies
+    a = dict(arm_hand_ff_pos=tip(ft[0]), arm_hand_mf_pos=tip(ft[1]), arm_hand_rf_pos=tip(ft[2]), arm_hand_th_pos=tip(ft[3]),
+             hand_base_pose=rb[:, 7, 0:7], segmentation_target_pose=tgt[:, 0:7], hand_base_linvel=rb[:, 7, 7:10],
+             hand_base_angvel=rb[:, 7, 10:13], segmentation_target_linvel=tgt[:, 7:10], segmentation_target_angvel=tgt[:, 10:13],
+             center_x=pix[:, 1].numpy(), center_y=pix[:, 2].numpy(), point_num=pix[:, 0].numpy())
+    for k in range(8):
+        a["hand_pos_history_%d" % k] = np.zeros((n, 3), np.float32)
+    for nm, b in zip(("ff", "mf", "rf", "th"), ft):
+        a["arm_hand_%s_rot" % nm], a["arm_hand_%s_linvel" % nm], a["arm_hand_%s_angvel" % nm] = rb[:, b, 3:7], rb[:, b, 7:10], rb[:, b, 10:13]
+    want = T.search_state_frame(dof, act, f["lower"], f["upper"], a)
+    st = s.STATES.cpu().numpy()
+    np.testing.assert_allclose(st[:, :188], want, rtol=3e-5, atol=3e-5)
+    assert not st[:, 188:].any()
+
+
+def test_search_reward_golden(golden_dir):
+    from seqdex_amd.sim import SdxSim
+    f = np.load(os.path.join(golden_dir, "S5_reward.npz"))
+    m = f["progress"].shape[0]
+    s = SdxSim(m, device="cuda:0", task_kind=3, max_episode_length=float(f["max_episode_length"]))
+    try:
+        root = s.ROOT.view(m, 142, 13)
+        seg = torch.tensor([s.scene.seg_index(i) for i in range(m)]).cuda()
+        ar = torch.arange(m).cuda()
+        root[ar, seg, 0:3] = _dev(f["target_pos"])
+        for body, key in zip(s.scene.fingertip_bodies, ["ff", "mf", "rf", "th"]):
+            s.RB[:, body, 0:3] = _dev(f[key] - np.array([0, 0, 0.04], np.float32))
+            s.RB[:, body, 3:7] = torch.tensor([0.0, 0, 0, 1]).cuda()
+        s.INIT_POS.copy_(_dev(f["init_pos"]))
+        s.ACTIONS.copy_(_dev(f["actions"]))
+        cf = torch.zeros(m, 165, 3)
+        cf[:, 1:7, 2] = torch.as_tensor(f["arm_contacts"]) * 1.0          # |force| >= 0.1 on the flagged arm links (SE: contacts >= 0.1)
+        s.CONTACT.copy_(cf.view(m, -1).cuda())
+        s.PROGRESS.copy_(_dev(f["progress"] - 1))                         # post_physics_step increments first
+        s.RESET.copy_(_dev(f["reset_buf"]))
+        s.SUCCESSES.copy_(_dev(f["successes"]))
+        s.CONS_SUCCESSES.copy_(_dev(f["cons_in"]))
+        s.post_physics()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(s.REW.cpu().numpy(), f["reward"], rtol=2e-4, atol=2e-3)      # the lift term scales metres by 1000
+        np.testing.assert_array_equal(s.RESET.cpu().numpy(), f["resets"])
+        np.testing.assert_allclose(s.CONS_SUCCESSES.cpu().numpy(), f["cons_out"], rtol=1e-6)
+    finally:
+        s.close()
+
+
+def test_search_task_end_to_end(scene):
+    """BlockAssemblySearch through the VecTask surface: the first step drops the pile (60 settling steps) and renders; the last step of
+    the episode parks the hand and renders again; the reset event that follows labels every env success / failure by its pixel count
+    and hands the successful piles on to BlockAssemblyOrient."""
+    import yaml
+    from seqdex_amd.tasks.block_assembly_orient import BlockAssemblyOrient
+    from seqdex_amd.tasks.block_assembly_search import BlockAssemblySearch
+    from seqdex_amd.vec_task_rlgames import RLgamesVecTaskPython
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root_dir, "seqdex_amd/cfg/allegro_hand_block_assembly_search.yaml")))
+    n = 16
+    cfg["env"]["numEnvs"] = n
+    task = BlockAssemblySearch(cfg, device_type="cuda", device_id=0, headless=True, seed=5)
+    env = RLgamesVecTaskPython(task, "cuda:0")
+    obs = env.reset()
+    torch.cuda.synchronize()
+    assert tuple(obs["obs"].shape) == (n, 186) and tuple(obs["states"].shape) == (n, 564)
+    r = task.sim.ROOT.view(n, 142, 13).cpu().numpy()
+    assert r[:, 9:81, 2].max() < 0.85 and r[:, 9:81, 2].min() > 0.55            # the lattice (up to z = 1.1) has fallen into the bin
+    pix0 = task.sim.SEG_PIXELS.cpu().numpy().copy()
+    assert (pix0[:, 0] >= 0).all() and pix0[:, 0].max() > 0                      # rendered after the settling steps
+    g = torch.Generator().manual_seed(0)
+    rews = []
+    for t in range(76):
+        obs, rew, reset, extras = env.step(((torch.rand(n, 23, generator=g) * 2 - 1) * 0.3).cuda())
+        rews.append(rew.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    assert np.isfinite(np.stack(rews)).all() and np.isfinite(obs["states"].cpu().numpy()).all()
+    tvc = task.sim.TV_COUNT.cpu().numpy()
+    pc = task.sim.PILE_HARVEST_COUNT.cpu().numpy()
+    assert tvc.sum() == n and pc.sum() == tvc[0], (tvc, pc)                      # one labelled reset event; successes handed on
+    assert int(task.extras["success_buf"].sum()) == tvc[0]
+    st = obs["states"].cpu().numpy()
+    assert not st[:, 96:120].any() and not st[:, 188:].any()
+    piles = task.pile_terminal_states()
+    if piles is not None:                                                        # every brick-type group had a success
+        ocfg = yaml.safe_load(open(os.path.join(root_dir, "seqdex_amd/cfg/allegro_hand_block_assembly_orient.yaml")))
+        ocfg["env"]["numEnvs"] = n
+        ot = BlockAssemblyOrient(ocfg, device_type="cuda", device_id=0, headless=True, seed=1, initial_piles=piles)
+        ot.step(torch.zeros(n, 23).cuda())
+        torch.cuda.synchronize()
+        assert np.isfinite(ot.sim.ROOT.cpu().numpy()).all()

@@ -140,12 +140,13 @@ def test_bi_optimization_outer_loop_one_round(tmp_path, monkeypatch):
     from seqdex_amd.scripts import bi_optimization as bo
     monkeypatch.chdir(tmp_path)
     paths, tv = bo.block_assembly(rounds=1, num_envs=64, epochs=2, tvalue_rollout=20, insert_minibatch=256)
-    for k in ("orient", "grasp", "insert"):
+    for k in ("search", "orient", "grasp", "insert"):
         ck = torch.load(paths[k], map_location="cpu", weights_only=False)
         assert "a2c_network.mu.weight" in ck["model"] and ck["epoch"] == 2
     from seqdex_amd.scripts import evaluation as ev
-    res = ev.block_assembly(paths["orient"], paths["grasp"], paths["insert"], num_envs=64, games=64, insert_minibatch=256)
-    assert set(res) == {"BlockAssemblyOrient", "BlockAssemblyGraspSim", "BlockAssemblyInsertSim"}
+    res = ev.block_assembly(paths["orient"], paths["grasp"], paths["insert"], num_envs=64, games=64, insert_minibatch=256,
+                            search_path=paths["search"])
+    assert set(res) == {"BlockAssemblySearch", "BlockAssemblyOrient", "BlockAssemblyGraspSim", "BlockAssemblyInsertSim"}
     assert all(np.isfinite(v["reward"]) and v["length"] > 0 for v in res.values()), res
     assert 0.0 <= res["BlockAssemblyInsertSim"]["insert_success_rate"] <= 1.0
     assert tv is None or set(tv) == {"linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "linear3.weight", "linear3.bias",

@@ -82,12 +82,13 @@ def test_insert_sim_scene_desc_places_three_plate_variants(scene):
     assert g.static_var_slot == -1 and abs(g.static_center[7][1] + 0.19) < 1e-6
 
 
-def test_launcher_maps_the_three_tasks():
+def test_launcher_maps_the_four_tasks():
     from seqdex_amd import config
-    assert set(config.TASK_CFG) == {"BlockAssemblyGraspSim", "BlockAssemblyOrient", "BlockAssemblyInsertSim"}
+    assert set(config.TASK_CFG) == {"BlockAssemblyGraspSim", "BlockAssemblyOrient", "BlockAssemblyInsertSim", "BlockAssemblySearch"}
     for t, rel in config.TASK_CFG.items():
         cfg = yaml.safe_load(open(os.path.join(os.path.dirname(config.__file__), rel)))
-        assert cfg["env"]["episodeLength"] == {"BlockAssemblyGraspSim": 150, "BlockAssemblyOrient": 75, "BlockAssemblyInsertSim": 125}[t]
+        assert cfg["env"]["episodeLength"] == {"BlockAssemblyGraspSim": 150, "BlockAssemblyOrient": 75, "BlockAssemblyInsertSim": 125,
+                                                "BlockAssemblySearch": 75}[t]
 
 
 def test_rlgames_checkpoint_layout_round_trip():
