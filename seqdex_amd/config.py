@@ -69,7 +69,7 @@ def get_args(argv=None):
     if args.checkpoint == "Base":                                                                           # TR:38-39
         args.checkpoint = ""
     if args.task not in TASK_CFG:
-        raise SystemExit("Unrecognized task!\nTask should be one of: %s (this build covers the GraspSim hot path only)"
+        raise SystemExit("Unrecognized task!\nTask should be one of: %s (the BlockAssembly chain tasks built here)"
                          % sorted(TASK_CFG))                                                                # CF:26-28
     if args.cfg_env == "Base":
         args.cfg_env = os.path.join(HERE, TASK_CFG[args.task])
