@@ -23,11 +23,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_ENV_STEP = 18496     # algorithmic HBM bytes per env-step of the sim+task path
 # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-# separate runs of this same command at the default config; both counters are in KiB; FETCH_SIZE is reported raw - the guide's
-# x2 correction is calibrated for 16 B/lane streaming reads only, the exchange words here are 8 B/lane).  PMC counters cannot
-# be read from inside this process, so `traffic` is quoted from those files and is null for any other configuration.
-PMC_TRAFFIC_BYTES = {("k_update_persistent", 1024): (14343183.0 + 7011506.7) * 1024,     # profiles/r1_bench_pmc_{fetch,write}_v4.csv
-                     ("k_physics", 1024): (2874.8 + 16285.8) * 1024}   # the 57 dispatches with 1024 workgroups (grid 524288) only
+# separate runs of this same command at the default config).  Units and corrections as MI355X_MICROARCH.md's HBM section
+# prescribes: both counters are in KiB; on gfx950 FETCH_SIZE tallies each 128-B memory-side read request at 64 B, i.e. reports
+# half of the bytes read -> doubled here.  (The guide calibrated that factor on 16 B/lane streaming reads and calls other
+# access widths and WRITE_SIZE uncalibrated; the raw counter values are kept next to the corrected figure.)  PMC counters
+# cannot be read from inside this process, so `traffic` is quoted from those files and is null for any other configuration.
+PMC_RAW_KIB = {("k_update_persistent", 1024): (14343183.0, 7011506.7),     # (FETCH_SIZE, WRITE_SIZE), profiles/r1_bench_pmc_{fetch,write}_v4.csv
+               ("k_physics", 1024): (2874.8, 16285.8)}                      # the 57 dispatches with 1024 workgroups (grid 524288) only
+PMC_TRAFFIC_BYTES = {k: (2.0 * f + w) * 1024 for k, (f, w) in PMC_RAW_KIB.items()}
+
+
+def pmc_raw(key):
+    if key not in PMC_RAW_KIB:
+        return None
+    f, w = PMC_RAW_KIB[key]
+    return {"FETCH_SIZE_bytes_as_reported": f * 1024, "WRITE_SIZE_bytes_as_reported": w * 1024,
+            "correction": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-B requests at 64 B)"}
 
 
 def parse():
@@ -218,7 +229,7 @@ def main():
     phys_bytes = BYTES_PER_ENV_STEP * n
     roof_phys = {"kernel": "k_physics", "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes,
-                 "traffic": PMC_TRAFFIC_BYTES.get(("k_physics", n))}
+                 "traffic": PMC_TRAFFIC_BYTES.get(("k_physics", n)), "traffic_counters": pmc_raw(("k_physics", n))}
     roof_phys["frac"] = roof_phys["achieved"] / HBM_PEAK_GBS
     # ---- roofline of the update phase.  Algorithmic bytes: one optimiser step streams w, m, v in and out once for all three
     # networks (6 x 4 B x params); the persistent kernel runs all optimiser steps of the epoch in ONE launch and keeps w, m, v in
@@ -248,7 +259,8 @@ def main():
       roof_upd = {"kernel": kname, "bound": "hbm", "achieved": upd_bytes_step / (upd_ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "avg_launch_ms": upd_launch_ms, "us_per_optimiser_step": upd_ms_step * 1e3,
                 "algorithmic_bytes_per_launch": upd_bytes_step * nsteps,
-                "traffic": PMC_TRAFFIC_BYTES.get(("k_update_persistent", n)) if impl == "persistent" and args.minibatch is None else None}
+                "traffic": PMC_TRAFFIC_BYTES.get(("k_update_persistent", n)) if impl == "persistent" and args.minibatch is None else None,
+                "traffic_counters": pmc_raw(("k_update_persistent", n)) if impl == "persistent" and args.minibatch is None else None}
       roof_upd["frac"] = roof_upd["achieved"] / HBM_PEAK_GBS
     dominant = roof_upd if upd_t > step_t else roof_phys
     out = {
