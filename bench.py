@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--num-envs", type=int, default=1024, help="envs per GPU (config[1]: 1024)")
     ap.add_argument("--minibatch", type=int, default=None, help="override minibatch_size (labelled variant, not the headline)")
+    ap.add_argument("--pretrain-epochs", type=int, default=0, help="untimed training epochs before the warm-up (SURVEY 8(d) config 2: "
+                    "second run with a partially trained policy after 200 epochs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-minibatch", action="store_true", help="skip the labelled large-minibatch variant")
     ap.add_argument("--cpu-baseline-envs", type=int, default=1024)
@@ -193,6 +195,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(args.pretrain_epochs):
+        agent.train_epoch()
     for _ in range(args.warmup):
         agent.train_epoch()
     barrier()
@@ -270,7 +274,8 @@ def main():
         "config": {"workload": "BlockAssemblyGraspSim num_envs=%d per GPU, fp32, PPO MLP policy [1024,512,256], horizon 8, "
                                "minibatch_size %d, mini_epochs 5, central value (configs[1])" % (n, agent.minibatch_size),
                    "step": "one rl_games epoch = 8 env steps x num_envs + full PPO update", "global_envs": n * world,
-                   "piles": "synthetic settled piles, 8 per brick-type group", "policy": "random init, seed 22+rank"},
+                   "piles": "synthetic settled piles, 8 per brick-type group",
+                   "policy": "random init, seed 22+rank" + (", then %d untimed training epochs" % args.pretrain_epochs if args.pretrain_epochs else "")},
         "fps_step": n * horizon * args.steps / step_t, "fps_step_and_inference": n * horizon * args.steps / play_t,
         "fps_total_rank0": n * horizon * args.steps / (play_t + upd_t),
         "update_ms_per_epoch": upd_t / args.steps * 1e3, "rollout_ms_per_epoch": play_t / args.steps * 1e3,
