@@ -78,6 +78,34 @@ def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mi
         po.simulate(scene_desc, root, dof, tg)
     sim_dt = time.time() - t
     sim_rate = n * args.cpu_baseline_steps / sim_dt
+    # the same leg with Isaac Gym's default num_threads (4, CF:201) and the shipped YAML's 64 (EG:158), on smaller samples
+    by_threads = {str(cores): sim_rate}
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        for th in (4, 64):
+            if th >= cores:
+                continue
+            gomp.omp_set_num_threads(th)
+            nt = min(n, th * 8)
+            r2, d2, t2 = root0[:nt].copy(), dof0[:nt].copy(), targets0[:nt].copy()
+            po.simulate(scene_desc, r2, d2, t2)
+            t = time.time()
+            for _ in range(8):
+                po.simulate(scene_desc, r2, d2, t2)
+            by_threads[str(th)] = nt * 8 / (time.time() - t)
+        gomp.omp_set_num_threads(cores)
+    except OSError:
+        pass
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     # PPO leg (rank-4 minibatches: the torch-CPU step is dispatch/Adam-stream bound, more than ~16 threads only adds fork/join cost)
     ppo_threads = min(16, cores)
     torch.set_num_threads(ppo_threads)
@@ -98,7 +126,8 @@ def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mi
     epoch_opt_steps = mini_epochs * (n_full * horizon // minibatch)
     epoch_s = n_full * horizon / sim_rate + epoch_opt_steps * us_per_opt_step * 1e-6
     return {"value": n_full * horizon / epoch_s, "unit": "env-steps/s", "cores": cores, "kind": "port", "ppo_threads": ppo_threads,
-            "sim_only_env_steps_per_s": sim_rate, "ppo_us_per_optimiser_step": us_per_opt_step,
+            "cpu_model": cpu_model, "sim_only_env_steps_per_s": sim_rate, "sim_only_env_steps_per_s_by_omp_threads": by_threads,
+            "ppo_us_per_optimiser_step": us_per_opt_step,
             "sample": "sim: %d envs x %d physics steps of oracle/physics_oracle.c (OpenMP over envs, %d threads), %.1f s; "
                       "PPO: %d optimiser steps (minibatch %d) of oracle/ppo_oracle.py on torch-CPU (%d threads), %.1f s, scaled to the "
                       "%d steps of one epoch; no policy inference / obs kernels in the CPU number"
