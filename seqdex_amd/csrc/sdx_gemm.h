@@ -160,7 +160,7 @@ static void gemm(const GemmArgs* gs, int count, int splits, hipStream_t st) {
   }
   gb.splits = splits;
   const long big = (long)((Nx + 127) / 128) * ((Mx + 127) / 128) * splits * count;
-  if (big >= 192) {
+  if (big >= 256) {
     dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, splits * count);
     hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 32>), grid, dim3(256), 0, st, gb);
   } else {
