@@ -41,80 +41,89 @@ struct GemmArgs {
 // blockIdx.z = problem * splits + split, so that the narrow layers still give every CU several workgroups.
 struct GemmBatch { GemmArgs a[3]; int splits; };
 
-template <int AT, int BT, int EPI, int WT, int KT>
+template <int AT, int BT, int EPI, int WTM, int WTN, int KT>
 __global__ __launch_bounds__(256) void k_gemm(GemmBatch gb) {
-  constexpr int T = TB * WT;                        // tile edge
-  constexpr int NV = T * KT / 4 / 256;              // float4 loads per thread and operand per reduction chunk
-  __shared__ float As[T][KT + 1];
-  __shared__ float Bs[T][KT + 1];
+  constexpr int TM = TB * WTM, TN = TB * WTN;       // tile: waves own (32 WTM) x (32 WTN) of it, 2 x 2 waves
+  constexpr int NVA = TM * KT / 4 / 256, NVB = TN * KT / 4 / 256;   // float4 loads per thread per reduction chunk
+  __shared__ float As[TM][KT + 1];
+  __shared__ float Bs[TN][KT + 1];
   const GemmArgs& g = gb.a[blockIdx.z / gb.splits];
   const int zs = blockIdx.z % gb.splits;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
+  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
   if (i0 >= g.M || j0 >= g.N) return;               // the grid covers the largest problem of the batch
   const int kbeg = zs * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-  const int wm = (wave >> 1) * 32 * WT, wn = (wave & 1) * 32 * WT;
-  f32x16 acc[WT][WT];
+  const int wm = (wave >> 1) * 32 * WTM, wn = (wave & 1) * 32 * WTN;
+  f32x16 acc[WTM][WTN];
 #pragma unroll
-  for (int u = 0; u < WT; ++u)
+  for (int u = 0; u < WTM; ++u)
 #pragma unroll
-    for (int v = 0; v < WT; ++v)
+    for (int v = 0; v < WTN; ++v)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[u][v][i] = 0.0f;
   // element e = tid + 256 p of a chunk: k-contiguous sources -> (row e / (KT/4), k offset 4 (e % (KT/4)));
   // transposed sources -> (k row e / (T/4), i/j offset 4 (e % (T/4))): consecutive lanes read consecutive 16-byte pieces
-  float4 av[NV], bv[NV];
+  float4 av[NVA], bv[NVB];
   float rsum = 0.0f;
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < NV; ++p) {
+    for (int p = 0; p < NVA; ++p) {
       const int e = tid + 256 * p;
-      av[p] = make_float4(0, 0, 0, 0); bv[p] = make_float4(0, 0, 0, 0);
+      av[p] = make_float4(0, 0, 0, 0);
       if (AT == 0) { const int r = i0 + e / (KT / 4), k = k0 + 4 * (e % (KT / 4)); if (r < g.M && k < kend) av[p] = load4(g.A + (size_t)r * g.lda + k, kend - k); }
-      else         { const int k = k0 + e / (T / 4), c = i0 + 4 * (e % (T / 4));   if (k < kend && c < g.M) av[p] = load4(g.A + (size_t)k * g.lda + c, g.M - c); }
+      else         { const int k = k0 + e / (TM / 4), c = i0 + 4 * (e % (TM / 4));  if (k < kend && c < g.M) av[p] = load4(g.A + (size_t)k * g.lda + c, g.M - c); }
+    }
+#pragma unroll
+    for (int p = 0; p < NVB; ++p) {
+      const int e = tid + 256 * p;
+      bv[p] = make_float4(0, 0, 0, 0);
       if (BT == 0) { const int r = j0 + e / (KT / 4), k = k0 + 4 * (e % (KT / 4)); if (r < g.N && k < kend) bv[p] = load4(g.B + (size_t)r * g.ldb + k, kend - k); }
-      else         { const int k = k0 + e / (T / 4), c = j0 + 4 * (e % (T / 4));   if (k < kend && c < g.N) bv[p] = load4(g.B + (size_t)k * g.ldb + c, g.N - c); }
+      else         { const int k = k0 + e / (TN / 4), c = j0 + 4 * (e % (TN / 4));  if (k < kend && c < g.N) bv[p] = load4(g.B + (size_t)k * g.ldb + c, g.N - c); }
     }
   };
   if (kbeg < kend) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += KT) {
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < NV; ++p) {
+    for (int p = 0; p < NVA; ++p) {
       const int e = tid + 256 * p;
       if (AT == 0) { float* d = &As[e / (KT / 4)][4 * (e % (KT / 4))]; d[0] = av[p].x; d[1] = av[p].y; d[2] = av[p].z; d[3] = av[p].w; }
-      else         { const int k = e / (T / 4), c = 4 * (e % (T / 4)); As[c][k] = av[p].x; As[c + 1][k] = av[p].y; As[c + 2][k] = av[p].z; As[c + 3][k] = av[p].w; }
+      else         { const int k = e / (TM / 4), c = 4 * (e % (TM / 4)); As[c][k] = av[p].x; As[c + 1][k] = av[p].y; As[c + 2][k] = av[p].z; As[c + 3][k] = av[p].w; }
+    }
+#pragma unroll
+    for (int p = 0; p < NVB; ++p) {
+      const int e = tid + 256 * p;
       if (BT == 0) { float* d = &Bs[e / (KT / 4)][4 * (e % (KT / 4))]; d[0] = bv[p].x; d[1] = bv[p].y; d[2] = bv[p].z; d[3] = bv[p].w; }
-      else         { const int k = e / (T / 4), c = 4 * (e % (T / 4)); Bs[c][k] = bv[p].x; Bs[c + 1][k] = bv[p].y; Bs[c + 2][k] = bv[p].z; Bs[c + 3][k] = bv[p].w; }
+      else         { const int k = e / (TN / 4), c = 4 * (e % (TN / 4)); Bs[c][k] = bv[p].x; Bs[c + 1][k] = bv[p].y; Bs[c + 2][k] = bv[p].z; Bs[c + 3][k] = bv[p].w; }
     }
     __syncthreads();
     if (k0 + KT < kend) fetch(k0 + KT);
-    if (EPI == 4 && blockIdx.x == 0 && tid < T) {
+    if (EPI == 4 && blockIdx.x == 0 && tid < TM) {
 #pragma unroll
       for (int kk = 0; kk < KT; ++kk) rsum += As[tid][kk];
     }
 #pragma unroll
     for (int kk = 0; kk < KT; kk += 2) {
-      float a[WT], b[WT];
+      float a[WTM], b[WTN];
 #pragma unroll
-      for (int u = 0; u < WT; ++u) a[u] = As[wm + 32 * u + (lane & 31)][kk + (lane >> 5)];
+      for (int u = 0; u < WTM; ++u) a[u] = As[wm + 32 * u + (lane & 31)][kk + (lane >> 5)];
 #pragma unroll
-      for (int v = 0; v < WT; ++v) b[v] = Bs[wn + 32 * v + (lane & 31)][kk + (lane >> 5)];
+      for (int v = 0; v < WTN; ++v) b[v] = Bs[wn + 32 * v + (lane & 31)][kk + (lane >> 5)];
 #pragma unroll
-      for (int u = 0; u < WT; ++u)
+      for (int u = 0; u < WTM; ++u)
 #pragma unroll
-        for (int v = 0; v < WT; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[v], acc[u][v], 0, 0, 0);
+        for (int v = 0; v < WTN; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[v], acc[u][v], 0, 0, 0);
     }
   }
-  if (EPI == 4 && blockIdx.x == 0 && tid < T && i0 + tid < g.M) g.rowsum[(size_t)zs * g.cz + i0 + tid] = rsum;
+  if (EPI == 4 && blockIdx.x == 0 && tid < TM && i0 + tid < g.M) g.rowsum[(size_t)zs * g.cz + i0 + tid] = rsum;
   float* C = g.C + (size_t)zs * g.cz;
 #pragma unroll
-  for (int v = 0; v < WT; ++v) {
+  for (int v = 0; v < WTN; ++v) {
     const int col = j0 + wn + 32 * v + (lane & 31);
     if (col >= g.N) continue;
     const float bias = (EPI == 1 || EPI == 2) ? g.bias[col] : 0.0f;
 #pragma unroll
-    for (int u = 0; u < WT; ++u)
+    for (int u = 0; u < WTM; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = i0 + wm + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -159,13 +168,20 @@ static void gemm(const GemmArgs* gs, int count, int splits, hipStream_t st) {
     if (q < count) { Mx = gs[q].M > Mx ? gs[q].M : Mx; Nx = gs[q].N > Nx ? gs[q].N : Nx; }
   }
   gb.splits = splits;
-  const long big = (long)((Nx + 127) / 128) * ((Mx + 127) / 128) * splits * count;
-  if (big >= 256) {
+  // tile choice: 128 x 128 (each wave 64 x 64: least LDS / L2 traffic per flop) when that fills the 256 CUs with whole rounds
+  // of workgroups, else 128 x 64, else 64 x 64
+  auto blocks = [&](int tm, int tn) { return (long)((Nx + tn - 1) / tn) * ((Mx + tm - 1) / tm) * splits * count; };
+  auto waste = [&](long b) { const long rounds = (b + 255) / 256; return (double)(rounds * 256 - b) / (double)(rounds * 256); };
+  const long b22 = blocks(128, 128), b21 = blocks(128, 64);
+  if (b22 >= 256 && waste(b22) <= 0.15) {
     dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, splits * count);
-    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 32>), grid, dim3(256), 0, st, gb);
+    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 2, 32>), grid, dim3(256), 0, st, gb);
+  } else if (b21 >= 256 && waste(b21) <= 0.15) {
+    dim3 grid((Nx + 63) / 64, (Mx + 127) / 128, splits * count);
+    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 1, 32>), grid, dim3(256), 0, st, gb);
   } else {
     dim3 grid((Nx + TB - 1) / TB, (Mx + TB - 1) / TB, splits * count);
-    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 1, 16>), grid, dim3(256), 0, st, gb);
+    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 1, 1, 16>), grid, dim3(256), 0, st, gb);
   }
 }
 
