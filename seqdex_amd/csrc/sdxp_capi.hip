@@ -212,7 +212,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     D.foff.dh = o; o += MB * 34; D.foff.dls = o; o += 32; D.foff.kl = o; o += 1;
     D.foff.total = (o + 63) / 64 * 64;
     D.world = cfg->world_size > 0 ? cfg->world_size : 1;
-    PAL(D.fact, D.foff.total); PAL(D.fact_all, (size_t)D.foff.total * D.world); PAL(D.sqn_part, 1024);
+    PAL(D.fact, D.foff.total); PAL(D.fact_all, (size_t)D.foff.total * D.world); PAL(D.sqn_part, 4096);   // 2 x SDXP_SQN_STRIDE (sdxp_kernels.hip)
   }
   if (h->big) {   // activations and pre-activation gradients of one large minibatch, split partials of the weight gradients
     SdxpBigWs& w = h->bigws;
