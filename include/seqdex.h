@@ -347,7 +347,7 @@ int sdxp_backward(sdxp_handle h, int32_t which, int32_t mb, void* stream);
  * sdxp_apply(1).  The *_GRADS buffers then hold the same rank SUM an all-reduce would have produced. */
 int sdxp_backward_factors(sdxp_handle h, int32_t mb, void* stream);
 int sdxp_grads_from_factors(sdxp_handle h, void* stream);
-/* = sdxp_grads_from_factors + sdxp_apply(0, -INFINITY) + sdxp_apply(1), fused into four launches */
+/* = sdxp_grads_from_factors + sdxp_apply(0, -INFINITY) + sdxp_apply(1), fused into three launches */
 int sdxp_apply_factors(sdxp_handle h, void* stream);
 /* kl: the rank-averaged KL for the LR schedule; NaN = take SdxpCtrl.last_kl that the caller all-reduced (SUM) in place through
  * SDXP_T_STATS; -INFINITY = take the KL word of SDXP_T_ALL_GRADS that the caller all-reduced (SUM) with the gradients. */

@@ -139,7 +139,7 @@ class SdxPPO:
         self._check(self.lib.sdxp_grads_from_factors(self.h, _stream_ptr(self.device)))
 
     def apply_factors(self):
-        """grads_from_factors() + apply(0, -inf) + apply(1) in four launches"""
+        """grads_from_factors() + apply(0, -inf) + apply(1) in three launches"""
         self._check(self.lib.sdxp_apply_factors(self.h, _stream_ptr(self.device)))
 
     def kl_view(self):
