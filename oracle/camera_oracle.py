@@ -30,17 +30,19 @@ def scene_boxes(desc, root_env, rb_env):
     c = [r[:, 0:3] + quat_apply(q, bc[bt])]
     qs, hs, ids = [q], [bh[bt]], [np.arange(1, 133)]
     ns = desc.n_static
-    c.append(np.array([list(desc.static_center[s]) for s in range(ns)], F))
-    qs.append(np.tile(np.array([[0, 0, 0, 1]], F), (ns, 1)))
-    hs.append(np.array([list(desc.static_half[s]) for s in range(ns)], F))
-    ids.append(np.zeros(ns, int))
+    if ns:
+        c.append(np.array([list(desc.static_center[s]) for s in range(ns)], F))
+        qs.append(np.tile(np.array([[0, 0, 0, 1]], F), (ns, 1)))
+        hs.append(np.array([list(desc.static_half[s]) for s in range(ns)], F))
+        ids.append(np.zeros(ns, int))
     nr = desc.n_rbox
-    link = np.array(list(desc.rbox_link))[:nr]
-    ql = rb_env[link, 3:7].astype(F)
-    c.append(rb_env[link, 0:3].astype(F) + quat_apply(ql, np.array([list(desc.rbox_center[k]) for k in range(nr)], F)))
-    qs.append(quat_mul(ql, np.array([list(desc.rbox_quat[k]) for k in range(nr)], F)))
-    hs.append(np.array([list(desc.rbox_half[k]) for k in range(nr)], F))
-    ids.append(np.zeros(nr, int))
+    if nr:
+        link = np.array(list(desc.rbox_link))[:nr]
+        ql = rb_env[link, 3:7].astype(F)
+        c.append(rb_env[link, 0:3].astype(F) + quat_apply(ql, np.array([list(desc.rbox_center[k]) for k in range(nr)], F)))
+        qs.append(quat_mul(ql, np.array([list(desc.rbox_quat[k]) for k in range(nr)], F)))
+        hs.append(np.array([list(desc.rbox_half[k]) for k in range(nr)], F))
+        ids.append(np.zeros(nr, int))
     return np.concatenate(c).astype(F), np.concatenate(qs).astype(F), np.concatenate(hs).astype(F), np.concatenate(ids)
 
 
