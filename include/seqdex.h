@@ -100,7 +100,7 @@ typedef enum {
   SDX_T_TV_FAILURE = 34,   /* f32 [65536,4]     ... of failed ones                                                  GS:1420-1438, IS:1401-1410 */
   SDX_T_TV_COUNT = 35,     /* i32 [2]           rows logged so far: [success, failure] (ring index = count % 65536)                      */
   SDX_T_PILE_HARVEST = 36, /* f32 [8,S,132,13]  Orient: brick states of finished episodes that left the target brick reachable (ring per
-                            *                    brick-type group; S = 512 for task_kind 1, else 1) = the saved piles GraspSim starts from    OR:1463-1488, GS:412-413 */
+                            *                    brick-type group; S = 512 for task_kind 1 (Orient) and 3 (Search, SE:1398-1420), else 1) = the saved piles the next task starts from    OR:1463-1488, GS:412-413 */
   SDX_T_PILE_HARVEST_COUNT = 37, /* i32 [8]     pile states harvested so far (ring index = count % S)                                    */
   SDX_T_SEG_IMAGE = 38,    /* i16 [N,128,128]   Search: segmentation image of the last render (0 = background / robot / bin, i+1 = brick i)  SE:877 */
   SDX_T_SEG_PIXELS = 39,   /* f32 [N,4]         Search: target pixel count, centroid row, centroid column, count of the render before   SE:1232-1241 */
@@ -325,6 +325,12 @@ int sdxp_store_rewards(sdxp_handle h, int32_t t, const float* rew_dev, const int
 /* play_steps tail (PS:329-339) + prepare_dataset (RC:1639-1651): last_values = V(states), GAE (R5), returns,
  * flatten env-major, advantage normalisation with unbiased std (R6); updates the CV running mean/std. */
 int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, const int64_t* last_dones_dev, void* stream);
+/* The three stages of sdxp_finish_rollout one by one, for callers that keep rl_games-style driver code (PS:329-343):
+ * get_values (RC:1725-1745; the central value of `states`, f32 [N] out), discount_values (PS:331-336; raw advantages ->
+ * SDXP_T_ADVANTAGES, returns -> SDXP_T_RETURNS, both env-major), prepare_dataset (RC:1645-1651; advantage normalisation in place). */
+int sdxp_get_values(sdxp_handle h, const float* states_dev, float* values_out_dev, void* stream);
+int sdxp_discount_values(sdxp_handle h, const float* last_values_dev, const int64_t* last_dones_dev, void* stream);
+int sdxp_prepare_dataset(sdxp_handle h, void* stream);
 /* train_central_value + the actor-critic minibatch loop of train_epoch (PS:294-326, RC:1339-1365): all
  * mini-epochs, contiguous unshuffled minibatches, loss R7, grad-norm clip, Adam, legacy adaptive LR after
  * every minibatch (R8).  Single-rank fast path: everything stays on the device. */
@@ -352,6 +358,16 @@ int sdxp_apply_factors(sdxp_handle h, void* stream);
 /* kl: the rank-averaged KL for the LR schedule; NaN = take SdxpCtrl.last_kl that the caller all-reduced (SUM) in place through
  * SDXP_T_STATS; -INFINITY = take the KL word of SDXP_T_ALL_GRADS that the caller all-reduced (SUM) with the gradients. */
 int sdxp_apply(sdxp_handle h, int32_t which, float kl_allreduced_or_nan, void* stream);
+/* Optimiser state kept in the device control block, for checkpoints (rl_games restores the same items: the Adam step counters of
+ * optimizer.state_dict(), running_mean_std.count of the central value, last_lr; A2CBase.set_full_state_weights).  Both calls block.
+ * sdxp_set_state also re-derives the bias-correction powers 0.9^t / 0.999^t. */
+typedef struct {
+  double rms_count;          /* RunningMeanStd.count of the central-value input normalisation (1.0 after create) */
+  int32_t ac_t, cv_t;        /* Adam step counters of the actor-critic / central-value optimisers                 */
+  float ac_lr, cv_lr;        /* current learning rates (ac_lr moves with the adaptive schedule, PS:306-312)       */
+} sdxp_opt_state;
+int sdxp_get_state(sdxp_handle h, sdxp_opt_state* out, void* stream);
+int sdxp_set_state(sdxp_handle h, const sdxp_opt_state* in, void* stream);
 const char* sdxp_last_error(sdxp_handle h);
 
 /* ------------------------------------------------------------------------------------------------------------------------------

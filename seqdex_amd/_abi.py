@@ -63,6 +63,11 @@ class PPOConfig(C.Structure):
     ]
 
 
+class OptState(C.Structure):
+    """sdxp_opt_state"""
+    _fields_ = [("rms_count", C.c_double), ("ac_t", i32), ("cv_t", i32), ("ac_lr", f32), ("cv_lr", f32)]
+
+
 # tensor ids (sdx_tensor_id)
 T = dict(ROOT=0, DOF=1, RB=2, CONTACT=3, JAC_EEF=4, TARGETS=5, PREV_TARGETS=6, OBS=7, STATES=8, OBS_CLAMPED=9,
          STATES_CLAMPED=10, REW=11, RESET=12, PROGRESS=13, RANDOMIZE=14, ACTIONS=15, INIT_POS=16, INIT_ROT=17,
@@ -79,8 +84,8 @@ SDX_EXPORTS = ["sdx_create", "sdx_destroy", "sdx_tensor", "sdx_load_initial_stat
                "sdx_step", "sdx_pre_physics", "sdx_simulate", "sdx_post_physics", "sdx_compute_observations",
                "sdx_reset_idx", "sdx_refresh_kinematics", "sdx_render_segmentation", "sdx_num_envs", "sdx_last_error",
                "sdxp_create", "sdxp_destroy", "sdxp_tensor", "sdxp_param_count", "sdxp_act", "sdxp_store_rewards",
-               "sdxp_finish_rollout", "sdxp_update", "sdxp_update_impl", "sdxp_update_status", "sdxp_backward", "sdxp_apply", "sdxp_backward_factors",
-               "sdxp_grads_from_factors", "sdxp_apply_factors", "sdxp_last_error",
+               "sdxp_finish_rollout", "sdxp_get_values", "sdxp_discount_values", "sdxp_prepare_dataset", "sdxp_update", "sdxp_update_impl", "sdxp_update_status", "sdxp_backward", "sdxp_apply", "sdxp_backward_factors",
+               "sdxp_grads_from_factors", "sdxp_apply_factors", "sdxp_get_state", "sdxp_set_state", "sdxp_last_error",
                "sdxtv_create", "sdxtv_destroy", "sdxtv_tensor", "sdxtv_sample", "sdxtv_step", "sdxtv_train", "sdxtv_predict",
                "sdxtv_last_error"]
 
@@ -121,6 +126,9 @@ def load_library():
     lib.sdxp_act.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     lib.sdxp_store_rewards.argtypes = [vp, i32, vp, vp, vp]
     lib.sdxp_finish_rollout.argtypes = [vp, vp, vp, vp]
+    lib.sdxp_get_values.argtypes = [vp, vp, vp, vp]
+    lib.sdxp_discount_values.argtypes = [vp, vp, vp, vp]
+    lib.sdxp_prepare_dataset.argtypes = [vp, vp]
     lib.sdxtv_create.argtypes = [i32, i32, C.c_uint64, C.POINTER(vp)]
     lib.sdxtv_destroy.argtypes = [vp]
     lib.sdxtv_tensor.argtypes = [vp, i32, C.POINTER(vp), i64p, i32p, i32p]
@@ -138,6 +146,8 @@ def load_library():
     lib.sdxp_backward_factors.argtypes = [vp, i32, vp]
     lib.sdxp_grads_from_factors.argtypes = [vp, vp]
     lib.sdxp_apply_factors.argtypes = [vp, vp]
+    lib.sdxp_get_state.argtypes = [vp, C.POINTER(OptState), vp]
+    lib.sdxp_set_state.argtypes = [vp, C.POINTER(OptState), vp]
     lib.sdxp_last_error.argtypes = [vp]
     lib.sdxp_last_error.restype = C.c_char_p
     for n in SDX_EXPORTS:

@@ -8,7 +8,7 @@ import time
 
 import torch
 
-from .ppo import SdxPPO, make_config
+from .ppo import Ctrl, SdxPPO, make_config
 
 
 class _Meter:
@@ -23,6 +23,35 @@ class _Meter:
 
     def get_mean(self):
         return [self.mean]
+
+
+class _Dataset:
+    """rl_games' PPODataset surface (`len(dataset)`, `dataset[i]`, `update_mu_sigma`, `update_values_dict`; App. C): minibatch i is
+    rows [i*mb, (i+1)*mb) of the env-major experience buffer - contiguous, unshuffled.  The rows are VIEWS of library-owned memory;
+    `mb_index` is what calc_gradients hands to sdxp_backward."""
+
+    def __init__(self, agent):
+        self.agent = agent
+
+    def __len__(self):
+        return self.agent.batch_size // self.agent.minibatch_size
+
+    def __getitem__(self, i):
+        a, t = self.agent, self.agent.ppo.t
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        mb = a.minibatch_size
+        sl = slice(i * mb, (i + 1) * mb)
+        flat = lambda x: x.reshape(a.batch_size, -1)[sl]
+        return {"mb_index": i, "obs": flat(t["MB_OBS"]), "states": flat(t["MB_STATES"]), "actions": flat(t["MB_ACTIONS"]),
+                "mu": flat(t["MB_MUS"]), "sigma": flat(t["MB_SIGMAS"]), "old_logp_actions": t["MB_NEGLOGP"].reshape(-1)[sl],
+                "old_values": t["MB_VALUES"].reshape(-1)[sl], "returns": t["RETURNS"][sl], "advantages": t["ADVANTAGES"][sl]}
+
+    def update_mu_sigma(self, mu, sigma):
+        pass            # the step kernels write the new mu / sigma rows back themselves (RC:1358)
+
+    def update_values_dict(self, values_dict):
+        pass            # the dataset IS the library's experience buffer
 
 
 class A2CAgent:
@@ -59,6 +88,18 @@ class A2CAgent:
         self.entropy_coef = cfg.get("entropy_coef", 0.0)
         self.game_rewards, self.game_lengths = _Meter(), _Meter()
         self.last_mean_rewards = -100500
+        self.save_freq = int(cfg.get("save_frequency", 0) or 0)               # App. C: A2CBase reads these from params.config
+        self.save_best_after = int(cfg.get("save_best_after", 100))
+        self.train_dir = cfg.get("train_dir", "runs")
+        self.experiment_name = cfg.get("full_experiment_name", self.name)
+        self.nn_dir = os.path.join(self.train_dir, self.experiment_name, "nn")
+        self.schedule_type = cfg.get("schedule_type", "legacy")
+        self.bounds_loss_coef = cfg.get("bounds_loss_coef", None)
+        self.normalize_input = False                                          # YG: only the central value normalises its input
+        self.dataset = _Dataset(self)
+        self.update_list = ["actions", "neglogpacs", "values", "mus", "sigmas"]
+        self.tensor_list = self.update_list + ["obses", "states", "dones"]
+        self._stats_off = {k: getattr(Ctrl, k).offset // 4 for k in ("acc", "last_kl", "ac_lr")}
         self.obs, self.dones = None, None
         self.curr_frames = self.batch_size
         self.experience_buffer = type("ExperienceBuffer", (), {})()
@@ -102,6 +143,59 @@ class A2CAgent:
     def get_action_values(self, obs, t=0):
         a = self.ppo.act(t, obs["obs"], obs["states"], self.dones)
         return {"actions": a}
+
+    def get_values(self, obs):
+        """RC:1725-1745: the central value of obs["states"], shape [N, 1]"""
+        return self.ppo.get_values(obs["states"]).unsqueeze(1)
+
+    def discount_values(self, fdones=None, last_extrinsic_values=None, mb_fdones=None, mb_extrinsic_values=None, mb_rewards=None):
+        """PS:331-336 on the library's own experience buffer (the mb_* arguments of rl_games are those buffers; passing different
+        tensors is not supported).  Returns the raw advantages in rl_games' [H, N, 1] orientation (a view of SDXP_T_ADVANTAGES)."""
+        t = self.ppo.t
+        for given, own in ((mb_fdones, t["MB_DONES"]), (mb_extrinsic_values, t["MB_VALUES"]), (mb_rewards, t["MB_REWARDS"])):
+            if given is not None and given.data_ptr() != own.data_ptr():
+                raise ValueError("discount_values works on the agent's own experience buffer")
+        lv = last_extrinsic_values.reshape(-1).contiguous()
+        ld = None if fdones is None else (fdones.reshape(-1) != 0).to(torch.int64)
+        self.ppo.discount_values(lv, ld)
+        return t["ADVANTAGES"].view(self.num_actors, self.horizon_length).t().unsqueeze(2)
+
+    def prepare_dataset(self, batch_dict=None):
+        """RC:1621-1683: advantage normalisation; the returns / values / actions of `batch_dict` are the library's buffers already.
+        Also opens the update phase (control block reset, central-value input normalisation for the epoch)."""
+        self.ppo.prepare_dataset()
+        self.ppo.backward(0, -1)
+
+    def train_central_value(self):
+        """fused into the actor-critic minibatch loop: the two optimisers never exchange data (RC:1323-1324), so running the
+        central-value step of minibatch i in the same launches as the actor-critic step of minibatch i changes no result"""
+        return 0.0
+
+    def train_actor_critic(self, input_dict):
+        return self.calc_gradients(input_dict)
+
+    def calc_gradients(self, input_dict):
+        """RC:1767-1877 for minibatch input_dict["mb_index"] (dataset[i]; minibatches must come in order): forward, losses,
+        backward, [all-reduce], clip, Adam, LR rule - for all three networks.  Returns rl_games' train_result tuple
+        (a_loss, c_loss, entropy, kl, last_lr, lr_mul, mu, sigma, b_loss) with device scalars (no host sync)."""
+        ppo, mb = self.ppo, int(input_dict["mb_index"])
+        ppo.backward(0, mb)
+        st = ppo.t["STATS"]
+        acc = st[self._stats_off["acc"]:self._stats_off["acc"] + 8].clone()    # per-minibatch sums of the HEAD kernel: [1]a [2]c [3]b [4]kl [6]entropy
+        if self.multi_gpu and self.rank_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(ppo.t["ALL_GRADS"])
+            ppo.apply(0, float("-inf"))
+        else:
+            ppo.apply(0)
+        ppo.apply(1)
+        n = float(self.minibatch_size)
+        lr = st[self._stats_off["ac_lr"]].clone()
+        return (acc[1] / n, acc[2] / n, acc[6] / n, acc[4] / n, lr, 1.0, input_dict["mu"], input_dict["sigma"], acc[3] / n)
+
+    def update_lr(self, lr):
+        self.ppo.set_state(ac_lr=float(lr))
+        self.last_lr = float(lr)
 
     def play_steps(self, deterministic=False):
         """PS:220-275 / RC:1394-1483: horizon loop; every call below is asynchronous on the current stream.  deterministic: zero noise
@@ -206,6 +300,16 @@ class A2CAgent:
                 fps_total = curr_frames / sum_time
                 print(f"fps step: {fps_step:.0f} fps step and policy inference: {fps_step_inference:.0f} "
                       f"fps total: {fps_total:.0f} epoch: {epoch_num}/{self.max_epochs}")
+            if self.rank == 0 and self.game_rewards.current_size > 0:      # A2CBase.train: periodic + best checkpoints (App. C)
+                mean_rewards = self.game_rewards.get_mean()[0]
+                name = "%s_ep_%d_rew_%s" % (self.name, epoch_num, mean_rewards)
+                if self.save_freq > 0 and epoch_num % self.save_freq == 0:
+                    os.makedirs(self.nn_dir, exist_ok=True)
+                    self.save(os.path.join(self.nn_dir, "last_" + name))
+                if mean_rewards > self.last_mean_rewards and epoch_num >= self.save_best_after:
+                    self.last_mean_rewards = mean_rewards
+                    os.makedirs(self.nn_dir, exist_ok=True)
+                    self.save(os.path.join(self.nn_dir, self.name))
             if epoch_num >= self.max_epochs:
                 return self.game_rewards.get_mean()[0], epoch_num
 
@@ -233,14 +337,28 @@ class A2CAgent:
         `assymetric_vf_nets` are named state_dicts (seqdex_amd/rlgames_checkpoint.py); the Adam moments are kept flat under `optimizer`
         (rl_games stores torch.optim state there, which only another rl_games process could consume)."""
         from .rlgames_checkpoint import rlgames_from_flat
-        t, c = self.ppo.t, self.ppo.ctrl()
+        t, st = self.ppo.t, self.ppo.get_state()
         cfg = self.ppo.cfg
+        obs_cols, state_cols = self._checkpoint_widths()
         model, vf = rlgames_from_flat(t["AC_PARAMS"], t["CV_PARAMS"], cfg.obs_dim, cfg.state_dim, cfg.act_dim, tuple(cfg.units),
-                                      t["CV_RMS_MEAN"], t["CV_RMS_VAR"], c.rms_count)
+                                      t["CV_RMS_MEAN"], t["CV_RMS_VAR"], st["rms_count"], obs_cols=obs_cols, state_cols=state_cols)
         return {"model": model, "assymetric_vf_nets": vf,
                 "optimizer": {"ac_m": t["AC_ADAM_M"].cpu(), "ac_v": t["AC_ADAM_V"].cpu(), "cv_m": t["CV_ADAM_M"].cpu(),
-                              "cv_v": t["CV_ADAM_V"].cpu(), "ac_t": c.ac_t, "cv_t": c.cv_t},
-                "epoch": self.epoch_num, "frame": self.frame, "last_mean_rewards": self.last_mean_rewards, "env_state": None}
+                              "cv_v": t["CV_ADAM_V"].cpu(), "ac_t": st["ac_t"], "cv_t": st["cv_t"], "cv_lr": st["cv_lr"]},
+                "epoch": self.epoch_num, "frame": self.frame, "last_mean_rewards": self.last_mean_rewards,
+                "last_lr": st["ac_lr"], "env_state": None}
+
+    def _checkpoint_widths(self):
+        """real input widths of the two networks: the library pads observation rows to a multiple of 4 (Orient / Search 186 -> 188)
+        and keeps 564-wide state rows for every task (InsertSim's one frame is 188 wide); rl_games' first layers have the real
+        widths, so checkpoints are written / read with them and the padded columns carry zero weights."""
+        cfg = self.ppo.cfg
+        obs_cols = cfg.obs_cols if cfg.obs_cols > 0 else cfg.obs_dim
+        task = getattr(getattr(self, "vec_env", None), "task", None)
+        state_cols = cfg.state_dim
+        if task is not None and getattr(task, "stack_obs", 3) == 1:
+            state_cols = int(getattr(task, "one_frame_num_states", cfg.state_dim))
+        return obs_cols, state_cols
 
     def save(self, fn):
         torch.save(self.get_full_state_weights(), fn + ".pth")
@@ -256,13 +374,13 @@ class A2CAgent:
             ac, cv = ck["model"]["ac_flat"], ck["model"]["cv_flat"]
             rms = (ck["running_mean_std"]["mean"], ck["running_mean_std"]["var"], None)
         else:
-            obs_cols = cfg.obs_cols if cfg.obs_cols > 0 else None
-            try:
+            obs_cols, state_cols = self._checkpoint_widths()
+            try:      # real widths first (what rl_games and save() write), then the library's padded widths (round-1 files)
                 ac, cv, rms = flat_from_rlgames(ck["model"], ck["assymetric_vf_nets"], cfg.obs_dim, cfg.state_dim, cfg.act_dim,
-                                                tuple(cfg.units))
+                                                tuple(cfg.units), obs_cols=obs_cols, state_cols=state_cols)
             except ValueError:
                 ac, cv, rms = flat_from_rlgames(ck["model"], ck["assymetric_vf_nets"], cfg.obs_dim, cfg.state_dim, cfg.act_dim,
-                                                tuple(cfg.units), obs_cols=obs_cols, state_cols=getattr(self, "state_cols", None))
+                                                tuple(cfg.units))
         t["AC_PARAMS"].copy_(ac); t["CV_PARAMS"].copy_(cv)
         if rms is not None:
             t["CV_RMS_MEAN"].copy_(rms[0]); t["CV_RMS_VAR"].copy_(rms[1])
@@ -270,4 +388,19 @@ class A2CAgent:
         if isinstance(opt, dict) and "ac_m" in opt:
             t["AC_ADAM_M"].copy_(opt["ac_m"]); t["AC_ADAM_V"].copy_(opt["ac_v"])
             t["CV_ADAM_M"].copy_(opt["cv_m"]); t["CV_ADAM_V"].copy_(opt["cv_v"])
+        # the rest of the optimiser state (rl_games restores all of it): running_mean_std.count, Adam step counters (bias-correction
+        # powers follow them), the adaptive learning rate
+        state = {}
+        if rms is not None and rms[2] is not None and float(rms[2]) > 0:
+            state["rms_count"] = float(rms[2])
+        if isinstance(opt, dict):
+            for k in ("ac_t", "cv_t", "cv_lr"):
+                if k in opt:
+                    state[k] = opt[k]
+        if "last_lr" in ck:
+            state["ac_lr"] = float(ck["last_lr"])
+            self.last_lr = float(ck["last_lr"])
+        if state:
+            self.ppo.set_state(**state)
         self.epoch_num, self.frame = ck.get("epoch", 0), ck.get("frame", 0)
+        self.last_mean_rewards = ck.get("last_mean_rewards", self.last_mean_rewards)

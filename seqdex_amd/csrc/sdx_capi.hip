@@ -168,7 +168,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(tv_succ, (size_t)SDX_TV_LOG_SLOTS * 4);
   ALLOC(tv_fail, (size_t)SDX_TV_LOG_SLOTS * 4);
   ALLOC(tv_count, 2);
-  B.pile_slots = scene->task_kind == 1 ? SDX_PILE_HARVEST_SLOTS : 1;
+  B.pile_slots = (scene->task_kind == 1 || scene->task_kind == 3) ? SDX_PILE_HARVEST_SLOTS : 1;   // Orient and Search harvest piles
   ALLOC(pile_harvest, (size_t)8 * B.pile_slots * SDX_NBRICK * 13);
   ALLOC(pile_harvest_count, 8);
   ALLOC(seg_stats, (size_t)N * 4);

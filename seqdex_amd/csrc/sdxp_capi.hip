@@ -379,6 +379,28 @@ extern "C" int sdxp_finish_rollout(sdxp_handle h, const float* last_states_dev, 
   return plaunch_ok(h, "sdxp_finish_rollout");
 }
 
+// The three stages of sdxp_finish_rollout as separate entry points, for callers that drive rl_games-style code themselves
+// (policy_sequencing/policy_seq_runner.py:329-343 calls get_values, discount_values and prepare_dataset one by one).
+extern "C" int sdxp_get_values(sdxp_handle h, const float* states_dev, float* values_out_dev, void* stream) {
+  if (!h || !states_dev || !values_out_dev) return SDX_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  trunk_forward(h, 2, states_dev, h->D.N, st);
+  sdxpk_value_head(&h->D, values_out_dev, st);
+  return plaunch_ok(h, "sdxp_get_values");
+}
+extern "C" void sdxpk_gae_only(const SdxpDev*, const float*, const int64_t*, hipStream_t);
+extern "C" void sdxpk_adv_norm(const SdxpDev*, hipStream_t);
+extern "C" int sdxp_discount_values(sdxp_handle h, const float* last_values_dev, const int64_t* last_dones_dev, void* stream) {
+  if (!h || !last_values_dev) return SDX_ERR_INVALID;
+  sdxpk_gae_only(&h->D, last_values_dev, last_dones_dev, (hipStream_t)stream);
+  return plaunch_ok(h, "sdxp_discount_values");
+}
+extern "C" int sdxp_prepare_dataset(sdxp_handle h, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  sdxpk_adv_norm(&h->D, (hipStream_t)stream);
+  return plaunch_ok(h, "sdxp_prepare_dataset");
+}
+
 extern "C" int sdxp_update(sdxp_handle h, void* stream) {
   if (!h) return SDX_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -552,6 +574,35 @@ extern "C" int sdxp_update_status(sdxp_handle h, void* stream) {
   h->err = "sdxp_update: the persistent update kernel timed out waiting for an exchange word (not all 256 workgroups co-resident?); "
            "nothing was applied, inputs restored; this handle now uses the hipGraph path - call sdxp_update again";
   return SDX_ERR_STATE;
+}
+// Optimiser state that lives in the device control block and that a checkpoint must carry besides the parameters and Adam moments
+// (rl_games restores all of it: optimizer.state_dict() holds the step counters, running_mean_std.count is part of the central-value
+// state_dict, last_lr is re-applied to the param groups).  Blocking.
+extern "C" int sdxp_get_state(sdxp_handle h, sdxp_opt_state* out, void* stream) {
+  if (!h || !out) return SDX_ERR_INVALID;
+  PCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  SdxpCtrl c;
+  PCHK(h, hipMemcpy(&c, h->D.ctrl, sizeof(c), hipMemcpyDeviceToHost));
+  out->rms_count = c.rms_count; out->ac_t = c.ac_t; out->cv_t = c.cv_t; out->ac_lr = c.ac_lr; out->cv_lr = c.cv_lr;
+  return SDX_OK;
+}
+extern "C" int sdxp_set_state(sdxp_handle h, const sdxp_opt_state* in, void* stream) {
+  if (!h || !in) return SDX_ERR_INVALID;
+  if (in->ac_t < 0 || in->cv_t < 0 || !(in->rms_count >= 0.0) || !(in->ac_lr > 0.0f) || !(in->cv_lr > 0.0f)) {
+    h->err = "sdxp_set_state: negative step counter / count or non-positive learning rate"; return SDX_ERR_INVALID;
+  }
+  PCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  SdxpCtrl c;
+  PCHK(h, hipMemcpy(&c, h->D.ctrl, sizeof(c), hipMemcpyDeviceToHost));
+  c.rms_count = in->rms_count;
+  c.ac_t = in->ac_t; c.cv_t = in->cv_t;
+  c.ac_lr = c.ac_lr_applied = in->ac_lr; c.cv_lr = c.cv_lr_applied = in->cv_lr;
+  c.ac_b1pow = std::pow(0.9, (double)in->ac_t); c.ac_b2pow = std::pow(0.999, (double)in->ac_t);
+  c.cv_b1pow = std::pow(0.9, (double)in->cv_t); c.cv_b2pow = std::pow(0.999, (double)in->cv_t);
+  c.ac_bc1 = in->ac_t ? (float)(1.0 - c.ac_b1pow) : 1.0f; c.ac_bc2 = in->ac_t ? (float)(1.0 - c.ac_b2pow) : 1.0f;
+  c.cv_bc1 = in->cv_t ? (float)(1.0 - c.cv_b1pow) : 1.0f; c.cv_bc2 = in->cv_t ? (float)(1.0 - c.cv_b2pow) : 1.0f;
+  PCHK(h, hipMemcpy(h->D.ctrl, &c, sizeof(c), hipMemcpyHostToDevice));
+  return SDX_OK;
 }
 extern "C" int sdxp_update_impl(sdxp_handle h) { return !h ? 0 : (h->big ? 2 : (h->use_persist ? 1 : 0)); }
 

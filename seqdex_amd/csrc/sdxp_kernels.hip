@@ -902,8 +902,10 @@ __global__ void k_cv_prenorm(SdxpDev D) {
       dst[((size_t)mb * MB + s) * S + k] = D.cv_normalize_input ? clampf((x[s] - fm) / rs, -5.0f, 5.0f) : x[s];
   }
   D.rms_mean[k] = mean; D.rms_var[k] = var;
-  if (k == 0 && D.cv_normalize_input) D.ctrl->rms_count = cnt;
+  // rms_count is advanced by k_cv_rms_count AFTER this launch: every block of this grid reads the starting count above, and no
+  // ordering exists between the blocks of one launch
 }
+__global__ void k_cv_rms_count(SdxpDev D, int rows) { if (D.cv_normalize_input) D.ctrl->rms_count += (double)rows; }
 // mini-epochs >= 1: statistics frozen at their end-of-mini-epoch-0 values -> cvx1 (one thread per element)
 __global__ __launch_bounds__(256) void k_cv_prenorm_frozen(SdxpDev D) {
   const int S = D.state_dim;
@@ -1170,6 +1172,12 @@ extern "C" void sdxpk_store_rewards(const SdxpDev* D, int t, const float* rew, c
 extern "C" void sdxpk_value_head(const SdxpDev* D, float* out, hipStream_t st) {
   hipLaunchKernelGGL(k_value_head, dim3(D->N), dim3(64), 0, st, *D, out);
 }
+extern "C" void sdxpk_gae_only(const SdxpDev* D, const float* last_values, const int64_t* last_dones, hipStream_t st) {
+  hipLaunchKernelGGL(k_gae, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, last_values, last_dones);
+}
+extern "C" void sdxpk_adv_norm(const SdxpDev* D, hipStream_t st) {
+  if (D->normalize_advantage) hipLaunchKernelGGL(k_adv_norm, dim3(1), dim3(1024), 0, st, *D);
+}
 extern "C" void sdxpk_gae(const SdxpDev* D, const float* last_values, const int64_t* last_dones, hipStream_t st) {
   hipLaunchKernelGGL(k_gae, dim3((D->N + 255) / 256), dim3(256), 0, st, *D, last_values, last_dones);
   if (D->normalize_advantage) hipLaunchKernelGGL(k_adv_norm, dim3(1), dim3(1024), 0, st, *D);
@@ -1226,6 +1234,7 @@ extern "C" int sdxpk_update_step(const SdxpDev* D, int mb_size, hipStream_t st) 
 // begin of an epoch's update phase: central-value pre-normalisation for all minibatches + cursor/accumulator reset
 extern "C" int sdxpk_update_begin(const SdxpDev* D, int mb_size, hipStream_t st) {
 #define C_(M) hipLaunchKernelGGL(k_cv_prenorm<M>, dim3((D->state_dim + 63) / 64), dim3(64), 0, st, *D); \
+              hipLaunchKernelGGL(k_cv_rms_count, dim3(1), dim3(1), 0, st, *D, D->num_minibatches * M); \
               hipLaunchKernelGGL(k_cv_prenorm_frozen, dim3(1024), dim3(256), 0, st, *D); \
               hipLaunchKernelGGL(k_ctrl<M>, dim3(1), dim3(1024), 0, st, *D, 2)
   MB_SWITCH(mb_size, C_)
@@ -1233,6 +1242,7 @@ extern "C" int sdxpk_update_begin(const SdxpDev* D, int mb_size, hipStream_t st)
 }
 extern "C" int sdxpk_prenorm(const SdxpDev* D, int mb_size, hipStream_t st) {
 #define C_(M) hipLaunchKernelGGL(k_cv_prenorm<M>, dim3((D->state_dim + 63) / 64), dim3(64), 0, st, *D); \
+              hipLaunchKernelGGL(k_cv_rms_count, dim3(1), dim3(1), 0, st, *D, D->num_minibatches * M); \
               hipLaunchKernelGGL(k_cv_prenorm_frozen, dim3(1024), dim3(256), 0, st, *D)
   MB_SWITCH(mb_size, C_)
 #undef C_

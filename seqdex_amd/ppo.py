@@ -102,6 +102,22 @@ class SdxPPO:
         self._check(self.lib.sdxp_finish_rollout(self.h, self._p(last_states), self._p(last_dones, torch.int64),
                                                  _stream_ptr(self.device)))
 
+    def get_values(self, states, out=None):
+        """central value of `states` [N, state_dim] -> f32 [N] (sdxp_get_values)"""
+        if out is None:
+            out = torch.empty(self.num_actors, device=self.device)
+        self._check(self.lib.sdxp_get_values(self.h, self._p(states), self._p(out), _stream_ptr(self.device)))
+        return out
+
+    def discount_values(self, last_values, last_dones=None):
+        """GAE over the experience buffer (PS:331-336): raw advantages -> t["ADVANTAGES"], returns -> t["RETURNS"]"""
+        self._check(self.lib.sdxp_discount_values(self.h, self._p(last_values), self._p(last_dones, torch.int64),
+                                                  _stream_ptr(self.device)))
+
+    def prepare_dataset(self):
+        """advantage normalisation in place (RC:1645-1651)"""
+        self._check(self.lib.sdxp_prepare_dataset(self.h, _stream_ptr(self.device)))
+
     def update(self):
         self._check(self.lib.sdxp_update(self.h, _stream_ptr(self.device)))
 
@@ -150,6 +166,21 @@ class SdxPPO:
     def ctrl(self):
         raw = self.t["STATS"].cpu().numpy().tobytes()
         return Ctrl.from_buffer_copy(raw[:C.sizeof(Ctrl)])
+
+    def get_state(self):
+        """optimiser state of the control block: dict(rms_count, ac_t, cv_t, ac_lr, cv_lr) (sdxp_get_state; blocking)"""
+        st = _abi.OptState()
+        self._check(self.lib.sdxp_get_state(self.h, C.byref(st), _stream_ptr(self.device)))
+        return dict(rms_count=st.rms_count, ac_t=st.ac_t, cv_t=st.cv_t, ac_lr=st.ac_lr, cv_lr=st.cv_lr)
+
+    def set_state(self, rms_count=None, ac_t=None, cv_t=None, ac_lr=None, cv_lr=None):
+        """write the given items back (the others keep their current values); bias-correction powers follow the step counters"""
+        cur = self.get_state()
+        for k, v in dict(rms_count=rms_count, ac_t=ac_t, cv_t=cv_t, ac_lr=ac_lr, cv_lr=cv_lr).items():
+            if v is not None:
+                cur[k] = v
+        st = _abi.OptState(float(cur["rms_count"]), int(cur["ac_t"]), int(cur["cv_t"]), float(cur["ac_lr"]), float(cur["cv_lr"]))
+        self._check(self.lib.sdxp_set_state(self.h, C.byref(st), _stream_ptr(self.device)))
 
     def param_count(self, which=0):
         return int(self.lib.sdxp_param_count(self.h, which))

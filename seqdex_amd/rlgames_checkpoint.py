@@ -23,10 +23,13 @@ def _layers(in_dim, units):
 
 
 def rlgames_from_flat(ac_flat, cv_flat, obs_dim, state_dim, act_dim=23, units=(1024, 512, 256), rms_mean=None, rms_var=None,
-                      rms_count=None):
-    """flat actor-critic / central-value parameter vectors -> (model_state_dict, assymetric_vf_nets_state_dict)"""
+                      rms_count=None, obs_cols=None, state_cols=None):
+    """flat actor-critic / central-value parameter vectors -> (model_state_dict, assymetric_vf_nets_state_dict).  obs_cols /
+    state_cols: the real input widths when the library pads its network inputs (see flat_from_rlgames): first-layer weights and
+    the running statistics are cut to them, so rl_games can load the file for that task."""
     ac, cv = torch.as_tensor(ac_flat).float().cpu(), torch.as_tensor(cv_flat).float().cpu()
     model, o = {}, 0
+    obs_cols, state_cols = obs_cols or obs_dim, state_cols or state_dim
 
     def take(buf, off, shape):
         n = int(np.prod(shape))
@@ -44,6 +47,8 @@ def rlgames_from_flat(ac_flat, cv_flat, obs_dim, state_dim, act_dim=23, units=(1
     model["a2c_network.value.weight"], o = take(ac, o, (1, units[-1]))
     model["a2c_network.value.bias"], o = take(ac, o, (1,))
     assert o == ac.numel(), (o, ac.numel())
+    for k in ("a2c_network.actor_mlp.0.weight", "a2c_network.critic_mlp.0.weight"):
+        model[k] = model[k][:, :obs_cols].clone()
     vf, o = {}, 0
     for i, (out, inn) in enumerate(_layers(state_dim, units)):
         vf["model.a2c_network.critic_mlp.%d.weight" % (2 * i)], o = take(cv, o, (out, inn))
@@ -51,9 +56,10 @@ def rlgames_from_flat(ac_flat, cv_flat, obs_dim, state_dim, act_dim=23, units=(1
     vf["model.a2c_network.value.weight"], o = take(cv, o, (1, units[-1]))
     vf["model.a2c_network.value.bias"], o = take(cv, o, (1,))
     assert o == cv.numel(), (o, cv.numel())
+    vf["model.a2c_network.critic_mlp.0.weight"] = vf["model.a2c_network.critic_mlp.0.weight"][:, :state_cols].clone()
     if rms_mean is not None:
-        vf["running_mean_std.running_mean"] = torch.as_tensor(rms_mean).double().cpu().clone()
-        vf["running_mean_std.running_var"] = torch.as_tensor(rms_var).double().cpu().clone()
+        vf["running_mean_std.running_mean"] = torch.as_tensor(rms_mean).double().cpu()[:state_cols].clone()
+        vf["running_mean_std.running_var"] = torch.as_tensor(rms_var).double().cpu()[:state_cols].clone()
         vf["running_mean_std.count"] = torch.tensor(float(rms_count if rms_count is not None else 0.0), dtype=torch.float64)
     return model, vf
 

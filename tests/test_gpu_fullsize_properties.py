@@ -299,5 +299,18 @@ def test_checkpoint_round_trip_in_rlgames_layout(tmp_path):
         for k in ("AC_PARAMS", "CV_PARAMS", "AC_ADAM_M", "AC_ADAM_V", "CV_ADAM_M", "CV_ADAM_V", "CV_RMS_MEAN", "CV_RMS_VAR"):
             np.testing.assert_array_equal(a.t[k].cpu().numpy(), b.t[k].cpu().numpy(), err_msg=k)
         assert bg.epoch_num == 3 and bg.frame == 384
+        # the rest of the optimiser state: RunningMeanStd.count, Adam step counters (+ bias-correction powers), adaptive LR
+        ca, cb = a.ctrl(), b.ctrl()
+        assert ca.ac_t > 0 and ca.rms_count > 1.0
+        assert cb.rms_count == ca.rms_count and cb.ac_t == ca.ac_t and cb.cv_t == ca.cv_t
+        assert cb.ac_lr == ca.ac_lr and cb.cv_lr == ca.cv_lr and bg.last_lr == ca.ac_lr
+        assert abs(cb.ac_b1pow - 0.9 ** ca.ac_t) < 1e-12 and abs(cb.cv_b2pow - 0.999 ** ca.cv_t) < 1e-12
+        # and the next epoch continues identically on both handles (same data rows)
+        for k in ("MB_OBS", "MB_STATES", "MB_ACTIONS", "MB_MUS", "MB_SIGMAS", "MB_NEGLOGP", "MB_VALUES", "RETURNS", "ADVANTAGES"):
+            b.t[k].copy_(a.t[k])
+        a.update(); b.update()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(a.t["AC_PARAMS"].cpu().numpy(), b.t["AC_PARAMS"].cpu().numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(a.t["CV_PARAMS"].cpu().numpy(), b.t["CV_PARAMS"].cpu().numpy(), rtol=0, atol=1e-6)
     finally:
         a.close(); b.close()

@@ -116,3 +116,16 @@ def test_rlgames_checkpoint_layout_round_trip():
     acp, _, _ = flat_from_rlgames(m186, v188, 188, 564, obs_cols=186)
     w0 = acp[:1024 * 188].reshape(1024, 188)
     assert torch.equal(w0[:, :186], m186["a2c_network.actor_mlp.0.weight"]) and not w0[:, 186:].any()
+    # saving from the library's padded widths cuts the first layers and the running statistics to the real ones (what rl_games
+    # builds for that task: Orient obs 186, InsertSim states 188) and loading such a file zero-fills the padded columns again
+    acp188 = torch.randn(2131503 - 2 * 1024 * 208, generator=g)
+    mo, vo = rlgames_from_flat(acp188, cv, 188, 564, rms_mean=torch.arange(564.0), rms_var=torch.ones(564), rms_count=5.0,
+                               obs_cols=186, state_cols=188)
+    assert tuple(mo["a2c_network.actor_mlp.0.weight"].shape) == (1024, 186) and tuple(mo["a2c_network.critic_mlp.0.weight"].shape) == (1024, 186)
+    assert tuple(vo["model.a2c_network.critic_mlp.0.weight"].shape) == (1024, 188) and vo["running_mean_std.running_mean"].numel() == 188
+    ac3, cv3, rms3 = flat_from_rlgames(mo, vo, 188, 564, obs_cols=186, state_cols=188)
+    w3 = ac3[:1024 * 188].reshape(1024, 188)
+    assert torch.equal(w3[:, :186], acp188[:1024 * 188].reshape(1024, 188)[:, :186]) and not w3[:, 186:].any()
+    c3 = cv3[:1024 * 564].reshape(1024, 564)
+    assert torch.equal(c3[:, :188], cv[:1024 * 564].reshape(1024, 564)[:, :188]) and not c3[:, 188:].any()
+    assert rms3[2] == 5.0 and torch.equal(rms3[0][:188], torch.arange(188.0).double()) and not rms3[0][188:].any()
