@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "sdx_common.h"
+#include "sdx_const_build.h"
 
 extern "C" {
 void sdxk_pre_physics(const SdxConst*, const SdxBuf*, const float*, const uint8_t*, const int32_t*, int, hipStream_t);
@@ -92,27 +93,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   const int N = num_envs;
   // ---- constants + derived tables
   SdxConst& K = h->h_const;
-  memset(&K, 0, sizeof(K));
-  K.sc = *scene;
-  K.max_depth = 0;
-  for (int k = 0; k < SDX_NLINK; ++k) {
-    const int p = scene->parent[k];
-    K.anc[k] = (k == 0) ? 0u : (K.anc[p] | (1u << (k - 1)));
-    K.depth[k] = (k == 0) ? 0 : K.depth[p] + 1;
-    if (K.depth[k] > K.max_depth) K.max_depth = K.depth[k];
-  }
-  for (int t = 0; t < SDX_NBRICK_TYPES; ++t) {
-    const float* hh = scene->brick_half[t];
-    K.brick_radius[t] = sqrtf(hh[0] * hh[0] + hh[1] * hh[1] + hh[2] * hh[2]);
-  }
-  for (int r = 0; r < scene->n_rbox; ++r) {
-    const float* hh = scene->rbox_half[r];
-    K.rbox_radius[r] = sqrtf(hh[0] * hh[0] + hh[1] * hh[1] + hh[2] * hh[2]);
-  }
-  for (int j = 0; j < SDX_NDOF; ++j) {
-    if (j < 7) K.hand_reset_pose[j] = scene->arm_prepare_pose[j];
-    else K.hand_reset_pose[j] = 0.5f * (scene->finger_reset_unscaled[j - 7] + 1.0f) * (scene->upper[j] - scene->lower[j]) + scene->lower[j];
-  }
+  sdx_build_const(scene, &K);
   int rc;
   if ((rc = dalloc(h, &h->d_const, 1)) != SDX_OK) { g_create_err = h->err; delete h; return rc; }
   HIPCHK(h, hipMemcpy(h->d_const, &K, sizeof(K), hipMemcpyHostToDevice));

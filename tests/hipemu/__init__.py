@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE ONLY: builds the product's HIP kernel SOURCES with g++ against a small SIMT emulator (one fiber per GPU
+thread, wave collectives resolved per call site; tests/hipemu/include/hip/hip_runtime.h) and runs them on the CPU, so that kernel
+logic can be checked against the oracles in the `-m "not gpu"` suite.  Nothing under seqdex_amd/ uses this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "seqdex_amd", "csrc")
+_SO = os.path.join(HERE, "libsdx_emu.so")
+_SRCS = [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "physics_driver.cpp"), os.path.join(CSRC, "sdx_physics.hip")]
+_DEPS = _SRCS + [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(CSRC, "sdx_common.h"),
+                 os.path.join(CSRC, "sdx_const_build.h"), os.path.join(ROOT, "include", "seqdex.h")]
+_lib = None
+
+
+def build(force=False):
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in _DEPS):
+        return _SO
+    objs = []
+    for src in _SRCS:
+        obj = os.path.join(HERE, os.path.basename(src) + ".emu.o")
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-w", "-x", "c++",
+                               "-I", os.path.join(HERE, "include"), "-I", CSRC, "-c", src, "-o", obj])
+        objs.append(obj)
+    subprocess.check_call(["g++", "-shared", "-o", _SO] + objs)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.emu_simulate.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def simulate(desc, root, dof, targets):
+    """same contract as oracle.physics_oracle.simulate, executed by the emulated k_physics"""
+    n = root.shape[0]
+    assert root.dtype == np.float32 and root.flags.c_contiguous and dof.flags.c_contiguous
+    rb = np.zeros((n, 165, 13), np.float32)
+    contact = np.zeros((n, 165, 3), np.float32)
+    jac = np.zeros((n, 6, 7), np.float32)
+    nc = np.zeros(n, np.int32)
+    tg = np.ascontiguousarray(targets, np.float32)
+    lib().emu_simulate(C.byref(desc), C.c_int(n), _p(root), _p(dof), _p(tg), _p(rb), _p(contact), _p(jac), _p(nc), None)
+    return rb, contact, jac, nc

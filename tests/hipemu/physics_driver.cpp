@@ -1,0 +1,39 @@
+// TEST INFRASTRUCTURE ONLY: runs seqdex_amd/csrc/sdx_physics.hip (the product's kernel source, compiled by g++ against the SIMT
+// emulator) for N envs on the CPU.  Same argument layout as oracle/physics_oracle.c::sdxo_simulate so that the two can be compared.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sdx_common.h"
+#include "sdx_const_build.h"
+
+extern "C" void sdxk_physics(const SdxConst* C, const SdxBuf* B, hipStream_t st);
+extern "C" void sdxk_kinematics(const SdxConst* C, const SdxBuf* B, hipStream_t st);
+extern "C" size_t sdxk_physics_lds_bytes();
+
+extern "C" int emu_simulate(const sdx_scene_desc* sc, int N, float* root, float* dof, const float* targets, float* rb, float* contact,
+                            float* jac, int* ncontacts, long long* dbg) {
+  static SdxConst K;
+  sdx_build_const(sc, &K);
+  SdxBuf B;
+  memset(&B, 0, sizeof(B));
+  B.N = N; B.K = 1; B.task_kind = sc->task_kind; B.obs_w = SDX_NUM_OBS;
+  B.root = root; B.dof = dof; B.targets = const_cast<float*>(targets); B.rb = rb; B.contact = contact; B.jac = jac;
+  B.ncontacts = ncontacts;
+  std::vector<long long> d(64, 0);
+  B.dbg = dbg ? dbg : d.data();
+  sdxk_physics(&K, &B, nullptr);
+  return (int)sdxk_physics_lds_bytes();
+}
+extern "C" void emu_kinematics(const sdx_scene_desc* sc, int N, float* dof, float* rb, float* jac) {
+  static SdxConst K;
+  sdx_build_const(sc, &K);
+  SdxBuf B;
+  memset(&B, 0, sizeof(B));
+  B.N = N; B.dof = dof; B.rb = rb; B.jac = jac;
+  std::vector<long long> d(64, 0);
+  B.dbg = d.data();
+  sdxk_kinematics(&K, &B, nullptr);
+}
