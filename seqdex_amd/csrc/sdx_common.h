@@ -8,6 +8,9 @@
 #define SDX_WAVE 64
 #define SDX_MAXC 1536        // contact points per env = 3 rows per lane x 512 lanes of k_physics
 #define SDX_MAXP 1024        // candidate box pairs per env (LDS)
+#ifndef SDX_PHYS_NT_DEFAULT
+#define SDX_PHYS_NT_DEFAULT 512   // threads per env of k_physics (384 or 512; SDX_PHYS_NT overrides at run time)
+#endif
 #define SDX_CFIELDS 17       // ab, p3, n3, sep, lam3, wA3, wB3
 #define SDX_NSAMP 28
 #define SDX_BODY_STATIC 255
@@ -54,6 +57,7 @@ struct SdxBuf {
   int32_t pile_slots;
   float *tv_succ, *tv_fail;   // [SDX_TV_LOG_SLOTS,4] camera-frame target quaternions logged at episode ends (T-value datasets)
   int32_t* tv_count;       // [2] rows logged: success, failure
+  float* jac_full;         // [N,23,6,23] or nullptr: the whole-hand Jacobian (GS:241), written by k_kinematics only
   float* insert_aux;       // [N,8] InsertSim: 0..2 rot_err of the last pre_physics_step (IS:1539), 3 |brick - site|, 4 rot_dist
 };
 

@@ -1,26 +1,47 @@
-// sdx_physics.hip — the per-env physics step (kernels K3/K4/K5), one wavefront
-// per env, state tiled in LDS, contact rows in an L2/MALL-resident SoA scratch (coalesced, lane = contact).
+// sdx_physics.hip — the per-env physics step: one workgroup per env, TWO workgroups resident per CU.
 //
-// Replaces gym.simulate()/fetch_results() (BT:138-144) and the refresh_* calls (GS:1091-1095) of the
-// reference, whose arithmetic lives in the closed Isaac Gym / PhysX binary.  The step is OUR definition
-// ("SDX-1"), restated independently in plain C in oracle/physics_oracle.c:
-//   A FK  B joint-space inertia + implicit-PD matrix, Cholesky inverse  C implicit PD drive, gravity
+// Replaces gym.simulate()/fetch_results() (BT:138-144) and the refresh_* calls (GS:1091-1095) of the reference, whose arithmetic
+// lives in the closed Isaac Gym / PhysX binary.  The step is OUR definition ("SDX-1"), restated independently in
+// plain C in oracle/physics_oracle.c:
+//   A FK  B joint-space inertia + implicit-PD matrix, Cholesky inverse  C implicit PD drive, velocity-product terms, gravity
 //   D sampled-SDF box/box contacts (<= 4 per pair)  E active-set mass-split Jacobi on accumulated impulses
 //   F semi-implicit Euler;  then outputs: rigid-body states, end-effector Jacobian, net arm contact forces.
 //
-// Workgroup structure: one workgroup of 4 wavefronts (256 lanes) per env; "lane = link / dof / brick / matrix entry /
-// candidate pair / contact" in turn; every phase is a lane-strided loop separated by workgroup barriers.  Each lane
-// OWNS up to CPT = 5 contact rows (contact c belongs to lane c % 256): their geometry, effective masses and
-// accumulated impulses stay in VGPRs across all solver iterations, so the iteration loop touches only LDS.
+// Shape of the kernel (round 2; the round-1 kernel ran one 512-thread workgroup per CU at 256 VGPRs and spent 68 % of its
+// wave-cycles parked at barriers, profiles/r1_bench_pmc_sq_v3.csv):
+//   * NT threads per env, NT = 384 (6 waves, <= 168 VGPRs) or 512 (8 waves, <= 128 VGPRs): either way two workgroups share a CU
+//     (LDS <= 80 KiB each), so one env's barrier / latency phases overlap the other env's arithmetic;
+//   * contact geometry (point, normal) stays in LDS; each lane keeps only what changes or divides per iteration for its CPT
+//     contacts in registers (accumulated impulses, un-split inverse masses of both sides, separation, body ids);
+//   * per solver iteration: [A] relative velocity + active flag, ACTIVE counts per body by integer LDS atomics (deterministic)
+//     | barrier | [C] Jacobi update, impulse to LDS | barrier | [D] CSR gather per brick (4 lanes each) and per robot dof
+//     (walking the ordered robot-side list) | barrier | robot only: wave 0 applies Hinv and rebuilds the link twists | barrier;
+//   * everything serial (FK levels, Cholesky, drive, twists) runs on wave 0 with wave-synchronous LDS hand-offs instead of
+//     workgroup barriers; the other waves meet it at the next barrier;
+//   * broadphase: every lane tests its strided candidates into a bit mask, ONE block scan places all hits.
+#include <stdlib.h>
+
 #include "sdx_common.h"
 
-#define NT 512
-#define NWAVE (NT / 64)
-#define CPT ((SDX_MAXC + NT - 1) / NT)   // contact rows owned by one lane
 #define NL SDX_NLINK
 #define ND SDX_NDOF
 #define NF SDX_NFREE
-#define HP 24  // padded row stride of the 23x23 matrices in LDS
+#define HP 24                 // padded row stride of the 23x23 matrices in LDS
+#define MAXC SDX_MAXC
+#define MAXP SDX_MAXP
+#define GL 4                  // gather lanes per brick
+#define NBODY (NF + NL + 1)   // bricks, links, the static world
+#define BODY_W (NF + NL)      // body id of the static world inside the kernel (SDX_BODY_STATIC = 255 outside)
+// link frame origins / twists are rows NF.. of the body table: S.bp[NF + k], S.bv[NF + k], S.bw[NF + k]
+
+// LDS written by one lane and read by another lane of the SAME wave without a workgroup barrier: the wave runs in lockstep and the
+// LDS executes one wave's operations in order, so only the compiler must be kept from moving accesses across this point
+#define WAVE_SYNC()                                         \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+  } while (0)
 
 __constant__ float c_samp[SDX_NSAMP][3] = {
     {-1, -1, -1}, {1, -1, -1}, {-1, 1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1},
@@ -29,43 +50,45 @@ __constant__ float c_samp[SDX_NSAMP][3] = {
     {-0.5f, -1, -1}, {0.5f, -1, -1}, {-0.5f, 1, -1}, {0.5f, 1, -1}, {-0.5f, -1, 1}, {0.5f, -1, 1}, {-0.5f, 1, 1}, {0.5f, 1, 1}};
 
 struct PhysLds {
+  // robot
   float q[ND], qd[ND], tgt[ND], qds[ND], Q[ND], tau[ND];
-  float lq[NL][4], lp[NL][3], la[NL][3], lc[NL][3], lv[NL][3], lw[NL][3], lI[NL][6];
+  float lq[NL][4], la[NL][3], lc[NL][3], lI[NL][6];
   float lal[NL][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
-  float A[ND][HP];   // H -> L -> Hinv
-  float bp[NF][3], bq[NF][4], bv[NF][3], bw[NF][3], dv[NF][3], dw[NF][3];
-  int bcount[NF];
-  int rcount, nc, np, overflow;
-  float rc[SDX_MAX_RBOX][3], rq[SDX_MAX_RBOX][4];
-  uint32_t pairs[SDX_MAXP];
-  int wsum[NWAVE];       // per-wave totals for block-level scans
+  float A[ND][HP];      // H -> L -> Hinv
+  uint32_t anc[NL];     // bit j: dof j lies on the path base -> link
   float cf[NL][3];
-  int nrobot;            // contact rows touching the robot in this substep
-  int seg_brick;         // this env's target brick (its mass and inertia carry sc.seg_mass_scale)
-  float sincos[NL][2];   // sin/cos of half the joint angle, computed for all joints at once
-  // contact staging [8][SDX_MAXC] written by the narrowphase (ab, p3, n3, sep); after the rows are in registers the
-  // same area is reused by the solver for the per-contact impulse P (3) and moment p x P (3)
-  float stage[8][SDX_MAXC];
-  unsigned char act[SDX_MAXC];
-  unsigned short ent[2 * SDX_MAXC];   // CSR entries: contact index | side << 15, grouped by brick, ascending contact index
-  int eoff[NF + 1];
-  int efill[NF];
-  // robot-side contact sides: contact index | side << 15, ascending (contact, side) order, and the link each one touches
-  unsigned short rent[SDX_MAXC];
-  unsigned char rlink[SDX_MAXC];
-  int rfill;
+  // bricks (centre-of-box frame) and their per-brick constants
+  // position / linear / angular velocity of EVERY body in one table: bricks 0..71 (centre of the box), links 72..95 (frame origin),
+  // entry 96 = the static world (zeros): the solver's point velocities need no case distinction
+  float bp[NBODY][3], bv[NBODY][3], bw[NBODY][3];
+  float bq[NF][4];
+  float bh[NF][3], brad[NF];
+  float bim[NF], bii[NF][3];   // inverse mass / inverse principal inertia (target brick already scaled by 1 / seg_mass_scale)
+  // robot collision boxes in the world
+  float rc[SDX_MAX_RBOX][3], rq[SDX_MAX_RBOX][4], rh[SDX_MAX_RBOX][3], rrad[SDX_MAX_RBOX];
+  int rbl[SDX_MAX_RBOX];
+  float sth[SDX_MAX_STATIC][3], stc[SDX_MAX_STATIC][3];   // static boxes as THIS env sees them
+  int bcount[NF + 2];   // entries per brick (CSR build), then per iteration: ACTIVE contacts per brick, [NF] on the robot, [NF + 1] = 0 (static world)
+  int nc, np, overflow, nrobot, rfill, seg_brick, pad0;
+  int eoff[NF + 1], efill[NF];
+  int wsum[16];
+  // contacts: geometry in LDS for the whole solve
+  float cp[3][MAXC], cn[3][MAXC];
+  // three rows that are, in turn: the narrowphase's staging of (separation, body ids) + the candidate pair list; L^-1 of the mass
+  // matrix; the unsorted CSR fill order during the solver set-up; and the per-contact impulse P of the current iteration
+  float P[3][MAXC];
+  unsigned short ent[2 * MAXC];   // CSR entries: contact index | side << 15, grouped by brick, ascending contact index
+  unsigned short rent[MAXC];      // robot-side contact sides in ascending (contact, side) order
+  unsigned char rlink[MAXC];      // ... and the link each one touches
 };
-
-// Scratch that lives inside the contact staging area while those rows are dead (keeps PhysLds under 80 KiB, the LDS half of what two
-// workgroups per CU would need; the register half does not fit yet: at the 128-VGPR budget of 4 waves/SIMD the solver's contact
-// rows spill 640 B/lane and a launch gets 5 % SLOWER (2.15 vs 2.05 ms at N = 1024), so the kernel stays at 256 VGPRs, 1 workgroup/CU):
-//   L^-1 of the mass-matrix inversion (substep 0, before the narrowphase writes the staging rows)            -> stage[0]
-//   unsorted CSR fill order of the brick sides / robot sides (rank pass; rows 6 (n.z) and 7 (sep) are in registers by then and
-//   the solver reuses only rows 0..5)                                                                        -> stage[6], stage[7]
-#define S_T(S) (reinterpret_cast<float (*)[HP]>(&(S).stage[0][0]))
-#define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).stage[6][0]))
-#define S_RENT2(S) (reinterpret_cast<unsigned short*>(&(S).stage[7][0]))
-static_assert(ND * HP <= SDX_MAXC, "L^-1 must fit one staging row");
+#define S_T(S) (reinterpret_cast<float (*)[HP]>(&(S).P[0][0]))                       // L^-1 (mass matrix phase)
+#define S_PAIRS(S) (reinterpret_cast<uint32_t*>(&(S).P[2][0]))                       // candidate pairs (collide)
+#define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[0][0]))                  // unsorted brick-side entries (solver set-up)
+#define S_RENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[1][0]))                 // unsorted robot-side entries
+#define S_RLINK2(S) (reinterpret_cast<unsigned char*>(&(S).P[2][0]))                 // ... and the links they touch
+static_assert(ND * HP <= MAXC, "L^-1 must fit one row");
+static_assert(MAXP <= MAXC, "the pair list must fit one row");
+static_assert(sizeof(PhysLds) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
 
 struct Box { f3 c; f4 q; f3 h; };
 #define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && sub == 0) B.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -102,35 +125,24 @@ __device__ __forceinline__ void tangents(f3 n, f3* t1, f3* t2) {
   *t2 = cross(n, t);
 }
 
-// static box s of env blockIdx.x: InsertSim's base plate has one of three heights by env % 3 (sdx_scene_desc.static_var_*)
-__device__ __forceinline__ void static_box(const sdx_scene_desc& sc, int s, f3* c, f3* h) {
-  *c = ld3(sc.static_center[s]);
-  *h = ld3(sc.static_half[s]);
-  if (s == sc.static_var_slot) {
-    const int k = (int)(blockIdx.x % 3u);
-    c->z = sc.static_var_center_z[k];
-    h->z = sc.static_var_half_z[k];
-  }
-}
 // box id: 0..71 brick, 72..103 robot box, 128.. static
-__device__ __forceinline__ Box load_box(const SdxConst* C, const PhysLds& S, int id) {
-  const sdx_scene_desc& sc = C->sc;
+__device__ __forceinline__ Box load_box(const PhysLds& S, int id) {
   Box b;
   if (id < NF) {
-    b.c = ld3(S.bp[id]); b.q = ld4(S.bq[id]); b.h = ld3(sc.brick_half[sc.brick_type[id]]);
+    b.c = ld3(S.bp[id]); b.q = ld4(S.bq[id]); b.h = ld3(S.bh[id]);
   } else if (id < 128) {
     const int r = id - NF;
-    b.c = ld3(S.rc[r]); b.q = ld4(S.rq[r]); b.h = ld3(sc.rbox_half[r]);
+    b.c = ld3(S.rc[r]); b.q = ld4(S.rq[r]); b.h = ld3(S.rh[r]);
   } else {
     const int s = id - 128;
-    static_box(sc, s, &b.c, &b.h); b.q.x = 0; b.q.y = 0; b.q.z = 0; b.q.w = 1;
+    b.c = ld3(S.stc[s]); b.h = ld3(S.sth[s]); b.q.x = 0; b.q.y = 0; b.q.z = 0; b.q.w = 1;
   }
   return b;
 }
-__device__ __forceinline__ int box_body(const SdxConst* C, int id) {
+__device__ __forceinline__ int box_body(const PhysLds& S, int id) {
   if (id < NF) return id;
-  if (id < 128) return NF + C->sc.rbox_link[id - NF];
-  return SDX_BODY_STATIC;
+  if (id < 128) return NF + S.rbl[id - NF];
+  return BODY_W;
 }
 
 // samples of A against the SDF of B; returns count (<=4), indices packed 8 bits each
@@ -149,21 +161,13 @@ __device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off,
   return cnt;
 }
 
-__device__ __forceinline__ void cwrite(float (*cs)[SDX_MAXC], int c, int a, int b, f3 p, f3 n, float sep) {
-  cs[0][c] = __int_as_float(a | (b << 8));
-  cs[1][c] = p.x; cs[2][c] = p.y; cs[3][c] = p.z;
-  cs[4][c] = n.x; cs[5][c] = n.y; cs[6][c] = n.z;
-  cs[7][c] = sep;
-}
-
-__device__ __forceinline__ void emit_dir(const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k,
-                                         float (*cs)[SDX_MAXC], int base) {
+__device__ __forceinline__ void emit_dir(PhysLds& S, const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k, int base) {
   const f4 qbi = qconj(B.q);
   const f3 t = qrot(qbi, A.c - B.c);
   const f4 qrel = qmul(qbi, A.q);
   for (int i = 0; i < k; ++i) {
     const int c = base + i;
-    if (c >= SDX_MAXC) break;
+    if (c >= MAXC) break;
     const int s = (packed >> (8 * i)) & 0xff;
     const f3 l = F3(A.h.x * c_samp[s][0], A.h.y * c_samp[s][1], A.h.z * c_samp[s][2]);
     const f3 pb = t + qrot(qrel, l);
@@ -171,118 +175,105 @@ __device__ __forceinline__ void emit_dir(const Box& A, const Box& B, int ida, in
     const float sd = box_sdf(pb, B.h, &g);
     const f3 n = qrot(B.q, g);
     const f3 pw = B.c + qrot(B.q, pb);
-    cwrite(cs, c, ida, idb, pw - n * (0.5f * sd), n, sd);
+    const f3 p = pw - n * (0.5f * sd);
+    S.cp[0][c] = p.x; S.cp[1][c] = p.y; S.cp[2][c] = p.z;
+    S.cn[0][c] = n.x; S.cn[1][c] = n.y; S.cn[2][c] = n.z;
+    S.P[0][c] = sd;                                       // staged for the owner lane of contact c (solver set-up)
+    S.P[1][c] = __int_as_float(ida | (idb << 8));
   }
 }
 
-__device__ __forceinline__ f3 point_vel(const PhysLds& S, int id, f3 p) {
-  if (id == SDX_BODY_STATIC) return F3(0, 0, 0);
-  if (id < NF) return ld3(S.bv[id]) + cross(ld3(S.bw[id]), p - ld3(S.bp[id]));
-  const int k = id - NF;
-  return ld3(S.lv[k]) + cross(ld3(S.lw[k]), p - ld3(S.lp[k]));
+__device__ __forceinline__ f3 point_vel(const PhysLds& S, int id, f3 p) {   // id: row of the body table (static world = zeros)
+  return ld3(S.bv[id]) + cross(ld3(S.bw[id]), p - ld3(S.bp[id]));
 }
 
-__device__ __forceinline__ float brick_w(const SdxConst* C, const PhysLds& S, int i, f3 p, f3 d) {
-  const sdx_scene_desc& sc = C->sc;
-  const int t = sc.brick_type[i];
+__device__ __forceinline__ float brick_w(const PhysLds& S, int i, f3 p, f3 d) {
   const f3 rxd = cross(p - ld3(S.bp[i]), d);
   const f3 l = qrot(qconj(ld4(S.bq[i])), rxd);
-  const float* I = sc.brick_inertia[t];
-  const float w = 1.0f / sc.brick_mass[t] + l.x * l.x / I[0] + l.y * l.y / I[1] + l.z * l.z / I[2];
-  return i == S.seg_brick ? w / sc.seg_mass_scale : w;
+  return S.bim[i] + l.x * l.x * S.bii[i][0] + l.y * l.y * S.bii[i][1] + l.z * l.z * S.bii[i][2];
 }
 
-// ---------------------------------------------------------------- A: FK (level-parallel over the tree)
+// ---------------------------------------------------------------- A: FK, on wave 0 only (lane = link; levels by wave-synchronous hand-off)
 // world inertia times vector: R I R^T x with I = (xx yy zz xy xz yz) in the link frame
 __device__ __forceinline__ f3 inertia_mul(f4 q, const float* I, f3 x) {
   const f3 l = qrot(qconj(q), x);
   return qrot(q, F3(I[0] * l.x + I[3] * l.y + I[4] * l.z, I[3] * l.x + I[1] * l.y + I[5] * l.z, I[4] * l.x + I[5] * l.y + I[2] * l.z));
 }
-__device__ void fk(const SdxConst* C, PhysLds& S, int tid) {
+// called by every lane of wave 0 (tid < 64); with_inertia: also the world inertia tensors the mass matrix needs
+__device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid, bool with_inertia) {
   const sdx_scene_desc& sc = C->sc;
+  const bool link = tid > 0 && tid < NL;
+  // this lane's link constants, fetched once (all loads in flight together) instead of inside the level loop
+  int par = 0, dep = -1;
+  f4 jq = {0, 0, 0, 1};
+  f3 jp = F3(0, 0, 0), ax = F3(0, 0, 1), com = F3(0, 0, 0);
+  float mass = 0.0f, I6[6] = {0, 0, 0, 0, 0, 0}, sn = 0.0f, cs = 1.0f, qdk = 0.0f;
+  if (link) {
+    par = sc.parent[tid]; dep = C->depth[tid];
+    jq = ld4(sc.joint_quat[tid]); jp = ld3(sc.joint_pos[tid]); ax = ld3(sc.joint_axis[tid]); com = ld3(sc.link_com[tid]);
+    mass = sc.link_mass[tid];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) I6[i] = sc.link_inertia[tid][i];
+    sincosf(0.5f * S.q[tid - 1], &sn, &cs);
+    qdk = S.qd[tid - 1];
+  }
   if (tid == 0) {
     st4(S.lq[0], ld4(sc.base_quat));
-    st3(S.lp[0], ld3(sc.base_pos));
+    st3(S.bp[NF + 0], ld3(sc.base_pos));
     st3(S.la[0], F3(0, 0, 1));
-    st3(S.lv[0], F3(0, 0, 0));
-    st3(S.lw[0], F3(0, 0, 0));
+    st3(S.bv[NF + 0], F3(0, 0, 0));
+    st3(S.bw[NF + 0], F3(0, 0, 0));
     st3(S.lal[0], F3(0, 0, 0)); st3(S.lao[0], F3(0, 0, 0)); st3(S.lF[0], F3(0, 0, 0)); st3(S.lN[0], F3(0, 0, 0));
     st3(S.lc[0], ld3(sc.base_pos) + qrot(ld4(sc.base_quat), ld3(sc.link_com[0])));
+    com = ld3(sc.link_com[0]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) I6[i] = sc.link_inertia[0][i];
   }
-  if (tid > 0 && tid < NL) sincosf(0.5f * S.q[tid - 1], &S.sincos[tid][0], &S.sincos[tid][1]);
-  __syncthreads();
-  for (int d = 1; d <= C->max_depth; ++d) {
-    if (tid > 0 && tid < NL && C->depth[tid] == d) {
-      const int k = tid, p = sc.parent[k];
+  WAVE_SYNC();
+  const int max_depth = C->max_depth;
+  for (int d = 1; d <= max_depth; ++d) {
+    if (link && dep == d) {
+      const int k = tid, p = par;
       const f4 qp = ld4(S.lq[p]);
-      const f3 pp = ld3(S.lp[p]);
-      const f4 qj = qmul(qp, ld4(sc.joint_quat[k]));
-      const f3 ax = ld3(sc.joint_axis[k]);
-      f4 qa; qa.x = ax.x * S.sincos[k][0]; qa.y = ax.y * S.sincos[k][0]; qa.z = ax.z * S.sincos[k][0]; qa.w = S.sincos[k][1];
+      const f3 pp = ld3(S.bp[NF + p]);
+      const f4 qj = qmul(qp, jq);
+      f4 qa; qa.x = ax.x * sn; qa.y = ax.y * sn; qa.z = ax.z * sn; qa.w = cs;
       const f4 qk = qnormalize(qmul(qj, qa));
-      const f3 pk = pp + qrot(qp, ld3(sc.joint_pos[k]));
+      const f3 pk = pp + qrot(qp, jp);
       const f3 ak = qrot(qj, ax);
-      const f3 wp = ld3(S.lw[p]);
+      const f3 wp = ld3(S.bw[NF + p]);
       st4(S.lq[k], qk);
-      st3(S.lp[k], pk);
+      st3(S.bp[NF + k], pk);
       st3(S.la[k], ak);
-      st3(S.lc[k], pk + qrot(qk, ld3(sc.link_com[k])));
-      const f3 wk = wp + ak * S.qd[k - 1];
-      st3(S.lw[k], wk);
-      st3(S.lv[k], ld3(S.lv[p]) + cross(wp, pk - pp));
+      const f3 dk = qrot(qk, com);
+      st3(S.lc[k], pk + dk);
+      const f3 wk = wp + ak * qdk;
+      st3(S.bw[NF + k], wk);
+      st3(S.bv[NF + k], ld3(S.bv[NF + p]) + cross(wp, pk - pp));
       // velocity-product terms (recursive Newton-Euler at zero joint acceleration, fixed base, no gravity on the robot)
       const f3 alp = ld3(S.lal[p]), r = pk - pp;
-      const f3 alk = alp + cross(wp, ak * S.qd[k - 1]);
+      const f3 alk = alp + cross(wp, ak * qdk);
       const f3 aok = ld3(S.lao[p]) + cross(alp, r) + cross(wp, cross(wp, r));
       st3(S.lal[k], alk);
       st3(S.lao[k], aok);
-      const f3 dk = qrot(qk, ld3(sc.link_com[k]));
       const f3 acom = aok + cross(alk, dk) + cross(wk, cross(wk, dk));
-      st3(S.lF[k], acom * sc.link_mass[k]);
-      st3(S.lN[k], inertia_mul(qk, sc.link_inertia[k], alk) + cross(wk, inertia_mul(qk, sc.link_inertia[k], wk)));
+      st3(S.lF[k], acom * mass);
+      st3(S.lN[k], inertia_mul(qk, I6, alk) + cross(wk, inertia_mul(qk, I6, wk)));
     }
-    __syncthreads();
+    WAVE_SYNC();
   }
   if (tid < sc.n_rbox) {
-    const int k = sc.rbox_link[tid];
+    const int k = S.rbl[tid];
     const f4 qk = ld4(S.lq[k]);
-    st3(S.rc[tid], ld3(S.lp[k]) + qrot(qk, ld3(sc.rbox_center[tid])));
+    st3(S.rc[tid], ld3(S.bp[NF + k]) + qrot(qk, ld3(sc.rbox_center[tid])));
     st4(S.rq[tid], qmul(qk, ld4(sc.rbox_quat[tid])));
   }
-  __syncthreads();
-}
-
-// link twists from qd: w_k = sum_j a_j qd_j, v_k = sum_j (a_j qd_j) x (p_k - p_j) over the dofs j on the path
-__device__ void twists(const SdxConst* C, PhysLds& S, int tid) {
-  if (tid > 0 && tid < NL) {
-    f3 w = F3(0, 0, 0), v = F3(0, 0, 0);
-    const f3 pk = ld3(S.lp[tid]);
-    uint32_t m = C->anc[tid];
-    while (m) {
-      const int j = __ffs(m) - 1;
-      m &= m - 1;
-      const f3 aj = ld3(S.la[j + 1]) * S.qd[j];
-      w = w + aj;
-      v = v + cross(aj, pk - ld3(S.lp[j + 1]));
-    }
-    st3(S.lw[tid], w);
-    st3(S.lv[tid], v);
-  }
-  __syncthreads();
-}
-
-// ---------------------------------------------------------------- B: H = M + implicit PD terms, Hinv
-__device__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
-  const sdx_scene_desc& sc = C->sc;
-  if (tid < NL) {  // world inertia R I R^T of each link (xx yy zz xy xz yz)
+  if (with_inertia && tid < NL) {   // world inertia R I R^T of each link (xx yy zz xy xz yz)
     const f4 q = ld4(S.lq[tid]);
-    const float* I = sc.link_inertia[tid];
     const f3 ex = qrot(q, F3(1, 0, 0)), ey = qrot(q, F3(0, 1, 0)), ez = qrot(q, F3(0, 0, 1));  // columns of R
-    // Iw = sum_ab I_ab e_a e_b^T
-    const f3 c0 = ex * I[0] + ey * I[3] + ez * I[4];
-    const f3 c1 = ex * I[3] + ey * I[1] + ez * I[5];
-    const f3 c2 = ex * I[4] + ey * I[5] + ez * I[2];
-    // Iw = [c0 c1 c2] R^T  -> Iw_rc = c0_r ex_c + c1_r ey_c + c2_r ez_c
+    const f3 c0 = ex * I6[0] + ey * I6[3] + ez * I6[4];
+    const f3 c1 = ex * I6[3] + ey * I6[1] + ez * I6[5];
+    const f3 c2 = ex * I6[4] + ey * I6[5] + ez * I6[2];
     S.lI[tid][0] = c0.x * ex.x + c1.x * ey.x + c2.x * ez.x;
     S.lI[tid][1] = c0.y * ex.y + c1.y * ey.y + c2.y * ez.y;
     S.lI[tid][2] = c0.z * ex.z + c1.z * ey.z + c2.z * ez.z;
@@ -290,18 +281,48 @@ __device__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
     S.lI[tid][4] = c0.x * ex.z + c1.x * ey.z + c2.x * ez.z;
     S.lI[tid][5] = c0.y * ex.z + c1.y * ey.z + c2.y * ez.z;
   }
-  __syncthreads();
+  WAVE_SYNC();
+}
+
+// link twists from qd, on wave 0: w_k = sum_j a_j qd_j, v_k = sum_j (a_j qd_j) x (p_k - p_j) over the dofs j on the path
+__device__ __forceinline__ void twists_wave0(PhysLds& S, int tid) {
+  if (tid > 0 && tid < NL) {
+    f3 w = F3(0, 0, 0), v = F3(0, 0, 0);
+    const f3 pk = ld3(S.bp[NF + tid]);
+    uint32_t m = S.anc[tid];
+    while (m) {
+      const int j = __ffs(m) - 1;
+      m &= m - 1;
+      const f3 aj = ld3(S.la[j + 1]) * S.qd[j];
+      w = w + aj;
+      v = v + cross(aj, pk - ld3(S.bp[NF + j + 1]));
+    }
+    st3(S.bw[NF + tid], w);
+    st3(S.bv[NF + tid], v);
+  }
+}
+
+__device__ __forceinline__ void tri_index(int idx, int* i, int* j) {   // idx -> (i, j), j <= i, row-major lower triangle
+  int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+  while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+  while (r * (r + 1) / 2 > idx) --r;
+  *i = r;
+  *j = idx - r * (r + 1) / 2;
+}
+
+// ---------------------------------------------------------------- B: H = M + implicit PD terms, Hinv (once per step)
+template <int NT>
+__device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
+  const sdx_scene_desc& sc = C->sc;
   for (int idx = tid; idx < ND * (ND + 1) / 2; idx += NT) {
-    int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-    while (i * (i + 1) / 2 > idx) --i;
-    const int j = idx - i * (i + 1) / 2;
+    int i, j;
+    tri_index(idx, &i, &j);
     float s = 0.0f;
-    if ((C->anc[i + 1] >> j) & 1u) {
+    if ((S.anc[i + 1] >> j) & 1u) {
       const f3 ai = ld3(S.la[i + 1]), aj = ld3(S.la[j + 1]);
-      const f3 pi = ld3(S.lp[i + 1]), pj = ld3(S.lp[j + 1]);
+      const f3 pi = ld3(S.bp[NF + i + 1]), pj = ld3(S.bp[NF + j + 1]);
       for (int k = i + 1; k < NL; ++k) {
-        if (!((C->anc[k] >> i) & 1u)) continue;
+        if (!((S.anc[k] >> i) & 1u)) continue;
         const f3 ck = ld3(S.lc[k]);
         const f3 li = cross(ai, ck - pi), lj = cross(aj, ck - pj);
         const float* I = S.lI[k];
@@ -315,34 +336,38 @@ __device__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
     S.A[j][i] = s;
   }
   __syncthreads();
-  // left-looking Cholesky, lane = row
-  for (int j = 0; j < ND; ++j) {
-    float s = 0.0f;
-    if (tid >= j && tid < ND) {
-      s = S.A[tid][j];
-      for (int k = 0; k < j; ++k) s -= S.A[tid][k] * S.A[j][k];
+  if (tid < 64) {
+    // left-looking Cholesky on wave 0, lane = row; column j is final before any lane reads it in the next step
+    for (int j = 0; j < ND; ++j) {
+      float s = 0.0f;
+      if (tid >= j && tid < ND) {
+        s = S.A[tid][j];
+        for (int k = 0; k < j; ++k) s -= S.A[tid][k] * S.A[j][k];
+      }
+      const float d = sqrtf(__shfl(s, j, 64));
+      if (tid >= j && tid < ND) S.A[tid][j] = (tid == j) ? d : s / d;
+      WAVE_SYNC();
     }
-    const float d = sqrtf(__shfl(s, j, 64));   // rows 0..22 live in wave 0; other waves idle through this loop
-    if (tid >= j && tid < ND) S.A[tid][j] = (tid == j) ? d : s / d;
-    __syncthreads();
-  }
-  // T = L^-1, lane = column
-  if (tid < ND) {
-    const int c = tid;
-    for (int i = 0; i < c; ++i) S_T(S)[i][c] = 0.0f;
-    for (int i = c; i < ND; ++i) {
-      float s = (i == c) ? 1.0f : 0.0f;
-      for (int k = c; k < i; ++k) s -= S.A[i][k] * S_T(S)[k][c];
-      S_T(S)[i][c] = s / S.A[i][i];
+    // T = L^-1, lane = column c, the column in registers: t[i] = ([i == c] - sum_{k < i} L[i][k] t[k]) / L[i][i], t[k] = 0 above the diagonal
+    if (tid < ND) {
+      const int c = tid;
+      float t[ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        float s = (i == c) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= S.A[i][k] * t[k];
+        t[i] = i >= c ? s / S.A[i][i] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) S_T(S)[i][c] = t[i];
     }
   }
   __syncthreads();
   // Hinv = T^T T
   for (int idx = tid; idx < ND * (ND + 1) / 2; idx += NT) {
-    int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-    while (i * (i + 1) / 2 > idx) --i;
-    const int j = idx - i * (i + 1) / 2;
+    int i, j;
+    tri_index(idx, &i, &j);
     float s = 0.0f;
     for (int k = i; k < ND; ++k) s += S_T(S)[k][i] * S_T(S)[k][j];
     S.A[i][j] = s;
@@ -351,28 +376,15 @@ __device__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
   __syncthreads();
 }
 
-// ---------------------------------------------------------------- block-level exclusive scan helpers (NT = 4 waves)
-// exclusive prefix of a 0/1 flag over the workgroup in thread order; *total = number of set flags.  Two barriers.
-__device__ __forceinline__ int block_scan_flag(PhysLds& S, bool flag, int tid, int* total) {
-  const int lane = tid & 63, wave = tid >> 6;
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const uint64_t bal = __ballot(flag);
-  if (lane == 0) S.wsum[wave] = __popcll(bal);
-  __syncthreads();
-  int off = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < NWAVE; ++w) { const int c = S.wsum[w]; if (w < wave) off += c; tot += c; }
-  __syncthreads();
-  *total = tot;
-  return off + __popcll(bal & lt);
-}
-// exclusive prefix of a small count k (0..4)
+// ---------------------------------------------------------------- block-level exclusive scan of a small count k (0..15), thread order
+template <int NT>
 __device__ __forceinline__ int block_scan_small(PhysLds& S, int k, int tid, int* total) {
+  constexpr int NW = NT / 64;
   const int lane = tid & 63, wave = tid >> 6;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int pre = 0, wt = 0;
 #pragma unroll
-  for (int b = 0; b < 3; ++b) {
+  for (int b = 0; b < 4; ++b) {
     const uint64_t bal = __ballot((k >> b) & 1);
     pre += __popcll(bal & lt) << b;
     wt += __popcll(bal) << b;
@@ -381,65 +393,87 @@ __device__ __forceinline__ int block_scan_small(PhysLds& S, int k, int tid, int*
   __syncthreads();
   int off = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < NWAVE; ++w) { const int c = S.wsum[w]; if (w < wave) off += c; tot += c; }
+  for (int w = 0; w < NW; ++w) { const int c = S.wsum[w]; if (w < wave) off += c; tot += c; }
   __syncthreads();
   *total = tot;
   return off + pre;
 }
 
 // ---------------------------------------------------------------- D: contacts
-__device__ void collide(const SdxConst* C, PhysLds& S, int tid) {
-  float (*cs)[SDX_MAXC] = S.stage;
+// candidate test of pair index idx in the fixed enumeration (brick/static, brick/brick i < j, then per robot box: bricks, statics).
+// Conservative: a pair can only produce a contact when a sample point of one box lies within `off` of the other box, and the SDF is
+// 1-Lipschitz, so |sdf_B(centre of A)| <= radius_A + off (or the same with A and B exchanged) must hold.
+__device__ __forceinline__ bool box_near(const PhysLds& S, f3 ca, float ra, f3 cb, f4 qb, f3 hb, float off) {
+  return box_sdf_val(qrot(qconj(qb), ca - cb), hb) <= ra + off;
+}
+// pair index -> (box a | box b << 8); box ids: 0..71 brick, 72..103 robot box, 128.. static
+__device__ __forceinline__ uint32_t pair_code(int idx, int n1, int n2, int ns, int per) {
+  if (idx < n1) return (uint32_t)(idx / ns) | ((uint32_t)(128 + idx % ns) << 8);
+  if (idx < n1 + n2) {
+    int i, j;
+    tri_index(idx - n1, &i, &j);   // lower triangle without the diagonal: bricks (j, i + 1), j <= i
+    return (uint32_t)j | ((uint32_t)(i + 1) << 8);
+  }
+  const int t = idx - n1 - n2, r = t / per, u = t % per;
+  return (uint32_t)(NF + r) | ((uint32_t)(u < NF ? u : 128 + u - NF) << 8);
+}
+__device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int n2, int ns, int per, float off) {
+  if (idx < n1) {
+    const int i = idx / ns, s = idx % ns;
+    return box_sdf_val(ld3(S.bp[i]) - ld3(S.stc[s]), ld3(S.sth[s])) <= S.brad[i] + off;
+  }
+  if (idx < n1 + n2) {
+    int i, j;
+    tri_index(idx - n1, &i, &j);
+    i += 1;
+    const f3 ci = ld3(S.bp[i]), cj = ld3(S.bp[j]);
+    const f3 d = ci - cj;
+    const float rr = S.brad[i] + S.brad[j] + off;
+    if (dot(d, d) > rr * rr) return false;
+    return box_near(S, ci, S.brad[i], cj, ld4(S.bq[j]), ld3(S.bh[j]), off) || box_near(S, cj, S.brad[j], ci, ld4(S.bq[i]), ld3(S.bh[i]), off);
+  }
+  const int t = idx - n1 - n2, r = t / per, u = t % per;
+  if (S.rbl[r] == 0) return false;   // the fixed base never generates contacts
+  const f3 rc = ld3(S.rc[r]);
+  const float rr0 = S.rrad[r];
+  if (u < NF) {
+    const f3 cb = ld3(S.bp[u]);
+    const f3 d = rc - cb;
+    const float rr = rr0 + S.brad[u] + off;
+    if (dot(d, d) > rr * rr) return false;
+    return box_near(S, rc, rr0, cb, ld4(S.bq[u]), ld3(S.bh[u]), off) || box_near(S, cb, S.brad[u], rc, ld4(S.rq[r]), ld3(S.rh[r]), off);
+  }
+  const int s = u - NF;
+  return box_sdf_val(rc - ld3(S.stc[s]), ld3(S.sth[s])) <= rr0 + off;
+}
+
+template <int NT>
+__device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid) {
   const sdx_scene_desc& sc = C->sc;
   const float off = sc.contact_offset;
   const int ns = sc.n_static;
-  // ---- broadphase: fixed enumeration order (brick/static, brick/brick, then per robot box: bricks, statics)
-  const int n1 = NF * ns, n2 = NF * NF, per = NF + ns, n3 = sc.n_rbox * per;
-  int np = 0;
-  for (int base = 0; base < n1 + n2 + n3; base += NT) {
-    const int idx = base + tid;
-    bool hit = false;
-    uint32_t pr = 0;
-    if (idx < n1) {
-      const int i = idx / ns, s = idx % ns;
-      const float r = C->brick_radius[sc.brick_type[i]];
-      f3 stc, sth;
-      static_box(sc, s, &stc, &sth);
-      hit = box_sdf_val(ld3(S.bp[i]) - stc, sth) <= r + off;
-      pr = (uint32_t)i | ((uint32_t)(128 + s) << 8);
-    } else if (idx < n1 + n2) {
-      const int t = idx - n1, i = t / NF, j = t % NF;
-      if (j > i) {
-        const f3 d = ld3(S.bp[i]) - ld3(S.bp[j]);
-        const float rr = C->brick_radius[sc.brick_type[i]] + C->brick_radius[sc.brick_type[j]] + off;
-        hit = dot(d, d) <= rr * rr;
-        pr = (uint32_t)i | ((uint32_t)j << 8);
-      }
-    } else if (idx < n1 + n2 + n3) {
-      const int t = idx - n1 - n2, r = t / per, u = t % per;
-      if (sc.rbox_link[r] != 0) {
-        const f3 rc = ld3(S.rc[r]);
-        const float rr0 = C->rbox_radius[r];
-        if (u < NF) {
-          const f3 d = rc - ld3(S.bp[u]);
-          const float rr = rr0 + C->brick_radius[sc.brick_type[u]] + off;
-          hit = dot(d, d) <= rr * rr;
-          pr = (uint32_t)(NF + r) | ((uint32_t)u << 8);
-        } else {
-          const int s = u - NF;
-          f3 stc, sth;
-          static_box(sc, s, &stc, &sth);
-          hit = box_sdf_val(rc - stc, sth) <= rr0 + off;
-          pr = (uint32_t)(NF + r) | ((uint32_t)(128 + s) << 8);
-        }
-      }
+  // ---- broadphase: lane tid tests candidates tid, tid + NT, ...; hits as a bit mask; ONE block scan places them (lane-major order)
+  const int n1 = NF * ns, n2 = NF * (NF - 1) / 2, per = NF + ns, n3 = sc.n_rbox * per, ntot = n1 + n2 + n3;
+  uint32_t mask = 0;
+  {
+    int it = 0;
+    for (int idx = tid; idx < ntot; idx += NT, ++it) {
+      if (candidate(S, idx, n1, n2, ns, per, off)) mask |= 1u << it;
     }
-    int tot;
-    const int pos = np + block_scan_flag(S, hit, tid, &tot);
-    if (hit && pos < SDX_MAXP) S.pairs[pos] = pr;
-    np += tot;
   }
-  if (np > SDX_MAXP) np = SDX_MAXP;
+  int np;
+  {
+    // at most 15 candidates per lane: (72 * 8 + 72 * 71 / 2 + 32 * 80) / 384 < 15
+    int pos = block_scan_small<NT>(S, __popc(mask), tid, &np);
+    uint32_t m = mask;
+    while (m) {
+      const int it = __ffs(m) - 1;
+      m &= m - 1;
+      if (pos < MAXP) S_PAIRS(S)[pos] = pair_code(tid + it * NT, n1, n2, ns, per);
+      ++pos;
+    }
+  }
+  if (np > MAXP) np = MAXP;
   __syncthreads();
   // ---- narrowphase: lane = candidate pair; contacts appended in pair order (block prefix sum of the counts)
   int nc = 0;
@@ -447,54 +481,47 @@ __device__ void collide(const SdxConst* C, PhysLds& S, int tid) {
     const int pi = base + tid;
     int k1 = 0, k2 = 0, ida = 0, idb = 0;
     uint32_t p1 = 0, p2 = 0;
-    Box A, B;
+    Box A, Bx;
     if (pi < np) {
-      const uint32_t pr = S.pairs[pi];
+      const uint32_t pr = S_PAIRS(S)[pi];
       const int ba = pr & 0xff, bb = (pr >> 8) & 0xff;
-      A = load_box(C, S, ba);
-      B = load_box(C, S, bb);
-      ida = box_body(C, ba);
-      idb = box_body(C, bb);
-      const int c1 = sample_dir(A, B, off, &p1);
-      const int c2 = (bb >= 128) ? 0 : sample_dir(B, A, off, &p2);
+      A = load_box(S, ba);
+      Bx = load_box(S, bb);
+      ida = box_body(S, ba);
+      idb = box_body(S, bb);
+      const int c1 = sample_dir(A, Bx, off, &p1);
+      const int c2 = (bb >= 128) ? 0 : sample_dir(Bx, A, off, &p2);
       const int m2 = c2 < 2 ? c2 : 2;
       k1 = c1 < 4 - m2 ? c1 : 4 - m2;
       k2 = c2 < 4 - k1 ? c2 : 4 - k1;
     }
     int tot;
-    const int pre = block_scan_small(S, k1 + k2, tid, &tot);
-    if (k1 > 0) emit_dir(A, B, ida, idb, p1, k1, cs, nc + pre);
-    if (k2 > 0) emit_dir(B, A, idb, ida, p2, k2, cs, nc + pre + k1);
+    const int pre = block_scan_small<NT>(S, k1 + k2, tid, &tot);
+    if (k1 > 0) emit_dir(S, A, Bx, ida, idb, p1, k1, nc + pre);
+    if (k2 > 0) emit_dir(S, Bx, A, idb, ida, p2, k2, nc + pre + k1);
     nc += tot;
   }
   if (tid == 0) {
-    S.overflow = nc > SDX_MAXC ? nc - SDX_MAXC : 0;
-    S.nc = nc > SDX_MAXC ? SDX_MAXC : nc;
+    S.overflow = nc > MAXC ? nc - MAXC : 0;
+    S.nc = nc > MAXC ? MAXC : nc;
     S.np = np;
   }
   __syncthreads();
 }
 
 // ---------------------------------------------------------------- E: solver
-// contact rows owned by this lane, held in registers for the whole solve
-struct Rows {
-  int a[CPT], b[CPT];
-  f3 p[CPT], n[CPT];
-  float sep[CPT], lam[CPT][3], wA[CPT][3], wB[CPT][3];
-};
-
 // row weight of the robot side: J Hinv J^T with J_j = (a_j x (p - p_j)) . d over the <= 11 dofs on the link's path
-__device__ __attribute__((noinline)) float robot_w(const SdxConst* C, const PhysLds& S, int k, f3 p, f3 d) {
+__device__ __forceinline__ float robot_w(const PhysLds& S, int k, f3 p, f3 d) {
   float Jp[11];
   int idx[11];
-  uint32_t m = C->anc[k];
+  uint32_t m = S.anc[k];
 #pragma unroll
   for (int q = 0; q < 11; ++q) {
     if (m) {
       const int j = __ffs(m) - 1;
       m &= m - 1;
       idx[q] = j;
-      Jp[q] = dot(cross(ld3(S.la[j + 1]), p - ld3(S.lp[j + 1])), d);
+      Jp[q] = dot(cross(ld3(S.la[j + 1]), p - ld3(S.bp[NF + j + 1])), d);
     } else { idx[q] = 0; Jp[q] = 0.0f; }
   }
   float acc = 0.0f;
@@ -508,58 +535,79 @@ __device__ __attribute__((noinline)) float robot_w(const SdxConst* C, const Phys
   return acc;
 }
 
-__device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last_substep, long long* dbg) {
+template <int NT>
+__device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last_substep, long long* dbg) {
+  constexpr int CPT = MAXC / NT;   // contact rows owned by one lane
+  static_assert(CPT * NT == MAXC, "NT must divide SDX_MAXC");
+  static_assert(NF * GL <= NT, "gather lanes");
   const sdx_scene_desc& sc = C->sc;
   const int nc = S.nc;
-  const float mu = sc.friction;
-  Rows R;
+  const float mu = sc.friction, relax = sc.jacobi_relax;
   SSTAMP(16);
-  // ---- this lane's rows from the LDS staging area into registers
+  // ---- what stays in registers for the whole solve: body ids (rows of the body table), target normal velocity, accumulated
+  // impulses, un-split inverse masses of both sides
+  int ab[CPT];
+  float vtgt[CPT], lam[CPT][3], wA[CPT][3], wB[CPT][3];
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
-    R.a[q] = SDX_BODY_STATIC; R.b[q] = SDX_BODY_STATIC;
-    R.p[q] = F3(0, 0, 0); R.n[q] = F3(0, 0, 1); R.sep[q] = 1.0f;
+    ab[q] = BODY_W | (BODY_W << 8);
+    vtgt[q] = 0.0f;
     if (c < nc) {
-      const int ab = __float_as_int(S.stage[0][c]);
-      R.a[q] = ab & 0xff; R.b[q] = (ab >> 8) & 0xff;
-      R.p[q] = F3(S.stage[1][c], S.stage[2][c], S.stage[3][c]);
-      R.n[q] = F3(S.stage[4][c], S.stage[5][c], S.stage[6][c]);
-      R.sep[q] = S.stage[7][c];
+      const float sep = S.P[0][c];
+      ab[q] = __float_as_int(S.P[1][c]);
+      vtgt[q] = sep > 0 ? -sep / h : fminf(sc.baumgarte * (-sep) / h, sc.max_depenetration_vel);
     }
   }
-  // ---- CSR of contact sides per brick (ascending contact index inside a brick = the oracle's summation order)
+  // ---- CSR of contact sides per brick (ascending contact index inside a brick)
   for (int i = tid; i < NF; i += NT) { S.bcount[i] = 0; S.efill[i] = 0; }
   if (tid == 0) { S.nrobot = 0; S.rfill = 0; }
-  __syncthreads();
+  __syncthreads();   // also: every lane has read its (separation, ids) out of the staging rows, which the fill lists reuse below
 #pragma unroll
   for (int q = 0; q < CPT; ++q)
     if (tid + q * NT < nc) {
-      const int a = R.a[q], b = R.b[q];
-      if (a < NF) atomicAdd(&S.bcount[a], 1); else if (a != SDX_BODY_STATIC) atomicAdd(&S.nrobot, 1);
-      if (b < NF) atomicAdd(&S.bcount[b], 1); else if (b != SDX_BODY_STATIC) atomicAdd(&S.nrobot, 1);
+      const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
+      if (a < NF) atomicAdd(&S.bcount[a], 1); else if (a != BODY_W) atomicAdd(&S.nrobot, 1);
+      if (b < NF) atomicAdd(&S.bcount[b], 1); else if (b != BODY_W) atomicAdd(&S.nrobot, 1);
     }
   __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    for (int i = 0; i < NF; ++i) { S.eoff[i] = o; o += S.bcount[i]; }
-    S.eoff[NF] = o;
+  if (tid < 64) {   // exclusive prefix over the 72 bricks on wave 0: two bricks per lane, shuffle scan
+    const int i0 = 2 * tid, i1 = 2 * tid + 1;
+    const int c0 = i0 < NF ? S.bcount[i0] : 0, c1 = i1 < NF ? S.bcount[i1] : 0;
+    int incl = c0 + c1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (tid >= o) incl += up;
+    }
+    const int excl = incl - (c0 + c1);
+    if (i0 < NF) S.eoff[i0] = excl;
+    if (i1 < NF) S.eoff[i1] = excl + c0;
+    if (i1 == NF - 1 || i0 == NF - 1) S.eoff[NF] = incl;
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
     if (c < nc) {
-      const int a = R.a[q], b = R.b[q];
+      const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
       if (a < NF) S_ENT2(S)[S.eoff[a] + atomicAdd(&S.efill[a], 1)] = (unsigned short)c;
-      else if (a != SDX_BODY_STATIC) { const int i = atomicAdd(&S.rfill, 1); if (i < SDX_MAXC) S_RENT2(S)[i] = (unsigned short)c; }
+      else if (a != BODY_W) {
+        const int i = atomicAdd(&S.rfill, 1);
+        if (i < MAXC) { S_RENT2(S)[i] = (unsigned short)c; S_RLINK2(S)[i] = (unsigned char)(a - NF); }
+      }
       if (b < NF) S_ENT2(S)[S.eoff[b] + atomicAdd(&S.efill[b], 1)] = (unsigned short)(c | 0x8000);
-      else if (b != SDX_BODY_STATIC) { const int i = atomicAdd(&S.rfill, 1); if (i < SDX_MAXC) S_RENT2(S)[i] = (unsigned short)(c | 0x8000); }
+      else if (b != BODY_W) {
+        const int i = atomicAdd(&S.rfill, 1);
+        if (i < MAXC) { S_RENT2(S)[i] = (unsigned short)(c | 0x8000); S_RLINK2(S)[i] = (unsigned char)(b - NF); }
+      }
     }
   }
   __syncthreads();
-  // rank pass: entry -> position = number of entries of the same brick with a smaller contact index (a contact touches
-  // a brick at most once, so indices are distinct) => every brick's list is in ascending contact order, deterministically
+  const int nrob = min(S.nrobot, MAXC);
+  const bool has_robot = nrob > 0;   // block-uniform
+  // rank pass: entry -> position = number of entries of the same brick with a smaller contact index (a contact touches a brick at
+  // most once, so indices are distinct) => every brick's list is in ascending contact order, deterministically
   {
     const int total = S.eoff[NF];
     for (int i = tid; i < total; i += NT) {
@@ -573,247 +621,243 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
       S.ent[o + rank] = v;
     }
     // the same for the robot-side list (one list for the whole robot; key = contact index, then side)
-    const int nr = min(S.nrobot, SDX_MAXC);
-    for (int i = tid; i < nr; i += NT) {
+    for (int i = tid; i < nrob; i += NT) {
       const unsigned short v = S_RENT2(S)[i];
       const int key = ((v & 0x7fff) << 1) | (v >> 15);
       int rank = 0;
-      for (int j = 0; j < nr; ++j) { const unsigned short u = S_RENT2(S)[j]; rank += (((u & 0x7fff) << 1) | (u >> 15)) < key; }
+      for (int j = 0; j < nrob; ++j) { const unsigned short u = S_RENT2(S)[j]; rank += (((u & 0x7fff) << 1) | (u >> 15)) < key; }
       S.rent[rank] = v;
-      const int ab = __float_as_int(S.stage[0][v & 0x7fff]);
-      S.rlink[rank] = (unsigned char)(((v & 0x8000) ? ((ab >> 8) & 0xff) : (ab & 0xff)) - NF);
+      S.rlink[rank] = S_RLINK2(S)[i];
     }
   }
-  __syncthreads();
-  const bool has_robot = S.nrobot > 0;   // block-uniform (read after the barrier above)
-  const int nrob = min(S.nrobot, SDX_MAXC);
-  // ---- un-split inverse effective masses per row and side; zero accumulated impulses
+  // ---- un-split inverse effective masses of the BRICK sides (owner lanes); zero accumulated impulses
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
-    const bool on = tid + q * NT < nc;
+    const int c = tid + q * NT;
+    const bool on = c < nc;
+    const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
+    f3 p = F3(0, 0, 0), n = F3(0, 0, 1);
+    if (on) { p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]); n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]); }
     f3 t1, t2;
-    tangents(R.n[q], &t1, &t2);
-    const f3 dir[3] = {R.n[q], t1, t2};
+    tangents(n, &t1, &t2);
+    const f3 dir[3] = {n, t1, t2};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      float wa = 0.0f, wb = 0.0f;
-      if (on) {
-        const int a = R.a[q], b = R.b[q];
-        if (a < NF) wa = brick_w(C, S, a, R.p[q], dir[r]);
-        else if (a != SDX_BODY_STATIC) wa = robot_w(C, S, a - NF, R.p[q], dir[r]);
-        if (b < NF) wb = brick_w(C, S, b, R.p[q], dir[r]);
-        else if (b != SDX_BODY_STATIC) wb = robot_w(C, S, b - NF, R.p[q], dir[r]);
-      }
-      R.wA[q][r] = wa; R.wB[q][r] = wb; R.lam[q][r] = 0.0f;
+      wA[q][r] = (on && a < NF) ? brick_w(S, a, p, dir[r]) : 0.0f;
+      wB[q][r] = (on && b < NF) ? brick_w(S, b, p, dir[r]) : 0.0f;
+      lam[q][r] = 0.0f;
     }
   }
-  if (tid < ND) { S.qds[tid] = S.qd[tid]; }
-  // gather lanes: GL lanes per brick (tid = GL*brick + sub), each caches its slice of the brick's entry list (entries
-  // sub, sub+4, ... up to GE of them) in registers for all iterations
-  constexpr int GE = 8, GL = 4;   // GL lanes per brick, GE cached entries per lane
+  if (tid < ND) S.qds[tid] = S.qd[tid];
+  __syncthreads();   // rank pass complete (ent / rent / rlink final); the fill lists in the P rows are dead from here on
+  // ---- robot sides: one lane per (contact, side) of the ordered robot list computes J Hinv J^T of its three rows -> P rows
+  if (has_robot) {
+    for (int r = tid; r < nrob; r += NT) {
+      const int c = S.rent[r] & 0x7fff, k = S.rlink[r];
+      const f3 p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]), n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
+      f3 t1, t2;
+      tangents(n, &t1, &t2);
+      S.P[0][r] = robot_w(S, k, p, n);
+      S.P[1][r] = robot_w(S, k, p, t1);
+      S.P[2][r] = robot_w(S, k, p, t2);
+    }
+    __syncthreads();
+    // owner lanes fetch them: position of (contact, side) in the ordered list by binary search (keys are distinct)
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const int c = tid + q * NT;
+      if (c < nc) {
+        const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const int id = side ? b : a;
+          if (id >= NF && id != BODY_W) {
+            const int key = (c << 1) | side;
+            int lo = 0, hi = nrob;   // first position whose key is >= key
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              const unsigned short u = S.rent[mid];
+              if ((((u & 0x7fff) << 1) | (u >> 15)) < key) lo = mid + 1; else hi = mid;
+            }
+            const float w0 = S.P[0][lo], w1 = S.P[1][lo], w2 = S.P[2][lo];
+            if (side) { wB[q][0] = w0; wB[q][1] = w1; wB[q][2] = w2; }
+            else { wA[q][0] = w0; wA[q][1] = w1; wA[q][2] = w2; }
+          }
+        }
+      }
+    }
+  }
+  // gather lanes: GL lanes per brick (tid = GL*brick + sub); lane sub sums entries sub, sub + GL, ... of its brick's list
   const int gbrick = tid / GL, gsub = tid % GL;
   const bool glane = gbrick < NF;
-  int gent[GE];
-  int gn = 0, gbeg = 0, gend = 0;
+  int gbeg = 0, gend = 0;
+  float g_im = 0.0f, g_ii0 = 0.0f, g_ii1 = 0.0f, g_ii2 = 0.0f;
   if (glane) {
-    gbeg = S.eoff[gbrick]; gend = S.eoff[gbrick + 1];
-#pragma unroll
-    for (int k = 0; k < GE; ++k) {
-      const int i = gbeg + gsub + GL * k;
-      gent[k] = i < gend ? (int)S.ent[i] : -1;
-      if (i < gend) gn = k + 1;
-    }
+    gbeg = S.eoff[gbrick] + gsub; gend = S.eoff[gbrick + 1];
+    g_im = S.bim[gbrick]; g_ii0 = S.bii[gbrick][0]; g_ii1 = S.bii[gbrick][1]; g_ii2 = S.bii[gbrick][2];
   }
+  // ACTIVE-contact counts per iteration: slots 0..71 bricks, NF = the whole robot, NF + 1 = the static world (stays zero)
+  for (int i = tid; i < NF + 2; i += NT) S.bcount[i] = 0;
   __syncthreads();
   SSTAMP(17);
-  float (*Pm)[SDX_MAXC] = S.stage;   // rows 0..2: impulse P of the contact (on A), rows 3..5: p x P
+  // robot gather lanes: RL lanes per dof over the ordered robot-side list, on the lanes the brick gather leaves free
+  constexpr int RL = (NT - NF * GL >= ND * 8) ? 8 : 4;
+  static_assert(NT - NF * GL >= ND * RL, "robot gather lanes");
+  const int rt = tid - NF * GL;
+  const bool rlane = has_robot && rt >= 0 && rt < ND * RL;
+  const int rj = rlane ? rt / RL : 0, rsub = rt % RL;
 
   for (int it = 0; it < sc.solver_iters; ++it) {
     if (it == 1) dbg = nullptr;
     SSTAMP(18);
-    // pass 1 (lane = contact): relative velocity, active flag
+    // ---- [A] lane = contact: relative velocity from the current body velocities, active flag, ACTIVE counts by integer atomics
     f3 vr[CPT];
-    bool act[CPT];
-    int ract = 0;
+    uint32_t actm = 0;
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
-      act[q] = false;
       vr[q] = F3(0, 0, 0);
       const int c = tid + q * NT;
       if (c < nc) {
-        const int a = R.a[q], b = R.b[q];
-        vr[q] = point_vel(S, a, R.p[q]) - point_vel(S, b, R.p[q]);
-        const float sep = R.sep[q];
-        const float target = sep > 0 ? -sep / h : fminf(sc.baumgarte * (-sep) / h, sc.max_depenetration_vel);
-        act[q] = R.lam[q][0] > 0.0f || dot(vr[q], R.n[q]) < target;
-        S.act[c] = act[q] ? 1 : 0;
-        if (act[q]) ract += (a >= NF && a != SDX_BODY_STATIC) + (b >= NF && b != SDX_BODY_STATIC);
+        const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
+        const f3 p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]), n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
+        vr[q] = point_vel(S, a, p) - point_vel(S, b, p);
+        if (lam[q][0] > 0.0f || dot(vr[q], n) < vtgt[q]) {
+          actm |= 1u << q;
+          if (a != BODY_W) atomicAdd(&S.bcount[a < NF ? a : NF], 1);
+          if (b != BODY_W) atomicAdd(&S.bcount[b < NF ? b : NF], 1);
+        }
       }
     }
-    if (tid == 0) S.rcount = 0;
     __syncthreads();
     SSTAMP(19);
-    // counts of ACTIVE contacts per brick (4 lanes per brick, quad reduction) and on the robot
-    if (glane) {
-      int n = 0;
-#pragma unroll
-      for (int k = 0; k < GE; ++k) if (k < gn) n += S.act[gent[k] & 0x7fff];
-      for (int i = gbeg + gsub + GL * GE; i < gend; i += GL) n += S.act[S.ent[i] & 0x7fff];
-      n += __shfl_xor(n, 1, 64);
-      n += __shfl_xor(n, 2, 64);
-      if (GL == 8) n += __shfl_xor(n, 4, 64);
-      if (gsub == 0) S.bcount[gbrick] = n;
-    }
-    if (has_robot && ract) atomicAdd(&S.rcount, ract);
-    __syncthreads();
-    SSTAMP(20);
-    // pass 2 (lane = contact): Jacobi update from the same velocity snapshot; P and p x P to LDS
+    // ---- [C] lane = contact: Jacobi update from the same velocity snapshot; impulse P (on body A) to LDS, zero when inactive
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
       const int c = tid + q * NT;
       f3 P = F3(0, 0, 0);
-      if (act[q]) {
-        const int a = R.a[q], b = R.b[q];
-        const f3 n = R.n[q];
-        const float sep = R.sep[q];
-        const float target = sep > 0 ? -sep / h : fminf(sc.baumgarte * (-sep) / h, sc.max_depenetration_vel);
+      if ((actm >> q) & 1u) {
+        const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
+        const f3 n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
         f3 t1, t2;
         tangents(n, &t1, &t2);
-        const float na = a == SDX_BODY_STATIC ? 0.0f : (a < NF ? (float)S.bcount[a] : (float)S.rcount);
-        const float nb = b == SDX_BODY_STATIC ? 0.0f : (b < NF ? (float)S.bcount[b] : (float)S.rcount);
-        const float w0 = na * R.wA[q][0] + nb * R.wB[q][0];
-        const float w1 = na * R.wA[q][1] + nb * R.wB[q][1];
-        const float w2 = na * R.wA[q][2] + nb * R.wB[q][2];
-        const float lam0 = R.lam[q][0], lam1 = R.lam[q][1], lam2 = R.lam[q][2];
-        const float ln = fmaxf(0.0f, lam0 - sc.jacobi_relax * (dot(vr[q], n) - target) / w0);
+        const float na = (float)S.bcount[a < NF ? a : (a != BODY_W ? NF : NF + 1)];
+        const float nb = (float)S.bcount[b < NF ? b : (b != BODY_W ? NF : NF + 1)];
+        const float w0 = na * wA[q][0] + nb * wB[q][0];
+        const float w1 = na * wA[q][1] + nb * wB[q][1];
+        const float w2 = na * wA[q][2] + nb * wB[q][2];
+        const float lam0 = lam[q][0], lam1 = lam[q][1], lam2 = lam[q][2];
+        const float ln = fmaxf(0.0f, lam0 - relax * (dot(vr[q], n) - vtgt[q]) / w0);
         const float lim = mu * ln;
-        float l1 = lam1 - sc.jacobi_relax * dot(vr[q], t1) / w1;
+        float l1 = lam1 - relax * dot(vr[q], t1) / w1;
         l1 = fminf(lim, fmaxf(-lim, l1));
-        float l2 = lam2 - sc.jacobi_relax * dot(vr[q], t2) / w2;
+        float l2 = lam2 - relax * dot(vr[q], t2) / w2;
         l2 = fminf(lim, fmaxf(-lim, l2));
-        R.lam[q][0] = ln; R.lam[q][1] = l1; R.lam[q][2] = l2;
+        lam[q][0] = ln; lam[q][1] = l1; lam[q][2] = l2;
         P = n * (ln - lam0) + t1 * (l1 - lam1) + t2 * (l2 - lam2);
       }
-      if (c < nc) {
-        const f3 M = cross(R.p[q], P);
-        Pm[0][c] = P.x; Pm[1][c] = P.y; Pm[2][c] = P.z;
-        Pm[3][c] = M.x; Pm[4][c] = M.y; Pm[5][c] = M.z;
-      }
+      if (c < nc) { S.P[0][c] = P.x; S.P[1][c] = P.y; S.P[2][c] = P.z; }
     }
     __syncthreads();
-    SSTAMP(21);
-    // gather (4 lanes per brick): dv = sum(+-P)/m, dw = Iw^-1 (sum(+-(p x P)) - x x sum(+-P)); each lane sums its
-    // slice in ascending contact order, the four partial sums are combined in a fixed order (deterministic)
+    SSTAMP(20);
+    // ---- [D] gather (GL lanes per brick): dv = sum(+-P)/m, dw = Iw^-1 sum(+-(p - x) x P); each lane sums its slice in ascending
+    // contact order, the partial sums are combined in a fixed order (deterministic); inactive contacts carry P = 0
     if (glane) {
       float acc[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < GE; ++k)
-        if (k < gn) {
-          const int e = gent[k], c = e & 0x7fff;
-          if (S.act[c]) {
-            const float sg = (e & 0x8000) ? -1.0f : 1.0f;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[r] += Pm[r][c] * sg;
-          }
-        }
-      for (int i = gbeg + gsub + GL * GE; i < gend; i += GL) {
-        const int e = S.ent[i], c = e & 0x7fff;
-        if (S.act[c]) {
-          const float sg = (e & 0x8000) ? -1.0f : 1.0f;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) acc[r] += Pm[r][c] * sg;
-        }
+      const f3 x = ld3(S.bp[gbrick]);
+      // two entries per trip (both index loads, then both payloads, in flight together); not unrolled further: the decoded
+      // addresses of a longer window would be kept in registers across the whole iteration loop
+#pragma unroll 1
+      for (int i = gbeg; i < gend; i += 2 * GL) {
+        const bool two = i + GL < gend;
+        const int e0 = S.ent[i], e1 = two ? (int)S.ent[i + GL] : e0;
+        const int c0 = e0 & 0x7fff, c1 = e1 & 0x7fff;
+        const float s0 = (e0 & 0x8000) ? -1.0f : 1.0f, s1 = two ? ((e1 & 0x8000) ? -1.0f : 1.0f) : 0.0f;
+        const f3 P0 = F3(S.P[0][c0], S.P[1][c0], S.P[2][c0]) * s0, P1 = F3(S.P[0][c1], S.P[1][c1], S.P[2][c1]) * s1;
+        const f3 M0 = cross(F3(S.cp[0][c0], S.cp[1][c0], S.cp[2][c0]) - x, P0);
+        const f3 M1 = cross(F3(S.cp[0][c1], S.cp[1][c1], S.cp[2][c1]) - x, P1);
+        acc[0] += P0.x; acc[1] += P0.y; acc[2] += P0.z; acc[3] += M0.x; acc[4] += M0.y; acc[5] += M0.z;
+        acc[0] += P1.x; acc[1] += P1.y; acc[2] += P1.z; acc[3] += M1.x; acc[4] += M1.y; acc[5] += M1.z;
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         acc[r] += __shfl_xor(acc[r], 1, 64);
         acc[r] += __shfl_xor(acc[r], 2, 64);
-        if (GL == 8) acc[r] += __shfl_xor(acc[r], 4, 64);
       }
       if (gsub == 0) {
-        const f3 sp = F3(acc[0], acc[1], acc[2]), sm = F3(acc[3], acc[4], acc[5]);
-        const int t = sc.brick_type[gbrick];
-        const f3 x = ld3(S.bp[gbrick]);
         const f4 qq = ld4(S.bq[gbrick]);
-        const f3 tau = sm - cross(x, sp);
-        const f3 l = qrot(qconj(qq), tau);
-        const float* I = sc.brick_inertia[t];
-        const float isc = gbrick == S.seg_brick ? 1.0f / sc.seg_mass_scale : 1.0f;
-        const f3 dw = qrot(qq, F3(l.x / I[0], l.y / I[1], l.z / I[2])) * isc;
-        const float im = isc / sc.brick_mass[t];
-        st3(S.bv[gbrick], ld3(S.bv[gbrick]) + sp * im);
+        const f3 l = qrot(qconj(qq), F3(acc[3], acc[4], acc[5]));
+        const f3 dw = qrot(qq, F3(l.x * g_ii0, l.y * g_ii1, l.z * g_ii2));
+        st3(S.bv[gbrick], ld3(S.bv[gbrick]) + F3(acc[0], acc[1], acc[2]) * g_im);
         st3(S.bw[gbrick], ld3(S.bw[gbrick]) + dw);
+        S.bcount[gbrick] = 0;   // read by [C] before the barrier above; counted afresh by [A] of the next iteration
       }
+      if (tid == 0) S.bcount[NF] = 0;
+    }
+    if (rlane) {
+      // robot side: generalised impulse Q_j += sum over the robot's contact sides of a_j . ((p - o_j) x (+-P)) for the dofs j on the
+      // path to the touched link; RL lanes per dof walk the (contact, side)-ordered list with a fixed stride and combine in a fixed order
+      const f3 aj = ld3(S.la[rj + 1]), oj = ld3(S.bp[NF + rj + 1]);
+      float acc = 0.0f;
+      for (int i = rsub; i < nrob; i += RL) {
+        const int e = S.rent[i], c = e & 0x7fff;
+        if ((S.anc[S.rlink[i]] >> rj) & 1u) {
+          const f3 P = F3(S.P[0][c], S.P[1][c], S.P[2][c]);
+          const float t = dot(aj, cross(F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]) - oj, P));
+          acc += (e & 0x8000) ? -t : t;
+        }
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (RL == 8) acc += __shfl_xor(acc, 4, 64);
+      if (rsub == 0) S.Q[rj] += acc;
     }
     if (has_robot) {
-      // robot side: generalised impulse Q_j += sum over the robot's contact sides of a_j . ((p - o_j) x (+-P)) = a_j . (+-(M - o_j x P))
-      // for the dofs j on the path to the touched link; 8 lanes per dof walk the (contact, side)-ordered list with a fixed
-      // stride and combine in a fixed order (deterministic; LDS float atomics are not)
-      constexpr int RL = 8;
-      const int rt = tid - NF * GL;
-      if (rt >= 0 && rt < ND * RL) {
-        const int j = rt / RL, rsub = rt % RL;
-        const f3 aj = ld3(S.la[j + 1]), oj = ld3(S.lp[j + 1]);
-        float acc = 0.0f;
-        for (int i = rsub; i < nrob; i += RL) {
-          const int e = S.rent[i], c = e & 0x7fff;
-          if (S.act[c] && ((C->anc[S.rlink[i]] >> j) & 1u)) {
-            const f3 P = F3(Pm[0][c], Pm[1][c], Pm[2][c]), M = F3(Pm[3][c], Pm[4][c], Pm[5][c]);
-            const float t = dot(aj, M - cross(oj, P));
-            acc += (e & 0x8000) ? -t : t;
-          }
+      __syncthreads();
+      SSTAMP(21);
+      if (tid < 64) {   // wave 0: qd = qd* + Hinv Q, then the link twists, handed over wave-synchronously
+        if (tid < ND) {
+          float sacc = S.qds[tid];
+          for (int j = 0; j < ND; ++j) sacc += S.A[tid][j] * S.Q[j];
+          S.qd[tid] = sacc;
         }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        if (rsub == 0) S.Q[j] += acc;
+        WAVE_SYNC();
+        twists_wave0(S, tid);
       }
-      __syncthreads();
-      if (tid < ND) {
-        float sacc = S.qds[tid];
-        for (int j = 0; j < ND; ++j) sacc += S.A[tid][j] * S.Q[j];
-        S.qd[tid] = sacc;
-      }
-      __syncthreads();
-      SSTAMP(22);
-      twists(C, S, tid);
-    } else {
-      __syncthreads();
-      SSTAMP(22);
     }
-    SSTAMP(23);
+    __syncthreads();
+    SSTAMP(22);
   }
   // net contact force on the robot bodies from the last substep's accumulated impulses (GS:1094; bodies 1..6 are read)
   if (last_substep) {
     for (int i = tid; i < NL * 3; i += NT) (&S.cf[0][0])[i] = 0.0f;
-    __syncthreads();
     if (has_robot) {
       const float ih = 1.0f / h;
 #pragma unroll
       for (int q = 0; q < CPT; ++q) {
         const int c = tid + q * NT;
         if (c < nc) {
+          const f3 n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
           f3 t1, t2;
-          tangents(R.n[q], &t1, &t2);
-          const f3 P = (R.n[q] * R.lam[q][0] + t1 * R.lam[q][1] + t2 * R.lam[q][2]) * ih;
-          Pm[0][c] = P.x; Pm[1][c] = P.y; Pm[2][c] = P.z;
+          tangents(n, &t1, &t2);
+          const f3 F = (n * lam[q][0] + t1 * lam[q][1] + t2 * lam[q][2]) * ih;
+          S.P[0][c] = F.x; S.P[1][c] = F.y; S.P[2][c] = F.z;
         }
       }
       __syncthreads();
-      constexpr int RL = 8;
-      if (tid < NL * RL) {   // 8 lanes per link over the ordered robot-side list, fixed combination order
-        const int k = tid / RL, rsub = tid % RL;
+      constexpr int FL = 8;
+      if (tid < NL * FL) {   // 8 lanes per link over the ordered robot-side list, fixed combination order
+        const int k = tid / FL, fsub = tid % FL;
         float ax = 0.0f, ay = 0.0f, az = 0.0f;
-        for (int i = rsub; i < nrob; i += RL) {
+        for (int i = fsub; i < nrob; i += FL) {
           if (S.rlink[i] == k) {
             const int e = S.rent[i], c = e & 0x7fff;
             const float sg = (e & 0x8000) ? -1.0f : 1.0f;
-            ax += sg * Pm[0][c]; ay += sg * Pm[1][c]; az += sg * Pm[2][c];
+            ax += sg * S.P[0][c]; ay += sg * S.P[1][c]; az += sg * S.P[2][c];
           }
         }
 #pragma unroll
-        for (int o = 1; o < RL; o <<= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
-        if (rsub == 0) { S.cf[k][0] = ax; S.cf[k][1] = ay; S.cf[k][2] = az; }
+        for (int o = 1; o < FL; o <<= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
+        if (fsub == 0) { S.cf[k][0] = ax; S.cf[k][1] = ay; S.cf[k][2] = az; }
       }
     }
     __syncthreads();
@@ -821,29 +865,62 @@ __device__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last
 }
 
 // ---------------------------------------------------------------- outputs shared by step and refresh
-__device__ void write_kinematics(const SdxConst* C, PhysLds& S, const SdxBuf& B, int e, int tid) {
+template <int NT>
+__device__ __forceinline__ void write_kinematics(const SdxConst* C, PhysLds& S, const SdxBuf& B, int e, int tid) {
   const sdx_scene_desc& sc = C->sc;
   float* rb_e = B.rb + (size_t)e * SDX_BODIES * 13;
   for (int i = tid; i < NL * 13; i += NT) {
     const int k = i / 13, c = i % 13;
     float v;
-    if (c < 3) v = S.lp[k][c];
+    if (c < 3) v = S.bp[NF + k][c];
     else if (c < 7) v = S.lq[k][c - 3];
-    else if (c < 10) v = S.lv[k][c - 7];
-    else v = S.lw[k][c - 10];
+    else if (c < 10) v = S.bv[NF + k][c - 7];
+    else v = S.bw[NF + k][c - 10];
     rb_e[i] = v;
   }
   if (tid < 42) {  // geometric Jacobian of the hand-base body origin wrt the 7 arm dofs (GS:1601)
     const int r = tid / 7, j = tid % 7, ee = sc.hand_base_body;
     const f3 a = ld3(S.la[j + 1]);
-    const f3 lin = cross(a, ld3(S.lp[ee]) - ld3(S.lp[j + 1]));
+    const f3 lin = cross(a, ld3(S.bp[NF + ee]) - ld3(S.bp[NF + j + 1]));
     const float v = r == 0 ? lin.x : r == 1 ? lin.y : r == 2 ? lin.z : r == 3 ? a.x : r == 4 ? a.y : a.z;
     B.jac[(size_t)e * 42 + tid] = v;
   }
 }
 
+// per-env constants into LDS (bricks, robot boxes, statics, ancestor masks)
+template <int NT>
+__device__ __forceinline__ void load_constants(const SdxConst* C, PhysLds& S, int e, int tid) {
+  const sdx_scene_desc& sc = C->sc;
+  const int segb = seg_actor(e) - SDX_ACTOR_BRICK0;
+  if (tid == 0) {
+    S.seg_brick = segb;
+    st3(S.bp[BODY_W], F3(0, 0, 0)); st3(S.bv[BODY_W], F3(0, 0, 0)); st3(S.bw[BODY_W], F3(0, 0, 0));   // the static world
+  }
+  if (tid < NL) S.anc[tid] = C->anc[tid];
+  for (int i = tid; i < NF; i += NT) {
+    const int t = sc.brick_type[i];
+    st3(S.bh[i], ld3(sc.brick_half[t]));
+    S.brad[i] = C->brick_radius[t];
+    const float isc = i == segb ? 1.0f / sc.seg_mass_scale : 1.0f;
+    S.bim[i] = isc / sc.brick_mass[t];
+    S.bii[i][0] = isc / sc.brick_inertia[t][0]; S.bii[i][1] = isc / sc.brick_inertia[t][1]; S.bii[i][2] = isc / sc.brick_inertia[t][2];
+  }
+  if (tid < SDX_MAX_RBOX) {
+    const bool on = tid < sc.n_rbox;
+    S.rbl[tid] = on ? sc.rbox_link[tid] : 0;
+    st3(S.rh[tid], on ? ld3(sc.rbox_half[tid]) : F3(0, 0, 0));
+    S.rrad[tid] = on ? C->rbox_radius[tid] : 0.0f;
+  }
+  if (tid < SDX_MAX_STATIC) {   // InsertSim's base plate has one of three heights by env % 3 (sdx_scene_desc.static_var_*)
+    f3 c = ld3(sc.static_center[tid]), hh = ld3(sc.static_half[tid]);
+    if (tid == sc.static_var_slot) { const int k = e % 3; c.z = sc.static_var_center_z[k]; hh.z = sc.static_var_half_z[k]; }
+    st3(S.stc[tid], c); st3(S.sth[tid], hh);
+  }
+}
+
 // ---------------------------------------------------------------- the step kernel
-__global__ __launch_bounds__(NT, 2) void k_physics(const SdxConst* __restrict__ C, SdxBuf B) {
+template <int NT>
+__global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __restrict__ C, SdxBuf B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PhysLds& S = *reinterpret_cast<PhysLds*>(smem);
   const int e = blockIdx.x, tid = threadIdx.x;
@@ -852,7 +929,7 @@ __global__ __launch_bounds__(NT, 2) void k_physics(const SdxConst* __restrict__ 
   const float h = sc.dt / (float)sc.substeps;
 
   // ---- load per-env state (coalesced rows) into LDS
-  if (tid == 0) S.seg_brick = seg_actor(e) - SDX_ACTOR_BRICK0;
+  load_constants<NT>(C, S, e, tid);
   if (tid < ND) {
     S.q[tid] = B.dof[((size_t)e * ND + tid) * 2];
     S.qd[tid] = B.dof[((size_t)e * ND + tid) * 2 + 1];
@@ -870,36 +947,44 @@ __global__ __launch_bounds__(NT, 2) void k_physics(const SdxConst* __restrict__ 
 
   for (int sub = 0; sub < sc.substeps; ++sub) {
     PSTAMP(0);
-    fk(C, S, tid);
-    PSTAMP(1);
-    if (sub == 0) mass_matrix(C, S, tid, h);   // M(q) is evaluated once per step (frozen over the substeps)
-    PSTAMP(2);
-    // C: implicit PD drive (P1) + gravity on the free bricks
-    if (tid < ND) {
-      const float t = sc.kp[tid] * (S.tgt[tid] - S.q[tid]) - (sc.kd[tid] + h * sc.kp[tid]) * S.qd[tid];
-      // velocity-product bias torque of dof tid: inertial wrenches of the links below it, projected on its axis
-      float tc = 0.0f;
-      const f3 aj = ld3(S.la[tid + 1]), oj = ld3(S.lp[tid + 1]);
-      for (int k = 1; k < NL; ++k)
-        if ((C->anc[k] >> tid) & 1u) tc += dot(aj, cross(ld3(S.lc[k]) - oj, ld3(S.lF[k])) + ld3(S.lN[k]));
-      S.tau[tid] = fminf(sc.effort[tid], fmaxf(-sc.effort[tid], t)) - tc;   // the effort limit applies to the drive only
-      S.Q[tid] = 0.0f;
+    if (sub == 0) {   // M(q) is evaluated once per step (frozen over the substeps)
+      if (tid < 64) fk_wave0(C, S, tid, true);
+      __syncthreads();
+      PSTAMP(1);
+      mass_matrix<NT>(C, S, tid, h);
+      PSTAMP(2);
+    }
+    // A + C on wave 0 (FK, implicit PD drive (P1), velocity-product bias torques, twists); the other waves: gravity on the free bricks
+    if (tid < 64) {
+      if (sub != 0) fk_wave0(C, S, tid, false);
+      if (tid < ND) {
+        const float t = sc.kp[tid] * (S.tgt[tid] - S.q[tid]) - (sc.kd[tid] + h * sc.kp[tid]) * S.qd[tid];
+        // velocity-product bias torque of dof tid: inertial wrenches of the links below it, projected on its axis
+        float tc = 0.0f;
+        const f3 aj = ld3(S.la[tid + 1]), oj = ld3(S.bp[NF + tid + 1]);
+        for (int k = 1; k < NL; ++k)
+          if ((S.anc[k] >> tid) & 1u) tc += dot(aj, cross(ld3(S.lc[k]) - oj, ld3(S.lF[k])) + ld3(S.lN[k]));
+        S.tau[tid] = fminf(sc.effort[tid], fmaxf(-sc.effort[tid], t)) - tc;   // the effort limit applies to the drive only
+        S.Q[tid] = 0.0f;
+      }
+      WAVE_SYNC();
+      if (tid < ND) {
+        float s = 0.0f;
+        for (int j = 0; j < ND; ++j) s += S.A[tid][j] * S.tau[j];
+        S.qd[tid] += h * s;
+      }
+      WAVE_SYNC();
+      twists_wave0(S, tid);
+    } else {
+      for (int i = tid - 64; i < NF; i += NT - 64) {
+        S.bv[i][0] += sc.gravity[0] * h; S.bv[i][1] += sc.gravity[1] * h; S.bv[i][2] += sc.gravity[2] * h;
+      }
     }
     __syncthreads();
-    if (tid < ND) {
-      float s = 0.0f;
-      for (int j = 0; j < ND; ++j) s += S.A[tid][j] * S.tau[j];
-      S.qd[tid] += h * s;
-    }
-    for (int i = tid; i < NF; i += NT) {
-      S.bv[i][0] += sc.gravity[0] * h; S.bv[i][1] += sc.gravity[1] * h; S.bv[i][2] += sc.gravity[2] * h;
-    }
-    __syncthreads();
-    twists(C, S, tid);
     PSTAMP(3);
-    collide(C, S, tid);
+    collide<NT>(C, S, tid);
     PSTAMP(4);
-    solve(C, S, tid, h, sub == sc.substeps - 1, sub == 0 ? B.dbg : nullptr);
+    solve<NT>(C, S, tid, h, sub == sc.substeps - 1, sub == 0 ? B.dbg : nullptr);
     PSTAMP(5);
     // F: integrate
     if (tid < ND) {
@@ -925,12 +1010,13 @@ __global__ __launch_bounds__(NT, 2) void k_physics(const SdxConst* __restrict__ 
   }
 
   // ---- outputs (refresh_* of GS:1091-1095)
-  fk(C, S, tid);
+  if (tid < 64) fk_wave0(C, S, tid, false);
+  __syncthreads();
   if (tid < ND) {
     B.dof[((size_t)e * ND + tid) * 2] = S.q[tid];
     B.dof[((size_t)e * ND + tid) * 2 + 1] = S.qd[tid];
   }
-  write_kinematics(C, S, B, e, tid);
+  write_kinematics<NT>(C, S, B, e, tid);
   float* rb_e = B.rb + (size_t)e * SDX_BODIES * 13;
   for (int i = tid; i < NF * 13; i += NT) {
     const int k = i / 13, c = i % 13;
@@ -948,8 +1034,8 @@ __global__ __launch_bounds__(NT, 2) void k_physics(const SdxConst* __restrict__ 
   if (tid == 0) B.ncontacts[e] = S.nc + S.overflow;
 }
 
-// kinematics only: rigid-body states of the 24 links + end-effector Jacobian from SDX_T_DOF
-__global__ __launch_bounds__(NT) void k_kinematics(const SdxConst* __restrict__ C, SdxBuf B) {
+// kinematics only: rigid-body states of the 24 links + end-effector Jacobian from SDX_T_DOF (one wave per env)
+__global__ __launch_bounds__(64) void k_kinematics(const SdxConst* __restrict__ C, SdxBuf B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PhysLds& S = *reinterpret_cast<PhysLds*>(smem);
   const int e = blockIdx.x, tid = threadIdx.x;
@@ -957,24 +1043,45 @@ __global__ __launch_bounds__(NT) void k_kinematics(const SdxConst* __restrict__ 
     S.q[tid] = B.dof[((size_t)e * ND + tid) * 2];
     S.qd[tid] = B.dof[((size_t)e * ND + tid) * 2 + 1];
   }
-  __syncthreads();
-  fk(C, S, tid);
-  write_kinematics(C, S, B, e, tid);
+  if (tid < NL) S.anc[tid] = C->anc[tid];
+  if (tid < SDX_MAX_RBOX) S.rbl[tid] = tid < C->sc.n_rbox ? C->sc.rbox_link[tid] : 0;
+  WAVE_SYNC();
+  fk_wave0(C, S, tid, false);
+  write_kinematics<64>(C, S, B, e, tid);
+  if (B.jac_full) {   // acquire_jacobian_tensor(sim, "hand") (GS:241): [23 links (fixed base excluded), 6, 23 dofs]
+    float* J = B.jac_full + (size_t)e * (NL - 1) * 6 * ND;
+    for (int i = tid; i < (NL - 1) * 6 * ND; i += 64) {
+      const int k = i / (6 * ND) + 1, r = (i / ND) % 6, j = i % ND;
+      float v = 0.0f;
+      if ((S.anc[k] >> j) & 1u) {
+        const f3 a = ld3(S.la[j + 1]);
+        const f3 lin = cross(a, ld3(S.bp[NF + k]) - ld3(S.bp[NF + j + 1]));
+        v = r == 0 ? lin.x : r == 1 ? lin.y : r == 2 ? lin.z : r == 3 ? a.x : r == 4 ? a.y : a.z;
+      }
+      J[i] = v;
+    }
+  }
 }
 
 extern "C" size_t sdxk_physics_lds_bytes() { return sizeof(PhysLds); }
-static void ensure_lds_attr() {   // PhysLds exceeds the default 64 KiB dynamic-LDS limit (gfx950 has 160 KiB per CU)
-  static bool done = false;
-  if (done) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_physics), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PhysLds));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_kinematics), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PhysLds));
-  done = true;
+// threads per env: 384 (6 waves) or 512 (8 waves); either way two envs share a CU.  SDX_PHYS_NT overrides the default.
+static int physics_nt() {
+  static int nt = 0;
+  if (!nt) {
+    const char* e = getenv("SDX_PHYS_NT");
+    nt = (e && atoi(e) == 384) ? 384 : ((e && atoi(e) == 512) ? 512 : SDX_PHYS_NT_DEFAULT);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_physics<384>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PhysLds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_physics<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PhysLds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_kinematics), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PhysLds));
+  }
+  return nt;
 }
+extern "C" int sdxk_physics_threads() { return physics_nt(); }
 extern "C" void sdxk_physics(const SdxConst* C, const SdxBuf* B, hipStream_t st) {
-  ensure_lds_attr();
-  hipLaunchKernelGGL(k_physics, dim3(B->N), dim3(NT), sizeof(PhysLds), st, C, *B);
+  if (physics_nt() == 384) hipLaunchKernelGGL(k_physics<384>, dim3(B->N), dim3(384), sizeof(PhysLds), st, C, *B);
+  else hipLaunchKernelGGL(k_physics<512>, dim3(B->N), dim3(512), sizeof(PhysLds), st, C, *B);
 }
 extern "C" void sdxk_kinematics(const SdxConst* C, const SdxBuf* B, hipStream_t st) {
-  ensure_lds_attr();
-  hipLaunchKernelGGL(k_kinematics, dim3(B->N), dim3(NT), sizeof(PhysLds), st, C, *B);
+  (void)physics_nt();
+  hipLaunchKernelGGL(k_kinematics, dim3(B->N), dim3(64), sizeof(PhysLds), st, C, *B);
 }

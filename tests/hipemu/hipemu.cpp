@@ -103,6 +103,7 @@ static void resolve_wave(int lo, int hi) {
       if (kind == K_SHFL) src = f.arg & 63;
       else if (kind == K_SHFL_XOR) src = lane ^ f.arg;
       else if (kind == K_SHFL_DOWN) src = lane + f.arg;
+      else if (kind == K_SHFL_UP) src = lane - f.arg;
       f.result = (src >= 0 && src < 64 && ((mask >> src) & 1ull)) ? g_f[lo + src].value : f.value;
     }
     for (int m = 0; m < nm; ++m) g_f[members[m]].st = RUN;

@@ -48,7 +48,7 @@ struct Idx { unsigned x, y, z; };
 extern Idx g_tid, g_bid, g_bdim, g_gdim;   // refreshed by the scheduler every time a fiber is resumed
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void barrier();
-enum { K_BALLOT = 0, K_SHFL = 1, K_SHFL_XOR = 2, K_SHFL_DOWN = 3 };
+enum { K_BALLOT = 0, K_SHFL = 1, K_SHFL_XOR = 2, K_SHFL_DOWN = 3, K_SHFL_UP = 4, K_WAVE_SYNC = 5 };
 unsigned long long collective(int kind, uint32_t value, int arg, const void* site);
 }  // namespace hipemu
 
@@ -83,6 +83,14 @@ static inline unsigned hipemu_shfl(int site, int kind, unsigned v, int arg, int 
 #define __shfl(...) hipemu_shfl(__COUNTER__, hipemu::K_SHFL, __VA_ARGS__)
 #define __shfl_xor(...) hipemu_shfl(__COUNTER__, hipemu::K_SHFL_XOR, __VA_ARGS__)
 #define __shfl_down(...) hipemu_shfl(__COUNTER__, hipemu::K_SHFL_DOWN, __VA_ARGS__)
+#define __shfl_up(...) hipemu_shfl(__COUNTER__, hipemu::K_SHFL_UP, __VA_ARGS__)
+// wave-synchronous sections (LDS written by one lane, read by another lane of the SAME wave, no workgroup barrier): on the GPU the
+// wave executes in lockstep and the builtins below only constrain the compiler; here they are a rendezvous of the wave's lanes
+#define __builtin_amdgcn_wave_barrier() ((void)hipemu::collective(hipemu::K_WAVE_SYNC, 0u, 0, (const void*)(intptr_t)(__COUNTER__ + 1)))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_s_sleep(p) ((void)0)
 
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
