@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDX_ABI_VERSION 4
+#define SDX_ABI_VERSION 5
 
 /* ---- fixed scene dimensions of BlockAssemblyGraspSim (GS:523-1058) ---- */
 #define SDX_NLINK 24        /* robot bodies after collapse_fixed_joints (GS:543); body 0 is the fixed base  */
@@ -105,7 +105,10 @@ typedef enum {
   SDX_T_SEG_IMAGE = 38,    /* i16 [N,128,128]   Search: segmentation image of the last render (0 = background / robot / bin, i+1 = brick i)  SE:877 */
   SDX_T_SEG_PIXELS = 39,   /* f32 [N,4]         Search: target pixel count, centroid row, centroid column, count of the render before   SE:1232-1241 */
   SDX_T_EMERGENCE = 40,    /* f32 [N]           Search: extras["emergence_reward"] = 5 x change of the pixel count                    SE:1640-1646 */
-  SDX_T_COUNT = 41
+  SDX_T_JACOBIAN = 41,     /* f32 [N,23,6,23]   acquire_jacobian_tensor(sim, "hand") of a fixed-base articulation: link k+1 is row k, rows 0..2 linear,
+                            *                    3..5 angular; the task reads [:, 7-1, :, :7] (GS:241,1601).  Refreshed by sdx_refresh_kinematics()
+                            *                    (= gym.refresh_jacobian_tensors, GS:1095), NOT by sdx_step/sdx_simulate, which keep SDX_T_JAC_EEF current */
+  SDX_T_COUNT = 42
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the
@@ -237,6 +240,16 @@ int sdx_reset_idx(sdx_handle h, const uint8_t* env_mask_dev, const int32_t* pile
  * SDX_T_EMERGENCE (gym.render_all_camera_sensors + the pixel statistics of SE:1232-1241,1640-1646).  task_kind 3 only. */
 int sdx_render_segmentation(sdx_handle h, void* stream);
 int sdx_refresh_kinematics(sdx_handle h, void* stream);
+
+/* set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed / set_dof_position_target_tensor_indexed
+ * (GS:1355,1514,1539,1543; gymtorch.unwrap_tensor(...) + int32 sim-domain actor indices): applies the rows of `src_dev` that belong to
+ * the listed actors.  id selects the state: SDX_T_ROOT (src f32 [N*142,13]: rows of the listed actors -> SDX_T_ROOT and the actor's
+ * body row of SDX_T_RB; the robot's fixed base ignores it), SDX_T_DOF (src f32 [N*23,2]) or SDX_T_TARGETS (src f32 [N,23]): the
+ * listed actors must be hand actors (slot 0 of an env, index env*142) and all 23 rows of that env are taken; SDX_T_DOF also refreshes
+ * the link states and Jacobians of every env (sdx_refresh_kinematics).  src_dev may be the library's own tensor (the caller edited
+ * it in place, as the reference does with root_state_tensor / dof_state) or a tensor of the caller's (as the reference's cur_targets).
+ * actor_ids_dev: device i32 [n]; actor index = env * SDX_ACTORS + slot.  Out-of-range ids are ignored. */
+int sdx_set_indexed(sdx_handle h, int32_t id, const float* src_dev, const int32_t* actor_ids_dev, int32_t n, void* stream);
 
 int sdx_num_envs(sdx_handle h);
 const char* sdx_last_error(sdx_handle h);   /* never NULL; h may be NULL for create-time errors */

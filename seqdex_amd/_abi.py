@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libseqdex_hip.so")
 
-SDX_ABI_VERSION = 4
+SDX_ABI_VERSION = 5
 NLINK, NDOF, MAX_RBOX, NBRICK, NFREE, NBRICK_TYPES, MAX_STATIC = 24, 23, 32, 132, 72, 8, 8
 ACTORS, BODIES, ACTOR_BRICK0, BODY_BRICK0 = 142, 165, 9, 32
 NUM_OBS, NUM_STATES, NUM_ACTIONS, OBS_FRAME, STATE_FRAME = 396, 564, 23, 132, 188
@@ -73,7 +73,7 @@ T = dict(ROOT=0, DOF=1, RB=2, CONTACT=3, JAC_EEF=4, TARGETS=5, PREV_TARGETS=6, O
          STATES_CLAMPED=10, REW=11, RESET=12, PROGRESS=13, RANDOMIZE=14, ACTIONS=15, INIT_POS=16, INIT_ROT=17,
          SUCCESSES=18, META_REW=19, CONS_SUCCESSES=20, FINGER_DIST=21, TVALUE=22, ARM_CONTACTS=23, STUDENT_OBS=24,
          SUCCESS_BUF=25, PILE_CHOICE=26, NCONTACTS=27, DEBUG=28, HARVEST_HAND=29, HARVEST_OBJ=30,
-         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35, PILE_HARVEST=36, PILE_HARVEST_COUNT=37, SEG_IMAGE=38, SEG_PIXELS=39, EMERGENCE=40)
+         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35, PILE_HARVEST=36, PILE_HARVEST_COUNT=37, SEG_IMAGE=38, SEG_PIXELS=39, EMERGENCE=40, JACOBIAN=41)
 # sdxp_tensor_id
 TP = dict(AC_PARAMS=0, AC_GRADS=1, CV_PARAMS=2, CV_GRADS=3, MB_OBS=4, MB_STATES=5, MB_ACTIONS=6, MB_MUS=7,
           MB_SIGMAS=8, MB_NEGLOGP=9, MB_VALUES=10, MB_REWARDS=11, MB_DONES=12, RETURNS=13, ADVANTAGES=14,
@@ -82,7 +82,7 @@ TP = dict(AC_PARAMS=0, AC_GRADS=1, CV_PARAMS=2, CV_GRADS=3, MB_OBS=4, MB_STATES=
 
 SDX_EXPORTS = ["sdx_create", "sdx_destroy", "sdx_tensor", "sdx_load_initial_states", "sdx_set_tvalue_weights",
                "sdx_step", "sdx_pre_physics", "sdx_simulate", "sdx_post_physics", "sdx_compute_observations",
-               "sdx_reset_idx", "sdx_refresh_kinematics", "sdx_render_segmentation", "sdx_num_envs", "sdx_last_error",
+               "sdx_reset_idx", "sdx_set_indexed", "sdx_refresh_kinematics", "sdx_render_segmentation", "sdx_num_envs", "sdx_last_error",
                "sdxp_create", "sdxp_destroy", "sdxp_tensor", "sdxp_param_count", "sdxp_act", "sdxp_store_rewards",
                "sdxp_finish_rollout", "sdxp_get_values", "sdxp_discount_values", "sdxp_prepare_dataset", "sdxp_update", "sdxp_update_impl", "sdxp_update_status", "sdxp_backward", "sdxp_apply", "sdxp_backward_factors",
                "sdxp_grads_from_factors", "sdxp_apply_factors", "sdxp_get_state", "sdxp_set_state", "sdxp_last_error",
@@ -112,6 +112,7 @@ def load_library():
     for n in ["sdx_simulate", "sdx_post_physics", "sdx_compute_observations", "sdx_refresh_kinematics", "sdx_render_segmentation"]:
         getattr(lib, n).argtypes = [vp, vp]
     lib.sdx_reset_idx.argtypes = [vp, vp, vp, vp]
+    lib.sdx_set_indexed.argtypes = [vp, i32, vp, vp, i32, vp]
     lib.sdx_num_envs.argtypes = [vp]
     lib.sdx_last_error.argtypes = [vp]
     lib.sdx_last_error.restype = C.c_char_p

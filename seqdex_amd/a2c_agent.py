@@ -403,4 +403,4 @@ class A2CAgent:
         if state:
             self.ppo.set_state(**state)
         self.epoch_num, self.frame = ck.get("epoch", 0), ck.get("frame", 0)
-        self.last_mean_rewards = ck.get("last_mean_rewards", self.last_mean_rewards)
+        self.last_mean_rewards = ck.get("last_mean_rewards", getattr(self, "last_mean_rewards", -100500))

@@ -112,6 +112,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(rb, (size_t)N * SDX_BODIES * 13);
   ALLOC(contact, (size_t)N * SDX_BODIES * 3);
   ALLOC(jac, (size_t)N * 42);
+  ALLOC(jac_full, (size_t)N * (SDX_NLINK - 1) * 6 * SDX_NDOF);
   ALLOC(targets, (size_t)N * SDX_NDOF);
   ALLOC(prev_targets, (size_t)N * SDX_NDOF);
   ALLOC(obs, (size_t)N * SDX_NUM_OBS);
@@ -199,6 +200,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   else set_tensor(h, SDX_T_SEG_IMAGE, B.seg_image, SDX_I16, {1, 1, 1});   // placeholder: the camera belongs to Search
   set_tensor(h, SDX_T_SEG_PIXELS, B.seg_pix, SDX_F32, {N, 4});
   set_tensor(h, SDX_T_EMERGENCE, B.emergence, SDX_F32, {N});
+  set_tensor(h, SDX_T_JACOBIAN, B.jac_full, SDX_F32, {N, SDX_NLINK - 1, 6, SDX_NDOF});
 
   // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
   std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);
@@ -425,6 +427,33 @@ extern "C" int sdx_refresh_kinematics(sdx_handle h, void* stream) {
   if (!h) return SDX_ERR_INVALID;
   sdxk_kinematics(h->d_const, &h->buf, (hipStream_t)stream);
   return check_launch(h, "sdx_refresh_kinematics");
+}
+// one thread per (listed actor, column)
+__global__ void k_set_indexed(SdxBuf B, int id, const float* __restrict__ src, const int32_t* __restrict__ ids, int n) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  if (i >= n) return;
+  const int actor = ids[i];
+  if (actor < 0 || actor >= B.N * SDX_ACTORS) return;
+  const int e = actor / SDX_ACTORS, slot = actor % SDX_ACTORS;
+  if (id == SDX_T_ROOT) {
+    if (slot == 0 || t >= 13) return;                       // the hand actor has a fixed base: its root state is not settable
+    const float v = src[(size_t)actor * 13 + t];
+    B.root[(size_t)actor * 13 + t] = v;
+    B.rb[((size_t)e * SDX_BODIES + SDX_NLINK + slot - 1) * 13 + t] = v;
+  } else if (slot == 0) {
+    if (id == SDX_T_DOF) { if (t < SDX_NDOF * 2) B.dof[(size_t)e * SDX_NDOF * 2 + t] = src[(size_t)e * SDX_NDOF * 2 + t]; }
+    else if (t < SDX_NDOF) B.targets[(size_t)e * SDX_NDOF + t] = src[(size_t)e * SDX_NDOF + t];
+  }
+}
+extern "C" int sdx_set_indexed(sdx_handle h, int32_t id, const float* src_dev, const int32_t* actor_ids_dev, int32_t n, void* stream) {
+  if (!h) return SDX_ERR_INVALID;
+  if (!src_dev || !actor_ids_dev || n < 0 || (id != SDX_T_ROOT && id != SDX_T_DOF && id != SDX_T_TARGETS)) {
+    h->err = "sdx_set_indexed: id must be SDX_T_ROOT, SDX_T_DOF or SDX_T_TARGETS, src / ids non-NULL"; return SDX_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 0) hipLaunchKernelGGL(k_set_indexed, dim3(n), dim3(64), 0, st, h->buf, id, src_dev, actor_ids_dev, n);
+  if (id == SDX_T_DOF && n > 0) sdxk_kinematics(h->d_const, &h->buf, st);
+  return check_launch(h, "sdx_set_indexed");
 }
 extern "C" int sdx_num_envs(sdx_handle h) { return h ? h->buf.N : SDX_ERR_INVALID; }
 extern "C" const char* sdx_last_error(sdx_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }

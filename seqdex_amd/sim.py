@@ -133,6 +133,16 @@ class SdxSim:
             pc = C.c_void_p(pile_choice.data_ptr())
         self._check(self.lib.sdx_reset_idx(self.h, C.c_void_p(env_mask.data_ptr()), pc, _stream_ptr(self.device)))
 
+    def set_indexed(self, name, src, actor_ids):
+        """gym.set_{actor_root_state,dof_state,dof_position_target}_tensor_indexed: name in ROOT / DOF / TARGETS, src the full-size
+        tensor (the library's own view after in-place edits, or a tensor of the caller's), actor_ids int32 sim-domain actor indices"""
+        assert name in ("ROOT", "DOF", "TARGETS"), name
+        own = self._tensors[name]
+        assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and src.numel() == own.numel(), (src.shape, own.shape)
+        assert actor_ids.is_cuda and actor_ids.dtype == torch.int32 and actor_ids.is_contiguous()
+        self._check(self.lib.sdx_set_indexed(self.h, _abi.T[name], C.c_void_p(src.data_ptr()), C.c_void_p(actor_ids.data_ptr()),
+                                             int(actor_ids.numel()), _stream_ptr(self.device)))
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
             self._tensors.clear()

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "seqdex_amd", "csrc")
 _SO = os.path.join(HERE, "libsdx_emu.so")
 _SRCS = [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "physics_driver.cpp"), os.path.join(CSRC, "sdx_physics.hip")]
-_DEPS = _SRCS + [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(CSRC, "sdx_common.h"),
+_DEPS = _SRCS + [os.path.abspath(__file__), os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(CSRC, "sdx_common.h"),
                  os.path.join(CSRC, "sdx_const_build.h"), os.path.join(ROOT, "include", "seqdex.h")]
 _lib = None
 
@@ -26,7 +26,8 @@ def build(force=False):
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-w", "-x", "c++",
                                "-I", os.path.join(HERE, "include"), "-I", CSRC, "-c", src, "-o", obj])
         objs.append(obj)
-    subprocess.check_call(["g++", "-shared", "-o", _SO] + objs)
+    # -Bsymbolic: the product library may already be loaded RTLD_GLOBAL in this process and exports the same sdxk_* names
+    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", _SO] + objs)
     return _SO
 
 

@@ -189,6 +189,19 @@ def test_search_task_end_to_end(scene):
     assert int(task.extras["success_buf"].sum()) == tvc[0]
     st = obs["states"].cpu().numpy()
     assert not st[:, 96:120].any() and not st[:, 188:].any()
+    # the ring keeps every success of a brick-type group (512 slots, as Orient's), not only the latest one: a second episode adds to it
+    assert task.sim.PILE_HARVEST.shape[1] == 512
+    for t in range(75):
+        env.step(((torch.rand(n, 23, generator=g) * 2 - 1) * 0.3).cuda())
+    torch.cuda.synchronize()
+    tvc2, pc2 = task.sim.TV_COUNT.cpu().numpy(), task.sim.PILE_HARVEST_COUNT.cpu().numpy()
+    assert tvc2.sum() == 2 * n and pc2.sum() == tvc2[0] and (pc2 >= pc).all(), (tvc2, pc2)
+    ring = task.sim.PILE_HARVEST.cpu().numpy()
+    for grp in range(8):
+        for slot in range(min(int(pc2[grp]), 4)):
+            assert np.abs(ring[grp, slot, :72, :3]).max() > 0.1, (grp, slot)     # a pile state was stored in every counted slot
+        if pc2[grp] >= 2:
+            assert np.abs(ring[grp, 0] - ring[grp, 1]).max() > 1e-4              # ... and the second success did not overwrite the first
     piles = task.pile_terminal_states()
     if piles is not None:                                                        # every brick-type group had a success
         ocfg = yaml.safe_load(open(os.path.join(root_dir, "seqdex_amd/cfg/allegro_hand_block_assembly_orient.yaml")))

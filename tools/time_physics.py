@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""k_physics timing on one MI355X: average launch time at N envs (HIP events) and the phase clock of env 0 (SDX_T_DEBUG stamps).
+usage: [SDX_PHYS_NT=384|512] python tools/time_physics.py [N] [warm-steps]"""
+import json
+import os
+import sys
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from seqdex_amd.tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+cfg = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd/cfg/allegro_hand_block_assembly_grasp_sim.yaml")))
+cfg["env"]["numEnvs"] = n
+task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=0, headless=True, seed=22, piles_per_type=8)
+s = task.sim
+g = torch.Generator().manual_seed(0)
+for _ in range(warm):                         # random flailing: the contact-rich workload of the bench
+    task.step((torch.rand(n, 23, generator=g) * 2 - 1).cuda())
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 20
+e0.record()
+for _ in range(reps):
+    s.simulate()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+d = s.DEBUG.cpu().numpy().astype("int64")
+nc = s.NCONTACTS.cpu().numpy()
+ph = {"fk+inertia": d[1] - d[0], "mass_matrix": d[2] - d[1], "drive": d[3] - d[2], "collide": d[4] - d[3], "solve": d[5] - d[4],
+      "integrate": d[6] - d[5], "solve_setup": d[17] - d[16], "it_A": d[19] - d[18], "it_C": d[20] - d[19],
+      "it_D": (d[21] if d[21] > d[20] else d[22]) - d[20], "it_robot": (d[22] - d[21]) if d[21] > d[20] else 0, "it_total": d[22] - d[18]}
+print(json.dumps({"threads_per_env": int(s.lib.sdxk_physics_threads()), "n_envs": n, "k_physics_ms": ms,
+                  "env_steps_per_s": n / (ms * 1e-3), "contacts_mean": float(nc.mean()), "contacts_max": int(nc.max()),
+                  "phase_cycles_env0_substep0": {k: int(v) for k, v in ph.items()}}))
