@@ -61,6 +61,15 @@ struct SdxBuf {
   float* insert_aux;       // [N,8] InsertSim: 0..2 rot_err of the last pre_physics_step (IS:1539), 3 |brick - site|, 4 rot_dist
 };
 
+// An empty asm the compiler must assume rewrites x: values derived from x afterwards (LDS addresses of the same rows in every
+// solver iteration) are recomputed where they are used instead of being kept in registers across the loop.  (tests/hipemu compiles
+// the kernels with g++ for the CPU, where the constraint letter does not exist.)
+#ifdef HIPEMU
+#define SDX_OPAQUE(x) ((void)0)
+#else
+#define SDX_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 

@@ -51,8 +51,8 @@ __constant__ float c_samp[SDX_NSAMP][3] = {
 
 struct PhysLds {
   // robot
-  float q[ND], qd[ND], tgt[ND], qds[ND], Q[ND], tau[ND];
-  float lq[NL][4], la[NL][3], lc[NL][3], lI[NL][6];
+  float q[ND], qd[ND + 1], tgt[ND], qds[ND], Q[ND], tau[ND];   // qd[ND] = 0: the padding dof of exhausted paths
+  float lq[NL][4], la[NL + 1][3], lc[NL][3], lI[NL][6];
   float lal[NL][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
   float A[ND][HP];      // H -> L -> Hinv
   uint32_t anc[NL];     // bit j: dof j lies on the path base -> link
@@ -68,24 +68,23 @@ struct PhysLds {
   float rc[SDX_MAX_RBOX][3], rq[SDX_MAX_RBOX][4], rh[SDX_MAX_RBOX][3], rrad[SDX_MAX_RBOX];
   int rbl[SDX_MAX_RBOX];
   float sth[SDX_MAX_STATIC][3], stc[SDX_MAX_STATIC][3];   // static boxes as THIS env sees them
-  int bcount[NF + 2];   // entries per brick (CSR build), then per iteration: ACTIVE contacts per brick, [NF] on the robot, [NF + 1] = 0 (static world)
-  int nc, np, overflow, nrobot, rfill, seg_brick, pad0;
-  int eoff[NF + 1], efill[NF];
+  int acount[NF + 2];   // per iteration: ACTIVE contacts per brick, [NF] on the whole robot, [NF + 1] = 0 (static world); integer atomics
+  int ecount[NF + NL];  // CSR build: contact sides per body
+  float lwr[NL][6];     // per iteration: wrench (F, M about the link origin) the contacts apply to each link
+  uint32_t desc[ND];    // bit k: link k lies below dof j
+  int nc, np, overflow, seg_brick;
+  int eoff[NF + NL + 1], efill[NF + NL];
   int wsum[16];
   // contacts: geometry in LDS for the whole solve
   float cp[3][MAXC], cn[3][MAXC];
   // three rows that are, in turn: the narrowphase's staging of (separation, body ids) + the candidate pair list; L^-1 of the mass
   // matrix; the unsorted CSR fill order during the solver set-up; and the per-contact impulse P of the current iteration
   float P[3][MAXC];
-  unsigned short ent[2 * MAXC];   // CSR entries: contact index | side << 15, grouped by brick, ascending contact index
-  unsigned short rent[MAXC];      // robot-side contact sides in ascending (contact, side) order
-  unsigned char rlink[MAXC];      // ... and the link each one touches
+  unsigned short ent[2 * MAXC];   // CSR entries: contact index | side << 15, grouped by body (bricks, then links), ascending contact index
 };
 #define S_T(S) (reinterpret_cast<float (*)[HP]>(&(S).P[0][0]))                       // L^-1 (mass matrix phase)
 #define S_PAIRS(S) (reinterpret_cast<uint32_t*>(&(S).P[2][0]))                       // candidate pairs (collide)
-#define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[0][0]))                  // unsorted brick-side entries (solver set-up)
-#define S_RENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[1][0]))                 // unsorted robot-side entries
-#define S_RLINK2(S) (reinterpret_cast<unsigned char*>(&(S).P[2][0]))                 // ... and the links they touch
+#define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[0][0]))                  // unsorted CSR entries (solver set-up)
 static_assert(ND * HP <= MAXC, "L^-1 must fit one row");
 static_assert(MAXP <= MAXC, "the pair list must fit one row");
 static_assert(sizeof(PhysLds) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
@@ -284,14 +283,16 @@ __device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid,
   WAVE_SYNC();
 }
 
-// link twists from qd, on wave 0: w_k = sum_j a_j qd_j, v_k = sum_j (a_j qd_j) x (p_k - p_j) over the dofs j on the path
+// link twists from qd, on wave 0: w_k = sum_j a_j qd_j, v_k = sum_j (a_j qd_j) x (p_k - p_j) over the dofs j on the path (<= 11 of them:
+// 7 arm joints + 4 of one finger).  Fixed trip count, no branches: an exhausted path reads dof ND, whose velocity slot is zero
 __device__ __forceinline__ void twists_wave0(PhysLds& S, int tid) {
   if (tid > 0 && tid < NL) {
     f3 w = F3(0, 0, 0), v = F3(0, 0, 0);
     const f3 pk = ld3(S.bp[NF + tid]);
     uint32_t m = S.anc[tid];
-    while (m) {
-      const int j = __ffs(m) - 1;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+      const int j = m ? __ffs(m) - 1 : ND;
       m &= m - 1;
       const f3 aj = ld3(S.la[j + 1]) * S.qd[j];
       w = w + aj;
@@ -448,7 +449,7 @@ __device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int
 }
 
 template <int NT>
-__device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid) {
+__device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, long long* dbg) {
   const sdx_scene_desc& sc = C->sc;
   const float off = sc.contact_offset;
   const int ns = sc.n_static;
@@ -461,6 +462,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid) 
       if (candidate(S, idx, n1, n2, ns, per, off)) mask |= 1u << it;
     }
   }
+  SSTAMP(32);
   int np;
   {
     // at most 15 candidates per lane: (72 * 8 + 72 * 71 / 2 + 32 * 80) / 384 < 15
@@ -475,6 +477,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid) 
   }
   if (np > MAXP) np = MAXP;
   __syncthreads();
+  SSTAMP(33);
   // ---- narrowphase: lane = candidate pair; contacts appended in pair order (block prefix sum of the counts)
   int nc = 0;
   for (int base = 0; base < np; base += NT) {
@@ -538,8 +541,8 @@ __device__ __forceinline__ float robot_w(const PhysLds& S, int k, f3 p, f3 d) {
 template <int NT>
 __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last_substep, long long* dbg) {
   constexpr int CPT = MAXC / NT;   // contact rows owned by one lane
+  constexpr int NB = NF + NL;      // bodies with a CSR list: bricks 0..71, links 72..95
   static_assert(CPT * NT == MAXC, "NT must divide SDX_MAXC");
-  static_assert(NF * GL <= NT, "gather lanes");
   const sdx_scene_desc& sc = C->sc;
   const int nc = S.nc;
   const float mu = sc.friction, relax = sc.jacobi_relax;
@@ -559,21 +562,23 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       vtgt[q] = sep > 0 ? -sep / h : fminf(sc.baumgarte * (-sep) / h, sc.max_depenetration_vel);
     }
   }
-  // ---- CSR of contact sides per brick (ascending contact index inside a brick)
-  for (int i = tid; i < NF; i += NT) { S.bcount[i] = 0; S.efill[i] = 0; }
-  if (tid == 0) { S.nrobot = 0; S.rfill = 0; }
-  __syncthreads();   // also: every lane has read its (separation, ids) out of the staging rows, which the fill lists reuse below
+  SSTAMP(23);
+  // ---- CSR of contact sides per body (bricks AND robot links), ascending contact index inside a body
+  for (int i = tid; i < NB; i += NT) { S.ecount[i] = 0; S.efill[i] = 0; }
+  if (last_substep) for (int i = tid; i < NL * 3; i += NT) (&S.cf[0][0])[i] = 0.0f;
+  __syncthreads();   // also: every lane has read its (separation, ids) out of the staging rows, which the fill list reuses below
 #pragma unroll
   for (int q = 0; q < CPT; ++q)
     if (tid + q * NT < nc) {
       const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
-      if (a < NF) atomicAdd(&S.bcount[a], 1); else if (a != BODY_W) atomicAdd(&S.nrobot, 1);
-      if (b < NF) atomicAdd(&S.bcount[b], 1); else if (b != BODY_W) atomicAdd(&S.nrobot, 1);
+      if (a != BODY_W) atomicAdd(&S.ecount[a], 1);
+      if (b != BODY_W) atomicAdd(&S.ecount[b], 1);
     }
   __syncthreads();
-  if (tid < 64) {   // exclusive prefix over the 72 bricks on wave 0: two bricks per lane, shuffle scan
+  SSTAMP(24);
+  if (tid < 64) {   // exclusive prefix over the 96 bodies on wave 0: two per lane, shuffle scan
     const int i0 = 2 * tid, i1 = 2 * tid + 1;
-    const int c0 = i0 < NF ? S.bcount[i0] : 0, c1 = i1 < NF ? S.bcount[i1] : 0;
+    const int c0 = i0 < NB ? S.ecount[i0] : 0, c1 = i1 < NB ? S.ecount[i1] : 0;
     int incl = c0 + c1;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -581,37 +586,31 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       if (tid >= o) incl += up;
     }
     const int excl = incl - (c0 + c1);
-    if (i0 < NF) S.eoff[i0] = excl;
-    if (i1 < NF) S.eoff[i1] = excl + c0;
-    if (i1 == NF - 1 || i0 == NF - 1) S.eoff[NF] = incl;
+    if (i0 < NB) S.eoff[i0] = excl;
+    if (i1 < NB) S.eoff[i1] = excl + c0;
+    if (i1 == NB - 1 || i0 == NB - 1) S.eoff[NB] = incl;
   }
   __syncthreads();
+  SSTAMP(25);
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
     if (c < nc) {
       const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
-      if (a < NF) S_ENT2(S)[S.eoff[a] + atomicAdd(&S.efill[a], 1)] = (unsigned short)c;
-      else if (a != BODY_W) {
-        const int i = atomicAdd(&S.rfill, 1);
-        if (i < MAXC) { S_RENT2(S)[i] = (unsigned short)c; S_RLINK2(S)[i] = (unsigned char)(a - NF); }
-      }
-      if (b < NF) S_ENT2(S)[S.eoff[b] + atomicAdd(&S.efill[b], 1)] = (unsigned short)(c | 0x8000);
-      else if (b != BODY_W) {
-        const int i = atomicAdd(&S.rfill, 1);
-        if (i < MAXC) { S_RENT2(S)[i] = (unsigned short)(c | 0x8000); S_RLINK2(S)[i] = (unsigned char)(b - NF); }
-      }
+      if (a != BODY_W) S_ENT2(S)[S.eoff[a] + atomicAdd(&S.efill[a], 1)] = (unsigned short)c;
+      if (b != BODY_W) S_ENT2(S)[S.eoff[b] + atomicAdd(&S.efill[b], 1)] = (unsigned short)(c | 0x8000);
     }
   }
   __syncthreads();
-  const int nrob = min(S.nrobot, MAXC);
-  const bool has_robot = nrob > 0;   // block-uniform
-  // rank pass: entry -> position = number of entries of the same brick with a smaller contact index (a contact touches a brick at
-  // most once, so indices are distinct) => every brick's list is in ascending contact order, deterministically
+  SSTAMP(26);
+  const int rbeg = S.eoff[NF], nrob = S.eoff[NB] - rbeg;   // the robot's sides: entries [rbeg, rbeg + nrob), grouped by link
+  const bool has_robot = nrob > 0;                          // block-uniform
+  // rank pass: entry -> position = number of entries of the same body with a smaller contact index (a contact touches a body at
+  // most once, so indices are distinct) => every body's list is in ascending contact order, deterministically
   {
-    const int total = S.eoff[NF];
+    const int total = S.eoff[NB];
     for (int i = tid; i < total; i += NT) {
-      int lo = 0, hi = NF;                       // brick of entry i: largest b with eoff[b] <= i
+      int lo = 0, hi = NB;                       // body of entry i: largest b with eoff[b] <= i
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.eoff[mid] <= i) lo = mid; else hi = mid; }
       const int o = S.eoff[lo], n = S.eoff[lo + 1] - o;
       const unsigned short v = S_ENT2(S)[i];
@@ -620,16 +619,8 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       for (int j = 0; j < n; ++j) rank += (S_ENT2(S)[o + j] & 0x7fff) < key;
       S.ent[o + rank] = v;
     }
-    // the same for the robot-side list (one list for the whole robot; key = contact index, then side)
-    for (int i = tid; i < nrob; i += NT) {
-      const unsigned short v = S_RENT2(S)[i];
-      const int key = ((v & 0x7fff) << 1) | (v >> 15);
-      int rank = 0;
-      for (int j = 0; j < nrob; ++j) { const unsigned short u = S_RENT2(S)[j]; rank += (((u & 0x7fff) << 1) | (u >> 15)) < key; }
-      S.rent[rank] = v;
-      S.rlink[rank] = S_RLINK2(S)[i];
-    }
   }
+  SSTAMP(27);
   // ---- un-split inverse effective masses of the BRICK sides (owner lanes); zero accumulated impulses
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
@@ -649,11 +640,15 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     }
   }
   if (tid < ND) S.qds[tid] = S.qd[tid];
-  __syncthreads();   // rank pass complete (ent / rent / rlink final); the fill lists in the P rows are dead from here on
-  // ---- robot sides: one lane per (contact, side) of the ordered robot list computes J Hinv J^T of its three rows -> P rows
+  __syncthreads();   // rank pass complete (ent final); the fill list in the P rows is dead from here on
+  SSTAMP(28);
+  // ---- robot sides: one lane per (contact, side) of the robot's entries computes J Hinv J^T of its three rows -> P rows
   if (has_robot) {
     for (int r = tid; r < nrob; r += NT) {
-      const int c = S.rent[r] & 0x7fff, k = S.rlink[r];
+      const int i = rbeg + r;
+      int lo = NF, hi = NB;                       // link of entry i
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.eoff[mid] <= i) lo = mid; else hi = mid; }
+      const int c = S.ent[i] & 0x7fff, k = lo - NF;
       const f3 p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]), n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
       f3 t1, t2;
       tangents(n, &t1, &t2);
@@ -662,7 +657,8 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       S.P[2][r] = robot_w(S, k, p, t2);
     }
     __syncthreads();
-    // owner lanes fetch them: position of (contact, side) in the ordered list by binary search (keys are distinct)
+    SSTAMP(29);
+    // owner lanes fetch them: position of the contact in its link's list by binary search (ascending contact index)
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
       const int c = tid + q * NT;
@@ -672,14 +668,12 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         for (int side = 0; side < 2; ++side) {
           const int id = side ? b : a;
           if (id >= NF && id != BODY_W) {
-            const int key = (c << 1) | side;
-            int lo = 0, hi = nrob;   // first position whose key is >= key
+            int lo = S.eoff[id], hi = S.eoff[id + 1];   // first position whose contact index is >= c
             while (lo < hi) {
               const int mid = (lo + hi) >> 1;
-              const unsigned short u = S.rent[mid];
-              if ((((u & 0x7fff) << 1) | (u >> 15)) < key) lo = mid + 1; else hi = mid;
+              if ((S.ent[mid] & 0x7fff) < c) lo = mid + 1; else hi = mid;
             }
-            const float w0 = S.P[0][lo], w1 = S.P[1][lo], w2 = S.P[2][lo];
+            const float w0 = S.P[0][lo - rbeg], w1 = S.P[1][lo - rbeg], w2 = S.P[2][lo - rbeg];
             if (side) { wB[q][0] = w0; wB[q][1] = w1; wB[q][2] = w2; }
             else { wA[q][0] = w0; wA[q][1] = w1; wA[q][2] = w2; }
           }
@@ -687,25 +681,42 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       }
     }
   }
-  // gather lanes: GL lanes per brick (tid = GL*brick + sub); lane sub sums entries sub, sub + GL, ... of its brick's list
-  const int gbrick = tid / GL, gsub = tid % GL;
-  const bool glane = gbrick < NF;
+  SSTAMP(30);
+  // gather lanes: GL = 4 lanes per brick (tid = 4 * brick + sub), LL = 8 per link (links in the pile collect far more contacts than
+  // a brick does); lane sub sums entries sub, sub + stride, ... of its body's list
+  constexpr int LL = (NT - NF * GL >= NL * 8) ? 8 : 4;
+  static_assert(NF * GL + NL * LL <= NT, "gather lanes");
+  const bool blane = tid < NF * GL;
+  const int gbody = blane ? tid / GL : NF + (tid - NF * GL) / LL, gsub = blane ? tid % GL : (tid - NF * GL) % LL;
+  const int gstride = blane ? GL : LL;
+  const bool glane = gbody < NB;
   int gbeg = 0, gend = 0;
   float g_im = 0.0f, g_ii0 = 0.0f, g_ii1 = 0.0f, g_ii2 = 0.0f;
   if (glane) {
-    gbeg = S.eoff[gbrick] + gsub; gend = S.eoff[gbrick + 1];
-    g_im = S.bim[gbrick]; g_ii0 = S.bii[gbrick][0]; g_ii1 = S.bii[gbrick][1]; g_ii2 = S.bii[gbrick][2];
+    gbeg = S.eoff[gbody] + gsub; gend = S.eoff[gbody + 1];
+    if (gbody < NF) { g_im = S.bim[gbody]; g_ii0 = S.bii[gbody][0]; g_ii1 = S.bii[gbody][1]; g_ii2 = S.bii[gbody][2]; }
+  }
+  // links that carry contacts in this substep (block-uniform mask), and per robot lane: the touched links below its dof
+  uint32_t touched = 0;
+  if (has_robot)
+    for (int k = 0; k < NL; ++k) if (S.eoff[NF + k + 1] > S.eoff[NF + k]) touched |= 1u << k;
+  // robot section lanes: 8 per dof (stages 1, 2) / per link (stage 3): rj = dof or link, rs = lane within the group
+  const int rj = tid / 8, rs = tid % 8;
+  const uint32_t mydesc = (rj < ND) ? (S.desc[rj] & touched) : 0u;
+  int tj0 = ND, tj1 = ND;   // the rs-th and (rs + 8)-th dof on the path base -> link rj
+  if (rj < NL) {
+    uint32_t m = S.anc[rj];
+    for (int t = 0; m; ++t) {
+      const int j = __ffs(m) - 1;
+      m &= m - 1;
+      if (t == rs) tj0 = j;
+      if (t == rs + 8) tj1 = j;
+    }
   }
   // ACTIVE-contact counts per iteration: slots 0..71 bricks, NF = the whole robot, NF + 1 = the static world (stays zero)
-  for (int i = tid; i < NF + 2; i += NT) S.bcount[i] = 0;
+  for (int i = tid; i < NF + 2; i += NT) S.acount[i] = 0;
   __syncthreads();
   SSTAMP(17);
-  // robot gather lanes: RL lanes per dof over the ordered robot-side list, on the lanes the brick gather leaves free
-  constexpr int RL = (NT - NF * GL >= ND * 8) ? 8 : 4;
-  static_assert(NT - NF * GL >= ND * RL, "robot gather lanes");
-  const int rt = tid - NF * GL;
-  const bool rlane = has_robot && rt >= 0 && rt < ND * RL;
-  const int rj = rlane ? rt / RL : 0, rsub = rt % RL;
 
   for (int it = 0; it < sc.solver_iters; ++it) {
     if (it == 1) dbg = nullptr;
@@ -716,15 +727,17 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
       vr[q] = F3(0, 0, 0);
-      const int c = tid + q * NT;
+      int abq = ab[q], ct = tid;
+      SDX_OPAQUE(abq); SDX_OPAQUE(ct);
+      const int c = ct + q * NT;
       if (c < nc) {
-        const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
+        const int a = abq & 0xff, b = (abq >> 8) & 0xff;
         const f3 p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]), n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
         vr[q] = point_vel(S, a, p) - point_vel(S, b, p);
         if (lam[q][0] > 0.0f || dot(vr[q], n) < vtgt[q]) {
           actm |= 1u << q;
-          if (a != BODY_W) atomicAdd(&S.bcount[a < NF ? a : NF], 1);
-          if (b != BODY_W) atomicAdd(&S.bcount[b < NF ? b : NF], 1);
+          if (a != BODY_W) atomicAdd(&S.acount[a < NF ? a : NF], 1);
+          if (b != BODY_W) atomicAdd(&S.acount[b < NF ? b : NF], 1);
         }
       }
     }
@@ -733,15 +746,17 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     // ---- [C] lane = contact: Jacobi update from the same velocity snapshot; impulse P (on body A) to LDS, zero when inactive
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
-      const int c = tid + q * NT;
+      int abq = ab[q], ct = tid;
+      SDX_OPAQUE(abq); SDX_OPAQUE(ct);
+      const int c = ct + q * NT;
       f3 P = F3(0, 0, 0);
       if ((actm >> q) & 1u) {
-        const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
+        const int a = abq & 0xff, b = (abq >> 8) & 0xff;
         const f3 n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
         f3 t1, t2;
         tangents(n, &t1, &t2);
-        const float na = (float)S.bcount[a < NF ? a : (a != BODY_W ? NF : NF + 1)];
-        const float nb = (float)S.bcount[b < NF ? b : (b != BODY_W ? NF : NF + 1)];
+        const float na = (float)S.acount[a < NF ? a : (a != BODY_W ? NF : NF + 1)];
+        const float nb = (float)S.acount[b < NF ? b : (b != BODY_W ? NF : NF + 1)];
         const float w0 = na * wA[q][0] + nb * wB[q][0];
         const float w1 = na * wA[q][1] + nb * wB[q][1];
         const float w2 = na * wA[q][2] + nb * wB[q][2];
@@ -759,108 +774,99 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     }
     __syncthreads();
     SSTAMP(20);
-    // ---- [D] gather (GL lanes per brick): dv = sum(+-P)/m, dw = Iw^-1 sum(+-(p - x) x P); each lane sums its slice in ascending
-    // contact order, the partial sums are combined in a fixed order (deterministic); inactive contacts carry P = 0
+    // ---- [D] gather (GL lanes per body): F = sum(+-P), M = sum(+-(p - x) x P) about the body's reference point x; each lane sums its
+    // slice in ascending contact order, the partial sums are combined in a fixed order (deterministic); inactive contacts carry P = 0.
+    // Bricks: dv = F / m, dw = Iw^-1 M.  Links: the wrench (F, M about the link origin) goes to LDS for the robot section below.
     if (glane) {
       float acc[6] = {0, 0, 0, 0, 0, 0};
-      const f3 x = ld3(S.bp[gbrick]);
-      // two entries per trip (both index loads, then both payloads, in flight together); not unrolled further: the decoded
+      int gb = gbody;
+      SDX_OPAQUE(gb);
+      const f3 x = ld3(S.bp[gb]);
+      // four entries per trip (the index loads, then the payloads, in flight together); not unrolled further: the decoded
       // addresses of a longer window would be kept in registers across the whole iteration loop
 #pragma unroll 1
-      for (int i = gbeg; i < gend; i += 2 * GL) {
-        const bool two = i + GL < gend;
-        const int e0 = S.ent[i], e1 = two ? (int)S.ent[i + GL] : e0;
-        const int c0 = e0 & 0x7fff, c1 = e1 & 0x7fff;
-        const float s0 = (e0 & 0x8000) ? -1.0f : 1.0f, s1 = two ? ((e1 & 0x8000) ? -1.0f : 1.0f) : 0.0f;
-        const f3 P0 = F3(S.P[0][c0], S.P[1][c0], S.P[2][c0]) * s0, P1 = F3(S.P[0][c1], S.P[1][c1], S.P[2][c1]) * s1;
-        const f3 M0 = cross(F3(S.cp[0][c0], S.cp[1][c0], S.cp[2][c0]) - x, P0);
-        const f3 M1 = cross(F3(S.cp[0][c1], S.cp[1][c1], S.cp[2][c1]) - x, P1);
-        acc[0] += P0.x; acc[1] += P0.y; acc[2] += P0.z; acc[3] += M0.x; acc[4] += M0.y; acc[5] += M0.z;
-        acc[0] += P1.x; acc[1] += P1.y; acc[2] += P1.z; acc[3] += M1.x; acc[4] += M1.y; acc[5] += M1.z;
+      for (int i = gbeg; i < gend; i += 4 * gstride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int iu = i + u * gstride;
+          const bool on = iu < gend;
+          const int e = S.ent[on ? iu : i], c = e & 0x7fff;
+          const float sg = on ? ((e & 0x8000) ? -1.0f : 1.0f) : 0.0f;
+          const f3 P = F3(S.P[0][c], S.P[1][c], S.P[2][c]) * sg;
+          const f3 M = cross(F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]) - x, P);
+          acc[0] += P.x; acc[1] += P.y; acc[2] += P.z; acc[3] += M.x; acc[4] += M.y; acc[5] += M.z;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         acc[r] += __shfl_xor(acc[r], 1, 64);
         acc[r] += __shfl_xor(acc[r], 2, 64);
+        if (LL == 8 && !blane) acc[r] += __shfl_xor(acc[r], 4, 64);
       }
       if (gsub == 0) {
-        const f4 qq = ld4(S.bq[gbrick]);
-        const f3 l = qrot(qconj(qq), F3(acc[3], acc[4], acc[5]));
-        const f3 dw = qrot(qq, F3(l.x * g_ii0, l.y * g_ii1, l.z * g_ii2));
-        st3(S.bv[gbrick], ld3(S.bv[gbrick]) + F3(acc[0], acc[1], acc[2]) * g_im);
-        st3(S.bw[gbrick], ld3(S.bw[gbrick]) + dw);
-        S.bcount[gbrick] = 0;   // read by [C] before the barrier above; counted afresh by [A] of the next iteration
-      }
-      if (tid == 0) S.bcount[NF] = 0;
-    }
-    if (rlane) {
-      // robot side: generalised impulse Q_j += sum over the robot's contact sides of a_j . ((p - o_j) x (+-P)) for the dofs j on the
-      // path to the touched link; RL lanes per dof walk the (contact, side)-ordered list with a fixed stride and combine in a fixed order
-      const f3 aj = ld3(S.la[rj + 1]), oj = ld3(S.bp[NF + rj + 1]);
-      float acc = 0.0f;
-      for (int i = rsub; i < nrob; i += RL) {
-        const int e = S.rent[i], c = e & 0x7fff;
-        if ((S.anc[S.rlink[i]] >> rj) & 1u) {
-          const f3 P = F3(S.P[0][c], S.P[1][c], S.P[2][c]);
-          const float t = dot(aj, cross(F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]) - oj, P));
-          acc += (e & 0x8000) ? -t : t;
+        if (gbody < NF) {
+          const f4 qq = ld4(S.bq[gbody]);
+          const f3 l = qrot(qconj(qq), F3(acc[3], acc[4], acc[5]));
+          const f3 dw = qrot(qq, F3(l.x * g_ii0, l.y * g_ii1, l.z * g_ii2));
+          st3(S.bv[gbody], ld3(S.bv[gbody]) + F3(acc[0], acc[1], acc[2]) * g_im);
+          st3(S.bw[gbody], ld3(S.bw[gbody]) + dw);
+          S.acount[gbody] = 0;   // read by [C] before the barrier above; counted afresh by [A] of the next iteration
+        } else {
+          const int k = gbody - NF;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) S.lwr[k][r] = acc[r];
+          if (last_substep) { S.cf[k][0] += acc[0]; S.cf[k][1] += acc[1]; S.cf[k][2] += acc[2]; }   // net impulse on the link so far
         }
       }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      if (RL == 8) acc += __shfl_xor(acc, 4, 64);
-      if (rsub == 0) S.Q[rj] += acc;
+      if (tid == 0) S.acount[NF] = 0;
     }
     if (has_robot) {
+      // robot section, three short stages on 8 lanes per dof / link with a workgroup barrier between them (a single wave walking
+      // the three dependent chains took 6-9 k cycles per iteration): Q += J^T (link wrenches); qd = qd* + Hinv Q; link twists
       __syncthreads();
       SSTAMP(21);
-      if (tid < 64) {   // wave 0: qd = qd* + Hinv Q, then the link twists, handed over wave-synchronously
-        if (tid < ND) {
-          float sacc = S.qds[tid];
-          for (int j = 0; j < ND; ++j) sacc += S.A[tid][j] * S.Q[j];
-          S.qd[tid] = sacc;
+      if (tid < ND * 8) {
+        // generalised impulse of dof j: sum over the touched links k below it of a_j . (M_k + (o_k - o_j) x F_k); lane rs takes links rs, rs+8, rs+16
+        const f3 aj = ld3(S.la[rj + 1]), oj = ld3(S.bp[NF + rj + 1]);
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int k = rs + 8 * u;
+          if ((mydesc >> k) & 1u) {
+            const f3 F = F3(S.lwr[k][0], S.lwr[k][1], S.lwr[k][2]), M = F3(S.lwr[k][3], S.lwr[k][4], S.lwr[k][5]);
+            acc += dot(aj, M + cross(ld3(S.bp[NF + k]) - oj, F));
+          }
         }
-        WAVE_SYNC();
-        twists_wave0(S, tid);
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        if (rs == 0) S.Q[rj] += acc;
+      }
+      __syncthreads();
+      if (tid < ND * 8) {   // lane rs takes columns rs, rs+8, rs+16 of row rj
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int j = rs + 8 * u;
+          if (j < ND) acc += S.A[rj][j] * S.Q[j];
+        }
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        if (rs == 0) S.qd[rj] = S.qds[rj] + acc;
+      }
+      __syncthreads();
+      if (tid < NL * 8) {   // link twists: lane rs of link rj adds the terms of its (<= 2) dofs tj0, tj1 of the path (ND = none: zero velocity slot)
+        const f3 pk = ld3(S.bp[NF + rj]);
+        const f3 a0 = ld3(S.la[tj0 + 1]) * S.qd[tj0], a1 = ld3(S.la[tj1 + 1]) * S.qd[tj1];
+        f3 w = a0 + a1;
+        f3 v = cross(a0, pk - ld3(S.bp[NF + tj0 + 1])) + cross(a1, pk - ld3(S.bp[NF + tj1 + 1]));
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+          w.x += __shfl_xor(w.x, o, 64); w.y += __shfl_xor(w.y, o, 64); w.z += __shfl_xor(w.z, o, 64);
+          v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64);
+        }
+        if (rs == 0 && rj > 0) { st3(S.bw[NF + rj], w); st3(S.bv[NF + rj], v); }
       }
     }
     __syncthreads();
     SSTAMP(22);
-  }
-  // net contact force on the robot bodies from the last substep's accumulated impulses (GS:1094; bodies 1..6 are read)
-  if (last_substep) {
-    for (int i = tid; i < NL * 3; i += NT) (&S.cf[0][0])[i] = 0.0f;
-    if (has_robot) {
-      const float ih = 1.0f / h;
-#pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        const int c = tid + q * NT;
-        if (c < nc) {
-          const f3 n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
-          f3 t1, t2;
-          tangents(n, &t1, &t2);
-          const f3 F = (n * lam[q][0] + t1 * lam[q][1] + t2 * lam[q][2]) * ih;
-          S.P[0][c] = F.x; S.P[1][c] = F.y; S.P[2][c] = F.z;
-        }
-      }
-      __syncthreads();
-      constexpr int FL = 8;
-      if (tid < NL * FL) {   // 8 lanes per link over the ordered robot-side list, fixed combination order
-        const int k = tid / FL, fsub = tid % FL;
-        float ax = 0.0f, ay = 0.0f, az = 0.0f;
-        for (int i = fsub; i < nrob; i += FL) {
-          if (S.rlink[i] == k) {
-            const int e = S.rent[i], c = e & 0x7fff;
-            const float sg = (e & 0x8000) ? -1.0f : 1.0f;
-            ax += sg * S.P[0][c]; ay += sg * S.P[1][c]; az += sg * S.P[2][c];
-          }
-        }
-#pragma unroll
-        for (int o = 1; o < FL; o <<= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
-        if (fsub == 0) { S.cf[k][0] = ax; S.cf[k][1] = ay; S.cf[k][2] = az; }
-      }
-    }
-    __syncthreads();
   }
 }
 
@@ -897,6 +903,12 @@ __device__ __forceinline__ void load_constants(const SdxConst* C, PhysLds& S, in
     st3(S.bp[BODY_W], F3(0, 0, 0)); st3(S.bv[BODY_W], F3(0, 0, 0)); st3(S.bw[BODY_W], F3(0, 0, 0));   // the static world
   }
   if (tid < NL) S.anc[tid] = C->anc[tid];
+  if (tid < ND) {
+    uint32_t d = 0;
+    for (int k = 1; k < NL; ++k) d |= ((C->anc[k] >> tid) & 1u) << k;
+    S.desc[tid] = d;
+  }
+  if (tid == 0) { S.qd[ND] = 0.0f; st3(S.la[NL], F3(0, 0, 0)); }
   for (int i = tid; i < NF; i += NT) {
     const int t = sc.brick_type[i];
     st3(S.bh[i], ld3(sc.brick_half[t]));
@@ -982,7 +994,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     }
     __syncthreads();
     PSTAMP(3);
-    collide<NT>(C, S, tid);
+    collide<NT>(C, S, tid, sub == 0 ? B.dbg : nullptr);
     PSTAMP(4);
     solve<NT>(C, S, tid, h, sub == sc.substeps - 1, sub == 0 ? B.dbg : nullptr);
     PSTAMP(5);
@@ -1030,7 +1042,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     root_e[SDX_ACTOR_BRICK0 * 13 + i] = v;
     rb_e[SDX_BODY_BRICK0 * 13 + i] = v;
   }
-  for (int i = tid; i < NL * 3; i += NT) B.contact[(size_t)e * SDX_BODIES * 3 + i] = (&S.cf[0][0])[i];
+  for (int i = tid; i < NL * 3; i += NT) B.contact[(size_t)e * SDX_BODIES * 3 + i] = (&S.cf[0][0])[i] * (1.0f / h);   // net impulse of the last substep / h
   if (tid == 0) B.ncontacts[e] = S.nc + S.overflow;
 }
 

@@ -34,6 +34,9 @@ d = s.DEBUG.cpu().numpy().astype("int64")
 nc = s.NCONTACTS.cpu().numpy()
 ph = {"fk+inertia": d[1] - d[0], "mass_matrix": d[2] - d[1], "drive": d[3] - d[2], "collide": d[4] - d[3], "solve": d[5] - d[4],
       "integrate": d[6] - d[5], "solve_setup": d[17] - d[16], "it_A": d[19] - d[18], "it_C": d[20] - d[19],
+      "setup_load": d[23] - d[16], "setup_count": d[24] - d[23], "setup_prefix": d[25] - d[24], "setup_fill": d[26] - d[25],
+      "setup_rank": d[27] - d[26], "setup_brickw": d[28] - d[27], "setup_robotw": d[29] - d[28], "setup_fetch": d[30] - d[29],
+      "setup_tail": d[17] - d[30], "broad_mask": d[32] - d[3], "broad_scan": d[33] - d[32], "narrow": d[4] - d[33],
       "it_D": (d[21] if d[21] > d[20] else d[22]) - d[20], "it_robot": (d[22] - d[21]) if d[21] > d[20] else 0, "it_total": d[22] - d[18]}
 print(json.dumps({"threads_per_env": int(s.lib.sdxk_physics_threads()), "n_envs": n, "k_physics_ms": ms,
                   "env_steps_per_s": n / (ms * 1e-3), "contacts_mean": float(nc.mean()), "contacts_max": int(nc.max()),
