@@ -70,6 +70,20 @@ struct SdxBuf {
 #define SDX_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
+// sums over aligned groups of 4 / 8 lanes with DPP moves (VALU speed; __shfl_xor goes through ds_bpermute and its LDS latency):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror.  Every lane of the group ends up with the group's sum; the order of the
+// additions is fixed (deterministic).  All lanes of the group must be active.
+__device__ __forceinline__ float sum4(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+__device__ __forceinline__ float sum8(float v) {
+  v = sum4(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 

@@ -64,6 +64,7 @@ struct PhysLds {
   float bq[NF][4];
   float bh[NF][3], brad[NF];
   float bim[NF], bii[NF][3];   // inverse mass / inverse principal inertia (target brick already scaled by 1 / seg_mass_scale)
+  float bK[NF][6];             // world inverse inertia R diag(1/I) R^T of the substep (xx yy zz xy xz yz)
   // robot collision boxes in the world
   float rc[SDX_MAX_RBOX][3], rq[SDX_MAX_RBOX][4], rh[SDX_MAX_RBOX][3], rrad[SDX_MAX_RBOX];
   int rbl[SDX_MAX_RBOX];
@@ -85,6 +86,7 @@ struct PhysLds {
 #define S_T(S) (reinterpret_cast<float (*)[HP]>(&(S).P[0][0]))                       // L^-1 (mass matrix phase)
 #define S_PAIRS(S) (reinterpret_cast<uint32_t*>(&(S).P[2][0]))                       // candidate pairs (collide)
 #define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[0][0]))                  // unsorted CSR entries (solver set-up)
+#define S_EBODY2(S) (reinterpret_cast<unsigned char*>(&(S).P[1][0]))                 // ... and the body each one belongs to
 static_assert(ND * HP <= MAXC, "L^-1 must fit one row");
 static_assert(MAXP <= MAXC, "the pair list must fit one row");
 static_assert(sizeof(PhysLds) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
@@ -513,29 +515,29 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
 }
 
 // ---------------------------------------------------------------- E: solver
-// row weight of the robot side: J Hinv J^T with J_j = (a_j x (p - p_j)) . d over the <= 11 dofs on the link's path
+// row weight of a robot-side contact: w = J Hinv J^T with J[j] = (a_j x (p - p_j)) . d over the <= 11 dofs on the link's path.  Hinv is
+// symmetric: every off-diagonal entry is loaded once.  ONE instance per kernel (the caller loops over the three row directions at run
+// time): three unrolled copies side by side cost the solver loop its registers (33 scratch reloads per iteration).
 __device__ __forceinline__ float robot_w(const PhysLds& S, int k, f3 p, f3 d) {
   float Jp[11];
   int idx[11];
   uint32_t m = S.anc[k];
 #pragma unroll
   for (int q = 0; q < 11; ++q) {
-    if (m) {
-      const int j = __ffs(m) - 1;
-      m &= m - 1;
-      idx[q] = j;
-      Jp[q] = dot(cross(ld3(S.la[j + 1]), p - ld3(S.bp[NF + j + 1])), d);
-    } else { idx[q] = 0; Jp[q] = 0.0f; }
+    const int j = m ? __ffs(m) - 1 : ND;      // exhausted path: the padding dof (zero axis)
+    m &= m - 1;
+    idx[q] = j < ND ? j : 0;
+    Jp[q] = dot(cross(ld3(S.la[j + 1]), p - ld3(S.bp[NF + j + 1])), d);
   }
   float acc = 0.0f;
 #pragma unroll
   for (int q = 0; q < 11; ++q) {
-    float t = 0.0f;
+    float t = 0.5f * S.A[idx[q]][idx[q]] * Jp[q];
 #pragma unroll
-    for (int r = 0; r < 11; ++r) t += S.A[idx[q]][idx[r]] * Jp[r];
+    for (int r = q + 1; r < 11; ++r) t += S.A[idx[q]][idx[r]] * Jp[r];
     acc += Jp[q] * t;
   }
-  return acc;
+  return 2.0f * acc;
 }
 
 template <int NT>
@@ -550,7 +552,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   // ---- what stays in registers for the whole solve: body ids (rows of the body table), target normal velocity, accumulated
   // impulses, un-split inverse masses of both sides
   int ab[CPT];
-  float vtgt[CPT], lam[CPT][3], wA[CPT][3], wB[CPT][3];
+  float vtgt[CPT];
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
@@ -597,8 +599,8 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     const int c = tid + q * NT;
     if (c < nc) {
       const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
-      if (a != BODY_W) S_ENT2(S)[S.eoff[a] + atomicAdd(&S.efill[a], 1)] = (unsigned short)c;
-      if (b != BODY_W) S_ENT2(S)[S.eoff[b] + atomicAdd(&S.efill[b], 1)] = (unsigned short)(c | 0x8000);
+      if (a != BODY_W) { const int i = S.eoff[a] + atomicAdd(&S.efill[a], 1); S_ENT2(S)[i] = (unsigned short)c; S_EBODY2(S)[i] = (unsigned char)a; }
+      if (b != BODY_W) { const int i = S.eoff[b] + atomicAdd(&S.efill[b], 1); S_ENT2(S)[i] = (unsigned short)(c | 0x8000); S_EBODY2(S)[i] = (unsigned char)b; }
     }
   }
   __syncthreads();
@@ -610,17 +612,38 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   {
     const int total = S.eoff[NB];
     for (int i = tid; i < total; i += NT) {
-      int lo = 0, hi = NB;                       // body of entry i: largest b with eoff[b] <= i
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.eoff[mid] <= i) lo = mid; else hi = mid; }
-      const int o = S.eoff[lo], n = S.eoff[lo + 1] - o;
+      const int body = S_EBODY2(S)[i];
+      const int o = S.eoff[body], n = S.eoff[body + 1] - o;
       const unsigned short v = S_ENT2(S)[i];
       const int key = v & 0x7fff;
       int rank = 0;
+#pragma unroll 4
       for (int j = 0; j < n; ++j) rank += (S_ENT2(S)[o + j] & 0x7fff) < key;
       S.ent[o + rank] = v;
     }
   }
+  if (tid < ND) S.qds[tid] = S.qd[tid];
+  __syncthreads();   // rank pass complete (ent final); the fill list in the P rows is dead from here on
   SSTAMP(27);
+  SSTAMP(28);
+  // ---- robot sides: one lane per (contact, side) of the robot's entries computes J Hinv J^T of its three rows -> P rows
+  if (has_robot) {
+    for (int r = tid; r < nrob; r += NT) {
+      const int i = rbeg + r;
+      int lo = NF, hi = NB;                       // link of entry i
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.eoff[mid] <= i) lo = mid; else hi = mid; }
+      const int c = S.ent[i] & 0x7fff, k = lo - NF;
+      const f3 p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]), n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
+      f3 t1, t2;
+      tangents(n, &t1, &t2);
+#pragma unroll 1
+      for (int dd = 0; dd < 3; ++dd) S.P[dd][r] = robot_w(S, k, p, dd == 0 ? n : (dd == 1 ? t1 : t2));
+    }
+    __syncthreads();
+  }
+  SSTAMP(29);
+  // (the per-lane impulse / weight registers are born only here: the robot rows above need ~50 registers of their own)
+  float lam[CPT][3], wA[CPT][3], wB[CPT][3];
   // ---- un-split inverse effective masses of the BRICK sides (owner lanes); zero accumulated impulses
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
@@ -639,25 +662,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       lam[q][r] = 0.0f;
     }
   }
-  if (tid < ND) S.qds[tid] = S.qd[tid];
-  __syncthreads();   // rank pass complete (ent final); the fill list in the P rows is dead from here on
-  SSTAMP(28);
-  // ---- robot sides: one lane per (contact, side) of the robot's entries computes J Hinv J^T of its three rows -> P rows
   if (has_robot) {
-    for (int r = tid; r < nrob; r += NT) {
-      const int i = rbeg + r;
-      int lo = NF, hi = NB;                       // link of entry i
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S.eoff[mid] <= i) lo = mid; else hi = mid; }
-      const int c = S.ent[i] & 0x7fff, k = lo - NF;
-      const f3 p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]), n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
-      f3 t1, t2;
-      tangents(n, &t1, &t2);
-      S.P[0][r] = robot_w(S, k, p, n);
-      S.P[1][r] = robot_w(S, k, p, t1);
-      S.P[2][r] = robot_w(S, k, p, t2);
-    }
-    __syncthreads();
-    SSTAMP(29);
     // owner lanes fetch them: position of the contact in its link's list by binary search (ascending contact index)
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
@@ -688,29 +693,40 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   static_assert(NF * GL + NL * LL <= NT, "gather lanes");
   const bool blane = tid < NF * GL;
   const int gbody = blane ? tid / GL : NF + (tid - NF * GL) / LL, gsub = blane ? tid % GL : (tid - NF * GL) % LL;
-  const int gstride = blane ? GL : LL;
   const bool glane = gbody < NB;
   int gbeg = 0, gend = 0;
-  float g_im = 0.0f, g_ii0 = 0.0f, g_ii1 = 0.0f, g_ii2 = 0.0f;
   if (glane) {
     gbeg = S.eoff[gbody] + gsub; gend = S.eoff[gbody + 1];
-    if (gbody < NF) { g_im = S.bim[gbody]; g_ii0 = S.bii[gbody][0]; g_ii1 = S.bii[gbody][1]; g_ii2 = S.bii[gbody][2]; }
+    if (gbody < NF && gsub == 0) {
+      const f4 q = ld4(S.bq[gbody]);
+      const f3 ex = qrot(q, F3(1, 0, 0)), ey = qrot(q, F3(0, 1, 0)), ez = qrot(q, F3(0, 0, 1));   // columns of R
+      const float i0 = S.bii[gbody][0], i1 = S.bii[gbody][1], i2 = S.bii[gbody][2];
+      S.bK[gbody][0] = i0 * ex.x * ex.x + i1 * ey.x * ey.x + i2 * ez.x * ez.x;
+      S.bK[gbody][1] = i0 * ex.y * ex.y + i1 * ey.y * ey.y + i2 * ez.y * ez.y;
+      S.bK[gbody][2] = i0 * ex.z * ex.z + i1 * ey.z * ey.z + i2 * ez.z * ez.z;
+      S.bK[gbody][3] = i0 * ex.x * ex.y + i1 * ey.x * ey.y + i2 * ez.x * ez.y;
+      S.bK[gbody][4] = i0 * ex.x * ex.z + i1 * ey.x * ey.z + i2 * ez.x * ez.z;
+      S.bK[gbody][5] = i0 * ex.y * ex.z + i1 * ey.y * ey.z + i2 * ez.y * ez.z;
+    }
   }
   // links that carry contacts in this substep (block-uniform mask), and per robot lane: the touched links below its dof
   uint32_t touched = 0;
   if (has_robot)
     for (int k = 0; k < NL; ++k) if (S.eoff[NF + k + 1] > S.eoff[NF + k]) touched |= 1u << k;
   // robot section lanes: 8 per dof (stages 1, 2) / per link (stage 3): rj = dof or link, rs = lane within the group
-  const int rj = tid / 8, rs = tid % 8;
-  const uint32_t mydesc = (rj < ND) ? (S.desc[rj] & touched) : 0u;
-  int tj0 = ND, tj1 = ND;   // the rs-th and (rs + 8)-th dof on the path base -> link rj
-  if (rj < NL) {
-    uint32_t m = S.anc[rj];
-    for (int t = 0; m; ++t) {
-      const int j = __ffs(m) - 1;
-      m &= m - 1;
-      if (t == rs) tj0 = j;
-      if (t == rs + 8) tj1 = j;
+  int tjp = ND | (ND << 8);   // packed: the rs-th and (rs + 8)-th dof on the path base -> link rj (ND = none)
+  {
+    const int rj = tid / 8, rs = tid % 8;
+    if (rj < NL) {
+      int tj0 = ND, tj1 = ND;
+      uint32_t m = S.anc[rj];
+      for (int t = 0; m; ++t) {
+        const int j = __ffs(m) - 1;
+        m &= m - 1;
+        if (t == rs) tj0 = j;
+        if (t == rs + 8) tj1 = j;
+      }
+      tjp = tj0 | (tj1 << 8);
     }
   }
   // ACTIVE-contact counts per iteration: slots 0..71 bricks, NF = the whole robot, NF + 1 = the static world (stays zero)
@@ -718,6 +734,15 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   __syncthreads();
   SSTAMP(17);
 
+  // fresh values for the loop: whatever the set-up phases above did to these registers (some are parked in scratch across the robot
+  // rows), inside the loop they are plain registers again
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    SDX_OPAQUE(ab[q]); SDX_OPAQUE(vtgt[q]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { SDX_OPAQUE(lam[q][r]); SDX_OPAQUE(wA[q][r]); SDX_OPAQUE(wB[q][r]); }
+  }
+  SDX_OPAQUE(gbeg); SDX_OPAQUE(gend); SDX_OPAQUE(tjp);
   for (int it = 0; it < sc.solver_iters; ++it) {
     if (it == 1) dbg = nullptr;
     SSTAMP(18);
@@ -761,11 +786,11 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         const float w1 = na * wA[q][1] + nb * wB[q][1];
         const float w2 = na * wA[q][2] + nb * wB[q][2];
         const float lam0 = lam[q][0], lam1 = lam[q][1], lam2 = lam[q][2];
-        const float ln = fmaxf(0.0f, lam0 - relax * (dot(vr[q], n) - vtgt[q]) / w0);
+        const float ln = fmaxf(0.0f, lam0 - __fdividef(relax * (dot(vr[q], n) - vtgt[q]), w0));
         const float lim = mu * ln;
-        float l1 = lam1 - relax * dot(vr[q], t1) / w1;
+        float l1 = lam1 - __fdividef(relax * dot(vr[q], t1), w1);
         l1 = fminf(lim, fmaxf(-lim, l1));
-        float l2 = lam2 - relax * dot(vr[q], t2) / w2;
+        float l2 = lam2 - __fdividef(relax * dot(vr[q], t2), w2);
         l2 = fminf(lim, fmaxf(-lim, l2));
         lam[q][0] = ln; lam[q][1] = l1; lam[q][2] = l2;
         P = n * (ln - lam0) + t1 * (l1 - lam1) + t2 * (l2 - lam2);
@@ -777,11 +802,14 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     // ---- [D] gather (GL lanes per body): F = sum(+-P), M = sum(+-(p - x) x P) about the body's reference point x; each lane sums its
     // slice in ascending contact order, the partial sums are combined in a fixed order (deterministic); inactive contacts carry P = 0.
     // Bricks: dv = F / m, dw = Iw^-1 M.  Links: the wrench (F, M about the link origin) goes to LDS for the robot section below.
-    if (glane) {
+    int td = tid;
+    SDX_OPAQUE(td);   // lane coordinates re-derived per iteration instead of living in registers across the loop
+    const bool d_brick = td < NF * GL;
+    const int d_body = d_brick ? td / GL : NF + (td - NF * GL) / LL, d_sub = d_brick ? td % GL : (td - NF * GL) % LL;
+    const int gstride = d_brick ? GL : LL;
+    if (d_body < NB) {
       float acc[6] = {0, 0, 0, 0, 0, 0};
-      int gb = gbody;
-      SDX_OPAQUE(gb);
-      const f3 x = ld3(S.bp[gb]);
+      const f3 x = ld3(S.bp[d_body]);
       // four entries per trip (the index loads, then the payloads, in flight together); not unrolled further: the decoded
       // addresses of a longer window would be kept in registers across the whole iteration loop
 #pragma unroll 1
@@ -799,33 +827,36 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        acc[r] += __shfl_xor(acc[r], 1, 64);
-        acc[r] += __shfl_xor(acc[r], 2, 64);
-        if (LL == 8 && !blane) acc[r] += __shfl_xor(acc[r], 4, 64);
+        acc[r] = sum4(acc[r]);
+        if (LL == 8 && !d_brick) acc[r] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r]), 0x141, 0xF, 0xF, true));
       }
-      if (gsub == 0) {
-        if (gbody < NF) {
-          const f4 qq = ld4(S.bq[gbody]);
-          const f3 l = qrot(qconj(qq), F3(acc[3], acc[4], acc[5]));
-          const f3 dw = qrot(qq, F3(l.x * g_ii0, l.y * g_ii1, l.z * g_ii2));
-          st3(S.bv[gbody], ld3(S.bv[gbody]) + F3(acc[0], acc[1], acc[2]) * g_im);
-          st3(S.bw[gbody], ld3(S.bw[gbody]) + dw);
-          S.acount[gbody] = 0;   // read by [C] before the barrier above; counted afresh by [A] of the next iteration
+      if (d_sub == 0) {
+        if (d_brick) {
+          const float* K = S.bK[d_body];
+          const f3 dw = F3(K[0] * acc[3] + K[3] * acc[4] + K[4] * acc[5], K[3] * acc[3] + K[1] * acc[4] + K[5] * acc[5],
+                           K[4] * acc[3] + K[5] * acc[4] + K[2] * acc[5]);
+          st3(S.bv[d_body], ld3(S.bv[d_body]) + F3(acc[0], acc[1], acc[2]) * S.bim[d_body]);
+          st3(S.bw[d_body], ld3(S.bw[d_body]) + dw);
+          S.acount[d_body] = 0;   // read by [C] before the barrier above; counted afresh by [A] of the next iteration
         } else {
-          const int k = gbody - NF;
+          const int k = d_body - NF;
 #pragma unroll
           for (int r = 0; r < 6; ++r) S.lwr[k][r] = acc[r];
           if (last_substep) { S.cf[k][0] += acc[0]; S.cf[k][1] += acc[1]; S.cf[k][2] += acc[2]; }   // net impulse on the link so far
         }
       }
-      if (tid == 0) S.acount[NF] = 0;
+      if (td == 0) S.acount[NF] = 0;
     }
     if (has_robot) {
-      // robot section, three short stages on 8 lanes per dof / link with a workgroup barrier between them (a single wave walking
-      // the three dependent chains took 6-9 k cycles per iteration): Q += J^T (link wrenches); qd = qd* + Hinv Q; link twists
+      // robot section in two short stages on 8 lanes per dof / link (a single wave walking the dependent chains took 6-9 k cycles
+      // per iteration): [R1] Q += J^T (link wrenches) | barrier | [R2] qd = qd* + Hinv Q for the (<= 2) dofs of this lane, link twists
       __syncthreads();
       SSTAMP(21);
-      if (tid < ND * 8) {
+      int tr = tid;
+      SDX_OPAQUE(tr);
+      const int rj = tr / 8, rs = tr % 8;
+      if (tr < ND * 8) {
+        const uint32_t mydesc = S.desc[rj] & touched;
         // generalised impulse of dof j: sum over the touched links k below it of a_j . (M_k + (o_k - o_j) x F_k); lane rs takes links rs, rs+8, rs+16
         const f3 aj = ld3(S.la[rj + 1]), oj = ld3(S.bp[NF + rj + 1]);
         float acc = 0.0f;
@@ -837,31 +868,26 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
             acc += dot(aj, M + cross(ld3(S.bp[NF + k]) - oj, F));
           }
         }
-        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        acc = sum8(acc);
         if (rs == 0) S.Q[rj] += acc;
       }
       __syncthreads();
-      if (tid < ND * 8) {   // lane rs takes columns rs, rs+8, rs+16 of row rj
-        float acc = 0.0f;
+      if (tr < NL * 8) {   // lane rs of link rj: the rs-th and (rs + 8)-th dof of the path (tj0, tj1; ND = none: zero velocity)
+        const int tj0 = tjp & 0xff, tj1 = tjp >> 8;
+        const int r0 = tj0 < ND ? tj0 : 0, r1 = tj1 < ND ? tj1 : 0;
+        float q0 = 0.0f, q1 = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int j = rs + 8 * u;
-          if (j < ND) acc += S.A[rj][j] * S.Q[j];
-        }
-        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-        if (rs == 0) S.qd[rj] = S.qds[rj] + acc;
-      }
-      __syncthreads();
-      if (tid < NL * 8) {   // link twists: lane rs of link rj adds the terms of its (<= 2) dofs tj0, tj1 of the path (ND = none: zero velocity slot)
+        for (int j = 0; j < ND; ++j) { const float Qj = S.Q[j]; q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }
+        q0 = tj0 < ND ? S.qds[r0] + q0 : 0.0f;
+        q1 = tj1 < ND ? S.qds[r1] + q1 : 0.0f;
+        if (tj0 == rj - 1) S.qd[tj0] = q0;      // the link's own dof is written by the lane that holds it (exactly one per dof)
+        if (tj1 == rj - 1) S.qd[tj1] = q1;
         const f3 pk = ld3(S.bp[NF + rj]);
-        const f3 a0 = ld3(S.la[tj0 + 1]) * S.qd[tj0], a1 = ld3(S.la[tj1 + 1]) * S.qd[tj1];
+        const f3 a0 = ld3(S.la[tj0 + 1]) * q0, a1 = ld3(S.la[tj1 + 1]) * q1;
         f3 w = a0 + a1;
         f3 v = cross(a0, pk - ld3(S.bp[NF + tj0 + 1])) + cross(a1, pk - ld3(S.bp[NF + tj1 + 1]));
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-          w.x += __shfl_xor(w.x, o, 64); w.y += __shfl_xor(w.y, o, 64); w.z += __shfl_xor(w.z, o, 64);
-          v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64);
-        }
+        w.x = sum8(w.x); w.y = sum8(w.y); w.z = sum8(w.z);
+        v.x = sum8(v.x); v.y = sum8(v.y); v.z = sum8(v.z);
         if (rs == 0 && rj > 0) { st3(S.bw[NF + rj], w); st3(S.bv[NF + rj], v); }
       }
     }

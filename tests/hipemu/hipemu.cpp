@@ -104,6 +104,12 @@ static void resolve_wave(int lo, int hi) {
       else if (kind == K_SHFL_XOR) src = lane ^ f.arg;
       else if (kind == K_SHFL_DOWN) src = lane + f.arg;
       else if (kind == K_SHFL_UP) src = lane - f.arg;
+      else if (kind == K_DPP) {
+        if (f.arg >= 0 && f.arg <= 0xff) src = (lane & ~3) | ((f.arg >> (2 * (lane & 3))) & 3);   // quad_perm
+        else if (f.arg == 0x141) src = (lane & ~7) | (7 - (lane & 7));                          // row_half_mirror
+        else if (f.arg == 0x140) src = (lane & ~15) | (15 - (lane & 15));                       // row_mirror
+        else { fprintf(stderr, "hipemu: dpp control 0x%x not emulated\n", f.arg); abort(); }
+      }
       f.result = (src >= 0 && src < 64 && ((mask >> src) & 1ull)) ? g_f[lo + src].value : f.value;
     }
     for (int m = 0; m < nm; ++m) g_f[members[m]].st = RUN;

@@ -48,7 +48,7 @@ struct Idx { unsigned x, y, z; };
 extern Idx g_tid, g_bid, g_bdim, g_gdim;   // refreshed by the scheduler every time a fiber is resumed
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void barrier();
-enum { K_BALLOT = 0, K_SHFL = 1, K_SHFL_XOR = 2, K_SHFL_DOWN = 3, K_SHFL_UP = 4, K_WAVE_SYNC = 5 };
+enum { K_BALLOT = 0, K_SHFL = 1, K_SHFL_XOR = 2, K_SHFL_DOWN = 3, K_SHFL_UP = 4, K_WAVE_SYNC = 5, K_DPP = 6 };
 unsigned long long collective(int kind, uint32_t value, int arg, const void* site);
 }  // namespace hipemu
 
@@ -87,6 +87,8 @@ static inline unsigned hipemu_shfl(int site, int kind, unsigned v, int arg, int 
 // wave-synchronous sections (LDS written by one lane, read by another lane of the SAME wave, no workgroup barrier): on the GPU the
 // wave executes in lockstep and the builtins below only constrain the compiler; here they are a rendezvous of the wave's lanes
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::collective(hipemu::K_WAVE_SYNC, 0u, 0, (const void*)(intptr_t)(__COUNTER__ + 1)))
+// v_mov_b32 dpp (quad_perm 0x00-0xff, row_half_mirror 0x141, row_mirror 0x140): (old, src, ctrl, row_mask, bank_mask, bound_ctrl)
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) ((int)(uint32_t)hipemu::collective(hipemu::K_DPP, (uint32_t)(src), (ctrl), (const void*)(intptr_t)(__COUNTER__ + 1)))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
