@@ -284,6 +284,9 @@ typedef struct {
                                 sdxp_backward_* and sdxp_apply_* when world_size > 1 */
   int32_t obs_cols;          /* columns of the caller's observation rows if fewer than obs_dim (0 = obs_dim): the network input is
                                 zero-padded to obs_dim, which must be a multiple of 4 (BlockAssemblyOrient: 186 -> 188) */
+  int32_t mixed_precision;   /* rl_games' `mixed_precision` (App. C; False in YG): 1 = the trunk GEMMs of the large-minibatch update path
+                                (minibatch_size > 8) run on bf16 MFMA with fp32 accumulation; weights, Adam state, activations in HBM, losses,
+                                heads and the rollout stay fp32 (BASELINE.json configs[4]: "bf16 policy").  Ignored by the rank-MB paths */
 } sdxp_config;
 
 typedef enum {

@@ -59,7 +59,7 @@ class PPOConfig(C.Structure):
         ("units", i32 * 3), ("gamma", f32), ("tau", f32), ("lr", f32), ("cv_lr", f32), ("e_clip", f32),
         ("grad_norm", f32), ("critic_coef", f32), ("entropy_coef", f32), ("bounds_loss_coef", f32),
         ("kl_threshold", f32), ("clip_value", i32), ("truncate_grads", i32), ("normalize_advantage", i32),
-        ("cv_normalize_input", i32), ("adaptive_lr", i32), ("world_size", i32), ("obs_cols", i32),
+        ("cv_normalize_input", i32), ("adaptive_lr", i32), ("world_size", i32), ("obs_cols", i32), ("mixed_precision", i32),
     ]
 
 

@@ -5,8 +5,11 @@
 #include "sdx_common.h"
 #include <cstddef>
 #include <cstdint>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define TB 64   // output tile
 
@@ -41,12 +44,19 @@ struct GemmArgs {
 // blockIdx.z = problem * splits + split, so that the narrow layers still give every CU several workgroups.
 struct GemmBatch { GemmArgs a[3]; int splits; };
 
-template <int AT, int BT, int EPI, int WTM, int WTN, int KT>
+// BF = 1: the operands are rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on their way into LDS and multiplied on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; sources, results, weights and optimiser state stay fp32 (BASELINE.json
+// configs[4] "bf16 policy", SURVEY 8(d) config 5: fp32 master weights / accumulate).  Lane l feeds row / column l & 31 and the eight
+// reduction indices 8 (l >> 5) .. + 7 of a 16-wide step to BOTH operands, so the sum over k is complete whatever order the matrix
+// core pairs them in.
+template <int AT, int BT, int EPI, int WTM, int WTN, int KT, int BF = 0>
 __global__ __launch_bounds__(256) void k_gemm(GemmBatch gb) {
   constexpr int TM = TB * WTM, TN = TB * WTN;       // tile: waves own (32 WTM) x (32 WTN) of it, 2 x 2 waves
   constexpr int NVA = TM * KT / 4 / 256, NVB = TN * KT / 4 / 256;   // float4 loads per thread per reduction chunk
-  __shared__ float As[TM][KT + 1];
-  __shared__ float Bs[TN][KT + 1];
+  constexpr int KP = BF ? KT + 8 : KT + 1;          // LDS row stride: odd for 4-byte reads, 16-byte aligned rows for the 8 x bf16 reads
+  typedef typename std::conditional<BF != 0, __bf16, float>::type lds_t;
+  __shared__ __attribute__((aligned(16))) lds_t As[TM][KP];
+  __shared__ __attribute__((aligned(16))) lds_t Bs[TN][KP];
   const GemmArgs& g = gb.a[blockIdx.z / gb.splits];
   const int zs = blockIdx.z % gb.splits;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -87,21 +97,35 @@ __global__ __launch_bounds__(256) void k_gemm(GemmBatch gb) {
 #pragma unroll
     for (int p = 0; p < NVA; ++p) {
       const int e = tid + 256 * p;
-      if (AT == 0) { float* d = &As[e / (KT / 4)][4 * (e % (KT / 4))]; d[0] = av[p].x; d[1] = av[p].y; d[2] = av[p].z; d[3] = av[p].w; }
-      else         { const int k = e / (TM / 4), c = 4 * (e % (TM / 4)); As[c][k] = av[p].x; As[c + 1][k] = av[p].y; As[c + 2][k] = av[p].z; As[c + 3][k] = av[p].w; }
+      if (AT == 0) { lds_t* d = &As[e / (KT / 4)][4 * (e % (KT / 4))]; d[0] = (lds_t)av[p].x; d[1] = (lds_t)av[p].y; d[2] = (lds_t)av[p].z; d[3] = (lds_t)av[p].w; }
+      else         { const int k = e / (TM / 4), c = 4 * (e % (TM / 4)); As[c][k] = (lds_t)av[p].x; As[c + 1][k] = (lds_t)av[p].y; As[c + 2][k] = (lds_t)av[p].z; As[c + 3][k] = (lds_t)av[p].w; }
     }
 #pragma unroll
     for (int p = 0; p < NVB; ++p) {
       const int e = tid + 256 * p;
-      if (BT == 0) { float* d = &Bs[e / (KT / 4)][4 * (e % (KT / 4))]; d[0] = bv[p].x; d[1] = bv[p].y; d[2] = bv[p].z; d[3] = bv[p].w; }
-      else         { const int k = e / (TN / 4), c = 4 * (e % (TN / 4)); Bs[c][k] = bv[p].x; Bs[c + 1][k] = bv[p].y; Bs[c + 2][k] = bv[p].z; Bs[c + 3][k] = bv[p].w; }
+      if (BT == 0) { lds_t* d = &Bs[e / (KT / 4)][4 * (e % (KT / 4))]; d[0] = (lds_t)bv[p].x; d[1] = (lds_t)bv[p].y; d[2] = (lds_t)bv[p].z; d[3] = (lds_t)bv[p].w; }
+      else         { const int k = e / (TN / 4), c = 4 * (e % (TN / 4)); Bs[c][k] = (lds_t)bv[p].x; Bs[c + 1][k] = (lds_t)bv[p].y; Bs[c + 2][k] = (lds_t)bv[p].z; Bs[c + 3][k] = (lds_t)bv[p].w; }
     }
     __syncthreads();
     if (k0 + KT < kend) fetch(k0 + KT);
     if (EPI == 4 && blockIdx.x == 0 && tid < TM) {
 #pragma unroll
-      for (int kk = 0; kk < KT; ++kk) rsum += As[tid][kk];
+      for (int kk = 0; kk < KT; ++kk) rsum += (float)As[tid][kk];
     }
+    if constexpr (BF != 0) {
+#pragma unroll
+      for (int kk = 0; kk < KT; kk += 16) {
+        bf16x8 a[WTM], b[WTN];
+#pragma unroll
+        for (int u = 0; u < WTM; ++u) a[u] = *reinterpret_cast<const bf16x8*>(&As[wm + 32 * u + (lane & 31)][kk + 8 * (lane >> 5)]);
+#pragma unroll
+        for (int v = 0; v < WTN; ++v) b[v] = *reinterpret_cast<const bf16x8*>(&Bs[wn + 32 * v + (lane & 31)][kk + 8 * (lane >> 5)]);
+#pragma unroll
+        for (int u = 0; u < WTM; ++u)
+#pragma unroll
+          for (int v = 0; v < WTN; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[v], acc[u][v], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int kk = 0; kk < KT; kk += 2) {
       float a[WTM], b[WTN];
@@ -160,7 +184,7 @@ static __global__ __launch_bounds__(256) void k_reduce_parts3(ReduceBatch rb) {
 
 // 128 x 128 tiles (each wave 64 x 64: half the LDS and L2 traffic per flop) when they still give every CU a workgroup
 template <int AT, int BT, int EPI>
-static void gemm(const GemmArgs* gs, int count, int splits, hipStream_t st) {
+static void gemm(const GemmArgs* gs, int count, int splits, hipStream_t st, bool bf16 = false) {
   GemmBatch gb;
   int Mx = 0, Nx = 0;
   for (int q = 0; q < 3; ++q) {
@@ -175,13 +199,16 @@ static void gemm(const GemmArgs* gs, int count, int splits, hipStream_t st) {
   const long b22 = blocks(128, 128), b21 = blocks(128, 64);
   if (b22 >= 256 && waste(b22) <= 0.15) {
     dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, splits * count);
-    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 2, 32>), grid, dim3(256), 0, st, gb);
+    if (bf16) hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 2, 32, 1>), grid, dim3(256), 0, st, gb);
+    else hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 2, 32>), grid, dim3(256), 0, st, gb);
   } else if (b21 >= 256 && waste(b21) <= 0.15) {
     dim3 grid((Nx + 63) / 64, (Mx + 127) / 128, splits * count);
-    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 1, 32>), grid, dim3(256), 0, st, gb);
+    if (bf16) hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 1, 32, 1>), grid, dim3(256), 0, st, gb);
+    else hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 2, 1, 32>), grid, dim3(256), 0, st, gb);
   } else {
     dim3 grid((Nx + TB - 1) / TB, (Mx + TB - 1) / TB, splits * count);
-    hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 1, 1, 16>), grid, dim3(256), 0, st, gb);
+    if (bf16) hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 1, 1, 16, 1>), grid, dim3(256), 0, st, gb);
+    else hipLaunchKernelGGL((k_gemm<AT, BT, EPI, 1, 1, 16>), grid, dim3(256), 0, st, gb);
   }
 }
 

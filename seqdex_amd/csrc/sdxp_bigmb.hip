@@ -296,7 +296,7 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
       const float* X = l == 0 ? X0[net] : ws->h[net][l - 1];
       g[net] = {X, in, P[net] + woff(net, l), in, ws->h[net][l], D.units[l], 0, MB, D.units[l], in, in, P[net] + boff(net, l), nullptr, 0, nullptr};
     }
-    gemm<0, 0, 1>(g, 3, 1, st);
+    gemm<0, 0, 1>(g, 3, 1, st, D.bf16 != 0);
   }
   {  // heads
     GemmArgs g = {ws->h[0][2], U2, D.ac + D.off.mu_w, U2, ws->mu, 24, 0, MB, A, U2, U2, D.ac + D.off.mu_b, nullptr, 0, nullptr};
@@ -341,14 +341,14 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
       gw[net] = {ws->dy[net][l], Nl, Xl, Kl, part, Kl, pz, Nl, Kl, MB, rchunk, nullptr, nullptr, 0, part + (size_t)Nl * Kl};
       rb.part[net] = part; rb.pz[net] = pz; rb.n[net] = pz; rb.out[net] = G[net] + woff(net, l);
     }
-    gemm<1, 1, 4>(gw, 3, S, st);                                          // G_l = dY_l^T X_l, b_l = row sums of dY_l^T (fused)
+    gemm<1, 1, 4>(gw, 3, S, st, D.bf16 != 0);                             // G_l = dY_l^T X_l, b_l = row sums of dY_l^T (fused)
     hipLaunchKernelGGL(k_reduce_parts3, dim3(256, 3), dim3(256), 0, st, rb);
     if (l > 0) {
       GemmArgs gx[3];
       const int Kl = D.units[l - 1];
       for (int net = 0; net < 3; ++net)
         gx[net] = {ws->dy[net][l], Nl, P[net] + woff(net, l), Kl, ws->dy[net][l - 1], Kl, 0, MB, Kl, Nl, Nl, nullptr, ws->h[net][l - 1], Kl, nullptr};
-      gemm<0, 1, 3>(gx, 3, 1, st);                                        // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
+      gemm<0, 1, 3>(gx, 3, 1, st, D.bf16 != 0);                           // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
     }
   }
 }

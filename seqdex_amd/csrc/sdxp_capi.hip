@@ -156,6 +156,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   D.gamma = cfg->gamma; D.tau = cfg->tau; D.e_clip = cfg->e_clip; D.grad_norm = cfg->grad_norm;
   D.critic_coef = cfg->critic_coef; D.entropy_coef = cfg->entropy_coef; D.bounds_coef = cfg->bounds_loss_coef;
   D.kl_threshold = cfg->kl_threshold; D.seed = seed;
+  D.bf16 = cfg->mixed_precision != 0;
   // ---- flat parameter layouts
   {
     size_t o = 0;

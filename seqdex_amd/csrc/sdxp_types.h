@@ -71,5 +71,6 @@ struct SdxpDev {
   float* obs_pad;
   float* sqn_part;       // [512] block partials of the deterministic gradient-norm reduction
   size_t g_tail;         // ALL_GRADS = [ac_g | pad | cv_g | pad | kl word | pad]: offset (floats, from ac_g) of the kl word
+  int32_t bf16;          // large-minibatch path: trunk GEMMs on bf16 MFMA (fp32 sources, accumulation, weights and optimiser state)
   unsigned long long* ll; // [SDXP_LL_WORDS] (value, step tag) words exchanged between the CUs of the persistent update kernel
 };

@@ -54,6 +54,7 @@ def make_config(num_actors, params=None, world_size=1, obs_dim=None, state_dim=N
     c.cv_normalize_input = int(bool(cv.get("normalize_input", True)))
     c.adaptive_lr = int(cfgd.get("lr_schedule", "adaptive") == "adaptive")
     c.world_size = world_size
+    c.mixed_precision = int(bool(cfgd.get("mixed_precision", False)))   # bf16 trunk GEMMs on the large-minibatch path
     return c
 
 
