@@ -255,12 +255,39 @@ class A2CAgent:
         if "FACTORS" in ppo.t and hasattr(ppo, "backward_factors") and self.minibatch_size <= 8:
             # preferred: all-gather the rank-MB factors (194 KB per rank) and rebuild the summed gradient locally
             fact, fact_all = ppo.t["FACTORS"], ppo.t["FACTORS_ALL"]
-            ppo.backward_factors(-1)
-            for _ in range(self.mini_epochs_num):
-                for mb in range(nmb):
-                    ppo.backward_factors(mb)
+
+            def steps(k):
+                for _ in range(k):
+                    ppo.backward_factors(0)          # the minibatch is the one under the DEVICE cursor; the argument is only range-checked
                     dist.all_gather_into_tensor(fact_all, fact)
                     ppo.apply_factors()
+
+            ppo.backward_factors(-1)
+            total = self.mini_epochs_num * nmb
+            done = 0
+            # the optimiser step (one persistent forward/backward launch, the RCCL all-gather, three apply launches) carries no
+            # host-side argument that changes from step to step - cursor, exchange tags, Adam counters and the LR all live in the
+            # device control block - so a chunk of steps is captured ONCE into a hipGraph (RCCL collectives are capturable) and
+            # replayed: per step the host then issues 1/64 of a graph launch instead of four launches and a collective call
+            chunk = next((c for c in (64, 32, 16, 8) if total % c == 0 and total >= 2 * c), 0)
+            if chunk and os.environ.get("SDX_MULTI_RANK_GRAPH", "1") != "0" and getattr(self, "_mr_graph", None) is not False:
+                if getattr(self, "_mr_graph", None) is None:
+                    steps(chunk)                     # eagerly once: communicator set-up, lazy module loads, function attributes
+                    done = chunk
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            steps(chunk)
+                        self._mr_graph, self._mr_chunk = g, chunk
+                    except Exception as ex:          # capture refused (old RCCL / torch): stay on eager launches for good
+                        print("seqdex_amd: multi-rank step not captured (%s); eager launches" % (str(ex).splitlines()[0] if str(ex) else type(ex).__name__))
+                        self._mr_graph = False
+                        torch.cuda.synchronize()
+                if self._mr_graph:
+                    while done + self._mr_chunk <= total:
+                        self._mr_graph.replay()
+                        done += self._mr_chunk
+            steps(total - done)
             ppo.update_status()
             return
         ppo.backward(0, -1)

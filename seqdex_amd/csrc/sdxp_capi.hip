@@ -27,8 +27,8 @@ void sdxpk_pad_obs(const SdxpDev*, const float*, hipStream_t);
 int sdxpk_backward_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_grads_from_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_apply_factors(const SdxpDev*, int, hipStream_t);
-int sdxpk_update_persistent(const SdxpDev*, int, unsigned, unsigned*, hipStream_t);
-int sdxpk_fwd_bwd_persistent(const SdxpDev*, unsigned, unsigned*, hipStream_t);
+int sdxpk_update_persistent(const SdxpDev*, int, unsigned*, hipStream_t);
+int sdxpk_fwd_bwd_persistent(const SdxpDev*, unsigned*, hipStream_t);
 int sdxpk_prenorm(const SdxpDev*, int, hipStream_t);
 void sdxpk_apply_explicit(const SdxpDev*, int, float, int, hipStream_t);
 }
@@ -64,7 +64,6 @@ struct sdxp_agent {
   int graph_chunk = 0;
   bool use_persist = false;      // persistent register-resident update kernel (sdxp_persist.hip)
   unsigned* bar_dev = nullptr;   // [64] grid-barrier counter (+ fail flag at [32])
-  unsigned ll_tag = 0;           // last exchange tag handed to a persistent launch (tags only grow: the buffer is never cleared)
   bool last_was_step = false;    // the most recent persistent launch was a single forward/backward (no restore possible on failure)
   bool use_persist_step = false; // multi-rank path: forward/backward of one minibatch as one persistent-style launch
   unsigned* fail_host = nullptr; // pinned mirror of the fail flag, refreshed after every persistent update
@@ -440,10 +439,8 @@ extern "C" int sdxp_update(sdxp_handle h, void* stream) {
   hipLaunchKernelGGL(k_ctrl_begin_epoch, dim3(1), dim3(1), 0, st, h->D.ctrl);
   if (h->use_persist) {
     sdxpk_prenorm(&h->D, MB, st);
-    const unsigned tag_base = h->ll_tag;
-    h->ll_tag += (unsigned)total + 2u;
     h->last_was_step = false;
-    if (sdxpk_update_persistent(&h->D, (int)total, tag_base, h->bar_dev + 32, st) != 0) { h->err = "persistent update launch failed"; return SDX_ERR_HIP; }
+    if (sdxpk_update_persistent(&h->D, (int)total, h->bar_dev + 32, st) != 0) { h->err = "persistent update launch failed"; return SDX_ERR_HIP; }
     PCHK(h, hipMemcpyAsync(h->fail_host, h->bar_dev + 32, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     return plaunch_ok(h, "sdxp_update(persistent)");
   }
@@ -514,10 +511,8 @@ extern "C" int sdxp_backward_factors(sdxp_handle h, int32_t mb, void* stream) {
   if (mb < 0) return sdxp_backward(h, 0, -1, stream);
   if (mb >= h->D.num_minibatches) { h->err = "sdxp_backward_factors: minibatch index out of range"; return SDX_ERR_INVALID; }
   if (h->use_persist_step) {   // one launch: forward + backward on 256 CUs with tagged-word exchange, factors straight into D.fact
-    const unsigned tag_base = h->ll_tag;
-    h->ll_tag += 3u;
     h->last_was_step = true;
-    if (sdxpk_fwd_bwd_persistent(&h->D, tag_base, h->bar_dev + 32, st) != 0) { h->err = "persistent forward/backward launch failed"; return SDX_ERR_HIP; }
+    if (sdxpk_fwd_bwd_persistent(&h->D, h->bar_dev + 32, st) != 0) { h->err = "persistent forward/backward launch failed"; return SDX_ERR_HIP; }
     return plaunch_ok(h, "sdxp_backward_factors(persistent)");
   }
   sdxpk_backward_factors(&h->D, MB, st);
@@ -557,6 +552,12 @@ extern "C" int sdxp_update_status(sdxp_handle h, void* stream) {
     *h->fail_host = 0;
     h->use_persist_step = false;
     PCHK(h, hipMemset(h->bar_dev, 0, 256));
+    {   // tags of the failed launch must never be handed out again
+      SdxpCtrl c;
+      PCHK(h, hipMemcpy(&c, h->D.ctrl, sizeof(c), hipMemcpyDeviceToHost));
+      c.ll_tag += 1024u;
+      PCHK(h, hipMemcpy(h->D.ctrl, &c, sizeof(c), hipMemcpyHostToDevice));
+    }
     h->err = "sdxp_backward_factors: a persistent forward/backward launch timed out waiting for an exchange word (not all 256 "
              "workgroups co-resident?); at least one optimiser step of this epoch used invalid factors; this handle now uses the "
              "multi-kernel forward/backward - restore a checkpoint";
@@ -572,6 +573,12 @@ extern "C" int sdxp_update_status(sdxp_handle h, void* stream) {
   PCHK(h, hipMemcpyAsync(h->D.rms_var, h->rms_bak + h->D.state_dim, sd, hipMemcpyDeviceToDevice, st));
   PCHK(h, hipMemcpyAsync(h->D.ctrl, h->ctrl_bak, sizeof(SdxpCtrl), hipMemcpyDeviceToDevice, st));
   PCHK(h, hipStreamSynchronize(st));
+  {   // the restored block carries the tag from BEFORE the failed launch: move it past every word that launch may have written
+    SdxpCtrl c;
+    PCHK(h, hipMemcpy(&c, h->D.ctrl, sizeof(c), hipMemcpyDeviceToHost));
+    c.ll_tag += (uint32_t)((long)h->cfg.mini_epochs * h->D.num_minibatches) + 1024u;
+    PCHK(h, hipMemcpy(h->D.ctrl, &c, sizeof(c), hipMemcpyHostToDevice));
+  }
   h->err = "sdxp_update: the persistent update kernel timed out waiting for an exchange word (not all 256 workgroups co-resident?); "
            "nothing was applied, inputs restored; this handle now uses the hipGraph path - call sdxp_update again";
   return SDX_ERR_STATE;

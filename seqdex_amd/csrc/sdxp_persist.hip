@@ -201,8 +201,7 @@ __device__ __forceinline__ const float* cvx_rows(const SdxpDev& D, int mb, int m
 // device cursor SdxpCtrl.mb_index points at) with the current parameters; no optimiser state is touched, the rank-MB factors
 // are written to D.fact for the multi-rank exchange and the cursor / loss statistics advance as k_ctrl does in explicit mode.
 template <bool SINGLE>
-__global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int total_steps, unsigned* bar, unsigned* failflag, int stamps, int fault,
-                                                              unsigned tag_base) {
+__global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int total_steps, unsigned* bar, unsigned* failflag, int stamps, int fault) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   PLds& S = *reinterpret_cast<PLds*>(smem_raw);
   // Thread coordinates are re-derived from an opaque copy of threadIdx/blockIdx at the start of every phase (refresh()):
@@ -319,6 +318,9 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
   }
   // replicated control state (every CU runs the same state machine on identical inputs)
   SdxpCtrl* gctl = D.ctrl;
+  // first exchange tag of this launch minus one: read from the device control block (CU 0 advances it at the end of the launch, when
+  // every CU has long read it: nobody finishes a step without everybody's words) - so launches replayed from a hipGraph keep growing tags
+  const unsigned tag_base = gctl->ll_tag;
   if (tid == 0) {
     PLds::Ctl& C = S.ctl;
     C.ac_lr = gctl->ac_lr; C.ac_lr_applied = C.ac_lr; C.cv_lr = gctl->cv_lr; C.ac_t = gctl->ac_t; C.cv_t = gctl->cv_t;
@@ -1009,6 +1011,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
           if (mbn >= D.num_minibatches) { mbn = 0; gctl->mini_epoch += 1; }
           gctl->mb_index = mbn;
           gctl->step += 1;
+          gctl->ll_tag = tag_base + 3u;
         }
       }
       return;
@@ -1092,6 +1095,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       gctl->sum_cv_loss = C.sum_cv; gctl->sum_entropy = C.sum_ent; gctl->n_mb = total_steps; gctl->last_kl = C.last_kl;
       gctl->ac_gnorm = C.ac_gn; gctl->cv_gnorm = C.cv_gn; gctl->ac_pending = 0; gctl->cv_pending = 0;
       gctl->mb_index = 0; gctl->mini_epoch = total_steps / D.num_minibatches;
+      gctl->ll_tag = tag_base + (unsigned)total_steps + 2u;
     }
   }
   if (tid < 12) {
@@ -1114,8 +1118,7 @@ extern "C" int sdxpk_persist_supported(const SdxpDev* D, int minibatch, int n_cu
   return minibatch == MB && D->obs_dim <= OBS && D->obs_dim % 4 == 0 && D->state_dim == ST && D->units[0] == U0 && D->units[1] == U1 &&
          D->units[2] == U2 && D->act_dim == ACT && n_cus >= NWG;
 }
-// tag_base: first exchange tag of this launch minus one; the caller advances it by total_steps + 2 per launch
-extern "C" int sdxpk_update_persistent(const SdxpDev* D, int total_steps, unsigned tag_base, unsigned* failflag, hipStream_t st) {
+extern "C" int sdxpk_update_persistent(const SdxpDev* D, int total_steps, unsigned* failflag, hipStream_t st) {
   static bool attr = false;
   static const int stamps = (getenv("SDXP_PERSIST_STAMPS") && getenv("SDXP_PERSIST_STAMPS")[0] == '1') ? 1 : 0;
   const char* fe = getenv("SDXP_PERSIST_FAULT");   // read per call: the failure-path test sets and clears it
@@ -1126,17 +1129,17 @@ extern "C" int sdxpk_update_persistent(const SdxpDev* D, int total_steps, unsign
     attr = true;
   }
   if (hipMemsetAsync(failflag, 0, sizeof(unsigned), st) != hipSuccess) return -1;
-  hipLaunchKernelGGL(k_update_persistent<false>, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, total_steps, nullptr, failflag, stamps, fault, tag_base);
+  hipLaunchKernelGGL(k_update_persistent<false>, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, total_steps, nullptr, failflag, stamps, fault);
   return 0;
 }
 // forward + backward of the minibatch under the device cursor -> D.fact (multi-rank path); the fail flag is sticky (not cleared here)
-extern "C" int sdxpk_fwd_bwd_persistent(const SdxpDev* D, unsigned tag_base, unsigned* failflag, hipStream_t st) {
+extern "C" int sdxpk_fwd_bwd_persistent(const SdxpDev* D, unsigned* failflag, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_persistent<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sizeof(PLds)) != hipSuccess) return -1;
     attr = true;
   }
-  hipLaunchKernelGGL(k_update_persistent<true>, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, 1, nullptr, failflag, 0, 0, tag_base);
+  hipLaunchKernelGGL(k_update_persistent<true>, dim3(NWG), dim3(NTH), sizeof(PLds), st, *D, 1, nullptr, failflag, 0, 0);
   return 0;
 }

@@ -25,7 +25,9 @@ struct SdxpCtrl {
   float acc[8];          // per-minibatch sums written by the HEAD kernel: [1]a [2]c [3]b [4]kl [5]cv [6]entropy
   float games_sum_rew, games_sum_len, games_cnt, pad0;
   float gn2_ac, gn2_cv;  // explicit-gradient path: sum of squares of the (all-reduced) flat gradients
-  int32_t world, pad1;
+  int32_t world;
+  uint32_t ll_tag;       // last exchange tag handed out to a persistent launch: lives on the DEVICE so that launches captured in a hipGraph
+                         // still see tags that only grow (the exchange buffer is never cleared)
   int32_t prev_mb, prev_mini_epoch;
   float n2_part[4];      // grad-norm^2 contributions of heads + trunk layer 2 per net (written by the HEAD kernel)
   float gx[3][3][64];    // Gram matrices (MB x MB) of the inputs of trunk layers 0..2 per net (written by the L kernels)

@@ -18,7 +18,7 @@ class Ctrl(C.Structure):
                 ("last_kl", C.c_float), ("sum_a_loss", C.c_float), ("sum_c_loss", C.c_float), ("sum_b_loss", C.c_float),
                 ("sum_kl", C.c_float), ("sum_cv_loss", C.c_float), ("sum_entropy", C.c_float), ("acc", C.c_float * 8),
                 ("games_sum_rew", C.c_float), ("games_sum_len", C.c_float), ("games_cnt", C.c_float), ("pad0", C.c_float),
-                ("gn2_ac", C.c_float), ("gn2_cv", C.c_float), ("world", C.c_int32), ("pad1", C.c_int32),
+                ("gn2_ac", C.c_float), ("gn2_cv", C.c_float), ("world", C.c_int32), ("ll_tag", C.c_uint32),
                 ("prev_mb", C.c_int32), ("prev_mini_epoch", C.c_int32), ("n2_part", C.c_float * 4),
                 ("gx", C.c_float * (3 * 3 * 64)), ("rms_count", C.c_double),
                 ("ac_b1pow", C.c_double), ("ac_b2pow", C.c_double), ("cv_b1pow", C.c_double), ("cv_b2pow", C.c_double)]

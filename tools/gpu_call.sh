@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-(time timeout 900 python -m pytest tests/test_gpu_ppo_parity.py -m gpu -q -s -k "bf16_gradients") > gpurun_out/gputests.log 2>&1
-grep -E "passed|failed|bf16 |Error|error|ACTUAL|DESIRED|Max" gpurun_out/gputests.log | tail -16
+timeout -k 5 120 python tools/time_multi_rank_parts.py 1024 > gpurun_out/mr_parts.txt 2>&1; grep "us per call\|Error\|error" gpurun_out/mr_parts.txt | head
