@@ -22,23 +22,31 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_ENV_STEP = 18496     # algorithmic HBM bytes per env-step of the sim+task path
-# HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-# separate runs of this same command at the default config).  Units and corrections as MI355X_MICROARCH.md's HBM section
-# prescribes: both counters are in KiB; on gfx950 FETCH_SIZE tallies each 128-B memory-side read request at 64 B, i.e. reports
-# half of the bytes read -> doubled here.  (The guide calibrated that factor on 16 B/lane streaming reads and calls other
-# access widths and WRITE_SIZE uncalibrated; the raw counter values are kept next to the corrected figure.)  PMC counters
-# cannot be read from inside this process, so `traffic` is quoted from those files and is null for any other configuration.
-PMC_RAW_KIB = {("k_update_persistent", 1024): (14343183.0, 7011506.7),     # (FETCH_SIZE, WRITE_SIZE), profiles/r1_bench_pmc_{fetch,write}_v4.csv
-               ("k_physics", 1024): (2874.8, 16285.8)}                      # the 57 dispatches with 1024 workgroups (grid 524288) only
-PMC_TRAFFIC_BYTES = {k: (2.0 * f + w) * 1024 for k, (f, w) in PMC_RAW_KIB.items()}
+# HBM traffic per launch: PMC counters cannot be read from inside this process, so `traffic` is NOT a measurement of this run.  It is
+# QUOTED from the rocprofv3 passes of this same command committed under profiles/ (profiles/pmc_traffic.json: raw FETCH_SIZE /
+# WRITE_SIZE per launch in KiB, the files they came from, the kernel build they were taken on) and is null when no entry matches
+# the configuration.  Units and corrections as MI355X_MICROARCH.md's HBM section prescribes: on gfx950 FETCH_SIZE tallies each
+# 128-B memory-side read request at 64 B, i.e. reports half of the bytes read -> doubled; other access widths and WRITE_SIZE are
+# uncalibrated, so the raw counters are kept next to the corrected figure.
+def _load_pmc():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
 
 
-def pmc_raw(key):
-    if key not in PMC_RAW_KIB:
-        return None
-    f, w = PMC_RAW_KIB[key]
-    return {"FETCH_SIZE_bytes_as_reported": f * 1024, "WRITE_SIZE_bytes_as_reported": w * 1024,
-            "correction": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-B requests at 64 B)"}
+PMC = _load_pmc()
+
+
+def pmc_traffic(kernel, n):
+    e = PMC.get("%s@%d" % (kernel, n))
+    if not e:
+        return None, None
+    f, w = e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"]
+    return (2.0 * f + w) * 1024, {"quoted_from": e["source"], "FETCH_SIZE_bytes_as_reported": f * 1024, "WRITE_SIZE_bytes_as_reported": w * 1024,
+                                  "correction": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-B requests at 64 B)",
+                                  "note": e.get("note", "")}
 
 
 def parse():
@@ -50,6 +58,9 @@ def parse():
     ap.add_argument("--minibatch", type=int, default=None, help="override minibatch_size (labelled variant, not the headline)")
     ap.add_argument("--pretrain-epochs", type=int, default=0, help="untimed training epochs before the warm-up (SURVEY 8(d) config 2: "
                     "second run with a partially trained policy after 200 epochs)")
+    ap.add_argument("--piles-per-type", type=int, default=64, help="saved pile states per brick-type group (SURVEY 8(d) config 2: K = 64)")
+    ap.add_argument("--mixed-precision", action="store_true", help="bf16 trunk GEMMs (fp32 master weights / accumulation) on the large-minibatch "
+                    "path: BASELINE.json configs[4]; only affects minibatch sizes > 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-minibatch", action="store_true", help="skip the labelled large-minibatch variant")
     ap.add_argument("--cpu-baseline-envs", type=int, default=1024)
@@ -135,6 +146,7 @@ def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mi
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: v_mfma_f32_32x32x16_bf16, dense (no 2:1 sparsity)
 
 
 def gemm_roofline(agent, n, horizon, upd_ms_per_epoch):
@@ -145,9 +157,11 @@ def gemm_roofline(agent, n, horizon, upd_ms_per_epoch):
     flops_step = 6.0 * agent.minibatch_size * p
     ms_step = upd_ms_per_epoch / nsteps
     ach = flops_step / (ms_step * 1e-3) / 1e12
-    return {"kernel": "k_gemm<NT|NN|TN> fp32 MFMA (forward, data gradient, weight gradient of 3 networks; whole optimiser step incl. "
-                      "losses, reductions, clip + Adam in the time)", "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": ms_step, "us_per_optimiser_step": ms_step * 1e3,
+    bf = bool(agent.config.get("mixed_precision", False))
+    peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
+    return {"kernel": "k_gemm<NT|NN|TN> %s MFMA (forward, data gradient, weight gradient of 3 networks; whole optimiser step incl. "
+                      "losses, reductions, clip + Adam in the time)" % ("bf16" if bf else "fp32"), "bound": "mfma", "achieved": ach, "peak": peak,
+            "unit": "TFLOP/s", "frac": ach / peak, "avg_launch_ms": ms_step, "us_per_optimiser_step": ms_step * 1e3,
             "algorithmic_flops_per_step": flops_step, "optimiser_steps_per_epoch": nsteps, "traffic": None}
 
 
@@ -161,6 +175,7 @@ def large_minibatch_variant(train, env, n, horizon, args):
     mbs = n * horizon
     pc["minibatch_size"] = mbs
     pc["central_value_config"]["minibatch_size"] = mbs
+    pc["mixed_precision"] = bool(args.mixed_precision)
     pc.update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22, multi_gpu=False)
     tr["config"] = pc
     agent = A2CAgent("run_large_minibatch", tr)
@@ -174,9 +189,12 @@ def large_minibatch_variant(train, env, n, horizon, args):
         play_t += r[1]; upd_t += r[2]
     torch.cuda.synchronize()
     dt = time.time() - t0
-    return {"label": "NOT the shipped schedule: minibatch_size %d instead of 4 (BASELINE.md protocol row; the insert policy ships 4096)" % mbs,
-            "minibatch_size": mbs, "value": n * horizon * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3,
+    return {"label": "NOT the shipped schedule: minibatch_size %d instead of 4 (BASELINE.md protocol row; the insert policy ships 4096)%s"
+                     % (mbs, "; bf16 trunk GEMMs, fp32 master weights / accumulation (configs[4])" if args.mixed_precision else ""),
+            "minibatch_size": mbs, "dtype": "bf16 (trunk GEMM operands) / f32" if args.mixed_precision else "f32", "value": n * horizon * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3,
             "update_ms_per_epoch": upd_t / args.steps * 1e3, "rollout_ms_per_epoch": play_t / args.steps * 1e3,
+        "update_path": ("multi-rank: hipGraph of [forward/backward -> RCCL all-gather of the rank-MB factors -> rebuild + clip + Adam]" if agent.multi_gpu
+                        else agent.ppo.update_impl()),
             "update_impl": agent.ppo.update_impl(), "roofline": gemm_roofline(agent, n, horizon, upd_t / args.steps * 1e3)}
 
 
@@ -210,8 +228,9 @@ def main():
     if args.minibatch:
         train["params"]["config"]["minibatch_size"] = args.minibatch
         train["params"]["config"]["central_value_config"]["minibatch_size"] = args.minibatch
+    train["params"]["config"]["mixed_precision"] = bool(args.mixed_precision)
     seed = 22 + rank
-    task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=local_rank, headless=True, seed=seed, piles_per_type=8)
+    task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=local_rank, headless=True, seed=seed, piles_per_type=args.piles_per_type)
     env = RLgamesVecTaskPython(task, "cuda:%d" % local_rank)
     pc = train["params"]["config"]
     pc.update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22, multi_gpu=world > 1 or force_multi)
@@ -260,16 +279,19 @@ def main():
     torch.cuda.synchronize()
     phys_ms = e0.elapsed_time(e1) / reps
     phys_bytes = BYTES_PER_ENV_STEP * n
-    roof_phys = {"kernel": "k_physics", "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+    ptraf, pctr = pmc_traffic("k_physics", n)
+    roof_phys = {"kernel": "k_physics<%d> (%d threads per env, two workgroups per CU)" % (int(sim.lib.sdxk_physics_threads()), int(sim.lib.sdxk_physics_threads())),
+                 "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes,
-                 "traffic": PMC_TRAFFIC_BYTES.get(("k_physics", n)), "traffic_counters": pmc_raw(("k_physics", n))}
+                 "contacts_per_env_mean": float(sim.NCONTACTS.float().mean().item()), "contacts_per_env_max": int(sim.NCONTACTS.max().item()),
+                 "contact_capacity_per_env": 1536, "traffic": ptraf, "traffic_counters": pctr}
     roof_phys["frac"] = roof_phys["achieved"] / HBM_PEAK_GBS
-    # ---- roofline of the update phase.  Algorithmic bytes: one optimiser step streams w, m, v in and out once for all three
-    # networks (6 x 4 B x params); the persistent kernel runs all optimiser steps of the epoch in ONE launch and keeps w, m, v in
-    # VGPRs, so its real HBM traffic is far below that figure
+    # ---- roofline of the update phase.  Algorithmic bytes: one optimiser step touches 5 x 4 B per parameter
+    # (w, g, m, v in, w' out) for all three networks; the persistent kernel runs all optimiser steps of the epoch in ONE launch and
+    # keeps w, m, v in VGPRs, so its real HBM traffic is far below that figure
     p_ac, p_cv = agent.ppo.param_count(0), agent.ppo.param_count(1)
     nsteps = agent.mini_epochs_num * (n * horizon // agent.minibatch_size)
-    upd_bytes_step = 6 * 4 * (p_ac + p_cv)
+    upd_bytes_step = 5 * 4 * (p_ac + p_cv)
     impl = agent.ppo.update_impl() if not agent.multi_gpu else "explicit"
     if impl == "persistent":
         for _ in range(2):      # HIP events on the stream the kernel is launched on (torch's current stream)
@@ -286,30 +308,35 @@ def main():
                  "(per epoch: %d optimiser steps)" % nsteps)
         launches = nsteps
     upd_ms_step = upd_launch_ms / nsteps
+    utraf, uctr = pmc_traffic("k_update_persistent", n) if impl == "persistent" and args.minibatch is None else (None, None)
     if impl == "gemm":
         roof_upd = gemm_roofline(agent, n, horizon, upd_launch_ms)
     else:
       roof_upd = {"kernel": kname, "bound": "hbm", "achieved": upd_bytes_step / (upd_ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "avg_launch_ms": upd_launch_ms, "us_per_optimiser_step": upd_ms_step * 1e3,
                 "algorithmic_bytes_per_launch": upd_bytes_step * nsteps,
-                "traffic": PMC_TRAFFIC_BYTES.get(("k_update_persistent", n)) if impl == "persistent" and args.minibatch is None else None,
-                "traffic_counters": pmc_raw(("k_update_persistent", n)) if impl == "persistent" and args.minibatch is None else None}
+                "traffic": utraf, "traffic_counters": uctr}
       roof_upd["frac"] = roof_upd["achieved"] / HBM_PEAK_GBS
     dominant = roof_upd if upd_t > step_t else roof_phys
     out = {
         "metric": "env-steps/sec BlockAssemblyGraspSim num_envs=%d/GPU" % n, "value": value, "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 trunk GEMMs / f32" if (args.mixed_precision and agent.minibatch_size > 8) else "f32", "data": "synthetic",
         "config": {"workload": "BlockAssemblyGraspSim num_envs=%d per GPU, fp32, PPO MLP policy [1024,512,256], horizon 8, "
                                "minibatch_size %d, mini_epochs 5, central value (configs[1])" % (n, agent.minibatch_size),
                    "step": "one rl_games epoch = 8 env steps x num_envs + full PPO update", "global_envs": n * world,
-                   "piles": "synthetic settled piles, 8 per brick-type group",
+                   "piles": "synthetic settled piles, %d per brick-type group" % args.piles_per_type,
                    "policy": "random init, seed 22+rank" + (", then %d untimed training epochs" % args.pretrain_epochs if args.pretrain_epochs else "")},
         "fps_step": n * horizon * args.steps / step_t, "fps_step_and_inference": n * horizon * args.steps / play_t,
         "fps_total_rank0": n * horizon * args.steps / (play_t + upd_t),
         "update_ms_per_epoch": upd_t / args.steps * 1e3, "rollout_ms_per_epoch": play_t / args.steps * 1e3,
+        "update_path": ("multi-rank: hipGraph of [forward/backward -> RCCL all-gather of the rank-MB factors -> rebuild + clip + Adam]" if agent.multi_gpu
+                        else agent.ppo.update_impl()),
         "roofline": {"bound": dominant["bound"], "achieved": dominant["achieved"], "peak": dominant["peak"],
-                     "unit": dominant["unit"], "frac": dominant["frac"], "traffic": dominant["traffic"], "kernel": dominant["kernel"]},
+                     "unit": dominant["unit"], "frac": dominant["frac"], "traffic": dominant["traffic"], "kernel": dominant["kernel"],
+                     "traffic_is": "quoted from the committed rocprofv3 PMC passes (see traffic_counters.quoted_from), not measured in this run"
+                                   if dominant["traffic"] is not None else "not available for this configuration"},
         "roofline_physics": roof_phys, "roofline_update": roof_upd,
     }
     if world == 1 and not force_multi and args.minibatch is None and not args.no_large_minibatch:

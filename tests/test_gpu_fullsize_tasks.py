@@ -1,0 +1,200 @@
+"""-m gpu: the three tasks SURVEY.md section 8(f) ranks after GraspSim, at the sizes the reference runs them (Orient 1024, InsertSim
+2048 = its shipped numEnvs, Search 128 = the outer loop's), where the golden fixtures (16 envs) do not reach:
+  * the observation / state kernels against the numpy oracle (itself pinned to the reference's functions on CPU) on seeded random
+    simulator states for EVERY env - env-dependent branches (target brick by env % 8, plate height by env % 3) included;
+  * determinism: two instances, same seed, same actions -> bit-identical buffers, through resets;
+  * env independence: a small instance reproduces its env range of the big one bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import task_oracle as T  # noqa: E402
+
+TOL = dict(rtol=3e-5, atol=3e-5)
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _random_state(rng, n, scene):
+    lo, hi = scene.lower, scene.upper
+    root = rng.normal(size=(n, 142, 13)).astype(np.float32) * 0.3
+    rb = rng.normal(size=(n, 165, 13)).astype(np.float32) * 0.3
+    for a in (root, rb):
+        a[..., 3:7] /= np.linalg.norm(a[..., 3:7], axis=-1, keepdims=True)
+    dof = np.stack([lo + (hi - lo) * rng.uniform(size=(n, 23)), rng.normal(size=(n, 23))], -1).astype(np.float32)
+    contact = (rng.normal(size=(n, 165, 3)) * 0.08).astype(np.float32)
+    actions = rng.uniform(-1, 1, (n, 23)).astype(np.float32)
+    return root, rb, dof, contact, actions
+
+
+def _load(s, root, rb, dof, contact, actions):
+    n = root.shape[0]
+    s.ROOT.copy_(_dev(root.reshape(-1, 13))); s.RB.copy_(_dev(rb)); s.DOF.copy_(_dev(dof.reshape(-1, 2)))
+    s.CONTACT.copy_(_dev(contact.reshape(n, -1))); s.ACTIONS.copy_(_dev(actions))
+
+
+def test_orient_1024_observations_against_oracle(scene):
+    from seqdex_amd.sim import SdxSim
+    n = 1024
+    s = SdxSim(n, task_kind=1)
+    try:
+        rng = np.random.default_rng(5)
+        seg = np.array([scene.seg_index(i) for i in range(n)])
+        init_pos = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        init_rot = rng.normal(size=(n, 4)).astype(np.float32); init_rot /= np.linalg.norm(init_rot, axis=1, keepdims=True)
+        s.INIT_POS.copy_(_dev(init_pos)); s.INIT_ROT.copy_(_dev(init_rot))
+        st_prev = np.zeros((n, 564), np.float32)
+        for it in range(3):
+            root, rb, dof, contact, actions = _random_state(rng, n, scene)
+            _load(s, root, rb, dof, contact, actions)
+            s.compute_observations()
+            torch.cuda.synchronize()
+            obs = np.zeros((n, 186), np.float32)
+            obs[:, :62] = T.orient_obs_frame(dof, actions, scene.lower, scene.upper)
+            np.testing.assert_allclose(s.OBS.cpu().numpy(), obs, **TOL)                     # 62 numbers, never stacked (OR:1308-1326)
+            _, st, d = T.compute_observation_frames(root, rb, dof, contact, actions, seg, init_pos, init_rot, scene.lower, scene.upper,
+                                                    np.array(scene.camera_offset_quat, np.float32),
+                                                    np.array(scene.camera_offset_pos, np.float32), scene.fingertip_bodies)
+            st_prev = T.stack_frames(st_prev, st)
+            np.testing.assert_allclose(s.STATES.cpu().numpy(), st_prev, **TOL)               # asymmetric states as GraspSim, 188 x 3
+            tv = s.TVALUE.cpu().numpy()
+            assert set(np.unique(tv)) <= {0.0, 1.0}                                          # gated at 0.99 (OR:1203)
+    finally:
+        s.close()
+
+
+def test_insert_2048_observations_against_oracle(scene):
+    from seqdex_amd.sim import SdxSim
+    n = 2048
+    s = SdxSim(n, task_kind=2, max_episode_length=125.0)
+    try:
+        rng = np.random.default_rng(6)
+        seg = np.array([scene.seg_index(i) for i in range(n)])
+        init_pos = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        s.INIT_POS.copy_(_dev(init_pos))
+        for it in range(2):
+            root, rb, dof, contact, actions = _random_state(rng, n, scene)
+            progress = rng.integers(0, 124, n)
+            _load(s, root, rb, dof, contact, actions)
+            s.PROGRESS.copy_(_dev(progress))
+            s.compute_observations()
+            torch.cuda.synchronize()
+            o, st, d = T.insert_observation_frames(root, rb, dof, actions, seg, init_pos, scene.lower, scene.upper,
+                                                   np.array(scene.camera_offset_quat, np.float32),
+                                                   np.array(scene.camera_offset_pos, np.float32), scene.fingertip_bodies, progress)
+            np.testing.assert_allclose(s.OBS.cpu().numpy(), o, **TOL)                        # 75 numbers, one frame (IS:1280-1298)
+            got = s.STATES.cpu().numpy()
+            np.testing.assert_allclose(got[:, :188], st, **TOL)                              # one 188-wide frame, site-relative (IS:1220-1278)
+            assert not got[:, 188:].any()
+            # every env % 3 plate class and the env % 8 == 5 offset occur and were checked above
+            np.testing.assert_allclose(s.INSERT_AUX.cpu().numpy()[:, 3],
+                                       np.linalg.norm(root[np.arange(n), seg, 0:3] - d["extra_target_pos"], axis=-1), rtol=3e-5, atol=3e-6)
+    finally:
+        s.close()
+
+
+def test_search_128_observations_against_oracle(scene):
+    from seqdex_amd.sim import SdxSim
+    n = 128
+    s = SdxSim(n, task_kind=3, max_episode_length=75.0, act_moving_average=0.6, target_euler=[0.0, 3.14, 1.57])
+    try:
+        rng = np.random.default_rng(7)
+        seg = np.array([scene.seg_index(i) for i in range(n)])
+        ft = scene.fingertip_bodies
+        for it in range(2):
+            root, rb, dof, contact, actions = _random_state(rng, n, scene)
+            _load(s, root, rb, dof, contact, actions)
+            pix = np.stack([rng.integers(0, 400, n), rng.uniform(0, 128, n), rng.uniform(0, 128, n), np.zeros(n)], 1).astype(np.float32)
+            s.SEG_PIXELS.copy_(_dev(pix))
+            s.compute_observations()
+            torch.cuda.synchronize()
+            obs = np.zeros((n, 186), np.float32)
+            obs[:, :62] = T.search_obs_frame(dof, actions, scene.lower, scene.upper)
+            np.testing.assert_allclose(s.OBS.cpu().numpy(), obs, **TOL)
+            tgt = root[np.arange(n), seg]
+            tip = lambda b: (rb[:, b, 0:3] + T.quat_apply(rb[:, b, 3:7], np.broadcast_to(T.FT_OFFSET, (n, 3)))).astype(np.float32)
+            a = dict(arm_hand_ff_pos=tip(ft[0]), arm_hand_mf_pos=tip(ft[1]), arm_hand_rf_pos=tip(ft[2]), arm_hand_th_pos=tip(ft[3]),
+                     hand_base_pose=rb[:, 7, 0:7], segmentation_target_pose=tgt[:, 0:7], hand_base_linvel=rb[:, 7, 7:10],
+                     hand_base_angvel=rb[:, 7, 10:13], segmentation_target_linvel=tgt[:, 7:10], segmentation_target_angvel=tgt[:, 10:13],
+                     center_x=pix[:, 1], center_y=pix[:, 2], point_num=pix[:, 0])
+            for k in range(8):
+                a["hand_pos_history_%d" % k] = np.zeros((n, 3), np.float32)
+            for nm, b in zip(("ff", "mf", "rf", "th"), ft):
+                a["arm_hand_%s_rot" % nm], a["arm_hand_%s_linvel" % nm], a["arm_hand_%s_angvel" % nm] = rb[:, b, 3:7], rb[:, b, 7:10], rb[:, b, 10:13]
+            want = T.search_state_frame(dof, actions, scene.lower, scene.upper, a)
+            got = s.STATES.cpu().numpy()
+            np.testing.assert_allclose(got[:, :188], want, **TOL)
+            assert not got[:, 188:].any()
+    finally:
+        s.close()
+
+
+def _task(name, n, seed):
+    import yaml
+    from seqdex_amd.config import TASK_CFG
+    from seqdex_amd.tasks.block_assembly_insert_sim import BlockAssemblyInsertSim
+    from seqdex_amd.tasks.block_assembly_orient import BlockAssemblyOrient
+    from seqdex_amd.tasks.block_assembly_search import BlockAssemblySearch
+    from seqdex_amd.vec_task_rlgames import RLgamesVecTaskPython
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root_dir, "seqdex_amd", TASK_CFG[name])))
+    cfg["env"]["numEnvs"] = n
+    cls = {"BlockAssemblyOrient": BlockAssemblyOrient, "BlockAssemblyInsertSim": BlockAssemblyInsertSim, "BlockAssemblySearch": BlockAssemblySearch}[name]
+    task = cls(cfg, device_type="cuda", device_id=0, headless=True, seed=seed, piles_per_type=2)
+    return task, RLgamesVecTaskPython(task, "cuda:0")
+
+
+def _drive(env, task, n, steps, act_seed):
+    g = torch.Generator().manual_seed(act_seed)
+    # VecTask.reset() draws its 0.01 (1 - 2U) first action from torch's GLOBAL generator, as the reference does (VR:180); the same
+    # first step with a seeded action instead, so that two instances can be compared
+    env.step((0.01 * (1 - 2 * torch.rand(n, 23, generator=g))).cuda())
+    out = []
+    for _ in range(steps):
+        a = ((torch.rand(n, 23, generator=g) * 2 - 1) * 0.5).cuda()
+        obs, rew, reset, _ = env.step(a)
+        out.append((obs["obs"].cpu().numpy().copy(), obs["states"].cpu().numpy().copy(), rew.cpu().numpy().copy(), reset.cpu().numpy().copy()))
+    torch.cuda.synchronize()
+    return out, task.sim.ROOT.cpu().numpy().copy(), task.sim.DOF.cpu().numpy().copy()
+
+
+@pytest.mark.parametrize("name,n,steps,small", [("BlockAssemblyOrient", 1024, 6, 64), ("BlockAssemblyInsertSim", 2048, 10, 96),
+                                                ("BlockAssemblySearch", 128, 4, 32)])
+def test_task_fullsize_deterministic_and_env_independent(name, n, steps, small):
+    """through the VecTask surface (reset with its scripted / settling phases, device-side resets of InsertSim's short first episodes):
+    run-to-run bit-identical, and the first `small` envs of a `small`-env instance equal those of the big one bit for bit (same seed:
+    every per-env random stream is keyed by (seed, env index, step), no buffer is shared between envs)."""
+    ta, ea = _task(name, n, 31)
+    a, ra, da = _drive(ea, ta, n, steps, 1)
+    del ea, ta
+    tb, eb = _task(name, n, 31)
+    b, rb_, db = _drive(eb, tb, n, steps, 1)
+    del eb, tb
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(u, v)
+    np.testing.assert_array_equal(ra, rb_); np.testing.assert_array_equal(da, db)
+    assert np.isfinite(ra).all() and all(np.isfinite(x[0]).all() and np.isfinite(x[1]).all() and np.isfinite(x[2]).all() for x in a)
+    if name == "BlockAssemblyInsertSim":
+        return   # its resets draw from rings of grasp states that ALL envs of a brick-type group fill (as the reference's saved state
+                 # lists, IS:1416-1494): by design an env's restart depends on what the others harvested, so a smaller instance differs
+    # env independence: the action stream of the small instance is the first rows of the big one's
+    ts, es = _task(name, small, 31)
+    g = torch.Generator().manual_seed(1)
+    es.step((0.01 * (1 - 2 * torch.rand(n, 23, generator=g)))[:small].contiguous().cuda())
+    for t in range(steps):
+        act = ((torch.rand(n, 23, generator=g) * 2 - 1) * 0.5)[:small].contiguous().cuda()
+        obs, rew, reset, _ = es.step(act)
+        np.testing.assert_array_equal(obs["obs"].cpu().numpy(), a[t][0][:small], err_msg="%s obs step %d" % (name, t))
+        np.testing.assert_array_equal(obs["states"].cpu().numpy(), a[t][1][:small])
+        np.testing.assert_array_equal(rew.cpu().numpy(), a[t][2][:small])
+        np.testing.assert_array_equal(reset.cpu().numpy(), a[t][3][:small])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ts.sim.ROOT.cpu().numpy(), ra[:small * 142])
+    del es, ts

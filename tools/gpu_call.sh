@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 5 120 python tools/time_multi_rank_parts.py 1024 > gpurun_out/mr_parts.txt 2>&1; grep "us per call\|Error\|error" gpurun_out/mr_parts.txt | head
+(time timeout -k 5 600 python -m pytest tests/test_gpu_fullsize_tasks.py -m gpu -q -k deterministic) > gpurun_out/gputests.log 2>&1
+grep -E "passed|failed|Error|error|assert|Mismatch|Max |step" gpurun_out/gputests.log | tail -25
