@@ -49,6 +49,8 @@ extern "C" {
 #define SDX_TV_LOG_SLOTS 65536 /* rows of each T-value dataset ring (success / failure)                          */
 #define SDX_HARVEST_SLOTS 5001 /* ring of grasp terminal states per brick-type group (GS:1440: index wraps after 5000) */
 #define SDX_TV_PARAMS 42562 /* GraspInsertTValue 4-256-128-64-2 weights+biases (terminal_value_function.py:30-46) */
+#define SDX_RETRI_TV_PARAMS 1257346 /* RetriGraspTValue 650-1024-512-128-2 weights+biases (terminal_value_function.py:12-28) */
+#define SDX_RETRI_TV_IN 650    /* 65 x 10 (SE:397) */
 
 typedef enum {
   SDX_OK = 0,
@@ -108,7 +110,10 @@ typedef enum {
   SDX_T_JACOBIAN = 41,     /* f32 [N,23,6,23]   acquire_jacobian_tensor(sim, "hand") of a fixed-base articulation: link k+1 is row k, rows 0..2 linear,
                             *                    3..5 angular; the task reads [:, 7-1, :, :7] (GS:241,1601).  Refreshed by sdx_refresh_kinematics()
                             *                    (= gym.refresh_jacobian_tensors, GS:1095), NOT by sdx_step/sdx_simulate, which keep SDX_T_JAC_EEF current */
-  SDX_T_COUNT = 42
+  SDX_T_TVALUE_OBS = 42,   /* f32 [N,652]       Search: t_value_obs_buf, ten 65-number frames (SE:375,1155-1166), newest last; columns 650, 651 are row
+                            *                    padding (zeros).  Frame = obs_buf[:, 0:62] with [26:30] = camera-frame target quaternion, then the target's
+                            *                    pixel centroid / 128 and pixel count / 100 */
+  SDX_T_COUNT = 43
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the
@@ -213,6 +218,12 @@ int sdx_load_initial_states(sdx_handle h, const float* piles_host, int32_t K);
 /* GraspInsertTValue parameters (GS:417-419): host float32[SDX_TV_PARAMS] packed as
  * W1[256,4] b1[256] W2[128,256] b2[128] W3[64,128] b3[64] W4[2,64] b4[2].  Blocking. */
 int sdx_set_tvalue_weights(sdx_handle h, const float* params_host, int32_t n);
+
+/* BlockAssemblySearch only (task_kind 3): RetriGraspTValue(650, 2) parameters (SE:395-410): host float32[SDX_RETRI_TV_PARAMS] packed as
+ * W1[1024,650] b1[1024] W2[512,1024] b2[512] W3[128,512] b3[128] W4[2,128] b4[2] (torch layout W[out][in]).  Every step the task
+ * evaluates it on SDX_T_TVALUE_OBS as it stood BEFORE this step's frame is appended and stores sigmoid(out)[:, 1] in SDX_T_TVALUE
+ * (SE:1133-1134); like the reference's, the value reaches compute_hand_reward but does not enter the reward (SE:1687).  Blocking. */
+int sdx_set_retri_tvalue_weights(sdx_handle h, const float* params_host, int32_t n);
 
 /* BaseTask.step(actions) (BT:130-150) fused: pre_physics_step (GS:1555-1638, device-side masked reset
  * instead of reset_buf.nonzero()) -> simulate x controlFreqInv (BT:138-140) -> post_physics_step

@@ -591,3 +591,44 @@ def search_heap_movement(brick_pos):
     """SE:1648-1652: number of bricks thrown out of the bin region (|x - 1| > 0.25 and |y| > 0.35 in the env frame)"""
     out = (np.abs(brick_pos[:, :, 0] - 1) > 0.25) & (np.abs(brick_pos[:, :, 1]) > 0.35)
     return out.sum(axis=1).astype(F)
+
+
+# ------------------------------------------------------------------------------------------------ Search: RetriGraspTValue (SE:395-410,1133-1166)
+RETRI_LAYERS = (("linear1", 1024, 650), ("linear2", 512, 1024), ("linear3", 128, 512), ("output_layer", 2, 128))   # terminal_value_function.py:12-19
+
+
+def retri_tvalue_formula_weights():
+    """a fixed, formula-defined parameter set for RetriGraspTValue(650, 2) (1.26 M numbers are too many for a fixture file): the golden
+    generator loads exactly these into the reference's module, the tests load them into the oracle and the GPU task"""
+    sd = {}
+    for li, (name, out, inn) in enumerate(RETRI_LAYERS):
+        i = np.arange(out, dtype=np.float64)[:, None]
+        j = np.arange(inn, dtype=np.float64)[None, :]
+        sd[name + ".weight"] = (np.sin(0.37 * i + 0.11 * j + 0.5 * li) * np.cos(0.013 * i * (1 + li) - 0.029 * j) / np.sqrt(inn)).astype(F)
+        sd[name + ".bias"] = (0.05 * np.cos(0.7 * np.arange(out, dtype=np.float64) + li)).astype(F)
+    return sd
+
+
+def retri_tvalue_forward(x, sd):
+    """RetriGraspTValue.forward (terminal_value_function.py:21-27): ELU after every layer, the output layer included; returns the two
+    activations and tvalue = sigmoid(out)[:, 1] (SE:1133-1134)"""
+    h = x.astype(F)
+    for name, _, _ in RETRI_LAYERS:
+        h = elu(h @ sd[name + ".weight"].T.astype(F) + sd[name + ".bias"].astype(F)).astype(F)
+    return h, (F(1) / (F(1) + np.exp(-h[:, 1]))).astype(F)
+
+
+def search_tvalue_buffer_update(buf, obs62, cam_rot, center_x, center_y, point_num):
+    """the ten-frame buffer of SE:1155-1166: frames 0..8 <- frames 1..9, frame 9 <- [obs_buf[:, 0:62] with columns 26..29 replaced by the
+    camera-frame target quaternion, centroid x / 128, centroid y / 128, pixel count / 100].  buf [N, 650] (returns a new array)"""
+    n = buf.shape[0]
+    out = np.zeros_like(buf, dtype=F)
+    out[:, :9 * 65] = buf[:, 65:]
+    fr = np.zeros((n, 65), dtype=F)
+    fr[:, 0:62] = obs62
+    fr[:, 26:30] = cam_rot
+    fr[:, 62] = center_x.reshape(-1) / F(128)
+    fr[:, 63] = center_y.reshape(-1) / F(128)
+    fr[:, 64] = point_num.reshape(-1) / F(100)
+    out[:, 9 * 65:] = fr
+    return out

@@ -13,6 +13,7 @@ ACTORS, BODIES, ACTOR_BRICK0, BODY_BRICK0 = 142, 165, 9, 32
 NUM_OBS, NUM_STATES, NUM_ACTIONS, OBS_FRAME, STATE_FRAME = 396, 564, 23, 132, 188
 HARVEST_SLOTS = 5001      # SDX_HARVEST_SLOTS
 TV_PARAMS = 42562
+RETRI_TV_PARAMS = 1257346   # RetriGraspTValue 650-1024-512-128-2
 
 f32, i32 = C.c_float, C.c_int32
 
@@ -73,14 +74,14 @@ T = dict(ROOT=0, DOF=1, RB=2, CONTACT=3, JAC_EEF=4, TARGETS=5, PREV_TARGETS=6, O
          STATES_CLAMPED=10, REW=11, RESET=12, PROGRESS=13, RANDOMIZE=14, ACTIONS=15, INIT_POS=16, INIT_ROT=17,
          SUCCESSES=18, META_REW=19, CONS_SUCCESSES=20, FINGER_DIST=21, TVALUE=22, ARM_CONTACTS=23, STUDENT_OBS=24,
          SUCCESS_BUF=25, PILE_CHOICE=26, NCONTACTS=27, DEBUG=28, HARVEST_HAND=29, HARVEST_OBJ=30,
-         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35, PILE_HARVEST=36, PILE_HARVEST_COUNT=37, SEG_IMAGE=38, SEG_PIXELS=39, EMERGENCE=40, JACOBIAN=41)
+         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35, PILE_HARVEST=36, PILE_HARVEST_COUNT=37, SEG_IMAGE=38, SEG_PIXELS=39, EMERGENCE=40, JACOBIAN=41, TVALUE_OBS=42)
 # sdxp_tensor_id
 TP = dict(AC_PARAMS=0, AC_GRADS=1, CV_PARAMS=2, CV_GRADS=3, MB_OBS=4, MB_STATES=5, MB_ACTIONS=6, MB_MUS=7,
           MB_SIGMAS=8, MB_NEGLOGP=9, MB_VALUES=10, MB_REWARDS=11, MB_DONES=12, RETURNS=13, ADVANTAGES=14,
           CV_RMS_MEAN=15, CV_RMS_VAR=16, STATS=17, LAST_VALUES=18, AC_ADAM_M=19, AC_ADAM_V=20, CV_ADAM_M=21,
           CV_ADAM_V=22, DEBUG=23, ALL_GRADS=24, FACTORS=25, FACTORS_ALL=26)
 
-SDX_EXPORTS = ["sdx_create", "sdx_destroy", "sdx_tensor", "sdx_load_initial_states", "sdx_set_tvalue_weights",
+SDX_EXPORTS = ["sdx_create", "sdx_destroy", "sdx_tensor", "sdx_load_initial_states", "sdx_set_tvalue_weights", "sdx_set_retri_tvalue_weights",
                "sdx_step", "sdx_pre_physics", "sdx_simulate", "sdx_post_physics", "sdx_compute_observations",
                "sdx_reset_idx", "sdx_set_indexed", "sdx_refresh_kinematics", "sdx_render_segmentation", "sdx_num_envs", "sdx_last_error",
                "sdxp_create", "sdxp_destroy", "sdxp_tensor", "sdxp_param_count", "sdxp_act", "sdxp_store_rewards",
@@ -107,6 +108,7 @@ def load_library():
     lib.sdx_tensor.argtypes = [vp, i32, C.POINTER(vp), i64p, i32p, i32p]
     lib.sdx_load_initial_states.argtypes = [vp, vp, i32]
     lib.sdx_set_tvalue_weights.argtypes = [vp, vp, i32]
+    lib.sdx_set_retri_tvalue_weights.argtypes = [vp, vp, i32]
     for n in ["sdx_step", "sdx_pre_physics"]:
         getattr(lib, n).argtypes = [vp, vp, vp]
     for n in ["sdx_simulate", "sdx_post_physics", "sdx_compute_observations", "sdx_refresh_kinematics", "sdx_render_segmentation"]:

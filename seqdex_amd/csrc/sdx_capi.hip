@@ -157,6 +157,11 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(seg_image, scene->task_kind == 3 ? (size_t)N * 128 * 128 : 1);
   ALLOC(seg_pix, (size_t)N * 4);
   ALLOC(emergence, N);
+  if (scene->task_kind == 3) {
+    ALLOC(tvt_buf, (size_t)N * 652);
+    ALLOC(tvt_w, (size_t)1024 * 652 + 1024 + 512 * 1024 + 512 + 128 * 512 + 128 + 2 * 128 + 2);
+    ALLOC(tvt_h, (size_t)N * (1024 + 512 + 128 + 4));
+  }
 #undef ALLOC
   set_tensor(h, SDX_T_ROOT, B.root, SDX_F32, {(int64_t)N * SDX_ACTORS, 13});
   set_tensor(h, SDX_T_DOF, B.dof, SDX_F32, {(int64_t)N * SDX_NDOF, 2});
@@ -201,6 +206,8 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_SEG_PIXELS, B.seg_pix, SDX_F32, {N, 4});
   set_tensor(h, SDX_T_EMERGENCE, B.emergence, SDX_F32, {N});
   set_tensor(h, SDX_T_JACOBIAN, B.jac_full, SDX_F32, {N, SDX_NLINK - 1, 6, SDX_NDOF});
+  if (scene->task_kind == 3) set_tensor(h, SDX_T_TVALUE_OBS, B.tvt_buf, SDX_F32, {N, 652});
+  else set_tensor(h, SDX_T_TVALUE_OBS, B.seg_pix, SDX_F32, {1, 1});   // placeholder: the temporal buffer belongs to Search
 
   // ---- initial actor states (what create_actor's start poses give, GS:897-1000)
   std::vector<float> root((size_t)N * SDX_ACTORS * 13, 0.0f), rbv((size_t)N * SDX_BODIES * 13, 0.0f);
@@ -298,6 +305,20 @@ extern "C" int sdx_set_tvalue_weights(sdx_handle h, const float* w, int32_t n) {
   }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpy(h->buf.tv_w, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  return SDX_OK;
+}
+
+extern "C" int sdx_set_retri_tvalue_weights(sdx_handle h, const float* w, int32_t n) {
+  if (!h) return SDX_ERR_INVALID;
+  if (h->h_const.sc.task_kind != 3) { h->err = "sdx_set_retri_tvalue_weights: RetriGraspTValue belongs to BlockAssemblySearch (task_kind 3)"; return SDX_ERR_STATE; }
+  if (!w || n != SDX_RETRI_TV_PARAMS) { h->err = "sdx_set_retri_tvalue_weights: expected SDX_RETRI_TV_PARAMS floats"; return SDX_ERR_INVALID; }
+  // device layout = host layout with the rows of W1 padded from 650 to 652 columns (16-byte rows for the float4 loads of the GEMM)
+  std::vector<float> t((size_t)1024 * 652 + (n - (size_t)1024 * 650), 0.0f);
+  for (int r = 0; r < 1024; ++r) memcpy(&t[(size_t)r * 652], w + (size_t)r * 650, 650 * sizeof(float));
+  memcpy(&t[(size_t)1024 * 652], w + (size_t)1024 * 650, (n - (size_t)1024 * 650) * sizeof(float));
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(h->buf.tvt_w, t.data(), t.size() * 4, hipMemcpyHostToDevice));
   return SDX_OK;
 }
 

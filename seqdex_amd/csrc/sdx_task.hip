@@ -716,6 +716,41 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ Search: temporal T-value (SE:1133-1166)
+#define TVT_STRIDE 652
+#define TVT_FRAME 65
+// B.tvalue = sigmoid(out[:, 1]) of the RetriGraspTValue forward that the host launcher ran on the buffer of the PREVIOUS step (SE:1133-1134)
+__global__ void k_search_tvalue_out(SdxBuf B) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B.N) return;
+  const float y = B.tvt_h[(size_t)B.N * (1024 + 512 + 128) + (size_t)e * 2 + 1];   // ELU already applied by the last layer (the reference activates the output layer too)
+  B.tvalue[e] = 1.0f / (1.0f + expf(-y));
+}
+// shift the ten frames by one and append this step's (SE:1155-1166): obs_buf[:, 0:62] with [26:30] = camera-frame target quaternion,
+// centroid x / 128, centroid y / 128, pixel count / 100.  One wave per env; the shift reads a frame before anything overwrites it.
+__global__ __launch_bounds__(SDX_WAVE) void k_search_tvalue_append(SdxBuf B) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  float* row = B.tvt_buf + (size_t)e * TVT_STRIDE;
+  for (int f = 0; f < 9; ++f) {
+    float a = 0.0f, b = 0.0f;
+    if (lane < TVT_FRAME) a = row[(f + 1) * TVT_FRAME + lane];
+    if (lane == 0) b = row[(f + 1) * TVT_FRAME + 64];
+    __syncthreads();
+    if (lane < 64) row[f * TVT_FRAME + lane] = a;
+    if (lane == 0) row[f * TVT_FRAME + 64] = b;
+    __syncthreads();
+  }
+  float v = 0.0f;
+  if (lane < 62) v = B.obs[(size_t)e * B.obs_w + lane];
+  if (lane >= 26 && lane < 30) v = B.cam_rot[(size_t)e * 4 + lane - 26];
+  if (lane == 62) v = B.seg_pix[(size_t)e * 4 + 1] / 128.0f;       // segmentation_object_center_point_x
+  if (lane == 63) v = B.seg_pix[(size_t)e * 4 + 2] / 128.0f;
+  row[9 * TVT_FRAME + lane] = v;
+  if (lane == 0) row[9 * TVT_FRAME + 64] = B.seg_pix[(size_t)e * 4 + 0] / 100.0f;
+}
+extern "C" void sdxpk_linear(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int elu_flag,
+                             const double* nmean, const double* nvar, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------------ host launchers
 // ------------------------------------------------------------------------------------------------ BlockAssemblyOrient reset
 // The Orient task scripts the arm with the tracking IK of its pre_physics_step while the simulator runs 50 steps, twice per reset:
@@ -818,4 +853,25 @@ extern "C" void sdxk_pre_physics(const SdxConst* C, const SdxBuf* B, const float
 extern "C" void sdxk_post_physics(const SdxConst* C, const SdxBuf* B, int flags, hipStream_t st) {
   hipLaunchKernelGGL(k_post_physics, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, flags);
   hipLaunchKernelGGL(k_tvalue, dim3((B->N + TV_ENVS - 1) / TV_ENVS), dim3(256), 0, st, *B, flags & 1);
+  if (B->task_kind == 3 && B->tvt_buf) {   // Search's own T-value: RetriGraspTValue on the ten-frame buffer as it stood before this step
+    const int N = B->N;
+    const float* W1 = B->tvt_w;
+    const float* b1 = W1 + (size_t)1024 * TVT_STRIDE;
+    const float* W2 = b1 + 1024;
+    const float* b2 = W2 + (size_t)512 * 1024;
+    const float* W3 = b2 + 512;
+    const float* b3 = W3 + (size_t)128 * 512;
+    const float* W4 = b3 + 128;
+    const float* b4 = W4 + 2 * 128;
+    float* h1 = B->tvt_h;
+    float* h2 = h1 + (size_t)N * 1024;
+    float* h3 = h2 + (size_t)N * 512;
+    float* o = h3 + (size_t)N * 128;
+    sdxpk_linear(B->tvt_buf, W1, b1, h1, N, 1024, TVT_STRIDE, 1, nullptr, nullptr, st);
+    sdxpk_linear(h1, W2, b2, h2, N, 512, 1024, 1, nullptr, nullptr, st);
+    sdxpk_linear(h2, W3, b3, h3, N, 128, 512, 1, nullptr, nullptr, st);
+    sdxpk_linear(h3, W4, b4, o, N, 2, 128, 1, nullptr, nullptr, st);
+    hipLaunchKernelGGL(k_search_tvalue_out, dim3((N + 255) / 256), dim3(256), 0, st, *B);
+    hipLaunchKernelGGL(k_search_tvalue_append, dim3(N), dim3(SDX_WAVE), 0, st, *B);
+  }
 }

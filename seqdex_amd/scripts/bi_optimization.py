@@ -2,7 +2,9 @@
 
     forward initialisation : train the sub-policies in chain order, each starting from what its predecessor produced
     backward fine-tuning   : run the LAST policy again to collect success / failure data, fit the transition value on it, give it to
-                             the policy before it and fine-tune that one, and so on towards the front of the chain
+                             the policy before it and fine-tune that one, and so on towards the front of the chain:
+                             InsertSim -> fit -> GraspSim -> fit -> Orient -> fit (bi_optimization.py:120-124; every fit is the
+                             4-input GraspInsertTValue on the camera-frame quaternions that task logged at its episode ends)
 
 for the chain BlockAssemblySearch -> BlockAssemblyOrient -> BlockAssemblyGraspSim -> BlockAssemblyInsertSim.  Where the reference hands data over through files (pickles of terminal states, an HDF5 file of
 quaternions, .pth checkpoints), the stages here hand over device tensors of the same content; checkpoints are still written.
@@ -88,8 +90,14 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
                                  task_kwargs={"grasp_states": grasp_states}, keep=True, minibatch_size=insert_minibatch)
         tv = transition_value_trainer(insert, tvalue_rollout, tv, seed=i)
         insert.sim.close()
-        paths["grasp"], _ = main_rlgames("BlockAssemblyGraspSim", num_envs, use_t_value=True, policy_path=paths["grasp"],
-                                         max_iterations=epochs, tvalue_state=tv)
+        paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, use_t_value=True, policy_path=paths["grasp"],
+                                             max_iterations=epochs, tvalue_state=tv, keep=True, task_kwargs={"initial_piles": piles})
+        tv = transition_value_trainer(grasp, tvalue_rollout, tv, seed=100 + i)            # bi_optimization.py:122: fit on GraspSim's own outcomes
+        grasp.sim.close()
+        paths["orient"], orient = main_rlgames("BlockAssemblyOrient", min(num_envs, 128), use_t_value=True, policy_path=paths["orient"],
+                                               max_iterations=epochs, tvalue_state=tv, keep=True, task_kwargs={"initial_piles": dug})   # :123
+        tv = transition_value_trainer(orient, tvalue_rollout, tv, seed=200 + i)           # bi_optimization.py:124
+        orient.sim.close()
         print("bi-optimisation round %d done: %s" % (i, paths))
     return paths, tv
 

@@ -98,6 +98,19 @@ class SdxSim:
         assert flat.size == _abi.TV_PARAMS
         self._check(self.lib.sdx_set_tvalue_weights(self.h, flat.ctypes.data_as(C.c_void_p), flat.size))
 
+    def set_retri_tvalue_weights(self, state_dict_or_flat):
+        """BlockAssemblySearch: RetriGraspTValue(650, 2) parameters (state_dict with linear1/2/3 + output_layer, or the flat packing)"""
+        if isinstance(state_dict_or_flat, dict):
+            parts = []
+            for n in ["linear1", "linear2", "linear3", "output_layer"]:
+                parts.append(np.asarray(state_dict_or_flat[n + ".weight"], dtype=np.float32).ravel())
+                parts.append(np.asarray(state_dict_or_flat[n + ".bias"], dtype=np.float32).ravel())
+            flat = np.concatenate(parts)
+        else:
+            flat = np.ascontiguousarray(state_dict_or_flat, dtype=np.float32)
+        assert flat.size == _abi.RETRI_TV_PARAMS, flat.size
+        self._check(self.lib.sdx_set_retri_tvalue_weights(self.h, flat.ctypes.data_as(C.c_void_p), flat.size))
+
     def _act_ptr(self, actions):
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
         assert actions.shape == (self.num_envs, _abi.NUM_ACTIONS)

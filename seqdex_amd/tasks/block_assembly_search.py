@@ -13,7 +13,8 @@ The hand digs through the brick pile until the target brick becomes visible to a
   * reset (SE:1274-1538): success = more target pixels than the brick type's threshold; successes hand their whole pile on
     (`pile_terminal_states()` -> `BlockAssemblyOrient(initial_piles=...)`); bricks back on the spawn lattice with +-0.02 noise, target
     dropped from 0.9 m, 60 settling steps, render, hand to the prepare pose.
-Not reproduced: the 10-frame temporal T-value buffer (SE:1155-1166; the T-value does not enter this task's reward), teleoperation
+Also built: RetriGraspTValue(650, 2) on the ten-frame buffer of 65-number frames (SE:395-410,1133-1166; computed and exposed as in the
+reference, where it does not enter the reward either).  Not reproduced: teleoperation
 perturbations, cv2 debug windows, the hand states saved next to the piles (SE:1325).  The pixel counts come from box geometry, not
 from the studded meshes: thresholds tuned on Isaac Gym's renderer are only approximately meaningful (parity unpinned).
 """
@@ -52,6 +53,15 @@ class BlockAssemblySearch(BlockAssemblyOrient):
         super().__init__(cfg, sim_params, physics_engine, device_type, device_id, headless, agent_index, is_multi_agent, seed,
                          lattice, piles_per_type)
         s = self.sim
+        # RetriGraspTValue(650, 2) with torch-default init (SE:395-400); evaluated every step on the ten-frame buffer (SE:1133-1166)
+        g = torch.Generator().manual_seed(seed + 1)
+        flat = []
+        for fin, fout in ((650, 1024), (1024, 512), (512, 128), (128, 2)):
+            b = 1.0 / (fin ** 0.5)
+            flat.append(((torch.rand(fout, fin, generator=g) * 2 - 1) * b).reshape(-1))
+            flat.append((torch.rand(fout, generator=g) * 2 - 1) * b)
+        s.set_retri_tvalue_weights(torch.cat(flat).numpy())
+        self.t_value_obs_buf = s.TVALUE_OBS                                       # [N, 652]: 650 + 2 padding columns
         self.segmentation_pixels, self.emergence_reward = s.SEG_PIXELS, s.EMERGENCE
         self.extras["emergence_reward"] = s.EMERGENCE                          # SE:965
 

@@ -210,3 +210,39 @@ def test_search_task_end_to_end(scene):
         ot.step(torch.zeros(n, 23).cuda())
         torch.cuda.synchronize()
         assert np.isfinite(ot.sim.ROOT.cpu().numpy()).all()
+
+
+def test_search_retri_tvalue_and_temporal_buffer(search16, golden_dir, scene):
+    """RetriGraspTValue(650, 2) on the ten-frame buffer (SE:395-410,1133-1166): the value of a step is the network applied to the buffer as
+    it stood BEFORE the step's frame is appended (golden vectors from the reference's module class), and the append is the shift of
+    SE:1155-1166 (numpy restatement)."""
+    f = np.load(os.path.join(golden_dir, "S7_retri_tvalue.npz"))
+    g3 = np.load(os.path.join(golden_dir, "F3_observations.npz"))
+    s, n = search16, 16
+    s.set_retri_tvalue_weights(T.retri_tvalue_formula_weights())
+    assert tuple(s.TVALUE_OBS.shape) == (n, 652)
+    buf = np.zeros((n, 652), np.float32)
+    buf[:, :650] = f["x"]
+    s.TVALUE_OBS.copy_(_dev(buf))
+    s.ROOT.copy_(_dev(g3["c0_root"])); s.RB.copy_(_dev(g3["c0_rb"])); s.DOF.copy_(_dev(g3["c0_dof"]).view(-1, 2))
+    s.CONTACT.copy_(_dev(g3["c0_contact"])); s.ACTIONS.copy_(_dev(g3["c0_actions"]))
+    pix = np.stack([np.arange(n) * 9.0, np.arange(n) + 30.0, 90.0 - np.arange(n), np.zeros(n)], 1).astype(np.float32)
+    s.SEG_PIXELS.copy_(_dev(pix))
+    s.compute_observations()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(s.TVALUE.cpu().numpy(), f["tvalue"], rtol=2e-4, atol=2e-4)        # fp32 MFMA chain over K = 650 / 1024 / 512
+    # the frame appended by the same call
+    obs = s.OBS.cpu().numpy()
+    root = g3["c0_root"].reshape(n, 142, 13)
+    want = T.search_tvalue_buffer_update(f["x"], obs[:, :62], np.zeros((n, 4), np.float32), pix[:, 1], pix[:, 2], pix[:, 0])
+    got = s.TVALUE_OBS.cpu().numpy()
+    assert not got[:, 650:].any()
+    mask = np.ones(650, bool); mask[585 + 26:585 + 30] = False                                   # the camera-frame quaternion is checked below
+    np.testing.assert_allclose(got[:, :650][:, mask], want[:, mask], rtol=1e-6, atol=1e-6)
+    q = got[:, 585 + 26:585 + 30]
+    np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-4)                        # a unit quaternion: camera_view_segmentation_target_rot
+    # a second step evaluates the network on the shifted buffer
+    s.compute_observations()
+    torch.cuda.synchronize()
+    _, tv2 = T.retri_tvalue_forward(got[:, :650], T.retri_tvalue_formula_weights())
+    np.testing.assert_allclose(s.TVALUE.cpu().numpy(), tv2, rtol=2e-4, atol=2e-4)

@@ -50,3 +50,25 @@ def test_search_reward_golden(golden_dir):
     np.testing.assert_allclose(em, g["em_reward"], **TOL)
     np.testing.assert_array_equal(T.search_heap_movement(g["heap_pos"]), g["heap_penalty"])
     assert g["heap_penalty"].max() > 0
+
+
+def test_retri_tvalue_forward_golden(golden_dir):
+    """RetriGraspTValue(650, 2) of the reference (terminal_value_function.py:12-28) with the formula-defined parameters: the numpy
+    restatement reproduces the module's output and the sigmoid the task takes of it (SE:1133-1134)"""
+    f = np.load(os.path.join(golden_dir, "S7_retri_tvalue.npz"))
+    out, tv = T.retri_tvalue_forward(f["x"], T.retri_tvalue_formula_weights())
+    np.testing.assert_allclose(out, f["out"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(tv, f["tvalue"], rtol=2e-5, atol=2e-5)
+    assert sum(w.size for w in T.retri_tvalue_formula_weights().values()) == 1257346
+
+
+def test_search_tvalue_buffer_shift():
+    rng = np.random.default_rng(0)
+    buf = rng.normal(size=(4, 650)).astype(np.float32)
+    obs = rng.normal(size=(4, 62)).astype(np.float32)
+    q = rng.normal(size=(4, 4)).astype(np.float32)
+    nb = T.search_tvalue_buffer_update(buf, obs, q, np.full(4, 64.0, np.float32), np.full(4, 32.0, np.float32), np.full(4, 250.0, np.float32))
+    np.testing.assert_array_equal(nb[:, :585], buf[:, 65:])
+    np.testing.assert_array_equal(nb[:, 585:611], obs[:, :26]); np.testing.assert_array_equal(nb[:, 611:615], q)
+    np.testing.assert_array_equal(nb[:, 615:647], obs[:, 30:62])
+    np.testing.assert_allclose(nb[:, 647:650], np.tile([0.5, 0.25, 2.5], (4, 1)))
