@@ -2,13 +2,14 @@
 its Search->Orient stages (GS:412-413, 1507-1513); that artefact is not shipped, so the engine settles its own:
 72 free bricks dropped from the spawn lattice (GS:737-742) with per-pile jitter, robot parked in the prepare pose,
 `steps` simulate() calls on the GPU."""
+import pickle
+
 import numpy as np
 import torch
 
-from .sim import SdxSim
-
 
 def generate_piles(per_type=8, steps=150, device="cuda:0", seed=22):
+    from .sim import SdxSim
     n = 8 * per_type
     sim = SdxSim(n, device=device, seed=seed)
     try:
@@ -40,3 +41,40 @@ def generate_piles(per_type=8, steps=150, device="cuda:0", seed=22):
         return out
     finally:
         sim.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The reference's on-disk hand-off of pile states (GS:412-413, OR:419-420 read; SE:1349-1350, OR:1505-1510 write):
+#   pickle.dump(saved_searching_ternimal_states_list, f) - a python list of 8 torch tensors [slots, 132, 13] (one per brick-type
+#   group; slots = 10000 + num_envs in the reference, filled from index 0, unfilled slots all zero).
+def save_pile_pickle(path, piles, counts=None):
+    """piles: [8, K, 132, 13] (tensor / array) or a list of 8 [K_t, 132, 13]; writes the reference's list-of-8-tensors pickle"""
+    if not isinstance(piles, (list, tuple)):
+        piles = [torch.as_tensor(np.asarray(piles[t])) for t in range(8)]
+    out = []
+    for t in range(8):
+        x = torch.as_tensor(np.asarray(piles[t].cpu() if torch.is_tensor(piles[t]) else piles[t]), dtype=torch.float32)
+        if counts is not None:
+            x = x[:int(counts[t])]
+        assert x.ndim == 3 and tuple(x.shape[1:]) == (132, 13), tuple(x.shape)
+        out.append(x.contiguous())
+    with open(path, "wb") as f:
+        pickle.dump(out, f)
+
+
+def load_pile_pickle(path):
+    """the reference's pickle (or one written by save_pile_pickle) -> float32 [8, K, 132, 13] for sdx_load_initial_states, K = the
+    smallest number of FILLED slots over the 8 groups (a slot is filled when any brick has a non-zero quaternion)"""
+    with open(path, "rb") as f:
+        lst = pickle.load(f)
+    assert isinstance(lst, (list, tuple)) and len(lst) == 8, "expected a list of 8 tensors [slots, 132, 13]"
+    arrs, ks = [], []
+    for x in lst:
+        a = np.asarray(x.detach().cpu().numpy() if torch.is_tensor(x) else x, dtype=np.float32).reshape(-1, 132, 13)
+        filled = np.abs(a[:, :, 3:7]).sum(axis=(1, 2)) > 0
+        k = int(filled.sum()) if filled.all() or not filled.any() else int(np.argmin(filled))   # filled from index 0: first empty slot
+        arrs.append(a); ks.append(k)
+    k = min(ks)
+    if k == 0:
+        raise ValueError("load_pile_pickle: a brick-type group has no saved pile state")
+    return np.stack([a[:k] for a in arrs]).astype(np.float32)

@@ -75,6 +75,9 @@ class BlockAssemblyGraspSim:
         self.total_steps = 0
         # saved pile states: the reference unpickles intermediate_state/...tvalue.pkl (GS:412-413), produced by the
         # Search->Orient stages; that artefact is not shipped, so piles are settled with the engine itself.
+        if isinstance(initial_piles, str):                                    # the reference's pickle: list[8] of [slots, 132, 13] (GS:412-413)
+            from ..piles import load_pile_pickle
+            initial_piles = load_pile_pickle(initial_piles)
         if initial_piles is None:
             initial_piles = generate_piles(piles_per_type, device=self.device, seed=seed)
         s.load_initial_states(initial_piles)

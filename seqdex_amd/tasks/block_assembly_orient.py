@@ -36,3 +36,12 @@ class BlockAssemblyOrient(BlockAssemblyGraspSim):
         cnt = np.minimum(s.PILE_HARVEST_COUNT.cpu().numpy(), s.PILE_HARVEST.shape[1])
         k = int(cnt.min())
         return s.PILE_HARVEST[:, :k].clone() if k > 0 else None
+
+    def save_pile_terminal_states(self, path):
+        """the harvested piles as the reference's pickle (list[8] of [K_t, 132, 13]; OR:1505-1510, SE:1349-1350): what
+        `BlockAssemblyGraspSim(initial_piles=path)` / the reference's GS:412-413 load"""
+        import numpy as np
+        from ..piles import save_pile_pickle
+        s = self.sim
+        cnt = np.minimum(s.PILE_HARVEST_COUNT.cpu().numpy(), s.PILE_HARVEST.shape[1])
+        save_pile_pickle(path, [s.PILE_HARVEST[t] for t in range(8)], counts=cnt)

@@ -129,3 +129,30 @@ def test_rlgames_checkpoint_layout_round_trip():
     c3 = cv3[:1024 * 564].reshape(1024, 564)
     assert torch.equal(c3[:, :188], cv[:1024 * 564].reshape(1024, 564)[:, :188]) and not c3[:, 188:].any()
     assert rms3[2] == 5.0 and torch.equal(rms3[0][:188], torch.arange(188.0).double()) and not rms3[0][188:].any()
+
+
+def test_pile_pickle_round_trip(tmp_path):
+    """the reference hands pile states over as a pickled list of 8 tensors [slots, 132, 13] filled from index 0 (GS:412-413, SE:1349-1350);
+    written and read back, with the reference's zero-padded tail trimmed to the filled slots"""
+    import pickle
+    import numpy as np
+    import torch
+    from seqdex_amd.piles import load_pile_pickle, save_pile_pickle
+    rng = np.random.default_rng(0)
+    piles = rng.normal(size=(8, 5, 132, 13)).astype(np.float32)
+    piles[..., 3:7] /= np.linalg.norm(piles[..., 3:7], axis=-1, keepdims=True)
+    p = str(tmp_path / "piles.pkl")
+    save_pile_pickle(p, piles)
+    lst = pickle.load(open(p, "rb"))
+    assert isinstance(lst, list) and len(lst) == 8 and all(torch.is_tensor(x) and tuple(x.shape) == (5, 132, 13) for x in lst)
+    np.testing.assert_array_equal(load_pile_pickle(p), piles)
+    # the reference's buffers are larger than what was filled: slots past the fill index are zero; groups may be filled unevenly
+    big = [torch.zeros(40, 132, 13) for _ in range(8)]
+    for t in range(8):
+        big[t][:3 + t % 2] = torch.as_tensor(piles[t, :3 + t % 2])
+    pickle.dump(big, open(p, "wb"))
+    got = load_pile_pickle(p)
+    assert got.shape == (8, 3, 132, 13)
+    np.testing.assert_array_equal(got, piles[:, :3])
+    save_pile_pickle(p, piles, counts=[2] * 8)
+    assert load_pile_pickle(p).shape == (8, 2, 132, 13)
