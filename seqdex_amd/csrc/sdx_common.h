@@ -69,8 +69,10 @@ struct SdxBuf {
 // the kernels with g++ for the CPU, where the constraint letter does not exist.)
 #ifdef HIPEMU
 #define SDX_OPAQUE(x) ((void)0)
+#define SDX_RCP(x) (1.0f / (x))
 #else
 #define SDX_OPAQUE(x) asm volatile("" : "+v"(x))
+#define SDX_RCP(x) __builtin_amdgcn_rcpf(x)   // v_rcp_f32, 1 ulp: the solver's step lengths do not need IEEE division (12 instructions)
 #endif
 
 // sums over aligned groups of 4 / 8 lanes with DPP moves (VALU speed; __shfl_xor goes through ds_bpermute and its LDS latency):

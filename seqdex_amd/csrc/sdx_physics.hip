@@ -53,14 +53,15 @@ struct PhysLds {
   // robot
   float q[ND], qd[ND + 1], tgt[ND], qds[ND], Q[ND], tau[ND];   // qd[ND] = 0: the padding dof of exhausted paths
   float lq[NL][4], la[NL + 1][3], lc[NL][3], lI[NL][6];
-  float lal[NL][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
+  float lal[NL + 1][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
   float A[ND][HP];      // H -> L -> Hinv
   uint32_t anc[NL];     // bit j: dof j lies on the path base -> link
+  int par[NL + 1];      // parent link; [NL] = NL: the padding link of exhausted paths (zero rows of the body table)
   float cf[NL][3];
   // bricks (centre-of-box frame) and their per-brick constants
   // position / linear / angular velocity of EVERY body in one table: bricks 0..71 (centre of the box), links 72..95 (frame origin),
   // entry 96 = the static world (zeros): the solver's point velocities need no case distinction
-  float bp[NBODY][3], bv[NBODY][3], bw[NBODY][3];
+  float bp[NBODY][3], bv[NBODY][3], bw[NBODY][3];   // (16-byte rows + ds_read_b96 were tried: register tuples push 21 reloads into the solver loop)
   float bq[NF][4];
   float bh[NF][3], brad[NF];
   float bim[NF], bii[NF][3];   // inverse mass / inverse principal inertia (target brick already scaled by 1 / seg_mass_scale)
@@ -200,23 +201,36 @@ __device__ __forceinline__ f3 inertia_mul(f4 q, const float* I, f3 x) {
   const f3 l = qrot(qconj(q), x);
   return qrot(q, F3(I[0] * l.x + I[3] * l.y + I[4] * l.z, I[3] * l.x + I[1] * l.y + I[5] * l.z, I[4] * l.x + I[5] * l.y + I[2] * l.z));
 }
-// called by every lane of wave 0 (tid < 64); with_inertia: also the world inertia tensors the mass matrix needs
-__device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid, bool with_inertia) {
+// forward declaration (the velocity phases of FK use it)
+__device__ __forceinline__ void twists_wave0(PhysLds& S, int tid);
+
+// called by every lane of wave 0 (tid < 64).  Only the link POSES form a serial chain over the tree depth (one quaternion product and
+// one rotation per level); everything else is one lane per link in parallel: joint axes / centres of mass, then the twists and the
+// velocity-product terms as sums over the (<= 11) dofs of each link's path - the same terms in the same order as the recursions
+// w_k = w_p + a_k qd_k, al_k = al_p + w_p x (a_k qd_k), ao_k = ao_p + al_p x r + w_p x (w_p x r) (recursive Newton-Euler at zero joint
+// acceleration, fixed base, no gravity on the robot).  with_bias: the velocity-product wrenches the drive needs; with_inertia: the world
+// inertia tensors the mass matrix needs.
+__device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid, bool with_inertia, bool with_bias) {
   const sdx_scene_desc& sc = C->sc;
   const bool link = tid > 0 && tid < NL;
-  // this lane's link constants, fetched once (all loads in flight together) instead of inside the level loop
+  // this lane's link constants, fetched once (all loads in flight together)
   int par = 0, dep = -1;
-  f4 jq = {0, 0, 0, 1};
-  f3 jp = F3(0, 0, 0), ax = F3(0, 0, 1), com = F3(0, 0, 0);
-  float mass = 0.0f, I6[6] = {0, 0, 0, 0, 0, 0}, sn = 0.0f, cs = 1.0f, qdk = 0.0f;
+  f4 ql = {0, 0, 0, 1};
+  f3 jp = F3(0, 0, 0), axl = F3(0, 0, 1), com = F3(0, 0, 0);
+  float mass = 0.0f, I6[6] = {0, 0, 0, 0, 0, 0};
   if (link) {
     par = sc.parent[tid]; dep = C->depth[tid];
-    jq = ld4(sc.joint_quat[tid]); jp = ld3(sc.joint_pos[tid]); ax = ld3(sc.joint_axis[tid]); com = ld3(sc.link_com[tid]);
+    const f4 jq = ld4(sc.joint_quat[tid]);
+    const f3 ax = ld3(sc.joint_axis[tid]);
+    jp = ld3(sc.joint_pos[tid]); com = ld3(sc.link_com[tid]);
     mass = sc.link_mass[tid];
 #pragma unroll
     for (int i = 0; i < 6; ++i) I6[i] = sc.link_inertia[tid][i];
+    float sn, cs;
     sincosf(0.5f * S.q[tid - 1], &sn, &cs);
-    qdk = S.qd[tid - 1];
+    f4 qa; qa.x = ax.x * sn; qa.y = ax.y * sn; qa.z = ax.z * sn; qa.w = cs;
+    ql = qmul(jq, qa);            // rotation parent frame -> link frame
+    axl = qrot(jq, ax);           // joint axis in the parent frame
   }
   if (tid == 0) {
     st4(S.lq[0], ld4(sc.base_quat));
@@ -231,43 +245,66 @@ __device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid,
     for (int i = 0; i < 6; ++i) I6[i] = sc.link_inertia[0][i];
   }
   WAVE_SYNC();
+  // ---- the serial part: poses, level by level
   const int max_depth = C->max_depth;
   for (int d = 1; d <= max_depth; ++d) {
     if (link && dep == d) {
-      const int k = tid, p = par;
-      const f4 qp = ld4(S.lq[p]);
-      const f3 pp = ld3(S.bp[NF + p]);
-      const f4 qj = qmul(qp, jq);
-      f4 qa; qa.x = ax.x * sn; qa.y = ax.y * sn; qa.z = ax.z * sn; qa.w = cs;
-      const f4 qk = qnormalize(qmul(qj, qa));
-      const f3 pk = pp + qrot(qp, jp);
-      const f3 ak = qrot(qj, ax);
-      const f3 wp = ld3(S.bw[NF + p]);
-      st4(S.lq[k], qk);
-      st3(S.bp[NF + k], pk);
-      st3(S.la[k], ak);
-      const f3 dk = qrot(qk, com);
-      st3(S.lc[k], pk + dk);
-      const f3 wk = wp + ak * qdk;
-      st3(S.bw[NF + k], wk);
-      st3(S.bv[NF + k], ld3(S.bv[NF + p]) + cross(wp, pk - pp));
-      // velocity-product terms (recursive Newton-Euler at zero joint acceleration, fixed base, no gravity on the robot)
-      const f3 alp = ld3(S.lal[p]), r = pk - pp;
-      const f3 alk = alp + cross(wp, ak * qdk);
-      const f3 aok = ld3(S.lao[p]) + cross(alp, r) + cross(wp, cross(wp, r));
-      st3(S.lal[k], alk);
-      st3(S.lao[k], aok);
-      const f3 acom = aok + cross(alk, dk) + cross(wk, cross(wk, dk));
-      st3(S.lF[k], acom * mass);
-      st3(S.lN[k], inertia_mul(qk, I6, alk) + cross(wk, inertia_mul(qk, I6, wk)));
+      const f4 qp = ld4(S.lq[par]);
+      st4(S.lq[tid], qnormalize(qmul(qp, ql)));
+      st3(S.bp[NF + tid], ld3(S.bp[NF + par]) + qrot(qp, jp));
     }
     WAVE_SYNC();
   }
+  // ---- one lane per link: world joint axis, centre of mass
+  f4 qk = {0, 0, 0, 1};
+  f3 dk = F3(0, 0, 0);
+  if (link) {
+    qk = ld4(S.lq[tid]);
+    st3(S.la[tid], qrot(ld4(S.lq[par]), axl));
+    dk = qrot(qk, com);
+    st3(S.lc[tid], ld3(S.bp[NF + tid]) + dk);
+  }
+  WAVE_SYNC();
+  twists_wave0(S, tid);            // w_k, v_k from the dofs on the path
+  if (with_bias) {
+    WAVE_SYNC();
+    // al_k = sum over the links m on the path of w_par(m) x (a_m qd_m)
+    f3 alk = F3(0, 0, 0);
+    if (link) {
+      uint32_t m = S.anc[tid];
+#pragma unroll
+      for (int t = 0; t < 11; ++t) {
+        const int j = m ? __ffs(m) - 1 : ND;
+        m &= m - 1;
+        alk = alk + cross(ld3(S.bw[NF + S.par[j + 1]]), ld3(S.la[j + 1]) * S.qd[j]);
+      }
+      st3(S.lal[tid], alk);
+    }
+    WAVE_SYNC();
+    // ao_k = sum over the links m on the path of al_par(m) x r_m + w_par(m) x (w_par(m) x r_m), r_m = p_m - p_par(m)
+    if (link) {
+      f3 aok = F3(0, 0, 0);
+      uint32_t m = S.anc[tid];
+#pragma unroll
+      for (int t = 0; t < 11; ++t) {
+        const int j = m ? __ffs(m) - 1 : ND;
+        m &= m - 1;
+        const int pm = S.par[j + 1];
+        const f3 r = ld3(S.bp[NF + j + 1]) - ld3(S.bp[NF + pm]), wp = ld3(S.bw[NF + pm]);
+        aok = aok + cross(ld3(S.lal[pm]), r) + cross(wp, cross(wp, r));
+      }
+      st3(S.lao[tid], aok);
+      const f3 wk = ld3(S.bw[NF + tid]);
+      const f3 acom = aok + cross(alk, dk) + cross(wk, cross(wk, dk));
+      st3(S.lF[tid], acom * mass);
+      st3(S.lN[tid], inertia_mul(qk, I6, alk) + cross(wk, inertia_mul(qk, I6, wk)));
+    }
+  }
   if (tid < sc.n_rbox) {
     const int k = S.rbl[tid];
-    const f4 qk = ld4(S.lq[k]);
-    st3(S.rc[tid], ld3(S.bp[NF + k]) + qrot(qk, ld3(sc.rbox_center[tid])));
-    st4(S.rq[tid], qmul(qk, ld4(sc.rbox_quat[tid])));
+    const f4 q = ld4(S.lq[k]);
+    st3(S.rc[tid], ld3(S.bp[NF + k]) + qrot(q, ld3(sc.rbox_center[tid])));
+    st4(S.rq[tid], qmul(q, ld4(sc.rbox_quat[tid])));
   }
   if (with_inertia && tid < NL) {   // world inertia R I R^T of each link (xx yy zz xy xz yz)
     const f4 q = ld4(S.lq[tid]);
@@ -786,11 +823,11 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         const float w1 = na * wA[q][1] + nb * wB[q][1];
         const float w2 = na * wA[q][2] + nb * wB[q][2];
         const float lam0 = lam[q][0], lam1 = lam[q][1], lam2 = lam[q][2];
-        const float ln = fmaxf(0.0f, lam0 - __fdividef(relax * (dot(vr[q], n) - vtgt[q]), w0));
+        const float ln = fmaxf(0.0f, lam0 - relax * (dot(vr[q], n) - vtgt[q]) * SDX_RCP(w0));
         const float lim = mu * ln;
-        float l1 = lam1 - __fdividef(relax * dot(vr[q], t1), w1);
+        float l1 = lam1 - relax * dot(vr[q], t1) * SDX_RCP(w1);
         l1 = fminf(lim, fmaxf(-lim, l1));
-        float l2 = lam2 - __fdividef(relax * dot(vr[q], t2), w2);
+        float l2 = lam2 - relax * dot(vr[q], t2) * SDX_RCP(w2);
         l2 = fminf(lim, fmaxf(-lim, l2));
         lam[q][0] = ln; lam[q][1] = l1; lam[q][2] = l2;
         P = n * (ln - lam0) + t1 * (l1 - lam1) + t2 * (l2 - lam2);
@@ -934,7 +971,8 @@ __device__ __forceinline__ void load_constants(const SdxConst* C, PhysLds& S, in
     for (int k = 1; k < NL; ++k) d |= ((C->anc[k] >> tid) & 1u) << k;
     S.desc[tid] = d;
   }
-  if (tid == 0) { S.qd[ND] = 0.0f; st3(S.la[NL], F3(0, 0, 0)); }
+  if (tid <= NL) S.par[tid] = tid < NL ? (tid == 0 ? 0 : sc.parent[tid]) : NL;
+  if (tid == 0) { S.qd[ND] = 0.0f; st3(S.la[NL], F3(0, 0, 0)); st3(S.lal[NL], F3(0, 0, 0)); }
   for (int i = tid; i < NF; i += NT) {
     const int t = sc.brick_type[i];
     st3(S.bh[i], ld3(sc.brick_half[t]));
@@ -986,7 +1024,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
   for (int sub = 0; sub < sc.substeps; ++sub) {
     PSTAMP(0);
     if (sub == 0) {   // M(q) is evaluated once per step (frozen over the substeps)
-      if (tid < 64) fk_wave0(C, S, tid, true);
+      if (tid < 64) fk_wave0(C, S, tid, true, true);
       __syncthreads();
       PSTAMP(1);
       mass_matrix<NT>(C, S, tid, h);
@@ -994,7 +1032,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     }
     // A + C on wave 0 (FK, implicit PD drive (P1), velocity-product bias torques, twists); the other waves: gravity on the free bricks
     if (tid < 64) {
-      if (sub != 0) fk_wave0(C, S, tid, false);
+      if (sub != 0) fk_wave0(C, S, tid, false, true);
       if (tid < ND) {
         const float t = sc.kp[tid] * (S.tgt[tid] - S.q[tid]) - (sc.kd[tid] + h * sc.kp[tid]) * S.qd[tid];
         // velocity-product bias torque of dof tid: inertial wrenches of the links below it, projected on its axis
@@ -1048,7 +1086,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
   }
 
   // ---- outputs (refresh_* of GS:1091-1095)
-  if (tid < 64) fk_wave0(C, S, tid, false);
+  if (tid < 64) fk_wave0(C, S, tid, false, false);
   __syncthreads();
   if (tid < ND) {
     B.dof[((size_t)e * ND + tid) * 2] = S.q[tid];
@@ -1083,8 +1121,13 @@ __global__ __launch_bounds__(64) void k_kinematics(const SdxConst* __restrict__ 
   }
   if (tid < NL) S.anc[tid] = C->anc[tid];
   if (tid < SDX_MAX_RBOX) S.rbl[tid] = tid < C->sc.n_rbox ? C->sc.rbox_link[tid] : 0;
+  if (tid <= NL) S.par[tid] = tid < NL ? (tid == 0 ? 0 : C->sc.parent[tid]) : NL;
+  if (tid == 0) {
+    S.qd[ND] = 0.0f; st3(S.la[NL], F3(0, 0, 0)); st3(S.lal[NL], F3(0, 0, 0));
+    st3(S.bp[BODY_W], F3(0, 0, 0)); st3(S.bv[BODY_W], F3(0, 0, 0)); st3(S.bw[BODY_W], F3(0, 0, 0));
+  }
   WAVE_SYNC();
-  fk_wave0(C, S, tid, false);
+  fk_wave0(C, S, tid, false, false);
   write_kinematics<64>(C, S, B, e, tid);
   if (B.jac_full) {   // acquire_jacobian_tensor(sim, "hand") (GS:241): [23 links (fixed base excluded), 6, 23 dofs]
     float* J = B.jac_full + (size_t)e * (NL - 1) * 6 * ND;

@@ -16,6 +16,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 cfg = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd/cfg/allegro_hand_block_assembly_grasp_sim.yaml")))
 cfg["env"]["numEnvs"] = n
+if os.environ.get("SDX_TP_ITERS"):          # ablation: solver iterations per substep (the YAML ships 16)
+    cfg.setdefault("sim", {}).setdefault("physx", {})["num_position_iterations"] = int(os.environ["SDX_TP_ITERS"])
 task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=0, headless=True, seed=22, piles_per_type=8)
 s = task.sim
 g = torch.Generator().manual_seed(0)
@@ -38,6 +40,6 @@ ph = {"fk+inertia": d[1] - d[0], "mass_matrix": d[2] - d[1], "drive": d[3] - d[2
       "setup_rank": d[27] - d[26], "setup_brickw": d[28] - d[27], "setup_robotw": d[29] - d[28], "setup_fetch": d[30] - d[29],
       "setup_tail": d[17] - d[30], "broad_mask": d[32] - d[3], "broad_scan": d[33] - d[32], "narrow": d[4] - d[33],
       "it_D": (d[21] if d[21] > d[20] else d[22]) - d[20], "it_robot": (d[22] - d[21]) if d[21] > d[20] else 0, "it_total": d[22] - d[18]}
-print(json.dumps({"threads_per_env": int(s.lib.sdxk_physics_threads()), "n_envs": n, "k_physics_ms": ms,
+print(json.dumps({"solver_iters": int(os.environ.get("SDX_TP_ITERS", 16)), "threads_per_env": int(s.lib.sdxk_physics_threads()), "n_envs": n, "k_physics_ms": ms,
                   "env_steps_per_s": n / (ms * 1e-3), "contacts_mean": float(nc.mean()), "contacts_max": int(nc.max()),
                   "phase_cycles_env0_substep0": {k: int(v) for k, v in ph.items()}}))
