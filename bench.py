@@ -284,7 +284,8 @@ def main():
                  "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes,
                  "contacts_per_env_mean": float(sim.NCONTACTS.float().mean().item()), "contacts_per_env_max": int(sim.NCONTACTS.max().item()),
-                 "contact_capacity_per_env": 1536, "traffic": ptraf, "traffic_counters": pctr}
+                 "contact_capacity_per_env": 1536, "contacts_per_env_max_since_create": int(sim.CONTACT_STATS[0].item()),
+                 "env_steps_over_capacity_since_create": int(sim.CONTACT_STATS[1].item()), "traffic": ptraf, "traffic_counters": pctr}
     roof_phys["frac"] = roof_phys["achieved"] / HBM_PEAK_GBS
     # ---- roofline of the update phase.  Algorithmic bytes: one optimiser step touches 5 x 4 B per parameter
     # (w, g, m, v in, w' out) for all three networks; the persistent kernel runs all optimiser steps of the epoch in ONE launch and

@@ -113,7 +113,10 @@ typedef enum {
   SDX_T_TVALUE_OBS = 42,   /* f32 [N,652]       Search: t_value_obs_buf, ten 65-number frames (SE:375,1155-1166), newest last; columns 650, 651 are row
                             *                    padding (zeros).  Frame = obs_buf[:, 0:62] with [26:30] = camera-frame target quaternion, then the target's
                             *                    pixel centroid / 128 and pixel count / 100 */
-  SDX_T_COUNT = 43
+  SDX_T_CONTACT_STATS = 43, /* i32 [2]           since create: [0] the largest number of contact points one env generated in one substep, [1] the number
+                            *                    of env-steps in which an env exceeded the per-env capacity (1536) and lost the excess in enumeration
+                            *                    order.  [1] must stay 0 for results to mean anything; bench.py and the full-size tests check it */
+  SDX_T_COUNT = 44
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the

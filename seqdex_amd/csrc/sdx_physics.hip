@@ -1059,6 +1059,10 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     __syncthreads();
     PSTAMP(3);
     collide<NT>(C, S, tid, sub == 0 ? B.dbg : nullptr);
+    if (tid == 0 && B.cstats) {   // capacity statistics of this substep (integer atomics: order-independent)
+      atomicMax(&B.cstats[0], S.nc + S.overflow);
+      if (S.overflow) atomicAdd(&B.cstats[1], 1);
+    }
     PSTAMP(4);
     solve<NT>(C, S, tid, h, sub == sc.substeps - 1, sub == 0 ? B.dbg : nullptr);
     PSTAMP(5);
@@ -1107,7 +1111,9 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     rb_e[SDX_BODY_BRICK0 * 13 + i] = v;
   }
   for (int i = tid; i < NL * 3; i += NT) B.contact[(size_t)e * SDX_BODIES * 3 + i] = (&S.cf[0][0])[i] * (1.0f / h);   // net impulse of the last substep / h
-  if (tid == 0) B.ncontacts[e] = S.nc + S.overflow;
+  if (tid == 0) {
+    B.ncontacts[e] = S.nc + S.overflow;
+  }
 }
 
 // kinematics only: rigid-body states of the 24 links + end-effector Jacobian from SDX_T_DOF (one wave per env)

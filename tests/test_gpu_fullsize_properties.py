@@ -52,6 +52,8 @@ def test_physics_1024_deterministic_env_independent_and_sampled_oracle(golden_di
             np.testing.assert_array_equal(x, y)
         assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
         assert a[2].max() < 1536 and a[2].min() > 100            # contact-rich, inside the per-env capacity
+        st = s.CONTACT_STATS.cpu().numpy()
+        assert st[1] == 0 and 100 < st[0] <= 1536, st            # no env-step ever lost contacts to the capacity
         # envs do not interact: a 64-env simulator fed envs [512, 576) reproduces those rows bit for bit
         s2 = SdxSim(64)
         try:

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-(timeout -k 5 300 python -m pytest tests/test_gpu_physics_parity.py tests/test_gpu_fullsize_properties.py -m gpu -q -x -k "physics or kinematics or free_fall or teacher") 2>&1 | grep -E "passed|failed|Error" | tail -3
-SDX_PHYS_NT=512 timeout -k 5 120 python tools/time_physics.py 1024 24 > gpurun_out/phys_nt512.json 2>/dev/null; cat gpurun_out/phys_nt512.json
-SDX_TP_ITERS=1 timeout -k 5 120 python tools/time_physics.py 1024 24 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print(d['solver_iters'], round(d['k_physics_ms'],4), d['contacts_mean'])"
+timeout -k 5 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-large-minibatch > gpurun_out/bench_protocol.json 2>/dev/null; head -c 300 gpurun_out/bench_protocol.json; echo
+SDX_FORCE_MULTI_RANK=1 timeout -k 5 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch 2>/dev/null | head -1 > gpurun_out/bench_fmr.json; head -c 300 gpurun_out/bench_fmr.json; echo
+timeout -k 5 200 python bench.py --num-envs 4096 --minibatch 32768 --mixed-precision --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch > gpurun_out/bench_n4096_bf16.json 2>gpurun_out/bench_n4096_bf16.err; head -c 300 gpurun_out/bench_n4096_bf16.json; echo; tail -2 gpurun_out/bench_n4096_bf16.err
+timeout -k 5 200 python bench.py --num-envs 4096 --minibatch 32768 --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch > gpurun_out/bench_n4096_fp32.json 2>/dev/null; head -c 300 gpurun_out/bench_n4096_fp32.json; echo
+timeout -k 5 300 python bench.py --pretrain-epochs 200 --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch > gpurun_out/bench_trained200.json 2>/dev/null; head -c 300 gpurun_out/bench_trained200.json; echo
