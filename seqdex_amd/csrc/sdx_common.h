@@ -70,9 +70,11 @@ struct SdxBuf {
 // the kernels with g++ for the CPU, where the constraint letter does not exist.)
 #ifdef HIPEMU
 #define SDX_OPAQUE(x) ((void)0)
+#define SDX_OPAQUE_S(x) ((void)0)
 #define SDX_RCP(x) (1.0f / (x))
 #else
 #define SDX_OPAQUE(x) asm volatile("" : "+v"(x))
+#define SDX_OPAQUE_S(x) asm volatile("" : "+s"(x))   // the same for a wave-uniform value (scalar register)
 #define SDX_RCP(x) __builtin_amdgcn_rcpf(x)   // v_rcp_f32, 1 ulp: the solver's step lengths do not need IEEE division (12 instructions)
 #endif
 

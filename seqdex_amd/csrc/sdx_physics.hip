@@ -1021,61 +1021,70 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
   }
   __syncthreads();
 
-  for (int sub = 0; sub < sc.substeps; ++sub) {
+  const int nsub = sc.substeps;
+  for (int sub = 0; sub < nsub; ++sub) {
+    // per-substep opaque copies of the constants pointer and the thread index: without them every loop-invariant load and address
+    // of the substep body (scene constants, per-lane offsets) is hoisted in front of the loop and parked in scratch - 48 spills per
+    // lane, 100 MB of scratch writes per launch at N = 1024 (profiles/r2_kphysics_pmc_write.csv before this change)
+    const SdxConst* Cs = C;
+    SDX_OPAQUE_S(Cs);
+    int tl = threadIdx.x;
+    SDX_OPAQUE(tl);
+    const sdx_scene_desc& scl = Cs->sc;
     PSTAMP(0);
     if (sub == 0) {   // M(q) is evaluated once per step (frozen over the substeps)
-      if (tid < 64) fk_wave0(C, S, tid, true, true);
+      if (tl < 64) fk_wave0(Cs, S, tl, true, true);
       __syncthreads();
       PSTAMP(1);
-      mass_matrix<NT>(C, S, tid, h);
+      mass_matrix<NT>(Cs, S, tl, h);
       PSTAMP(2);
     }
     // A + C on wave 0 (FK, implicit PD drive (P1), velocity-product bias torques, twists); the other waves: gravity on the free bricks
-    if (tid < 64) {
-      if (sub != 0) fk_wave0(C, S, tid, false, true);
-      if (tid < ND) {
-        const float t = sc.kp[tid] * (S.tgt[tid] - S.q[tid]) - (sc.kd[tid] + h * sc.kp[tid]) * S.qd[tid];
-        // velocity-product bias torque of dof tid: inertial wrenches of the links below it, projected on its axis
+    if (tl < 64) {
+      if (sub != 0) fk_wave0(Cs, S, tl, false, true);
+      if (tl < ND) {
+        const float t = scl.kp[tl] * (S.tgt[tl] - S.q[tl]) - (scl.kd[tl] + h * scl.kp[tl]) * S.qd[tl];
+        // velocity-product bias torque of dof tl: inertial wrenches of the links below it, projected on its axis
         float tc = 0.0f;
-        const f3 aj = ld3(S.la[tid + 1]), oj = ld3(S.bp[NF + tid + 1]);
+        const f3 aj = ld3(S.la[tl + 1]), oj = ld3(S.bp[NF + tl + 1]);
         for (int k = 1; k < NL; ++k)
-          if ((S.anc[k] >> tid) & 1u) tc += dot(aj, cross(ld3(S.lc[k]) - oj, ld3(S.lF[k])) + ld3(S.lN[k]));
-        S.tau[tid] = fminf(sc.effort[tid], fmaxf(-sc.effort[tid], t)) - tc;   // the effort limit applies to the drive only
-        S.Q[tid] = 0.0f;
+          if ((S.anc[k] >> tl) & 1u) tc += dot(aj, cross(ld3(S.lc[k]) - oj, ld3(S.lF[k])) + ld3(S.lN[k]));
+        S.tau[tl] = fminf(scl.effort[tl], fmaxf(-scl.effort[tl], t)) - tc;   // the effort limit applies to the drive only
+        S.Q[tl] = 0.0f;
       }
       WAVE_SYNC();
-      if (tid < ND) {
+      if (tl < ND) {
         float s = 0.0f;
-        for (int j = 0; j < ND; ++j) s += S.A[tid][j] * S.tau[j];
-        S.qd[tid] += h * s;
+        for (int j = 0; j < ND; ++j) s += S.A[tl][j] * S.tau[j];
+        S.qd[tl] += h * s;
       }
       WAVE_SYNC();
-      twists_wave0(S, tid);
+      twists_wave0(S, tl);
     } else {
-      for (int i = tid - 64; i < NF; i += NT - 64) {
-        S.bv[i][0] += sc.gravity[0] * h; S.bv[i][1] += sc.gravity[1] * h; S.bv[i][2] += sc.gravity[2] * h;
+      for (int i = tl - 64; i < NF; i += NT - 64) {
+        S.bv[i][0] += scl.gravity[0] * h; S.bv[i][1] += scl.gravity[1] * h; S.bv[i][2] += scl.gravity[2] * h;
       }
     }
     __syncthreads();
     PSTAMP(3);
-    collide<NT>(C, S, tid, sub == 0 ? B.dbg : nullptr);
-    if (tid == 0 && B.cstats) {   // capacity statistics of this substep (integer atomics: order-independent)
+    collide<NT>(Cs, S, tl, sub == 0 ? B.dbg : nullptr);
+    if (tl == 0 && B.cstats) {   // capacity statistics of this substep (integer atomics: order-independent)
       atomicMax(&B.cstats[0], S.nc + S.overflow);
       if (S.overflow) atomicAdd(&B.cstats[1], 1);
     }
     PSTAMP(4);
-    solve<NT>(C, S, tid, h, sub == sc.substeps - 1, sub == 0 ? B.dbg : nullptr);
+    solve<NT>(Cs, S, tl, h, sub == nsub - 1, sub == 0 ? B.dbg : nullptr);
     PSTAMP(5);
     // F: integrate
-    if (tid < ND) {
-      float v = fminf(sc.vel_limit[tid], fmaxf(-sc.vel_limit[tid], S.qd[tid]));
-      float qn = S.q[tid] + h * v;
-      if (qn < sc.lower[tid]) { qn = sc.lower[tid]; v = fmaxf(v, 0.0f); }
-      if (qn > sc.upper[tid]) { qn = sc.upper[tid]; v = fminf(v, 0.0f); }
-      S.q[tid] = qn;
-      S.qd[tid] = v;
+    if (tl < ND) {
+      float v = fminf(scl.vel_limit[tl], fmaxf(-scl.vel_limit[tl], S.qd[tl]));
+      float qn = S.q[tl] + h * v;
+      if (qn < scl.lower[tl]) { qn = scl.lower[tl]; v = fmaxf(v, 0.0f); }
+      if (qn > scl.upper[tl]) { qn = scl.upper[tl]; v = fminf(v, 0.0f); }
+      S.q[tl] = qn;
+      S.qd[tl] = v;
     }
-    for (int i = tid; i < NF; i += NT) {
+    for (int i = tl; i < NF; i += NT) {
       const f3 v = ld3(S.bv[i]), w = ld3(S.bw[i]);
       st3(S.bp[i], ld3(S.bp[i]) + v * h);
       const f4 q = ld4(S.bq[i]);
