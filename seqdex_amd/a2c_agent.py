@@ -270,7 +270,10 @@ class A2CAgent:
             # device control block - so a chunk of steps is captured ONCE into a hipGraph (RCCL collectives are capturable) and
             # replayed: per step the host then issues 1/64 of a graph launch instead of four launches and a collective call
             chunk = next((c for c in (64, 32, 16, 8) if total % c == 0 and total >= 2 * c), 0)
-            if chunk and os.environ.get("SDX_MULTI_RANK_GRAPH", "1") != "0" and getattr(self, "_mr_graph", None) is not False:
+            # default: on at world size 1 (where it is measured: 77.5 -> 70.4 us per step); at world size > 1 the capture contains a real
+            # RCCL collective, which this build could never run (gpurun boxes have one GPU), so it is opt-in there: SDX_MULTI_RANK_GRAPH=1
+            want = os.environ.get("SDX_MULTI_RANK_GRAPH", "1" if self.rank_size == 1 else "0") == "1"
+            if chunk and want and getattr(self, "_mr_graph", None) is not False:
                 if getattr(self, "_mr_graph", None) is None:
                     steps(chunk)                     # eagerly once: communicator set-up, lazy module loads, function attributes
                     done = chunk

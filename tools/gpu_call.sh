@@ -1,13 +1,11 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
+cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-(timeout -k 5 300 python -m pytest tests/test_gpu_physics_parity.py tests/test_gpu_fullsize_properties.py -m gpu -q -x -k "physics or kinematics or free_fall or teacher") 2>&1 | grep -E "passed|failed|Error" | tail -3
-timeout -k 5 120 python tools/time_physics.py 1024 24 > gpurun_out/phys_nt512.json 2>/dev/null; cat gpurun_out/phys_nt512.json | cut -c1-200
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 200 rocprofv3 --pmc $c -d gpurun_out/prof_r2_$c -o r2 -- python tools/time_physics.py 1024 8 > gpurun_out/prof_$c.log 2>&1; echo "$c rc=$?"
-  db=$(find gpurun_out/prof_r2_$c -name "*_results.db" | head -1)
-  [ -n "$db" ] && python tools/rocpd_summary.py pmc $db gpurun_out/r2b_kphysics_pmc_$c.csv
-  rm -rf gpurun_out/prof_r2_$c
-  grep "k_physics" gpurun_out/r2b_kphysics_pmc_$c.csv | cut -c1-150
-done
+(time timeout -k 5 900 python -m pytest tests -m gpu -q) > gpurun_out/gputests.log 2>&1
+grep -E "passed|failed|Error " gpurun_out/gputests.log | tail -4
+timeout -k 5 400 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; head -c 200 gpurun_out/bench_default.json; echo
+timeout -k 5 200 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-large-minibatch > gpurun_out/bench_protocol.json 2>/dev/null; head -c 200 gpurun_out/bench_protocol.json; echo
+SDX_FORCE_MULTI_RANK=1 timeout -k 5 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch 2>/dev/null | head -1 > gpurun_out/bench_fmr.json; head -c 200 gpurun_out/bench_fmr.json; echo
+timeout -k 5 200 python bench.py --num-envs 4096 --minibatch 32768 --mixed-precision --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch > gpurun_out/bench_n4096_bf16.json 2>/dev/null; head -c 200 gpurun_out/bench_n4096_bf16.json; echo
+timeout -k 5 200 python bench.py --num-envs 4096 --minibatch 32768 --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch > gpurun_out/bench_n4096_fp32.json 2>/dev/null; head -c 200 gpurun_out/bench_n4096_fp32.json; echo
+timeout -k 5 300 python bench.py --pretrain-epochs 200 --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch > gpurun_out/bench_trained200.json 2>/dev/null; head -c 200 gpurun_out/bench_trained200.json; echo
+timeout -k 5 300 python tools/bench_config3.py 1024 12 > gpurun_out/config3.json 2>/dev/null; tail -c 300 gpurun_out/config3.json
