@@ -80,7 +80,7 @@ static void st4(float* p, q4 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w
 /* sample points of a box in units of its half extents: 8 corners, 12 edge midpoints, 8 quarter points on the
  * x-parallel edges.  Corners come first: selection is "first k in table order" (DESIGN.md §3.D). */
 static const real SAMP[NSAMP][3] = {
-    {-1, -1, -1}, {1, -1, -1}, {-1, 1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1},
+    {1, 1, 1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1},
     {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
     {-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0},
     {-0.5f, -1, -1}, {0.5f, -1, -1}, {-0.5f, 1, -1}, {0.5f, 1, -1}, {-0.5f, -1, 1}, {0.5f, -1, 1}, {-0.5f, 1, 1}, {0.5f, 1, 1}};
@@ -253,32 +253,93 @@ static void add_contact(env_t* e, int a, int b, v3 p, v3 n, real sep) {
   e->csep[c] = sep;
 }
 
-/* samples of A against the SDF of B: fills up to 4 candidate sample indices (table order), returns count (<=4).
- * A's sample l (A frame) in B's frame: t + qrel l with t = qB^-1 (cA - cB), qrel = qB^-1 qA. */
-static int sample_dir(const box_t* A, const box_t* B, real offset, int idx[4]) {
-  int cnt = 0;
+/* ---- contact manifold of one direction (samples of A against box B), DESIGN.md section 3.D
+ * Reference face: the face axis k of B with the smallest overlap of the two boxes' extents (separating-axis test over B's three face
+ * normals: s_k = |t_k| - hB_k - sum_j |R_kj| hA_j, largest s wins, ties x > y > z), on the side of B's centre where A's centre lies.
+ * A sample of A whose projection falls on that face (within FACE_TOL of its outline) is a FACE sample: normal = the face normal,
+ * separation measured along it.  Every other sample uses the point's own signed distance to B (edge / corner regions).
+ * Up to 4 samples per direction: face samples in table order first, then the others in table order.
+ * Only for shallow overlaps (s_k >= -FACE_DEPTH x contact offset): a deeply interpenetrating pair (bricks spawned inside the floor slab)
+ * has no meaningful meeting face and every sample keeps its own signed distance, as in round 1.
+ * (Round 1 used the sample's nearest face and plain table order: two equal bricks stacked flush pushed each other sideways, the
+ * speculative samples beside B used up the 4 slots, and the upper brick tipped over one edge or sank through.) */
+#define FACE_TOL 1e-4f
+#define FACE_DEPTH 4.0f
+typedef struct { v3 t, ex, ey, ez; int kax; real sgn, smax; } dir_t; /* ex, ey, ez: A's half edges in B's frame: sample = t + sx ex + sy ey + sz ez */
+
+static dir_t dir_setup(const box_t* A, const box_t* B, real offset) {
+  dir_t D;
   q4 qbi = qconj(B->q);
-  v3 t = qrot(qbi, vsub(A->c, B->c));
+  D.t = qrot(qbi, vsub(A->c, B->c));
   q4 qrel = qmul(qbi, A->q);
-  for (int s = 0; s < NSAMP && cnt < 4; ++s) {
-    v3 l = V(A->h.x * SAMP[s][0], A->h.y * SAMP[s][1], A->h.z * SAMP[s][2]);
-    v3 pb = vadd(t, qrot(qrel, l));
-    v3 g;
-    if (box_sdf(pb, B->h, &g) < offset) idx[cnt++] = s;
-  }
-  return cnt;
+  D.ex = qrot(qrel, V(A->h.x, 0, 0));
+  D.ey = qrot(qrel, V(0, A->h.y, 0));
+  D.ez = qrot(qrel, V(0, 0, A->h.z));
+  v3 ex = D.ex, ey = D.ey, ez = D.ez;
+  real sx = fabsf(D.t.x) - B->h.x - (fabsf(ex.x) + fabsf(ey.x) + fabsf(ez.x));
+  real sy = fabsf(D.t.y) - B->h.y - (fabsf(ex.y) + fabsf(ey.y) + fabsf(ez.y));
+  real sz = fabsf(D.t.z) - B->h.z - (fabsf(ex.z) + fabsf(ey.z) + fabsf(ez.z));
+  if (sx >= sy && sx >= sz) { D.kax = 0; D.sgn = D.t.x < 0 ? -1.0f : 1.0f; }
+  else if (sy >= sz) { D.kax = 1; D.sgn = D.t.y < 0 ? -1.0f : 1.0f; }
+  else { D.kax = 2; D.sgn = D.t.z < 0 ? -1.0f : 1.0f; }
+  D.smax = fmaxf(sx, fmaxf(sy, sz)); /* >= offset: a face axis of B separates the boxes by the whole contact offset: no sample can be inside it */
+  if (D.smax < -FACE_DEPTH * offset) D.kax = -1;
+  return D;
 }
 
-static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb, const int idx[4], int k) {
-  q4 qbi = qconj(B->q);
-  v3 t = qrot(qbi, vsub(A->c, B->c));
-  q4 qrel = qmul(qbi, A->q);
+static v3 sample_point(const dir_t* D, int s) {
+  return vadd(vadd(vadd(D->t, vscale(D->ex, SAMP[s][0])), vscale(D->ey, SAMP[s][1])), vscale(D->ez, SAMP[s][2]));
+}
+
+/* one sample (B frame): returns 1 = face sample, 2 = other sample inside the contact offset, 0 = no contact; *g, *sd as box_sdf */
+static int sample_contact(const dir_t* D, v3 pb, v3 h, real offset, v3* g, real* sd) {
+  v3 d = V(fabsf(pb.x) - h.x, fabsf(pb.y) - h.y, fabsf(pb.z) - h.z);
+  real lat = D->kax == 0 ? fmaxf(d.y, d.z) : D->kax == 1 ? fmaxf(d.x, d.z) : fmaxf(d.x, d.y);
+  if (D->kax >= 0 && lat <= FACE_TOL) {
+    real pk = D->kax == 0 ? pb.x : D->kax == 1 ? pb.y : pb.z, hk = D->kax == 0 ? h.x : D->kax == 1 ? h.y : h.z;
+    *sd = D->sgn * pk - hk;
+    *g = V(D->kax == 0 ? D->sgn : 0.0f, D->kax == 1 ? D->sgn : 0.0f, D->kax == 2 ? D->sgn : 0.0f);
+    return *sd < offset ? 1 : 0;
+  }
+  *sd = box_sdf(pb, h, g);
+  return *sd < offset ? 2 : 0;
+}
+
+/* class of one sample without the distance itself (the kernel's test: squared distance against the squared offset, no sqrt) */
+static int sample_class(const dir_t* D, v3 pb, v3 h, real offset) {
+  v3 d = V(fabsf(pb.x) - h.x, fabsf(pb.y) - h.y, fabsf(pb.z) - h.z);
+  real lat = D->kax == 0 ? fmaxf(d.y, d.z) : D->kax == 1 ? fmaxf(d.x, d.z) : fmaxf(d.x, d.y);
+  if (D->kax >= 0 && lat <= FACE_TOL) {
+    real pk = D->kax == 0 ? pb.x : D->kax == 1 ? pb.y : pb.z, hk = D->kax == 0 ? h.x : D->kax == 1 ? h.y : h.z;
+    return D->sgn * pk - hk < offset ? 1 : 0;
+  }
+  if (fmaxf(d.x, fmaxf(d.y, d.z)) <= 0) return 2;
+  v3 o = V(fmaxf(d.x, 0), fmaxf(d.y, 0), fmaxf(d.z, 0));
+  return vdot(o, o) < offset * offset ? 2 : 0;
+}
+
+static int sample_dir(const box_t* A, const box_t* B, real offset, int idx[4]) {
+  int c1 = 0, c2 = 0, other[4];
+  dir_t D = dir_setup(A, B, offset);
+  if (D.smax >= offset) return -1; /* separated: neither direction has a sample inside the offset */
+  for (int s = 0; s < NSAMP && c1 < 4; ++s) {
+    v3 pb = sample_point(&D, s);
+    int cls = sample_class(&D, pb, B->h, offset);
+    if (cls == 1) idx[c1++] = s;
+    else if (cls == 2 && c2 < 4) other[c2++] = s;
+  }
+  for (int i = 0; i < c2 && c1 < 4; ++i) idx[c1++] = other[i];
+  return c1;
+}
+
+static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb, const int idx[4], int k, real offset) {
+  dir_t D = dir_setup(A, B, offset);
   for (int i = 0; i < k; ++i) {
     int s = idx[i];
-    v3 l = V(A->h.x * SAMP[s][0], A->h.y * SAMP[s][1], A->h.z * SAMP[s][2]);
-    v3 pb = vadd(t, qrot(qrel, l));
+    v3 pb = sample_point(&D, s);
     v3 g;
-    real sd = box_sdf(pb, B->h, &g);
+    real sd;
+    sample_contact(&D, pb, B->h, 1e30f, &g, &sd);
     v3 n = qrot(B->q, g); /* out of B, towards A */
     v3 pw = vadd(B->c, qrot(B->q, pb));
     add_contact(e, ida, idb, vsub(pw, vscale(n, 0.5f * sd)), n, sd);
@@ -289,12 +350,14 @@ static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb,
 static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int idb, int bstatic, real offset) {
   int i1[4], i2[4];
   int c1 = sample_dir(A, B, offset, i1);
+  if (c1 < 0) return;
   int c2 = bstatic ? 0 : sample_dir(B, A, offset, i2);
+  if (c2 < 0) return;
   int m2 = c2 < 2 ? c2 : 2;
   int k1 = c1 < 4 - m2 ? c1 : 4 - m2;
   int k2 = c2 < 4 - k1 ? c2 : 4 - k1;
-  emit_dir(e, A, B, ida, idb, i1, k1);
-  if (k2 > 0) emit_dir(e, B, A, idb, ida, i2, k2);
+  emit_dir(e, A, B, ida, idb, i1, k1, offset);
+  if (k2 > 0) emit_dir(e, B, A, idb, ida, i2, k2, offset);
 }
 
 static real box_radius(v3 h) { return sqrtf(vdot(h, h)); }

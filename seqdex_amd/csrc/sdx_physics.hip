@@ -44,7 +44,7 @@
   } while (0)
 
 __constant__ float c_samp[SDX_NSAMP][3] = {
-    {-1, -1, -1}, {1, -1, -1}, {-1, 1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1},
+    {1, 1, 1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1},
     {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
     {-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0},
     {-0.5f, -1, -1}, {0.5f, -1, -1}, {-0.5f, 1, -1}, {0.5f, 1, -1}, {-0.5f, -1, 1}, {0.5f, -1, 1}, {-0.5f, 1, 1}, {0.5f, 1, 1}};
@@ -147,34 +147,97 @@ __device__ __forceinline__ int box_body(const PhysLds& S, int id) {
   return BODY_W;
 }
 
-// samples of A against the SDF of B; returns count (<=4), indices packed 8 bits each
-__device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off, uint32_t* packed) {
+// ---- contact manifold of one direction (samples of A against box B); oracle: dir_setup / sample_contact
+// Reference face = the face axis of B with the smallest overlap of the two boxes' extents (separating-axis test over B's three face
+// normals), on A's side of B's centre.  Samples whose projection falls on that face (within FACE_TOL of its outline) are FACE samples:
+// normal = face normal, separation along it; the others use their own signed distance to B.  <= 4 samples per direction: face samples
+// in table order first, then the others.  Shallow overlaps only (s_k >= -FACE_DEPTH x contact offset): a deeply interpenetrating pair
+// has no meaningful meeting face (kax = -1) and every sample keeps its own signed distance.
+#define FACE_TOL 1e-4f
+#define FACE_DEPTH 4.0f
+struct Dir { f3 t, ex, ey, ez; int kax; float sgn, smax; };   // ex, ey, ez: A's half edges in B's frame: sample = t + sx ex + sy ey + sz ez
+__device__ __forceinline__ Dir dir_setup(const Box& A, const Box& B, float off) {
+  Dir D;
   const f4 qbi = qconj(B.q);
-  const f3 t = qrot(qbi, A.c - B.c);
+  D.t = qrot(qbi, A.c - B.c);
   const f4 qrel = qmul(qbi, A.q);
-  int cnt = 0;
-  uint32_t pk = 0;
-  for (int s = 0; s < SDX_NSAMP && cnt < 4; ++s) {
-    const f3 l = F3(A.h.x * c_samp[s][0], A.h.y * c_samp[s][1], A.h.z * c_samp[s][2]);
-    const f3 pb = t + qrot(qrel, l);
-    if (box_sdf_val(pb, B.h) < off) { pk |= (uint32_t)s << (8 * cnt); ++cnt; }
+  D.ex = qrot(qrel, F3(A.h.x, 0, 0));
+  D.ey = qrot(qrel, F3(0, A.h.y, 0));
+  D.ez = qrot(qrel, F3(0, 0, A.h.z));
+  const f3 ex = D.ex, ey = D.ey, ez = D.ez;
+  const float sx = fabsf(D.t.x) - B.h.x - (fabsf(ex.x) + fabsf(ey.x) + fabsf(ez.x));
+  const float sy = fabsf(D.t.y) - B.h.y - (fabsf(ex.y) + fabsf(ey.y) + fabsf(ez.y));
+  const float sz = fabsf(D.t.z) - B.h.z - (fabsf(ex.z) + fabsf(ey.z) + fabsf(ez.z));
+  if (sx >= sy && sx >= sz) { D.kax = 0; D.sgn = D.t.x < 0 ? -1.0f : 1.0f; }
+  else if (sy >= sz) { D.kax = 1; D.sgn = D.t.y < 0 ? -1.0f : 1.0f; }
+  else { D.kax = 2; D.sgn = D.t.z < 0 ? -1.0f : 1.0f; }
+  D.smax = fmaxf(sx, fmaxf(sy, sz));   // >= off: a face axis of B separates the boxes by the whole contact offset, no sample can be inside it
+  if (D.smax < -FACE_DEPTH * off) D.kax = -1;
+  return D;
+}
+__device__ __forceinline__ float sample_contact(const Dir& D, f3 pb, f3 h, f3* g) {
+  const f3 d = F3(fabsf(pb.x) - h.x, fabsf(pb.y) - h.y, fabsf(pb.z) - h.z);
+  const float lat = D.kax == 0 ? fmaxf(d.y, d.z) : D.kax == 1 ? fmaxf(d.x, d.z) : fmaxf(d.x, d.y);
+  if (D.kax >= 0 && lat <= FACE_TOL) {
+    const float pk = D.kax == 0 ? pb.x : D.kax == 1 ? pb.y : pb.z, hk = D.kax == 0 ? h.x : D.kax == 1 ? h.y : h.z;
+    *g = F3(D.kax == 0 ? D.sgn : 0.0f, D.kax == 1 ? D.sgn : 0.0f, D.kax == 2 ? D.sgn : 0.0f);
+    return D.sgn * pk - hk;
   }
-  *packed = pk;
-  return cnt;
+  return box_sdf(pb, h, g);
 }
 
-__device__ __forceinline__ void emit_dir(PhysLds& S, const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k, int base) {
-  const f4 qbi = qconj(B.q);
-  const f3 t = qrot(qbi, A.c - B.c);
-  const f4 qrel = qmul(qbi, A.q);
+// samples of A against B; returns count (<= 4; -1: separated), indices packed 8 bits each.  The 28 samples are unrolled with their table
+// entries as immediates (corners are three adds), in a copy of B's frame whose z axis is the reference face axis (no per-sample
+// selects), and the classes land in two bit masks: face samples / other samples inside the contact offset (squared distance, no sqrt).
+constexpr float kSamp[SDX_NSAMP][3] = {
+    {1, 1, 1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1},
+    {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
+    {-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0},
+    {-0.5f, -1, -1}, {0.5f, -1, -1}, {-0.5f, 1, -1}, {0.5f, 1, -1}, {-0.5f, -1, 1}, {0.5f, -1, 1}, {-0.5f, 1, 1}, {0.5f, 1, 1}};
+__device__ __forceinline__ f3 face_frame(f3 v, int kax) {   // component kax moves to z
+  return kax == 0 ? F3(v.y, v.z, v.x) : kax == 1 ? F3(v.x, v.z, v.y) : v;
+}
+__device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off, uint32_t* packed) {
+  const Dir D = dir_setup(A, B, off);
+  *packed = 0;
+  if (D.smax >= off) return -1;   // separated: neither direction has a sample inside the offset
+  const f3 t = face_frame(D.t, D.kax), ex = face_frame(D.ex, D.kax), ey = face_frame(D.ey, D.kax), ez = face_frame(D.ez, D.kax);
+  const f3 h = face_frame(B.h, D.kax);
+  const float ftol = D.kax >= 0 ? FACE_TOL : -1e30f, off2 = off * off;
+  uint32_t mface = 0, mother = 0;
+#pragma unroll
+  for (int s = 0; s < SDX_NSAMP; ++s) {
+    const f3 pb = ((t + ex * kSamp[s][0]) + ey * kSamp[s][1]) + ez * kSamp[s][2];
+    const float dx = fabsf(pb.x) - h.x, dy = fabsf(pb.y) - h.y, dz = fabsf(pb.z) - h.z;
+    const float lat = fmaxf(dx, dy);
+    const bool face = lat <= ftol;
+    const float sdf = D.sgn * pb.z - h.z;
+    const float ox = fmaxf(dx, 0.0f), oy = fmaxf(dy, 0.0f), oz = fmaxf(dz, 0.0f);
+    const bool near = fmaxf(lat, dz) <= 0.0f || ox * ox + oy * oy + oz * oz < off2;
+    if (face ? sdf < off : false) mface |= 1u << s;
+    if (face ? false : near) mother |= 1u << s;
+  }
+  int c = 0;
+  uint32_t pk = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (mface) { pk |= (uint32_t)(__ffs(mface) - 1) << (8 * c); mface &= mface - 1; ++c; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (mother && c < 4) { pk |= (uint32_t)(__ffs(mother) - 1) << (8 * c); mother &= mother - 1; ++c; }
+  *packed = pk;
+  return c;
+}
+
+__device__ __forceinline__ void emit_dir(PhysLds& S, const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k, int base, float off) {
+  const Dir D = dir_setup(A, B, off);
   for (int i = 0; i < k; ++i) {
     const int c = base + i;
     if (c >= MAXC) break;
     const int s = (packed >> (8 * i)) & 0xff;
-    const f3 l = F3(A.h.x * c_samp[s][0], A.h.y * c_samp[s][1], A.h.z * c_samp[s][2]);
-    const f3 pb = t + qrot(qrel, l);
+    const f3 pb = ((D.t + D.ex * c_samp[s][0]) + D.ey * c_samp[s][1]) + D.ez * c_samp[s][2];
     f3 g;
-    const float sd = box_sdf(pb, B.h, &g);
+    const float sd = sample_contact(D, pb, B.h, &g);
     const f3 n = qrot(B.q, g);
     const f3 pw = B.c + qrot(B.q, pb);
     const f3 p = pw - n * (0.5f * sd);
@@ -516,6 +579,38 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   }
   if (np > MAXP) np = MAXP;
   __syncthreads();
+  // ---- separating-axis pass: a pair that a face axis of either box separates by the whole contact offset cannot produce a contact
+  // (sample_dir would return -1 for it); about half of the sphere-vs-box candidates leave the list here, so that the sampling below
+  // runs once over <= NT pairs instead of twice.  Lane tid looks at the consecutive pairs tid * q .. tid * q + q - 1: order preserved.
+  {
+    constexpr int QMAX = (MAXP + NT - 1) / NT;
+    static_assert(QMAX <= 3, "three survivor slots per lane");
+    const int q = (np + NT - 1) / NT;
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    int kept = 0;
+#pragma unroll
+    for (int k = 0; k < QMAX; ++k) {
+      const int pi = tid * q + k;
+      if (k < q && pi < np) {
+        const uint32_t pr = S_PAIRS(S)[pi];
+        const int bb = (pr >> 8) & 0xff;
+        const Box A = load_box(S, pr & 0xff), Bx = load_box(S, bb);
+        bool sep = dir_setup(A, Bx, off).smax >= off;
+        if (!sep && bb < 128) sep = dir_setup(Bx, A, off).smax >= off;
+        if (!sep) {
+          if (kept == 0) c0 = pr; else if (kept == 1) c1 = pr; else c2 = pr;
+          ++kept;
+        }
+      }
+    }
+    int np2;
+    const int pos = block_scan_small<NT>(S, kept, tid, &np2);   // its barrier comes after every lane's reads of the old list
+    if (kept > 0) S_PAIRS(S)[pos] = c0;
+    if (kept > 1) S_PAIRS(S)[pos + 1] = c1;
+    if (kept > 2) S_PAIRS(S)[pos + 2] = c2;
+    np = np2;
+    __syncthreads();
+  }
   SSTAMP(33);
   // ---- narrowphase: lane = candidate pair; contacts appended in pair order (block prefix sum of the counts)
   int nc = 0;
@@ -532,15 +627,17 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       ida = box_body(S, ba);
       idb = box_body(S, bb);
       const int c1 = sample_dir(A, Bx, off, &p1);
-      const int c2 = (bb >= 128) ? 0 : sample_dir(Bx, A, off, &p2);
-      const int m2 = c2 < 2 ? c2 : 2;
-      k1 = c1 < 4 - m2 ? c1 : 4 - m2;
-      k2 = c2 < 4 - k1 ? c2 : 4 - k1;
+      const int c2 = (bb >= 128 || c1 < 0) ? 0 : sample_dir(Bx, A, off, &p2);
+      if (c1 >= 0 && c2 >= 0) {
+        const int m2 = c2 < 2 ? c2 : 2;
+        k1 = c1 < 4 - m2 ? c1 : 4 - m2;
+        k2 = c2 < 4 - k1 ? c2 : 4 - k1;
+      }
     }
     int tot;
     const int pre = block_scan_small<NT>(S, k1 + k2, tid, &tot);
-    if (k1 > 0) emit_dir(S, A, Bx, ida, idb, p1, k1, nc + pre);
-    if (k2 > 0) emit_dir(S, Bx, A, idb, ida, p2, k2, nc + pre + k1);
+    if (k1 > 0) emit_dir(S, A, Bx, ida, idb, p1, k1, nc + pre, off);
+    if (k2 > 0) emit_dir(S, Bx, A, idb, ida, p2, k2, nc + pre + k1, off);
     nc += tot;
   }
   if (tid == 0) {
