@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDX_ABI_VERSION 5
+#define SDX_ABI_VERSION 6
 
 /* ---- fixed scene dimensions of BlockAssemblyGraspSim (GS:523-1058) ---- */
 #define SDX_NLINK 24        /* robot bodies after collapse_fixed_joints (GS:543); body 0 is the fixed base  */
@@ -116,7 +116,9 @@ typedef enum {
   SDX_T_CONTACT_STATS = 43, /* i32 [2]           since create: [0] the largest number of contact points one env generated in one substep, [1] the number
                             *                    of env-steps in which an env exceeded the per-env capacity (1536) and lost the excess in enumeration
                             *                    order.  [1] must stay 0 for results to mean anything; bench.py and the full-size tests check it */
-  SDX_T_COUNT = 44
+  SDX_T_WARM_COUNT = 44,   /* i32 [N]           contacts in each env's warm-start cache (scene.warm_start); the engine clears an
+                            *                    env's entry when it resets the env; a caller that teleports bodies by hand may zero it too */
+  SDX_T_COUNT = 45
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the
@@ -180,6 +182,8 @@ typedef struct {
   float baumgarte;                     /* position-error feedback factor  */
   float max_depenetration_vel;
   float jacobi_relax;                  /* relaxation on the mass-split Jacobi update */
+  float warm_start;                    /* every solve starts from this fraction of the impulses the same contacts
+                                        * (pair, direction, sample) ended the previous solve with; 0 = start from zero */
   /* which task's per-step tensor code the pre/post-physics kernels run: 0 = BlockAssemblyGraspSim (GS),
    * 1 = BlockAssemblyOrient (OR = tasks/block_assembly/allegro_hand_block_assembly_orient.py; targets/IK OR:1720-1778),
    * 2 = BlockAssemblyInsertSim (IS; position action + fixed wrist orientation IS:1526-1572, 75-number observation IS:1280-1298,

@@ -111,6 +111,8 @@ typedef struct {
   unsigned char ca[SDXO_MAXC], cb[SDXO_MAXC]; /* body ids: 0..71 brick, 72+k robot link k, 255 static */
   v3 cn[SDXO_MAXC], cp[SDXO_MAXC];
   real csep[SDXO_MAXC];
+  unsigned ckey[SDXO_MAXC], cur_key; /* identity of every contact: (box a, box b, direction, sample) - the warm-start key */
+  int* wcount; unsigned* wkey; float* wlam; /* this env's impulse cache: count, keys [MAXC], impulses [3][MAXC] of the previous solve */
   real lam[SDXO_MAXC][3], w[SDXO_MAXC][2][3]; /* w[c][side][row]: un-split inverse effective mass */
   unsigned char active[SDXO_MAXC];
   int overflow;
@@ -251,6 +253,7 @@ static void add_contact(env_t* e, int a, int b, v3 p, v3 n, real sep) {
   e->cp[c] = p;
   e->cn[c] = n;
   e->csep[c] = sep;
+  e->ckey[c] = e->cur_key;
 }
 
 /* ---- contact manifold of one direction (samples of A against box B), DESIGN.md section 3.D
@@ -265,6 +268,8 @@ static void add_contact(env_t* e, int a, int b, v3 p, v3 n, real sep) {
  * speculative samples beside B used up the 4 slots, and the upper brick tipped over one edge or sank through.) */
 #define FACE_TOL 1e-4f
 #define FACE_DEPTH 4.0f
+#define WARM_SPEED 0.25f /* m/s: relative speed at the contact point (before the solve) above which a contact starts cold */
+#define WARM_DEPTH 1.5f /* contacts deeper than this many contact offsets are not warm-started (section 3.E) */
 typedef struct { v3 t, ex, ey, ez; int kax; real sgn, smax; } dir_t; /* ex, ey, ez: A's half edges in B's frame: sample = t + sx ex + sy ey + sz ez */
 
 static dir_t dir_setup(const box_t* A, const box_t* B, real offset) {
@@ -332,7 +337,7 @@ static int sample_dir(const box_t* A, const box_t* B, real offset, int idx[4]) {
   return c1;
 }
 
-static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb, const int idx[4], int k, real offset) {
+static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb, const int idx[4], int k, real offset, unsigned pkey) {
   dir_t D = dir_setup(A, B, offset);
   for (int i = 0; i < k; ++i) {
     int s = idx[i];
@@ -342,12 +347,14 @@ static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb,
     sample_contact(&D, pb, B->h, 1e30f, &g, &sd);
     v3 n = qrot(B->q, g); /* out of B, towards A */
     v3 pw = vadd(B->c, qrot(B->q, pb));
+    e->cur_key = pkey | (unsigned)s;
     add_contact(e, ida, idb, vsub(pw, vscale(n, 0.5f * sd)), n, sd);
   }
 }
 
-/* pair of boxes; bstatic != 0: B is a static box (only A's samples are tested) */
-static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int idb, int bstatic, real offset) {
+/* pair of boxes; bstatic != 0: B is a static box (only A's samples are tested); boxa / boxb: box ids (brick 0..71, robot box 72 + r,
+ * static 128 + s) - with the direction bit and the sample index they identify a contact from one solve to the next */
+static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int idb, int bstatic, real offset, int boxa, int boxb) {
   int i1[4], i2[4];
   int c1 = sample_dir(A, B, offset, i1);
   if (c1 < 0) return;
@@ -356,8 +363,9 @@ static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int 
   int m2 = c2 < 2 ? c2 : 2;
   int k1 = c1 < 4 - m2 ? c1 : 4 - m2;
   int k2 = c2 < 4 - k1 ? c2 : 4 - k1;
-  emit_dir(e, A, B, ida, idb, i1, k1, offset);
-  if (k2 > 0) emit_dir(e, B, A, idb, ida, i2, k2, offset);
+  unsigned pk = ((unsigned)boxa << 20) | ((unsigned)boxb << 12);
+  emit_dir(e, A, B, ida, idb, i1, k1, offset, pk);
+  if (k2 > 0) emit_dir(e, B, A, idb, ida, i2, k2, offset, pk | 0x100u);
 }
 
 static real box_radius(v3 h) { return sqrtf(vdot(h, h)); }
@@ -390,7 +398,7 @@ static void collide(const sdx_scene_desc* sc, env_t* e) {
       box_t S = static_box(sc, s, e->env_index);
       v3 g;
       if (box_sdf(vsub(bb[i].c, S.c), S.h, &g) > br[i] + off) continue;
-      collide_pair(e, &bb[i], &S, i, BODY_STATIC, 1, off);
+      collide_pair(e, &bb[i], &S, i, BODY_STATIC, 1, off, i, 128 + s);
     }
   /* (2) brick vs brick */
   for (int i = 0; i < NF; ++i)
@@ -398,7 +406,7 @@ static void collide(const sdx_scene_desc* sc, env_t* e) {
       v3 d = vsub(bb[i].c, bb[j].c);
       real rr = br[i] + br[j] + off;
       if (vdot(d, d) > rr * rr) continue;
-      collide_pair(e, &bb[i], &bb[j], i, j, 0, off);
+      collide_pair(e, &bb[i], &bb[j], i, j, 0, off, i, j);
     }
   /* (3) robot box vs brick, (4) robot box vs static */
   for (int r = 0; r < sc->n_rbox; ++r) {
@@ -410,13 +418,13 @@ static void collide(const sdx_scene_desc* sc, env_t* e) {
       v3 d = vsub(R.c, bb[i].c);
       real rr = rr0 + br[i] + off;
       if (vdot(d, d) > rr * rr) continue;
-      collide_pair(e, &R, &bb[i], NF + k, i, 0, off);
+      collide_pair(e, &R, &bb[i], NF + k, i, 0, off, NF + r, i);
     }
     for (int s = 0; s < sc->n_static; ++s) {
       box_t S = static_box(sc, s, e->env_index);
       v3 g;
       if (box_sdf(vsub(R.c, S.c), S.h, &g) > rr0 + off) continue;
-      collide_pair(e, &R, &S, NF + k, BODY_STATIC, 1, off);
+      collide_pair(e, &R, &S, NF + k, BODY_STATIC, 1, off, NF + r, 128 + s);
     }
   }
 }
@@ -465,6 +473,48 @@ static real robot_w(const env_t* e, int k, v3 p, v3 d) {
   return s;
 }
 
+/* impulse P on side 0 (body a) and -P on side 1 (body b) of contact c: brick velocity deltas into dv / dw, robot side into dQ */
+static void apply_impulse(const sdx_scene_desc* sc, env_t* e, int c, v3 P, real dQ[ND]) {
+  int ids[2] = {e->ca[c], e->cb[c]};
+  v3 p = e->cp[c];
+  for (int s = 0; s < 2; ++s) {
+    int id = ids[s];
+    v3 Ps = s == 0 ? P : vscale(P, -1.0f);
+    if (id == BODY_STATIC) continue;
+    if (id < NF) {
+      int t = sc->brick_type[id];
+      real isc = id == e->seg_brick ? 1.0f / sc->seg_mass_scale : 1.0f;
+      e->dv[id] = vadd(e->dv[id], vscale(Ps, isc / sc->brick_mass[t]));
+      v3 l = qrot(qconj(e->bq[id]), vcross(vsub(p, e->bp[id]), Ps));
+      const float* I = sc->brick_inertia[t];
+      e->dw[id] = vadd(e->dw[id], vscale(qrot(e->bq[id], V(l.x / I[0], l.y / I[1], l.z / I[2])), isc));
+    } else {
+      int k = id - NF;
+      for (int j = 0; j < ND; ++j)
+        if ((e->anc[k] >> j) & 1u) dQ[j] += vdot(vcross(e->la[j + 1], vsub(p, e->lp[j + 1])), Ps);
+    }
+  }
+}
+
+/* the velocity update that closes an iteration (and the warm start): bricks += dv, dw; Q += dQ; qd = qd* + Hinv Q; link twists */
+static void apply_deltas(const sdx_scene_desc* sc, env_t* e, const real dQ[ND]) {
+  for (int i = 0; i < NF; ++i) {
+    e->bv[i] = vadd(e->bv[i], e->dv[i]);
+    e->bw[i] = vadd(e->bw[i], e->dw[i]);
+  }
+  for (int j = 0; j < ND; ++j) e->Q[j] += dQ[j];
+  for (int i = 0; i < ND; ++i) {
+    real s = e->qd_star[i];
+    for (int j = 0; j < ND; ++j) s += e->Hinv[i][j] * e->Q[j];
+    e->qd[i] = s;
+  }
+  for (int k = 1; k < NL; ++k) {
+    int p = sc->parent[k];
+    e->lw[k] = vadd(e->lw[p], vscale(e->la[k], e->qd[k - 1]));
+    e->lv[k] = vadd(e->lv[p], vcross(e->lw[p], vsub(e->lp[k], e->lp[p])));
+  }
+}
+
 static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
   const real mu = sc->friction;
   /* base (un-split) inverse effective masses per row and side */
@@ -486,6 +536,41 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
     }
   }
   for (int j = 0; j < ND; ++j) e->qd_star[j] = e->qd[j];
+  /* warm start: a contact that existed in the previous solve - same boxes, direction and sample - starts from
+   * warm_start x the impulses it ended with (normal impulse <= 0: from zero); their effect on the velocities is applied before the
+   * first iteration.  The cache is in contact order, which changes little from solve to solve: the search resumes where the last
+   * match was found. */
+  if (sc->warm_start > 0 && e->wcount && *e->wcount > 0) {
+    const int nold = *e->wcount;
+    real dQ[ND];
+    for (int j = 0; j < ND; ++j) dQ[j] = 0;
+    for (int i = 0; i < NF; ++i) e->dv[i] = e->dw[i] = V(0, 0, 0);
+    int pos = 0;
+    for (int c = 0; c < e->nc; ++c) {
+      int found = -1;
+      for (int k = 0; k < nold; ++k) {
+        int q = pos + k;
+        if (q >= nold) q -= nold;
+        if (e->wkey[q] == e->ckey[c]) { found = q; break; }
+      }
+      if (found < 0) continue;
+      pos = found;
+      if (e->csep[c] < -WARM_DEPTH * sc->contact_offset) continue; /* deep penetration is recovery, not rest: cold */
+      {
+        v3 vr = vsub(point_vel(e, e->ca[c], e->cp[c]), point_vel(e, e->cb[c], e->cp[c]));
+        if (vdot(vr, vr) > WARM_SPEED * WARM_SPEED) continue; /* an impact or a sliding contact: last solve's impulse says nothing */
+      }
+      real l0 = sc->warm_start * e->wlam[0 * SDXO_MAXC + found];
+      if (!(l0 > 0)) continue;
+      e->lam[c][0] = l0;
+      e->lam[c][1] = sc->warm_start * e->wlam[1 * SDXO_MAXC + found];
+      e->lam[c][2] = sc->warm_start * e->wlam[2 * SDXO_MAXC + found];
+      v3 t1, t2;
+      tangents(e->cn[c], &t1, &t2);
+      apply_impulse(sc, e, c, vadd(vadd(vscale(e->cn[c], e->lam[c][0]), vscale(t1, e->lam[c][1])), vscale(t2, e->lam[c][2])), dQ);
+    }
+    apply_deltas(sc, e, dQ);
+  }
   for (int it = 0; it < sc->solver_iters; ++it) {
     /* pass 1: active set and per-body active-contact counts (mass splitting over ACTIVE contacts only) */
     for (int i = 0; i < NF; ++i) e->bcount[i] = 0;
@@ -532,41 +617,15 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
       l2 = fminf(lim, fmaxf(-lim, l2));
       dl[2] = l2 - e->lam[c][2];
       e->lam[c][2] = l2;
-      v3 P = vadd(vadd(vscale(n, dl[0]), vscale(t1, dl[1])), vscale(t2, dl[2])); /* impulse on A; -P on B */
-      int ids[2] = {a, b};
-      for (int s = 0; s < 2; ++s) {
-        int id = ids[s];
-        v3 Ps = s == 0 ? P : vscale(P, -1.0f);
-        if (id == BODY_STATIC) continue;
-        if (id < NF) {
-          int t = sc->brick_type[id];
-          real isc = id == e->seg_brick ? 1.0f / sc->seg_mass_scale : 1.0f;
-          e->dv[id] = vadd(e->dv[id], vscale(Ps, isc / sc->brick_mass[t]));
-          v3 l = qrot(qconj(e->bq[id]), vcross(vsub(p, e->bp[id]), Ps));
-          const float* I = sc->brick_inertia[t];
-          e->dw[id] = vadd(e->dw[id], vscale(qrot(e->bq[id], V(l.x / I[0], l.y / I[1], l.z / I[2])), isc));
-        } else {
-          int k = id - NF;
-          for (int j = 0; j < ND; ++j)
-            if ((e->anc[k] >> j) & 1u) dQ[j] += vdot(vcross(e->la[j + 1], vsub(p, e->lp[j + 1])), Ps);
-        }
-      }
+      apply_impulse(sc, e, c, vadd(vadd(vscale(n, dl[0]), vscale(t1, dl[1])), vscale(t2, dl[2])), dQ); /* impulse on A; -P on B */
     }
-    for (int i = 0; i < NF; ++i) {
-      e->bv[i] = vadd(e->bv[i], e->dv[i]);
-      e->bw[i] = vadd(e->bw[i], e->dw[i]);
-    }
-    for (int j = 0; j < ND; ++j) e->Q[j] += dQ[j];
-    for (int i = 0; i < ND; ++i) {
-      real s = e->qd_star[i];
-      for (int j = 0; j < ND; ++j) s += e->Hinv[i][j] * e->Q[j];
-      e->qd[i] = s;
-    }
-    /* link twists for the next iteration */
-    for (int k = 1; k < NL; ++k) {
-      int p = sc->parent[k];
-      e->lw[k] = vadd(e->lw[p], vscale(e->la[k], e->qd[k - 1]));
-      e->lv[k] = vadd(e->lv[p], vcross(e->lw[p], vsub(e->lp[k], e->lp[p])));
+    apply_deltas(sc, e, dQ);
+  }
+  if (e->wcount && sc->warm_start > 0) { /* the cache for the next solve */
+    *e->wcount = e->nc;
+    for (int c = 0; c < e->nc; ++c) {
+      e->wkey[c] = e->ckey[c];
+      for (int r = 0; r < 3; ++r) e->wlam[r * SDXO_MAXC + c] = e->lam[c][r];
     }
   }
 }
@@ -678,25 +737,34 @@ static void store_env(const sdx_scene_desc* sc, env_t* e, real h, float* root, f
 /* ---------------------------------------------------------------- exported entry points (ctypes) */
 
 /* gym.simulate + refresh_* for N envs.  root [N,142,13], dof [N,23,2], targets [N,23], rb [N,165,13],
- * contact [N,165,3], jac [N,6,7], ncontacts [N] (may be NULL). */
+ * contact [N,165,3], jac [N,6,7], ncontacts [N] (may be NULL).
+ * Warm-start cache of the envs (all three NULL: every call starts from an empty cache, as a freshly created simulator does; the second
+ * substep still starts from the first one's impulses): wcount i32 [N], wkey u32 [N, MAXC], wlam f32 [N, 3, MAXC]; read and updated. */
 void sdxo_simulate(const sdx_scene_desc* sc, int N, float* root, float* dof, const float* targets, float* rb,
-                   float* contact, float* jac, int* ncontacts) {
+                   float* contact, float* jac, int* ncontacts, int* wcount, unsigned* wkey, float* wlam) {
   real h = sc->dt / (real)sc->substeps;
   /* envs are independent (collision groups = env id, GS:907-968): OpenMP over envs; thread count = OMP_NUM_THREADS */
 #pragma omp parallel
   {
     env_t* e = (env_t*)malloc(sizeof(env_t));
+    int tcount = 0;
+    unsigned* tkey = wcount ? NULL : (unsigned*)malloc(sizeof(unsigned) * SDXO_MAXC);
+    float* tlam = wcount ? NULL : (float*)malloc(sizeof(float) * 3 * SDXO_MAXC);
 #pragma omp for schedule(dynamic, 4)
     for (int n = 0; n < N; ++n) {
       float* r = root + (size_t)n * SDX_ACTORS * 13;
       float* d = dof + (size_t)n * ND * 2;
       e->overflow = 0;
+      if (wcount) { e->wcount = wcount + n; e->wkey = wkey + (size_t)n * SDXO_MAXC; e->wlam = wlam + (size_t)n * 3 * SDXO_MAXC; }
+      else { tcount = 0; e->wcount = &tcount; e->wkey = tkey; e->wlam = tlam; }
       load_env(sc, e, n, r, d, targets + (size_t)n * ND);
       for (int s = 0; s < sc->substeps; ++s) substep(sc, e, h, s == 0);
       store_env(sc, e, h, r, d, rb + (size_t)n * SDX_BODIES * 13, contact + (size_t)n * SDX_BODIES * 3,
                 jac + (size_t)n * 42, ncontacts ? ncontacts + n : NULL);
     }
     free(e);
+    free(tkey);
+    free(tlam);
   }
 }
 

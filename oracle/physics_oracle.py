@@ -30,8 +30,22 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def simulate(desc, root, dof, targets):
-    """root [N,142,13], dof [N,23,2], targets [N,23] (float32, modified in place for root/dof).
+class WarmState:
+    """impulse cache of n envs between calls of simulate(); fresh = empty, like a freshly created simulator"""
+
+    def __init__(self, n):
+        cap = lib().sdxo_max_contacts()
+        self.count = np.zeros(n, np.int32)
+        self.key = np.zeros((n, cap), np.uint32)
+        self.lam = np.zeros((n, 3, cap), np.float32)
+
+    def clear(self):
+        self.count[:] = 0
+
+
+def simulate(desc, root, dof, targets, warm=None):
+    """root [N,142,13], dof [N,23,2], targets [N,23] (float32, modified in place for root/dof).  warm: a WarmState that carries the
+    solver's impulses from one call to the next (None: every call starts from an empty cache).
     Returns rb [N,165,13], contact [N,165,3], jac [N,6,7], ncontacts [N]."""
     n = root.shape[0]
     assert root.dtype == np.float32 and root.flags.c_contiguous and dof.flags.c_contiguous
@@ -40,7 +54,12 @@ def simulate(desc, root, dof, targets):
     jac = np.zeros((n, 6, 7), np.float32)
     nc = np.zeros(n, np.int32)
     tg = np.ascontiguousarray(targets, np.float32)
-    lib().sdxo_simulate(C.byref(desc), C.c_int(n), _p(root), _p(dof), _p(tg), _p(rb), _p(contact), _p(jac), _p(nc))
+    if warm is None:
+        w = (None, None, None)
+    else:
+        assert warm.count.shape[0] == n
+        w = (_p(warm.count), _p(warm.key), _p(warm.lam))
+    lib().sdxo_simulate(C.byref(desc), C.c_int(n), _p(root), _p(dof), _p(tg), _p(rb), _p(contact), _p(jac), _p(nc), *w)
     return rb, contact, jac, nc
 
 

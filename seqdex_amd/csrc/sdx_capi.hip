@@ -158,6 +158,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(seg_pix, (size_t)N * 4);
   ALLOC(emergence, N);
   ALLOC(cstats, 2);
+  ALLOC(wcount, N);
+  ALLOC(wkey, (size_t)N * SDX_MAXC);
+  ALLOC(wlam, (size_t)N * 3 * SDX_MAXC);
   if (scene->task_kind == 3) {
     ALLOC(tvt_buf, (size_t)N * 652);
     ALLOC(tvt_w, (size_t)1024 * 652 + 1024 + 512 * 1024 + 512 + 128 * 512 + 128 + 2 * 128 + 2);
@@ -207,6 +210,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_SEG_PIXELS, B.seg_pix, SDX_F32, {N, 4});
   set_tensor(h, SDX_T_EMERGENCE, B.emergence, SDX_F32, {N});
   set_tensor(h, SDX_T_CONTACT_STATS, B.cstats, SDX_I32, {2});
+  set_tensor(h, SDX_T_WARM_COUNT, B.wcount, SDX_I32, {N});
   set_tensor(h, SDX_T_JACOBIAN, B.jac_full, SDX_F32, {N, SDX_NLINK - 1, 6, SDX_NDOF});
   if (scene->task_kind == 3) set_tensor(h, SDX_T_TVALUE_OBS, B.tvt_buf, SDX_F32, {N, 652});
   else set_tensor(h, SDX_T_TVALUE_OBS, B.seg_pix, SDX_F32, {1, 1});   // placeholder: the temporal buffer belongs to Search

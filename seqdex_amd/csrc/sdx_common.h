@@ -62,6 +62,10 @@ struct SdxBuf {
   float* tvt_buf;          // Search: [N,652] temporal T-value input (ten 65-number frames, 2 padding columns) or nullptr
   float* tvt_w;            // Search: RetriGraspTValue parameters, W1 rows padded to 652 columns
   float* tvt_h;            // Search: activations [N, 1024 + 512 + 128 + 4]
+  // warm start of the contact solver: what the last solve of every env ended with
+  int32_t* wcount;         // [N] contacts in the cache
+  uint32_t* wkey;          // [N, SDX_MAXC] contact identity (pair rank << 6 | direction << 5 | sample), ascending pair rank
+  float* wlam;             // [N, 3, SDX_MAXC] accumulated impulses (normal, two tangents)
   float* insert_aux;       // [N,8] InsertSim: 0..2 rot_err of the last pre_physics_step (IS:1539), 3 |brick - site|, 4 rot_dist
 };
 

@@ -90,6 +90,7 @@ struct PhysLds {
 #define S_EBODY2(S) (reinterpret_cast<unsigned char*>(&(S).P[1][0]))                 // ... and the body each one belongs to
 static_assert(ND * HP <= MAXC, "L^-1 must fit one row");
 static_assert(MAXP <= MAXC, "the pair list must fit one row");
+static_assert(2 * MAXC * sizeof(unsigned short) == MAXC * sizeof(uint32_t), "contact keys alias the CSR entries");
 static_assert(sizeof(PhysLds) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
 
 struct Box { f3 c; f4 q; f3 h; };
@@ -155,6 +156,8 @@ __device__ __forceinline__ int box_body(const PhysLds& S, int id) {
 // has no meaningful meeting face (kax = -1) and every sample keeps its own signed distance.
 #define FACE_TOL 1e-4f
 #define FACE_DEPTH 4.0f
+#define WARM_SPEED 0.25f   // m/s
+#define WARM_DEPTH 1.5f    // contact offsets
 struct Dir { f3 t, ex, ey, ez; int kax; float sgn, smax; };   // ex, ey, ez: A's half edges in B's frame: sample = t + sx ex + sy ey + sz ez
 __device__ __forceinline__ Dir dir_setup(const Box& A, const Box& B, float off) {
   Dir D;
@@ -229,7 +232,9 @@ __device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off,
   return c;
 }
 
-__device__ __forceinline__ void emit_dir(PhysLds& S, const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k, int base, float off) {
+#define S_CKEY(S) (reinterpret_cast<uint32_t*>(&(S).ent[0]))   // identity of contact c until the solver's set-up has read it (the CSR lives here later)
+__device__ __forceinline__ void emit_dir(PhysLds& S, const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k, int base, float off,
+                                         uint32_t pkey) {
   const Dir D = dir_setup(A, B, off);
   for (int i = 0; i < k; ++i) {
     const int c = base + i;
@@ -245,6 +250,7 @@ __device__ __forceinline__ void emit_dir(PhysLds& S, const Box& A, const Box& B,
     S.cn[0][c] = n.x; S.cn[1][c] = n.y; S.cn[2][c] = n.z;
     S.P[0][c] = sd;                                       // staged for the owner lane of contact c (solver set-up)
     S.P[1][c] = __int_as_float(ida | (idb << 8));
+    S_CKEY(S)[c] = pkey | (uint32_t)s;                    // (pair rank << 6 | direction << 5) | sample
   }
 }
 
@@ -567,13 +573,15 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   SSTAMP(32);
   int np;
   {
-    // at most 15 candidates per lane: (72 * 8 + 72 * 71 / 2 + 32 * 80) / 384 < 15
+    // at most 15 candidates per lane: (72 * 8 + 72 * 71 / 2 + 32 * 80) / 384 < 15 (4 bits of the pair rank)
     int pos = block_scan_small<NT>(S, __popc(mask), tid, &np);
     uint32_t m = mask;
     while (m) {
       const int it = __ffs(m) - 1;
       m &= m - 1;
-      if (pos < MAXP) S_PAIRS(S)[pos] = pair_code(tid + it * NT, n1, n2, ns, per);
+      // bits 16..28: rank of the candidate in this list's order (lane-major: tid * 16 + trip), the same from solve to solve: the
+      // major part of the warm-start key, ascending along the pair list and therefore along the contact list
+      if (pos < MAXP) S_PAIRS(S)[pos] = pair_code(tid + it * NT, n1, n2, ns, per) | ((uint32_t)(tid * 16 + it) << 16);
       ++pos;
     }
   }
@@ -617,10 +625,11 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   for (int base = 0; base < np; base += NT) {
     const int pi = base + tid;
     int k1 = 0, k2 = 0, ida = 0, idb = 0;
-    uint32_t p1 = 0, p2 = 0;
+    uint32_t p1 = 0, p2 = 0, prank = 0;
     Box A, Bx;
     if (pi < np) {
       const uint32_t pr = S_PAIRS(S)[pi];
+      prank = pr >> 16;
       const int ba = pr & 0xff, bb = (pr >> 8) & 0xff;
       A = load_box(S, ba);
       Bx = load_box(S, bb);
@@ -636,8 +645,8 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     }
     int tot;
     const int pre = block_scan_small<NT>(S, k1 + k2, tid, &tot);
-    if (k1 > 0) emit_dir(S, A, Bx, ida, idb, p1, k1, nc + pre, off);
-    if (k2 > 0) emit_dir(S, Bx, A, idb, ida, p2, k2, nc + pre + k1, off);
+    if (k1 > 0) emit_dir(S, A, Bx, ida, idb, p1, k1, nc + pre, off, prank << 6);
+    if (k2 > 0) emit_dir(S, Bx, A, idb, ida, p2, k2, nc + pre + k1, off, (prank << 6) | 32u);
     nc += tot;
   }
   if (tid == 0) {
@@ -674,11 +683,17 @@ __device__ __forceinline__ float robot_w(const PhysLds& S, int k, f3 p, f3 d) {
   return 2.0f * acc;
 }
 
-template <int NT>
-__device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last_substep, long long* dbg) {
+template <int NT, bool WARM>
+// Warm start (oracle: solve()): wcount / wkey / wlam are THIS env's impulse cache in HBM.  A contact that existed
+// in the previous solve (same pair, direction and sample) starts from sc.warm_start x the impulses it ended with; iteration -1 of the
+// loop below spreads those impulses over the bodies with the gather machinery of a normal iteration.  WARM is a template parameter:
+// the default (cold) solver carries none of this code (it cost 2.6 % of the kernel as a run-time switch).
+__device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last_substep, long long* dbg,
+                                      int32_t* wcount, uint32_t* wkey, float* wlam) {
   constexpr int CPT = MAXC / NT;   // contact rows owned by one lane
   constexpr int NB = NF + NL;      // bodies with a CSR list: bricks 0..71, links 72..95
   static_assert(CPT * NT == MAXC, "NT must divide SDX_MAXC");
+  static_assert(CPT * 11 <= 64 && MAXC < 0x7ff, "11-bit cache positions of a lane's contacts in one 64-bit word");
   const sdx_scene_desc& sc = C->sc;
   const int nc = S.nc;
   const float mu = sc.friction, relax = sc.jacobi_relax;
@@ -687,22 +702,59 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   // impulses, un-split inverse masses of both sides
   int ab[CPT];
   float vtgt[CPT];
+  uint32_t ckey[CPT];
+  const float beta = sc.warm_start;
+  // depth gate expressed on the velocity target the lane keeps anyway: sep < -WARM_DEPTH * offset <=> vtgt > baumgarte * depth / h
+  const float wdeep = sc.baumgarte * (WARM_DEPTH * sc.contact_offset) / h;
+  int nold = WARM ? *wcount : 0;   // block-uniform
+  if (nold > MAXC) nold = MAXC;
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
     ab[q] = BODY_W | (BODY_W << 8);
     vtgt[q] = 0.0f;
+    ckey[q] = 0xffffffffu;
     if (c < nc) {
       const float sep = S.P[0][c];
       ab[q] = __float_as_int(S.P[1][c]);
       vtgt[q] = sep > 0 ? -sep / h : fminf(sc.baumgarte * (-sep) / h, sc.max_depenetration_vel);
+      if (WARM) ckey[q] = S_CKEY(S)[c];
     }
   }
+  // the previous solve's keys into the free third impulse row (the pair list that lived there is dead)
+  if (WARM) for (int i = tid; i < nold; i += NT) S.P[2][i] = __int_as_float((int)wkey[i]);
   SSTAMP(23);
   // ---- CSR of contact sides per body (bricks AND robot links), ascending contact index inside a body
   for (int i = tid; i < NB; i += NT) { S.ecount[i] = 0; S.efill[i] = 0; }
   if (last_substep) for (int i = tid; i < NL * 3; i += NT) (&S.cf[0][0])[i] = 0.0f;
-  __syncthreads();   // also: every lane has read its (separation, ids) out of the staging rows, which the fill list reuses below
+  __syncthreads();   // also: every lane has read its (separation, ids, key) out of the staging rows, which the fill list reuses below
+  // warm-start match: the old keys ascend in their pair rank (bits 6..), so the pair's first old contact is a lower bound away; the
+  // <= 4 contacts of a pair are then compared exactly.  wmatch packs the matched positions (11 bits each, 0x7ff = none); the
+  // impulses themselves are fetched where the lam registers are born.  The new keys replace the old ones in HBM right away (the
+  // old ones are in LDS now; the old impulses stay untouched until the end of this solve).
+  uint64_t wmatch = ~0ull;
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const int c = tid + q * NT;
+    if (WARM && c < nc) {
+      const uint32_t key = ckey[q];
+      if (nold > 0) {
+        int lo = 0, hi = nold;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (((uint32_t)__float_as_int(S.P[2][mid]) >> 6) < (key >> 6)) lo = mid + 1; else hi = mid;
+        }
+        int found = 0x7ff;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = lo + u;
+          if (i < nold && (uint32_t)__float_as_int(S.P[2][i]) == key) found = i;
+        }
+        wmatch = (wmatch & ~(0x7ffull << (11 * q))) | ((uint64_t)found << (11 * q));
+      }
+      wkey[c] = key;
+    }
+  }
 #pragma unroll
   for (int q = 0; q < CPT; ++q)
     if (tid + q * NT < nc) {
@@ -795,6 +847,16 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       wB[q][r] = (on && b < NF) ? brick_w(S, b, p, dir[r]) : 0.0f;
       lam[q][r] = 0.0f;
     }
+    // warm start only where the last solve's impulse still means something: the contact is not in deep penetration (that is recovery,
+    // not rest) and the two bodies are nearly at rest relative to each other at the contact point (not an impact, not sliding)
+    const int wm = (int)((wmatch >> (11 * q)) & 0x7ffull);
+    if (WARM && on && wm != 0x7ff && vtgt[q] <= wdeep) {
+      const f3 vrel = point_vel(S, a, p) - point_vel(S, b, p);
+      const float l0 = beta * wlam[wm];
+      if (l0 > 0.0f && dot(vrel, vrel) <= WARM_SPEED * WARM_SPEED) {
+        lam[q][0] = l0; lam[q][1] = beta * wlam[MAXC + wm]; lam[q][2] = beta * wlam[2 * MAXC + wm];
+      }
+    }
   }
   if (has_robot) {
     // owner lanes fetch them: position of the contact in its link's list by binary search (ascending contact index)
@@ -877,7 +939,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     for (int r = 0; r < 3; ++r) { SDX_OPAQUE(lam[q][r]); SDX_OPAQUE(wA[q][r]); SDX_OPAQUE(wB[q][r]); }
   }
   SDX_OPAQUE(gbeg); SDX_OPAQUE(gend); SDX_OPAQUE(tjp);
-  for (int it = 0; it < sc.solver_iters; ++it) {
+  for (int it = (WARM && nold > 0) ? -1 : 0; it < sc.solver_iters; ++it) {   // it = -1: only the gather of the warm-start impulses
     if (it == 1) dbg = nullptr;
     SSTAMP(18);
     // ---- [A] lane = contact: relative velocity from the current body velocities, active flag, ACTIVE counts by integer atomics
@@ -889,7 +951,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       int abq = ab[q], ct = tid;
       SDX_OPAQUE(abq); SDX_OPAQUE(ct);
       const int c = ct + q * NT;
-      if (c < nc) {
+      if (c < nc && (!WARM || it >= 0)) {
         const int a = abq & 0xff, b = (abq >> 8) & 0xff;
         const f3 p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]), n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
         vr[q] = point_vel(S, a, p) - point_vel(S, b, p);
@@ -928,6 +990,11 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         l2 = fminf(lim, fmaxf(-lim, l2));
         lam[q][0] = ln; lam[q][1] = l1; lam[q][2] = l2;
         P = n * (ln - lam0) + t1 * (l1 - lam1) + t2 * (l2 - lam2);
+      } else if (WARM && it < 0 && c < nc && lam[q][0] > 0.0f) {   // warm start: the whole initial impulse
+        const f3 n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
+        f3 t1, t2;
+        tangents(n, &t1, &t2);
+        P = n * lam[q][0] + t1 * lam[q][1] + t2 * lam[q][2];
       }
       if (c < nc) { S.P[0][c] = P.x; S.P[1][c] = P.y; S.P[2][c] = P.z; }
     }
@@ -1027,6 +1094,17 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     }
     __syncthreads();
     SSTAMP(22);
+  }
+  // ---- the cache for the next solve (keys were written during the set-up)
+  if (WARM) {
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const int c = tid + q * NT;
+      if (c < nc) { wlam[c] = lam[q][0]; wlam[MAXC + c] = lam[q][1]; wlam[2 * MAXC + c] = lam[q][2]; }
+    }
+    if (tid == 0) *wcount = nc;
+    // no agent-scope fence: the next reader is this workgroup's next substep, many workgroup barriers later on the same CU (the
+    // vector L1 is shared by the waves of a workgroup), or the next launch
   }
 }
 
@@ -1170,7 +1248,10 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
       if (S.overflow) atomicAdd(&B.cstats[1], 1);
     }
     PSTAMP(4);
-    solve<NT>(Cs, S, tl, h, sub == nsub - 1, sub == 0 ? B.dbg : nullptr);
+    if (scl.warm_start > 0.0f)
+      solve<NT, true>(Cs, S, tl, h, sub == nsub - 1, sub == 0 ? B.dbg : nullptr, B.wcount + e, B.wkey + (size_t)e * MAXC, B.wlam + (size_t)e * 3 * MAXC);
+    else
+      solve<NT, false>(Cs, S, tl, h, sub == nsub - 1, sub == 0 ? B.dbg : nullptr, nullptr, nullptr, nullptr);
     PSTAMP(5);
     // F: integrate
     if (tl < ND) {

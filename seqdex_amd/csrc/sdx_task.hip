@@ -157,6 +157,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
       float v = src[i];
       dst[i] = (i % 13 >= 7) ? 0.0f : v;
     }
+    if (lane == 0 && B.wcount) B.wcount[e] = 0;                                  // a restored pile has no contact history (warm start)
     if (lane < 13) root_e[1 * 13 + lane] = sc.object_init_state[lane];           // GS:1475-1482
     if (lane < 3) root_e[2 * 13 + lane] = sc.goal_reset_pos[lane];               // GS:1348
     if (lane >= 7 && lane < 13) root_e[2 * 13 + lane] = 0.0f;                    // GS:1350

@@ -43,8 +43,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def simulate(desc, root, dof, targets):
-    """same contract as oracle.physics_oracle.simulate, executed by the emulated k_physics"""
+def simulate(desc, root, dof, targets, warm=None):
+    """same contract as oracle.physics_oracle.simulate (warm: an oracle.physics_oracle.WarmState of the emulated kernel's own cache -
+    its key encoding differs from the oracle's, the two are not interchangeable), executed by the emulated k_physics"""
     n = root.shape[0]
     assert root.dtype == np.float32 and root.flags.c_contiguous and dof.flags.c_contiguous
     rb = np.zeros((n, 165, 13), np.float32)
@@ -52,5 +53,6 @@ def simulate(desc, root, dof, targets):
     jac = np.zeros((n, 6, 7), np.float32)
     nc = np.zeros(n, np.int32)
     tg = np.ascontiguousarray(targets, np.float32)
-    lib().emu_simulate(C.byref(desc), C.c_int(n), _p(root), _p(dof), _p(tg), _p(rb), _p(contact), _p(jac), _p(nc), None)
+    w = (None, None, None) if warm is None else (_p(warm.count), _p(warm.key), _p(warm.lam))
+    lib().emu_simulate(C.byref(desc), C.c_int(n), _p(root), _p(dof), _p(tg), _p(rb), _p(contact), _p(jac), _p(nc), None, *w)
     return rb, contact, jac, nc

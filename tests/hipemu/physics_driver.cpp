@@ -13,8 +13,9 @@ extern "C" void sdxk_physics(const SdxConst* C, const SdxBuf* B, hipStream_t st)
 extern "C" void sdxk_kinematics(const SdxConst* C, const SdxBuf* B, hipStream_t st);
 extern "C" size_t sdxk_physics_lds_bytes();
 
+// wcount / wkey / wlam: the warm-start cache of the N envs ([N], [N, SDX_MAXC], [N, 3, SDX_MAXC]); NULL = an empty cache for this call
 extern "C" int emu_simulate(const sdx_scene_desc* sc, int N, float* root, float* dof, const float* targets, float* rb, float* contact,
-                            float* jac, int* ncontacts, long long* dbg) {
+                            float* jac, int* ncontacts, long long* dbg, int* wcount, unsigned* wkey, float* wlam) {
   static SdxConst K;
   sdx_build_const(sc, &K);
   SdxBuf B;
@@ -24,6 +25,14 @@ extern "C" int emu_simulate(const sdx_scene_desc* sc, int N, float* root, float*
   B.ncontacts = ncontacts;
   std::vector<long long> d(64, 0);
   B.dbg = dbg ? dbg : d.data();
+  std::vector<int32_t> tc;
+  std::vector<uint32_t> tk;
+  std::vector<float> tl;
+  if (!wcount) {
+    tc.assign(N, 0); tk.assign((size_t)N * SDX_MAXC, 0u); tl.assign((size_t)N * 3 * SDX_MAXC, 0.0f);
+    wcount = tc.data(); wkey = tk.data(); wlam = tl.data();
+  }
+  B.wcount = wcount; B.wkey = wkey; B.wlam = wlam;
   sdxk_physics(&K, &B, nullptr);
   return (int)sdxk_physics_lds_bytes();
 }

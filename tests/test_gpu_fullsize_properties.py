@@ -33,6 +33,7 @@ def _tiled_state(golden_dir, n):
 def _run(s, root, dof, tg, steps):
     n = root.shape[0]
     s.ROOT.copy_(_dev(root.reshape(-1, 13))); s.DOF.copy_(_dev(dof.reshape(-1, 2))); s.TARGETS.copy_(_dev(tg))
+    s.WARM_COUNT.zero_()                                          # a loaded state has no contact history: empty warm-start caches
     for _ in range(steps):
         s.simulate()
     torch.cuda.synchronize()

@@ -37,6 +37,7 @@ def _load(s, root, rb, dof, contact, actions):
     n = root.shape[0]
     s.ROOT.copy_(_dev(root.reshape(-1, 13))); s.RB.copy_(_dev(rb)); s.DOF.copy_(_dev(dof.reshape(-1, 2)))
     s.CONTACT.copy_(_dev(contact.reshape(n, -1))); s.ACTIONS.copy_(_dev(actions))
+    s.WARM_COUNT.zero_()                                          # a loaded state has no contact history: empty warm-start caches
 
 
 def test_orient_1024_observations_against_oracle(scene):

@@ -50,20 +50,23 @@ def _one_step(s, root, dof, targets):
             s.CONTACT.cpu().numpy().reshape(n, 165, 3), s.JAC_EEF.cpu().numpy(), s.NCONTACTS.cpu().numpy())
 
 
-def test_one_step_teacher_forcing(state, scene):
+@pytest.mark.parametrize("warm_start", [0.0, 0.8])
+def test_one_step_teacher_forcing(state, scene, warm_start):
     """same start state, one simulate() on each side.  Contact-rich piles amplify fp32 rounding through the
     discrete contact set (and, since the face manifold of DESIGN.md section 3.D, through its separating-axis choice), so the bar is: identical
     contact counts, robot pose to 1e-4 (velocities 5e-4 / 1e-3), brick poses to 2e-5 m for >= 99% and brick velocities to 2e-3 m/s for
     >= 98% of the bricks (98.6% measured; 99.3% with the round-1 manifold), no brick further than 1e-4 m off."""
     from seqdex_amd.sim import SdxSim
     n = state["root"].shape[0]
-    s = SdxSim(n)
+    s = SdxSim(n, warm_start=warm_start)      # default: cold solver; 0.8: the optional warm start of DESIGN.md section 3.E
     try:
         root, dof = state["root"].copy(), state["dof"].copy()
+        o_warm = po.WarmState(n)            # both sides keep their own impulse cache from step to step (DESIGN.md section 3.E)
         for it in range(3):
             g_root, g_dof, g_rb, g_contact, g_jac, g_nc = _one_step(s, root, dof, state["targets"])
             o_root, o_dof = root.copy(), dof.copy()
-            o_rb, o_contact, o_jac, o_nc = po.simulate(s._desc, o_root, o_dof, state["targets"])
+            o_rb, o_contact, o_jac, o_nc = po.simulate(s._desc, o_root, o_dof, state["targets"], o_warm)
+            np.testing.assert_array_equal(s.WARM_COUNT.cpu().numpy(), o_warm.count)
             np.testing.assert_array_equal(g_nc, o_nc)
             np.testing.assert_allclose(g_dof[..., 0], o_dof[..., 0], rtol=1e-4, atol=1e-4)     # joint positions
             np.testing.assert_allclose(g_dof[..., 1], o_dof[..., 1], rtol=1e-3, atol=2e-3)     # joint velocities (fingers in contact: 1.2e-3 rad/s seen)
@@ -118,12 +121,14 @@ def test_free_fall_and_invariants(scene):
         s.close()
 
 
-def test_stacked_bricks_stay_stacked_on_device(scene):
+@pytest.mark.parametrize("warm_start", [0.0, 0.8])
+def test_stacked_bricks_stay_stacked_on_device(scene, warm_start):
     """the stacking cases of tests/test_physics_oracle.py (flush equal bricks, offsets, crossed bricks), one per env, through k_physics:
     two seconds after the drop every upper brick still stands on its lower brick, and the device trajectory ends where the oracle's
     does (these quiet scenes do not amplify rounding: 0.2 mm / 2e-3 in the quaternion)."""
     from seqdex_amd.sim import SdxSim
-    from test_physics_oracle import STACKS, stacked_pair_state
+    from test_physics_oracle import STACKS, STACKS_WARM, check_stack, stacked_pair_state
+    STACKS = STACKS_WARM if warm_start > 0 else STACKS
     n = len(STACKS)
     roots, rests = [], []
     for (ia, ib, yaw, dx, dy) in STACKS:
@@ -131,23 +136,20 @@ def test_stacked_bricks_stay_stacked_on_device(scene):
         roots.append(root[0]); rests.append((za, zb))
     root = np.stack(roots).astype(np.float32)
     dof = np.repeat(dof, n, 0); tg = np.repeat(tg, n, 0)
-    s = SdxSim(n)
+    s = SdxSim(n, warm_start=warm_start)
     try:
         ref, refd = root.copy(), dof.copy()
+        o_warm = po.WarmState(n)
         s.ROOT.copy_(_dev(root.reshape(-1, 13))); s.DOF.copy_(_dev(dof.reshape(-1, 2))); s.TARGETS.copy_(_dev(tg))
         for _ in range(120):
             s.simulate()
-            po.simulate(s._desc, ref, refd, tg)
+            po.simulate(s._desc, ref, refd, tg, o_warm)
         torch.cuda.synchronize()
         r = s.ROOT.cpu().numpy().reshape(n, 142, 13)
         nc = s.NCONTACTS.cpu().numpy()
         for e, (ia, ib, yaw, dx, dy) in enumerate(STACKS):
             za, zb = rests[e]
-            sink_a = za - r[e, 9 + ia, 2]
-            sink_b = zb - r[e, 9 + ib, 2] - sink_a
-            assert -1e-4 < sink_a < 3e-3 and -1e-4 < sink_b < 3e-3, (e, sink_a, sink_b)
-            assert abs(r[e, 9 + ib, 0] - 0.25 - dx) < 6e-3 and abs(r[e, 9 + ib, 1] - 0.19 - dy) < 6e-3
-            assert nc[e] == 8
+            check_stack(r, nc, e, ia, ib, yaw, dx, dy, za, zb, *((6e-4, 1.5e-3) if warm_start > 0 else (3e-3, 6e-3)))
             np.testing.assert_allclose(r[e, [9 + ia, 9 + ib], 0:3], ref[e, [9 + ia, 9 + ib], 0:3], rtol=0, atol=2e-4)
             np.testing.assert_allclose(np.abs((r[e, [9 + ia, 9 + ib], 3:7] * ref[e, [9 + ia, 9 + ib], 3:7]).sum(-1)), 1.0, rtol=0, atol=2e-3)
     finally:
