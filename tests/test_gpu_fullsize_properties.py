@@ -317,3 +317,16 @@ def test_checkpoint_round_trip_in_rlgames_layout(tmp_path):
         np.testing.assert_allclose(a.t["CV_PARAMS"].cpu().numpy(), b.t["CV_PARAMS"].cpu().numpy(), rtol=0, atol=1e-6)
     finally:
         a.close(); b.close()
+
+
+def test_generated_piles_keep_every_brick_inside_the_bin():
+    """seqdex_amd.piles.generate_piles: a brick in a few thousand bounces out of the bin while the pile settles; saved pile states that
+    lost one are replaced, so every state the resets restore has its 72 free bricks over the bin"""
+    from seqdex_amd.piles import generate_piles
+    p = generate_piles(per_type=32, seed=3)                      # 256 piles
+    assert p.shape == (8, 32, 132, 13) and np.isfinite(p).all()
+    fb = p[:, :, :72, 0:3]
+    assert (np.abs(fb[..., 0] - 0.25) < 0.3).all() and (np.abs(fb[..., 1] - 0.19) < 0.21).all()
+    assert (fb[..., 2] > 0.55).all()
+    assert (p[:, :, :, 7:13] == 0).all()
+    assert len({p[t, k, :72, 0:3].tobytes() for t in range(8) for k in range(32)}) > 220      # replacements are the exception
