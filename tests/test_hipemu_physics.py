@@ -86,3 +86,26 @@ def test_emulated_stack_contacts_match_oracle(scene):
         np.testing.assert_allclose(g_root[:, 9:81, 7:], o_root[:, 9:81, 7:], atol=2e-4)
         root, dof = o_root, o_dof
     assert (o_nc == 8).all()
+
+
+def test_emulated_friction_and_joint_limit_match_oracle(scene):
+    """the sliding-friction and joint-limit cases of tests/test_physics_oracle.py through the kernel source: same decelerations, same clamp"""
+    from test_physics_oracle import base_state
+    desc = scene.to_desc()
+    root, dof, tg = base_state(scene)
+    t0 = scene.brick_types[0]
+    floor_top = scene.statics[6]["center"][2] + scene.statics[6]["half"][2]
+    root[0, 9, 0:3] = [0.25, 0.19, floor_top + t0["half"][2] - t0["center"][2] - 0.0005]
+    root[0, 9, 7:10] = [0.6, 0.0, 0.0]
+    tg[0, 8] = scene.upper[8] + 0.5
+    g_root, g_dof, o_root, o_dof = root.copy(), dof.copy(), root.copy(), dof.copy()
+    for it in range(8):
+        hipemu.simulate(desc, g_root, g_dof, tg)
+        po.simulate(desc, o_root, o_dof, tg)
+        np.testing.assert_allclose(g_root[0, 9, 7:10], o_root[0, 9, 7:10], atol=2e-5)
+        np.testing.assert_allclose(g_dof[0, :, 0], o_dof[0, :, 0], atol=1e-5)
+        np.testing.assert_allclose(g_dof[0, :, 1], o_dof[0, :, 1], atol=5e-5)
+    assert abs(o_root[0, 9, 7]) < 5e-3                       # the brick has stopped
+    for _ in range(40):
+        hipemu.simulate(desc, g_root, g_dof, tg)
+    assert g_dof[0, 8, 0] == np.float32(scene.upper[8]) and g_dof[0, 8, 1] == 0.0

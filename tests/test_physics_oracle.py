@@ -280,3 +280,37 @@ def test_cold_solver_lets_the_off_axis_stack_creep_over(scene, desc):
     for _ in range(240):
         po.simulate(desc, root, dof, tg)
     assert zb - root[0, 9 + 14, 2] > 0.03                                                            # the upper brick is on the floor
+
+
+def test_sliding_friction_decelerates_at_mu_g(scene, desc):
+    """Coulomb friction, mu = 1: a brick sliding on the floor along its long axis loses mu g dt of speed per
+    step until it stops, without turning (the friction pyramid's axes are x and y for a vertical normal)"""
+    root, dof, tg = base_state(scene)
+    t0 = scene.brick_types[0]
+    floor_top = scene.statics[6]["center"][2] + scene.statics[6]["half"][2]
+    root[0, 9, 0:3] = [0.25, 0.19, floor_top + t0["half"][2] - t0["center"][2] - 0.0015]
+    for _ in range(30):
+        po.simulate(desc, root, dof, tg)                     # settle
+    root[0, 9, 7:10] = [0.6, 0.0, 0.0]
+    v = [0.6]
+    for _ in range(5):
+        po.simulate(desc, root, dof, tg)
+        v.append(float(root[0, 9, 7]))
+    np.testing.assert_allclose(np.diff(v[:4]), -9.81 / 60.0, rtol=0.02)      # 0.6 -> 0.436 -> 0.273 -> 0.110
+    assert abs(v[4]) < 5e-3 and abs(v[5]) < 1e-3                             # stopped, and stays stopped (no friction overshoot)
+    assert np.abs(root[0, 9, 10:13]).max() < 0.05 and abs(root[0, 9, 8]) < 1e-3
+
+
+def test_joint_limit_holds(scene, desc):
+    """joint limits as clamp + velocity projection (section 3.F): a finger joint driven 0.5 rad beyond its upper limit ends AT the limit, at rest"""
+    root, dof, tg = base_state(scene)
+    j = 8
+    tg2 = tg.copy()
+    tg2[0, j] = scene.upper[j] + 0.5
+    for _ in range(60):
+        po.simulate(desc, root, dof, tg2)
+    assert dof[0, j, 0] == np.float32(scene.upper[j]) and dof[0, j, 1] == 0.0
+    tg2[0, j] = scene.lower[j] - 0.5
+    for _ in range(90):
+        po.simulate(desc, root, dof, tg2)
+    assert dof[0, j, 0] == np.float32(scene.lower[j]) and dof[0, j, 1] == 0.0
