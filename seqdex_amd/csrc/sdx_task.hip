@@ -147,6 +147,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
         for (int i = lane; i < SDX_NBRICK * 13; i += SDX_WAVE) dst[i] = srcb[i];
       }
     }
+    __builtin_amdgcn_wave_barrier();   // the harvests above read rows that the restore below rewrites with another lane assignment
     int choice;
     if (ext_choice) choice = ext_choice[e];
     else choice = (int)(sdx_hash(B.seed, (uint64_t)e, (uint64_t)B.step_count[0]) % (uint64_t)B.K);
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
     s_s[101 + lane] = s_in[13 * (f + 1) + 3 + c];
   }
   if (lane < 6) s_s[142 + lane] = s_tg[7 + lane];                                 // GS:1255-1256
+  __builtin_amdgcn_wave_barrier();   // lane 0 overwrites some of the bulk copies above (InsertSim's frame): program order across the lanes of the wave
   if (lane == 0) {
     st3(s_o + 16, hv_pos);  st4(s_o + 19, hv_rot);                                // GS:1304-1305
     st3(s_o + 23, ct_pos);  st4(s_o + 26, ct_rot);                                // GS:1307-1308
@@ -515,6 +517,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
       const int c = lane + r * SDX_WAVE;
       hist[r] = (c < 2 * SDX_OBS_FRAME) ? o[c] : 0.0f;
     }
+    __builtin_amdgcn_wave_barrier();   // every lane has read its part of the row before any lane overwrites it (no instruction: the wave runs in lockstep)
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
       const int c = lane + r * SDX_WAVE;
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
         const int c = lane + r * SDX_WAVE;
         hs[r] = (c < 2 * SDX_STATE_FRAME) ? s[c] : 0.0f;
       }
+      __builtin_amdgcn_wave_barrier();   // as for the observation row: all reads of the row precede its writes
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const int c = lane + r * SDX_WAVE;

@@ -15,6 +15,11 @@ _SRCS = [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "physics_driver.cp
 _DEPS = _SRCS + [os.path.abspath(__file__), os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(CSRC, "sdx_common.h"),
                  os.path.join(CSRC, "sdx_const_build.h"), os.path.join(ROOT, "include", "seqdex.h")]
 _lib = None
+# the whole simulator behind the C ABI of include/seqdex.h (sdx_capi + task + physics + camera sources) on the emulator
+_SIM_SO = os.path.join(HERE, "libsdx_emu_sim.so")
+_SIM_SRCS = [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "sim_driver.cpp")] + \
+            [os.path.join(CSRC, f) for f in ("sdx_capi.hip", "sdx_task.hip", "sdx_physics.hip", "sdx_camera.hip")]
+_sim_lib = None
 
 
 def build(force=False):
@@ -29,6 +34,47 @@ def build(force=False):
     # -Bsymbolic: the product library may already be loaded RTLD_GLOBAL in this process and exports the same sdxk_* names
     subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", _SO] + objs)
     return _SO
+
+
+def build_sim(force=False):
+    deps = _SIM_SRCS + [os.path.abspath(__file__), os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "seqdex.h")] + \
+        [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not force and os.path.exists(_SIM_SO) and all(os.path.getmtime(_SIM_SO) >= os.path.getmtime(d) for d in deps):
+        return _SIM_SO
+    objs = []
+    for src in _SIM_SRCS:
+        obj = os.path.join(HERE, os.path.basename(src) + ".emusim.o")
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-w", "-x", "c++",
+                               "-I", os.path.join(HERE, "include"), "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+        objs.append(obj)
+    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-o", _SIM_SO] + objs)
+    return _SIM_SO
+
+
+def sim_lib():
+    """ctypes handle of the emulated simulator library with the prototypes of seqdex_amd/_abi.py::load_library"""
+    global _sim_lib
+    if _sim_lib is None:
+        from seqdex_amd import _abi
+        lib_ = C.CDLL(build_sim())
+        vp, i64p, i32, i32p = C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)
+        lib_.sdx_create.argtypes = [C.POINTER(_abi.SceneDesc), i32, i32, C.c_uint64, C.POINTER(vp)]
+        lib_.sdx_destroy.argtypes = [vp]
+        lib_.sdx_tensor.argtypes = [vp, i32, C.POINTER(vp), i64p, i32p, i32p]
+        lib_.sdx_load_initial_states.argtypes = [vp, vp, i32]
+        lib_.sdx_set_tvalue_weights.argtypes = [vp, vp, i32]
+        lib_.sdx_set_retri_tvalue_weights.argtypes = [vp, vp, i32]
+        for n in ["sdx_step", "sdx_pre_physics"]:
+            getattr(lib_, n).argtypes = [vp, vp, vp]
+        for n in ["sdx_simulate", "sdx_post_physics", "sdx_compute_observations", "sdx_refresh_kinematics", "sdx_render_segmentation"]:
+            getattr(lib_, n).argtypes = [vp, vp]
+        lib_.sdx_reset_idx.argtypes = [vp, vp, vp, vp]
+        lib_.sdx_set_indexed.argtypes = [vp, i32, vp, vp, i32, vp]
+        lib_.sdx_num_envs.argtypes = [vp]
+        lib_.sdx_last_error.argtypes = [vp]
+        lib_.sdx_last_error.restype = C.c_char_p
+        _sim_lib = lib_
+    return _sim_lib
 
 
 def lib():

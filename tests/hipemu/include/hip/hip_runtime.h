@@ -41,6 +41,22 @@ enum { hipSuccess = 0 };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+// ---- the slice of the HIP runtime API the C-ABI layer (sdx_capi.hip, sdx_camera.hip) uses: "device" memory is host memory, streams
+// do not exist (every launch has completed when hipLaunchKernelGGL returns), there is exactly one device
+#include <stdlib.h>
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t = nullptr) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 
 namespace hipemu {
