@@ -123,3 +123,19 @@ def test_terminal_state_harvesting(scene):
 
 def test_segmentation_camera_matches_numpy_ray_caster(scene):
     GS.test_segmentation_camera_matches_numpy_ray_caster(scene)
+
+
+# ---------------------------------------------------------------- the full-size observation checks of the other three tasks (numpy oracle)
+def test_orient_1024_observations_against_oracle(scene):
+    import test_gpu_fullsize_tasks as GF
+    GF.test_orient_1024_observations_against_oracle(scene)
+
+
+def test_insert_2048_observations_against_oracle(scene):
+    import test_gpu_fullsize_tasks as GF
+    GF.test_insert_2048_observations_against_oracle(scene)
+
+
+def test_search_128_observations_against_oracle(scene):
+    import test_gpu_fullsize_tasks as GF
+    GF.test_search_128_observations_against_oracle(scene)
