@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDX_ABI_VERSION 6
+#define SDX_ABI_VERSION 7
 
 /* ---- fixed scene dimensions of BlockAssemblyGraspSim (GS:523-1058) ---- */
 #define SDX_NLINK 24        /* robot bodies after collapse_fixed_joints (GS:543); body 0 is the fixed base  */
@@ -113,9 +113,12 @@ typedef enum {
   SDX_T_TVALUE_OBS = 42,   /* f32 [N,652]       Search: t_value_obs_buf, ten 65-number frames (SE:375,1155-1166), newest last; columns 650, 651 are row
                             *                    padding (zeros).  Frame = obs_buf[:, 0:62] with [26:30] = camera-frame target quaternion, then the target's
                             *                    pixel centroid / 128 and pixel count / 100 */
-  SDX_T_CONTACT_STATS = 43, /* i32 [2]           since create: [0] the largest number of contact points one env generated in one substep, [1] the number
-                            *                    of env-steps in which an env exceeded the per-env capacity (1536) and lost the excess in enumeration
-                            *                    order.  [1] must stay 0 for results to mean anything; bench.py and the full-size tests check it */
+  SDX_T_CONTACT_STATS = 43, /* i32 [4]           since create, in env-SUBSTEPS: [0] the largest number of contact points one env generated in one substep;
+                            *                    [1] substeps in which an env still exceeded the per-env capacity (1536) after the rebuild of [2] and lost
+                            *                    the excess in enumeration order - must stay 0 for results to mean anything, bench.py and the full-size
+                            *                    tests check it; [2] substeps whose contact list was rebuilt without its speculative contacts (samples
+                            *                    that neither touch nor penetrate) because it would not fit; [3] substeps whose candidate pair list
+                            *                    exceeded its 1024 slots (the excess pairs were not tested) */
   SDX_T_WARM_COUNT = 44,   /* i32 [N]           contacts in each env's warm-start cache (scene.warm_start); the engine clears an
                             *                    env's entry when it resets the env; a caller that teleports bodies by hand may zero it too */
   SDX_T_COUNT = 45
@@ -184,6 +187,8 @@ typedef struct {
   float jacobi_relax;                  /* relaxation on the mass-split Jacobi update */
   float warm_start;                    /* every solve starts from this fraction of the impulses the same contacts
                                         * (pair, direction, sample) ended the previous solve with; 0 = start from zero */
+  float warm_age;                      /* the fraction ramps up linearly with the number of consecutive solves a contact has existed and
+                                        * reaches warm_start after warm_age of them (0: no ramp); DESIGN.md section 3.E */
   /* which task's per-step tensor code the pre/post-physics kernels run: 0 = BlockAssemblyGraspSim (GS),
    * 1 = BlockAssemblyOrient (OR = tasks/block_assembly/allegro_hand_block_assembly_orient.py; targets/IK OR:1720-1778),
    * 2 = BlockAssemblyInsertSim (IS; position action + fixed wrist orientation IS:1526-1572, 75-number observation IS:1280-1298,

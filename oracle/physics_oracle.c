@@ -115,7 +115,10 @@ typedef struct {
   int* wcount; unsigned* wkey; float* wlam; /* this env's impulse cache: count, keys [MAXC], impulses [3][MAXC] of the previous solve */
   real lam[SDXO_MAXC][3], w[SDXO_MAXC][2][3]; /* w[c][side][row]: un-split inverse effective mass */
   unsigned char active[SDXO_MAXC];
+  unsigned char cage[SDXO_MAXC]; /* warm start: consecutive solves each contact has existed before this one */
   int overflow;
+  real incl;           /* inclusion threshold of the current collide pass */
+  int rebuilt;         /* the last collide() had to drop the speculative contacts */
   int env_index;
   int seg_brick; /* this env's target brick: mass and inertia scaled by sc->seg_mass_scale */
 } env_t;
@@ -323,13 +326,14 @@ static int sample_class(const dir_t* D, v3 pb, v3 h, real offset) {
   return vdot(o, o) < offset * offset ? 2 : 0;
 }
 
-static int sample_dir(const box_t* A, const box_t* B, real offset, int idx[4]) {
+/* incl: samples closer than this are contacts - the contact offset, or 0 when the list is rebuilt after a capacity overflow (collide()) */
+static int sample_dir(const box_t* A, const box_t* B, real offset, real incl, int idx[4]) {
   int c1 = 0, c2 = 0, other[4];
   dir_t D = dir_setup(A, B, offset);
-  if (D.smax >= offset) return -1; /* separated: neither direction has a sample inside the offset */
+  if (D.smax >= incl) return -1; /* separated: neither direction has a sample inside the threshold */
   for (int s = 0; s < NSAMP && c1 < 4; ++s) {
     v3 pb = sample_point(&D, s);
-    int cls = sample_class(&D, pb, B->h, offset);
+    int cls = sample_class(&D, pb, B->h, incl);
     if (cls == 1) idx[c1++] = s;
     else if (cls == 2 && c2 < 4) other[c2++] = s;
   }
@@ -356,16 +360,17 @@ static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb,
  * static 128 + s) - with the direction bit and the sample index they identify a contact from one solve to the next */
 static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int idb, int bstatic, real offset, int boxa, int boxb) {
   int i1[4], i2[4];
-  int c1 = sample_dir(A, B, offset, i1);
+  const real incl = e->incl;
+  int c1 = sample_dir(A, B, offset, incl, i1);
   if (c1 < 0) return;
-  int c2 = bstatic ? 0 : sample_dir(B, A, offset, i2);
+  int c2 = bstatic ? 0 : sample_dir(B, A, offset, incl, i2);
   if (c2 < 0) return;
   int m2 = c2 < 2 ? c2 : 2;
   int k1 = c1 < 4 - m2 ? c1 : 4 - m2;
   int k2 = c2 < 4 - k1 ? c2 : 4 - k1;
-  unsigned pk = ((unsigned)boxa << 20) | ((unsigned)boxb << 12);
+  unsigned pk = ((unsigned)boxa << 14) | ((unsigned)boxb << 6); /* 22 bits with the direction bit and the 5-bit sample index; bits 24.. of a cached key hold the contact's age */
   emit_dir(e, A, B, ida, idb, i1, k1, offset, pk);
-  if (k2 > 0) emit_dir(e, B, A, idb, ida, i2, k2, offset, pk | 0x100u);
+  if (k2 > 0) emit_dir(e, B, A, idb, ida, i2, k2, offset, pk | 0x20u);
 }
 
 static real box_radius(v3 h) { return sqrtf(vdot(h, h)); }
@@ -380,9 +385,11 @@ static box_t static_box(const sdx_scene_desc* sc, int s, int env_index) {
   return S;
 }
 
-static void collide(const sdx_scene_desc* sc, env_t* e) {
+static void collide_pass(const sdx_scene_desc* sc, env_t* e, real incl) {
   const real off = sc->contact_offset;
   e->nc = 0;
+  e->overflow = 0;
+  e->incl = incl;
   box_t bb[NF];
   real br[NF];
   for (int i = 0; i < NF; ++i) {
@@ -426,6 +433,18 @@ static void collide(const sdx_scene_desc* sc, env_t* e) {
       if (box_sdf(vsub(R.c, S.c), S.h, &g) > rr0 + off) continue;
       collide_pair(e, &R, &S, NF + k, BODY_STATIC, 1, off, NF + r, 128 + s);
     }
+  }
+}
+
+/* D: the contact list of the substep.  Capacity rule: a list that would exceed SDXO_MAXC contacts is rebuilt
+ * without its speculative part - only samples that touch or penetrate (inclusion threshold 0 instead of the contact offset); what
+ * still does not fit is dropped in enumeration order and counted. */
+static void collide(const sdx_scene_desc* sc, env_t* e) {
+  collide_pass(sc, e, sc->contact_offset);
+  e->rebuilt = 0;
+  if (e->overflow > 0) {
+    collide_pass(sc, e, 0.0f);
+    e->rebuilt = 1;
   }
 }
 
@@ -536,6 +555,7 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
     }
   }
   for (int j = 0; j < ND; ++j) e->qd_star[j] = e->qd[j];
+  for (int c = 0; c < e->nc; ++c) e->cage[c] = 0;
   /* warm start: a contact that existed in the previous solve - same boxes, direction and sample - starts from
    * warm_start x the impulses it ended with (normal impulse <= 0: from zero); their effect on the velocities is applied before the
    * first iteration.  The cache is in contact order, which changes little from solve to solve: the search resumes where the last
@@ -546,25 +566,33 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
     for (int j = 0; j < ND; ++j) dQ[j] = 0;
     for (int i = 0; i < NF; ++i) e->dv[i] = e->dw[i] = V(0, 0, 0);
     int pos = 0;
+    const real inv_age = sc->warm_age > 0 ? 1.0f / sc->warm_age : 1e30f;
     for (int c = 0; c < e->nc; ++c) {
       int found = -1;
       for (int k = 0; k < nold; ++k) {
         int q = pos + k;
         if (q >= nold) q -= nold;
-        if (e->wkey[q] == e->ckey[c]) { found = q; break; }
+        if ((e->wkey[q] & 0xffffffu) == e->ckey[c]) { found = q; break; }
       }
       if (found < 0) continue;
       pos = found;
+      /* bits 24..31 of a cached key: the number of consecutive solves the contact had existed before that solve (saturating) */
+      unsigned age = (e->wkey[found] >> 24) + 1u;
+      if (age > 255u) age = 255u;
+      e->cage[c] = (unsigned char)age;
       if (e->csep[c] < -WARM_DEPTH * sc->contact_offset) continue; /* deep penetration is recovery, not rest: cold */
       {
         v3 vr = vsub(point_vel(e, e->ca[c], e->cp[c]), point_vel(e, e->cb[c], e->cp[c]));
         if (vdot(vr, vr) > WARM_SPEED * WARM_SPEED) continue; /* an impact or a sliding contact: last solve's impulse says nothing */
       }
-      real l0 = sc->warm_start * e->wlam[0 * SDXO_MAXC + found];
+      /* the cached impulse is trusted in proportion to the age of the contact: the full fraction after warm_age solves, nothing for
+       * a contact the previous solve saw for the first time (an impact) */
+      const real bq = sc->warm_start * fminf(1.0f, (real)age * inv_age);
+      real l0 = bq * e->wlam[0 * SDXO_MAXC + found];
       if (!(l0 > 0)) continue;
       e->lam[c][0] = l0;
-      e->lam[c][1] = sc->warm_start * e->wlam[1 * SDXO_MAXC + found];
-      e->lam[c][2] = sc->warm_start * e->wlam[2 * SDXO_MAXC + found];
+      e->lam[c][1] = bq * e->wlam[1 * SDXO_MAXC + found];
+      e->lam[c][2] = bq * e->wlam[2 * SDXO_MAXC + found];
       v3 t1, t2;
       tangents(e->cn[c], &t1, &t2);
       apply_impulse(sc, e, c, vadd(vadd(vscale(e->cn[c], e->lam[c][0]), vscale(t1, e->lam[c][1])), vscale(t2, e->lam[c][2])), dQ);
@@ -624,7 +652,7 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
   if (e->wcount && sc->warm_start > 0) { /* the cache for the next solve */
     *e->wcount = e->nc;
     for (int c = 0; c < e->nc; ++c) {
-      e->wkey[c] = e->ckey[c];
+      e->wkey[c] = e->ckey[c] | ((unsigned)e->cage[c] << 24);
       for (int r = 0; r < 3; ++r) e->wlam[r * SDXO_MAXC + c] = e->lam[c][r];
     }
   }

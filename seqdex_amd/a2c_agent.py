@@ -291,7 +291,14 @@ class A2CAgent:
                         self._mr_graph.replay()
                         done += self._mr_chunk
             steps(total - done)
-            ppo.update_status()
+            try:
+                ppo.update_status()
+            except Exception:
+                # an exchange-word timeout makes the library leave the persistent forward/backward launch for the multi-kernel one;
+                # the captured graph still holds the persistent launch, so it must not be replayed again: drop it (None = capture
+                # afresh, on the path the handle has switched to, the next time this method runs) and let the caller see the error
+                self._mr_graph = None
+                raise
             return
         ppo.backward(0, -1)
         if "ALL_GRADS" in ppo.t:

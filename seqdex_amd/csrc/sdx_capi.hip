@@ -157,10 +157,11 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(seg_image, scene->task_kind == 3 ? (size_t)N * 128 * 128 : 1);
   ALLOC(seg_pix, (size_t)N * 4);
   ALLOC(emergence, N);
-  ALLOC(cstats, 2);
+  ALLOC(cstats, 4);
   ALLOC(wcount, N);
-  ALLOC(wkey, (size_t)N * SDX_MAXC);
-  ALLOC(wlam, (size_t)N * 3 * SDX_MAXC);
+  // the solver's impulse cache (24.5 KB per env) only exists when the scene asks for the warm start; k_physics<.., false> never reads it
+  ALLOC(wkey, scene->warm_start > 0.0f ? (size_t)N * SDX_MAXC : 1);
+  ALLOC(wlam, scene->warm_start > 0.0f ? (size_t)N * 3 * SDX_MAXC : 1);
   if (scene->task_kind == 3) {
     ALLOC(tvt_buf, (size_t)N * 652);
     ALLOC(tvt_w, (size_t)1024 * 652 + 1024 + 512 * 1024 + 512 + 128 * 512 + 128 + 2 * 128 + 2);
@@ -209,7 +210,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   else set_tensor(h, SDX_T_SEG_IMAGE, B.seg_image, SDX_I16, {1, 1, 1});   // placeholder: the camera belongs to Search
   set_tensor(h, SDX_T_SEG_PIXELS, B.seg_pix, SDX_F32, {N, 4});
   set_tensor(h, SDX_T_EMERGENCE, B.emergence, SDX_F32, {N});
-  set_tensor(h, SDX_T_CONTACT_STATS, B.cstats, SDX_I32, {2});
+  set_tensor(h, SDX_T_CONTACT_STATS, B.cstats, SDX_I32, {4});
   set_tensor(h, SDX_T_WARM_COUNT, B.wcount, SDX_I32, {N});
   set_tensor(h, SDX_T_JACOBIAN, B.jac_full, SDX_F32, {N, SDX_NLINK - 1, 6, SDX_NDOF});
   if (scene->task_kind == 3) set_tensor(h, SDX_T_TVALUE_OBS, B.tvt_buf, SDX_F32, {N, 652});
@@ -456,7 +457,8 @@ extern "C" int sdx_refresh_kinematics(sdx_handle h, void* stream) {
   return check_launch(h, "sdx_refresh_kinematics");
 }
 // one thread per (listed actor, column)
-__global__ void k_set_indexed(SdxBuf B, int id, const float* __restrict__ src, const int32_t* __restrict__ ids, int n) {
+// src may BE the library's own tensor (the documented use: edit SDX_T_ROOT / SDX_T_DOF in place, then name the rows that changed): no __restrict__ on it
+__global__ void k_set_indexed(SdxBuf B, int id, const float* src, const int32_t* __restrict__ ids, int n) {
   const int i = blockIdx.x, t = threadIdx.x;
   if (i >= n) return;
   const int actor = ids[i];
@@ -467,6 +469,7 @@ __global__ void k_set_indexed(SdxBuf B, int id, const float* __restrict__ src, c
     const float v = src[(size_t)actor * 13 + t];
     B.root[(size_t)actor * 13 + t] = v;
     B.rb[((size_t)e * SDX_BODIES + SDX_NLINK + slot - 1) * 13 + t] = v;
+    if (t == 0) B.wcount[e] = 0;                            // a teleported body invalidates the env's cached contact impulses (warm start)
   } else if (slot == 0) {
     if (id == SDX_T_DOF) { if (t < SDX_NDOF * 2) B.dof[(size_t)e * SDX_NDOF * 2 + t] = src[(size_t)e * SDX_NDOF * 2 + t]; }
     else if (t < SDX_NDOF) B.targets[(size_t)e * SDX_NDOF + t] = src[(size_t)e * SDX_NDOF + t];

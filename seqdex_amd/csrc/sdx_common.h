@@ -58,7 +58,8 @@ struct SdxBuf {
   float *tv_succ, *tv_fail;   // [SDX_TV_LOG_SLOTS,4] camera-frame target quaternions logged at episode ends (T-value datasets)
   int32_t* tv_count;       // [2] rows logged: success, failure
   float* jac_full;         // [N,23,6,23] or nullptr: the whole-hand Jacobian (GS:241), written by k_kinematics only
-  int32_t* cstats;         // [2] largest contact count of one env-substep so far; env-steps that overflowed SDX_MAXC
+  int32_t* cstats;         // [4] since create: largest contact count of one env-substep; env-substeps that lost contacts (still over SDX_MAXC
+                           // after the rebuild); env-substeps whose list was rebuilt without speculative contacts; env-substeps whose pair list overflowed
   float* tvt_buf;          // Search: [N,652] temporal T-value input (ten 65-number frames, 2 padding columns) or nullptr
   float* tvt_w;            // Search: RetriGraspTValue parameters, W1 rows padded to 652 columns
   float* tvt_h;            // Search: activations [N, 1024 + 512 + 128 + 4]

@@ -74,7 +74,7 @@ struct PhysLds {
   int ecount[NF + NL];  // CSR build: contact sides per body
   float lwr[NL][6];     // per iteration: wrench (F, M about the link origin) the contacts apply to each link
   uint32_t desc[ND];    // bit k: link k lies below dof j
-  int nc, np, overflow, seg_brick;
+  int nc, np, overflow, seg_brick, rebuilt;
   int eoff[NF + NL + 1], efill[NF + NL];
   int wsum[16];
   // contacts: geometry in LDS for the whole solve
@@ -200,13 +200,14 @@ constexpr float kSamp[SDX_NSAMP][3] = {
 __device__ __forceinline__ f3 face_frame(f3 v, int kax) {   // component kax moves to z
   return kax == 0 ? F3(v.y, v.z, v.x) : kax == 1 ? F3(v.x, v.z, v.y) : v;
 }
-__device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off, uint32_t* packed) {
+// incl: samples closer than this are contacts - the contact offset, or 0 when the list is rebuilt after a capacity overflow (collide())
+__device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off, float incl, uint32_t* packed) {
   const Dir D = dir_setup(A, B, off);
   *packed = 0;
-  if (D.smax >= off) return -1;   // separated: neither direction has a sample inside the offset
+  if (D.smax >= incl) return -1;   // separated: neither direction has a sample inside the threshold
   const f3 t = face_frame(D.t, D.kax), ex = face_frame(D.ex, D.kax), ey = face_frame(D.ey, D.kax), ez = face_frame(D.ez, D.kax);
   const f3 h = face_frame(B.h, D.kax);
-  const float ftol = D.kax >= 0 ? FACE_TOL : -1e30f, off2 = off * off;
+  const float ftol = D.kax >= 0 ? FACE_TOL : -1e30f, off2 = incl * incl;
   uint32_t mface = 0, mother = 0;
 #pragma unroll
   for (int s = 0; s < SDX_NSAMP; ++s) {
@@ -217,7 +218,7 @@ __device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off,
     const float sdf = D.sgn * pb.z - h.z;
     const float ox = fmaxf(dx, 0.0f), oy = fmaxf(dy, 0.0f), oz = fmaxf(dz, 0.0f);
     const bool near = fmaxf(lat, dz) <= 0.0f || ox * ox + oy * oy + oz * oz < off2;
-    if (face ? sdf < off : false) mface |= 1u << s;
+    if (face ? sdf < incl : false) mface |= 1u << s;
     if (face ? false : near) mother |= 1u << s;
   }
   int c = 0;
@@ -585,6 +586,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       ++pos;
     }
   }
+  const int pairs_lost = np > MAXP;   // more candidate pairs than the list holds: the excess (lane-major order) is not tested
   if (np > MAXP) np = MAXP;
   __syncthreads();
   // ---- separating-axis pass: a pair that a face axis of either box separates by the whole contact offset cannot produce a contact
@@ -621,7 +623,14 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   }
   SSTAMP(33);
   // ---- narrowphase: lane = candidate pair; contacts appended in pair order (block prefix sum of the counts)
-  int nc = 0;
+  // Capacity rule (oracle: collide()): a list that would exceed MAXC contacts is rebuilt without its speculative
+  // part - only samples that touch or penetrate (inclusion threshold 0 instead of the contact offset); what still does not fit is
+  // dropped in enumeration order and counted.  The second pass is the same code in a run-time loop (block-uniform trip count).
+  int nc = 0, rebuilt = 0;
+  float incl = off;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+  nc = 0;
   for (int base = 0; base < np; base += NT) {
     const int pi = base + tid;
     int k1 = 0, k2 = 0, ida = 0, idb = 0;
@@ -635,8 +644,8 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       Bx = load_box(S, bb);
       ida = box_body(S, ba);
       idb = box_body(S, bb);
-      const int c1 = sample_dir(A, Bx, off, &p1);
-      const int c2 = (bb >= 128 || c1 < 0) ? 0 : sample_dir(Bx, A, off, &p2);
+      const int c1 = sample_dir(A, Bx, off, incl, &p1);
+      const int c2 = (bb >= 128 || c1 < 0) ? 0 : sample_dir(Bx, A, off, incl, &p2);
       if (c1 >= 0 && c2 >= 0) {
         const int m2 = c2 < 2 ? c2 : 2;
         k1 = c1 < 4 - m2 ? c1 : 4 - m2;
@@ -649,10 +658,15 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     if (k2 > 0) emit_dir(S, Bx, A, idb, ida, p2, k2, nc + pre + k1, off, (prank << 6) | 32u);
     nc += tot;
   }
+  if (nc <= MAXC || pass == 1) break;
+  incl = 0.0f;      // (the scans' barriers order this pass's LDS writes before the next pass's)
+  rebuilt = 1;
+  }
   if (tid == 0) {
     S.overflow = nc > MAXC ? nc - MAXC : 0;
     S.nc = nc > MAXC ? MAXC : nc;
     S.np = np;
+    S.rebuilt = rebuilt | (pairs_lost << 1);
   }
   __syncthreads();
 }
@@ -704,6 +718,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   float vtgt[CPT];
   uint32_t ckey[CPT];
   const float beta = sc.warm_start;
+  const float inv_age = sc.warm_age > 0.0f ? 1.0f / sc.warm_age : 1e30f;
   // depth gate expressed on the velocity target the lane keeps anyway: sep < -WARM_DEPTH * offset <=> vtgt > baumgarte * depth / h
   const float wdeep = sc.baumgarte * (WARM_DEPTH * sc.contact_offset) / h;
   int nold = WARM ? *wcount : 0;   // block-uniform
@@ -733,26 +748,31 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   // impulses themselves are fetched where the lam registers are born.  The new keys replace the old ones in HBM right away (the
   // old ones are in LDS now; the old impulses stay untouched until the end of this solve).
   uint64_t wmatch = ~0ull;
+  uint32_t wage = 0;   // 8 bits per contact: consecutive solves it has existed (0: new in this solve)
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
     if (WARM && c < nc) {
       const uint32_t key = ckey[q];
+      uint32_t age = 0;
       if (nold > 0) {
         int lo = 0, hi = nold;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
-          if (((uint32_t)__float_as_int(S.P[2][mid]) >> 6) < (key >> 6)) lo = mid + 1; else hi = mid;
+          if ((((uint32_t)__float_as_int(S.P[2][mid]) & 0xffffffu) >> 6) < (key >> 6)) lo = mid + 1; else hi = mid;
         }
         int found = 0x7ff;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = lo + u;
-          if (i < nold && (uint32_t)__float_as_int(S.P[2][i]) == key) found = i;
+          const uint32_t ok = i < nold ? (uint32_t)__float_as_int(S.P[2][i]) : 0xffffffffu;
+          if ((ok & 0xffffffu) == key) { found = i; age = (ok >> 24) + 1u; }
         }
         wmatch = (wmatch & ~(0x7ffull << (11 * q))) | ((uint64_t)found << (11 * q));
       }
-      wkey[c] = key;
+      if (age > 255u) age = 255u;
+      wage |= age << (8 * q);
+      wkey[c] = key | (age << 24);   // bits 24..31: the number of consecutive solves this contact has existed before (saturating)
     }
   }
 #pragma unroll
@@ -852,9 +872,12 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     const int wm = (int)((wmatch >> (11 * q)) & 0x7ffull);
     if (WARM && on && wm != 0x7ff && vtgt[q] <= wdeep) {
       const f3 vrel = point_vel(S, a, p) - point_vel(S, b, p);
-      const float l0 = beta * wlam[wm];
+      // the cached impulse is trusted in proportion to the age of the contact: a contact that has existed for warm_age solves starts
+      // from the full fraction, a contact the previous solve saw for the first time (an impact) from nothing
+      const float bq = beta * fminf(1.0f, (float)((wage >> (8 * q)) & 0xffu) * inv_age);
+      const float l0 = bq * wlam[wm];
       if (l0 > 0.0f && dot(vrel, vrel) <= WARM_SPEED * WARM_SPEED) {
-        lam[q][0] = l0; lam[q][1] = beta * wlam[MAXC + wm]; lam[q][2] = beta * wlam[2 * MAXC + wm];
+        lam[q][0] = l0; lam[q][1] = bq * wlam[MAXC + wm]; lam[q][2] = bq * wlam[2 * MAXC + wm];
       }
     }
   }
@@ -1246,6 +1269,8 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     if (tl == 0 && B.cstats) {   // capacity statistics of this substep (integer atomics: order-independent)
       atomicMax(&B.cstats[0], S.nc + S.overflow);
       if (S.overflow) atomicAdd(&B.cstats[1], 1);
+      if (S.rebuilt & 1) atomicAdd(&B.cstats[2], 1);
+      if (S.rebuilt & 2) atomicAdd(&B.cstats[3], 1);
     }
     PSTAMP(4);
     if (scl.warm_start > 0.0f)

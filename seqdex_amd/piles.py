@@ -35,7 +35,7 @@ def generate_piles(per_type=8, steps=150, device="cuda:0", seed=22):
         torch.cuda.synchronize()
         piles = sim.ROOT.view(n, 142, 13)[:, 9:141].clone()
         piles[:, :, 7:13] = 0.0
-        # a brick in a few thousand bounces out of the bin on the way down (tools/drop_test.py: 48 of 73 728); a pile that lost one is
+        # a brick in a few thousand bounces out of the bin on the way down (tools/drop_bricks.py: 48 of 73 728); a pile that lost one is
         # replaced by a copy of the next complete pile, so that every saved state has its 72 free bricks over the bin (a few still lie on the parked hand:
         # they drop into the pile when a reset moves the hand away)
         fb = piles[:, :72, 0:3]

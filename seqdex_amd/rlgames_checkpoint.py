@@ -110,8 +110,13 @@ def flat_from_rlgames(model, vf, obs_dim, state_dim, act_dim=23, units=(1024, 51
         pre = mean_keys[0][:-len("running_mean")]
         cols = state_cols or state_dim
         mean, var = torch.zeros(state_dim, dtype=torch.float64), torch.ones(state_dim, dtype=torch.float64)
-        mean[:cols] = torch.as_tensor(vf[pre + "running_mean"]).double().reshape(-1)[:cols]
-        var[:cols] = torch.as_tensor(vf[pre + "running_var"]).double().reshape(-1)[:cols]
+        rm = torch.as_tensor(vf[pre + "running_mean"]).double().reshape(-1)
+        rv = torch.as_tensor(vf[pre + "running_var"]).double().reshape(-1)
+        if rm.numel() < cols or rv.numel() != rm.numel():
+            raise ValueError("checkpoint running_mean_std has %d / %d entries, the central value network reads %d state columns"
+                             % (rm.numel(), rv.numel(), cols))
+        mean[:cols] = rm[:cols]
+        var[:cols] = rv[:cols]
         cnt = float(torch.as_tensor(vf[pre + "count"])) if (pre + "count") in vf else 0.0
         rms = (mean, var, cnt)
     return ac, cv, rms

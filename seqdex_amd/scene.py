@@ -48,7 +48,8 @@ class Scene:
         self.sim = dict(raw["sim"])
         # solver constants of our own physics definition
         self.solver = dict(friction=1.0, baumgarte=0.2, max_depenetration_vel=1.0, jacobi_relax=1.0, armature=0.0,
-                           warm_start=float(os.environ.get("SDX_WARM_START", "0")))   # experimental, off by default
+                           warm_start=float(os.environ.get("SDX_WARM_START", "0.8")),   # the default since round 3
+                           warm_age=float(os.environ.get("SDX_WARM_AGE", "16")))
 
     # ------------------------------------------------------------------ helpers used by tests / task
     def seg_index(self, env_i):
@@ -122,7 +123,7 @@ class Scene:
         d.gravity[:] = self.sim["gravity"]
         d.friction, d.baumgarte = self.solver["friction"], self.solver["baumgarte"]
         d.max_depenetration_vel, d.jacobi_relax = self.solver["max_depenetration_vel"], self.solver["jacobi_relax"]
-        d.warm_start = self.solver["warm_start"]
+        d.warm_start, d.warm_age = self.solver["warm_start"], self.solver["warm_age"]
         d.task_kind = 0                                   # BlockAssemblyGraspSim; 1 = BlockAssemblyOrient (per-step tensor code only)
         d.target_euler[:] = [0.0, 3.1415, 1.571]          # OR:477
         d.seg_mass_scale = 1.0                            # GS:980-981 (x1); Orient x50 (OR:977)

@@ -64,6 +64,23 @@ def test_emulated_physics_step_matches_oracle(state, scene, warm_start):
         root, dof = o_root, o_dof
 
 
+def test_emulated_capacity_rule_matches_oracle(state, scene):
+    """DESIGN.md section 3.D, capacity rule: with a contact offset of 1.4 cm the settled piles would need more than SDX_MAXC = 1536
+    contacts per env; both the kernel source and the oracle then rebuild the list from the samples that touch or penetrate only
+    (inclusion threshold 0), arrive at the same, much smaller, count and take the same step."""
+    desc = scene.to_desc(contact_offset=0.014, warm_start=0.0)
+    root, dof, tg = state["root"][:4].copy(), state["dof"][:4].copy(), state["targets"][:4].copy()
+    g_root, g_dof = root.copy(), dof.copy()
+    _, _, _, g_nc = hipemu.simulate(desc, g_root, g_dof, tg)
+    o_root, o_dof = root.copy(), dof.copy()
+    _, _, _, o_nc = po.simulate(desc, o_root, o_dof, tg)
+    np.testing.assert_array_equal(g_nc, o_nc)
+    plain = np.array([po.contacts(scene.to_desc(contact_offset=0.006), root[e], dof[e])[1] for e in range(4)])
+    assert (o_nc[1:] < plain[1:]).all() and (o_nc[1:] < 1000).all()        # envs 1..3 were rebuilt: fewer contacts than at a 6 mm offset
+    dp = np.abs(g_root[:, 9:81, :7] - o_root[:, 9:81, :7])
+    assert dp.max() < 1e-4 and (dp > 2e-5).mean() < 5e-3, (dp.max(), (dp > 2e-5).mean())
+
+
 def test_emulated_stack_contacts_match_oracle(scene):
     """flush and offset stacks (face manifold of DESIGN.md section 3.D, exact ties in the separating-axis choice): the landing steps of
     the kernel source and of the oracle agree contact by contact (same counts, same brick states)."""

@@ -70,7 +70,7 @@ def test_insert_sim_scene_desc_places_three_plate_variants(scene):
     """BlockAssemblyInsertSim (task_kind 2): plate actor at (0.25, -0.2, 0.618) (IS:1438-1440), static box 7 = stud-less plate body
     whose z extent depends on env % 3 (4x4x{1,2,4}, IS:971-977); a seated brick's origin is exactly at the insertion site."""
     d = scene.to_desc(task_kind=2)
-    assert d.abi_version == 6 and d.static_var_slot == 7 and d.n_static == 8
+    assert d.abi_version == __import__("seqdex_amd._abi", fromlist=["x"]).SDX_ABI_VERSION and d.static_var_slot == 7 and d.n_static == 8
     np.testing.assert_allclose(list(d.base_plate_pos), [0.25, -0.2, 0.618], atol=1e-7)
     np.testing.assert_allclose(list(d.static_center[7])[:2], [0.25, -0.2], atol=1e-7)
     assert abs(d.static_half[7][0] - (0.06 + scene.INSERT_PLATE_MARGIN)) < 1e-6

@@ -1,6 +1,6 @@
 """Search-style reset at scale: 72 bricks per env dropped from the spawn lattice (+-2 cm noise) into the bin, N envs, `steps` simulate()
 calls; counts the bricks that end outside the bin and the state of the settled piles, for the cold solver and for the optional warm
-start.   python tools/drop_test.py [N] [steps] [warm_start ...]"""
+start.   python tools/drop_bricks.py [N] [steps] [warm_start[:jacobi_relax[:key=value,...]] ...]"""
 import json
 import sys
 
@@ -12,9 +12,18 @@ from seqdex_amd.sim import SdxSim  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-betas = [float(x) for x in sys.argv[3:]] or [0.0, 0.8]
-for beta in betas:
-    s = SdxSim(n, warm_start=beta)
+variants = sys.argv[3:] or ["0.0", "0.8"]
+for var in variants:
+    parts = var.split(":")
+    beta = float(parts[0])
+    over = {"warm_start": beta}
+    if len(parts) > 1 and parts[1]:
+        over["jacobi_relax"] = float(parts[1])
+    if len(parts) > 2:
+        for kv in parts[2].split(","):
+            k_, v_ = kv.split("=")
+            over[k_] = float(v_)
+    s = SdxSim(n, **over)
     sc = s.scene
     g = torch.Generator().manual_seed(5)
     root = s.ROOT.view(n, 142, 13)
@@ -35,7 +44,7 @@ for beta in betas:
     r = s.ROOT.view(n, 142, 13)[:, 9:81].cpu().numpy()
     out = (np.abs(r[:, :, 0] - 0.25) > 0.3) | (np.abs(r[:, :, 1] - 0.19) > 0.21) | (r[:, :, 2] < 0.55)
     inside = ~out
-    print(json.dumps({"warm_start": beta, "n_envs": n, "steps": steps, "bricks": int(n * 72), "escaped": int(out.sum()),
+    print(json.dumps({"variant": var, "warm_start": beta, "n_envs": n, "steps": steps, "bricks": int(n * 72), "escaped": int(out.sum()),
                       "envs_with_escapes": int(out.any(1).sum()), "mean_v2_at": ke,
                       "settled_mean_speed": float(np.linalg.norm(r[:, :, 7:10], axis=-1)[inside].mean()),
                       "lowest_brick_origin_z": float(r[:, :, 2][inside].min()),
