@@ -599,8 +599,19 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
     }
     apply_deltas(sc, e, dQ);
   }
+  /* Mass splitting: a row's inverse effective mass is n_A w_A + n_B w_B, n_X = the number of contacts that were
+   * ACTIVE on body X in the PREVIOUS iteration (at least 1); the first iteration splits over every contact of the body.  (Rounds 1-2
+   * counted the active set of the same iteration, which costs the kernel a workgroup barrier between counting and updating; stacks,
+   * piles and the drop test behave the same with the lagged count.) */
+  int nb_prev[NF], nr_prev = 0;
+  for (int i = 0; i < NF; ++i) nb_prev[i] = 0;
+  for (int c = 0; c < e->nc; ++c) {
+    int a = e->ca[c], b = e->cb[c];
+    if (a < NF) nb_prev[a]++; else if (a != BODY_STATIC) nr_prev++;
+    if (b < NF) nb_prev[b]++; else if (b != BODY_STATIC) nr_prev++;
+  }
   for (int it = 0; it < sc->solver_iters; ++it) {
-    /* pass 1: active set and per-body active-contact counts (mass splitting over ACTIVE contacts only) */
+    /* pass 1: active set and per-body active-contact counts (they split the masses of the NEXT iteration) */
     for (int i = 0; i < NF; ++i) e->bcount[i] = 0;
     e->rcount = 0;
     for (int c = 0; c < e->nc; ++c) {
@@ -624,8 +635,9 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
       int a = e->ca[c], b = e->cb[c];
       v3 p = e->cp[c], n = e->cn[c], t1, t2;
       tangents(n, &t1, &t2);
-      real na = a == BODY_STATIC ? 0.0f : (a < NF ? (real)e->bcount[a] : (real)e->rcount);
-      real nb = b == BODY_STATIC ? 0.0f : (b < NF ? (real)e->bcount[b] : (real)e->rcount);
+      int ia = a == BODY_STATIC ? 0 : (a < NF ? nb_prev[a] : nr_prev), ib = b == BODY_STATIC ? 0 : (b < NF ? nb_prev[b] : nr_prev);
+      real na = a == BODY_STATIC ? 0.0f : (real)(ia > 1 ? ia : 1);
+      real nb = b == BODY_STATIC ? 0.0f : (real)(ib > 1 ? ib : 1);
       v3 vr = vsub(point_vel(e, a, p), point_vel(e, b, p));
       real sep = e->csep[c];
       real target = sep > 0 ? -sep / h : fminf(sc->baumgarte * (-sep) / h, sc->max_depenetration_vel);
@@ -648,6 +660,8 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
       apply_impulse(sc, e, c, vadd(vadd(vscale(n, dl[0]), vscale(t1, dl[1])), vscale(t2, dl[2])), dQ); /* impulse on A; -P on B */
     }
     apply_deltas(sc, e, dQ);
+    for (int i = 0; i < NF; ++i) nb_prev[i] = e->bcount[i];
+    nr_prev = e->rcount;
   }
   if (e->wcount && sc->warm_start > 0) { /* the cache for the next solve */
     *e->wcount = e->nc;

@@ -143,6 +143,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(stat, 4);
   ALLOC(step_count, 1);
   ALLOC(dbg, 64);
+  { const char* de = getenv("SDX_DEBUG_ENV"); B.dbg_env = de ? atoi(de) : 0; }
   ALLOC(harvest_hand, (size_t)8 * SDX_HARVEST_SLOTS * SDX_NDOF * 2);
   ALLOC(harvest_obj, (size_t)8 * SDX_HARVEST_SLOTS * 13);
   ALLOC(harvest_count, 8);
@@ -158,6 +159,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(seg_pix, (size_t)N * 4);
   ALLOC(emergence, N);
   ALLOC(cstats, 4);
+  ALLOC(order, N);
+  ALLOC(cost, N);
+  { std::vector<int32_t> iota((size_t)N); for (int i = 0; i < N; ++i) iota[i] = i; HIPCHK(h, hipMemcpy(B.order, iota.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice)); }
   ALLOC(wcount, N);
   // the solver's impulse cache (24.5 KB per env) only exists when the scene asks for the warm start; k_physics<.., false> never reads it
   ALLOC(wkey, scene->warm_start > 0.0f ? (size_t)N * SDX_MAXC : 1);

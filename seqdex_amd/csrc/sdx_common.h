@@ -45,7 +45,9 @@ struct SdxBuf {
   float* cscratch;         // [N, SDX_CFIELDS, SDX_MAXC]
   float* stat;             // [2][2] double-buffered (num_resets, finished successes) for cons_successes
   uint32_t* step_count;    // device counter, incremented by the post-physics kernel
-  long long* dbg;          // [64] phase time stamps of env 0 (profiling aid)
+  long long* dbg;          // [64] phase time stamps of env dbg_env (profiling aid)
+  int32_t dbg_env;         // SDX_DEBUG_ENV at sdx_create (default 0)
+  int32_t *order, *cost;   // [N] k_physics launch order (envs by the cost of their previous step, longest first) / that cost; nullptr: env order
   float *harvest_hand, *harvest_obj;   // [8, SDX_HARVEST_SLOTS, 23*2] / [8, SDX_HARVEST_SLOTS, 13]
   int32_t* harvest_count;  // [8]
   int32_t* seg_stats;      // [N,4] Search camera: accumulators (count, sum rows, sum cols)
@@ -134,6 +136,9 @@ __device__ __forceinline__ f4 qaxis(f3 ax, float ang) {
   f4 r = {ax.x * s, ax.y * s, ax.z * s, c};
   return r;
 }
+// a 16-byte aligned row read with ONE 128-bit access (ds_read_b128 for LDS rows)
+struct __attribute__((aligned(16))) f4v { float x, y, z, w; };
+__device__ __forceinline__ f3 ld3v(const float* p) { const f4v r = *reinterpret_cast<const f4v*>(p); return F3(r.x, r.y, r.z); }
 __device__ __forceinline__ f3 ld3(const float* p) { return F3(p[0], p[1], p[2]); }
 __device__ __forceinline__ f4 ld4(const float* p) { f4 r = {p[0], p[1], p[2], p[3]}; return r; }
 __device__ __forceinline__ void st3(float* p, f3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_physics timing on one MI355X: average launch time at N envs (HIP events) and the phase clock of env 0 (SDX_T_DEBUG stamps).
-usage: [SDX_PHYS_NT=384|512] python tools/time_physics.py [N] [warm-steps]"""
+usage: python tools/time_physics.py [N] [warm-steps]"""
 import json
 import os
 import sys
@@ -35,11 +35,15 @@ ms = e0.elapsed_time(e1) / reps
 d = s.DEBUG.cpu().numpy().astype("int64")
 nc = s.NCONTACTS.cpu().numpy()
 ph = {"fk+inertia": d[1] - d[0], "mass_matrix": d[2] - d[1], "drive": d[3] - d[2], "collide": d[4] - d[3], "solve": d[5] - d[4],
-      "integrate": d[6] - d[5], "solve_setup": d[17] - d[16], "it_A": d[19] - d[18], "it_C": d[20] - d[19],
+      "integrate": d[6] - d[5], "solve_setup": d[17] - d[16], "it_AC": d[20] - d[18],
       "setup_load": d[23] - d[16], "setup_count": d[24] - d[23], "setup_prefix": d[25] - d[24], "setup_fill": d[26] - d[25],
-      "setup_rank": d[27] - d[26], "setup_brickw": d[28] - d[27], "setup_robotw": d[29] - d[28], "setup_fetch": d[30] - d[29],
+      "setup_rank": d[27] - d[26], "setup_link_inertia": d[29] - d[28], "setup_weights": d[30] - d[29],
       "setup_tail": d[17] - d[30], "broad_mask": d[32] - d[3], "broad_scan": d[33] - d[32], "narrow": d[4] - d[33],
       "it_D": (d[21] if d[21] > d[20] else d[22]) - d[20], "it_robot": (d[22] - d[21]) if d[21] > d[20] else 0, "it_total": d[22] - d[18]}
-print(json.dumps({"solver_iters": int(os.environ.get("SDX_TP_ITERS", 16)), "threads_per_env": int(s.lib.sdxk_physics_threads()), "n_envs": n, "k_physics_ms": ms,
+cf = s.CONTACT.view(n, 165, 3)[:, :24].abs().sum(dim=(1, 2)).cpu().numpy()
+denv = int(os.environ.get("SDX_DEBUG_ENV", "0"))
+print(json.dumps({"debug_env": denv, "debug_env_contacts": int(nc[denv]), "debug_env_has_robot_contact": bool(cf[denv] > 0),
+                  "envs_with_robot_contact": int((cf > 0).sum()), "first_robot_contact_envs": [int(i) for i in (cf > 0).nonzero()[0][:6]],
+                  "solver_iters": int(os.environ.get("SDX_TP_ITERS", 16)), "threads_per_env": int(s.lib.sdxk_physics_threads()), "n_envs": n, "k_physics_ms": ms,
                   "env_steps_per_s": n / (ms * 1e-3), "contacts_mean": float(nc.mean()), "contacts_max": int(nc.max()),
                   "phase_cycles_env0_substep0": {k: int(v) for k, v in ph.items()}}))
