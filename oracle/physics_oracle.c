@@ -449,12 +449,14 @@ static void collide(const sdx_scene_desc* sc, env_t* e) {
 }
 
 /* ---------------------------------------------------------------- E: solver */
+/* orthonormal tangents of a unit normal (Duff et al. 2017: no square root, no branch on the direction); a vertical normal gives the
+ * world's x and y axes */
 static void tangents(v3 n, v3* t1, v3* t2) {
-  v3 a = fabsf(n.x) < 0.57735f ? V(1, 0, 0) : V(0, 1, 0);
-  v3 t = vcross(n, a);
-  t = vscale(t, 1.0f / sqrtf(vdot(t, t)));
-  *t1 = t;
-  *t2 = vcross(n, t);
+  real sg = n.z < 0.0f ? -1.0f : 1.0f;
+  real a = -1.0f / (sg + n.z);
+  real b = n.x * n.y * a;
+  *t1 = V(1.0f + sg * n.x * n.x * a, sg * b, -sg * n.x);
+  *t2 = V(b, sg + n.y * n.y * a, -n.y);
 }
 
 /* velocity of body `id` at world point p */

@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libseqdex_hip.so")
+LIB_PATH = os.environ.get("SDX_LIB_PATH") or os.path.join(HERE, "lib", "libseqdex_hip.so")   # SDX_LIB_PATH: an experimental build of the same library (kernel A/B timing)
 
 SDX_ABI_VERSION = 7
 NLINK, NDOF, MAX_RBOX, NBRICK, NFREE, NBRICK_TYPES, MAX_STATIC = 24, 23, 32, 132, 72, 8, 8

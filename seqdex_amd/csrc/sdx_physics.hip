@@ -51,7 +51,7 @@ __constant__ float c_samp[SDX_NSAMP][3] = {
 
 struct PhysLds {
   // robot
-  float q[ND], qd[ND + 1], tgt[ND], qds[ND], tau[ND];   // qd[ND] = 0: the padding dof of exhausted paths
+  float q[ND], qd[ND + 1], qdb[ND + 1], tgt[ND], tau[ND];   // qd[ND] = 0: the padding dof of exhausted paths; qdb: the solver's second copy (read one, write the other)
   float lq[NL][4], la[NL + 1][3], lc[NL][3], lI[NL][6];
   float lal[NL + 1][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
   float A[ND][HP];      // H -> L -> Hinv
@@ -124,12 +124,15 @@ __device__ __forceinline__ float box_sdf_val(f3 p, f3 h) {
   return sqrtf(dot(o, o));
 }
 
+// orthonormal tangents of a unit normal without a square root or a branch (Duff et al. 2017); n = (0, 0, +-1) gives t1 = (+-1, 0, 0)... the
+// friction pyramid's axes are the world's x and y for a vertical normal.  Recomputed in every solver iteration (12 instructions; the round-2
+// construction - cross product with the least-aligned axis, normalised - cost 40).  oracle: tangents()
 __device__ __forceinline__ void tangents(f3 n, f3* t1, f3* t2) {
-  f3 a = fabsf(n.x) < 0.57735f ? F3(1, 0, 0) : F3(0, 1, 0);
-  f3 t = cross(n, a);
-  t = t * (1.0f / sqrtf(dot(t, t)));
-  *t1 = t;
-  *t2 = cross(n, t);
+  const float sg = n.z < 0.0f ? -1.0f : 1.0f;
+  const float a = -1.0f / (sg + n.z);
+  const float b = n.x * n.y * a;
+  *t1 = F3(1.0f + sg * n.x * n.x * a, sg * b, -sg * n.x);
+  *t2 = F3(b, sg + n.y * n.y * a, -n.y);
 }
 
 // box id: 0..71 brick, 72..103 robot box, 128.. static
@@ -426,7 +429,7 @@ __device__ __forceinline__ void tri_index(int idx, int* i, int* j) {   // idx ->
 
 // ---------------------------------------------------------------- B: H = M + implicit PD terms, Hinv (once per step)
 template <int NT>
-__device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h) {
+__device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h, long long* dbg) {
   const sdx_scene_desc& sc = C->sc;
   for (int idx = tid; idx < ND * (ND + 1) / 2; idx += NT) {
     int i, j;
@@ -450,34 +453,42 @@ __device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int t
     S.A[j][i] = s;
   }
   __syncthreads();
+  SSTAMP(34);
   if (tid < 64) {
-    // left-looking Cholesky on wave 0, lane = row; column j is final before any lane reads it in the next step
+    // Cholesky on wave 0 with the matrix in registers: lane i holds row i of H; right-looking - column j is scaled, then every lane
+    // subtracts l_ij l_kj from its entries k > j, with l_kj read from lane k (v_readlane: wave-uniform, no LDS, no hand-off).  The
+    // upper triangle carries don't-care values; lanes >= ND carry zeros.  (The left-looking LDS version took 35 k of the 58 k cycles of
+    // this phase: 23 dependent columns with a wave-synchronous hand-off each.)
+    float a[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) a[k] = tid < ND ? S.A[tid][k] : 0.0f;
+#pragma unroll
     for (int j = 0; j < ND; ++j) {
-      float s = 0.0f;
-      if (tid >= j && tid < ND) {
-        s = S.A[tid][j];
-        for (int k = 0; k < j; ++k) s -= S.A[tid][k] * S.A[j][k];
-      }
-      const float d = sqrtf(__shfl(s, j, 64));
-      if (tid >= j && tid < ND) S.A[tid][j] = (tid == j) ? d : s / d;
-      WAVE_SYNC();
+      const float d = sqrtf(SDX_READLANE(a[j], j));
+      const float lij = tid == j ? d : a[j] / d;
+      a[j] = lij;
+#pragma unroll
+      for (int k = j + 1; k < ND; ++k) a[k] -= lij * SDX_READLANE(lij, k);
     }
-    // T = L^-1, lane = column c, the column in registers: t[i] = ([i == c] - sum_{k < i} L[i][k] t[k]) / L[i][i], t[k] = 0 above the diagonal
+    SSTAMP(35);
+    // T = L^-1, lane = column c: t[i] = ([i == c] - sum_{k < i} L[i][k] t[k]) / L[i][i], t[k] = 0 above the diagonal; L[i][k] from lane i
+    const int c = tid;
+    float t[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      float sacc = (i == c) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < i; ++k) sacc -= SDX_READLANE(a[k], i) * t[k];
+      const float lii = SDX_READLANE(a[i], i);
+      t[i] = i >= c ? sacc / lii : 0.0f;
+    }
     if (tid < ND) {
-      const int c = tid;
-      float t[ND];
-#pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        float s = (i == c) ? 1.0f : 0.0f;
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= S.A[i][k] * t[k];
-        t[i] = i >= c ? s / S.A[i][i] : 0.0f;
-      }
 #pragma unroll
       for (int i = 0; i < ND; ++i) S_T(S)[i][c] = t[i];
     }
   }
   __syncthreads();
+  SSTAMP(36);
   // Hinv = T^T T
   for (int idx = tid; idx < ND * (ND + 1) / 2; idx += NT) {
     int i, j;
@@ -833,7 +844,6 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       S.ent[o + rank] = v;
     }
   }
-  if (tid < ND) S.qds[tid] = S.qd[tid];
   __syncthreads();   // rank pass complete (ent final); the fill list in the P rows is dead from here on
   SSTAMP(27);
   SSTAMP(28);
@@ -957,6 +967,10 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   // gather lanes: LL = 8 per link first (tid = 8 * link + sub: the same lanes run the robot section), then GL = 4 per brick; lane sub sums
   // entries sub, sub + stride, ... of its body's list
   constexpr int LL = 8;
+#ifndef SDX_GU
+#define SDX_GU 4
+#endif
+  constexpr int GU = SDX_GU;   // entries per lane and trip of the gather
   static_assert(NF * GL + NL * LL <= NT, "gather lanes");
   const bool llane = tid < NL * LL;
   const int gbody = llane ? NF + tid / LL : (tid - NL * LL) / GL, gsub = llane ? tid % LL : (tid - NL * LL) % GL;
@@ -1001,7 +1015,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   __syncthreads();   // every lane has read what it needs of v / w in the body table (warm-start gate above)
   // body table -> (u, w): u = v - w x x.  Link rows too (their twists are those of the drive phase until the robot section rewrites them)
   for (int i = tid; i < NBODY; i += NT) st3(S.bv[i], ld3(S.bv[i]) - cross(ld3(S.bw[i]), ld3(S.bp[i])));
-  float Qacc[3] = {0.0f, 0.0f, 0.0f};   // robot lanes: accumulated generalised contact impulse of dofs rs, rs + 8, rs + 16 (every 8-lane group keeps the same copy)
+  int qpar = 0;   // robot section: joint velocities are read from S.qd (0) / S.qdb (1) and written to the other
   __syncthreads();
   SSTAMP(17);
 
@@ -1077,9 +1091,9 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       // four entries per trip (the index loads, then the payloads, in flight together); not unrolled further: the decoded
       // addresses of a longer window would be kept in registers across the whole iteration loop
 #pragma unroll 1
-      for (int i = gbeg; i < gend; i += 4 * gstride) {
+      for (int i = gbeg; i < gend; i += GU * gstride) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GU; ++u) {
           const int iu = i + u * gstride;
           const bool on = iu < gend;
           const int e = S.ent[on ? iu : i], c = e & 0x7fff;
@@ -1116,8 +1130,8 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     }
     if (has_robot) {
       // robot section, ONE stage on 8 lanes per link: every group sums the generalised impulses of all 23 dofs from the Qc rows of the
-      // touched links below each dof (3 dofs per lane; the running sums live in registers, every group holds the same copy), shares them
-      // inside the group through LDS (wave-synchronous), then qd = qd* + Hinv Q for the (<= 2) path dofs of this lane and the link's twist
+      // touched links below each dof (3 dofs per lane), shares them inside the group through LDS (wave-synchronous), then
+      // qd += Hinv dQ for the (<= 2) path dofs of this lane and the link's twist
       __syncthreads();
       SSTAMP(21);
       int tr = tid;
@@ -1129,15 +1143,22 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         for (int u = 0; u < 3; ++u) {
           const int j = rs + 8 * u;
           if (j < ND) {
+            // the position of dof j in the path of a link below it = the number of dofs above j: the same for every such link
+            const int slot = __popc(S.anc[j + 1] & ((1u << j) - 1u));
             uint32_t m = S.desc[j] & touched;
             float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {          // (independent loads: in flight together)
+              const int k = m ? __ffs(m) - 1 : 0;
+              acc += m ? S.Qc[k][slot] : 0.0f;
+              m &= m - 1;
+            }
             while (m) {
               const int k = __ffs(m) - 1;
               m &= m - 1;
-              acc += S.Qc[k][__popc(S.anc[k] & ((1u << j) - 1u))];
+              acc += S.Qc[k][slot];
             }
-            Qacc[u] += acc;
-            Qg[j] = Qacc[u];
+            Qg[j] = acc;
           }
         }
         WAVE_SYNC();
@@ -1146,10 +1167,12 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         float q0 = 0.0f, q1 = 0.0f;
 #pragma unroll
         for (int j = 0; j < ND; ++j) { const float Qj = Qg[j]; q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }
-        q0 = tj0 < ND ? S.qds[r0] + q0 : 0.0f;
-        q1 = tj1 < ND ? S.qds[r1] + q1 : 0.0f;
-        if (tj0 == rj - 1) S.qd[tj0] = q0;      // the link's own dof is written by the lane that holds it (exactly one per dof)
-        if (tj1 == rj - 1) S.qd[tj1] = q1;
+        const float* qsrc = qpar ? S.qdb : S.qd;
+        float* qdst = qpar ? S.qd : S.qdb;
+        q0 = tj0 < ND ? qsrc[r0] + q0 : 0.0f;   // qd += Hinv dQ (other groups read the same source copy while the owners write the other one)
+        q1 = tj1 < ND ? qsrc[r1] + q1 : 0.0f;
+        if (tj0 == rj - 1) qdst[tj0] = q0;      // the link's own dof is written by the lane that holds it (exactly one per dof)
+        if (tj1 == rj - 1) qdst[tj1] = q1;
         const f3 pk = ld3(S.bp[NF + rj]);
         const f3 a0 = ld3(S.la[tj0 + 1]) * q0, a1 = ld3(S.la[tj1 + 1]) * q1;
         f3 w = a0 + a1;
@@ -1158,10 +1181,12 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         v.x = sum8(v.x); v.y = sum8(v.y); v.z = sum8(v.z);
         if (rs == 0 && rj > 0) { st3(S.bw[NF + rj], w); st3(S.bv[NF + rj], v - cross(w, pk)); }
       }
+      qpar ^= 1;
     }
     __syncthreads();
     SSTAMP(22);
   }
+  if (qpar && tid < ND) S.qd[tid] = S.qdb[tid];   // (lane tid is also the one that integrates dof tid)
   // body table back to (v, w) for the bricks (the link twists are rebuilt from qd by the next FK pass)
   for (int i = tid; i < NF; i += NT) st3(S.bv[i], ld3(S.bv[i]) + cross(ld3(S.bw[i]), ld3(S.bp[i])));
   // ---- the cache for the next solve (keys were written during the set-up)
@@ -1281,7 +1306,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
       if (tl < 64) fk_wave0(Cs, S, tl, true, true);
       __syncthreads();
       PSTAMP(1);
-      mass_matrix<NT>(Cs, S, tl, h);
+      mass_matrix<NT>(Cs, S, tl, h, e == B.dbg_env ? B.dbg : nullptr);
       PSTAMP(2);
     }
     // A + C on wave 0 (FK, implicit PD drive (P1), velocity-product bias torques, twists); the other waves: gravity on the free bricks

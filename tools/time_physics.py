@@ -35,7 +35,7 @@ ms = e0.elapsed_time(e1) / reps
 d = s.DEBUG.cpu().numpy().astype("int64")
 nc = s.NCONTACTS.cpu().numpy()
 ph = {"fk+inertia": d[1] - d[0], "mass_matrix": d[2] - d[1], "drive": d[3] - d[2], "collide": d[4] - d[3], "solve": d[5] - d[4],
-      "integrate": d[6] - d[5], "solve_setup": d[17] - d[16], "it_AC": d[20] - d[18],
+      "integrate": d[6] - d[5], "mm_entries": d[34] - d[1], "mm_cholesky": d[35] - d[34], "mm_linv": d[36] - d[35], "mm_hinv": d[2] - d[36], "solve_setup": d[17] - d[16], "it_AC": d[20] - d[18],
       "setup_load": d[23] - d[16], "setup_count": d[24] - d[23], "setup_prefix": d[25] - d[24], "setup_fill": d[26] - d[25],
       "setup_rank": d[27] - d[26], "setup_link_inertia": d[29] - d[28], "setup_weights": d[30] - d[29],
       "setup_tail": d[17] - d[30], "broad_mask": d[32] - d[3], "broad_scan": d[33] - d[32], "narrow": d[4] - d[33],
