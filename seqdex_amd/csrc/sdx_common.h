@@ -80,12 +80,14 @@ struct SdxBuf {
 #define SDX_OPAQUE_S(x) ((void)0)
 #define SDX_RCP(x) (1.0f / (x))
 #define SDX_READLANE(x, lane) __shfl((x), (lane), 64)
+#define SDX_UNIFORM(x) (x)
 #else
 #define SDX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define SDX_OPAQUE_S(x) asm volatile("" : "+s"(x))   // the same for a wave-uniform value (scalar register)
 #define SDX_RCP(x) __builtin_amdgcn_rcpf(x)   // v_rcp_f32, 1 ulp: the solver's step lengths do not need IEEE division (12 instructions)
 // value of x in a lane known at compile time (v_readlane_b32: the result is wave-uniform, no LDS crossbar); every lane of the wave must be active
 #define SDX_READLANE(x, lane) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (lane)))
+#define SDX_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // a wave-uniform integer the compiler could not prove uniform -> scalar register
 #endif
 
 // sums over aligned groups of 4 / 8 lanes with DPP moves (VALU speed; __shfl_xor goes through ds_bpermute and its LDS latency):

@@ -98,8 +98,15 @@ static_assert(2 * MAXC * sizeof(unsigned short) == MAXC * sizeof(uint32_t), "con
 static_assert(sizeof(PhysLds) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
 
 struct Box { f3 c; f4 q; f3 h; };
+// phase clock of env B.dbg_env (tools/time_physics.py): compiled in only with -DSDX_PHASE_CLOCK (make prof -> lib/libseqdex_prof.so, selected
+// with SDX_LIB_PATH); the stamps keep a zero VGPR and the debug pointer alive through the whole kernel, which the production build does not pay for
+#ifdef SDX_PHASE_CLOCK
 #define PSTAMP(i) do { if (threadIdx.x == 0 && e == B.dbg_env && sub == 0) B.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #define SSTAMP(i) do { if (threadIdx.x == 0 && dbg) dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PSTAMP(i) ((void)0)
+#define SSTAMP(i) ((void)0)
+#endif
 
 __device__ __forceinline__ float box_sdf(f3 p, f3 h, f3* g) {
   f3 d = F3(fabsf(p.x) - h.x, fabsf(p.y) - h.y, fabsf(p.z) - h.z);
@@ -241,27 +248,6 @@ __device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off,
 }
 
 #define S_CKEY(S) (reinterpret_cast<uint32_t*>(&(S).ent[0]))   // identity of contact c until the solver's set-up has read it (the CSR lives here later)
-__device__ __forceinline__ void emit_dir(PhysLds& S, const Box& A, const Box& B, int ida, int idb, uint32_t packed, int k, int base, float off,
-                                         uint32_t pkey) {
-  const Dir D = dir_setup(A, B, off);
-  for (int i = 0; i < k; ++i) {
-    const int c = base + i;
-    if (c >= MAXC) break;
-    const int s = (packed >> (8 * i)) & 0xff;
-    const f3 pb = ((D.t + D.ex * c_samp[s][0]) + D.ey * c_samp[s][1]) + D.ez * c_samp[s][2];
-    f3 g;
-    const float sd = sample_contact(D, pb, B.h, &g);
-    const f3 n = qrot(B.q, g);
-    const f3 pw = B.c + qrot(B.q, pb);
-    const f3 p = pw - n * (0.5f * sd);
-    S.cp[0][c] = p.x; S.cp[1][c] = p.y; S.cp[2][c] = p.z;
-    S.cn[0][c] = n.x; S.cn[1][c] = n.y; S.cn[2][c] = n.z;
-    S.P[0][c] = sd;                                       // staged for the owner lane of contact c (solver set-up)
-    S.P[1][c] = __int_as_float(ida | (idb << 8));
-    S_CKEY(S)[c] = pkey | (uint32_t)s;                    // (pair rank << 6 | direction << 5) | sample
-  }
-}
-
 __device__ __forceinline__ f3 point_vel(const PhysLds& S, int id, f3 p) {   // id: row of the body table (static world = zeros)
   return ld3(S.bv[id]) + cross(ld3(S.bw[id]), p - ld3(S.bp[id]));
 }
@@ -637,7 +623,10 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     __syncthreads();
   }
   SSTAMP(33);
-  // ---- narrowphase: lane = candidate pair; contacts appended in pair order (block prefix sum of the counts)
+  // ---- narrowphase in two parts.  (1) lane = candidate pair: the <= 4 + 4 samples of the two directions that become contacts; a block prefix
+  // sum of the counts gives every contact its place in pair order, and the lane leaves ONE word per contact there: (pair, direction, sample).
+  // (2) lane = contact (below): geometry of that sample.  (Rounds 1-2 emitted from the pair lanes, which kept both boxes alive across the scan
+  // and ran up to eight emissions in a row on one lane while its neighbours idled: 36 spilled registers, 120 MB of scratch writes per launch.)
   // Capacity rule (oracle: collide()): a list that would exceed MAXC contacts is rebuilt without its speculative
   // part - only samples that touch or penetrate (inclusion threshold 0 instead of the contact offset); what still does not fit is
   // dropped in enumeration order and counted.  The second pass is the same code in a run-time loop (block-uniform trip count).
@@ -645,37 +634,62 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   float incl = off;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
-  nc = 0;
-  for (int base = 0; base < np; base += NT) {
-    const int pi = base + tid;
-    int k1 = 0, k2 = 0, ida = 0, idb = 0;
-    uint32_t p1 = 0, p2 = 0, prank = 0;
-    Box A, Bx;
-    if (pi < np) {
-      const uint32_t pr = S_PAIRS(S)[pi];
-      prank = pr >> 16;
-      const int ba = pr & 0xff, bb = (pr >> 8) & 0xff;
-      A = load_box(S, ba);
-      Bx = load_box(S, bb);
-      ida = box_body(S, ba);
-      idb = box_body(S, bb);
-      const int c1 = sample_dir(A, Bx, off, incl, &p1);
-      const int c2 = (bb >= 128 || c1 < 0) ? 0 : sample_dir(Bx, A, off, incl, &p2);
-      if (c1 >= 0 && c2 >= 0) {
-        const int m2 = c2 < 2 ? c2 : 2;
-        k1 = c1 < 4 - m2 ? c1 : 4 - m2;
-        k2 = c2 < 4 - k1 ? c2 : 4 - k1;
+    nc = 0;
+    for (int base = 0; base < np; base += NT) {
+      const int pi = base + tid;
+      int k1 = 0, k2 = 0;
+      uint32_t p1 = 0, p2 = 0;
+      if (pi < np) {
+        const uint32_t pr = S_PAIRS(S)[pi];
+        const int ba = pr & 0xff, bb = (pr >> 8) & 0xff;
+        const Box A = load_box(S, ba), Bx = load_box(S, bb);
+        const int c1 = sample_dir(A, Bx, off, incl, &p1);
+        const int c2 = (bb >= 128 || c1 < 0) ? 0 : sample_dir(Bx, A, off, incl, &p2);
+        if (c1 >= 0 && c2 >= 0) {
+          const int m2 = c2 < 2 ? c2 : 2;
+          k1 = c1 < 4 - m2 ? c1 : 4 - m2;
+          k2 = c2 < 4 - k1 ? c2 : 4 - k1;
+        }
       }
+      int tot;
+      const int pre = block_scan_small<NT>(S, k1 + k2, tid, &tot);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ca = nc + pre + i, cb = nc + pre + k1 + i;
+        if (i < k1 && ca < MAXC) S.P[0][ca] = __int_as_float(pi | (int)(((p1 >> (8 * i)) & 0xff) << 11));
+        if (i < k2 && cb < MAXC) S.P[0][cb] = __int_as_float(pi | (1 << 10) | (int)(((p2 >> (8 * i)) & 0xff) << 11));
+      }
+      nc += tot;
     }
-    int tot;
-    const int pre = block_scan_small<NT>(S, k1 + k2, tid, &tot);
-    if (k1 > 0) emit_dir(S, A, Bx, ida, idb, p1, k1, nc + pre, off, prank << 6);
-    if (k2 > 0) emit_dir(S, Bx, A, idb, ida, p2, k2, nc + pre + k1, off, (prank << 6) | 32u);
-    nc += tot;
+    if (nc <= MAXC || pass == 1) break;
+    incl = 0.0f;      // (the scans' barriers order this pass's LDS writes before the next pass's)
+    rebuilt = 1;
   }
-  if (nc <= MAXC || pass == 1) break;
-  incl = 0.0f;      // (the scans' barriers order this pass's LDS writes before the next pass's)
-  rebuilt = 1;
+  __syncthreads();
+  // ---- (2) lane = contact: point, normal, separation of sample s of box A against box B (oracle: emit_dir)
+  {
+    const int ncc = nc < MAXC ? nc : MAXC;
+#pragma unroll 1
+    for (int c = tid; c < ncc; c += NT) {
+      const int d = __float_as_int(S.P[0][c]);
+      const uint32_t pr = S_PAIRS(S)[d & 1023];
+      const int dirb = (d >> 10) & 1, sidx = d >> 11;
+      const int b0 = pr & 0xff, b1 = (pr >> 8) & 0xff;
+      const int ba = dirb ? b1 : b0, bb = dirb ? b0 : b1;
+      const Box A = load_box(S, ba), Bx = load_box(S, bb);
+      const Dir D = dir_setup(A, Bx, off);
+      const f3 pb = ((D.t + D.ex * c_samp[sidx][0]) + D.ey * c_samp[sidx][1]) + D.ez * c_samp[sidx][2];
+      f3 g;
+      const float sd = sample_contact(D, pb, Bx.h, &g);
+      const f3 n = qrot(Bx.q, g);
+      const f3 pw = Bx.c + qrot(Bx.q, pb);
+      const f3 p = pw - n * (0.5f * sd);
+      S.cp[0][c] = p.x; S.cp[1][c] = p.y; S.cp[2][c] = p.z;
+      S.cn[0][c] = n.x; S.cn[1][c] = n.y; S.cn[2][c] = n.z;
+      S.P[0][c] = sd;                                       // staged for the owner lane of contact c (solver set-up)
+      S.P[1][c] = __int_as_float(box_body(S, ba) | (box_body(S, bb) << 8));
+      S_CKEY(S)[c] = ((pr >> 16) << 6) | ((uint32_t)dirb << 5) | (uint32_t)sidx;   // (pair rank << 6 | direction << 5) | sample
+    }
   }
   if (tid == 0) {
     S.overflow = nc > MAXC ? nc - MAXC : 0;
@@ -1028,7 +1042,9 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   }
   SDX_OPAQUE(gbeg); SDX_OPAQUE(gend); SDX_OPAQUE(tjp);
   for (int it = (WARM && nold > 0) ? -1 : 0; it < sc.solver_iters; ++it) {   // it = -1: only the gather of the warm-start impulses
+#ifdef SDX_PHASE_CLOCK
     if (it == 1) dbg = nullptr;
+#endif
     SSTAMP(18);
     const int cur = it & 1, nxt = cur ^ 1;
     // ---- [AC] lane = contact: relative velocity from the current body table, active flag -> counted for the NEXT iteration (integer
@@ -1073,6 +1089,9 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         }
         S.P[0][c] = P.x; S.P[1][c] = P.y; S.P[2][c] = P.z;
       }
+#ifdef SDX_AC_SCHED_BARRIER
+      __builtin_amdgcn_sched_barrier(0);   // one contact after the other: interleaving the three costs the loop its registers
+#endif
     }
     __syncthreads();
     SSTAMP(20);
@@ -1165,8 +1184,8 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         const int tj0 = tjp & 0xff, tj1 = tjp >> 8;
         const int r0 = tj0 < ND ? tj0 : 0, r1 = tj1 < ND ? tj1 : 0;
         float q0 = 0.0f, q1 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < ND; ++j) { const float Qj = Qg[j]; q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }
+#pragma unroll 8
+        for (int j = 0; j < ND; ++j) { const float Qj = Qg[j]; q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }   // (fully unrolled, 69 loads in flight pushed 31 registers of the WHOLE kernel into scratch)
         const float* qsrc = qpar ? S.qdb : S.qd;
         float* qdst = qpar ? S.qd : S.qdb;
         q0 = tj0 < ND ? qsrc[r0] + q0 : 0.0f;   // qd += Hinv dQ (other groups read the same source copy while the owners write the other one)
@@ -1269,7 +1288,8 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
   extern __shared__ __attribute__((aligned(16))) char smem[];
   PhysLds& S = *reinterpret_cast<PhysLds*>(smem);
   // launch order: B.order lists the envs by the cost of their previous step, longest first (k_order below)
-  const int e = B.order ? B.order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
+  // (the loaded index is wave-uniform, but only readfirstlane tells the compiler: every address derived from it stays in scalar registers)
+  const int e = B.order ? SDX_UNIFORM(B.order[blockIdx.x]) : (int)blockIdx.x, tid = threadIdx.x;
   const sdx_scene_desc& sc = C->sc;
   float* root_e = B.root + (size_t)e * SDX_ACTORS * 13;
   const float h = sc.dt / (float)sc.substeps;

@@ -13,7 +13,7 @@ KERN = "_Z9k_physicsILi512EEvPK8SdxConst6SdxBuf"
 
 src = open(SRC).read().split("\n")
 lo = next(i for i, l in enumerate(src) if "for (int it = (WARM && nold > 0) ? -1 : 0;" in l) + 1
-hi = next(i for i, l in enumerate(src) if "SSTAMP(22);" in l) + 1
+hi = next(i for i, l in enumerate(src) if "SSTAMP(22);" in l and i > lo) + 1
 with tempfile.TemporaryDirectory() as td:
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-gline-tables-only",
            "-Rpass-analysis=kernel-resource-usage", "-save-temps=obj", "-c", SRC, "-o", os.path.join(td, "p.o")] + sys.argv[1:]
