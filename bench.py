@@ -135,9 +135,13 @@ def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mi
     ppo_steps = mini_epochs * (R // minibatch)
     us_per_opt_step = ppo_dt / ppo_steps * 1e6
     epoch_opt_steps = mini_epochs * (n_full * horizon // minibatch)
-    epoch_s = n_full * horizon / sim_rate + epoch_opt_steps * us_per_opt_step * 1e-6
-    return {"value": n_full * horizon / epoch_s, "unit": "env-steps/s", "cores": cores, "kind": "port", "ppo_threads": ppo_threads,
-            "cpu_model": cpu_model, "sim_only_env_steps_per_s": sim_rate, "sim_only_env_steps_per_s_by_omp_threads": by_threads,
+    # the headline CPU figure takes the BEST of the thread counts tried for the sim leg (more threads than ~64 lose to fork/join and
+    # memory traffic on this box); `cores` = the threads that figure used
+    best_threads = max(by_threads, key=lambda k: by_threads[k])
+    sim_best = by_threads[best_threads]
+    epoch_s = n_full * horizon / sim_best + epoch_opt_steps * us_per_opt_step * 1e-6
+    return {"value": n_full * horizon / epoch_s, "unit": "env-steps/s", "cores": int(best_threads), "host_cores": cores, "kind": "port", "ppo_threads": ppo_threads,
+            "cpu_model": cpu_model, "sim_only_env_steps_per_s": sim_best, "sim_only_env_steps_per_s_by_omp_threads": by_threads,
             "ppo_us_per_optimiser_step": us_per_opt_step,
             "sample": "sim: %d envs x %d physics steps of oracle/physics_oracle.c (OpenMP over envs, %d threads), %.1f s; "
                       "PPO: %d optimiser steps (minibatch %d) of oracle/ppo_oracle.py on torch-CPU (%d threads), %.1f s, scaled to the "
@@ -280,12 +284,21 @@ def main():
     phys_ms = e0.elapsed_time(e1) / reps
     phys_bytes = BYTES_PER_ENV_STEP * n
     ptraf, pctr = pmc_traffic("k_physics", n)
+    cstats = [int(x) for x in sim.CONTACT_STATS.cpu().tolist()]
+    nc_mean = float(sim.NCONTACTS.float().mean().item())
+    # the warm-started solver keeps (key, 3 impulses) = 16 B per contact in HBM between solves: read + written once per substep
+    warm = float(sim._desc.warm_start) > 0
+    cache_bytes = int(2 * sim._desc.substeps * 16 * nc_mean * n) if warm else 0
     roof_phys = {"kernel": "k_physics<%d> (%d threads per env, two workgroups per CU)" % (int(sim.lib.sdxk_physics_threads()), int(sim.lib.sdxk_physics_threads())),
                  "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes,
-                 "contacts_per_env_mean": float(sim.NCONTACTS.float().mean().item()), "contacts_per_env_max": int(sim.NCONTACTS.max().item()),
-                 "contact_capacity_per_env": 1536, "contacts_per_env_max_since_create": int(sim.CONTACT_STATS[0].item()),
-                 "env_steps_over_capacity_since_create": int(sim.CONTACT_STATS[1].item()), "traffic": ptraf, "traffic_counters": pctr}
+                 "warm_start_cache_bytes_per_launch": cache_bytes,
+                 "bound_actual": "latency: barrier-separated LDS-resident phases (VALU issue about 1/3 busy, LDS about 40 %, waves parked 60 % of "
+                                 "their cycles; profiles/r3_kphysics_pmc_*.csv); the working set never leaves LDS, so the HBM roofline is nominal",
+                 "contacts_per_env_mean": nc_mean, "contacts_per_env_max": int(sim.NCONTACTS.max().item()),
+                 "contact_capacity_per_env": 1536, "contacts_per_env_max_since_create": cstats[0],
+                 "env_substeps_over_capacity_since_create": cstats[1], "env_substeps_rebuilt_without_speculative_contacts": cstats[2],
+                 "env_substeps_pair_list_overflow": cstats[3], "traffic": ptraf, "traffic_counters": pctr}
     roof_phys["frac"] = roof_phys["achieved"] / HBM_PEAK_GBS
     # ---- roofline of the update phase.  Algorithmic bytes: one optimiser step touches 5 x 4 B per parameter
     # (w, g, m, v in, w' out) for all three networks; the persistent kernel runs all optimiser steps of the epoch in ONE launch and
@@ -318,6 +331,13 @@ def main():
                 "algorithmic_bytes_per_launch": upd_bytes_step * nsteps,
                 "traffic": utraf, "traffic_counters": uctr}
       roof_upd["frac"] = roof_upd["achieved"] / HBM_PEAK_GBS
+      if impl == "persistent":
+          # the bound the kernel actually sits at: a chain of CU-to-CU exchange edges per optimiser step plus the
+          # arithmetic that cannot leave the chain; weights and moments live in VGPRs, so HBM carries ~5 % of the algorithmic bytes
+          pc_ = PMC.get("k_update_persistent_phase_clock", {})
+          roof_upd["bound_actual"] = {"kind": "exchange-latency", "exchange_edges_per_optimiser_step": pc_.get("edges", 5),
+                                      "us_wait_on_edges_per_step": pc_.get("edge_wait_us"), "us_on_chain_arithmetic_per_step": pc_.get("on_chain_us"),
+                                      "us_per_optimiser_step_measured": upd_ms_step * 1e3, "quoted_from": pc_.get("source")}
     dominant = roof_upd if upd_t > step_t else roof_phys
     out = {
         "metric": "env-steps/sec BlockAssemblyGraspSim num_envs=%d/GPU" % n, "value": value, "unit": "env-steps/s",

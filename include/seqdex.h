@@ -121,7 +121,9 @@ typedef enum {
                             *                    exceeded its 1024 slots (the excess pairs were not tested) */
   SDX_T_WARM_COUNT = 44,   /* i32 [N]           contacts in each env's warm-start cache (scene.warm_start); the engine clears an
                             *                    env's entry when it resets the env; a caller that teleports bodies by hand may zero it too */
-  SDX_T_COUNT = 45
+  SDX_T_CAM_ROT = 45,      /* f32 [N,4]         camera_view_segmentation_target_rot: the target brick's quaternion in the camera frame, the input of
+                            *                    GraspInsertTValue (GS:1196-1201, OR:1201); written by sdx_compute_observations / sdx_post_physics */
+  SDX_T_COUNT = 46
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the
@@ -189,6 +191,9 @@ typedef struct {
                                         * (pair, direction, sample) ended the previous solve with; 0 = start from zero */
   float warm_age;                      /* the fraction ramps up linearly with the number of consecutive solves a contact has existed and
                                         * reaches warm_start after warm_age of them (0: no ramp); DESIGN.md section 3.E */
+  float grasp_tvalue_gate;             /* BlockAssemblyGraspSim harvests a terminal state only when its transition value exceeds this: 0.8 (GS:1406) */
+  float orient_tvalue_gate;            /* BlockAssemblyOrient binarises its transition value at this threshold before anything reads it: 0.99
+                                        * (OR:1203); a chain run with an early, not yet confident T-value may lower it (say so when you do) */
   /* which task's per-step tensor code the pre/post-physics kernels run: 0 = BlockAssemblyGraspSim (GS),
    * 1 = BlockAssemblyOrient (OR = tasks/block_assembly/allegro_hand_block_assembly_orient.py; targets/IK OR:1720-1778),
    * 2 = BlockAssemblyInsertSim (IS; position action + fixed wrist orientation IS:1526-1572, 75-number observation IS:1280-1298,

@@ -18,7 +18,8 @@ def lib():
     global _lib
     if _lib is None:
         src = os.path.join(HERE, "physics_oracle.c")
-        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        hdr = os.path.join(os.path.dirname(HERE), "include", "seqdex.h")      # the scene descriptor's layout lives there
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
             build()
         _lib = C.CDLL(_SO)
         _lib.sdxo_contacts.restype = C.c_int

@@ -45,7 +45,7 @@ class SceneDesc(C.Structure):
         ("max_episode_length", f32), ("act_moving_average", f32), ("av_factor", f32),
         ("clip_obs", f32), ("clip_actions", f32),
         ("dt", f32), ("substeps", i32), ("solver_iters", i32), ("contact_offset", f32), ("gravity", f32 * 3),
-        ("friction", f32), ("baumgarte", f32), ("max_depenetration_vel", f32), ("jacobi_relax", f32), ("warm_start", f32), ("warm_age", f32),
+        ("friction", f32), ("baumgarte", f32), ("max_depenetration_vel", f32), ("jacobi_relax", f32), ("warm_start", f32), ("warm_age", f32), ("grasp_tvalue_gate", f32), ("orient_tvalue_gate", f32),
         ("task_kind", i32), ("target_euler", f32 * 3), ("seg_mass_scale", f32),
         ("static_var_slot", i32), ("static_var_center_z", f32 * 3), ("static_var_half_z", f32 * 3),
         ("seg_cam_pos", f32 * 3), ("seg_cam_target", f32 * 3), ("seg_cam_hfov_deg", f32),
@@ -74,7 +74,7 @@ T = dict(ROOT=0, DOF=1, RB=2, CONTACT=3, JAC_EEF=4, TARGETS=5, PREV_TARGETS=6, O
          STATES_CLAMPED=10, REW=11, RESET=12, PROGRESS=13, RANDOMIZE=14, ACTIONS=15, INIT_POS=16, INIT_ROT=17,
          SUCCESSES=18, META_REW=19, CONS_SUCCESSES=20, FINGER_DIST=21, TVALUE=22, ARM_CONTACTS=23, STUDENT_OBS=24,
          SUCCESS_BUF=25, PILE_CHOICE=26, NCONTACTS=27, DEBUG=28, HARVEST_HAND=29, HARVEST_OBJ=30,
-         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35, PILE_HARVEST=36, PILE_HARVEST_COUNT=37, SEG_IMAGE=38, SEG_PIXELS=39, EMERGENCE=40, JACOBIAN=41, TVALUE_OBS=42, CONTACT_STATS=43, WARM_COUNT=44)
+         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35, PILE_HARVEST=36, PILE_HARVEST_COUNT=37, SEG_IMAGE=38, SEG_PIXELS=39, EMERGENCE=40, JACOBIAN=41, TVALUE_OBS=42, CONTACT_STATS=43, WARM_COUNT=44, CAM_ROT=45)
 # sdxp_tensor_id
 TP = dict(AC_PARAMS=0, AC_GRADS=1, CV_PARAMS=2, CV_GRADS=3, MB_OBS=4, MB_STATES=5, MB_ACTIONS=6, MB_MUS=7,
           MB_SIGMAS=8, MB_NEGLOGP=9, MB_VALUES=10, MB_REWARDS=11, MB_DONES=12, RETURNS=13, ADVANTAGES=14,

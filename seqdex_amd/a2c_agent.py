@@ -254,7 +254,8 @@ class A2CAgent:
         nmb = self.batch_size // self.minibatch_size
         if "FACTORS" in ppo.t and hasattr(ppo, "backward_factors") and self.minibatch_size <= 8:
             # preferred: all-gather the rank-MB factors (194 KB per rank) and rebuild the summed gradient locally
-            fact, fact_all = ppo.t["FACTORS"], ppo.t["FACTORS_ALL"]
+            # flat views: the concatenating form of all_gather_into_tensor is the one every backend accepts (gloo rejects [W, F] <- [F])
+            fact, fact_all = ppo.t["FACTORS"].view(-1), ppo.t["FACTORS_ALL"].view(-1)
 
             def steps(k):
                 for _ in range(k):

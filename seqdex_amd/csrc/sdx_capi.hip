@@ -103,6 +103,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   memset(&B, 0, sizeof(B));
   B.N = N;
   B.task_kind = scene->task_kind;
+  B.orient_gate = scene->orient_tvalue_gate;
   B.obs_w = (scene->task_kind == 1 || scene->task_kind == 3) ? 186 : (scene->task_kind == 2 ? 75 : SDX_NUM_OBS);
   B.K = 1;
   B.seed = seed;
@@ -216,6 +217,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_EMERGENCE, B.emergence, SDX_F32, {N});
   set_tensor(h, SDX_T_CONTACT_STATS, B.cstats, SDX_I32, {4});
   set_tensor(h, SDX_T_WARM_COUNT, B.wcount, SDX_I32, {N});
+  set_tensor(h, SDX_T_CAM_ROT, B.cam_rot, SDX_F32, {N, 4});
   set_tensor(h, SDX_T_JACOBIAN, B.jac_full, SDX_F32, {N, SDX_NLINK - 1, 6, SDX_NDOF});
   if (scene->task_kind == 3) set_tensor(h, SDX_T_TVALUE_OBS, B.tvt_buf, SDX_F32, {N, 652});
   else set_tensor(h, SDX_T_TVALUE_OBS, B.seg_pix, SDX_F32, {1, 1});   // placeholder: the temporal buffer belongs to Search

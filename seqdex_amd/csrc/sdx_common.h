@@ -47,6 +47,7 @@ struct SdxBuf {
   uint32_t* step_count;    // device counter, incremented by the post-physics kernel
   long long* dbg;          // [64] phase time stamps of env dbg_env (profiling aid)
   int32_t dbg_env;         // SDX_DEBUG_ENV at sdx_create (default 0)
+  float orient_gate;       // copy of sdx_scene_desc.orient_tvalue_gate
   int32_t *order, *cost;   // [N] k_physics launch order (envs by the cost of their previous step, longest first) / that cost; nullptr: env order
   float *harvest_hand, *harvest_obj;   // [8, SDX_HARVEST_SLOTS, 23*2] / [8, SDX_HARVEST_SLOTS, 13]
   int32_t* harvest_count;  // [8]

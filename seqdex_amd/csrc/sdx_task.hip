@@ -104,7 +104,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
     // (y < 0) with the fingers still around it and an accepting T-value is stored in the ring buffer of its type group
     if (B.step_count[0] > 0 && sc.task_kind == 0) {                                // `if self.total_steps > 0`; GraspSim's rule only
       const float* tg = root_e + seg_actor(e) * 13;
-      const bool good = tg[1] < 0.0f && B.finger_dist[e] < 0.6f && B.tvalue[e] > 0.8f;   // GS:1404-1406
+      const bool good = tg[1] < 0.0f && B.finger_dist[e] < 0.6f && B.tvalue[e] > sc.grasp_tvalue_gate;   // GS:1404-1406 (0.8)
       tv_log(B, e, lane, good);                                                    // the save_hdf5 datasets, GS:1407-1438
       if (good) {
         int slot = 0;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
     y = elu1(y);
     if (e0 + t < B.N) {
       float tvv = 1.0f / (1.0f + expf(-y));
-      if (B.task_kind == 1) tvv = tvv > 0.99f ? 1.0f : 0.0f;                      // Orient gates the T-value at 0.99, OR:1203
+      if (B.task_kind == 1) tvv = tvv > B.orient_gate ? 1.0f : 0.0f;             // Orient gates the T-value at 0.99, OR:1203 (sdx_scene_desc.orient_tvalue_gate)
       B.tvalue[e0 + t] = tvv;
     }
   }

@@ -105,8 +105,20 @@ class Scene:
         d.base_plate_pos[:] = raw["base_plate_pos"]
         for i, fb in enumerate(raw["fixed_bricks"]):
             d.fixed_brick_pos[i][:] = fb["pos"]
+        # The reference spawns the lowest layer of free bricks at z = 0.62 (GS:737-742), INSIDE its floor of fixed bricks (z = 0.625,
+        # GS:766-777), and lets PhysX push them out; a brick that overlaps the floor slab by its whole height has no meeting face in
+        # this engine (top samples just above the slab, bottom samples pushed down) and stays there - round 3
+        # found every target brick of the synthetic piles buried that way.  The lattice is lifted so that its lowest layer starts
+        # 2 mm above the floor; the piles then settle ON it, as the reference's saved pile states do.
+        floor = [st for st in self.statics if st["name"] == "brick_floor"]
+        lift = 0.0
+        if floor:
+            top = floor[0]["center"][2] + floor[0]["half"][2]
+            low = min(fs["pos"][2] + self.brick_types[fs["type"]]["center"][2] - self.brick_types[fs["type"]]["half"][2] for fs in raw["free_spawn"])
+            lift = max(0.0, top + 0.002 - low)
+        self.spawn_lift = lift
         for i, fs in enumerate(raw["free_spawn"]):
-            d.free_spawn_pos[i][:] = fs["pos"]
+            d.free_spawn_pos[i][:] = [fs["pos"][0], fs["pos"][1], fs["pos"][2] + lift]
         d.free_spawn_quat[:] = raw["free_spawn"][0]["quat"]
         d.hand_base_body = self.hand_base_body
         d.fingertip_body[:] = self.fingertip_bodies
@@ -124,6 +136,8 @@ class Scene:
         d.friction, d.baumgarte = self.solver["friction"], self.solver["baumgarte"]
         d.max_depenetration_vel, d.jacobi_relax = self.solver["max_depenetration_vel"], self.solver["jacobi_relax"]
         d.warm_start, d.warm_age = self.solver["warm_start"], self.solver["warm_age"]
+        d.orient_tvalue_gate = 0.99                        # OR:1203
+        d.grasp_tvalue_gate = 0.8                          # GS:1406
         d.task_kind = 0                                   # BlockAssemblyGraspSim; 1 = BlockAssemblyOrient (per-step tensor code only)
         d.target_euler[:] = [0.0, 3.1415, 1.571]          # OR:477
         d.seg_mass_scale = 1.0                            # GS:980-981 (x1); Orient x50 (OR:977)

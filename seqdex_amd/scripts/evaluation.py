@@ -1,73 +1,201 @@
-"""Sequential --play evaluation of the policy chain, after the reference's scripts/evaluation.py:36-119: every sub-policy is restored
-from its checkpoint and played (mean action, no update) on its own task, in chain order, each stage starting from what the stage
-before produced (Search's dug-out piles -> Orient; Orient's harvested piles -> GraspSim; GraspSim's grasp terminal states -> InsertSim).  Checkpoints: files written by A2CAgent.save (rl_games' layout) or
-by rl_games itself.
+"""Chained evaluation of the BlockAssembly sub-policies, after the reference's scripts/evaluation.py:36-119: every stage is played (no
+update) with the transition value switched on, and leaves the terminal states the next stage starts from:
 
-    python -m seqdex_amd.scripts.evaluation --tasks BlockAssembly --orient ck1.pth --grasp ck2.pth --insert ck3.pth [--games 512]
+    BlockAssemblyOrient    --pile states of episodes that end with the target brick reachable (OR:1463-1488)-->
+    BlockAssemblyGraspSim  --grasp terminal states: brick carried to the insertion side, still in the hand, T-value > 0.8 (GS:1404-1417)-->
+    BlockAssemblyInsertSim   (every reset draws the brick and the hand from those states, IS:372-375,1449-1456)
+
+Where the reference hands the states over through pickles under ./intermediate_state/, the stages here hand over device tensors with the
+same content (the pickle forms exist too: seqdex_amd/piles.py, BlockAssemblyGraspSim.save_grasp_terminal_states).  BASELINE.json
+configs[2] is this chain at num_envs = 1024 on one GPU; tools/bench_config3.py times it, tests/test_gpu_chain.py checks the hand-offs.
+
+    python -m seqdex_amd.scripts.evaluation --tasks BlockAssembly [--num_envs 512] [--orient_policy p.pth --grasp_policy p.pth --insert_policy p.pth]
 """
 import argparse
+import os
+import time
 
+import numpy as np
 import torch
+import yaml
 
-from ..config import get_args
-from ..train_rlgames import build
+from ..a2c_agent import A2CAgent
+from ..config import TASK_CFG, TRAIN_CFG
+from ..vec_task_rlgames import RLgamesVecTaskPython
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main_rlgames(task, num_envs, play=True, use_t_value=False, policy_path="", games=0, task_kwargs=None, minibatch_size=0):
-    """evaluation.py:36-103 for one stage.  Returns (mean episode reward, mean episode length, task object)."""
-    argv = ["--task=%s" % task, "--num_envs=%d" % num_envs, "--headless", "--play"]
+def _task_class(name):
+    import importlib
+    mod = {"BlockAssemblyGraspSim": "block_assembly_grasp_sim", "BlockAssemblyOrient": "block_assembly_orient",
+           "BlockAssemblyInsertSim": "block_assembly_insert_sim", "BlockAssemblySearch": "block_assembly_search"}[name]
+    return getattr(importlib.import_module("seqdex_amd.tasks." + mod), name)
+
+
+def main_rlgames(task, num_envs, play=True, use_t_value=True, policy_path="", steps=None, task_kwargs=None, tvalue_state=None,
+                 controller=None, seed=22, until=None, max_steps=None):
+    """one stage of scripts/evaluation.py:36-103: build the task and its agent, restore `policy_path`, play.  `steps` env steps are
+    played in horizon-sized chunks (default: one episode + its reset); `until(task)` may end the stage earlier / later (checked after
+    every chunk, at most `max_steps`).  `controller(task, step) -> actions [N, 23]` replaces the policy (a scripted stand-in; the
+    returned statistics say so).  Returns (task object - the caller closes task.sim -, statistics)."""
+    assert play, "the chain evaluation only plays"
+    cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG[task])))
+    cfg["env"]["numEnvs"] = num_envs
+    cfg["env"]["test"] = True
+    tr = yaml.safe_load(open(os.path.join(ROOT, TRAIN_CFG[task])))
+    t_obj = _task_class(task)(cfg, device_type="cuda", device_id=0, headless=True, seed=seed, **(task_kwargs or {}))
+    if tvalue_state is not None and use_t_value:
+        t_obj.sim.set_tvalue_weights(tvalue_state)
+    env = RLgamesVecTaskPython(t_obj, "cuda:0")
+    tr["params"]["config"].update(num_actors=num_envs, vec_env=env, env_info=env.get_env_info(), seed=seed, name=task)
+    agent = A2CAgent("run", tr["params"])
     if policy_path:
-        argv.append("--checkpoint=%s" % policy_path)
-    args = get_args(argv)
-    args.use_t_value = use_t_value
-    task_obj, env, agent, logdir, rank = build(args, task_kwargs, minibatch_size)
-    agent.play(games or num_envs)
+        agent.restore(policy_path)
+    horizon = agent.horizon_length
+    if steps is None:
+        steps = int(t_obj.max_episode_length) + horizon
+    max_steps = max_steps or steps
+    deterministic = bool(tr["params"]["config"].get("player", {}).get("deterministic", True))
     torch.cuda.synchronize()
-    rew, length = float(agent.game_rewards.get_mean()[0]), float(agent.game_lengths.get_mean()[0])
+    t0 = time.time()
+    done = 0
+    if controller is not None:
+        env.reset()
+    while done < max_steps:
+        if controller is None:
+            agent.play_steps(deterministic)
+        else:
+            for _ in range(horizon):
+                env.step(controller(t_obj, done + _))
+        done += horizon
+        if done >= steps and (until is None or until(t_obj)):
+            break
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    stats = {"task": task, "num_envs": num_envs, "env_steps": done * num_envs, "steps_per_env": done, "wall_s": dt,
+             "env_steps_per_s": done * num_envs / dt, "policy": (policy_path or "random initialisation (seed %d)" % seed) if controller is None
+             else "scripted stand-in controller (%s)" % getattr(controller, "__name__", "callable"),
+             "success_buf_mean": float(t_obj.extras["success_buf"].float().mean())}
     agent.ppo.close()
-    return rew, length, task_obj
+    return t_obj, stats
 
 
-def block_assembly(orient_path, grasp_path, insert_path, num_envs=512, games=0, insert_minibatch=0, search_path=None):
-    out = {}
-    dug = None
-    if search_path is not None:
-        r, l, search = main_rlgames("BlockAssemblySearch", min(num_envs, 128), use_t_value=True, policy_path=search_path, games=games)
-        dug = search.pile_terminal_states()
-        out["BlockAssemblySearch"] = dict(reward=r, length=l, search_success_rate=float(search.extras["success_buf"].float().mean()),
-                                          piles_handed_on=0 if dug is None else int(dug.shape[1]))
-        search.sim.close()
-    r, l, orient = main_rlgames("BlockAssemblyOrient", num_envs, use_t_value=True, policy_path=orient_path, games=games,
-                                task_kwargs={"initial_piles": dug})
+def scripted_grasp_controller(task, step):
+    """STAND-IN for a trained BlockAssemblyGraspSim policy (the reference's released checkpoint is from epoch 19 000, README.md:90; nothing of
+    that length can be trained inside a test): a hand-written reach - descend - pinch sequence on the task's own action interface
+    (GS:1586-1609: a[0:3] x 0.64 = hand-base displacement for the IK, a[7:23] = finger targets scaled to the joint limits).  After step 75 the
+    task itself lifts the hand and carries it to the insertion side with the fingers frozen (GS:1600-1609).  Used by tools/bench_config3.py and
+    tests/test_gpu_chain.py so that the grasp stage harvests REAL terminal states of this engine; success is far below a trained policy's."""
+    s, n = task.sim, task.num_envs
+    if not hasattr(task, "_sg_seg"):
+        sc = s.scene
+        task._sg_seg = torch.as_tensor([sc.seg_index(i) for i in range(n)], device=task.device, dtype=torch.long)
+        task._sg_env = torch.arange(n, device=task.device)
+        task._sg_q0 = torch.tensor([0.7107, -0.7033, 0.0113, -0.0091], device=task.device)          # hand base at the prepare pose (FK of the scene)
+    prog = s.PROGRESS.to(torch.float32)
+    hb = s.RB[:, s.scene.hand_base_body, 0:3]
+    brick = s.ROOT.view(n, 142, 13)[task._sg_env, task._sg_seg, 0:3]
+    # the pinch point between thumb and fingers sits (0.125, 0.02, -0.2) from the hand base in the prepare orientation (FK of the scene)
+    if not hasattr(task, "_sg_close"):
+        task._sg_close = torch.full((n,), 1e9, device=task.device)      # progress value at which the env's fingers started to close
+    task._sg_close = torch.where(prog < 2, torch.full_like(prog, 1e9), task._sg_close)          # a new episode
+    rel = hb - brick
+    horiz = torch.sqrt((rel[:, 0] + 0.125) ** 2 + (rel[:, 1] + 0.02) ** 2)
+    above = torch.where(horiz > 0.05, torch.full_like(prog, 0.25), torch.full_like(prog, 0.195))   # stay above the pile while travelling
+    target = brick + torch.stack([torch.full_like(prog, -0.125), torch.full_like(prog, -0.02), above], dim=1)
+    a = torch.zeros(n, 23, device=task.device)
+    a[:, 0:3] = torch.clamp(2.5 * (target - hb) / 0.64, -1.0, 1.0)
+    # hold the wrist at the prepare pose's orientation (palm down): a[3:6] x 0.2 = orientation error for the IK (GS:1596, OR:1922-1925)
+    q = s.RB[:, s.scene.hand_base_body, 3:7]
+    q0 = task._sg_q0
+    qr_w = q0[3] * q[:, 3] + (q0[:3] * q[:, :3]).sum(1)                                              # q0 * conj(q)
+    qr_v = -q0[3] * q[:, :3] + q[:, 3:4] * q0[:3] - torch.cross(q0[:3].expand_as(q[:, :3]), q[:, :3], dim=1)
+    a[:, 3:6] = torch.clamp(2.0 * qr_v * torch.sign(qr_w).unsqueeze(1) / 0.2, -1.0, 1.0)
+    arrived = (horiz < 0.012) & ((rel[:, 2] - 0.195).abs() < 0.012)
+    task._sg_close = torch.where(arrived | (prog >= 58), torch.minimum(task._sg_close, prog), task._sg_close)   # at the latest at step 58
+    frac = torch.clamp(0.3 + (prog - task._sg_close) / 14.0 * 0.6, min=0.3, max=0.9)
+    a[:, 7:23] = (2.0 * frac - 1.0).unsqueeze(1)
+    a[:, [7, 11, 15]] = 0.0                                            # abduction joints of the three fingers stay centred
+    return a
+
+
+def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, controllers=None, min_piles=8, seed=22, stage_steps=None,
+                         synthetic_fallback=False, orient_tvalue_gate=0.99, grasp_tvalue_gate=0.8):
+    """Orient -> GraspSim -> InsertSim played back to back on one GPU.  policies / controllers / stage_steps: dicts keyed "orient",
+    "grasp", "insert".  Orient plays until every brick-type group has `min_piles` harvested pile states (OR:1483-1488 fills rings of
+    10 000; at most 8 episodes here).  orient_tvalue_gate: the threshold Orient binarises the transition value at (0.99, OR:1203); a
+    T-value fitted to a few hundred epochs of outcomes never gets that confident, so the chain benchmark lowers it (and GraspSim's 0.8,
+    GS:1406) and says so.
+    Returns (statistics, hand-off tensors for inspection)."""
+    policies, controllers, stage_steps = policies or {}, controllers or {}, stage_steps or {}
+    out, hand = {"num_envs": num_envs, "min_piles_per_type": min_piles}, {}
+    t_begin = time.time()
+    # ---- stage 1: BlockAssemblyOrient
+    orient, st = main_rlgames("BlockAssemblyOrient", num_envs, policy_path=policies.get("orient", ""), tvalue_state=tvalue_state,
+                              controller=controllers.get("orient"), seed=seed, steps=stage_steps.get("orient"),
+                              until=lambda t: int(t.sim.PILE_HARVEST_COUNT.min()) >= min_piles,
+                              max_steps=8 * 80 if stage_steps.get("orient") is None else stage_steps["orient"],
+                              task_kwargs={"tvalue_gate": orient_tvalue_gate, "piles_per_type": 64})
+    st["piles_harvested_per_type"] = orient.sim.PILE_HARVEST_COUNT.cpu().tolist()
+    st["tvalue_gate"] = orient_tvalue_gate
     piles = orient.pile_terminal_states()
-    out["BlockAssemblyOrient"] = dict(reward=r, length=l, piles_handed_on=0 if piles is None else int(piles.shape[1]))
     orient.sim.close()
-    r, l, grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, use_t_value=True, policy_path=grasp_path, games=games,
-                               task_kwargs={"initial_piles": piles})
+    out["orient"] = st
+    if piles is None:
+        raise RuntimeError("BlockAssemblyOrient harvested no pile state for at least one brick-type group: %s" % st["piles_harvested_per_type"])
+    hand["piles"] = piles
+    # ---- stage 2: BlockAssemblyGraspSim from Orient's piles (GS:412-413)
+    grasp, st = main_rlgames("BlockAssemblyGraspSim", num_envs, policy_path=policies.get("grasp", ""), tvalue_state=tvalue_state,
+                             controller=controllers.get("grasp"), seed=seed, steps=stage_steps.get("grasp"),
+                             task_kwargs={"initial_piles": piles, "harvest_tvalue_gate": grasp_tvalue_gate})
     cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
-    states = grasp.grasp_terminal_states() if cnt.min() > 0 else None
-    out["BlockAssemblyGraspSim"] = dict(reward=r, length=l, grasp_states_handed_on=int(cnt.sum()))
+    st["tvalue_gate"] = grasp_tvalue_gate
+    st["grasp_states_harvested_per_type"] = cnt.tolist()
+    st["initial_piles"] = "BlockAssemblyOrient.pile_terminal_states(): %d per brick-type group" % piles.shape[1]
+    if cnt.min() > 0 or (synthetic_fallback and cnt.max() > 0):
+        grasp_states = grasp.grasp_terminal_states()          # (groups without a harvested state: empty tensors -> InsertSim's stand-ins)
+        hand["grasp_obj"], hand["grasp_hand"] = grasp_states
+    elif synthetic_fallback:
+        grasp_states = None
+    else:
+        grasp.sim.close()
+        out["grasp"] = st
+        raise RuntimeError("BlockAssemblyGraspSim harvested no grasp terminal state for at least one brick-type group: %s" % cnt.tolist())
     grasp.sim.close()
-    r, l, insert = main_rlgames("BlockAssemblyInsertSim", num_envs, use_t_value=True, policy_path=insert_path, games=games,
-                                task_kwargs={"grasp_states": states}, minibatch_size=insert_minibatch)
-    out["BlockAssemblyInsertSim"] = dict(reward=r, length=l, insert_success_rate=float(insert.extras["success_buf"].float().mean()),
-                                         grasp_states=insert.grasp_states_source)
-    insert.sim.close()
-    for k, v in out.items():
-        print(k, v)
-    return out
+    out["grasp"] = st
+    # ---- stage 3: BlockAssemblyInsertSim from the harvested grasp states (IS:372-375)
+    insert, st = main_rlgames("BlockAssemblyInsertSim", num_envs, policy_path=policies.get("insert", ""), tvalue_state=tvalue_state,
+                              controller=controllers.get("insert"), seed=seed, steps=stage_steps.get("insert"),
+                              task_kwargs={"grasp_states": grasp_states})
+    st["grasp_states_source"] = insert.grasp_states_source
+    hand["insert_task"] = insert          # the caller inspects it and closes insert.sim
+    out["insert"] = st
+    out["chain_wall_s"] = time.time() - t_begin
+    steps = sum(out[k]["env_steps"] for k in ("orient", "grasp", "insert"))
+    play = sum(out[k]["wall_s"] for k in ("orient", "grasp", "insert"))
+    out["chain_env_steps"] = steps
+    out["chain_env_steps_per_s"] = steps / play                      # the three rollouts back to back (task construction excluded)
+    out["chain_env_steps_per_s_incl_setup"] = steps / out["chain_wall_s"]
+    return out, hand
 
 
 if __name__ == "__main__":
     p = argparse.ArgumentParser()
     p.add_argument("--tasks", type=str, default="BlockAssembly")
-    p.add_argument("--search", type=str, default=None)
-    p.add_argument("--orient", type=str, default="")
-    p.add_argument("--grasp", type=str, default="")
-    p.add_argument("--insert", type=str, default="")
     p.add_argument("--num_envs", type=int, default=512)
-    p.add_argument("--games", type=int, default=0)
+    p.add_argument("--orient_policy", type=str, default="")
+    p.add_argument("--grasp_policy", type=str, default="")
+    p.add_argument("--insert_policy", type=str, default="")
+    p.add_argument("--tvalue", type=str, default="", help="GraspInsertTValue state_dict (.pt) for the harvest gates")
     a = p.parse_args()
     if a.tasks != "BlockAssembly":
-        raise Exception("Unrecognized task!")
-    block_assembly(a.orient, a.grasp, a.insert, a.num_envs, a.games, search_path=a.search)
+        raise Exception("Unrecognized task!")                        # evaluation.py:121-129 (ToolPositioning: not built)
+    tv = None
+    if a.tvalue:
+        from ..tvalue_trainer import flat_from_state_dict
+        tv = flat_from_state_dict(torch.load(a.tvalue, map_location="cpu")).numpy()
+    res, h = block_assembly_chain(a.num_envs, tv, {"orient": a.orient_policy, "grasp": a.grasp_policy, "insert": a.insert_policy})
+    h["insert_task"].sim.close()
+    import json
+    print(json.dumps(res))

@@ -18,10 +18,13 @@ class BlockAssemblyGraspSim:
 
     def _scene_overrides(self, scene):
         """task-specific entries of sdx_scene_desc (hook for the other BlockAssembly* tasks)"""
-        return {}
+        return {"grasp_tvalue_gate": float(getattr(self, "harvest_tvalue_gate", 0.8))}     # GS:1406
 
     def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True,
-                 agent_index=None, is_multi_agent=False, seed=22, initial_piles=None, piles_per_type=8):
+                 agent_index=None, is_multi_agent=False, seed=22, initial_piles=None, piles_per_type=8, harvest_tvalue_gate=None):
+        """harvest_tvalue_gate: the transition value above which a finished episode's grasp state is harvested (GS:1406: 0.8)"""
+        if harvest_tvalue_gate is not None:
+            self.harvest_tvalue_gate = float(harvest_tvalue_gate)
         self.cfg = cfg
         env = cfg["env"]
         self.num_envs = env["numEnvs"]

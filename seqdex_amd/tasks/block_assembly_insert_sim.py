@@ -43,9 +43,20 @@ class BlockAssemblyInsertSim(BlockAssemblyGraspSim):
         if grasp_states is None:
             obj, hand = self.synthesize_grasp_states(synthetic_states_per_type, seed)
             self.grasp_states_source = "synthetic"
+            self.synthetic_groups = list(range(8))
         else:
             obj, hand = self._read_grasp_states(grasp_states)
+            obj, hand = list(obj), list(hand)
             self.grasp_states_source = "given"
+            # a brick-type group the grasp stage harvested nothing for cannot reset (the reference would sample an empty list, IS:1449):
+            # such groups get the synthetic stand-ins, and the task says which
+            missing = [t for t in range(8) if obj[t] is None or len(obj[t]) == 0]
+            if missing:
+                so, sh = self.synthesize_grasp_states(synthetic_states_per_type, seed)
+                for t in missing:
+                    obj[t], hand[t] = so[t], sh[t]
+                self.grasp_states_source = "given; synthetic stand-ins for the brick-type groups %s that had no harvested state" % missing
+            self.synthetic_groups = missing
         self.load_grasp_states(obj, hand)
 
     # ------------------------------------------------------------------ IS:372-375

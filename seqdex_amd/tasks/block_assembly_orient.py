@@ -21,12 +21,18 @@ class BlockAssemblyOrient(BlockAssemblyGraspSim):
     TASK_KIND = 1
     ONE_FRAME_NUM_OBS = 62                                                     # OR:191-192
 
+    def __init__(self, *args, tvalue_gate=0.99, **kw):
+        """tvalue_gate: the threshold the task binarises its transition value at (OR:1203: 0.99)"""
+        self.tvalue_gate = float(tvalue_gate)
+        super().__init__(*args, **kw)
+
     def _scene_overrides(self, scene):
         kp = [float(scene.raw["robot"]["dof"][j]["kp"]) for j in range(23)]
         effort = [float(scene.raw["robot"]["dof"][j]["effort"]) for j in range(23)]
         for j in range(7, 23):                                                 # OR:595-597
             kp[j], effort[j] = 20.0, 0.7
-        return {"kp": kp, "effort": effort, "seg_mass_scale": 50.0, "target_euler": [0.0, 3.1415, 1.571]}
+        return {"kp": kp, "effort": effort, "seg_mass_scale": 50.0, "target_euler": [0.0, 3.1415, 1.571],
+                "orient_tvalue_gate": getattr(self, "tvalue_gate", 0.99)}
 
     def pile_terminal_states(self):
         """[8, K, 132, 13] pile states harvested so far (K = the smallest fill over the 8 brick-type groups; None while one is empty):

@@ -1,0 +1,62 @@
+"""BASELINE.json configs[2] on the GPU: the Orient -> GraspSim -> InsertSim chain at 1 024 envs (seqdex_amd/scripts/evaluation.py, after the
+reference's scripts/evaluation.py:111-119).  Checks the hand-offs themselves: Orient's harvested piles are what GraspSim resets from,
+GraspSim's harvested terminal states are what InsertSim resets from - bit for bit (OR:1463-1488 -> GS:412-413,1507-1513; GS:1404-1417 ->
+IS:372-375,1449-1456)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+N = 1024
+
+
+def test_chain_hand_offs_at_1024_envs():
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from seqdex_amd.scripts.evaluation import block_assembly_chain, scripted_grasp_controller
+    from tools.bench_config3 import prepare_tvalue_and_insert_policy
+    # stage 0: the transition value of the chain's gates, fitted to InsertSim's own episode outcomes (bi_optimization.py:120-121)
+    tv, _, prep = prepare_tvalue_and_insert_policy(N, 1000, fit_iters=2000)
+    assert tv is not None, prep                                   # both outcome classes were logged and the fit ran
+    # gates at 0.5 / 0.28 instead of 0.99 (OR:1203) / 0.8 (GS:1406): a T-value fitted to a thousand epochs of outcomes tops out near 0.85 and
+    # sits at its floor sigmoid(-1) = 0.27 for most orientations; two grasp episodes
+    res, hand = block_assembly_chain(N, tv, controllers={"grasp": scripted_grasp_controller}, synthetic_fallback=True, orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28,
+                                     stage_steps={"grasp": 320})
+    ins = hand["insert_task"]
+    try:
+        # ---- hand-off 1: Orient harvested >= 8 piles for every brick-type group, and GraspSim started from them
+        assert min(res["orient"]["piles_harvested_per_type"]) >= 8, res["orient"]
+        piles = hand["piles"]
+        assert piles.shape[0] == 8 and piles.shape[1] >= 8 and tuple(piles.shape[2:]) == (132, 13)
+        assert torch.isfinite(piles).all() and float(piles[..., 3:7].norm(dim=-1).min()) > 0.99     # every slot is a filled pile state
+        # ---- hand-off 2: the grasp stage harvested real terminal states for most groups (scripted stand-in policy) ...
+        cnt = np.array(res["grasp"]["grasp_states_harvested_per_type"])
+        assert (cnt > 0).sum() >= 3 and cnt.sum() >= 20, cnt
+        real = [t for t in range(8) if cnt[t] > 0]
+        assert sorted(ins.synthetic_groups) == [t for t in range(8) if cnt[t] == 0]
+        # ... and InsertSim's reset rows ARE those states: reset every env, then compare the target brick and the hand joint by joint
+        s = ins.sim
+        mask = torch.ones(N, dtype=torch.uint8, device=s.ROOT.device)
+        s.reset_idx(mask)
+        torch.cuda.synchronize()
+        root = s.ROOT.view(N, 142, 13).cpu().numpy()
+        dof = s.DOF.view(N, 23, 2).cpu().numpy()
+        obj_h = [o.reshape(-1, 13).cpu().numpy() for o in hand["grasp_obj"]]
+        hand_h = [h.reshape(-1, 23, 2).cpu().numpy() for h in hand["grasp_hand"]]
+        checked = 0
+        for e in range(N):
+            t = e % 8
+            if t not in real:
+                continue
+            row = root[e, s.scene.seg_index(e)]
+            hit = np.nonzero((obj_h[t][:, 0:7] == row[None, 0:7]).all(axis=1))[0]
+            assert hit.size >= 1, (e, row[:7])                         # bit for bit one of the harvested brick poses of its group ...
+            assert any((hand_h[t][k, :, 0] == dof[e, :, 0]).all() for k in hit), e      # ... with that state's hand joints
+            assert (row[7:13] == 0).all() and (dof[e, :, 1] == 0).all()                # velocities zeroed (IS:1452-1456)
+            checked += 1
+        assert checked >= N // 4
+        assert res["chain_env_steps_per_s"] > 0 and res["insert"]["steps_per_env"] >= 125
+    finally:
+        ins.sim.close()

@@ -1,8 +1,17 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[2]: BlockAssemblyOrient + BlockAssemblyInsertSim chained at num_envs = 1024 on one MI355X.  Each task trains
-with its own shipped PPO schedule for `epochs` epochs (one epoch = 8 env steps x N + the update); Orient's harvested pile states
-are what the next stage would load (printed K); InsertSim starts from its synthetic grasp states (no GraspSim stage in this config).
-Prints one JSON line.  usage: python tools/bench_config3.py [N] [epochs]"""
+"""BASELINE.json configs[2]: BlockAssemblyOrient -> BlockAssemblyGraspSim -> BlockAssemblyInsertSim as ONE chained rollout at num_envs = 1024
+on one MI355X, the stages handing over their harvested terminal states (seqdex_amd/scripts/evaluation.py, after the reference's
+scripts/evaluation.py:111-119; harvest rules OR:1463-1488, GS:1404-1417; InsertSim's reset from them IS:372-375).
+
+stage 0 (untimed; the backward pass of scripts/bi_optimization.py:120-121 in small): BlockAssemblyInsertSim trains `prep_epochs` epochs with its
+    shipped schedule from synthetic grasp states, its episode outcomes fill the T-value rings, GraspInsertTValue is fitted to them -> the
+    transition value that gates the harvests of the chain (policy_sequencing's T-value switch), and the insert policy of stage 3.
+stage 1 Orient (random-initialised policy: its arm is scripted by the task, OR:1720-1778) plays until every brick-type group has >= 8 piles;
+    its T-value gate is lowered from 0.99 (OR:1203) to 0.5: a T-value fitted to a thousand epochs of outcomes tops out near 0.85,
+stage 2 GraspSim starts from those piles (two episodes; harvest gate 0.28 instead of 0.8, GS:1406, for the same reason); a scripted stand-in
+    controller replaces the 19 000-epoch grasp policy (evaluation.py docstring); groups it harvests nothing for get InsertSim's synthetic states,
+stage 3 InsertSim resets from the harvested grasp states and plays one episode.
+value = env-steps of the three rollouts / their wall time.  Prints one JSON line.   usage: python tools/bench_config3.py [N] [prep_epochs]"""
 import json
 import os
 import sys
@@ -15,39 +24,59 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from seqdex_amd.a2c_agent import A2CAgent  # noqa: E402
 from seqdex_amd.config import TASK_CFG, TRAIN_CFG  # noqa: E402
+from seqdex_amd.scripts.evaluation import block_assembly_chain, scripted_grasp_controller  # noqa: E402
 from seqdex_amd.tasks.block_assembly_insert_sim import BlockAssemblyInsertSim  # noqa: E402
-from seqdex_amd.tasks.block_assembly_orient import BlockAssemblyOrient  # noqa: E402
+from seqdex_amd.tvalue_trainer import TValue_Trainer, flat_from_state_dict  # noqa: E402
 from seqdex_amd.vec_task_rlgames import RLgamesVecTaskPython  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-out = {"config": "BASELINE.json configs[2]: Orient -> InsertSim chained, num_envs=%d, 1 GPU" % n, "epochs_per_task": epochs}
-for name, cls in (("BlockAssemblyOrient", BlockAssemblyOrient), ("BlockAssemblyInsertSim", BlockAssemblyInsertSim)):
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd", TASK_CFG[name])))
+
+def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None):
+    """stage 0: returns (flat T-value weights or None, insert checkpoint path or "", statistics)"""
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd", TASK_CFG["BlockAssemblyInsertSim"])))
     cfg["env"]["numEnvs"] = n
-    tr = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd", TRAIN_CFG[name])))
-    task = cls(cfg, device_type="cuda", device_id=0, headless=True, seed=22, piles_per_type=8)
+    tr = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd", TRAIN_CFG["BlockAssemblyInsertSim"])))
+    task = BlockAssemblyInsertSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed)
     env = RLgamesVecTaskPython(task, "cuda:0")
-    tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22)
+    tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=seed)
     agent = A2CAgent("run", tr["params"])
-    agent.train_epoch()                                   # warm-up (first step = reset of every env)
-    torch.cuda.synchronize()
     t0 = time.time()
-    step_t = play_t = upd_t = 0.0
     for _ in range(epochs):
-        r = agent.train_epoch()
-        step_t += r[0]; play_t += r[1]; upd_t += r[2]
+        agent.train_epoch()
     torch.cuda.synchronize()
-    dt = time.time() - t0
-    e = {"env_steps_per_s": n * 8 * epochs / dt, "fps_step": n * 8 * epochs / step_t, "rollout_ms_per_epoch": play_t / epochs * 1e3,
-         "update_ms_per_epoch": upd_t / epochs * 1e3, "minibatch_size": agent.minibatch_size, "update_impl": agent.ppo.update_impl(),
-         "episode_length": int(task.max_episode_length), "mean_reward": float(task.rew_buf.mean().item())}
-    if name == "BlockAssemblyOrient":
-        piles = task.pile_terminal_states()
-        e["harvested_piles_per_type"] = 0 if piles is None else int(piles.shape[1])
-        e["note"] = "an episode is 75 steps; its reset event costs 103 extra simulator steps of all envs (two scripted 50-step phases, OR:1427-1461,1655-1695)"
-    out[name] = e
-    del agent, env, task
-    torch.cuda.empty_cache()
-out["chain_env_steps_per_s"] = 2.0 / (1.0 / out["BlockAssemblyOrient"]["env_steps_per_s"] + 1.0 / out["BlockAssemblyInsertSim"]["env_steps_per_s"])
-print(json.dumps(out))
+    st = {"epochs": epochs, "wall_s": time.time() - t0, "game_reward": agent.game_rewards.get_mean()[0],
+          "outcomes_logged(success, failure)": task.sim.TV_COUNT.cpu().tolist()}
+    path = ""
+    if save_to:
+        agent.save(save_to)
+        path = save_to + ".pth"
+    tv = None
+    try:
+        trn = TValue_Trainer.from_task(task, seed=seed)
+        trn.init_TValue_function("BlockAssemblyInsertSim", fit_iters)
+        trn.train_rollout()
+        st["tvalue_fit"] = {"iterations": fit_iters, "loss": trn.losses[-1], "held_out_success_rate": trn.valid_t_value_success_rate}
+        tv = flat_from_state_dict(trn.state_dict()).numpy()
+        trn.close()
+    except ValueError as ex:
+        st["tvalue_fit"] = "skipped: %s" % ex
+    agent.ppo.close()
+    task.sim.close()
+    return tv, path, st
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    prep = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, save_to=os.path.join(ROOT, "gpurun_out", "config3_insert_policy"))
+    print("stage 0:", json.dumps(prep_st), file=sys.stderr, flush=True)
+    res, hand = block_assembly_chain(n, tv, policies={"insert": insert_ckpt}, controllers={"grasp": scripted_grasp_controller},
+                                     synthetic_fallback=True, orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28,
+                                     stage_steps={"grasp": 320})
+    ins = hand["insert_task"]
+    res["insert"]["synthetic_groups"] = ins.synthetic_groups
+    ins.sim.close()
+    out = {"config": "BASELINE.json configs[2]: BlockAssemblyOrient -> BlockAssemblyGraspSim -> BlockAssemblyInsertSim chained rollout, num_envs=%d, 1 GPU" % n,
+           "metric": "env-steps/s of the chained rollout (play, no update)", "value": res["chain_env_steps_per_s"], "unit": "env-steps/s",
+           "stage0_tvalue_and_insert_policy(untimed)": prep_st, "chain": res}
+    print(json.dumps(out))
