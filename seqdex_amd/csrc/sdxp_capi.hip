@@ -14,6 +14,8 @@
 
 extern "C" {
 void sdxpk_linear(const float*, const float*, const float*, float*, int, int, int, int, const double*, const double*, hipStream_t);
+void sdxpk_linear2(const float*, const float*, const float*, float*, int, int, const double*, const double*,
+                   const float*, const float*, const float*, float*, int, int, const double*, const double*, int, int, hipStream_t);
 void sdxpk_act_heads(const SdxpDev*, int, const float*, const float*, const int64_t*, const float*, float*, uint64_t, hipStream_t);
 void sdxpk_store_rewards(const SdxpDev*, int, const float*, const int64_t*, hipStream_t);
 void sdxpk_value_head(const SdxpDev*, float*, hipStream_t);
@@ -352,14 +354,28 @@ static void trunk_forward(sdxp_agent* h, int net, const float* x, int M, hipStre
   }
 }
 
+// actor and central-value trunks side by side: the same layer of both networks is ONE launch (3 launches per env step instead of 6)
+static void trunk_forward2(sdxp_agent* h, const float* obs, const float* states, int M, hipStream_t st) {
+  const SdxpDev& D = h->D;
+  const float* xa = obs; const float* xv = states;
+  int ina = D.obs_dim, inv = D.state_dim;
+  for (int l = 0; l < 3; ++l) {
+    const bool norm = (l == 0 && D.cv_normalize_input);
+    sdxpk_linear2(xa, D.ac + D.off.a_w[l], D.ac + D.off.a_b[l], D.h_a[l], D.units[l], ina, nullptr, nullptr,
+                  xv, D.cv + D.coff.w[l], D.cv + D.coff.b[l], D.h_v[l], D.units[l], inv, norm ? D.rms_mean : nullptr, norm ? D.rms_var : nullptr,
+                  M, 1, st);
+    xa = D.h_a[l]; xv = D.h_v[l];
+    ina = inv = D.units[l];
+  }
+}
+
 extern "C" int sdxp_act(sdxp_handle h, int32_t t, const float* obs_dev, const float* states_dev, const int64_t* dones_dev,
                         const float* eps_dev, float* actions_out_dev, void* stream) {
   if (!h || !obs_dev || !states_dev || !actions_out_dev || t < 0 || t >= h->D.horizon) { if (h) h->err = "sdxp_act: bad argument"; return SDX_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   if (t == 0) hipLaunchKernelGGL(k_ctrl_begin_rollout, dim3(1), dim3(1), 0, st, h->D.ctrl);
   if (h->D.obs_cols != h->D.obs_dim) { sdxpk_pad_obs(&h->D, obs_dev, st); obs_dev = h->D.obs_pad; }
-  trunk_forward(h, 0, obs_dev, h->D.N, st);
-  trunk_forward(h, 2, states_dev, h->D.N, st);
+  trunk_forward2(h, obs_dev, states_dev, h->D.N, st);
   sdxpk_act_heads(&h->D, t, obs_dev, states_dev, dones_dev, eps_dev, actions_out_dev, h->act_counter++, st);
   return plaunch_ok(h, "sdxp_act");
 }

@@ -43,58 +43,112 @@ __device__ __forceinline__ float lane0(float v) { return __builtin_bit_cast(floa
 // ------------------------------------------------------------------------------------------------ rollout GEMM
 // Y[M,N] = act(X[M,K] W[N,K]^T + b[N]); act = ELU when elu_flag.  X may be normalised on the fly with (mean, rstd)
 // (central-value running mean/std, clamp +-5; App. C of SURVEY.md).  K % 4 == 0.
+// One launch serves up to TWO such products (blockIdx.z): the same layer of the actor and of the central-value trunk during a rollout.
+// 64 x 64 output tile per workgroup (4 waves, one 32 x 32 v_mfma_f32_32x32x2_f32 tile each), reduction chunks of 32.  The operands of chunk
+// c + 2 are in flight from HBM / L2 (registers) while chunk c is multiplied out of one LDS buffer and chunk c + 1 is written into the other:
+// ONE barrier per chunk and two chunks of load latency hidden.  (Round 2's kernel loaded, stored, synchronised and multiplied one
+// 16-wide chunk at a time: 25 dependent round trips for the 396-wide first layer, 35 us per launch, 6 launches per env step.)
 #define GT 64
-#define GK 16
-__global__ __launch_bounds__(256) void k_linear_mfma(const float* __restrict__ X, const float* __restrict__ W,
-                                                     const float* __restrict__ b, float* __restrict__ Y, int M, int N,
-                                                     int K, int elu_flag, const double* __restrict__ nmean,
-                                                     const double* __restrict__ nvar) {
-  __shared__ float Xs[GT][GK + 1];
-  __shared__ float Ws[GT][GK + 1];
+#define GK 32
+struct LinArgs { const float* X; const float* W; const float* b; float* Y; int M, N, K, elu; const double* nmean; const double* nvar; };
+struct LinBatch { LinArgs a[2]; };
+// WTM = 1: 64 x 64 tile (wave = 32 x 32); WTM = 2: 128 x 64 tile (wave = 64 x 32: two MFMAs share one W operand - 21 instead of 16 flops
+// per operand byte fetched from L2, which is what bounds these small products: a 64 x 64 tile at the fp32 matrix peak would need 10 TB/s)
+template <int WTM>
+__global__ __launch_bounds__(256) void k_linear_mfma(LinBatch lb) {
+  constexpr int TM = GT * WTM, NX = 2 * WTM;       // rows of X per tile, float4 loads of X per thread and chunk
+  __shared__ float Xs[2][TM][GK + 1];
+  __shared__ float Ws[2][GT][GK + 1];
+  const LinArgs& g = lb.a[blockIdx.z];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  f32x16 acc;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GT;
+  const int M = g.M, N = g.N, K = g.K;
+  if (m0 >= M || n0 >= N) return;                 // the grid covers the larger problem of the batch
+  const int wm = (wave >> 1) * 32 * WTM, wn = (wave & 1) * 32;
+  f32x16 acc[WTM];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  const int lr = tid >> 2, lk = (tid & 3) * 4;  // this thread stages row lr, k-offset lk of both tiles
-  for (int k0 = 0; k0 < K; k0 += GK) {
-    float4 xv = make_float4(0, 0, 0, 0), wv = make_float4(0, 0, 0, 0);
-    if (m0 + lr < M && k0 + lk < K) {
-      xv = *reinterpret_cast<const float4*>(X + (size_t)(m0 + lr) * K + k0 + lk);
-      if (nmean) {
-        float* xp = reinterpret_cast<float*>(&xv);
+  for (int u = 0; u < WTM; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float mu = (float)nmean[k0 + lk + j], var = (float)nvar[k0 + lk + j];
-          xp[j] = clampf((xp[j] - mu) / sqrtf(var + 1e-5f), -5.0f, 5.0f);
+    for (int i = 0; i < 16; ++i) acc[u][i] = 0.0f;
+  // element e = tid + 256 p of a chunk: row e / 8, k offset 4 (e % 8): consecutive lanes read consecutive 16-byte pieces of a row
+  float4 xv[2][NX], wv[2][2];
+  auto fetch = [&](int k0, float4 (&xr)[NX], float4 (&wr)[2]) {
+#pragma unroll
+    for (int p = 0; p < NX; ++p) {
+      const int e = tid + 256 * p, r = e >> 3, k = k0 + 4 * (e & 7);
+      xr[p] = make_float4(0, 0, 0, 0);
+      if (m0 + r < M && k < K) {
+        xr[p] = *reinterpret_cast<const float4*>(g.X + (size_t)(m0 + r) * K + k);
+        if (g.nmean) {
+          float* xp = reinterpret_cast<float*>(&xr[p]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xp[j] = clampf((xp[j] - (float)g.nmean[k + j]) / sqrtf((float)g.nvar[k + j] + 1e-5f), -5.0f, 5.0f);
         }
       }
     }
-    if (n0 + lr < N && k0 + lk < K) wv = *reinterpret_cast<const float4*>(W + (size_t)(n0 + lr) * K + k0 + lk);
-    __syncthreads();
-    Xs[lr][lk] = xv.x; Xs[lr][lk + 1] = xv.y; Xs[lr][lk + 2] = xv.z; Xs[lr][lk + 3] = xv.w;
-    Ws[lr][lk] = wv.x; Ws[lr][lk + 1] = wv.y; Ws[lr][lk + 2] = wv.z; Ws[lr][lk + 3] = wv.w;
-    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int e = tid + 256 * p, r = e >> 3, k = k0 + 4 * (e & 7);
+      wr[p] = make_float4(0, 0, 0, 0);
+      if (n0 + r < N && k < K) wr[p] = *reinterpret_cast<const float4*>(g.W + (size_t)(n0 + r) * K + k);
+    }
+  };
+  auto stage = [&](int buf, const float4 (&xr)[NX], const float4 (&wr)[2]) {
+#pragma unroll
+    for (int p = 0; p < NX; ++p) {
+      const int e = tid + 256 * p, r = e >> 3, k = 4 * (e & 7);
+      float* dx = &Xs[buf][r][k]; dx[0] = xr[p].x; dx[1] = xr[p].y; dx[2] = xr[p].z; dx[3] = xr[p].w;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int e = tid + 256 * p, r = e >> 3, k = 4 * (e & 7);
+      float* dw = &Ws[buf][r][k]; dw[0] = wr[p].x; dw[1] = wr[p].y; dw[2] = wr[p].z; dw[3] = wr[p].w;
+    }
+  };
+  const int nchunk = (K + GK - 1) / GK;
+  fetch(0, xv[0], wv[0]);
+  if (nchunk > 1) fetch(GK, xv[1], wv[1]);
+  stage(0, xv[0], wv[0]);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    // registers: slot c & 1 is free (chunk c is in LDS), slot (c + 1) & 1 holds chunk c + 1
+    if (c + 2 < nchunk) { if (c & 1) fetch((c + 2) * GK, xv[1], wv[1]); else fetch((c + 2) * GK, xv[0], wv[0]); }
+    const int buf = c & 1;
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 2) {
-      const float a = Xs[wm + (lane & 31)][kk + (lane >> 5)];
-      const float bb = Ws[wn + (lane & 31)][kk + (lane >> 5)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+      const float bb = Ws[buf][wn + (lane & 31)][kk + (lane >> 5)];
+#pragma unroll
+      for (int u = 0; u < WTM; ++u) {
+        const float a = Xs[buf][wm + 32 * u + (lane & 31)][kk + (lane >> 5)];
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[u], 0, 0, 0);
+      }
     }
+    if (c + 1 < nchunk) { if (c & 1) stage(buf ^ 1, xv[0], wv[0]); else stage(buf ^ 1, xv[1], wv[1]); }   // chunk c + 1 into the other buffer
+    __syncthreads();
   }
   const int col = n0 + wn + (lane & 31);
   if (col < N) {
-    const float bias = b[col];
+    const float bias = g.b[col];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < M) {
-        float v = acc[r] + bias;
-        Y[(size_t)row * N + col] = elu_flag ? elu(v) : v;
+    for (int u = 0; u < WTM; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) {
+          const float v = acc[u][r] + bias;
+          g.Y[(size_t)row * N + col] = g.elu ? elu(v) : v;
+        }
       }
-    }
   }
+}
+static void launch_linear(const LinBatch& lb, int count, int M, int Nx, hipStream_t st) {
+  // 64 x 64 tiles up to 2048 rows, 128 x 64 beyond; SDXP_LINEAR_TILE=1|2 forces one (timing aid).  Measured at M = 1024 (tools/time_act.py,
+  // profiles/r3_act_pmc.csv): 143 us per sdxp_act with 64 x 64 tiles, 206 us with 128 x 64 - at this size the layers are bound by the
+  // latency of their 13-32 dependent chunks (waves wait 52 % of their cycles, the matrix pipe is 26 % busy), not by operand bandwidth
+  static const int forced = getenv("SDXP_LINEAR_TILE") ? atoi(getenv("SDXP_LINEAR_TILE")) : 0;
+  const bool big = forced ? forced == 2 : M > 2048;
+  if (big) hipLaunchKernelGGL(k_linear_mfma<2>, dim3((Nx + GT - 1) / GT, (M + 2 * GT - 1) / (2 * GT), count), dim3(256), 0, st, lb);
+  else hipLaunchKernelGGL(k_linear_mfma<1>, dim3((Nx + GT - 1) / GT, (M + GT - 1) / GT, count), dim3(256), 0, st, lb);
 }
 
 // counter-based standard normal (Box-Muller on two hashed uniforms)
@@ -1159,8 +1213,20 @@ __global__ void k_apply_fin(SdxpDev D, int which, float kl_host) {
 // ------------------------------------------------------------------------------------------------ launch helpers
 extern "C" void sdxpk_linear(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int elu_flag,
                              const double* nmean, const double* nvar, hipStream_t st) {
-  dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT);
-  hipLaunchKernelGGL(k_linear_mfma, grid, dim3(256), 0, st, X, W, b, Y, M, N, K, elu_flag, nmean, nvar);
+  LinBatch lb;
+  lb.a[0] = LinArgs{X, W, b, Y, M, N, K, elu_flag, nmean, nvar};
+  lb.a[1] = lb.a[0];
+  launch_linear(lb, 1, M, N, st);
+}
+// two independent products in one launch (the same layer of the actor and of the central-value trunk)
+extern "C" void sdxpk_linear2(const float* X0, const float* W0, const float* b0, float* Y0, int N0, int K0, const double* nmean0, const double* nvar0,
+                              const float* X1, const float* W1, const float* b1, float* Y1, int N1, int K1, const double* nmean1, const double* nvar1,
+                              int M, int elu_flag, hipStream_t st) {
+  LinBatch lb;
+  lb.a[0] = LinArgs{X0, W0, b0, Y0, M, N0, K0, elu_flag, nmean0, nvar0};
+  lb.a[1] = LinArgs{X1, W1, b1, Y1, M, N1, K1, elu_flag, nmean1, nvar1};
+  const int Nx = N0 > N1 ? N0 : N1;
+  launch_linear(lb, 2, M, Nx, st);
 }
 extern "C" void sdxpk_act_heads(const SdxpDev* D, int t, const float* obs, const float* states, const int64_t* dones,
                                 const float* eps, float* actions_out, uint64_t counter, hipStream_t st) {

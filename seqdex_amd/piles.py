@@ -10,7 +10,8 @@ import torch
 
 def generate_piles(per_type=8, steps=150, device="cuda:0", seed=22):
     from .sim import SdxSim
-    n = 8 * per_type
+    n_out = 8 * per_type
+    n = ((int(n_out * 1.4) + 7) // 8) * 8          # 40 % spare: a fifth of the dropped piles loses a brick over the bin wall (below)
     sim = SdxSim(n, device=device, seed=seed)
     try:
         sc = sim.scene
@@ -35,18 +36,18 @@ def generate_piles(per_type=8, steps=150, device="cuda:0", seed=22):
         torch.cuda.synchronize()
         piles = sim.ROOT.view(n, 142, 13)[:, 9:141].clone()
         piles[:, :, 7:13] = 0.0
-        # a brick in a few thousand bounces out of the bin on the way down (tools/drop_bricks.py: 48 of 73 728); a pile that lost one is
-        # replaced by a copy of the next complete pile, so that every saved state has its 72 free bricks over the bin (a few still lie on the parked hand:
-        # they drop into the pile when a reset moves the hand away)
+        # a pile in five loses a brick over the 10 cm bin wall while the lattice collapses (tools/drop_bricks.py: 133 of 73 728 bricks with the
+        # lattice starting above the floor); only complete piles are kept - 40 % more than needed are dropped - and should fewer survive,
+        # the rest are copies of complete ones, so that every saved state has its 72 free bricks over the bin (a few still lie on the parked
+        # hand: they drop into the pile when a reset moves the hand away)
         fb = piles[:, :72, 0:3]
         inside = ((fb[:, :, 0] - 0.25).abs() < 0.3) & ((fb[:, :, 1] - 0.19).abs() < 0.21) & (fb[:, :, 2] > 0.55)
         good = inside.all(dim=1)
         if not bool(good.any()):
             raise RuntimeError("generate_piles: no pile kept all its bricks inside the bin")
         gi = torch.nonzero(good).flatten()
-        for b in torch.nonzero(~good).flatten().tolist():
-            src = gi[torch.searchsorted(gi, torch.tensor(b, device=gi.device)) % len(gi)]
-            piles[b] = piles[src]
+        pick = gi[torch.arange(n_out, device=gi.device) % len(gi)]          # the first n_out complete piles (wrapping around if fewer)
+        piles = piles[pick]
         # env i of the generator uses type group i % 8 only as a label: piles are exchangeable across groups
         out = piles.view(per_type, 8, 132, 13).permute(1, 0, 2, 3).contiguous().cpu().numpy()
         assert np.isfinite(out).all()

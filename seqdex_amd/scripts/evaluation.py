@@ -180,6 +180,61 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     return out, hand
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the checkpoint-driven form (round 2): every stage through the launcher's own argument parsing, optional BlockAssemblySearch stage first
+def _launcher():
+    from ..config import get_args
+    from ..train_rlgames import build
+    return get_args, build
+
+
+def play_checkpoint(task, num_envs, play=True, use_t_value=False, policy_path="", games=0, task_kwargs=None, minibatch_size=0):
+    """evaluation.py:36-103 for one stage through the reference's command line (--task --num_envs --checkpoint --play; seqdex_amd.train_rlgames.build):
+    the sub-policy is restored from its checkpoint and played for `games` finished episodes.  Returns (mean episode reward, mean episode length, task object)."""
+    argv = ["--task=%s" % task, "--num_envs=%d" % num_envs, "--headless", "--play"]
+    if policy_path:
+        argv.append("--checkpoint=%s" % policy_path)
+    get_args, build = _launcher()
+    args = get_args(argv)
+    args.use_t_value = use_t_value
+    task_obj, env, agent, logdir, rank = build(args, task_kwargs, minibatch_size)
+    agent.play(games or num_envs)
+    torch.cuda.synchronize()
+    rew, length = float(agent.game_rewards.get_mean()[0]), float(agent.game_lengths.get_mean()[0])
+    agent.ppo.close()
+    return rew, length, task_obj
+
+
+def block_assembly(orient_path, grasp_path, insert_path, num_envs=512, games=0, insert_minibatch=0, search_path=None):
+    out = {}
+    dug = None
+    if search_path is not None:
+        r, l, search = play_checkpoint("BlockAssemblySearch", min(num_envs, 128), use_t_value=True, policy_path=search_path, games=games)
+        dug = search.pile_terminal_states()
+        out["BlockAssemblySearch"] = dict(reward=r, length=l, search_success_rate=float(search.extras["success_buf"].float().mean()),
+                                          piles_handed_on=0 if dug is None else int(dug.shape[1]))
+        search.sim.close()
+    r, l, orient = play_checkpoint("BlockAssemblyOrient", num_envs, use_t_value=True, policy_path=orient_path, games=games,
+                                task_kwargs={"initial_piles": dug})
+    piles = orient.pile_terminal_states()
+    out["BlockAssemblyOrient"] = dict(reward=r, length=l, piles_handed_on=0 if piles is None else int(piles.shape[1]))
+    orient.sim.close()
+    r, l, grasp = play_checkpoint("BlockAssemblyGraspSim", num_envs, use_t_value=True, policy_path=grasp_path, games=games,
+                               task_kwargs={"initial_piles": piles})
+    cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
+    states = grasp.grasp_terminal_states() if cnt.min() > 0 else None
+    out["BlockAssemblyGraspSim"] = dict(reward=r, length=l, grasp_states_handed_on=int(cnt.sum()))
+    grasp.sim.close()
+    r, l, insert = play_checkpoint("BlockAssemblyInsertSim", num_envs, use_t_value=True, policy_path=insert_path, games=games,
+                                task_kwargs={"grasp_states": states}, minibatch_size=insert_minibatch)
+    out["BlockAssemblyInsertSim"] = dict(reward=r, length=l, insert_success_rate=float(insert.extras["success_buf"].float().mean()),
+                                         grasp_states=insert.grasp_states_source)
+    insert.sim.close()
+    for k, v in out.items():
+        print(k, v)
+    return out
+
+
 if __name__ == "__main__":
     p = argparse.ArgumentParser()
     p.add_argument("--tasks", type=str, default="BlockAssembly")
