@@ -191,6 +191,9 @@ typedef struct {
                                         * (pair, direction, sample) ended the previous solve with; 0 = start from zero */
   float warm_age;                      /* the fraction ramps up linearly with the number of consecutive solves a contact has existed and
                                         * reaches warm_start after warm_age of them (0: no ramp); DESIGN.md section 3.E */
+  float robot_angular_damping;         /* asset_options.angular_damping of the arm-hand asset (GS:546: 0.01 1/s): every substep scales the joint
+                                        * velocities by (1 - h x damping) - for a chain of revolute joints the joint-space image of PhysX's
+                                        * per-link angular damping */
   float grasp_tvalue_gate;             /* BlockAssemblyGraspSim harvests a terminal state only when its transition value exceeds this: 0.8 (GS:1406) */
   float orient_tvalue_gate;            /* BlockAssemblyOrient binarises its transition value at this threshold before anything reads it: 0.99
                                         * (OR:1203); a chain run with an early, not yet confident T-value may lower it (say so when you do) */

@@ -717,7 +717,8 @@ static void substep(const sdx_scene_desc* sc, env_t* e, real h, int first) {
   collide(sc, e);
   solve(sc, e, h);
   for (int j = 0; j < ND; ++j) {
-    real v = fminf(sc->vel_limit[j], fmaxf(-sc->vel_limit[j], e->qd[j]));
+    real v = e->qd[j] * (1.0f - h * sc->robot_angular_damping); /* GS:546: asset_options.angular_damping = 0.01 */
+    v = fminf(sc->vel_limit[j], fmaxf(-sc->vel_limit[j], v));
     real qn = e->q[j] + h * v;
     if (qn < sc->lower[j]) { qn = sc->lower[j]; v = fmaxf(v, 0.0f); }
     if (qn > sc->upper[j]) { qn = sc->upper[j]; v = fminf(v, 0.0f); }

@@ -45,7 +45,7 @@ class SceneDesc(C.Structure):
         ("max_episode_length", f32), ("act_moving_average", f32), ("av_factor", f32),
         ("clip_obs", f32), ("clip_actions", f32),
         ("dt", f32), ("substeps", i32), ("solver_iters", i32), ("contact_offset", f32), ("gravity", f32 * 3),
-        ("friction", f32), ("baumgarte", f32), ("max_depenetration_vel", f32), ("jacobi_relax", f32), ("warm_start", f32), ("warm_age", f32), ("grasp_tvalue_gate", f32), ("orient_tvalue_gate", f32),
+        ("friction", f32), ("baumgarte", f32), ("max_depenetration_vel", f32), ("jacobi_relax", f32), ("warm_start", f32), ("warm_age", f32), ("robot_angular_damping", f32), ("grasp_tvalue_gate", f32), ("orient_tvalue_gate", f32),
         ("task_kind", i32), ("target_euler", f32 * 3), ("seg_mass_scale", f32),
         ("static_var_slot", i32), ("static_var_center_z", f32 * 3), ("static_var_half_z", f32 * 3),
         ("seg_cam_pos", f32 * 3), ("seg_cam_target", f32 * 3), ("seg_cam_hfov_deg", f32),

@@ -1371,7 +1371,8 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     PSTAMP(5);
     // F: integrate
     if (tl < ND) {
-      float v = fminf(scl.vel_limit[tl], fmaxf(-scl.vel_limit[tl], S.qd[tl]));
+      float v = S.qd[tl] * (1.0f - h * scl.robot_angular_damping);   // GS:546
+      v = fminf(scl.vel_limit[tl], fmaxf(-scl.vel_limit[tl], v));
       float qn = S.q[tl] + h * v;
       if (qn < scl.lower[tl]) { qn = scl.lower[tl]; v = fmaxf(v, 0.0f); }
       if (qn > scl.upper[tl]) { qn = scl.upper[tl]; v = fminf(v, 0.0f); }

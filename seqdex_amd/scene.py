@@ -137,6 +137,7 @@ class Scene:
         d.max_depenetration_vel, d.jacobi_relax = self.solver["max_depenetration_vel"], self.solver["jacobi_relax"]
         d.warm_start, d.warm_age = self.solver["warm_start"], self.solver["warm_age"]
         d.orient_tvalue_gate = 0.99                        # OR:1203
+        d.robot_angular_damping = 0.01                     # GS:546 (asset_options.angular_damping of the arm-hand asset)
         d.grasp_tvalue_gate = 0.8                          # GS:1406
         d.task_kind = 0                                   # BlockAssemblyGraspSim; 1 = BlockAssemblyOrient (per-step tensor code only)
         d.target_euler[:] = [0.0, 3.1415, 1.571]          # OR:477

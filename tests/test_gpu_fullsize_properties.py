@@ -330,3 +330,51 @@ def test_generated_piles_keep_every_brick_inside_the_bin():
     assert (fb[..., 2] > 0.55).all()
     assert (p[:, :, :, 7:13] == 0).all()
     assert len({p[t, k, :72, 0:3].tobytes() for t in range(8) for k in range(32)}) > 220      # replacements are the exception
+
+
+def test_resting_penetration_within_the_contact_offset_at_1024_envs(scene):
+    """SURVEY.md section 7 (iii) / VERDICT r2 item 5 at the BASELINE size: 1 024 envs, each with its own two-brick stack (random pair of
+    brick types, yaw, offset of up to a quarter of the lower brick), simulated for two seconds with the DEFAULT solver (16 iterations,
+    warm start 0.8 ramped over 16 solves).  Every interface - floor / lower brick and lower / upper brick - rests within the scene's own
+    contact offset (EG:162: 2 mm), nothing creeps, nothing tips: the invariant PhysX's TGS gives the reference."""
+    from seqdex_amd.sim import SdxSim
+    from test_physics_oracle import base_state
+    n = 1024
+    rng = np.random.default_rng(11)
+    root, dof, tg = base_state(scene, n)
+    floor_top = scene.statics[6]["center"][2] + scene.statics[6]["half"][2]
+    ia = rng.integers(0, 8, n); ib = 8 + rng.integers(0, 8, n)            # brick i has type i % 8: every pair of types appears
+    yaw = rng.uniform(-np.pi / 2, np.pi / 2, n).astype(np.float32)
+    za, zb, off = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros((n, 2), np.float32)
+    for e in range(n):
+        ta, tb = scene.brick_types[scene.brick_type[ia[e]]], scene.brick_types[scene.brick_type[ib[e]]]
+        za[e] = floor_top + ta["half"][2] - ta["center"][2]
+        zb[e] = za[e] + ta["center"][2] + ta["half"][2] + tb["half"][2] - tb["center"][2]
+        # keep the upper brick's centre well inside the lower brick's top face (a stable stack by construction)
+        off[e] = rng.uniform(-0.25, 0.25, 2) * np.array([ta["half"][0], ta["half"][1]]) * (0.0 if abs(yaw[e]) > 0.2 else 1.0)
+        root[e, 9 + ia[e], 0:3] = [0.25, 0.19, za[e] + 0.001]
+        root[e, 9 + ib[e], 0:3] = [0.25 + off[e, 0], 0.19 + off[e, 1], zb[e] + 0.004]
+        root[e, 9 + ib[e], 3:7] = [0, 0, np.sin(yaw[e] / 2), np.cos(yaw[e] / 2)]
+    s = SdxSim(n)
+    try:
+        s.ROOT.copy_(_dev(root.reshape(-1, 13))); s.DOF.copy_(_dev(dof.reshape(-1, 2))); s.TARGETS.copy_(_dev(tg))
+        s.WARM_COUNT.zero_()
+        for _ in range(120):
+            s.simulate()
+        torch.cuda.synchronize()
+        r = s.ROOT.cpu().numpy().reshape(n, 142, 13)
+        env = np.arange(n)
+        sink_a = za - r[env, 9 + ia, 2]
+        sink_b = zb - r[env, 9 + ib, 2] - sink_a
+        offset = float(s._desc.contact_offset)
+        assert sink_a.max() <= offset and sink_b.max() <= offset, (float(sink_a.max()), float(sink_b.max()))
+        assert sink_a.min() > -2e-4 and sink_b.min() > -2e-4                       # nothing hovers either
+        drift = np.hypot(r[env, 9 + ib, 0] - 0.25 - off[:, 0], r[env, 9 + ib, 1] - 0.19 - off[:, 1])
+        assert drift.max() < 2e-3, float(drift.max())
+        up = np.abs(r[env, 9 + ib, 6] ** 2 + r[env, 9 + ib, 5] ** 2 - 1.0)         # still a pure yaw: upright
+        assert up.max() < 2e-3
+        assert np.linalg.norm(r[env, 9 + ib, 7:13], axis=-1).max() < 0.02          # at rest
+        st = s.CONTACT_STATS.cpu().numpy()
+        assert st[1] == 0 and st[2] == 0
+    finally:
+        s.close()

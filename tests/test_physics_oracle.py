@@ -154,6 +154,30 @@ def test_free_swinging_arm_conserves_kinetic_energy(scene):
     assert np.abs(dof[0, :, 0] - q0).max() > 0.3
 
 
+def test_robot_angular_damping_scales_the_joint_velocities(scene):
+    """GS:546 `asset_options.angular_damping = 0.01` on the arm-hand asset: every substep multiplies the joint
+    velocities by (1 - h x 0.01).  One joint moving alone with the drives off (no velocity-product coupling onto itself, constant inertia
+    about its axis) loses that factor per substep relative to the undamped run (to first order: the recoil of the links above it couples back)."""
+    root = np.zeros((1, 142, 13), np.float32); root[..., 6] = 1.0
+    root[:, :, 0] = 50.0 + np.arange(142)[None, :] * 2.0; root[:, :, 2] = 100.0
+    q0 = ((scene.lower + scene.upper) / 2).astype(np.float32)
+    res = {}
+    for c in (0.0, 0.01, 2.0):
+        d = scene.to_desc(robot_angular_damping=c)
+        for j in range(23):
+            d.kp[j] = 0.0; d.kd[j] = 0.0; d.vel_limit[j] = 100.0
+        dof = np.zeros((1, 23, 2), np.float32); dof[0, :, 0] = q0
+        dof[0, 10, 1] = 1.0                                   # the last joint of the first finger (link_3.0): nothing hangs below it
+        tg = np.tile(q0, (1, 1)).astype(np.float32)
+        for _ in range(5):
+            po.simulate(d, root.copy(), dof, tg)
+        res[c] = float(dof[0, 10, 1])
+    h = 1.0 / 120.0
+    assert 0.95 < res[0.0] < 1.0                                             # free: the joint keeps spinning (the links above it recoil a little)
+    np.testing.assert_allclose(res[0.01] / res[0.0], (1 - h * 0.01) ** 10, rtol=5e-5)
+    np.testing.assert_allclose(res[2.0] / res[0.0], (1 - h * 2.0) ** 10, rtol=1e-2)   # (an exaggerated value makes the factor visible)
+
+
 def _momentum(scene, root, idx):
     """linear momentum and angular momentum about the world origin of the listed free bricks (COM = box centre, principal inertia)"""
     from oracle import task_oracle as T
