@@ -356,6 +356,7 @@ def main():
                         else agent.ppo.update_impl()),
         "roofline": {"bound": dominant["bound"], "achieved": dominant["achieved"], "peak": dominant["peak"],
                      "unit": dominant["unit"], "frac": dominant["frac"], "traffic": dominant["traffic"], "kernel": dominant["kernel"],
+                     "bound_actual": dominant.get("bound_actual"),
                      "traffic_is": "quoted from the committed rocprofv3 PMC passes (see traffic_counters.quoted_from), not measured in this run"
                                    if dominant["traffic"] is not None else "not available for this configuration"},
         "roofline_physics": roof_phys, "roofline_update": roof_upd,
