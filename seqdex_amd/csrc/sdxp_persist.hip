@@ -474,10 +474,13 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
           for (int s = 0; s < MB; ++s) pv[s] += w0v[i] * S.cvx[s][k];
         }
       }
+      // (all twelve wave reductions first - independent DPP chains the scheduler interleaves - then the stores: one reduction, one store
+      // at a time serialises the chains behind each other's LDS traffic; same sums, same order, bit-identical results)
 #pragma unroll
-      for (int s = 0; s < MB; ++s) {
-        const float ra = wave_sum(pa[s]), rc = wave_sum(pc[s]), rv = wave_sum(pv[s]);
-        if (lane == 0) { S.fpart[(0 * MB + s) * NWV + wave] = ra; S.fpart[(1 * MB + s) * NWV + wave] = rc; S.fpart[(2 * MB + s) * NWV + wave] = rv; }
+      for (int s = 0; s < MB; ++s) { pa[s] = wave_sum(pa[s]); pc[s] = wave_sum(pc[s]); pv[s] = wave_sum(pv[s]); }
+      if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < MB; ++s) { S.fpart[(0 * MB + s) * NWV + wave] = pa[s]; S.fpart[(1 * MB + s) * NWV + wave] = pc[s]; S.fpart[(2 * MB + s) * NWV + wave] = pv[s]; }
       }
       __syncthreads();
       if (tid < 3 * MB * 4) {
@@ -552,21 +555,28 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
       TS(4)
       __syncthreads();
+      {
+        float q[3][MB];
 #pragma unroll
-      for (int net = 0; net < 3; ++net) {
-        float q[MB];
+        for (int net = 0; net < 3; ++net) {
 #pragma unroll
-        for (int s = 0; s < MB; ++s) q[s] = 0.0f;
+          for (int s = 0; s < MB; ++s) q[net][s] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = q1 * 256 + lane + 64 * i;
+          for (int i = 0; i < 4; ++i) {
+            const int k = q1 * 256 + lane + 64 * i;
 #pragma unroll
-          for (int s = 0; s < MB; ++s) q[s] += w1[net][i] * S.x1[net][s][k];
+            for (int s = 0; s < MB; ++s) q[net][s] += w1[net][i] * S.x1[net][s][k];
+          }
         }
 #pragma unroll
-        for (int s = 0; s < MB; ++s) {
-          const float r = wave_sum(q[s]);
-          if (lane == 0) S.fpart[(net * MB + s) * NWV + wave] = r;
+        for (int net = 0; net < 3; ++net)
+#pragma unroll
+          for (int s = 0; s < MB; ++s) q[net][s] = wave_sum(q[net][s]);
+        if (lane == 0) {
+#pragma unroll
+          for (int net = 0; net < 3; ++net)
+#pragma unroll
+            for (int s = 0; s < MB; ++s) S.fpart[(net * MB + s) * NWV + wave] = q[net][s];
         }
       }
       __syncthreads();
@@ -667,13 +677,22 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     }
     TS(7)
     __syncthreads();
-#pragma unroll
-    for (int net = 0; net < 3; ++net) {
+    {
+      float q[3][MB];
       const int k = wave * 64 + lane;
 #pragma unroll
-      for (int s = 0; s < MB; ++s) {
-        const float r = wave_sum(w2[net] * S.x2[net][s][k]);
-        if (lane == 0) S.fpart[(net * MB + s) * NWV + wave] = r;
+      for (int net = 0; net < 3; ++net)
+#pragma unroll
+        for (int s = 0; s < MB; ++s) q[net][s] = w2[net] * S.x2[net][s][k];
+#pragma unroll
+      for (int net = 0; net < 3; ++net)
+#pragma unroll
+        for (int s = 0; s < MB; ++s) q[net][s] = wave_sum(q[net][s]);
+      if (lane == 0) {
+#pragma unroll
+        for (int net = 0; net < 3; ++net)
+#pragma unroll
+          for (int s = 0; s < MB; ++s) S.fpart[(net * MB + s) * NWV + wave] = q[net][s];
       }
     }
     __syncthreads();
@@ -738,36 +757,77 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     TS(10)
     __syncthreads();
     // head forward: wave per row
+    {
+      // rows wave, wave + 8, wave + 16 (< 23: actor rows, except row 23 = the critic's value on wave 7) and wave + 24 (only wave 0: row 24,
+      // the central value): the actor rows of a wave share ONE set of x3 loads
+      float q[HR][MB], xa[MB][4];
 #pragma unroll
-    for (int j = 0; j < HR; ++j) {
-      const int row = wave + 8 * j;
-      if (row < A + 2) {
-        const int net = head_net(row);
+      for (int s = 0; s < MB; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xa[s][e] = S.x3[0][s][lane + 64 * e];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < MB; ++s) {
-          float q = 0.0f;
+          float t = 0.0f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) q += wh[j][e] * S.x3[net][s][lane + 64 * e];
-          const float y = wave_sum(q) + S.bias[21 + row];
-          if (lane == 0) { if (row < A) S.mu[s][row] = y; else S.val[row - A][s] = y; }
+          for (int e = 0; e < 4; ++e) t += wh[j][e] * xa[s][e];
+          q[j][s] = t;
+        }
+      if (wave == NWV - 1) {          // row 23: critic value (net 1)
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          float t = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t += wh[2][e] * S.x3[1][s][lane + 64 * e];
+          q[2][s] = t;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          float t = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t += wh[2][e] * xa[s][e];
+          q[2][s] = t;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < MB; ++s) q[j][s] = wave_sum(q[j][s]);                       // 12 independent chains, then the stores
+      if (wave == 0) {                // row 24: central value (net 2)
+#pragma unroll
+        for (int s = 0; s < MB; ++s) {
+          float t = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t += wh[3][e] * S.x3[2][s][lane + 64 * e];
+          q[3][s] = wave_sum(t);
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < HR; ++j) {
+          const int row = wave + 8 * j;
+          if (row < A + 2) {
+#pragma unroll
+            for (int s = 0; s < MB; ++s) { const float y = q[j][s] + S.bias[21 + row]; if (row < A) S.mu[s][row] = y; else S.val[row - A][s] = y; }
+          }
         }
       }
     }
     __syncthreads();
     TS(11)
     const float invM = 1.0f / (float)MB;
-    if (tid < MB * 32) {
-      const int s = tid / 32, a = tid % 32;
-      S.z[s][a] = (a < A) ? (S.act[s][a] - S.mu[s][a]) / expf(S.ls[a]) : 0.0f;
-    }
-    __syncthreads();
     {
       float r_nlp = 0.0f, r_kl = 0.0f, r_bl = 0.0f, r_ent = 0.0f;
       if (tid < MB * 32) {
         const int s = tid / 32, a = tid % 32;
+        // z of (sample s, action a): formed by the thread that uses it here; S.z is only for the dmu / dlogstd lanes after the barrier below
+        const float zz = (a < A) ? (S.act[s][a] - S.mu[s][a]) / expf(S.ls[a]) : 0.0f;
+        S.z[s][a] = zz;
         if (a < A) {
           const float ls = S.ls[a], sg = expf(ls), mu = S.mu[s][a];
-          r_nlp = 0.5f * S.z[s][a] * S.z[s][a] + ls;
+          r_nlp = 0.5f * zz * zz + ls;
           const float omu = S.omu[s][a], osg = S.osg[s][a];
           r_kl = logf(osg / sg + 1e-5f) + (sg * sg + (omu - mu) * (omu - mu)) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
           const float hi = fmaxf(mu - 1.1f, 0.0f), lo = fminf(mu + 1.1f, 0.0f);
