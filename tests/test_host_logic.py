@@ -156,3 +156,24 @@ def test_pile_pickle_round_trip(tmp_path):
     np.testing.assert_array_equal(got, piles[:, :3])
     save_pile_pickle(p, piles, counts=[2] * 8)
     assert load_pile_pickle(p).shape == (8, 2, 132, 13)
+
+
+def test_scene_desc_round3_defaults(scene):
+    """the solver / task constants round 3 added to sdx_scene_desc carry the reference's values (or this engine's documented defaults):
+    warm start 0.8 ramped over 16 solves, T-value gates 0.99 (OR:1203) / 0.8 (GS:1406), link angular damping
+    0.01 (GS:546), and a spawn lattice whose lowest brick layer starts 2 mm above the floor slab instead of inside it (GS:737-742)."""
+    d = scene.to_desc()
+    assert abs(d.warm_start - 0.8) < 1e-7 and d.warm_age == 16.0
+    assert abs(d.orient_tvalue_gate - 0.99) < 1e-7 and abs(d.grasp_tvalue_gate - 0.8) < 1e-7
+    assert abs(d.robot_angular_damping - 0.01) < 1e-9
+    floor_top = scene.statics[6]["center"][2] + scene.statics[6]["half"][2]
+    lows = []
+    for i, fs in enumerate(scene.raw["free_spawn"]):
+        t = scene.brick_types[fs["type"]]
+        lows.append(d.free_spawn_pos[i][2] + t["center"][2] - t["half"][2])
+        assert abs(d.free_spawn_pos[i][0] - fs["pos"][0]) < 1e-6 and abs(d.free_spawn_pos[i][1] - fs["pos"][1]) < 1e-6   # only z moves
+    assert abs(min(lows) - (floor_top + 0.002)) < 1e-5
+    assert 0.06 < scene.spawn_lift < 0.07
+    # overrides reach the descriptor (what BlockAssemblyOrient(tvalue_gate=...) / BlockAssemblyGraspSim(harvest_tvalue_gate=...) use)
+    d2 = scene.to_desc(orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28, warm_start=0.0)
+    assert abs(d2.orient_tvalue_gate - 0.5) < 1e-7 and abs(d2.grasp_tvalue_gate - 0.28) < 1e-7 and d2.warm_start == 0.0
