@@ -57,6 +57,19 @@ class Scene:
         b = env_i % 8
         return _abi.ACTOR_BRICK0 + (0 if b in (3, 4, 7) else b)
 
+    def spawn_positions(self):
+        """the 72 lattice positions of the free bricks, lifted as a whole so that the lowest layer starts 2 mm above the floor slab
+        (see to_desc); sets self.spawn_lift"""
+        raw = self.raw
+        floor = [st for st in self.statics if st["name"] == "brick_floor"]
+        lift = 0.0
+        if floor:
+            top = floor[0]["center"][2] + floor[0]["half"][2]
+            low = min(fs["pos"][2] + self.brick_types[fs["type"]]["center"][2] - self.brick_types[fs["type"]]["half"][2] for fs in raw["free_spawn"])
+            lift = max(0.0, top + 0.002 - low)
+        self.spawn_lift = lift
+        return [[fs["pos"][0], fs["pos"][1], fs["pos"][2] + lift] for fs in raw["free_spawn"]]
+
     def to_desc(self, **overrides):
         d = _abi.SceneDesc()
         raw, rb = self.raw, self.raw["robot"]
@@ -110,15 +123,8 @@ class Scene:
         # this engine (top samples just above the slab, bottom samples pushed down) and stays there - round 3
         # found every target brick of the synthetic piles buried that way.  The lattice is lifted so that its lowest layer starts
         # 2 mm above the floor; the piles then settle ON it, as the reference's saved pile states do.
-        floor = [st for st in self.statics if st["name"] == "brick_floor"]
-        lift = 0.0
-        if floor:
-            top = floor[0]["center"][2] + floor[0]["half"][2]
-            low = min(fs["pos"][2] + self.brick_types[fs["type"]]["center"][2] - self.brick_types[fs["type"]]["half"][2] for fs in raw["free_spawn"])
-            lift = max(0.0, top + 0.002 - low)
-        self.spawn_lift = lift
-        for i, fs in enumerate(raw["free_spawn"]):
-            d.free_spawn_pos[i][:] = [fs["pos"][0], fs["pos"][1], fs["pos"][2] + lift]
+        for i, pos in enumerate(self.spawn_positions()):
+            d.free_spawn_pos[i][:] = pos
         d.free_spawn_quat[:] = raw["free_spawn"][0]["quat"]
         d.hand_base_body = self.hand_base_body
         d.fingertip_body[:] = self.fingertip_bodies

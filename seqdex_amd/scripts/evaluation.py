@@ -121,7 +121,7 @@ def scripted_grasp_controller(task, step):
 
 
 def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, controllers=None, min_piles=8, seed=22, stage_steps=None,
-                         synthetic_fallback=False, orient_tvalue_gate=0.99, grasp_tvalue_gate=0.8):
+                         synthetic_fallback=False, orient_tvalue_gate=0.99, grasp_tvalue_gate=0.8, with_search=False):
     """Orient -> GraspSim -> InsertSim played back to back on one GPU.  policies / controllers / stage_steps: dicts keyed "orient",
     "grasp", "insert".  Orient plays until every brick-type group has `min_piles` harvested pile states (OR:1483-1488 fills rings of
     10 000; at most 8 episodes here).  orient_tvalue_gate: the threshold Orient binarises the transition value at (0.99, OR:1203); a
@@ -131,12 +131,26 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     policies, controllers, stage_steps = policies or {}, controllers or {}, stage_steps or {}
     out, hand = {"num_envs": num_envs, "min_piles_per_type": min_piles}, {}
     t_begin = time.time()
+    dug = None
+    if with_search:
+        # ---- stage 0: BlockAssemblySearch at <= 128 envs (evaluation.py:111): piles whose target brick the camera sees go to Orient (SE:1323-1353)
+        search, st = main_rlgames("BlockAssemblySearch", min(num_envs, 128), policy_path=policies.get("search", ""), seed=seed,
+                                  controller=controllers.get("search"), steps=stage_steps.get("search", 2 * (75 + 8)))
+        st["piles_harvested_per_type"] = search.sim.PILE_HARVEST_COUNT.cpu().tolist()
+        dug = search.pile_terminal_states()
+        if dug is not None and dug.shape[1] < 8:      # too few states to start 128 envs per group from: Orient would replay the same handful
+            st["handed_on"] = "only %d piles per group (< 8): Orient settles its own piles" % dug.shape[1]
+            dug = None
+        else:
+            st["handed_on"] = "none (a brick-type group has no dug-out pile): Orient settles its own piles" if dug is None else "%d piles per group" % dug.shape[1]
+        search.sim.close()
+        out["search"] = st
     # ---- stage 1: BlockAssemblyOrient
     orient, st = main_rlgames("BlockAssemblyOrient", num_envs, policy_path=policies.get("orient", ""), tvalue_state=tvalue_state,
                               controller=controllers.get("orient"), seed=seed, steps=stage_steps.get("orient"),
                               until=lambda t: int(t.sim.PILE_HARVEST_COUNT.min()) >= min_piles,
                               max_steps=8 * 80 if stage_steps.get("orient") is None else stage_steps["orient"],
-                              task_kwargs={"tvalue_gate": orient_tvalue_gate, "piles_per_type": 64})
+                              task_kwargs={"tvalue_gate": orient_tvalue_gate, "piles_per_type": 64, "initial_piles": dug})
     st["piles_harvested_per_type"] = orient.sim.PILE_HARVEST_COUNT.cpu().tolist()
     st["tvalue_gate"] = orient_tvalue_gate
     piles = orient.pile_terminal_states()
@@ -172,8 +186,9 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     hand["insert_task"] = insert          # the caller inspects it and closes insert.sim
     out["insert"] = st
     out["chain_wall_s"] = time.time() - t_begin
-    steps = sum(out[k]["env_steps"] for k in ("orient", "grasp", "insert"))
-    play = sum(out[k]["wall_s"] for k in ("orient", "grasp", "insert"))
+    stages = [k for k in ("search", "orient", "grasp", "insert") if k in out]
+    steps = sum(out[k]["env_steps"] for k in stages)
+    play = sum(out[k]["wall_s"] for k in stages)
     out["chain_env_steps"] = steps
     out["chain_env_steps_per_s"] = steps / play                      # the three rollouts back to back (task construction excluded)
     out["chain_env_steps_per_s_incl_setup"] = steps / out["chain_wall_s"]

@@ -45,8 +45,8 @@ class BlockAssemblySearch(BlockAssemblyOrient):
         sc = load_scene()
         lattice = torch.zeros(8, 1, 132, 13)
         lattice[:, :, :, 6] = 1.0
-        for i, fs in enumerate(sc.raw["free_spawn"]):
-            lattice[:, 0, i, 0:3] = torch.tensor(fs["pos"])
+        for i, (fs, pos) in enumerate(zip(sc.raw["free_spawn"], sc.spawn_positions())):   # (lifted above the floor slab, scene.to_desc)
+            lattice[:, 0, i, 0:3] = torch.tensor(pos)
             lattice[:, 0, i, 3:7] = torch.tensor(fs["quat"])
         for i, fb in enumerate(sc.raw["fixed_bricks"]):
             lattice[:, 0, 72 + i, 0:3] = torch.tensor(fb["pos"])

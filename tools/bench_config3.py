@@ -11,7 +11,7 @@ stage 1 Orient (random-initialised policy: its arm is scripted by the task, OR:1
 stage 2 GraspSim starts from those piles (two episodes; harvest gate 0.28 instead of 0.8, GS:1406, for the same reason); a scripted stand-in
     controller replaces the 19 000-epoch grasp policy (evaluation.py docstring); groups it harvests nothing for get InsertSim's synthetic states,
 stage 3 InsertSim resets from the harvested grasp states and plays one episode.
-value = env-steps of the three rollouts / their wall time.  Prints one JSON line.   usage: python tools/bench_config3.py [N] [prep_epochs]"""
+value = env-steps of the three rollouts / their wall time.  Prints one JSON line.   usage: python tools/bench_config3.py [N] [prep_epochs] [--with-search] [--out file.json]"""
 import json
 import os
 import sys
@@ -65,18 +65,22 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to
 
 
 if __name__ == "__main__":
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    prep = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
+    prep = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1200
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, save_to=os.path.join(ROOT, "gpurun_out", "config3_insert_policy"))
     print("stage 0:", json.dumps(prep_st), file=sys.stderr, flush=True)
     res, hand = block_assembly_chain(n, tv, policies={"insert": insert_ckpt}, controllers={"grasp": scripted_grasp_controller},
                                      synthetic_fallback=True, orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28,
-                                     stage_steps={"grasp": 320})
+                                     stage_steps={"grasp": 320}, with_search="--with-search" in sys.argv)
     ins = hand["insert_task"]
     res["insert"]["synthetic_groups"] = ins.synthetic_groups
     ins.sim.close()
     out = {"config": "BASELINE.json configs[2]: BlockAssemblyOrient -> BlockAssemblyGraspSim -> BlockAssemblyInsertSim chained rollout, num_envs=%d, 1 GPU" % n,
            "metric": "env-steps/s of the chained rollout (play, no update)", "value": res["chain_env_steps_per_s"], "unit": "env-steps/s",
            "stage0_tvalue_and_insert_policy(untimed)": prep_st, "chain": res}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    for i, a in enumerate(sys.argv):
+        if a == "--out" and i + 1 < len(sys.argv):
+            with open(sys.argv[i + 1], "w") as fh:
+                fh.write(json.dumps(out) + "\n")
