@@ -92,7 +92,8 @@ def scripted_grasp_controller(task, step):
         sc = s.scene
         task._sg_seg = torch.as_tensor([sc.seg_index(i) for i in range(n)], device=task.device, dtype=torch.long)
         task._sg_env = torch.arange(n, device=task.device)
-        task._sg_q0 = torch.tensor([0.7107, -0.7033, 0.0113, -0.0091], device=task.device)          # hand base at the prepare pose (FK of the scene)
+        # the wrist orientation to hold = the hand base's at the prepare pose: (0.7107, -0.7033, 0.0113, -0.0091) by the scene's FK (palm down)
+        task._sg_q0 = torch.tensor([0.7107, -0.7033, 0.0113, -0.0091], device=task.device)
     prog = s.PROGRESS.to(torch.float32)
     hb = s.RB[:, s.scene.hand_base_body, 0:3]
     brick = s.ROOT.view(n, 142, 13)[task._sg_env, task._sg_seg, 0:3]

@@ -67,8 +67,9 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
     prep = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1200
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, save_to=os.path.join(ROOT, "gpurun_out", "config3_insert_policy"))
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="sdx_config3_")          # the stage-0 checkpoint (30 MB) is a hand-off inside this run, not an artefact
+    tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, save_to=os.path.join(tmp, "config3_insert_policy"))
     print("stage 0:", json.dumps(prep_st), file=sys.stderr, flush=True)
     res, hand = block_assembly_chain(n, tv, policies={"insert": insert_ckpt}, controllers={"grasp": scripted_grasp_controller},
                                      synthetic_fallback=True, orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28,
