@@ -8,9 +8,6 @@
 #define SDX_WAVE 64
 #define SDX_MAXC 1536        // contact points per env = 3 rows per lane x 512 lanes of k_physics
 #define SDX_MAXP 1024        // candidate box pairs per env (LDS)
-#ifndef SDX_PHYS_NT_DEFAULT
-#define SDX_PHYS_NT_DEFAULT 512   // threads per env of k_physics (384 or 512; SDX_PHYS_NT overrides at run time)
-#endif
 #define SDX_CFIELDS 17       // ab, p3, n3, sep, lam3, wA3, wB3
 #define SDX_NSAMP 28
 #define SDX_BODY_STATIC 255

@@ -7,18 +7,19 @@
 //   D sampled-SDF box/box contacts (<= 4 per pair)  E active-set mass-split Jacobi on accumulated impulses
 //   F semi-implicit Euler;  then outputs: rigid-body states, end-effector Jacobian, net arm contact forces.
 //
-// Shape of the kernel (round 2; the round-1 kernel ran one 512-thread workgroup per CU at 256 VGPRs and spent 68 % of its
-// wave-cycles parked at barriers, profiles/r1_bench_pmc_sq_v3.csv):
-//   * NT threads per env, NT = 384 (6 waves, <= 168 VGPRs) or 512 (8 waves, <= 128 VGPRs): either way two workgroups share a CU
-//     (LDS <= 80 KiB each), so one env's barrier / latency phases overlap the other env's arithmetic;
-//   * contact geometry (point, normal) stays in LDS; each lane keeps only what changes or divides per iteration for its CPT
-//     contacts in registers (accumulated impulses, un-split inverse masses of both sides, separation, body ids);
-//   * per solver iteration: [A] relative velocity + active flag, ACTIVE counts per body by integer LDS atomics (deterministic)
-//     | barrier | [C] Jacobi update, impulse to LDS | barrier | [D] CSR gather per brick (4 lanes each) and per robot dof
-//     (walking the ordered robot-side list) | barrier | robot only: wave 0 applies Hinv and rebuilds the link twists | barrier;
-//   * everything serial (FK levels, Cholesky, drive, twists) runs on wave 0 with wave-synchronous LDS hand-offs instead of
+// Shape of the kernel (rewritten in round 2, restructured in round 3):
+//   * 512 threads (8 waves, <= 128 VGPRs) per env, two workgroups per CU (LDS <= 80 KiB each), so one env's barrier / latency phases overlap
+//     the other env's arithmetic; launch order = envs by the cost of their previous step, longest first (k_order);
+//   * contact geometry (point, normal) stays in LDS; each lane keeps only what changes or divides per iteration for its 3 contacts in
+//     registers (accumulated impulses, un-split inverse masses of both sides, target velocity, body ids);
+//   * per solver iteration: [AC] relative velocity, active flag -> counted for the NEXT iteration (integer LDS atomics), Jacobi update with
+//     the counts of the previous one, impulse to LDS | barrier | [D] CSR gather per body (8 lanes per link, 4 per brick); links project
+//     their wrench on the dofs of their path | barrier | robot only: every 8-lane group sums the generalised impulses, applies Hinv and
+//     rebuilds its link's twist | barrier;
+//   * everything serial (FK levels, Cholesky in registers, drive, twists) runs on wave 0 with wave-synchronous hand-offs instead of
 //     workgroup barriers; the other waves meet it at the next barrier;
-//   * broadphase: every lane tests its strided candidates into a bit mask, ONE block scan places all hits.
+//   * broadphase: every lane tests its strided candidates into a bit mask, ONE block scan places all hits; narrowphase: lane = pair picks
+//     the samples, lane = contact computes their geometry.
 #include <stdlib.h>
 
 #include "sdx_common.h"
@@ -52,7 +53,7 @@ __constant__ float c_samp[SDX_NSAMP][3] = {
 struct PhysLds {
   // robot
   float q[ND], qd[ND + 1], qdb[ND + 1], tgt[ND], tau[ND];   // qd[ND] = 0: the padding dof of exhausted paths; qdb: the solver's second copy (read one, write the other)
-  float lq[NL][4], la[NL + 1][3], lc[NL][3], lI[NL][6];
+  float lq[NL][4], la[NL + 1][3], lc[NL][3], lI[NL][6], lmass[NL];   // lmass: link masses (a per-lane global load inside the mass-matrix loop cost it 8 k cycles)
   float lal[NL + 1][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
   float A[ND][HP];      // H -> L -> Hinv
   uint32_t anc[NL];     // bit j: dof j lies on the path base -> link
@@ -431,7 +432,7 @@ __device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int t
         const float* I = S.lI[k];
         const f3 Ia = F3(I[0] * aj.x + I[3] * aj.y + I[4] * aj.z, I[3] * aj.x + I[1] * aj.y + I[5] * aj.z,
                          I[4] * aj.x + I[5] * aj.y + I[2] * aj.z);
-        s += sc.link_mass[k] * dot(li, lj) + dot(ai, Ia);
+        s += S.lmass[k] * dot(li, lj) + dot(ai, Ia);
       }
     }
     if (i == j) s += sc.armature[i] + h * sc.kd[i] + h * h * sc.kp[i];
@@ -575,7 +576,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   SSTAMP(32);
   int np;
   {
-    // at most 15 candidates per lane: (72 * 8 + 72 * 71 / 2 + 32 * 80) / 384 < 15 (4 bits of the pair rank)
+    // at most 15 candidates per lane: (72 * 8 + 72 * 71 / 2 + 32 * 80) / 512 < 12 (4 bits of the pair rank)
     int pos = block_scan_small<NT>(S, __popc(mask), tid, &np);
     uint32_t m = mask;
     while (m) {
@@ -1253,7 +1254,7 @@ __device__ __forceinline__ void load_constants(const SdxConst* C, PhysLds& S, in
     S.seg_brick = segb;
     st3(S.bp[BODY_W], F3(0, 0, 0)); st3(S.bv[BODY_W], F3(0, 0, 0)); st3(S.bw[BODY_W], F3(0, 0, 0));   // the static world
   }
-  if (tid < NL) S.anc[tid] = C->anc[tid];
+  if (tid < NL) { S.anc[tid] = C->anc[tid]; S.lmass[tid] = sc.link_mass[tid]; }
   if (tid < ND) {
     uint32_t d = 0;
     for (int k = 1; k < NL; ++k) d |= ((C->anc[k] >> tid) & 1u) << k;
