@@ -676,10 +676,15 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = b2[n];
-    for (int k = 0; k < 256; ++k) {
-      const float w = W2[k * 128 + n];
+    for (int k0 = 0; k0 < 256; k0 += 16) {     // 16 weight loads in flight (a rolled loop waits for one L2 round trip per k: 32 us per launch);
+      float w[16];                             // the sums still run over k in ascending order
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += w * s_h1[eh + e][k];
+      for (int j = 0; j < 16; ++j) w[j] = W2[(k0 + j) * 128 + n];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w[j] * s_h1[eh + e][k0 + j];
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) s_h2[eh + e][n] = elu1(acc[e]);
@@ -690,10 +695,15 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
     float acc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = b3[n];
-    for (int k = 0; k < 128; ++k) {
-      const float w = W3[k * 64 + n];
+    for (int k0 = 0; k0 < 128; k0 += 16) {
+      float w[16];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += w * s_h2[eq + e][k];
+      for (int j = 0; j < 16; ++j) w[j] = W3[(k0 + j) * 64 + n];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w[j] * s_h2[eq + e][k0 + j];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) s_h3[eq + e][n] = elu1(acc[e]);
@@ -701,7 +711,14 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
   __syncthreads();
   if (t < TV_ENVS) {  // layer 4, output 1 only feeds the sigmoid (GS:1201)
     float y = b4[1];
-    for (int k = 0; k < 64; ++k) y += W4[k * 2 + 1] * s_h3[t][k];
+    for (int k0 = 0; k0 < 64; k0 += 16) {
+      float w[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) w[j] = W4[(k0 + j) * 2 + 1];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) y += w[j] * s_h3[t][k0 + j];
+    }
     y = elu1(y);
     if (e0 + t < B.N) {
       float tvv = 1.0f / (1.0f + expf(-y));

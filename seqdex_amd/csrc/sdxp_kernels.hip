@@ -49,18 +49,27 @@ __device__ __forceinline__ float lane0(float v) { return __builtin_bit_cast(floa
 // ONE barrier per chunk and two chunks of load latency hidden.  (Round 2's kernel loaded, stored, synchronised and multiplied one
 // 16-wide chunk at a time: 25 dependent round trips for the 396-wide first layer, 35 us per launch, 6 launches per env step.)
 #define GT 64
-#define GK 32
+#define SDXP_NORM_K 1024   // widest input that may be normalised on the fly (checked by the launchers)
 struct LinArgs { const float* X; const float* W; const float* b; float* Y; int M, N, K, elu; const double* nmean; const double* nvar; };
 struct LinBatch { LinArgs a[2]; };
 // WTM = 1: 64 x 64 tile (wave = 32 x 32); WTM = 2: 128 x 64 tile (wave = 64 x 32: two MFMAs share one W operand - 21 instead of 16 flops
-// per operand byte fetched from L2, which is what bounds these small products: a 64 x 64 tile at the fp32 matrix peak would need 10 TB/s)
-template <int WTM>
-__global__ __launch_bounds__(256) void k_linear_mfma(LinBatch lb) {
-  constexpr int TM = GT * WTM, NX = 2 * WTM;       // rows of X per tile, float4 loads of X per thread and chunk
-  __shared__ float Xs[2][TM][GK + 1];
-  __shared__ float Ws[2][GT][GK + 1];
+// per operand byte fetched from L2).  GKc = reduction chunk staged per barrier.  KS = split of every chunk over KS groups of four waves
+// (256 KS threads): group g multiplies the k range [g GKc / KS, (g + 1) GKc / KS) of each chunk into its own accumulators and the groups
+// are summed through LDS, in group order, at the end.  At M = 1024 the middle and last layers launch only 256 / 128 workgroups, one wave
+// per SIMD: every LDS read and every barrier was exposed (matrix pipe 26 % busy, profiles/r3_act_pmc.csv); with KS groups a SIMD holds
+// KS waves whose reads and multiplies overlap, and each thread moves 1 / KS of the operands.
+template <int WTM, int KS, int GKc>
+__global__ __launch_bounds__(256 * KS) void k_linear_mfma(LinBatch lb) {
+  constexpr int TM = GT * WTM, NT = 256 * KS, F4R = GKc / 4;       // rows of X per tile, threads, float4 pieces per row and chunk
+  constexpr int NX = TM * F4R / NT, NW = GT * F4R / NT, KG = GKc / KS;
+  static_assert(NX >= 1 && NW >= 1 && TM * F4R % NT == 0 && GT * F4R % NT == 0 && KG % 2 == 0, "chunk does not divide over the threads");
+  constexpr int OPER = 2 * (TM + GT) * (GKc + 1), RED = (KS - 1) * 4 * 16 * 64;
+  __shared__ float lds[OPER > RED ? OPER : RED];
+  __shared__ float nmu[SDXP_NORM_K], nsd[SDXP_NORM_K];            // mean and sqrt(var + eps) of the normalised input, as floats
+  float (*Xs)[TM][GKc + 1] = reinterpret_cast<float (*)[TM][GKc + 1]>(lds);
+  float (*Ws)[GT][GKc + 1] = reinterpret_cast<float (*)[GT][GKc + 1]>(lds + 2 * TM * (GKc + 1));
   const LinArgs& g = lb.a[blockIdx.z];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = (tid >> 6) & 3, kg = tid >> 8, lane = tid & 63;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GT;
   const int M = g.M, N = g.N, K = g.K;
   if (m0 >= M || n0 >= N) return;                 // the grid covers the larger problem of the batch
@@ -70,61 +79,104 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinBatch lb) {
   for (int u = 0; u < WTM; ++u)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[u][i] = 0.0f;
-  // element e = tid + 256 p of a chunk: row e / 8, k offset 4 (e % 8): consecutive lanes read consecutive 16-byte pieces of a row
-  float4 xv[2][NX], wv[2][2];
-  auto fetch = [&](int k0, float4 (&xr)[NX], float4 (&wr)[2]) {
+  // element e = tid + NT p of a chunk: row e / F4R, k offset 4 (e % F4R): consecutive lanes read consecutive 16-byte pieces of a row.
+  // fetch() only issues loads, from clamped (always valid) addresses and without a branch, so that the compiler can count them: with
+  // exec-masked loads every wait became vmcnt(0) and the chunk in flight was waited for where it was issued.  stage() zeroes the pieces
+  // outside the matrix and applies the running-mean/std normalisation of X from per-k tables built once per workgroup (same arithmetic
+  // as normalising at load time)
+  float4 xv0[NX], xv1[NX], wv0[NW], wv1[NW];
+  auto fetch = [&](int k0, float4 (&xr)[NX], float4 (&wr)[NW]) {
 #pragma unroll
     for (int p = 0; p < NX; ++p) {
-      const int e = tid + 256 * p, r = e >> 3, k = k0 + 4 * (e & 7);
-      xr[p] = make_float4(0, 0, 0, 0);
-      if (m0 + r < M && k < K) {
-        xr[p] = *reinterpret_cast<const float4*>(g.X + (size_t)(m0 + r) * K + k);
-        if (g.nmean) {
-          float* xp = reinterpret_cast<float*>(&xr[p]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) xp[j] = clampf((xp[j] - (float)g.nmean[k + j]) / sqrtf((float)g.nvar[k + j] + 1e-5f), -5.0f, 5.0f);
-        }
-      }
+      const int e = tid + NT * p, r = e / F4R, k = k0 + 4 * (e % F4R);
+      const int rr = m0 + r < M ? m0 + r : M - 1, kc = k < K ? k : 0;
+      xr[p] = *reinterpret_cast<const float4*>(g.X + (size_t)rr * K + kc);
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int e = tid + 256 * p, r = e >> 3, k = k0 + 4 * (e & 7);
-      wr[p] = make_float4(0, 0, 0, 0);
-      if (n0 + r < N && k < K) wr[p] = *reinterpret_cast<const float4*>(g.W + (size_t)(n0 + r) * K + k);
+    for (int p = 0; p < NW; ++p) {
+      const int e = tid + NT * p, r = e / F4R, k = k0 + 4 * (e % F4R);
+      const int rr = n0 + r < N ? n0 + r : N - 1, kc = k < K ? k : 0;
+      wr[p] = *reinterpret_cast<const float4*>(g.W + (size_t)rr * K + kc);
     }
   };
-  auto stage = [&](int buf, const float4 (&xr)[NX], const float4 (&wr)[2]) {
+  const bool norm = g.nmean != nullptr;
+  auto stage = [&](int buf, int k0, const float4 (&xr)[NX], const float4 (&wr)[NW]) {
 #pragma unroll
     for (int p = 0; p < NX; ++p) {
-      const int e = tid + 256 * p, r = e >> 3, k = 4 * (e & 7);
-      float* dx = &Xs[buf][r][k]; dx[0] = xr[p].x; dx[1] = xr[p].y; dx[2] = xr[p].z; dx[3] = xr[p].w;
+      const int e = tid + NT * p, r = e / F4R, k = 4 * (e % F4R);
+      const bool in = m0 + r < M && k0 + k < K;
+      float xq[4] = {xr[p].x, xr[p].y, xr[p].z, xr[p].w};
+      if (norm) {
+        const int kt = in ? k0 + k : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xq[j] = clampf((xq[j] - nmu[kt + j]) / nsd[kt + j], -5.0f, 5.0f);
+      }
+      float* dx = &Xs[buf][r][k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dx[j] = in ? xq[j] : 0.0f;
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int e = tid + 256 * p, r = e >> 3, k = 4 * (e & 7);
-      float* dw = &Ws[buf][r][k]; dw[0] = wr[p].x; dw[1] = wr[p].y; dw[2] = wr[p].z; dw[3] = wr[p].w;
+    for (int p = 0; p < NW; ++p) {
+      const int e = tid + NT * p, r = e / F4R, k = 4 * (e % F4R);
+      const bool in = n0 + r < N && k0 + k < K;
+      float* dw = &Ws[buf][r][k]; dw[0] = in ? wr[p].x : 0.0f; dw[1] = in ? wr[p].y : 0.0f; dw[2] = in ? wr[p].z : 0.0f; dw[3] = in ? wr[p].w : 0.0f;
     }
   };
-  const int nchunk = (K + GK - 1) / GK;
-  fetch(0, xv[0], wv[0]);
-  if (nchunk > 1) fetch(GK, xv[1], wv[1]);
-  stage(0, xv[0], wv[0]);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    // registers: slot c & 1 is free (chunk c is in LDS), slot (c + 1) & 1 holds chunk c + 1
-    if (c + 2 < nchunk) { if (c & 1) fetch((c + 2) * GK, xv[1], wv[1]); else fetch((c + 2) * GK, xv[0], wv[0]); }
-    const int buf = c & 1;
+  // all LDS operands of the chunk are requested before the first multiply (the rolled form read two, waited, multiplied twice)
+  auto mma = [&](int buf) {
+    float av[WTM][KG / 2], bv[KG / 2];
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 2) {
-      const float bb = Ws[buf][wn + (lane & 31)][kk + (lane >> 5)];
+    for (int j = 0; j < KG / 2; ++j) {
+      const int kk = kg * KG + 2 * j + (lane >> 5);
+      bv[j] = Ws[buf][wn + (lane & 31)][kk];
 #pragma unroll
-      for (int u = 0; u < WTM; ++u) {
-        const float a = Xs[buf][wm + 32 * u + (lane & 31)][kk + (lane >> 5)];
-        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[u], 0, 0, 0);
-      }
+      for (int u = 0; u < WTM; ++u) av[u][j] = Xs[buf][wm + 32 * u + (lane & 31)][kk];
     }
-    if (c + 1 < nchunk) { if (c & 1) stage(buf ^ 1, xv[0], wv[0]); else stage(buf ^ 1, xv[1], wv[1]); }   // chunk c + 1 into the other buffer
+    __builtin_amdgcn_sched_barrier(0);             // (the scheduler otherwise sinks the reads back between the multiplies)
+#pragma unroll
+    for (int j = 0; j < KG / 2; ++j)
+#pragma unroll
+      for (int u = 0; u < WTM; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], bv[j], acc[u], 0, 0, 0);
+  };
+  const int nchunk = (K + GKc - 1) / GKc;
+  fetch(0, xv0, wv0);
+  fetch(GKc, xv1, wv1);
+  if (norm) {
+    for (int k = tid; k < K; k += NT) { nmu[k] = (float)g.nmean[k]; nsd[k] = sqrtf((float)g.nvar[k] + 1e-5f); }
     __syncthreads();
+  }
+  stage(0, 0, xv0, wv0);
+  __syncthreads();
+  // two chunks per trip so that the register slots and LDS buffers are fixed names: chunk c multiplies out of buffer c & 1 while chunk
+  // c + 2 is in flight into the slot chunk c came from and chunk c + 1 moves from the other slot into the other buffer; one barrier a chunk
+  int c = 0;
+  for (; c + 1 < nchunk; c += 2) {
+    fetch((c + 2) * GKc, xv0, wv0);
+    mma(0);
+    stage(1, (c + 1) * GKc, xv1, wv1);
+    __syncthreads();
+    fetch((c + 3) * GKc, xv1, wv1);
+    mma(1);
+    stage(0, (c + 2) * GKc, xv0, wv0);
+    __syncthreads();
+  }
+  if (c < nchunk) mma(0);                         // odd number of chunks: the last one sits in buffer 0
+  if constexpr (KS > 1) {                          // sum of the k groups, in group order (the operand buffers are reused)
+    static_assert(WTM == 1 || KS == 1, "the reduction buffer holds one accumulator tile per wave");
+    __syncthreads();                               // an odd last chunk is still being read out of buffer 0
+    for (int gsrc = 1; gsrc < KS; ++gsrc) {
+      float* red = lds + ((gsrc - 1) * 4 + wave) * 16 * 64;
+      if (kg == gsrc)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[i * 64 + lane] = acc[0][i];
+    }
+    __syncthreads();
+    if (kg != 0) return;
+    for (int gsrc = 1; gsrc < KS; ++gsrc) {
+      const float* red = lds + ((gsrc - 1) * 4 + wave) * 16 * 64;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] += red[i * 64 + lane];
+    }
   }
   const int col = n0 + wn + (lane & 31);
   if (col < N) {
@@ -141,14 +193,30 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinBatch lb) {
       }
   }
 }
+template <int WTM, int KS, int GKc>
+static void launch_linear_as(const LinBatch& lb, int count, int M, int Nx, hipStream_t st) {
+  hipLaunchKernelGGL((k_linear_mfma<WTM, KS, GKc>), dim3((Nx + GT - 1) / GT, (M + WTM * GT - 1) / (WTM * GT), count), dim3(256 * KS), 0, st, lb);
+}
+static int g_linear_shape = 0;           // sdxpk_linear_force_shape (tests / timing tools); 0 = automatic
+#define SDXP_LINEAR_SMALL_M_SHAPE 1     // the shape below M = 2048 when SDXP_LINEAR_TILE is unset
 static void launch_linear(const LinBatch& lb, int count, int M, int Nx, hipStream_t st) {
-  // 64 x 64 tiles up to 2048 rows, 128 x 64 beyond; SDXP_LINEAR_TILE=1|2 forces one (timing aid).  Measured at M = 1024 (tools/time_act.py,
-  // profiles/r3_act_pmc.csv): 143 us per sdxp_act with 64 x 64 tiles, 206 us with 128 x 64 - at this size the layers are bound by the
-  // latency of their 13-32 dependent chunks (waves wait 52 % of their cycles, the matrix pipe is 26 % busy), not by operand bandwidth
-  static const int forced = getenv("SDXP_LINEAR_TILE") ? atoi(getenv("SDXP_LINEAR_TILE")) : 0;
-  const bool big = forced ? forced == 2 : M > 2048;
-  if (big) hipLaunchKernelGGL(k_linear_mfma<2>, dim3((Nx + GT - 1) / GT, (M + 2 * GT - 1) / (2 * GT), count), dim3(256), 0, st, lb);
-  else hipLaunchKernelGGL(k_linear_mfma<1>, dim3((Nx + GT - 1) / GT, (M + GT - 1) / GT, count), dim3(256), 0, st, lb);
+  // 64 x 64 tiles up to 2048 rows, 128 x 64 beyond.  SDXP_LINEAR_TILE forces one shape (timing aid): 1 = 64 x 64, 2 = 128 x 64,
+  // 3 = 64 x 64 with 2 k groups, 4 = the same with chunks of 64, 5 = 4 k groups and chunks of 64, 6 = 64 x 64 with chunks of 64.
+  // Measured at M = 1024 (tools/time_act.py, profiles/r3_act_pmc.csv): 143 us per sdxp_act with shape 1, 206 us with shape 2 - at this size
+  // the layers are bound by the latency of their 13-32 dependent chunks, not by operand bandwidth
+  for (int i = 0; i < count; ++i)
+    if (lb.a[i].nmean && lb.a[i].K > SDXP_NORM_K) { fprintf(stderr, "seqdex: k_linear_mfma normalises at most %d input columns (got %d)\n", SDXP_NORM_K, lb.a[i].K); abort(); }
+  static const int env_forced = getenv("SDXP_LINEAR_TILE") ? atoi(getenv("SDXP_LINEAR_TILE")) : 0;
+  const int forced = g_linear_shape ? g_linear_shape : env_forced;
+  const int shape = forced ? forced : (M > 2048 ? 2 : SDXP_LINEAR_SMALL_M_SHAPE);
+  switch (shape) {
+    case 2: launch_linear_as<2, 1, 32>(lb, count, M, Nx, st); break;
+    case 3: launch_linear_as<1, 2, 32>(lb, count, M, Nx, st); break;
+    case 4: launch_linear_as<1, 2, 64>(lb, count, M, Nx, st); break;
+    case 5: launch_linear_as<1, 4, 64>(lb, count, M, Nx, st); break;
+    case 6: launch_linear_as<1, 1, 64>(lb, count, M, Nx, st); break;
+    default: launch_linear_as<1, 1, 32>(lb, count, M, Nx, st); break;
+  }
 }
 
 // counter-based standard normal (Box-Muller on two hashed uniforms)
@@ -178,7 +246,14 @@ __global__ __launch_bounds__(64) void k_act_heads(SdxpDev D, int t, const float*
   if (lane < A) {
     const float* w = D.ac + D.off.mu_w + (size_t)lane * U;
     float mu = D.ac[D.off.mu_b + lane];
-    for (int k = 0; k < U; ++k) mu += w[k] * s_h[0][k];
+    for (int k0 = 0; k0 < U; k0 += 16) {           // 16 weight loads in flight (rolled, every k waited for its own load: 13.7 us per launch);
+      float wv[16];                                // units[2] == 256 (sdxp_create); the sum still runs over k in ascending order
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wv[j] = w[k0 + j];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mu += wv[j] * s_h[0][k0 + j];
+    }
     const float ls = D.ac[D.off.logstd + lane], sg = expf(ls);
     const float eps = eps_in ? eps_in[(size_t)e * A + lane] : randn(D.seed, counter, (uint64_t)e * 64 + lane);
     const float a = mu + sg * eps;
@@ -1218,6 +1293,7 @@ extern "C" void sdxpk_linear(const float* X, const float* W, const float* b, flo
   lb.a[1] = lb.a[0];
   launch_linear(lb, 1, M, N, st);
 }
+extern "C" void sdxpk_linear_force_shape(int shape) { g_linear_shape = shape; }   // not part of include/*.h: kernel tests and timing tools only
 // two independent products in one launch (the same layer of the actor and of the central-value trunk)
 extern "C" void sdxpk_linear2(const float* X0, const float* W0, const float* b0, float* Y0, int N0, int K0, const double* nmean0, const double* nvar0,
                               const float* X1, const float* W1, const float* b1, float* Y1, int N1, int K1, const double* nmean1, const double* nvar1,
