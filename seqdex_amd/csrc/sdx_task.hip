@@ -640,6 +640,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
 // tv_w layout (device, transposed for coalesced neuron-major reads): W1T[4][256] b1[256] W2T[256][128] b2[128]
 // W3T[128][64] b3[64] W4T[64][2] b4[2].  One block = 16 envs x 256 threads.
 #define TV_ENVS 16
+#define TV_LOADS 64
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
 
 __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
@@ -676,13 +677,14 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = b2[n];
-    for (int k0 = 0; k0 < 256; k0 += 16) {     // 16 weight loads in flight (a rolled loop waits for one L2 round trip per k: 32 us per launch);
-      float w[16];                             // the sums still run over k in ascending order
-#pragma unroll
-      for (int j = 0; j < 16; ++j) w[j] = W2[(k0 + j) * 128 + n];
+#pragma unroll 1
+    for (int k0 = 0; k0 < 256; k0 += TV_LOADS) {   // TV_LOADS weight loads in flight: the launch is a chain of L2 round trips (about 0.7 us
+      float w[TV_LOADS];                           // each with 64 workgroups on the chip), one per k when rolled (32 us), 28 at 16 in flight (22 us);
+#pragma unroll                                     // the sums still run over k in ascending order
+      for (int j = 0; j < TV_LOADS; ++j) w[j] = W2[(k0 + j) * 128 + n];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
+      for (int j = 0; j < TV_LOADS; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += w[j] * s_h1[eh + e][k0 + j];
     }
@@ -695,13 +697,14 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
     float acc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = b3[n];
-    for (int k0 = 0; k0 < 128; k0 += 16) {
-      float w[16];
+#pragma unroll 1
+    for (int k0 = 0; k0 < 128; k0 += TV_LOADS) {
+      float w[TV_LOADS];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) w[j] = W3[(k0 + j) * 64 + n];
+      for (int j = 0; j < TV_LOADS; ++j) w[j] = W3[(k0 + j) * 64 + n];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
+      for (int j = 0; j < TV_LOADS; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += w[j] * s_h2[eq + e][k0 + j];
     }
@@ -711,13 +714,14 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
   __syncthreads();
   if (t < TV_ENVS) {  // layer 4, output 1 only feeds the sigmoid (GS:1201)
     float y = b4[1];
-    for (int k0 = 0; k0 < 64; k0 += 16) {
-      float w[16];
+#pragma unroll 1
+    for (int k0 = 0; k0 < 64; k0 += TV_LOADS) {
+      float w[TV_LOADS];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) w[j] = W4[(k0 + j) * 2 + 1];
+      for (int j = 0; j < TV_LOADS; ++j) w[j] = W4[(k0 + j) * 2 + 1];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) y += w[j] * s_h3[t][k0 + j];
+      for (int j = 0; j < TV_LOADS; ++j) y += w[j] * s_h3[t][k0 + j];
     }
     y = elu1(y);
     if (e0 + t < B.N) {

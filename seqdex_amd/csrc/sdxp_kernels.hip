@@ -51,7 +51,7 @@ __device__ __forceinline__ float lane0(float v) { return __builtin_bit_cast(floa
 #define GT 64
 #define SDXP_NORM_K 1024   // widest input that may be normalised on the fly (checked by the launchers)
 struct LinArgs { const float* X; const float* W; const float* b; float* Y; int M, N, K, elu; const double* nmean; const double* nvar; };
-struct LinBatch { LinArgs a[2]; };
+struct LinBatch { LinArgs a[2]; int plain_map; };
 // WTM = 1: 64 x 64 tile (wave = 32 x 32); WTM = 2: 128 x 64 tile (wave = 64 x 32: two MFMAs share one W operand - 21 instead of 16 flops
 // per operand byte fetched from L2).  GKc = reduction chunk staged per barrier.  KS = split of every chunk over KS groups of four waves
 // (256 KS threads): group g multiplies the k range [g GKc / KS, (g + 1) GKc / KS) of each chunk into its own accumulators and the groups
@@ -70,7 +70,22 @@ __global__ __launch_bounds__(256 * KS) void k_linear_mfma(LinBatch lb) {
   float (*Ws)[GT][GKc + 1] = reinterpret_cast<float (*)[GT][GKc + 1]>(lds + 2 * TM * (GKc + 1));
   const LinArgs& g = lb.a[blockIdx.z];
   const int tid = threadIdx.x, wave = (tid >> 6) & 3, kg = tid >> 8, lane = tid & 63;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GT;
+  // Workgroup -> tile map.  Workgroups are handed to the 8 XCDs round robin in launch order (observed, MI355X guide; only speed depends
+  // on it), so with the plain (x, y) map one XCD gets ONE column of tiles and pulls ALL of X through the fabric into its own L2.  Here
+  // the tiles are cut into 8 rectangles (pm x pn) and XCD c works through rectangle c: it touches 1 / pm of X and 1 / pn of W.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int GN = gridDim.x, GM = gridDim.y;
+    const int pm = GM % 4 == 0 && GN % 2 == 0 ? 4 : (GM % 2 == 0 && GN % 4 == 0 ? 2 : (GM % 8 == 0 ? 8 : (GN % 8 == 0 ? 1 : 0)));
+    if (pm && !lb.plain_map) {
+      const int pn = 8 / pm, mg = GM / pm, ng = GN / pn;
+      const int lin = bx + GN * by, xcd = lin & 7, slot = lin >> 3;
+      by = (xcd % pm) * mg + slot % mg;
+      bx = (xcd / pm) * ng + slot / mg;
+      (void)ng;
+    }
+  }
+  const int m0 = by * TM, n0 = bx * GT;
   const int M = g.M, N = g.N, K = g.K;
   if (m0 >= M || n0 >= N) return;                 // the grid covers the larger problem of the batch
   const int wm = (wave >> 1) * 32 * WTM, wn = (wave & 1) * 32;
@@ -198,8 +213,8 @@ static void launch_linear_as(const LinBatch& lb, int count, int M, int Nx, hipSt
   hipLaunchKernelGGL((k_linear_mfma<WTM, KS, GKc>), dim3((Nx + GT - 1) / GT, (M + WTM * GT - 1) / (WTM * GT), count), dim3(256 * KS), 0, st, lb);
 }
 static int g_linear_shape = 0;           // sdxpk_linear_force_shape (tests / timing tools); 0 = automatic
-#define SDXP_LINEAR_SMALL_M_SHAPE 1     // the shape below M = 2048 when SDXP_LINEAR_TILE is unset
-static void launch_linear(const LinBatch& lb, int count, int M, int Nx, hipStream_t st) {
+#define SDXP_LINEAR_SMALL_M_SHAPE 3     // the shape below M = 2048 when SDXP_LINEAR_TILE is unset
+static void launch_linear(LinBatch& lb, int count, int M, int Nx, hipStream_t st) {
   // 64 x 64 tiles up to 2048 rows, 128 x 64 beyond.  SDXP_LINEAR_TILE forces one shape (timing aid): 1 = 64 x 64, 2 = 128 x 64,
   // 3 = 64 x 64 with 2 k groups, 4 = the same with chunks of 64, 5 = 4 k groups and chunks of 64, 6 = 64 x 64 with chunks of 64.
   // Measured at M = 1024 (tools/time_act.py, profiles/r3_act_pmc.csv): 143 us per sdxp_act with shape 1, 206 us with shape 2 - at this size
@@ -207,7 +222,8 @@ static void launch_linear(const LinBatch& lb, int count, int M, int Nx, hipStrea
   for (int i = 0; i < count; ++i)
     if (lb.a[i].nmean && lb.a[i].K > SDXP_NORM_K) { fprintf(stderr, "seqdex: k_linear_mfma normalises at most %d input columns (got %d)\n", SDXP_NORM_K, lb.a[i].K); abort(); }
   static const int env_forced = getenv("SDXP_LINEAR_TILE") ? atoi(getenv("SDXP_LINEAR_TILE")) : 0;
-  const int forced = g_linear_shape ? g_linear_shape : env_forced;
+  const int forced = (g_linear_shape & 15) ? (g_linear_shape & 15) : env_forced;
+  lb.plain_map = (g_linear_shape >> 4) & 1;      // + 16: plain (x, y) tile map (timing aid)
   const int shape = forced ? forced : (M > 2048 ? 2 : SDXP_LINEAR_SMALL_M_SHAPE);
   switch (shape) {
     case 2: launch_linear_as<2, 1, 32>(lb, count, M, Nx, st); break;
@@ -234,25 +250,56 @@ __global__ __launch_bounds__(64) void k_act_heads(SdxpDev D, int t, const float*
                                                   const float* __restrict__ eps_in, float* __restrict__ actions_out,
                                                   uint64_t counter) {
   const int e = blockIdx.x, lane = threadIdx.x;
-  const int A = D.act_dim, U = D.units[2];
-  __shared__ float s_h[2][256];
-  for (int i = lane; i < U; i += 64) {
-    s_h[0][i] = D.h_a[2][(size_t)e * U + i];
-    s_h[1][i] = D.h_v[2][(size_t)e * U + i];
+  const int A = D.act_dim;
+  constexpr int U = 256;                            // units[2] (sdxp_create refuses other widths)
+  __shared__ float s_h[2][U];
+  const size_t row = (size_t)e * D.horizon + t;
+  // Everything this workgroup reads that does not depend on its own arithmetic is requested up front - the trunk outputs, the value-head
+  // weights and the observation / state rows that are copied into the dataset (16-byte pieces; obs_dim and state_dim are multiples of 4):
+  // with 4 waves per CU every dependent load is a full L2 round trip (about 0.7 us), and the rolled copy loops alone were 16 of them
+  constexpr int CP = 4;                             // 16-byte pieces per lane and row: rows up to 1024 floats (SDXP_NORM_K)
+  float ha[U / 64], hv[U / 64], wvh[U / 64];
+  float4 co[CP], cs[CP];
+  const float4* osrc = reinterpret_cast<const float4*>(obs + (size_t)e * D.obs_dim);
+  const float4* ssrc = reinterpret_cast<const float4*>(states + (size_t)e * D.state_dim);
+  const int on4 = D.obs_dim >> 2, sn4 = D.state_dim >> 2;
+#pragma unroll
+  for (int i = 0; i < U / 64; ++i) {
+    ha[i] = D.h_a[2][(size_t)e * U + lane + 64 * i];
+    hv[i] = D.h_v[2][(size_t)e * U + lane + 64 * i];
+    wvh[i] = D.cv[D.coff.v_w + lane + 64 * i];
+  }
+  // (lanes past the end of a row repeat its last piece, load and store alike: no branch for the optimiser to sink the loads into)
+#pragma unroll
+  for (int i = 0; i < CP; ++i) {
+    co[i] = osrc[min(lane + 64 * i, on4 - 1)];
+    cs[i] = ssrc[min(lane + 64 * i, sn4 - 1)];
+  }
+  __builtin_amdgcn_sched_barrier(0);               // (keeps the loads above the first use: the scheduler sinks each copy load to its store)
+#pragma unroll
+  for (int i = 0; i < U / 64; ++i) { s_h[0][lane + 64 * i] = ha[i]; s_h[1][lane + 64 * i] = hv[i]; }
+  {
+    float4* odst = reinterpret_cast<float4*>(D.mb_obs + row * D.obs_dim);
+    float4* sdst = reinterpret_cast<float4*>(D.mb_states + row * D.state_dim);
+#pragma unroll
+    for (int i = 0; i < CP; ++i) {
+      odst[min(lane + 64 * i, on4 - 1)] = co[i];
+      sdst[min(lane + 64 * i, sn4 - 1)] = cs[i];
+    }
   }
   __syncthreads();
-  const size_t row = (size_t)e * D.horizon + t;
   float nlp_part = 0.0f;
   if (lane < A) {
     const float* w = D.ac + D.off.mu_w + (size_t)lane * U;
     float mu = D.ac[D.off.mu_b + lane];
-    for (int k0 = 0; k0 < U; k0 += 16) {           // 16 weight loads in flight (rolled, every k waited for its own load: 13.7 us per launch);
-      float wv[16];                                // units[2] == 256 (sdxp_create); the sum still runs over k in ascending order
+#pragma unroll 1
+    for (int k0 = 0; k0 < U; k0 += 32) {           // 32 weight loads in flight (rolled, every k was its own L2 round trip: 13.7 us per launch);
+      float wv[32];                                // the sum still runs over k in ascending order
 #pragma unroll
-      for (int j = 0; j < 16; ++j) wv[j] = w[k0 + j];
+      for (int j = 0; j < 32; ++j) wv[j] = w[k0 + j];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) mu += wv[j] * s_h[0][k0 + j];
+      for (int j = 0; j < 32; ++j) mu += wv[j] * s_h[0][k0 + j];
     }
     const float ls = D.ac[D.off.logstd + lane], sg = expf(ls);
     const float eps = eps_in ? eps_in[(size_t)e * A + lane] : randn(D.seed, counter, (uint64_t)e * 64 + lane);
@@ -266,18 +313,14 @@ __global__ __launch_bounds__(64) void k_act_heads(SdxpDev D, int t, const float*
   }
   const float nlp = wave_sum(nlp_part) + 0.5f * 1.8378770664093453f * (float)A;
   float vpart = 0.0f;
-  {
-    const float* w = D.cv + D.coff.v_w;
-    for (int k = lane; k < U; k += 64) vpart += w[k] * s_h[1][k];
-  }
+#pragma unroll
+  for (int i = 0; i < U / 64; ++i) vpart += wvh[i] * hv[i];
   const float v = wave_sum(vpart) + D.cv[D.coff.v_b];
   if (lane == 0) {
     D.mb_neglogp[row] = nlp;
     D.mb_values[row] = v;
     D.mb_dones[row] = (dones && dones[e] != 0) ? 1.0f : 0.0f;
   }
-  for (int i = lane; i < D.obs_dim; i += 64) D.mb_obs[row * D.obs_dim + i] = obs[(size_t)e * D.obs_dim + i];
-  for (int i = lane; i < D.state_dim; i += 64) D.mb_states[row * D.state_dim + i] = states[(size_t)e * D.state_dim + i];
 }
 
 __global__ void k_store_rewards(SdxpDev D, int t, const float* __restrict__ rew, const int64_t* __restrict__ dones_after) {
