@@ -76,12 +76,22 @@ struct SdxBuf {
 #ifdef HIPEMU
 #define SDX_OPAQUE(x) ((void)0)
 #define SDX_OPAQUE_S(x) ((void)0)
+#define SDX_OPAQUE_AFTER(x, after) ((void)0)
+#define SDX_PIN4(a) ((void)0)
+#define SDX_PIN8(a) ((void)0)
 #define SDX_RCP(x) (1.0f / (x))
 #define SDX_READLANE(x, lane) __shfl((x), (lane), 64)
 #define SDX_UNIFORM(x) (x)
 #else
 #define SDX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define SDX_OPAQUE_S(x) asm volatile("" : "+s"(x))   // the same for a wave-uniform value (scalar register)
+// x becomes unknown at a point that is ordered after the arithmetic producing `after`: loads addressed through x cannot be hoisted above it
+#define SDX_OPAQUE_AFTER(x, after) asm volatile("" : "+v"(x) : "v"(after))
+// every element of a[0..3] / a[0..7] passes through one empty asm: pins the order of the arithmetic on them.  Instruction selection orders
+// only what hangs on a chain of side effects; unpinned accumulators of an unrolled loop are deferred to the end of the block and the
+// operands already loaded for them are spilled
+#define SDX_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#define SDX_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
 #define SDX_RCP(x) __builtin_amdgcn_rcpf(x)   // v_rcp_f32, 1 ulp: the solver's step lengths do not need IEEE division (12 instructions)
 // value of x in a lane known at compile time (v_readlane_b32: the result is wave-uniform, no LDS crossbar); every lane of the wave must be active
 #define SDX_READLANE(x, lane) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (lane)))

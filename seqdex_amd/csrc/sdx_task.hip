@@ -640,9 +640,14 @@ __global__ __launch_bounds__(SDX_WAVE) void k_post_physics(const SdxConst* __res
 // tv_w layout (device, transposed for coalesced neuron-major reads): W1T[4][256] b1[256] W2T[256][128] b2[128]
 // W3T[128][64] b3[64] W4T[64][2] b4[2].  One block = 16 envs x 256 threads.
 #define TV_ENVS 16
-#define TV_LOADS 64
+#define TV_LOADS 32
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
 
+// Batches of TV_LOADS weight loads.  TV_LOAD's index passes through an empty asm that also takes `after`, a value of the arithmetic the batch
+// must stay behind: the optimiser can then neither merge the batches into one 192-register group nor sink a load to its use, and
+// sched_barrier holds the order in the machine scheduler.
+#define TV_LOAD(w, expr, after) do { int o_ = 0; SDX_OPAQUE_AFTER(o_, after); _Pragma("unroll") for (int j = 0; j < TV_LOADS; ++j) { const int jj = j + o_; w[j] = (expr); } \
+                                     __builtin_amdgcn_sched_barrier(0); } while (0)
 __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
   __shared__ float s_x[TV_ENVS][4];
   __shared__ float s_h1[TV_ENVS][256];
@@ -657,81 +662,21 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
   const float* b3 = W3 + 128 * 64;
   const float* W4 = b3 + 64;
   const float* b4 = W4 + 64 * 2;
-  if (t < TV_ENVS * 4) {
-    const int e = e0 + t / 4;
-    s_x[t / 4][t % 4] = e < B.N ? B.cam_rot[(size_t)e * 4 + (t % 4)] : 0.0f;
-  }
-  __syncthreads();
-  {  // layer 1: thread = neuron, all 16 envs
-    float w[4];
+  // The launch is 64 workgroups on an otherwise idle chip: its time is the chain of dependent L2 round trips (about 0.7 us each), not
+  // arithmetic.  Rolled, every k of every layer was one (32 us per launch).  Now every input that depends on nothing is requested at the top,
+  // the weights move in batches of TV_LOADS, and batch i + 1 (or the next layer's first) is in flight while batch i is multiplied.
+  // The sums still run over k in ascending order: same values bit for bit.
+  const int n2 = t & 127, eh = (t >> 7) * 8;        // layer 2: neuron = t % 128, env half = t / 128
+  const int n3 = t & 63, eq = (t >> 6) * 4;         // layer 3: neuron = t % 64, env quarter = t / 64
+  float wa[TV_LOADS], wb[TV_LOADS], w1[4];
+  const float xin = t < TV_ENVS * 4 && e0 + t / 4 < B.N ? B.cam_rot[(size_t)(e0 + t / 4) * 4 + (t % 4)] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = W1[k * 256 + t];
-    const float b = b1[t];
-#pragma unroll
-    for (int e = 0; e < TV_ENVS; ++e)
-      s_h1[e][t] = elu1(b + w[0] * s_x[e][0] + w[1] * s_x[e][1] + w[2] * s_x[e][2] + w[3] * s_x[e][3]);
-  }
-  __syncthreads();
-  {  // layer 2: neuron = t % 128, env half = t / 128
-    const int n = t & 127, eh = (t >> 7) * 8;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = b2[n];
-#pragma unroll 1
-    for (int k0 = 0; k0 < 256; k0 += TV_LOADS) {   // TV_LOADS weight loads in flight: the launch is a chain of L2 round trips (about 0.7 us
-      float w[TV_LOADS];                           // each with 64 workgroups on the chip), one per k when rolled (32 us), 28 at 16 in flight (22 us);
-#pragma unroll                                     // the sums still run over k in ascending order
-      for (int j = 0; j < TV_LOADS; ++j) w[j] = W2[(k0 + j) * 128 + n];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < TV_LOADS; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += w[j] * s_h1[eh + e][k0 + j];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s_h2[eh + e][n] = elu1(acc[e]);
-  }
-  __syncthreads();
-  {  // layer 3: neuron = t % 64, env quarter = t / 64
-    const int n = t & 63, eq = (t >> 6) * 4;
-    float acc[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = b3[n];
-#pragma unroll 1
-    for (int k0 = 0; k0 < 128; k0 += TV_LOADS) {
-      float w[TV_LOADS];
-#pragma unroll
-      for (int j = 0; j < TV_LOADS; ++j) w[j] = W3[(k0 + j) * 64 + n];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < TV_LOADS; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += w[j] * s_h2[eq + e][k0 + j];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s_h3[eq + e][n] = elu1(acc[e]);
-  }
-  __syncthreads();
-  if (t < TV_ENVS) {  // layer 4, output 1 only feeds the sigmoid (GS:1201)
-    float y = b4[1];
-#pragma unroll 1
-    for (int k0 = 0; k0 < 64; k0 += TV_LOADS) {
-      float w[TV_LOADS];
-#pragma unroll
-      for (int j = 0; j < TV_LOADS; ++j) w[j] = W4[(k0 + j) * 2 + 1];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < TV_LOADS; ++j) y += w[j] * s_h3[t][k0 + j];
-    }
-    y = elu1(y);
-    if (e0 + t < B.N) {
-      float tvv = 1.0f / (1.0f + expf(-y));
-      if (B.task_kind == 1) tvv = tvv > B.orient_gate ? 1.0f : 0.0f;             // Orient gates the T-value at 0.99, OR:1203 (sdx_scene_desc.orient_tvalue_gate)
-      B.tvalue[e0 + t] = tvv;
-    }
-  }
-  if (finalize_stats && blockIdx.x == 0 && t == 0) {
-    // cons_successes EMA (GS:1771-1774) from the per-step sums gathered by k_post_physics
+  for (int k = 0; k < 4; ++k) w1[k] = W1[k * 256 + t];
+  const float bias1 = b1[t], bias2 = b2[n2], bias3 = b3[n3], bias4 = b4[1];
+  TV_LOAD(wa, W2[jj * 128 + n2], 0.0f);
+  if (finalize_stats && blockIdx.x == 0 && t == 255) {
+    // cons_successes EMA (GS:1771-1774) from the per-step sums gathered by k_post_physics (independent of the T-value: up here its three
+    // dependent round trips overlap the MLP instead of trailing it)
     const uint32_t step = B.step_count[0];
     const int par = (int)(step & 1u);
     const float num_resets = B.stat[par * 2 + 0], fin = B.stat[par * 2 + 1];
@@ -739,6 +684,65 @@ __global__ __launch_bounds__(256) void k_tvalue(SdxBuf B, int finalize_stats) {
     B.stat[par * 2 + 0] = 0.0f;
     B.stat[par * 2 + 1] = 0.0f;
     B.step_count[0] = step + 1;
+  }
+  if (t < TV_ENVS * 4) s_x[t / 4][t % 4] = xin;
+  __syncthreads();
+  float h1keep = 0.0f;
+#pragma unroll
+  for (int e = 0; e < TV_ENVS; ++e) {                // layer 1: thread = neuron, all 16 envs
+    h1keep = elu1(bias1 + w1[0] * s_x[e][0] + w1[1] * s_x[e][1] + w1[2] * s_x[e][2] + w1[3] * s_x[e][3]);
+    s_h1[e][t] = h1keep;
+  }
+  __syncthreads();
+  static_assert(TV_LOADS == 32, "the batches below are written out for 256 / 128 / 64 inputs in batches of 32");
+  // SDX_PIN after every 4 k: without it acc[0] (which the next TV_LOAD names) is finished first, the other accumulators are deferred to the end
+  // of the block and the LDS operands already read for them are spilled (6.5 KB of scratch per lane)
+#define TV_MAC(acc, NE, w, H, e0_, k0) do { _Pragma("unroll") for (int j4 = 0; j4 < TV_LOADS; j4 += 4) { _Pragma("unroll") for (int j = j4; j < j4 + 4; ++j) { \
+                                             _Pragma("unroll") for (int e = 0; e < NE; ++e) acc[e] += w[j] * H[e0_ + e][(k0) + j]; } \
+                                             SDX_PIN##NE(acc); } __builtin_amdgcn_sched_barrier(0); } while (0)
+  {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias2;
+    TV_LOAD(wb, W2[(32 + jj) * 128 + n2], h1keep);   TV_MAC(acc, 8, wa, s_h1, eh, 0);
+    TV_LOAD(wa, W2[(64 + jj) * 128 + n2], acc[0]);   TV_MAC(acc, 8, wb, s_h1, eh, 32);
+    TV_LOAD(wb, W2[(96 + jj) * 128 + n2], acc[0]);   TV_MAC(acc, 8, wa, s_h1, eh, 64);
+    TV_LOAD(wa, W2[(128 + jj) * 128 + n2], acc[0]);  TV_MAC(acc, 8, wb, s_h1, eh, 96);
+    TV_LOAD(wb, W2[(160 + jj) * 128 + n2], acc[0]);  TV_MAC(acc, 8, wa, s_h1, eh, 128);
+    TV_LOAD(wa, W2[(192 + jj) * 128 + n2], acc[0]);  TV_MAC(acc, 8, wb, s_h1, eh, 160);
+    TV_LOAD(wb, W2[(224 + jj) * 128 + n2], acc[0]);  TV_MAC(acc, 8, wa, s_h1, eh, 192);
+    TV_LOAD(wa, W3[jj * 64 + n3], acc[0]);           TV_MAC(acc, 8, wb, s_h1, eh, 224);       // (layer 3's first batch)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_h2[eh + e][n2] = elu1(acc[e]);
+    h1keep = acc[0];
+  }
+  __syncthreads();
+  {
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = bias3;
+    TV_LOAD(wb, W3[(32 + jj) * 64 + n3], h1keep);    TV_MAC(acc, 4, wa, s_h2, eq, 0);
+    TV_LOAD(wa, W3[(64 + jj) * 64 + n3], acc[0]);    TV_MAC(acc, 4, wb, s_h2, eq, 32);
+    TV_LOAD(wb, W3[(96 + jj) * 64 + n3], acc[0]);    TV_MAC(acc, 4, wa, s_h2, eq, 64);
+    TV_LOAD(wa, W4[jj * 2 + 1], acc[0]);             TV_MAC(acc, 4, wb, s_h2, eq, 96);        // (layer 4: one output, the same weights for every thread)
+    TV_LOAD(wb, W4[(32 + jj) * 2 + 1], acc[0]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_h3[eq + e][n3] = elu1(acc[e]);
+  }
+  __syncthreads();
+#undef TV_MAC
+  if (t < TV_ENVS) {  // layer 4, output 1 only feeds the sigmoid (GS:1201)
+    float y = bias4;
+#pragma unroll
+    for (int j = 0; j < TV_LOADS; ++j) y += wa[j] * s_h3[t][j];
+#pragma unroll
+    for (int j = 0; j < TV_LOADS; ++j) y += wb[j] * s_h3[t][32 + j];
+    y = elu1(y);
+    if (e0 + t < B.N) {
+      float tvv = 1.0f / (1.0f + expf(-y));
+      if (B.task_kind == 1) tvv = tvv > B.orient_gate ? 1.0f : 0.0f;             // Orient gates the T-value at 0.99, OR:1203 (sdx_scene_desc.orient_tvalue_gate)
+      B.tvalue[e0 + t] = tvv;
+    }
   }
 }
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ float lane0(float v) { return __builtin_bit_cast(floa
 #define GT 64
 #define SDXP_NORM_K 1024   // widest input that may be normalised on the fly (checked by the launchers)
 struct LinArgs { const float* X; const float* W; const float* b; float* Y; int M, N, K, elu; const double* nmean; const double* nvar; };
-struct LinBatch { LinArgs a[2]; int plain_map; };
+struct LinBatch { LinArgs a[2]; };
 // WTM = 1: 64 x 64 tile (wave = 32 x 32); WTM = 2: 128 x 64 tile (wave = 64 x 32: two MFMAs share one W operand - 21 instead of 16 flops
 // per operand byte fetched from L2).  GKc = reduction chunk staged per barrier.  KS = split of every chunk over KS groups of four waves
 // (256 KS threads): group g multiplies the k range [g GKc / KS, (g + 1) GKc / KS) of each chunk into its own accumulators and the groups
@@ -70,22 +70,10 @@ __global__ __launch_bounds__(256 * KS) void k_linear_mfma(LinBatch lb) {
   float (*Ws)[GT][GKc + 1] = reinterpret_cast<float (*)[GT][GKc + 1]>(lds + 2 * TM * (GKc + 1));
   const LinArgs& g = lb.a[blockIdx.z];
   const int tid = threadIdx.x, wave = (tid >> 6) & 3, kg = tid >> 8, lane = tid & 63;
-  // Workgroup -> tile map.  Workgroups are handed to the 8 XCDs round robin in launch order (observed, MI355X guide; only speed depends
-  // on it), so with the plain (x, y) map one XCD gets ONE column of tiles and pulls ALL of X through the fabric into its own L2.  Here
-  // the tiles are cut into 8 rectangles (pm x pn) and XCD c works through rectangle c: it touches 1 / pm of X and 1 / pn of W.
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int GN = gridDim.x, GM = gridDim.y;
-    const int pm = GM % 4 == 0 && GN % 2 == 0 ? 4 : (GM % 2 == 0 && GN % 4 == 0 ? 2 : (GM % 8 == 0 ? 8 : (GN % 8 == 0 ? 1 : 0)));
-    if (pm && !lb.plain_map) {
-      const int pn = 8 / pm, mg = GM / pm, ng = GN / pn;
-      const int lin = bx + GN * by, xcd = lin & 7, slot = lin >> 3;
-      by = (xcd % pm) * mg + slot % mg;
-      bx = (xcd / pm) * ng + slot / mg;
-      (void)ng;
-    }
-  }
-  const int m0 = by * TM, n0 = bx * GT;
+  // (An XCD-aware workgroup -> tile map - the tiles cut into 8 rectangles, XCD c working through rectangle c so that it pulls 1/4 of X and
+  // 1/2 of W through the fabric instead of all of X - was measured at M = 1024: 87.3 us per sdxp_act against 86.2 with the plain map.
+  // These layers are not bound by operand traffic.)
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GT;
   const int M = g.M, N = g.N, K = g.K;
   if (m0 >= M || n0 >= N) return;                 // the grid covers the larger problem of the batch
   const int wm = (wave >> 1) * 32 * WTM, wn = (wave & 1) * 32;
@@ -214,16 +202,16 @@ static void launch_linear_as(const LinBatch& lb, int count, int M, int Nx, hipSt
 }
 static int g_linear_shape = 0;           // sdxpk_linear_force_shape (tests / timing tools); 0 = automatic
 #define SDXP_LINEAR_SMALL_M_SHAPE 3     // the shape below M = 2048 when SDXP_LINEAR_TILE is unset
-static void launch_linear(LinBatch& lb, int count, int M, int Nx, hipStream_t st) {
-  // 64 x 64 tiles up to 2048 rows, 128 x 64 beyond.  SDXP_LINEAR_TILE forces one shape (timing aid): 1 = 64 x 64, 2 = 128 x 64,
-  // 3 = 64 x 64 with 2 k groups, 4 = the same with chunks of 64, 5 = 4 k groups and chunks of 64, 6 = 64 x 64 with chunks of 64.
-  // Measured at M = 1024 (tools/time_act.py, profiles/r3_act_pmc.csv): 143 us per sdxp_act with shape 1, 206 us with shape 2 - at this size
-  // the layers are bound by the latency of their 13-32 dependent chunks, not by operand bandwidth
+static void launch_linear(const LinBatch& lb, int count, int M, int Nx, hipStream_t st) {
+  // Up to 2048 rows: 64 x 64 tiles, every chunk split over two groups of four waves; beyond: 128 x 64.  SDXP_LINEAR_TILE forces one shape
+  // (timing aid): 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 64 with 2 k groups, 4 = the same with chunks of 64, 5 = 4 k groups and chunks of
+  // 64, 6 = 64 x 64 with chunks of 64.  sdxp_act at M = 1024 (tools/time_act.py, profiles/r3_act_shapes.txt): 87 us with shape 3 or 4, 95 with
+  // 1, 96 with 6, 95 with 5, 141 with 2 (round 3 started at 143 with shape 1: exec-masked loads made every wait vmcnt(0), and the LDS operands were
+  // read two at a time).  The matrix pipe is about half busy in the middle layer; the rest is the per-chunk barrier and LDS read latency
   for (int i = 0; i < count; ++i)
     if (lb.a[i].nmean && lb.a[i].K > SDXP_NORM_K) { fprintf(stderr, "seqdex: k_linear_mfma normalises at most %d input columns (got %d)\n", SDXP_NORM_K, lb.a[i].K); abort(); }
   static const int env_forced = getenv("SDXP_LINEAR_TILE") ? atoi(getenv("SDXP_LINEAR_TILE")) : 0;
-  const int forced = (g_linear_shape & 15) ? (g_linear_shape & 15) : env_forced;
-  lb.plain_map = (g_linear_shape >> 4) & 1;      // + 16: plain (x, y) tile map (timing aid)
+  const int forced = g_linear_shape ? g_linear_shape : env_forced;
   const int shape = forced ? forced : (M > 2048 ? 2 : SDXP_LINEAR_SMALL_M_SHAPE);
   switch (shape) {
     case 2: launch_linear_as<2, 1, 32>(lb, count, M, Nx, st); break;
