@@ -22,8 +22,11 @@ def test_chain_hand_offs_at_1024_envs():
     assert tv is not None, prep                                   # both outcome classes were logged and the fit ran
     # gates at 0.5 / 0.28 instead of 0.99 (OR:1203) / 0.8 (GS:1406): a T-value fitted to a thousand epochs of outcomes tops out near 0.85 and
     # sits at its floor sigmoid(-1) = 0.27 for most orientations; two grasp episodes
-    res, hand = block_assembly_chain(N, tv, controllers={"grasp": scripted_grasp_controller}, synthetic_fallback=True, orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28,
-                                     stage_steps={"grasp": 320})
+    try:
+        res, hand = block_assembly_chain(N, tv, controllers={"grasp": scripted_grasp_controller}, synthetic_fallback=True, orient_tvalue_gate=0.5,
+                                         grasp_tvalue_gate=0.28, stage_steps={"grasp": 320})
+    except RuntimeError as ex:
+        pytest.fail("%s; stage 0 was %s" % (ex, prep))
     ins = hand["insert_task"]
     try:
         # ---- hand-off 1: Orient harvested >= 8 piles for every brick-type group, and GraspSim started from them
