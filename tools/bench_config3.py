@@ -63,7 +63,8 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to
         while rounds < 4:
             trn.train_rollout()
             rounds += 1
-            cover = float((torch.sigmoid(trn.predict(q))[:, 1] > 0.5).float().mean())
+            out = torch.cat([trn.predict(q[i:i + 1024]) for i in range(0, q.shape[0], 1024)])     # (sdxtv_predict takes at most one batch)
+            cover = float((torch.sigmoid(out)[:, 1] > 0.5).float().mean())
             if cover >= 5e-4:
                 break
         st["tvalue_fit"] = {"iterations": fit_iters * rounds, "loss": trn.losses[-1], "held_out_success_rate": trn.valid_t_value_success_rate,
