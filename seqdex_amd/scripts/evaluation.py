@@ -155,6 +155,20 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     st["piles_harvested_per_type"] = orient.sim.PILE_HARVEST_COUNT.cpu().tolist()
     st["tvalue_gate"] = orient_tvalue_gate
     piles = orient.pile_terminal_states()
+    if synthetic_fallback:
+        # brick-type groups Orient could not fill (the gate of a briefly fitted T-value can miss the orientations one brick type settles
+        # in) start GraspSim from settled piles instead - the states GraspSim generates for itself when it is given none (piles.generate_piles) -
+        # as InsertSim's groups without a harvested grasp state fall back to its synthetic ones; the statistics name them
+        from ..piles import generate_piles
+        cnt = np.minimum(orient.sim.PILE_HARVEST_COUNT.cpu().numpy(), orient.sim.PILE_HARVEST.shape[1])
+        lacking = [t for t in range(8) if cnt[t] < min_piles]
+        if lacking and len(lacking) <= 2:
+            k = int(cnt[cnt >= min_piles].min())
+            piles = orient.sim.PILE_HARVEST[:, :k].clone()
+            settled = torch.as_tensor(generate_piles(k, device=str(piles.device), seed=seed)).to(piles.device)
+            for t in lacking:
+                piles[t] = settled[t]
+            st["settled_stand_in_groups"] = lacking
     orient.sim.close()
     out["orient"] = st
     if piles is None:
