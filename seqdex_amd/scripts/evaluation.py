@@ -121,6 +121,24 @@ def scripted_grasp_controller(task, step):
     return a
 
 
+def fill_missing_pile_groups(harvest, counts, min_piles, seed, max_missing=2):
+    """Brick-type groups Orient could not fill (the gate of a briefly fitted T-value can miss the orientations one brick type settles in)
+    start GraspSim from settled piles instead - the states GraspSim generates for itself when it is given none (piles.generate_piles) - as
+    InsertSim's groups without a harvested grasp state fall back to its synthetic ones.  harvest [8, slots, 132, 13], counts [8].
+    Returns ([8, K, 132, 13], the groups that were filled in) or (None, []) when every group has min_piles or more than max_missing lack them."""
+    from ..piles import generate_piles
+    cnt = np.minimum(counts.cpu().numpy(), harvest.shape[1])
+    lacking = [t for t in range(8) if cnt[t] < min_piles]
+    if not lacking or len(lacking) > max_missing:
+        return None, []
+    k = int(cnt[cnt >= min_piles].min())
+    piles = harvest[:, :k].clone()
+    settled = torch.as_tensor(generate_piles(k, device=str(piles.device), seed=seed)).to(piles.device)
+    for t in lacking:
+        piles[t] = settled[t]
+    return piles, lacking
+
+
 def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, controllers=None, min_piles=8, seed=22, stage_steps=None,
                          synthetic_fallback=False, orient_tvalue_gate=0.99, grasp_tvalue_gate=0.8, with_search=False):
     """Orient -> GraspSim -> InsertSim played back to back on one GPU.  policies / controllers / stage_steps: dicts keyed "orient",
@@ -156,19 +174,9 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     st["tvalue_gate"] = orient_tvalue_gate
     piles = orient.pile_terminal_states()
     if synthetic_fallback:
-        # brick-type groups Orient could not fill (the gate of a briefly fitted T-value can miss the orientations one brick type settles
-        # in) start GraspSim from settled piles instead - the states GraspSim generates for itself when it is given none (piles.generate_piles) -
-        # as InsertSim's groups without a harvested grasp state fall back to its synthetic ones; the statistics name them
-        from ..piles import generate_piles
-        cnt = np.minimum(orient.sim.PILE_HARVEST_COUNT.cpu().numpy(), orient.sim.PILE_HARVEST.shape[1])
-        lacking = [t for t in range(8) if cnt[t] < min_piles]
-        if lacking and len(lacking) <= 2:
-            k = int(cnt[cnt >= min_piles].min())
-            piles = orient.sim.PILE_HARVEST[:, :k].clone()
-            settled = torch.as_tensor(generate_piles(k, device=str(piles.device), seed=seed)).to(piles.device)
-            for t in lacking:
-                piles[t] = settled[t]
-            st["settled_stand_in_groups"] = lacking
+        filled, lacking = fill_missing_pile_groups(orient.sim.PILE_HARVEST, orient.sim.PILE_HARVEST_COUNT, min_piles, seed)
+        if lacking:
+            piles, st["settled_stand_in_groups"] = filled, lacking
     orient.sim.close()
     out["orient"] = st
     if piles is None:

@@ -65,3 +65,20 @@ def test_chain_hand_offs_at_1024_envs():
         assert res["chain_env_steps_per_s"] > 0 and res["insert"]["steps_per_env"] >= 125
     finally:
         ins.sim.close()
+
+
+def test_groups_without_harvested_piles_get_settled_ones():
+    from seqdex_amd.piles import generate_piles
+    from seqdex_amd.scripts.evaluation import fill_missing_pile_groups
+    harvest = torch.as_tensor(generate_piles(12, device="cuda:0", seed=3)).cuda()              # [8, 12, 132, 13]: stands for Orient's harvest ring
+    counts = torch.tensor([12, 30, 9, 12, 12, 12, 0, 3], device="cuda:0")
+    piles, lacking = fill_missing_pile_groups(harvest, counts, 8, seed=5)
+    assert lacking == [6, 7] and tuple(piles.shape) == (8, 9, 132, 13)                          # K = the smallest fill among the complete groups
+    for t in range(8):
+        if t in lacking:
+            assert not torch.equal(piles[t], harvest[t, :9])
+            assert torch.isfinite(piles[t]).all() and float(piles[t][..., 3:7].norm(dim=-1).min()) > 0.99
+        else:
+            assert torch.equal(piles[t], harvest[t, :9])
+    assert fill_missing_pile_groups(harvest, torch.full((8,), 12, device="cuda:0"), 8, seed=5) == (None, [])
+    assert fill_missing_pile_groups(harvest, torch.tensor([0, 0, 0, 12, 12, 12, 12, 12], device="cuda:0"), 8, seed=5) == (None, [])
