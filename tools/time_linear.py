@@ -1,6 +1,6 @@
 """one trunk layer of the rollout at a time (sdxpk_linear2: actor + central value in one launch), operands left untouched between launches
 (whatever the caches keep of them stays): us per launch.  Beside tools/time_act.py (where every layer reads what the previous launch
-has just written) this separates the memory system from the kernel's own pipeline.   usage: python tools/time_linear.py [M]"""
+has just written) this separates the memory system from the kernel's own pipeline.   usage: python tools/time_linear.py [M] [shape ...]"""
 import ctypes as C
 import os
 import sys
@@ -17,7 +17,7 @@ lib.sdxpk_linear2.restype = None
 lib.sdxpk_linear2.argtypes = ([C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p] * 2) * 2 + [C.c_int, C.c_int, C.c_void_p]
 lib.sdxpk_linear_force_shape.argtypes = [C.c_int]
 layers = [("L0 396/564 -> 1024", 1024, 396, 564), ("L1 1024 -> 512", 512, 1024, 1024), ("L2 512 -> 256", 256, 512, 512)]
-for shape in (3, 1, 4):
+for shape in ([int(a) for a in sys.argv[2:]] or [3, 1, 4]):
     lib.sdxpk_linear_force_shape(shape)
     tot = 0.0
     for name, n, k0, k1 in layers:
