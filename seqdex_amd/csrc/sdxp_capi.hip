@@ -140,6 +140,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
   if (cfg->units[2] != 256 || cfg->units[0] % 4 || cfg->units[1] % 4 || cfg->act_dim > 32 || cfg->obs_dim % 4 || cfg->state_dim % 4) {
     gp_create_err = "sdxp_create: unsupported network shape"; return SDX_ERR_INVALID;
   }
+  if (cfg->obs_dim < 4 || cfg->state_dim < 4) { gp_create_err = "sdxp_create: obs_dim and state_dim must be at least 4"; return SDX_ERR_INVALID; }
   if (cfg->obs_dim > 1024 || cfg->state_dim > 1024) {     // SDXP_NORM_K of k_linear_mfma: the per-k normalisation tables of the first layer
     gp_create_err = "sdxp_create: obs_dim / state_dim above 1024 are not supported by the rollout's first-layer kernel"; return SDX_ERR_INVALID;
   }

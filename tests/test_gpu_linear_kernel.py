@@ -80,3 +80,15 @@ def test_two_products_in_one_launch():
             np.testing.assert_allclose(y1.cpu().numpy(), _reference(x1, w1, b1, True, mean, var).float().cpu().numpy(), rtol=2e-5, atol=2e-5)
     finally:
         lib.sdxpk_linear_force_shape(0)
+
+
+def test_create_refuses_input_widths_the_rollout_kernels_cannot_take():
+    """sdxp_create: the first trunk layer normalises through per-column tables of 1 024 entries and the dataset copy of k_act_heads moves a row
+    as at most 256 16-byte pieces; widths outside [4, 1024] are refused with a message instead of being truncated"""
+    from seqdex_amd.ppo import SdxPPO, make_config
+    from seqdex_amd.sim import SdxError
+    for kw in ({"state_dim": 1028}, {"obs_dim": 1028}):
+        with pytest.raises(SdxError, match="above 1024"):
+            SdxPPO(16, config=make_config(16, **kw))
+    ok = SdxPPO(16, config=make_config(16, obs_dim=1024, state_dim=1024))
+    ok.close()
