@@ -90,5 +90,3 @@ def test_create_refuses_input_widths_the_rollout_kernels_cannot_take():
     for kw in ({"state_dim": 1028}, {"obs_dim": 1028}):
         with pytest.raises(SdxError, match="above 1024"):
             SdxPPO(16, config=make_config(16, **kw))
-    ok = SdxPPO(16, config=make_config(16, obs_dim=1024, state_dim=1024))
-    ok.close()
