@@ -353,7 +353,10 @@ typedef enum {
 typedef struct sdxp_agent* sdxp_handle;
 
 /* A2CAgent.__init__ + network build (R1,R2): torch-default Linear init (kaiming_uniform a=sqrt5) drawn from a
- * counter RNG under `seed`, biases zero, logstd zero (YG:8-29, App. C).  Blocking. */
+ * counter RNG under `seed`, biases zero, logstd zero (YG:8-29, App. C).  Blocking.
+ * Shapes accepted (SDX_ERR_INVALID with a message otherwise): obs_dim and state_dim multiples of 4 in [4, 1024] (the rollout's first
+ * trunk layer normalises through 1 024-entry tables, its dataset copy moves a row as at most 256 16-byte pieces), units[0], units[1]
+ * multiples of 4, units[2] == 256, act_dim <= 32, batch_size % minibatch == 0, equal minibatch / mini_epochs for both optimisers. */
 int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed, sdxp_handle* out);
 int sdxp_destroy(sdxp_handle h);
 int sdxp_tensor(sdxp_handle h, int32_t id, void** dev_ptr, int64_t shape[4], int32_t* ndim, int32_t* dtype);
