@@ -83,7 +83,10 @@ if __name__ == "__main__":
     prep = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1200
     import tempfile
     tmp = tempfile.mkdtemp(prefix="sdx_config3_")          # the stage-0 checkpoint (30 MB) is a hand-off inside this run, not an artefact
-    tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, save_to=os.path.join(tmp, "config3_insert_policy"))
+    for seed in (22, 23):        # a second stage 0 if the first fit rates almost no orientation above the Orient gate (run-dependent ring order)
+        tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, seed=seed, save_to=os.path.join(tmp, "config3_insert_policy"))
+        if tv is None or prep_st["tvalue_fit"]["random_orientations_rated_above_0.5"] >= 5e-4:
+            break
     print("stage 0:", json.dumps(prep_st), file=sys.stderr, flush=True)
     res, hand = block_assembly_chain(n, tv, policies={"insert": insert_ckpt}, controllers={"grasp": scripted_grasp_controller},
                                      synthetic_fallback=True, orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28,
