@@ -177,3 +177,27 @@ def test_scene_desc_round3_defaults(scene):
     # overrides reach the descriptor (what BlockAssemblyOrient(tvalue_gate=...) / BlockAssemblyGraspSim(harvest_tvalue_gate=...) use)
     d2 = scene.to_desc(orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28, warm_start=0.0)
     assert abs(d2.orient_tvalue_gate - 0.5) < 1e-7 and abs(d2.grasp_tvalue_gate - 0.28) < 1e-7 and d2.warm_start == 0.0
+
+
+def test_chain_fills_missing_pile_groups_from_settled_piles(monkeypatch):
+    """evaluation.py::fill_missing_pile_groups on CPU tensors (the settled piles come from a stand-in generator here; the GPU suite runs the
+    real one): complete groups keep their harvested states, K = the smallest complete fill, more than two empty groups are not papered over"""
+    import numpy as np
+    import torch
+    import seqdex_amd.piles as piles_mod
+    from seqdex_amd.scripts.evaluation import fill_missing_pile_groups
+    calls = []
+
+    def fake_generate(per_type=8, steps=150, device="cpu", seed=22):
+        calls.append((per_type, seed))
+        return np.full((8, per_type, 132, 13), 7.0, np.float32)
+
+    monkeypatch.setattr(piles_mod, "generate_piles", fake_generate)
+    harvest = torch.arange(8 * 12 * 132 * 13, dtype=torch.float32).reshape(8, 12, 132, 13)
+    piles, lacking = fill_missing_pile_groups(harvest, torch.tensor([12, 30, 9, 12, 12, 12, 0, 3]), 8, seed=5)
+    assert lacking == [6, 7] and tuple(piles.shape) == (8, 9, 132, 13) and calls == [(9, 5)]
+    for t in range(8):
+        assert torch.equal(piles[t], torch.full((9, 132, 13), 7.0) if t in lacking else harvest[t, :9])
+    assert fill_missing_pile_groups(harvest, torch.full((8,), 12), 8, seed=5) == (None, [])
+    assert fill_missing_pile_groups(harvest, torch.tensor([0, 0, 0, 12, 12, 12, 12, 12]), 8, seed=5) == (None, [])
+    assert calls == [(9, 5)]
