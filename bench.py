@@ -89,7 +89,8 @@ def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mi
         po.simulate(scene_desc, root, dof, tg)
     sim_dt = time.time() - t
     sim_rate = n * args.cpu_baseline_steps / sim_dt
-    # the same leg with Isaac Gym's default num_threads (4, CF:201) and the shipped YAML's 64 (EG:158), on smaller samples
+    # the same leg with Isaac Gym's default num_threads (4, CF:201) and the shipped YAML's 64 (EG:158): the SAME sample (same envs,
+    # same number of steps from the same start state) for every thread count, so that the best-of below compares like with like
     by_threads = {str(cores): sim_rate}
     try:
         import ctypes
@@ -98,13 +99,12 @@ def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mi
             if th >= cores:
                 continue
             gomp.omp_set_num_threads(th)
-            nt = min(n, th * 8)
-            r2, d2, t2 = root0[:nt].copy(), dof0[:nt].copy(), targets0[:nt].copy()
-            po.simulate(scene_desc, r2, d2, t2)
+            r2, d2, t2 = root0[:n].copy(), dof0[:n].copy(), targets0[:n].copy()
+            po.simulate(scene_desc, r2, d2, t2)           # the same warm-up step as the all-cores leg
             t = time.time()
-            for _ in range(8):
+            for _ in range(args.cpu_baseline_steps):
                 po.simulate(scene_desc, r2, d2, t2)
-            by_threads[str(th)] = nt * 8 / (time.time() - t)
+            by_threads[str(th)] = n * args.cpu_baseline_steps / (time.time() - t)
         gomp.omp_set_num_threads(cores)
     except OSError:
         pass
@@ -143,7 +143,7 @@ def cpu_baseline(args, scene_desc, root0, dof0, targets0, horizon, minibatch, mi
     return {"value": n_full * horizon / epoch_s, "unit": "env-steps/s", "cores": int(best_threads), "host_cores": cores, "kind": "port", "ppo_threads": ppo_threads,
             "cpu_model": cpu_model, "sim_only_env_steps_per_s": sim_best, "sim_only_env_steps_per_s_by_omp_threads": by_threads,
             "ppo_us_per_optimiser_step": us_per_opt_step,
-            "sample": "sim: %d envs x %d physics steps of oracle/physics_oracle.c (OpenMP over envs, %d threads), %.1f s; "
+            "sample": "sim: %d envs x %d physics steps of oracle/physics_oracle.c (OpenMP over envs; the same sample for every thread count tried, %d threads: %.1f s); "
                       "PPO: %d optimiser steps (minibatch %d) of oracle/ppo_oracle.py on torch-CPU (%d threads), %.1f s, scaled to the "
                       "%d steps of one epoch; no policy inference / obs kernels in the CPU number"
                       % (n, args.cpu_baseline_steps, cores, sim_dt, ppo_steps, minibatch, torch.get_num_threads(), ppo_dt, epoch_opt_steps)}
@@ -298,7 +298,9 @@ def main():
                  "contacts_per_env_mean": nc_mean, "contacts_per_env_max": int(sim.NCONTACTS.max().item()),
                  "contact_capacity_per_env": 1536, "contacts_per_env_max_since_create": cstats[0],
                  "env_substeps_over_capacity_since_create": cstats[1], "env_substeps_rebuilt_without_speculative_contacts": cstats[2],
-                 "env_substeps_pair_list_overflow": cstats[3], "traffic": ptraf, "traffic_counters": pctr}
+                 "env_substeps_pair_list_overflow": cstats[3],
+                 "contact_results_valid": cstats[1] == 0 and cstats[3] == 0,   # a lost contact or an untested pair invalidates the physics of the run
+                 "traffic": ptraf, "traffic_counters": pctr}
     roof_phys["frac"] = roof_phys["achieved"] / HBM_PEAK_GBS
     # ---- roofline of the update phase.  Algorithmic bytes: one optimiser step touches 5 x 4 B per parameter
     # (w, g, m, v in, w' out) for all three networks; the persistent kernel runs all optimiser steps of the epoch in ONE launch and

@@ -118,7 +118,8 @@ typedef enum {
                             *                    the excess in enumeration order - must stay 0 for results to mean anything, bench.py and the full-size
                             *                    tests check it; [2] substeps whose contact list was rebuilt without its speculative contacts (samples
                             *                    that neither touch nor penetrate) because it would not fit; [3] substeps whose candidate pair list
-                            *                    exceeded its 1024 slots (the excess pairs were not tested) */
+                            *                    exceeded its 1024 slots (the excess pairs were not tested: their contacts are MISSING) - like [1] it
+                            *                    must stay 0, the full-size tests assert it and bench.py flags it */
   SDX_T_WARM_COUNT = 44,   /* i32 [N]           contacts in each env's warm-start cache (scene.warm_start); the engine clears an
                             *                    env's entry when it resets the env; a caller that teleports bodies by hand may zero it too */
   SDX_T_CAM_ROT = 45,      /* f32 [N,4]         camera_view_segmentation_target_rot: the target brick's quaternion in the camera frame, the input of

@@ -9,7 +9,8 @@ Where the reference hands the states over through pickles under ./intermediate_s
 same content (the pickle forms exist too: seqdex_amd/piles.py, BlockAssemblyGraspSim.save_grasp_terminal_states).  BASELINE.json
 configs[2] is this chain at num_envs = 1024 on one GPU; tools/bench_config3.py times it, tests/test_gpu_chain.py checks the hand-offs.
 
-    python -m seqdex_amd.scripts.evaluation --tasks BlockAssembly [--num_envs 512] [--orient_policy p.pth --grasp_policy p.pth --insert_policy p.pth]
+    python -m seqdex_amd.scripts.evaluation --tasks BlockAssembly [--num_envs 512] [--search s.pth] --orient o.pth --grasp g.pth --insert i.pth [--games 512]
+    python -m seqdex_amd.scripts.evaluation --mode chain [--tvalue tv.pt] [--synthetic_fallback --orient_tvalue_gate 0.5 --grasp_tvalue_gate 0.28]
 """
 import argparse
 import os
@@ -204,7 +205,7 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     # ---- stage 3: BlockAssemblyInsertSim from the harvested grasp states (IS:372-375)
     insert, st = main_rlgames("BlockAssemblyInsertSim", num_envs, policy_path=policies.get("insert", ""), tvalue_state=tvalue_state,
                               controller=controllers.get("insert"), seed=seed, steps=stage_steps.get("insert"),
-                              task_kwargs={"grasp_states": grasp_states})
+                              task_kwargs={"grasp_states": grasp_states, "synthetic_fallback": synthetic_fallback})
     st["grasp_states_source"] = insert.grasp_states_source
     hand["insert_task"] = insert          # the caller inspects it and closes insert.sim
     out["insert"] = st
@@ -274,21 +275,37 @@ def block_assembly(orient_path, grasp_path, insert_path, num_envs=512, games=0, 
 
 
 if __name__ == "__main__":
-    p = argparse.ArgumentParser()
+    p = argparse.ArgumentParser(description="scripts/evaluation.py of the reference: play the BlockAssembly sub-policies back to back")
     p.add_argument("--tasks", type=str, default="BlockAssembly")
+    p.add_argument("--mode", choices=["checkpoint", "chain"], default="checkpoint",
+                   help="checkpoint: every stage restored from its rl_games .pth through the launcher and played for --games episodes "
+                        "(evaluation.py:111-119; a stage without a checkpoint plays its random initialisation); chain: the device-tensor "
+                        "hand-off chain of block_assembly_chain with the harvest gates below")
     p.add_argument("--num_envs", type=int, default=512)
-    p.add_argument("--orient_policy", type=str, default="")
-    p.add_argument("--grasp_policy", type=str, default="")
-    p.add_argument("--insert_policy", type=str, default="")
-    p.add_argument("--tvalue", type=str, default="", help="GraspInsertTValue state_dict (.pt) for the harvest gates")
+    for st_ in ("search", "orient", "grasp", "insert"):
+        p.add_argument("--%s" % st_, "--%s_policy" % st_, dest=st_, type=str, default="", help="rl_games checkpoint (.pth) of the %s stage" % st_)
+    p.add_argument("--with_search", action="store_true", help="put BlockAssemblySearch (128 envs) in front (always on in checkpoint mode when --search is given)")
+    p.add_argument("--games", type=int, default=0, help="checkpoint mode: finished episodes per stage (0 = num_envs)")
+    p.add_argument("--insert_minibatch", type=int, default=0)
+    p.add_argument("--tvalue", type=str, default="", help="chain mode: GraspInsertTValue state_dict (.pt) for the harvest gates")
+    p.add_argument("--synthetic_fallback", action="store_true", help="chain mode: brick-type groups a stage harvested nothing for start the next "
+                   "stage from settled piles / synthetic grasp states (named in the statistics) instead of failing as the reference does")
+    p.add_argument("--orient_tvalue_gate", type=float, default=0.99, help="OR:1203")
+    p.add_argument("--grasp_tvalue_gate", type=float, default=0.8, help="GS:1406")
     a = p.parse_args()
     if a.tasks != "BlockAssembly":
         raise Exception("Unrecognized task!")                        # evaluation.py:121-129 (ToolPositioning: not built)
-    tv = None
-    if a.tvalue:
-        from ..tvalue_trainer import flat_from_state_dict
-        tv = flat_from_state_dict(torch.load(a.tvalue, map_location="cpu")).numpy()
-    res, h = block_assembly_chain(a.num_envs, tv, {"orient": a.orient_policy, "grasp": a.grasp_policy, "insert": a.insert_policy})
-    h["insert_task"].sim.close()
-    import json
-    print(json.dumps(res))
+    if a.mode == "checkpoint":
+        block_assembly(a.orient, a.grasp, a.insert, num_envs=a.num_envs, games=a.games, insert_minibatch=a.insert_minibatch,
+                       search_path=a.search if (a.search or a.with_search) else None)
+    else:
+        tv = None
+        if a.tvalue:
+            from ..tvalue_trainer import flat_from_state_dict
+            tv = flat_from_state_dict(torch.load(a.tvalue, map_location="cpu")).numpy()
+        res, h = block_assembly_chain(a.num_envs, tv, {"search": a.search, "orient": a.orient, "grasp": a.grasp, "insert": a.insert},
+                                      synthetic_fallback=a.synthetic_fallback, orient_tvalue_gate=a.orient_tvalue_gate,
+                                      grasp_tvalue_gate=a.grasp_tvalue_gate, with_search=a.with_search)
+        h["insert_task"].sim.close()
+        import json
+        print(json.dumps(res))

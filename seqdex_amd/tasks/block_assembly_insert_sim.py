@@ -11,7 +11,8 @@ section 8(f) rank 1).  Same robot and table as BlockAssemblyGraspSim; what the t
   * reset: target brick and hand start from a grasp terminal state harvested by BlockAssemblyGraspSim (IS:1449-1456) - pass them
     with `grasp_states=` (the lists of `BlockAssemblyGraspSim.grasp_terminal_states()`, an .npz of `save_grasp_terminal_states`,
     or the reference's two pickles); without them kinematic stand-ins are synthesised (hand at GraspSim's last arm waypoint, fingers
-    closed, brick between the fingertips) and the task says so in `grasp_states_source`.
+    closed, brick between the fingertips) and the task says so in `grasp_states_source`.  Given states that leave a brick-type group
+    empty raise (as IS:1449 fails) unless `synthetic_fallback=True` asks for stand-ins for exactly those groups.
 Not reproduced: stud engagement (box-only contact: the plate is its stud-less body, a seated brick rests on
 it), the 8 parked bricks of IS:706-731 (the settled GraspSim pile stays in the bin instead; neither enters observation or reward),
 HDF5 T-value logging (IS:1392-1410), the replan bookkeeping (IS:1357-1374).
@@ -35,7 +36,7 @@ class BlockAssemblyInsertSim(BlockAssemblyGraspSim):
 
     def __init__(self, cfg, sim_params=None, physics_engine=None, device_type="cuda", device_id=0, headless=True,
                  agent_index=None, is_multi_agent=False, seed=22, initial_piles=None, piles_per_type=8, grasp_states=None,
-                 synthetic_states_per_type=64):
+                 synthetic_states_per_type=64, synthetic_fallback=False):
         super().__init__(cfg, sim_params, physics_engine, device_type, device_id, headless, agent_index, is_multi_agent, seed,
                          initial_piles, piles_per_type)
         self.one_frame_num_states = _abi.STATE_FRAME                           # 188 real columns (IS:190); rows are 564 wide
@@ -48,9 +49,13 @@ class BlockAssemblyInsertSim(BlockAssemblyGraspSim):
             obj, hand = self._read_grasp_states(grasp_states)
             obj, hand = list(obj), list(hand)
             self.grasp_states_source = "given"
-            # a brick-type group the grasp stage harvested nothing for cannot reset (the reference would sample an empty list, IS:1449):
-            # such groups get the synthetic stand-ins, and the task says which
+            # a brick-type group the grasp stage harvested nothing for cannot reset: the reference samples an empty list there and
+            # fails (IS:1449).  Only a caller that asks for it (`synthetic_fallback=True`: the chain benchmark with its stand-in grasp
+            # controller) gets the synthetic stand-ins for such groups, and the task says which; everybody else gets the failure
             missing = [t for t in range(8) if obj[t] is None or len(obj[t]) == 0]
+            if missing and not synthetic_fallback:
+                raise ValueError("BlockAssemblyInsertSim: no grasp terminal states for the brick-type groups %s (IS:1449 samples an "
+                                 "empty list); pass synthetic_fallback=True to start those groups from synthetic stand-ins" % missing)
             if missing:
                 so, sh = self.synthesize_grasp_states(synthetic_states_per_type, seed)
                 for t in missing:

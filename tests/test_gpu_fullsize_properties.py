@@ -54,7 +54,7 @@ def test_physics_1024_deterministic_env_independent_and_sampled_oracle(golden_di
         assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
         assert a[2].max() < 1536 and a[2].min() > 100            # contact-rich, inside the per-env capacity
         st = s.CONTACT_STATS.cpu().numpy()
-        assert st[1] == 0 and 100 < st[0] <= 1536, st            # no env-step ever lost contacts to the capacity
+        assert st[1] == 0 and st[3] == 0 and 100 < st[0] <= 1536, st   # no env-step ever lost contacts to the capacity or pairs to the pair list
         # envs do not interact: a 64-env simulator fed envs [512, 576) reproduces those rows bit for bit
         s2 = SdxSim(64)
         try:
@@ -388,6 +388,6 @@ def test_resting_penetration_within_the_contact_offset_at_1024_envs(scene):
         # at rest; a few shifted stacks keep rocking about the edge of the lower brick (1 % above 0.1 rad/s, none above 1 rad/s)
         assert vlin.max() < 0.05 and np.quantile(vang, 0.98) < 0.1 and vang.max() < 1.0, (float(vlin.max()), float(np.quantile(vang, 0.98)), float(vang.max()))
         st = s.CONTACT_STATS.cpu().numpy()
-        assert st[1] == 0 and st[2] == 0
+        assert st[1] == 0 and st[2] == 0 and st[3] == 0
     finally:
         s.close()

@@ -1,7 +1,8 @@
 """k_linear_mfma (the rollout's trunk layers and the T-value trainer's forward; seqdex_amd/csrc/sdxp_kernels.hip) against torch's float64
 linear + ELU, for every tile shape the launcher can pick, ragged sizes and on-the-fly input normalisation (the reference normalises the
-central-value input with its running mean/std before the trunk: rl_games central_value.py).  Shape 1 (the default below
-2048 rows) and shape 6 accumulate every output in the same order, so they must agree bit for bit."""
+central-value input with its running mean/std before the trunk: rl_games central_value.py).  The launcher's default below
+2048 rows is shape 3 (64 x 64 tiles, every chunk split over two groups of four waves), 2 beyond.  Shapes 1 and 6 (one k group) accumulate every
+output in the same order, so they must agree bit for bit."""
 import ctypes as C
 
 import numpy as np
