@@ -149,9 +149,10 @@ class PPOOracle:
         return adv, adv + values
 
     # ---- R6-R8 + central value: one train_epoch's update phase on an env-major dataset dict
-    def update(self, ds):
+    def update(self, ds, max_steps=None):
         """ds: dict of env-major flattened tensors (rows r = env*H + t): obs, states, actions, mus, sigmas, neglogp,
-        values, returns.  Mutates ds['mus'/'sigmas'] like dataset.update_mu_sigma.  Returns statistics."""
+        values, returns.  Mutates ds['mus'/'sigmas'] like dataset.update_mu_sigma.  Returns statistics.
+        max_steps: stop each of the two loops after that many minibatches (the library's SDXP_MAX_STEPS debug limit)."""
         c = self.cfg
         mbs = c["minibatch"]
         nmb = ds["obs"].shape[0] // mbs
@@ -161,8 +162,11 @@ class PPOOracle:
         ds["advantages"] = adv
         stats = dict(a=[], c=[], b=[], kl=[], cv=[], lr=[], gnorm=[], cv_gnorm=[])
         # central value first (RC:1323-1324)
-        for ep in range(c["mini_epochs"]):
-            for i in range(nmb):
+        todo = [(ep, i) for ep in range(c["mini_epochs"]) for i in range(nmb)]
+        if max_steps is not None:
+            todo = todo[:max_steps]
+        for ep, i in todo:
+            if True:
                 sl = slice(i * mbs, (i + 1) * mbs)
                 st = ds["states"][sl]
                 if ep == 0 and c.get("cv_normalize_input", True):
@@ -175,8 +179,8 @@ class PPOOracle:
                 self.cv_opt.step()
                 stats["cv"].append(float(loss))
                 stats["cv_gnorm"].append(float(gn))
-        for ep in range(c["mini_epochs"]):
-            for i in range(nmb):
+        for ep, i in todo:
+            if True:
                 sl = slice(i * mbs, (i + 1) * mbs)
                 obs = ds["obs"][sl]
                 mu = self.actor(obs)

@@ -380,9 +380,12 @@ class A2CAgent:
         obs_cols, state_cols = self._checkpoint_widths()
         model, vf = rlgames_from_flat(t["AC_PARAMS"], t["CV_PARAMS"], cfg.obs_dim, cfg.state_dim, cfg.act_dim, tuple(cfg.units),
                                       t["CV_RMS_MEAN"], t["CV_RMS_VAR"], st["rms_count"], obs_cols=obs_cols, state_cols=state_cols)
-        return {"model": model, "assymetric_vf_nets": vf,
-                "optimizer": {"ac_m": t["AC_ADAM_M"].cpu(), "ac_v": t["AC_ADAM_V"].cpu(), "cv_m": t["CV_ADAM_M"].cpu(),
-                              "cv_v": t["CV_ADAM_V"].cpu(), "ac_t": st["ac_t"], "cv_t": st["cv_t"], "cv_lr": st["cv_lr"]},
+        # `optimizer` is torch.optim.Adam's state_dict over model.parameters() (what rl_games' set_full_state_weights hands to
+        # optimizer.load_state_dict); the central-value optimiser's moments, which rl_games does not checkpoint, ride along as extra keys
+        from .rlgames_checkpoint import torch_adam_from_flat
+        opt = torch_adam_from_flat(t["AC_ADAM_M"], t["AC_ADAM_V"], st["ac_t"], st["ac_lr"], cfg.obs_dim, cfg.act_dim, tuple(cfg.units), obs_cols=obs_cols)
+        opt.update({"cv_m": t["CV_ADAM_M"].cpu(), "cv_v": t["CV_ADAM_V"].cpu(), "ac_t": st["ac_t"], "cv_t": st["cv_t"], "cv_lr": st["cv_lr"]})
+        return {"model": model, "assymetric_vf_nets": vf, "optimizer": opt,
                 "epoch": self.epoch_num, "frame": self.frame, "last_mean_rewards": self.last_mean_rewards,
                 "last_lr": st["ac_lr"], "env_state": None}
 
@@ -423,14 +426,25 @@ class A2CAgent:
         if rms is not None:
             t["CV_RMS_MEAN"].copy_(rms[0]); t["CV_RMS_VAR"].copy_(rms[1])
         opt = ck.get("optimizer", {})
-        if isinstance(opt, dict) and "ac_m" in opt:
+        torch_adam_step = None
+        if isinstance(opt, dict) and "ac_m" in opt:                  # flat moments (files of rounds 2-3)
             t["AC_ADAM_M"].copy_(opt["ac_m"]); t["AC_ADAM_V"].copy_(opt["ac_v"])
+        elif isinstance(opt, dict) and "state" in opt:               # torch.optim.Adam.state_dict() (rl_games, and save() since round 4)
+            from .rlgames_checkpoint import flat_from_torch_adam
+            obs_cols, _ = self._checkpoint_widths()
+            mv = flat_from_torch_adam(opt, cfg.obs_dim, cfg.act_dim, tuple(cfg.units), obs_cols=obs_cols)
+            if mv is not None:
+                t["AC_ADAM_M"].copy_(mv[0]); t["AC_ADAM_V"].copy_(mv[1])
+                torch_adam_step = mv[2]
+        if isinstance(opt, dict) and "cv_m" in opt:
             t["CV_ADAM_M"].copy_(opt["cv_m"]); t["CV_ADAM_V"].copy_(opt["cv_v"])
         # the rest of the optimiser state (rl_games restores all of it): running_mean_std.count, Adam step counters (bias-correction
         # powers follow them), the adaptive learning rate
         state = {}
         if rms is not None and rms[2] is not None and float(rms[2]) > 0:
             state["rms_count"] = float(rms[2])
+        if torch_adam_step is not None:
+            state["ac_t"] = torch_adam_step
         if isinstance(opt, dict):
             for k in ("ac_t", "cv_t", "cv_lr"):
                 if k in opt:

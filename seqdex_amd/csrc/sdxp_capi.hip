@@ -439,7 +439,10 @@ extern "C" int sdxp_update(sdxp_handle h, void* stream) {
     h->err = "sdxp_update: minibatch_size must be 2/4/8 (rank-MB paths) or > 8 (GEMM path)";
     return SDX_ERR_INVALID;
   }
-  const long total = (long)h->cfg.mini_epochs * h->D.num_minibatches;
+  long total = (long)h->cfg.mini_epochs * h->D.num_minibatches;
+  // debug step limit (tests/test_gpu_fullsize_properties.py pins the N = 1024 persistent update to the oracle step for step): the
+  // update phase stops after SDXP_MAX_STEPS optimiser steps, in minibatch order, on whichever path the handle uses
+  if (const char* ms = getenv("SDXP_MAX_STEPS")) { const long lim = atol(ms); if (lim > 0 && lim < total) total = lim; }
   if (h->fail_host && *h->fail_host) {
     h->use_persist = false;   // a grid barrier of the persistent kernel timed out earlier: fall back for good
     *h->fail_host = 0;

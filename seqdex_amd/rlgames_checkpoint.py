@@ -6,6 +6,16 @@ rl_games' `A2CBase.get_full_state_weights()` stores `model` = state_dict of `Mod
 libseqdex_hip.so use the torch layout W[out][in] in the order of `SdxpOff` / `SdxpCOff` (csrc/sdxp_types.h), so the conversion is
 slicing and naming only.  rl_games is not installed here and the reference ships no checkpoint: the key names below are the
 upstream ones as recalled (PARITY UNPINNED); `flat_from_rlgames` therefore matches keys by suffix and checks every shape.
+
+Structure the names come from (rl_games `A2CBuilder.Network.__init__`): `actor_cnn`, `critic_cnn` (empty),
+`actor_mlp = Sequential(Linear, ELU, Linear, ELU, Linear, ELU)` (Linear at indices 0 / 2 / 4), `critic_mlp` the same when
+`separate: True` (YG:10) and EMPTY otherwise, then `value = Linear`, and for a continuous space `mu = Linear`, `sigma = Parameter`.
+The central-value network (YG:86-95) has `central_value: True`, no `space` block and no `separate` key: its trunk is therefore
+`actor_mlp` and it has no `mu` / `sigma`; `CentralValueTrain.model` wraps it (`model.a2c_network.*`) and the input RunningMeanStd
+sits beside it (`model.running_mean_std.*` in 1.5.x, `running_mean_std.*` before).  Rounds 2-3 wrote the central-value trunk as
+`critic_mlp`; such files are still read.  tests/test_gpu_rlgames_checkpoint.py builds a plain torch.nn module of exactly this
+structure, saves ITS state_dict / optimizer.state_dict() the way rl_games does and checks that a restored handle computes the
+module's outputs.
 """
 import numpy as np
 import torch
@@ -51,16 +61,16 @@ def rlgames_from_flat(ac_flat, cv_flat, obs_dim, state_dim, act_dim=23, units=(1
         model[k] = model[k][:, :obs_cols].clone()
     vf, o = {}, 0
     for i, (out, inn) in enumerate(_layers(state_dim, units)):
-        vf["model.a2c_network.critic_mlp.%d.weight" % (2 * i)], o = take(cv, o, (out, inn))
-        vf["model.a2c_network.critic_mlp.%d.bias" % (2 * i)], o = take(cv, o, (out,))
+        vf["model.a2c_network.actor_mlp.%d.weight" % (2 * i)], o = take(cv, o, (out, inn))
+        vf["model.a2c_network.actor_mlp.%d.bias" % (2 * i)], o = take(cv, o, (out,))
     vf["model.a2c_network.value.weight"], o = take(cv, o, (1, units[-1]))
     vf["model.a2c_network.value.bias"], o = take(cv, o, (1,))
     assert o == cv.numel(), (o, cv.numel())
-    vf["model.a2c_network.critic_mlp.0.weight"] = vf["model.a2c_network.critic_mlp.0.weight"][:, :state_cols].clone()
+    vf["model.a2c_network.actor_mlp.0.weight"] = vf["model.a2c_network.actor_mlp.0.weight"][:, :state_cols].clone()
     if rms_mean is not None:
-        vf["running_mean_std.running_mean"] = torch.as_tensor(rms_mean).double().cpu()[:state_cols].clone()
-        vf["running_mean_std.running_var"] = torch.as_tensor(rms_var).double().cpu()[:state_cols].clone()
-        vf["running_mean_std.count"] = torch.tensor(float(rms_count if rms_count is not None else 0.0), dtype=torch.float64)
+        vf["model.running_mean_std.running_mean"] = torch.as_tensor(rms_mean).double().cpu()[:state_cols].clone()
+        vf["model.running_mean_std.running_var"] = torch.as_tensor(rms_var).double().cpu()[:state_cols].clone()
+        vf["model.running_mean_std.count"] = torch.tensor(float(rms_count if rms_count is not None else 0.0), dtype=torch.float64)
     return model, vf
 
 
@@ -85,20 +95,12 @@ def flat_from_rlgames(model, vf, obs_dim, state_dim, act_dim=23, units=(1024, 51
             w = torch.cat([w, torch.zeros(out, inn - cols)], dim=1)
         return w.reshape(-1)
 
+    ac = _ac_flat_only(model, obs_dim, act_dim, units, obs_cols)
     parts = []
-    for trunk, head, hout in (("actor_mlp", "mu", act_dim), ("critic_mlp", "value", 1)):
-        for i, (out, inn) in enumerate(_layers(obs_dim, units)):
-            name = "a2c_network.%s.%d" % (trunk, 2 * i)
-            parts.append(first(model, name, out, inn, obs_cols) if i == 0 else _find(model, name + ".weight", (out, inn)))
-            parts.append(_find(model, name + ".bias", (out,)))
-        parts.append(_find(model, "a2c_network.%s.weight" % head, (hout, units[-1])))
-        parts.append(_find(model, "a2c_network.%s.bias" % head, (hout,)))
-        if head == "mu":
-            parts.append(_find(model, "a2c_network.sigma", (act_dim,)))
-    ac = torch.cat(parts)
-    parts = []
+    # the central-value trunk is `actor_mlp` in an rl_games file (no `separate` key, see the header); `critic_mlp` in files of rounds 2-3
+    cv_trunk = "actor_mlp" if any(k.endswith("a2c_network.actor_mlp.0.weight") for k in vf) else "critic_mlp"
     for i, (out, inn) in enumerate(_layers(state_dim, units)):
-        name = "a2c_network.critic_mlp.%d" % (2 * i)
+        name = "a2c_network.%s.%d" % (cv_trunk, 2 * i)
         parts.append(first(vf, name, out, inn, state_cols) if i == 0 else _find(vf, name + ".weight", (out, inn)))
         parts.append(_find(vf, name + ".bias", (out,)))
     parts.append(_find(vf, "a2c_network.value.weight", (1, units[-1])))
@@ -120,3 +122,73 @@ def flat_from_rlgames(model, vf, obs_dim, state_dim, act_dim=23, units=(1024, 51
         cnt = float(torch.as_tensor(vf[pre + "count"])) if (pre + "count") in vf else 0.0
         rms = (mean, var, cnt)
     return ac, cv, rms
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# torch.optim.Adam state of the actor-critic (rl_games: weights['optimizer'] = self.optimizer.state_dict(), params = list(model.parameters()))
+def ac_parameter_order():
+    """names of the actor-critic parameters in `model.parameters()` order: nn.Module yields a module's OWN parameters before those of
+    its children, so the `sigma` Parameter of the network comes first, then the children in registration order (header)"""
+    names = ["a2c_network.sigma"]
+    for trunk in ("actor_mlp", "critic_mlp"):
+        for i in range(3):
+            names += ["a2c_network.%s.%d.weight" % (trunk, 2 * i), "a2c_network.%s.%d.bias" % (trunk, 2 * i)]
+    return names + ["a2c_network.value.weight", "a2c_network.value.bias", "a2c_network.mu.weight", "a2c_network.mu.bias"]
+
+
+def torch_adam_from_flat(m_flat, v_flat, step, lr, obs_dim, act_dim=23, units=(1024, 512, 256), obs_cols=None):
+    """flat Adam moments of the actor-critic -> torch.optim.Adam.state_dict() over `model.parameters()` (what rl_games stores and loads)"""
+    mn, _ = rlgames_from_flat(m_flat, _dummy_cv(units), obs_dim, 4, act_dim, units, obs_cols=obs_cols)
+    vn, _ = rlgames_from_flat(v_flat, _dummy_cv(units), obs_dim, 4, act_dim, units, obs_cols=obs_cols)
+    order = ac_parameter_order()
+    state = {i: {"step": torch.tensor(float(step)), "exp_avg": mn[k], "exp_avg_sq": vn[k]} for i, k in enumerate(order)}
+    group = {"lr": float(lr), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+             "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(order)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def _dummy_cv(units):
+    n, d = 0, 4
+    for u in units:
+        n += u * d + u
+        d = u
+    return torch.zeros(n + d + 1)
+
+
+def flat_from_torch_adam(opt_sd, obs_dim, act_dim=23, units=(1024, 512, 256), obs_cols=None):
+    """torch.optim.Adam.state_dict() of the actor-critic (parameters in `ac_parameter_order`) -> (m_flat, v_flat, step) or None when the
+    state is empty (a checkpoint saved before the first optimiser step) or does not have one entry per parameter"""
+    order = ac_parameter_order()
+    st = opt_sd.get("state", {})
+    if len(st) != len(order):
+        return None
+    ids = opt_sd["param_groups"][0]["params"] if opt_sd.get("param_groups") else sorted(st)
+    if len(ids) != len(order):
+        return None
+    m = {k: st[i]["exp_avg"] for k, i in zip(order, ids)}
+    v = {k: st[i]["exp_avg_sq"] for k, i in zip(order, ids)}
+    mf = _ac_flat_only(m, obs_dim, act_dim, units, obs_cols)
+    vf = _ac_flat_only(v, obs_dim, act_dim, units, obs_cols)
+    step = int(round(float(torch.as_tensor(st[ids[0]]["step"]))))
+    return mf, vf, step
+
+
+def _ac_flat_only(model, obs_dim, act_dim, units, obs_cols):
+    """the actor-critic half of flat_from_rlgames"""
+    def first(name, out, inn, cols):
+        cols = cols or inn
+        w = _find(model, name + ".weight", (out, cols)).reshape(out, cols)
+        if cols != inn:
+            w = torch.cat([w, torch.zeros(out, inn - cols)], dim=1)
+        return w.reshape(-1)
+    parts = []
+    for trunk, head, hout in (("actor_mlp", "mu", act_dim), ("critic_mlp", "value", 1)):
+        for i, (out, inn) in enumerate(_layers(obs_dim, units)):
+            name = "a2c_network.%s.%d" % (trunk, 2 * i)
+            parts.append(first(name, out, inn, obs_cols) if i == 0 else _find(model, name + ".weight", (out, inn)))
+            parts.append(_find(model, name + ".bias", (out,)))
+        parts.append(_find(model, "a2c_network.%s.weight" % head, (hout, units[-1])))
+        parts.append(_find(model, "a2c_network.%s.bias" % head, (hout,)))
+        if head == "mu":
+            parts.append(_find(model, "a2c_network.sigma", (act_dim,)))
+    return torch.cat(parts)

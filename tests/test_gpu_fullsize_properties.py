@@ -292,7 +292,7 @@ def test_checkpoint_round_trip_in_rlgames_layout(tmp_path):
         ag.save(str(tmp_path / "ck"))
         ck = torch.load(str(tmp_path / "ck.pth"), map_location="cpu", weights_only=False)
         assert tuple(ck["model"]["a2c_network.mu.weight"].shape) == (23, 256)
-        assert tuple(ck["assymetric_vf_nets"]["model.a2c_network.critic_mlp.0.weight"].shape) == (1024, 564)
+        assert tuple(ck["assymetric_vf_nets"]["model.a2c_network.actor_mlp.0.weight"].shape) == (1024, 564)
         assert set(ck) >= {"model", "optimizer", "epoch", "frame", "last_mean_rewards", "env_state", "assymetric_vf_nets"}
         bg = A2CAgent.__new__(A2CAgent)
         bg.ppo = b
@@ -391,3 +391,61 @@ def test_resting_penetration_within_the_contact_offset_at_1024_envs(scene):
         assert st[1] == 0 and st[2] == 0 and st[3] == 0
     finally:
         s.close()
+
+
+def test_persistent_update_at_1024_envs_matches_the_oracle_step_for_step():
+    """the N = 1024 launch of k_update_persistent (98 % of the headline's wall time) against oracle/ppo_oracle.py on the
+    same rows.  The debug limit SDXP_MAX_STEPS stops the update phase after 640 optimiser steps (2 560 dataset rows of mini-epoch 0, three
+    networks); parameters, Adam moments, learning rate, the refreshed mu rows and the loss statistics must agree at the bounds the 160-step
+    test at N = 16 uses (tests/test_gpu_ppo_parity.py).  The whole-epoch check stays aggregate (test above)."""
+    from test_gpu_ppo_parity import make_pair, rollout
+    n, steps = 1024, 640
+    agent, orc = make_pair(n, seed=3)
+    old = os.environ.get("SDXP_MAX_STEPS")
+    try:
+        if agent.update_impl() != "persistent":
+            pytest.skip("persistent update kernel not selected on this device (needs >= 256 CUs)")
+        ds = rollout(agent, orc, n, torch.Generator().manual_seed(21))
+        os.environ["SDXP_MAX_STEPS"] = str(steps)
+        assert agent.update_checked() == "persistent"
+        torch.cuda.synchronize()
+        st = orc.update(ds, max_steps=steps)
+        c = agent.ctrl()
+        assert c.ac_t == steps and c.cv_t == steps and c.n_mb == steps
+        np.testing.assert_allclose(c.ac_lr, orc.lr, rtol=1e-6)                                    # the adaptive schedule took the same decisions
+        np.testing.assert_allclose(c.sum_a_loss / steps, np.mean(st["a"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_c_loss / steps, np.mean(st["c"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_cv_loss / steps, np.mean(st["cv"]), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(c.sum_kl / steps, np.mean(st["kl"]), rtol=5e-3, atol=1e-5)
+        ac, cv = agent.t["AC_PARAMS"].cpu().numpy(), agent.t["CV_PARAMS"].cpu().numpy()
+        d_ac, d_cv = np.abs(ac - orc.ac_flat().numpy()).max(), np.abs(cv - orc.cv_flat().numpy()).max()
+        print("N = 1024, %d steps: max |param - oracle| actor-critic %.2e, central value %.2e" % (steps, d_ac, d_cv))
+        assert d_ac < 2e-4 and d_cv < 5e-4, (d_ac, d_cv)
+        # Adam moments in the flat layout (torch keeps them per parameter, in the order of PPOOracle.ac_params / cv.parameters())
+        def flat_state(opt, params, key):
+            return torch.cat([opt.state[p][key].reshape(-1) for p in params]).numpy()
+        a = orc.actor; cr = orc.critic
+        order = []
+        for l in a.layers:
+            order += [l.weight, l.bias]
+        order += [a.head.weight, a.head.bias, orc.logstd]
+        for l in cr.layers:
+            order += [l.weight, l.bias]
+        order += [cr.head.weight, cr.head.bias]
+        m_o, v_o = flat_state(orc.opt, order, "exp_avg"), flat_state(orc.opt, order, "exp_avg_sq")
+        m_g, v_g = agent.t["AC_ADAM_M"].cpu().numpy(), agent.t["AC_ADAM_V"].cpu().numpy()
+        assert np.abs(m_g - m_o).max() < 2e-4 * max(1.0, np.abs(m_o).max()), np.abs(m_g - m_o).max()
+        assert np.abs(v_g - v_o).max() < 2e-4 * max(1.0, np.abs(v_o).max()), np.abs(v_g - v_o).max()
+        # update_mu_sigma wrote the new mus of exactly the rows that were visited
+        np.testing.assert_allclose(agent.t["MB_MUS"].cpu().numpy().reshape(-1, 23), ds["mus"].numpy(), rtol=1e-3, atol=1e-3)
+        # the running statistics are hoisted: the device has seen every minibatch of mini-epoch 0, the limited oracle only the first 640
+        for i in range(steps, n * 8 // 4):
+            orc.rms.update(ds["states"][i * 4:(i + 1) * 4])
+        np.testing.assert_allclose(agent.t["CV_RMS_MEAN"].cpu().numpy(), orc.rms.mean.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(agent.t["CV_RMS_VAR"].cpu().numpy(), orc.rms.var.numpy(), rtol=1e-5, atol=1e-7)
+    finally:
+        if old is None:
+            os.environ.pop("SDXP_MAX_STEPS", None)
+        else:
+            os.environ["SDXP_MAX_STEPS"] = old
+        agent.close()

@@ -102,7 +102,7 @@ def test_rlgames_checkpoint_layout_round_trip():
     model, vf = rlgames_from_flat(ac, cv, 396, 564, rms_mean=torch.arange(564.0), rms_var=torch.ones(564) * 2, rms_count=77.0)
     assert tuple(model["a2c_network.actor_mlp.0.weight"].shape) == (1024, 396) and tuple(model["a2c_network.sigma"].shape) == (23,)
     assert tuple(model["a2c_network.critic_mlp.4.weight"].shape) == (256, 512) and tuple(model["a2c_network.value.weight"].shape) == (1, 256)
-    assert tuple(vf["model.a2c_network.critic_mlp.0.weight"].shape) == (1024, 564)
+    assert tuple(vf["model.a2c_network.actor_mlp.0.weight"].shape) == (1024, 564)    # no `separate` key in YG:86-95
     assert torch.equal(model["a2c_network.actor_mlp.0.weight"].reshape(-1), ac[:1024 * 396])          # torch layout W[out][in], first block
     wrapped = {"module." + k: v for k, v in model.items()}
     ac2, cv2, rms = flat_from_rlgames(wrapped, vf, 396, 564)
@@ -122,7 +122,7 @@ def test_rlgames_checkpoint_layout_round_trip():
     mo, vo = rlgames_from_flat(acp188, cv, 188, 564, rms_mean=torch.arange(564.0), rms_var=torch.ones(564), rms_count=5.0,
                                obs_cols=186, state_cols=188)
     assert tuple(mo["a2c_network.actor_mlp.0.weight"].shape) == (1024, 186) and tuple(mo["a2c_network.critic_mlp.0.weight"].shape) == (1024, 186)
-    assert tuple(vo["model.a2c_network.critic_mlp.0.weight"].shape) == (1024, 188) and vo["running_mean_std.running_mean"].numel() == 188
+    assert tuple(vo["model.a2c_network.actor_mlp.0.weight"].shape) == (1024, 188) and vo["model.running_mean_std.running_mean"].numel() == 188
     ac3, cv3, rms3 = flat_from_rlgames(mo, vo, 188, 564, obs_cols=186, state_cols=188)
     w3 = ac3[:1024 * 188].reshape(1024, 188)
     assert torch.equal(w3[:, :186], acp188[:1024 * 188].reshape(1024, 188)[:, :186]) and not w3[:, 186:].any()
