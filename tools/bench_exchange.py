@@ -1,0 +1,98 @@
+"""Floor of one exchange edge of the persistent PPO update kernel: the 256 -> 256 all-gather of (value, tag)
+words alone (csrc/sdxp_exbench.hip), for the word counts the kernel moves per optimiser step, 8-byte vs packed 16-byte words,
+producers on the consumer's own XCD vs another XCD vs all, and the point-to-point round trip of one word.
+
+    python tools/bench_exchange.py [--out profiles/r4_exchange_edge_floor.txt] [--rounds 2000]
+"""
+import argparse
+import ctypes as C
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from seqdex_amd import _abi  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    ap.add_argument("--rounds", type=int, default=2000)
+    a = ap.parse_args()
+    lib = _abi.load_library()
+    lib.sdxpk_exchange_bench.restype = C.c_int
+    lib.sdxpk_exchange_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_void_p]
+    lib.sdxpk_pingpong_bench.restype = C.c_int
+    lib.sdxpk_pingpong_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_void_p]
+    dev = torch.device("cuda:0")
+    ll = torch.zeros(1 << 18, dtype=torch.int64, device=dev)       # 2 MB: 12 288 words x 16 B fit with room
+    out = torch.zeros(4, dtype=torch.int64, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tag = [1]
+    lines, rows = [], []
+
+    def run(words, fmt, src, pattern, rounds):
+        res = []
+        for rep in range(3):                                        # first repetition = warm-up (code, TLB); report the best of the others
+            out.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib.sdxpk_exchange_bench(C.c_void_p(ll.data_ptr()), C.c_void_p(out.data_ptr()), words, rounds, fmt, src, pattern, tag[0], st)
+            e1.record()
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            tag[0] += rounds + 8
+            o = out.cpu().tolist()
+            res.append((e0.elapsed_time(e1) * 1e3 / rounds, o[0] / rounds, o[1], o[2]))
+        best = min(res[1:], key=lambda r: r[0])
+        return best
+
+    hdr = "%-34s %8s %6s %9s %8s %11s %11s %9s %8s" % ("edge", "floats", "fmt", "producers", "layout", "us/round", "ticks/round", "torn", "timeouts")
+    lines.append(hdr)
+    print(hdr)
+    edges = [("x3 (3 nets x 4 x 256)", 3072), ("x2 / dY1 (3 x 4 x 512)", 6144), ("dY0 Gram ~ (36 per CU)", 9216), ("x1 (3 x 4 x 1024)", 12288)]
+    for name, words in edges:
+        for fmt in (0, 1):
+            for src in (0, 1, 2):
+                for pattern in ((0, 1) if src == 0 else (1,)):
+                    us, ticks, bad, tmo = run(words, fmt, src, pattern, a.rounds)
+                    row = dict(edge=name, floats=words, fmt="8B (v,tag)" if fmt == 0 else "16B (3v,tag)",
+                               producers=("all 256 CUs", "own XCD (32)", "other XCD (32)")[src], layout=("contiguous", "interleaved")[pattern],
+                               us_per_round=us, ticks_per_round=ticks, torn_words=bad, timeouts=tmo)
+                    rows.append(row)
+                    ln = "%-34s %8d %6s %9s %8s %11.3f %11.1f %9d %8d" % (name, words, "8B" if fmt == 0 else "16B", ("all", "own-xcd", "oth-xcd")[src],
+                                                                         ("contig", "interl")[pattern], us, ticks, bad, tmo)
+                    lines.append(ln)
+                    print(ln)
+    # point-to-point
+    lib_pp = lib.sdxpk_pingpong_bench
+    for peer, what in ((8, "CU 0 <-> CU 8 (same XCD under b % 8 placement)"), (1, "CU 0 <-> CU 1 (different XCD)"), (129, "CU 0 <-> CU 129")):
+        best = None
+        for rep in range(3):
+            out.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib_pp(C.c_void_p(ll.data_ptr()), C.c_void_p(out.data_ptr()), peer, 20000, tag[0], st)
+            e1.record()
+            assert rc == 0
+            torch.cuda.synchronize()
+            tag[0] += 20008
+            us = e0.elapsed_time(e1) * 1e3 / 20000
+            if rep and (best is None or us < best):
+                best = us
+        ln = "ping-pong %-52s %8.3f us per round trip (%.3f one way)" % (what, best, best / 2)
+        rows.append(dict(pingpong=what, us_round_trip=best))
+        lines.append(ln)
+        print(ln)
+    if a.out:
+        with open(a.out, "w") as fh:
+            fh.write("# python tools/bench_exchange.py --rounds %d  (csrc/sdxp_exbench.hip; one MI355X; us/round from HIP events over the launch,\n"
+                     "# ticks/round = s_memtime of CU 0; torn = gathered payloads that did not match their tag)\n" % a.rounds)
+            fh.write("\n".join(lines) + "\n")
+        with open(a.out.rsplit(".", 1)[0] + ".json", "w") as fh:
+            json.dump(rows, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
