@@ -22,9 +22,13 @@ from ..tvalue_trainer import TValue_Trainer, flat_from_state_dict
 
 
 def main_rlgames(task, num_envs, use_t_value=False, policy_path="", max_iterations=0, task_kwargs=None, tvalue_state=None, keep=False,
-                 minibatch_size=0):
+                 minibatch_size=0, mixed_precision=False, report=None, leg=""):
     """one training run of `task` (bi_optimization.py:36-104).  Returns (checkpoint path, task object or None).  use_t_value marks the
-    backward-pass runs whose purpose is the task's success / failure datasets (they are always logged on the device here)."""
+    backward-pass runs whose purpose is the task's success / failure datasets (they are always logged on the device here).
+    mixed_precision: rl_games' `mixed_precision` key for this run (BASELINE.json configs[4] "bf16 policy": bf16 MFMA operands with fp32
+    master weights and accumulation wherever the schedule's update is GEMM-shaped, i.e. minibatch_size > 8).  report: a list that
+    receives one dict per run (what ran, on which update path, how fast)."""
+    import time
     argv = ["--task=%s" % task, "--num_envs=%d" % num_envs, "--headless"]
     if max_iterations:
         argv.append("--max_iterations=%d" % max_iterations)
@@ -32,12 +36,27 @@ def main_rlgames(task, num_envs, use_t_value=False, policy_path="", max_iteratio
         argv.append("--checkpoint=%s" % policy_path)
     args = get_args(argv)
     args.use_t_value = use_t_value
-    task_obj, env, agent, logdir, rank = build(args, task_kwargs, minibatch_size)
+    task_obj, env, agent, logdir, rank = build(args, task_kwargs, minibatch_size, {"mixed_precision": bool(mixed_precision)})
     if tvalue_state is not None:
         task_obj.sim.set_tvalue_weights(flat_from_state_dict(tvalue_state).numpy())
     if policy_path:
         agent.epoch_num = 0        # every run of the outer loop trains max_iterations MORE epochs (rl_games would resume the counter)
+    torch.cuda.synchronize()
+    t0 = time.time()
     agent.train()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if report is not None:
+        c = agent.ppo.ctrl()
+        p_ac = agent.ppo.t["AC_PARAMS"]
+        report.append({"leg": leg, "task": task, "num_envs": num_envs, "epochs": agent.epoch_num, "env_steps": agent.frame, "wall_s": dt,
+                       "env_steps_per_s": agent.frame / dt, "minibatch_size": agent.minibatch_size, "update_impl": agent.ppo.update_impl(),
+                       "mixed_precision": bool(agent.ppo.cfg.mixed_precision),
+                       "bf16_mfma_in_update": bool(agent.ppo.cfg.mixed_precision) and agent.ppo.update_impl() == "gemm",
+                       "optimiser_steps": int(c.ac_t), "params_finite": bool(torch.isfinite(p_ac).all()),
+                       "restored_from": policy_path or None, "tvalue_given": tvalue_state is not None,
+                       "tvalue_outcomes_logged(success, failure)": task_obj.sim.TV_COUNT.cpu().tolist(),
+                       "game_reward": float(agent.game_rewards.get_mean()[0])})
     os.makedirs(os.path.join(logdir, "nn"), exist_ok=True)
     path = os.path.join(logdir, "nn", "%s" % task)                                      # runner.nn_dir/<task>.pth, bi_optimization.py:104
     agent.save(path)
@@ -64,39 +83,94 @@ def transition_value_trainer(task_obj, rollout, state_dict=None, seed=0):
     return sd
 
 
-def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, insert_minibatch=0):
-    """insert_minibatch: override of the insert schedule's minibatch_size 4096 for runs with fewer than 512 envs"""
+def _handoff(report, name, tensor_or_none, fallback):
+    """record a stage-to-stage hand-off: its shape and finiteness, or the fallback the next stage takes when the stage harvested nothing"""
+    if report is None:
+        return
+    if tensor_or_none is None:
+        report.append({"handoff": name, "source": fallback, "empty": True})
+        return
+    ts = tensor_or_none if isinstance(tensor_or_none, (list, tuple)) else [tensor_or_none]
+    ts = [t for group in ts for t in (group if isinstance(group, (list, tuple)) else [group])]
+    report.append({"handoff": name, "source": "harvested", "empty": any(t.numel() == 0 for t in ts),
+                   "shapes": [list(t.shape) for t in ts][:4], "finite": all(bool(torch.isfinite(t.float()).all()) for t in ts)})
+
+
+def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, insert_minibatch=0, mixed_precision=False, report=None,
+                   stage_epochs=None, search_envs=128, orient_backward_envs=128, grasp_harvest_stand_in=False, gates=None):
+    """insert_minibatch: override of the insert schedule's minibatch_size 4096 for runs with fewer than 512 envs.
+    stage_epochs: {"search" | "orient" | "grasp" | "insert": max_iterations} overriding `epochs` per task (an episode is 75 / 75 / 150 / 125
+    env steps = 10 / 10 / 19 / 16 epochs of horizon 8: shorter runs finish no episode, harvest nothing and log no T-value outcome).
+    gates: {"orient": 0.99, "grasp": 0.8} harvest thresholds on the transition value (OR:1203, GS:1406).
+    grasp_harvest_stand_in: when the freshly trained grasp policy has not carried a single brick to the insertion side yet (the reference's
+    grasp checkpoint is from epoch 19 000, README.md:90), play two episodes of evaluation.scripted_grasp_controller on the same task so that
+    InsertSim starts from REAL terminal states of this engine; brick-type groups still empty get InsertSim's synthetic stand-ins.  Both are
+    named in the report.  Without it such a round hands `None` on and InsertSim synthesises all of its states (round-3 behaviour)."""
     tv = None
     paths = {}
+    se = lambda k: int((stage_epochs or {}).get(k, epochs))
+    gates = gates or {}
+    mp = dict(mixed_precision=mixed_precision, report=report)
+    orient_kw = {"tvalue_gate": gates["orient"]} if "orient" in gates else {}
+    grasp_kw = {"harvest_tvalue_gate": gates["grasp"]} if "grasp" in gates else {}
     for i in range(rounds):
         # ---- forward initialisation (bi_optimization.py:115-118)
-        paths["search"], search = main_rlgames("BlockAssemblySearch", min(num_envs, 128), max_iterations=epochs,
-                                               policy_path=paths.get("search", ""), keep=True)
+        paths["search"], search = main_rlgames("BlockAssemblySearch", min(num_envs, search_envs), max_iterations=se("search"),
+                                               policy_path=paths.get("search", ""), keep=True, leg="forward", **mp)
         dug = search.pile_terminal_states()                                               # hand-off SE:1323-1353 -> Orient's saved piles
+        if dug is not None and dug.shape[1] < 8:
+            dug = None                                                                    # too few to start hundreds of envs per group from
+        _handoff(report, "Search -> Orient: dug-out piles [8, K, 132, 13]", dug, "Orient settles its own piles (piles.generate_piles)")
         search.sim.close()
-        paths["orient"], orient = main_rlgames("BlockAssemblyOrient", num_envs, max_iterations=epochs, policy_path=paths.get("orient", ""),
-                                               keep=True, task_kwargs={"initial_piles": dug})
+        paths["orient"], orient = main_rlgames("BlockAssemblyOrient", num_envs, max_iterations=se("orient"), policy_path=paths.get("orient", ""),
+                                               tvalue_state=tv, keep=True, task_kwargs=dict(orient_kw, initial_piles=dug), leg="forward", **mp)
         piles = orient.pile_terminal_states()                                             # hand-off OR:1483-1510 -> GS:412-413
+        _handoff(report, "Orient -> GraspSim: pile terminal states [8, K, 132, 13]", piles, "GraspSim settles its own piles")
         orient.sim.close()
-        paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, max_iterations=epochs, policy_path=paths.get("grasp", ""),
-                                             tvalue_state=tv, keep=True, task_kwargs={"initial_piles": piles})
+        paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, max_iterations=se("grasp"), policy_path=paths.get("grasp", ""),
+                                             tvalue_state=tv, keep=True, task_kwargs=dict(grasp_kw, initial_piles=piles), leg="forward", **mp)
         cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
-        grasp_states = grasp.grasp_terminal_states() if cnt.min() > 0 else None          # hand-off GS:1447-1450 -> IS:372-375
+        harvest_by = "the trained grasp policy"
+        if cnt.min() == 0 and grasp_harvest_stand_in:
+            from .evaluation import scripted_grasp_controller
+            from ..vec_task_rlgames import RLgamesVecTaskPython
+            env = RLgamesVecTaskPython(grasp, "cuda:0")
+            env.reset()
+            for step in range(2 * 160):
+                env.step(scripted_grasp_controller(grasp, step))
+            torch.cuda.synchronize()
+            cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
+            harvest_by = "evaluation.scripted_grasp_controller, two episodes on the trained task (STAND-IN: the policy of %d epochs harvested nothing)" % se("grasp")
+        some = cnt.max() > 0 and (cnt.min() > 0 or grasp_harvest_stand_in)
+        grasp_states = grasp.grasp_terminal_states() if some else None                    # hand-off GS:1447-1450 -> IS:372-375
+        _handoff(report, "GraspSim -> InsertSim: grasp terminal states (8 x [K, 1, 13], 8 x [K, 23, 2])",
+                 None if grasp_states is None else [t for t in list(grasp_states[0]) + list(grasp_states[1]) if t.numel()],
+                 "InsertSim synthesises its start states")
+        if report is not None:
+            report[-1].update(harvested_per_type=cnt.tolist(), harvested_by=harvest_by)
         grasp.sim.close()
-        paths["insert"], _ = main_rlgames("BlockAssemblyInsertSim", num_envs, max_iterations=epochs, policy_path=paths.get("insert", ""),
-                                          task_kwargs={"grasp_states": grasp_states}, minibatch_size=insert_minibatch)
+        insert_kw = {"grasp_states": grasp_states, "synthetic_fallback": bool(grasp_harvest_stand_in)}
+        paths["insert"], _ = main_rlgames("BlockAssemblyInsertSim", num_envs, max_iterations=se("insert"), policy_path=paths.get("insert", ""),
+                                          task_kwargs=insert_kw, minibatch_size=insert_minibatch, leg="forward", **mp)
         # ---- backward fine-tuning (bi_optimization.py:120-124)
-        _, insert = main_rlgames("BlockAssemblyInsertSim", num_envs, use_t_value=True, policy_path=paths["insert"], max_iterations=epochs,
-                                 task_kwargs={"grasp_states": grasp_states}, keep=True, minibatch_size=insert_minibatch)
+        _, insert = main_rlgames("BlockAssemblyInsertSim", num_envs, use_t_value=True, policy_path=paths["insert"], max_iterations=se("insert"),
+                                 task_kwargs=insert_kw, keep=True, minibatch_size=insert_minibatch, leg="backward", **mp)
+        if report is not None:
+            report[-1]["grasp_states_source"] = insert.grasp_states_source
         tv = transition_value_trainer(insert, tvalue_rollout, tv, seed=i)
+        _handoff(report, "T-value fitted on InsertSim's outcomes -> GraspSim", None if tv is None else list(tv.values()), "no fit (too few outcomes of a class)")
         insert.sim.close()
         paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, use_t_value=True, policy_path=paths["grasp"],
-                                             max_iterations=epochs, tvalue_state=tv, keep=True, task_kwargs={"initial_piles": piles})
+                                             max_iterations=se("grasp"), tvalue_state=tv, keep=True,
+                                             task_kwargs=dict(grasp_kw, initial_piles=piles), leg="backward", **mp)
         tv = transition_value_trainer(grasp, tvalue_rollout, tv, seed=100 + i)            # bi_optimization.py:122: fit on GraspSim's own outcomes
+        _handoff(report, "T-value fitted on GraspSim's outcomes -> Orient", None if tv is None else list(tv.values()), "no fit")
         grasp.sim.close()
-        paths["orient"], orient = main_rlgames("BlockAssemblyOrient", min(num_envs, 128), use_t_value=True, policy_path=paths["orient"],
-                                               max_iterations=epochs, tvalue_state=tv, keep=True, task_kwargs={"initial_piles": dug})   # :123
+        paths["orient"], orient = main_rlgames("BlockAssemblyOrient", min(num_envs, orient_backward_envs), use_t_value=True, policy_path=paths["orient"],
+                                               max_iterations=se("orient"), tvalue_state=tv, keep=True,
+                                               task_kwargs=dict(orient_kw, initial_piles=dug), leg="backward", **mp)   # :123
         tv = transition_value_trainer(orient, tvalue_rollout, tv, seed=200 + i)           # bi_optimization.py:124
+        _handoff(report, "T-value fitted on Orient's outcomes -> next round", None if tv is None else list(tv.values()), "no fit")
         orient.sim.close()
         print("bi-optimisation round %d done: %s" % (i, paths))
     return paths, tv
@@ -109,7 +183,8 @@ if __name__ == "__main__":
     p.add_argument("--num_envs", type=int, default=512)
     p.add_argument("--epochs", type=int, default=0, help="max_iterations of every training run (0 = the YAML's max_epochs)")
     p.add_argument("--tvalue_rollout", type=int, default=10000)
+    p.add_argument("--mixed_precision", action="store_true", help="rl_games' mixed_precision key for every stage (bf16 MFMA on GEMM-shaped updates)")
     a = p.parse_args()
     if a.tasks != "BlockAssembly":
         raise Exception("Unrecognized task!")                                           # bi_optimization.py:141-143 (ToolPositioning: not built)
-    block_assembly(a.rounds, a.num_envs, a.epochs, a.tvalue_rollout)
+    block_assembly(a.rounds, a.num_envs, a.epochs, a.tvalue_rollout, mixed_precision=a.mixed_precision)

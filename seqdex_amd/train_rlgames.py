@@ -10,8 +10,9 @@ import os
 import yaml
 
 
-def build(args, task_kwargs=None, minibatch_size=0):
-    """args (config.get_args) -> (task, env, agent, logdir, rank): everything main() does before agent.train() / agent.play()"""
+def build(args, task_kwargs=None, minibatch_size=0, config_overrides=None):
+    """args (config.get_args) -> (task, env, agent, logdir, rank): everything main() does before agent.train() / agent.play().
+    config_overrides: keys written into the YAML's params.config before the agent is built (e.g. mixed_precision: True, rl_games' own key)"""
     import torch
     from .a2c_agent import A2CAgent
     from .config import load_cfg, set_seed
@@ -42,6 +43,7 @@ def build(args, task_kwargs=None, minibatch_size=0):
     if minibatch_size:     # programmatic override (the reference parses --minibatch_size but never applies it, CF:43)
         rl["params"]["config"]["minibatch_size"] = minibatch_size
         rl["params"]["config"]["central_value_config"]["minibatch_size"] = minibatch_size
+    rl["params"]["config"].update(config_overrides or {})
     rl["params"]["config"]["name"] = args.task
     rl["params"]["config"]["num_actors"] = env.num_environments
     rl["params"]["seed"] = seed

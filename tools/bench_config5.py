@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] on ONE MI355X: the full BlockAssembly Search -> Orient -> GraspSim -> InsertSim bi-optimisation loop
+(seqdex_amd/scripts/bi_optimization.py, after the reference's scripts/bi_optimization.py:110-124) at num_envs = 4096 (Search at its 128,
+the backward Orient leg at 128 as bi_optimization.py:123), `mixed_precision: True` in every stage's PPO YAML ("bf16 policy": bf16 MFMA
+operands, fp32 master weights / accumulation, wherever the shipped schedule's update is GEMM-shaped - InsertSim's minibatch 4096; the
+rank-4 schedules of the other three tasks run the fp32 persistent kernel) and each task's SHIPPED minibatch size.  One round: forward
+initialisation of the four sub-policies, then the three backward legs with a transition-value refit after each.
+
+The 8-GPU form of configs[4] cannot be run here (gpurun boxes have one GPU; no 8-GPU node was ever available to the driver): 4096 envs fit
+one GPU, so this is the whole loop at its full env count on 1/8 of the hardware.
+
+Stage lengths: an episode is 75 / 75 / 150 / 125 env steps, i.e. 10 / 10 / 19 / 16 epochs of horizon 8; shorter runs finish no episode,
+harvest nothing and log no T-value outcome, so the defaults are search 20, orient 10, grasp 20, insert 16 epochs.  What is a stand-in and says
+so in the JSON: (1) in the first forward pass no transition value has been fitted yet (as in the reference, whose first
+transition_value_trainer call comes after it), so the harvest gates are opened (0.0) and the physical criteria alone decide; (2) a grasp
+policy of 20 epochs carries no brick to the insertion side (the reference's is from epoch 19 000), so the grasp terminal states InsertSim
+starts from are harvested by two episodes of the scripted controller on the trained task; groups it leaves empty get synthetic states.
+
+    python tools/bench_config5.py [--num_envs 4096] [--out profiles/r4_config5_biopt_n4096.json] [--fp32]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DEFAULT_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 16}
+
+
+def run(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=300, workdir=None):
+    import torch
+    from seqdex_amd.scripts import bi_optimization as bo
+    stage_epochs = dict(DEFAULT_EPOCHS, **(stage_epochs or {}))
+    cwd = os.getcwd()
+    tmp = workdir or tempfile.mkdtemp(prefix="sdx_config5_")     # logs/<task>/nn/<task>.pth checkpoints are hand-offs inside the run
+    os.chdir(tmp)
+    report = []
+    torch.cuda.synchronize()
+    t0 = time.time()
+    try:
+        paths, tv = bo.block_assembly(rounds=1, num_envs=num_envs, tvalue_rollout=tvalue_rollout, mixed_precision=mixed_precision, report=report,
+                                      stage_epochs=stage_epochs, grasp_harvest_stand_in=True, gates={"orient": 0.0, "grasp": 0.0})
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    runs = [r for r in report if "task" in r]
+    hand = [r for r in report if "handoff" in r]
+    steps = sum(r["env_steps"] for r in runs)
+    train_s = sum(r["wall_s"] for r in runs)
+    out = {"config": "BASELINE.json configs[4] on one GPU: bi-optimisation loop Search -> Orient -> GraspSim -> InsertSim + three backward legs, "
+                     "num_envs=%d (Search 128, backward Orient 128), %s, shipped minibatch sizes" % (num_envs, "mixed_precision: True (bf16 MFMA on "
+                     "GEMM-shaped updates)" if mixed_precision else "fp32"),
+           "metric": "env-steps/s over the seven training runs of one round (rollout + PPO update; task construction and T-value fits excluded)",
+           "value": steps / train_s, "unit": "env-steps/s", "env_steps": steps, "training_wall_s": train_s, "loop_wall_s_incl_setup_and_fits": wall,
+           "n_gpus": 1, "configs4_on_8_gpus": "not run: no multi-GPU box has ever been available to this build (gpurun: 1 GPU)",
+           "stage_epochs": stage_epochs, "tvalue_fit_iterations": tvalue_rollout,
+           "stand_ins": ["harvest gates 0.0 in this first round: no transition value has been fitted before the first forward pass",
+                         "grasp terminal states harvested by evaluation.scripted_grasp_controller on the trained task when the 20-epoch policy harvested none"],
+           "runs": runs, "handoffs": hand, "checkpoints": paths, "tvalue_fitted": tv is not None}
+    return out, paths, tv
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num_envs", type=int, default=4096)
+    ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    res, _, _ = run(a.num_envs, not a.fp32)
+    print(json.dumps(res), flush=True)
+    if a.out:
+        with open(a.out, "w") as fh:
+            fh.write(json.dumps(res, indent=1) + "\n")
