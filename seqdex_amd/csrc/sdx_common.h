@@ -82,7 +82,13 @@ struct SdxBuf {
 #define SDX_RCP(x) (1.0f / (x))
 #define SDX_READLANE(x, lane) __shfl((x), (lane), 64)
 #define SDX_UNIFORM(x) (x)
+#define SDX_WAIT_VMCNT0() ((void)0)
+#define SDX_AS_GLOBAL(p) (p)
+#define SDX_AS_LDS(p) (p)
 #else
+#define SDX_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // this wave's outstanding global_load_lds pieces have landed
+#define SDX_AS_GLOBAL(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SDX_AS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define SDX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define SDX_OPAQUE_S(x) asm volatile("" : "+s"(x))   // the same for a wave-uniform value (scalar register)
 // x becomes unknown at a point that is ordered after the arithmetic producing `after`: loads addressed through x cannot be hoisted above it

@@ -21,8 +21,10 @@
 #include "sdxp_types.h"
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 
 #include "sdx_gemm.h"
+#include "sdx_gemm_nt.h"
 
 // column sums of Y[M][N] (ld) over the row range of split blockIdx.y -> out[blockIdx.y * oz + n]
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ Y, int ld, int M, int N, int rchunk, float* __restrict__ out, size_t oz) {
@@ -231,19 +233,6 @@ __global__ __launch_bounds__(256) void k_big_normalise(SdxpDev D, size_t r0, siz
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct SdxpBigWs {            // device workspace, allocated by sdxp_capi.hip (sizes: sdxpk_big_ws_floats)
-  float* h[3][3];             // trunk outputs  [MB][units[l]]
-  float* dy[3][3];            // dLoss/d(pre-activation) [MB][units[l]]
-  float* mu;                  // [MB][24]
-  float* dmu;                 // [MB][24]
-  float* v;                   // [2][MB] critic / central value
-  float* dv;                  // [2][MB]
-  float* part;                // split partials (max over layers of S * (N*K + N)), also head partials
-  double* dpart;              // [nsplit][state_dim][2]
-  int MB, nsplit;
-  size_t part_region;         // floats of split partials per network inside `part`
-};
-
 static int big_splits(int MB) { int s = (MB + 511) / 512; return s < 1 ? 1 : (s > 16 ? 16 : s); }
 
 extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB) {
@@ -258,6 +247,26 @@ extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB) {
   return need > hp ? need : hp;      // per network; the workspace holds three such regions
 }
 extern "C" int sdxpk_big_nsplit(int MB) { return big_splits(MB); }
+// The NT path (sdx_gemm_nt.h: staged operands, global_load_lds, two LDS stages) serves the trunk products unless SDXP_BIGMB_NT=0 asks for
+// the round-1 kernel (k_gemm of sdx_gemm.h; kept for A/B timing).  It needs 16-byte aligned minibatch windows in the transposed inputs.
+extern "C" int sdxpk_big_nt_enabled(const SdxpDev* D, int MB) {
+  const char* e = getenv("SDXP_BIGMB_NT");
+  if (e && e[0] == '0') return 0;
+  return MB % 8 == 0 && D->units[0] % 128 == 0 && D->units[1] % 128 == 0 && D->units[2] % 128 == 0 && D->obs_dim % 4 == 0 && D->state_dim % 4 == 0;
+}
+template <int BF>
+static void stage_launch(const StageArgs* a, int count, hipStream_t st) {
+  StageBatch sb;
+  int Rx = 0, Kx = 0;
+  for (int q = 0; q < 9; ++q) {
+    sb.a[q] = a[q < count ? q : 0];
+    if (q < count) { Rx = a[q].R > Rx ? a[q].R : Rx; Kx = a[q].Kp > Kx ? a[q].Kp : Kx; }
+  }
+  hipLaunchKernelGGL((k_stage<BF>), dim3((Kx + 63) / 64, (Rx + 63) / 64, count), dim3(256), 0, st, sb);
+}
+static void stage(const SdxpDev& D, const StageArgs* a, int count, hipStream_t st) {
+  if (D.bf16) stage_launch<1>(a, count, st); else stage_launch<0>(a, count, st);
+}
 
 // central-value inputs of the whole epoch: cvx0 (statistics updated minibatch by minibatch, mini-epoch 0), cvx1 (frozen)
 extern "C" void sdxpk_big_prenorm(const SdxpDev* D, const SdxpBigWs* ws, hipStream_t st) {
@@ -272,6 +281,13 @@ extern "C" void sdxpk_big_prenorm(const SdxpDev* D, const SdxpBigWs* ws, hipStre
     hipLaunchKernelGGL(k_big_normalise, dim3(1024), dim3(256), 0, st, *D, r0, (size_t)MB, D->cvx0);
   }
   hipLaunchKernelGGL(k_big_normalise, dim3(1024), dim3(256), 0, st, *D, (size_t)0, (size_t)D->N * D->horizon, D->cvx1);
+  if (ws->nt) {   // the epoch's layer-0 inputs in the element type of the run, both orientations (sdx_gemm_nt.h): once per epoch
+    const int R = D->N * D->horizon;
+    StageArgs a[3] = {{D->mb_obs, D->obs_dim, R, D->obs_dim, ws->kp[0][0], ws->xn[0], ws->kp[0][0], ws->xt[0], ws->Rp},
+                      {D->cvx0, D->state_dim, R, D->state_dim, ws->kp[2][0], ws->xn[1], ws->kp[2][0], ws->xt[1], ws->Rp},
+                      {D->cvx1, D->state_dim, R, D->state_dim, ws->kp[2][0], ws->xn[2], ws->kp[2][0], ws->xt[2], ws->Rp}};
+    stage(*D, a, 3, st);
+  }
 }
 
 // forward + losses + backward of minibatch `mb` (mini-epoch `me`) for all three networks; leaves the flat gradients in ac_g / cv_g,
@@ -288,7 +304,31 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
   auto woff = [&](int net, int l) { return net == 0 ? D.off.a_w[l] : (net == 1 ? D.off.c_w[l] : D.coff.w[l]); };
   auto boff = [&](int net, int l) { return net == 0 ? D.off.a_b[l] : (net == 1 ? D.off.c_b[l] : D.coff.b[l]); };
   const size_t region = ws->part_region;                                  // floats of split partials per network
+  const size_t ES = D.bf16 ? 2 : 4;
+  const int xsel[3] = {0, 0, me == 0 ? 1 : 2};                            // which staged dataset input a network reads
+  auto Kof = [&](int net, int l) { return l == 0 ? in0[net] : D.units[l - 1]; };
   // ---- forward: layer l of the three networks in one launch
+  if (ws->nt) {
+    {   // this step's weights in the element type, [out][in padded] and (layers 1, 2) transposed [in][out]
+      StageArgs a[9];
+      for (int net = 0; net < 3; ++net)
+        for (int l = 0; l < 3; ++l)
+          a[net * 3 + l] = {P[net] + woff(net, l), Kof(net, l), D.units[l], Kof(net, l), ws->kp[net][l], ws->wn[net][l], ws->kp[net][l],
+                            ws->wt[net][l], D.units[l]};
+      stage(D, a, 9, st);
+    }
+    for (int l = 0; l < 3; ++l) {
+      NtArgs g[3];
+      for (int net = 0; net < 3; ++net) {
+        const int kp = ws->kp[net][l];
+        const void* A = l == 0 ? (const void*)((const char*)ws->xn[xsel[net]] + r0 * kp * ES) : (const void*)ws->hn[net][l - 1];
+        g[net] = {A, l == 0 ? kp : D.units[l - 1], ws->wn[net][l], kp, MB, D.units[l], kp, kp, ws->h[net][l], D.units[l], 0,
+                  (D.bf16 && l < 2) ? ws->hn[net][l] : nullptr, D.units[l], l < 2 ? ws->ht[net][l] : nullptr, ws->MBp,
+                  P[net] + boff(net, l), nullptr, 0, nullptr};
+      }
+      if (D.bf16) gemm_nt<1, EPI_FWD>(g, 3, 1, st); else gemm_nt<0, EPI_FWD>(g, 3, 1, st);
+    }
+  } else
   for (int l = 0; l < 3; ++l) {
     GemmArgs g[3];
     for (int net = 0; net < 3; ++net) {
@@ -328,6 +368,41 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
     hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, vp1, (size_t)U2 + 1, VS, (size_t)U2 + 1, D.cv_g + D.coff.v_w);
   }
   // ---- trunk backward, layer by layer for the three networks at once
+  if (ws->nt) {
+    {   // the head kernels left dLoss/d(pre-activation of trunk layer 2) in fp32: element-type copy + transpose
+      StageArgs a[3];
+      for (int net = 0; net < 3; ++net)
+        a[net] = {ws->dy[net][2], U2, MB, U2, U2, D.bf16 ? ws->dyn[net][2] : nullptr, U2, ws->dyt[net][2], ws->MBp};
+      stage(D, a, 3, st);
+    }
+    const int kc = (((ws->MBp + S - 1) / S) + ws->KC - 1) / ws->KC * ws->KC;          // reduction rows per split, a whole number of chunks
+    for (int l = 2; l >= 0; --l) {
+      const int Nl = D.units[l];
+      NtArgs gw[3];
+      ReduceBatch rb;
+      rb.S = S;
+      for (int net = 0; net < 3; ++net) {
+        const int Kl = Kof(net, l);
+        const size_t pz = (size_t)Nl * Kl + Nl;                           // [W_l | b_l] contiguous in the flat layout
+        float* part = ws->part + (size_t)net * region;
+        const void* Xt = l == 0 ? (const void*)((const char*)ws->xt[xsel[net]] + r0 * ES) : (const void*)ws->ht[net][l - 1];
+        gw[net] = {ws->dyt[net][l], ws->MBp, Xt, l == 0 ? ws->Rp : ws->MBp, Nl, Kl, ws->MBp, kc, part, Kl, pz, nullptr, 0, nullptr, 0,
+                   nullptr, nullptr, 0, part + (size_t)Nl * Kl};
+        rb.part[net] = part; rb.pz[net] = pz; rb.n[net] = pz; rb.out[net] = G[net] + woff(net, l);
+      }
+      if (D.bf16) gemm_nt<1, EPI_TN>(gw, 3, S, st); else gemm_nt<0, EPI_TN>(gw, 3, S, st);   // G_l = dY_l^T X_l, b_l = row sums of dY_l^T
+      hipLaunchKernelGGL(k_reduce_parts3, dim3(256, 3), dim3(256), 0, st, rb);
+      if (l > 0) {
+        NtArgs gx[3];
+        const int Kl = D.units[l - 1];
+        for (int net = 0; net < 3; ++net)
+          gx[net] = {ws->dyn[net][l], Nl, ws->wt[net][l], Nl, MB, Kl, Nl, Nl, nullptr, 0, 0, l - 1 >= 1 ? ws->dyn[net][l - 1] : nullptr, Kl,
+                     ws->dyt[net][l - 1], ws->MBp, nullptr, ws->h[net][l - 1], Kl, nullptr};
+        if (D.bf16) gemm_nt<1, EPI_NN>(gx, 3, 1, st); else gemm_nt<0, EPI_NN>(gx, 3, 1, st);   // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
+      }
+    }
+    return;
+  }
   for (int l = 2; l >= 0; --l) {
     const int Nl = D.units[l];
     GemmArgs gw[3];
@@ -351,4 +426,21 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
       gemm<0, 1, 3>(gx, 3, 1, st, D.bf16 != 0);                           // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
     }
   }
+}
+
+// ---- timing / test hook (not part of include/seqdex.h): launch one batched NT product on caller-owned operands (tools/time_gemm_nt.py)
+extern "C" int sdxpk_gemm_nt_launch(int bf, int epi, const NtArgs* gs, int count, int splits, hipStream_t st) {
+  if (count < 1 || count > 3 || splits < 1) return -1;
+  if (bf) {
+    if (epi == EPI_FWD) gemm_nt<1, EPI_FWD>(gs, count, splits, st);
+    else if (epi == EPI_NN) gemm_nt<1, EPI_NN>(gs, count, splits, st);
+    else if (epi == EPI_TN) gemm_nt<1, EPI_TN>(gs, count, splits, st);
+    else return -1;
+  } else {
+    if (epi == EPI_FWD) gemm_nt<0, EPI_FWD>(gs, count, splits, st);
+    else if (epi == EPI_NN) gemm_nt<0, EPI_NN>(gs, count, splits, st);
+    else if (epi == EPI_TN) gemm_nt<0, EPI_TN>(gs, count, splits, st);
+    else return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -35,20 +35,9 @@ int sdxpk_prenorm(const SdxpDev*, int, hipStream_t);
 void sdxpk_apply_explicit(const SdxpDev*, int, float, int, hipStream_t);
 }
 
-struct SdxpBigWs {            // workspace of the large-minibatch update path (sdxp_bigmb.hip)
-  float* h[3][3];
-  float* dy[3][3];
-  float* mu;
-  float* dmu;
-  float* v;
-  float* dv;
-  float* part;
-  double* dpart;
-  int MB, nsplit;
-  size_t part_region;
-};
 extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB);
 extern "C" int sdxpk_big_nsplit(int MB);
+extern "C" int sdxpk_big_nt_enabled(const SdxpDev* D, int MB);
 extern "C" void sdxpk_big_prenorm(const SdxpDev* D, const SdxpBigWs* ws, hipStream_t st);
 extern "C" void sdxpk_big_step(const SdxpDev* D, const SdxpBigWs* ws, int mb, int me, hipStream_t st);
 extern "C" void sdxpk_apply_flat(const SdxpDev* D, hipStream_t st);
@@ -231,6 +220,38 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     w.part_region = sdxpk_big_part_floats(&D, cfg->minibatch);
     PAL(w.part, 3 * w.part_region);
     PAL(w.dpart, (size_t)w.nsplit * cfg->state_dim * 2);
+    w.nt = sdxpk_big_nt_enabled(&D, cfg->minibatch);
+    if (w.nt) {   // staged operands of the NT products (sdx_gemm_nt.h); hipMemset by palloc: the padding the kernels never write stays zero
+      const size_t ES = D.bf16 ? 2 : 4;
+      char* q;
+      w.KC = D.bf16 ? 64 : 32;
+      w.MBp = (cfg->minibatch + w.KC - 1) / w.KC * w.KC;
+      w.Rp = (int)R + 64;
+      for (int net = 0; net < 3; ++net)
+        for (int l = 0; l < 3; ++l) {
+          const int K = l == 0 ? (net == 2 ? cfg->state_dim : cfg->obs_dim) : cfg->units[l - 1];
+          w.kp[net][l] = (K + w.KC - 1) / w.KC * w.KC;
+        }
+      for (int i = 0; i < 3; ++i) {
+        const int kp0 = w.kp[i == 0 ? 0 : 2][0];
+        PAL(q, R * kp0 * ES); w.xn[i] = q;
+        PAL(q, (size_t)kp0 * w.Rp * ES); w.xt[i] = q;
+      }
+      for (int net = 0; net < 3; ++net)
+        for (int l = 0; l < 3; ++l) {
+          PAL(q, (size_t)cfg->units[l] * w.kp[net][l] * ES); w.wn[net][l] = q;
+          w.wt[net][l] = nullptr;
+          if (l > 0) { PAL(q, (size_t)w.kp[net][l] * cfg->units[l] * ES); w.wt[net][l] = q; }
+          PAL(q, (size_t)cfg->units[l] * w.MBp * ES); w.dyt[net][l] = q;
+          w.dyn[net][l] = nullptr;
+          if (l == 2 && !D.bf16) w.dyn[net][l] = w.dy[net][l];
+          else if (l > 0) { PAL(q, BM * cfg->units[l] * ES); w.dyn[net][l] = q; }
+          if (l < 2) {
+            PAL(q, (size_t)cfg->units[l] * w.MBp * ES); w.ht[net][l] = q;
+            if (D.bf16) { PAL(q, BM * cfg->units[l] * ES); w.hn[net][l] = q; } else w.hn[net][l] = w.h[net][l];
+          }
+        }
+    }
   }
 #undef PAL
   // ---- parameter init

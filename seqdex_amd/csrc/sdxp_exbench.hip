@@ -67,6 +67,10 @@ __global__ __launch_bounds__(XNTH, 2) void k_exchange_bench(ExArgs a) {
   const int xcd = g & 7, want = a.src == 0 ? -1 : (a.src == 1 ? xcd : ((xcd + 1) & 7));
   for (int r = 0; r < a.rounds; ++r) {
     const unsigned tag = a.tag0 + (unsigned)r + 1u;
+    // Two buffers by round parity, as the update kernel's factor buffers are doubled by step parity: a CU publishes round r + 1 as soon as
+    // IT has gathered round r, while a slower CU may still be reading round-r words; round r + 2 (the same buffer again) cannot be
+    // published before every CU has published r + 1, i.e. has finished gathering r.
+    const unsigned pb = (unsigned)(r & 1) * (unsigned)(a.fmt == 0 ? W : ((W + 2) / 3 / XNWG) * XNWG);
     // ---- publish this CU's share
     if (a.fmt == 0) {
       const int share = W / XNWG;                        // words per CU
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(XNTH, 2) void k_exchange_bench(ExArgs a) {
         const unsigned idx = a.pattern == 0 ? (unsigned)(g * share + j) : (unsigned)((j / 4) * 1024 + 4 * g + (j & 3));
         float v = payload(tag, idx);
         if (carry == -1.0f) v = 0.0f;                   // (never true: ties the store to the previous round's gather)
-        __hip_atomic_store(a.ll + idx, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ll + pb + idx, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       const int trip = (W + 2) / 3, share = trip / XNWG;   // 16-byte words per CU (3 floats each)
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(XNTH, 2) void k_exchange_bench(ExArgs a) {
         v.x = __float_as_uint(payload(tag, 3 * q)); v.y = __float_as_uint(payload(tag, 3 * q + 1)); v.z = __float_as_uint(payload(tag, 3 * q + 2));
         v.w = tag;
         if (carry == -1.0f) v.x = 0u;
-        store16(rs, q, v);
+        store16(rs, pb + q, v);
       }
     }
     // ---- gather the round: lane-consecutive elements (coalesced 512-byte / 1-KB requests per wave), XB per thread in flight
@@ -108,17 +112,17 @@ __global__ __launch_bounds__(XNTH, 2) void k_exchange_bench(ExArgs a) {
           bool ok = true;
           if (a.fmt == 0) {
 #pragma unroll
-            for (int b = 0; b < XB; ++b) w8[b] = idx[b] >= 0 ? __hip_atomic_load(a.ll + idx[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((u64)tag << 32);
+            for (int b = 0; b < XB; ++b) w8[b] = idx[b] >= 0 ? __hip_atomic_load(a.ll + pb + idx[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((u64)tag << 32);
 #pragma unroll
-            for (int b = 0; b < XB; ++b) ok = ok && (unsigned)(w8[b] >> 32) == tag;
+            for (int b = 0; b < XB; ++b) ok = ok && (int)((unsigned)(w8[b] >> 32) - tag) >= 0;   // this round's word, or (a producer that ran ahead) a later one
           } else {
 #pragma unroll
-            for (int b = 0; b < XB; ++b) { if (idx[b] >= 0) w16[b] = load16(rs, (unsigned)idx[b]); else { w16[b].w = tag; } }
+            for (int b = 0; b < XB; ++b) { if (idx[b] >= 0) w16[b] = load16(rs, pb + (unsigned)idx[b]); else { w16[b].w = tag; } }
 #pragma unroll
-            for (int b = 0; b < XB; ++b) ok = ok && w16[b].w == tag;
+            for (int b = 0; b < XB; ++b) ok = ok && (int)(w16[b].w - tag) >= 0;
           }
           if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-          if (++spins > (1u << 20)) { tmo += 1; break; }
+          if (++spins > (1u << 18)) { tmo += 1; atomicAdd(reinterpret_cast<unsigned long long*>(a.out + 2), 1ull); break; }
           __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
@@ -126,12 +130,13 @@ __global__ __launch_bounds__(XNTH, 2) void k_exchange_bench(ExArgs a) {
           if (idx[b] < 0) continue;
           if (a.fmt == 0) {
             const float v = __uint_as_float((unsigned)w8[b]);
-            if (v != payload(tag, (unsigned)idx[b])) bad += 1;
+            if (v != payload((unsigned)(w8[b] >> 32), (unsigned)idx[b])) bad += 1;
             sum += v;
           } else {
             const unsigned q = (unsigned)idx[b];
             const float f0 = __uint_as_float(w16[b].x), f1 = __uint_as_float(w16[b].y), f2 = __uint_as_float(w16[b].z);
-            if (f0 != payload(tag, 3u * q) || f1 != payload(tag, 3u * q + 1) || f2 != payload(tag, 3u * q + 2)) bad += 1;   // a torn word shows here
+            const unsigned wt = w16[b].w;
+            if (f0 != payload(wt, 3u * q) || f1 != payload(wt, 3u * q + 1) || f2 != payload(wt, 3u * q + 2)) bad += 1;   // a torn word shows here
             sum += f0 + f1 + f2;
           }
         }
@@ -141,13 +146,17 @@ __global__ __launch_bounds__(XNTH, 2) void k_exchange_bench(ExArgs a) {
     sum += __shfl_xor(sum, 32, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 8, 64);
     sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 1, 64);
     if ((tid & 63) == 0) atomicAdd(&acc_s[0], sum);
+    // somebody timed out -> every CU gives up (decided by one thread per workgroup, so that the barriers below stay uniform)
+    if (tid == 0) acc_s[1] = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.out + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1.0f : 0.0f;
     __syncthreads();
     carry = acc_s[0];
+    const bool stop = acc_s[1] != 0.0f;
     __syncthreads();
+    if (stop) break;
   }
   if (g == 0 && tid == 0) { a.out[0] = __builtin_amdgcn_s_memtime() - t0; a.out[3] = (long long)carry; }
   if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(a.out + 1), (unsigned long long)bad);
-  if (tmo) atomicAdd(reinterpret_cast<unsigned long long*>(a.out + 2), (unsigned long long)tmo);
+  (void)tmo;
 }
 
 // point-to-point latency: CU 0 and CU `peer` bounce one 8-byte word `rounds` times (peer & 7 == 0: the same XCD under the observed
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(64) void k_pingpong(u64* ll, long long* out, int pe
   if (g == 0) { out[0] = __builtin_amdgcn_s_memtime() - t0; out[2] = tmo; }
 }
 
-// host side: `ll` >= 2 * words * 8 bytes of device memory, `out` 4 x int64 on the device (zeroed by the caller).  Returns 0 / -1.
+// host side: `ll` >= 2 buffers x words x 8 bytes of device memory, `out` 4 x int64 on the device (zeroed by the caller).  Returns 0 / -1.
 extern "C" int sdxpk_exchange_bench(void* ll, long long* out, int words, int rounds, int fmt, int src, int pattern, unsigned tag0, hipStream_t st) {
   if (words % (XNWG * 12) != 0 || rounds < 1 || fmt < 0 || fmt > 1 || src < 0 || src > 2 || pattern < 0 || pattern > 1) return -1;
   static bool attr = false;

@@ -76,3 +76,29 @@ struct SdxpDev {
   int32_t bf16;          // large-minibatch path: trunk GEMMs on bf16 MFMA (fp32 sources, accumulation, weights and optimiser state)
   unsigned long long* ll; // [SDXP_LL_WORDS] (value, step tag) words exchanged between the CUs of the persistent update kernel
 };
+
+// workspace of the large-minibatch update path (sdxp_bigmb.hip), allocated by sdxp_capi.hip
+struct SdxpBigWs {
+  float* h[3][3];             // trunk outputs  [MB][units[l]] (fp32: the heads and the ELU' of the backward pass read these)
+  float* dy[3][3];            // dLoss/d(pre-activation) [MB][units[l]] (NT path: only l = 2, written by the head kernels)
+  float* mu;                  // [MB][24]
+  float* dmu;                 // [MB][24]
+  float* v;                   // [2][MB] critic / central value
+  float* dv;                  // [2][MB]
+  float* part;                // split partials (max over layers of S * (N*K + N)), also head partials
+  double* dpart;              // [nsplit][state_dim][2]
+  int MB, nsplit;
+  size_t part_region;         // floats of split partials per network inside `part`
+  // ---- NT path (sdx_gemm_nt.h): every operand staged k-contiguous in the element type of the run (fp32, or bf16 with mixed_precision)
+  int nt;                     // 1: the trunk products run on k_gemm_nt
+  int KC, MBp, Rp;            // chunk elements (32 fp32 / 64 bf16); MB rounded up to KC; dataset rows + 64 (row stride of the transposed inputs)
+  int kp[3][3];               // padded reduction length of forward layer l of net
+  void* xn[3];                // dataset inputs [R][kp0]: [0] observations (actor + critic), [1] cvx0, [2] cvx1
+  void* xt[3];                // their transposes [kp0][Rp]
+  void* wn[3][3];             // weights [units[l]][kp[net][l]]
+  void* wt[3][3];             // transposed weights [K_l][units[l]], l = 1, 2
+  void* hn[3][2];             // layer outputs l = 0, 1 in the element type [MB][units[l]] (fp32 runs: the h arrays themselves)
+  void* ht[3][2];             // ... transposed [units[l]][MBp]
+  void* dyn[3][3];            // gradients [MB][units[l]], l = 1, 2 (fp32 runs, l = 2: dy[net][2] itself)
+  void* dyt[3][3];            // ... transposed [units[l]][MBp], l = 0, 1, 2
+};

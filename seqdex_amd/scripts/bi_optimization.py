@@ -41,6 +41,7 @@ def main_rlgames(task, num_envs, use_t_value=False, policy_path="", max_iteratio
         task_obj.sim.set_tvalue_weights(flat_from_state_dict(tvalue_state).numpy())
     if policy_path:
         agent.epoch_num = 0        # every run of the outer loop trains max_iterations MORE epochs (rl_games would resume the counter)
+    frame0, t_opt0 = agent.frame, int(agent.ppo.ctrl().ac_t)        # (a restored checkpoint brings its frame and Adam step counters along)
     torch.cuda.synchronize()
     t0 = time.time()
     agent.train()
@@ -49,11 +50,12 @@ def main_rlgames(task, num_envs, use_t_value=False, policy_path="", max_iteratio
     if report is not None:
         c = agent.ppo.ctrl()
         p_ac = agent.ppo.t["AC_PARAMS"]
-        report.append({"leg": leg, "task": task, "num_envs": num_envs, "epochs": agent.epoch_num, "env_steps": agent.frame, "wall_s": dt,
-                       "env_steps_per_s": agent.frame / dt, "minibatch_size": agent.minibatch_size, "update_impl": agent.ppo.update_impl(),
+        frames = agent.frame - frame0
+        report.append({"leg": leg, "task": task, "num_envs": num_envs, "epochs": agent.epoch_num, "env_steps": frames, "wall_s": dt,
+                       "env_steps_per_s": frames / dt, "minibatch_size": agent.minibatch_size, "update_impl": agent.ppo.update_impl(),
                        "mixed_precision": bool(agent.ppo.cfg.mixed_precision),
                        "bf16_mfma_in_update": bool(agent.ppo.cfg.mixed_precision) and agent.ppo.update_impl() == "gemm",
-                       "optimiser_steps": int(c.ac_t), "params_finite": bool(torch.isfinite(p_ac).all()),
+                       "optimiser_steps": int(c.ac_t) - t_opt0, "params_finite": bool(torch.isfinite(p_ac).all()),
                        "restored_from": policy_path or None, "tvalue_given": tvalue_state is not None,
                        "tvalue_outcomes_logged(success, failure)": task_obj.sim.TV_COUNT.cpu().tolist(),
                        "game_reward": float(agent.game_rewards.get_mean()[0])})
@@ -97,23 +99,39 @@ def _handoff(report, name, tensor_or_none, fallback):
 
 
 def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, insert_minibatch=0, mixed_precision=False, report=None,
-                   stage_epochs=None, search_envs=128, orient_backward_envs=128, grasp_harvest_stand_in=False, gates=None):
+                   stage_epochs=None, search_envs=128, orient_backward_envs=128, grasp_harvest_stand_in=False, gates=None, gates_after_fit=None):
     """insert_minibatch: override of the insert schedule's minibatch_size 4096 for runs with fewer than 512 envs.
     stage_epochs: {"search" | "orient" | "grasp" | "insert": max_iterations} overriding `epochs` per task (an episode is 75 / 75 / 150 / 125
     env steps = 10 / 10 / 19 / 16 epochs of horizon 8: shorter runs finish no episode, harvest nothing and log no T-value outcome).
-    gates: {"orient": 0.99, "grasp": 0.8} harvest thresholds on the transition value (OR:1203, GS:1406).
+    (keys "<task>_backward" override the backward leg of a task.)
+    gates: {"orient": 0.99, "grasp": 0.8} harvest thresholds on the transition value (OR:1203, GS:1406) while no transition value has been
+    fitted yet; gates_after_fit: the same once one has (default: the reference's thresholds).
     grasp_harvest_stand_in: when the freshly trained grasp policy has not carried a single brick to the insertion side yet (the reference's
     grasp checkpoint is from epoch 19 000, README.md:90), play two episodes of evaluation.scripted_grasp_controller on the same task so that
     InsertSim starts from REAL terminal states of this engine; brick-type groups still empty get InsertSim's synthetic stand-ins.  Both are
-    named in the report.  Without it such a round hands `None` on and InsertSim synthesises all of its states (round-3 behaviour)."""
+    named in the report.  Without it such a round hands `None` on and InsertSim synthesises all of its states (round-3 behaviour).  The same
+    stand-in plays two episodes at the end of the BACKWARD grasp leg when that leg logged too few successful outcomes for a fit (the trainer
+    holds out 100 success rows, transition_value_trainer.py:170-171): outcomes of this engine's physics under a scripted hand."""
     tv = None
     paths = {}
-    se = lambda k: int((stage_epochs or {}).get(k, epochs))
-    gates = gates or {}
+    se = lambda k: int((stage_epochs or {}).get(k, (stage_epochs or {}).get(k.split("_")[0], epochs)))
     mp = dict(mixed_precision=mixed_precision, report=report)
-    orient_kw = {"tvalue_gate": gates["orient"]} if "orient" in gates else {}
-    grasp_kw = {"harvest_tvalue_gate": gates["grasp"]} if "grasp" in gates else {}
+
+    def gate_kw():
+        g = (gates_after_fit if tv is not None else gates) or {}
+        return ({"tvalue_gate": g["orient"]} if "orient" in g else {}), ({"harvest_tvalue_gate": g["grasp"]} if "grasp" in g else {})
+
+    def scripted_episodes(task_obj, episodes=2):
+        from .evaluation import scripted_grasp_controller
+        from ..vec_task_rlgames import RLgamesVecTaskPython
+        env = RLgamesVecTaskPython(task_obj, "cuda:0")
+        env.reset()
+        for step in range(episodes * 160):
+            env.step(scripted_grasp_controller(task_obj, step))
+        torch.cuda.synchronize()
+
     for i in range(rounds):
+        orient_kw, grasp_kw = gate_kw()
         # ---- forward initialisation (bi_optimization.py:115-118)
         paths["search"], search = main_rlgames("BlockAssemblySearch", min(num_envs, search_envs), max_iterations=se("search"),
                                                policy_path=paths.get("search", ""), keep=True, leg="forward", **mp)
@@ -132,13 +150,7 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
         cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
         harvest_by = "the trained grasp policy"
         if cnt.min() == 0 and grasp_harvest_stand_in:
-            from .evaluation import scripted_grasp_controller
-            from ..vec_task_rlgames import RLgamesVecTaskPython
-            env = RLgamesVecTaskPython(grasp, "cuda:0")
-            env.reset()
-            for step in range(2 * 160):
-                env.step(scripted_grasp_controller(grasp, step))
-            torch.cuda.synchronize()
+            scripted_episodes(grasp)
             cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
             harvest_by = "evaluation.scripted_grasp_controller, two episodes on the trained task (STAND-IN: the policy of %d epochs harvested nothing)" % se("grasp")
         some = cnt.max() > 0 and (cnt.min() > 0 or grasp_harvest_stand_in)
@@ -153,24 +165,39 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
         paths["insert"], _ = main_rlgames("BlockAssemblyInsertSim", num_envs, max_iterations=se("insert"), policy_path=paths.get("insert", ""),
                                           task_kwargs=insert_kw, minibatch_size=insert_minibatch, leg="forward", **mp)
         # ---- backward fine-tuning (bi_optimization.py:120-124)
-        _, insert = main_rlgames("BlockAssemblyInsertSim", num_envs, use_t_value=True, policy_path=paths["insert"], max_iterations=se("insert"),
+        _, insert = main_rlgames("BlockAssemblyInsertSim", num_envs, use_t_value=True, policy_path=paths["insert"], max_iterations=se("insert_backward"),
                                  task_kwargs=insert_kw, keep=True, minibatch_size=insert_minibatch, leg="backward", **mp)
         if report is not None:
             report[-1]["grasp_states_source"] = insert.grasp_states_source
+        tv_before = tv
         tv = transition_value_trainer(insert, tvalue_rollout, tv, seed=i)
-        _handoff(report, "T-value fitted on InsertSim's outcomes -> GraspSim", None if tv is None else list(tv.values()), "no fit (too few outcomes of a class)")
+        _handoff(report, "T-value fitted on InsertSim's outcomes -> GraspSim", None if tv is tv_before or tv is None else list(tv.values()),
+                 "no fit (too few outcomes of a class)")
+        if report is not None:
+            report[-1].update(outcomes_success_failure=insert.sim.TV_COUNT.cpu().tolist())
         insert.sim.close()
+        orient_kw, grasp_kw = gate_kw()                                                   # a transition value exists from here on
         paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, use_t_value=True, policy_path=paths["grasp"],
-                                             max_iterations=se("grasp"), tvalue_state=tv, keep=True,
+                                             max_iterations=se("grasp_backward"), tvalue_state=tv, keep=True,
                                              task_kwargs=dict(grasp_kw, initial_piles=piles), leg="backward", **mp)
+        outcomes_by = "the fine-tuned grasp policy"
+        if grasp_harvest_stand_in and int(grasp.sim.TV_COUNT[0]) <= 100:
+            scripted_episodes(grasp)
+            outcomes_by = "the fine-tuned grasp policy + two episodes of evaluation.scripted_grasp_controller (STAND-IN: the policy alone logged too few successes for a fit)"
+        tv_before = tv
         tv = transition_value_trainer(grasp, tvalue_rollout, tv, seed=100 + i)            # bi_optimization.py:122: fit on GraspSim's own outcomes
-        _handoff(report, "T-value fitted on GraspSim's outcomes -> Orient", None if tv is None else list(tv.values()), "no fit")
+        _handoff(report, "T-value fitted on GraspSim's outcomes -> Orient", None if tv is tv_before or tv is None else list(tv.values()), "no fit")
+        if report is not None:
+            report[-1].update(outcomes_by=outcomes_by, outcomes_success_failure=grasp.sim.TV_COUNT.cpu().tolist())
         grasp.sim.close()
         paths["orient"], orient = main_rlgames("BlockAssemblyOrient", min(num_envs, orient_backward_envs), use_t_value=True, policy_path=paths["orient"],
-                                               max_iterations=se("orient"), tvalue_state=tv, keep=True,
+                                               max_iterations=se("orient_backward"), tvalue_state=tv, keep=True,
                                                task_kwargs=dict(orient_kw, initial_piles=dug), leg="backward", **mp)   # :123
+        tv_before = tv
         tv = transition_value_trainer(orient, tvalue_rollout, tv, seed=200 + i)           # bi_optimization.py:124
-        _handoff(report, "T-value fitted on Orient's outcomes -> next round", None if tv is None else list(tv.values()), "no fit")
+        _handoff(report, "T-value fitted on Orient's outcomes -> next round", None if tv is tv_before or tv is None else list(tv.values()), "no fit")
+        if report is not None:
+            report[-1].update(outcomes_success_failure=orient.sim.TV_COUNT.cpu().tolist())
         orient.sim.close()
         print("bi-optimisation round %d done: %s" % (i, paths))
     return paths, tv

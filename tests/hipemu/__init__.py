@@ -51,6 +51,27 @@ def build_sim(force=False):
     return _SIM_SO
 
 
+_GEMM_SO = os.path.join(HERE, "libsdx_emu_gemm.so")
+_CLANG = "/opt/rocm/lib/llvm/bin/clang++"       # host x86 compile: the GEMM header uses ext_vector_type and __bf16, which g++ 11 lacks
+
+
+def build_gemm(force=False):
+    """seqdex_amd/csrc/sdx_gemm_nt.h (k_gemm_nt, k_stage) on the emulator: MFMA as a wave collective, global_load_lds as a per-lane copy"""
+    srcs = [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "gemm_driver.cpp")]
+    deps = srcs + [os.path.abspath(__file__), os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(HERE, "include", "hipemu_mfma.h")] + \
+        [os.path.join(CSRC, f) for f in ("sdx_gemm_nt.h", "sdx_gemm.h", "sdx_common.h")]
+    if not force and os.path.exists(_GEMM_SO) and all(os.path.getmtime(_GEMM_SO) >= os.path.getmtime(d) for d in deps):
+        return _GEMM_SO
+    objs = []
+    for src in srcs:
+        obj = os.path.join(HERE, os.path.basename(src) + ".emugemm.o")
+        subprocess.check_call([_CLANG, "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-w", "-x", "c++",
+                               "-I", os.path.join(HERE, "include"), "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+        objs.append(obj)
+    subprocess.check_call([_CLANG, "-shared", "-Wl,-Bsymbolic", "-o", _GEMM_SO] + objs)
+    return _GEMM_SO
+
+
 def sim_lib():
     """ctypes handle of the emulated simulator library with the prototypes of seqdex_amd/_abi.py::load_library"""
     global _sim_lib

@@ -1,0 +1,45 @@
+// TEST INFRASTRUCTURE ONLY: seqdex_amd/csrc/sdx_gemm_nt.h (the product's kernel source) on the SIMT emulator, so that the swizzle, the
+// fragment / accumulator layouts, the epilogues and the staging kernel are checked against numpy in the CPU suite.
+#include <hipemu_mfma.h>
+
+#include "sdx_common.h"
+#include "sdx_gemm_nt.h"
+
+// one product: A [M][lda], B [N][ldb] in the element type (fp32 or bf16 bit patterns as uint16), K a multiple of the chunk
+extern "C" int emu_gemm_nt(int bf, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int kchunk, int splits,
+                           float* Cf, int ldc, long long cz, void* Cn, int ldn, void* Ct, int ldt, const float* bias, const float* H, int ldh,
+                           float* rowsum) {
+  NtArgs g = {A, lda, B, ldb, M, N, K, kchunk, Cf, ldc, (size_t)cz, Cn, ldn, Ct, ldt, bias, H, ldh, rowsum};
+  NtArgs gs[3] = {g, g, g};
+  if (bf) {
+    if (epi == EPI_FWD) gemm_nt<1, EPI_FWD>(gs, 1, splits, nullptr);
+    else if (epi == EPI_NN) gemm_nt<1, EPI_NN>(gs, 1, splits, nullptr);
+    else gemm_nt<1, EPI_TN>(gs, 1, splits, nullptr);
+  } else {
+    if (epi == EPI_FWD) gemm_nt<0, EPI_FWD>(gs, 1, splits, nullptr);
+    else if (epi == EPI_NN) gemm_nt<0, EPI_NN>(gs, 1, splits, nullptr);
+    else gemm_nt<0, EPI_TN>(gs, 1, splits, nullptr);
+  }
+  return 0;
+}
+// the 128 x 64 tile shape (the launcher picks it for small grids) forced for a forward product
+extern "C" int emu_gemm_nt_narrow(int bf, const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* Cf, int ldc, void* Ct,
+                                  int ldt, const float* bias) {
+  NtBatch nb;
+  NtArgs g = {A, lda, B, ldb, M, N, K, K, Cf, ldc, 0, nullptr, 0, Ct, ldt, bias, nullptr, 0, nullptr};
+  nb.a[0] = nb.a[1] = nb.a[2] = g;
+  nb.splits = 1;
+  dim3 grid((N + 63) / 64, (M + 127) / 128, 1);
+  if (bf) hipLaunchKernelGGL((k_gemm_nt<1, EPI_FWD, 1>), grid, dim3(256), 2 * 192 * 128, nullptr, nb);
+  else hipLaunchKernelGGL((k_gemm_nt<0, EPI_FWD, 1>), grid, dim3(256), 2 * 192 * 128, nullptr, nb);
+  return 0;
+}
+extern "C" int emu_stage(int bf, const float* src, int lds, int R, int K, int Kp, void* dn, int ldn, void* dt, int ldt) {
+  StageBatch sb;
+  StageArgs a = {src, lds, R, K, Kp, dn, ldn, dt, ldt};
+  for (int q = 0; q < 9; ++q) sb.a[q] = a;
+  dim3 grid((Kp + 63) / 64, (R + 63) / 64, 1);
+  if (bf) hipLaunchKernelGGL((k_stage<1>), grid, dim3(256), 0, nullptr, sb);
+  else hipLaunchKernelGGL((k_stage<0>), grid, dim3(256), 0, nullptr, sb);
+  return 0;
+}

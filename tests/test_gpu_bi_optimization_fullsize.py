@@ -36,20 +36,23 @@ def test_bi_optimization_round_at_4096_envs_with_the_bf16_policy(tmp_path):
         assert r["params_finite"] and r["mixed_precision"]
         if r["task"] == "BlockAssemblyInsertSim":                       # cfg/lego/ppo_continuous_insert.yaml:50: minibatch 4096 -> GEMM-shaped, bf16 MFMA
             assert r["minibatch_size"] == 4096 and r["update_impl"] == "gemm" and r["bf16_mfma_in_update"]
-            assert r["optimiser_steps"] >= r["epochs"] * 5 * (r["num_envs"] * 8 // 4096)
+            assert r["optimiser_steps"] == r["epochs"] * 5 * (r["num_envs"] * 8 // 4096)
         else:                                                           # ppo_continuous_grasp.yaml:50: minibatch 4 -> the persistent kernel (fp32 by construction)
             assert r["minibatch_size"] == 4 and r["update_impl"] == "persistent" and not r["bf16_mfma_in_update"]
-            assert r["optimiser_steps"] >= r["epochs"] * 5 * (r["num_envs"] * 8 // 4)
+            assert r["optimiser_steps"] == r["epochs"] * 5 * (r["num_envs"] * 8 // 4)
         assert r["num_envs"] == (128 if r["task"] == "BlockAssemblySearch" or (r["task"] == "BlockAssemblyOrient" and r["leg"] == "backward") else 4096)
         assert sum(r["tvalue_outcomes_logged(success, failure)"]) > 0 or r["task"] == "BlockAssemblySearch", r     # episodes finished: outcomes were logged
     assert runs[4]["restored_from"] and runs[5]["restored_from"] and runs[6]["restored_from"]                      # backward legs start from the forward checkpoints
     assert runs[5]["tvalue_given"] and runs[6]["tvalue_given"]                                                     # ... and carry the refitted transition value
+    assert runs[3]["epochs"] == 300 and runs[4]["epochs"] == 32
     # ---- hand-offs: three stage-to-stage tensors + three fitted transition values, none empty, all finite
     assert len(hand) == 6, [h["handoff"] for h in hand]
     for h in hand:
         print(h)
         assert not h["empty"] and h.get("finite", False), h
     assert sum(hand[2]["harvested_per_type"]) >= 20 and sum(c > 0 for c in hand[2]["harvested_per_type"]) >= 3, hand[2]
+    for h in hand[3:]:                                                 # each fit had both classes (more than the 100 held-out successes)
+        assert h["outcomes_success_failure"][0] > 100 and h["outcomes_success_failure"][1] > 0, h
     assert tv is not None and all(bool(torch.isfinite(v).all()) for v in tv.values())
     for k in ("search", "orient", "grasp", "insert"):
         ck = torch.load(paths[k], map_location="cpu", weights_only=False)

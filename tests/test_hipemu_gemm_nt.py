@@ -1,0 +1,150 @@
+"""CPU: the SOURCE of the large-minibatch trunk products (seqdex_amd/csrc/sdx_gemm_nt.h: k_gemm_nt, k_stage) executed on the SIMT
+emulator (tests/hipemu: MFMA as a wave collective with the ISA's lane layouts, global_load_lds as the lane-linear copy it is) against
+numpy: source-side swizzle vs fragment reads, accumulator layout, the three epilogues incl. the transposed copies and the ones-MFMA
+row sums, split reductions, ragged edges, both element types.  What the emulator cannot show - bank conflicts, timing - is measured on
+the GPU (profiles/r4_bigmb_*); the GPU parity tests (tests/test_gpu_ppo_parity.py::test_large_minibatch_*) hold the assembled step to
+the autograd oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs ROCm's clang++ for the host build")
+
+EPI_FWD, EPI_NN, EPI_TN = 1, 3, 4
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tests import hipemu
+    l = C.CDLL(hipemu.build_gemm())
+    vp, i, fp = C.c_void_p, C.c_int, C.c_void_p
+    l.emu_gemm_nt.argtypes = [i, i, vp, i, vp, i, i, i, i, i, i, fp, i, C.c_longlong, vp, i, vp, i, fp, fp, i, fp]
+    l.emu_gemm_nt_narrow.argtypes = [i, vp, i, vp, i, i, i, i, fp, i, vp, i, fp]
+    l.emu_stage.argtypes = [i, fp, i, i, i, i, vp, i, vp, i]
+    return l
+
+
+def _elems(x, bf):
+    """(array handed to the kernel, float64 values it represents)"""
+    t = torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
+    if bf:
+        b = t.to(torch.bfloat16)
+        return b.view(torch.int16).numpy().copy(), b.to(torch.float64).numpy()
+    return t.numpy().copy(), t.to(torch.float64).numpy()
+
+
+def _from_elems(arr, bf):
+    if bf:
+        return torch.as_tensor(arr).view(torch.bfloat16).to(torch.float64).numpy()
+    return arr.astype(np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def elu(x):
+    return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+
+
+@pytest.mark.parametrize("bf", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 150, 192), (70, 36, 64)])
+def test_forward_product_all_outputs(lib, bf, M, N, K):
+    rng = np.random.default_rng(M + N + bf)
+    KC = 64 if bf else 32
+    assert K % KC == 0
+    A, Av = _elems(rng.standard_normal((M, K)) * 0.5, bf)
+    B, Bv = _elems(rng.standard_normal((N, K)) * 0.5, bf)
+    bias = rng.standard_normal(N).astype(np.float32)
+    Mp = (M + 63) // 64 * 64
+    Cf = np.full((M, N), np.nan, np.float32)
+    Cn = np.zeros((M, N), np.int16 if bf else np.float32)
+    Ct = np.zeros((N, Mp), np.int16 if bf else np.float32)
+    lib.emu_gemm_nt(bf, EPI_FWD, _p(A), K, _p(B), K, M, N, K, K, 1, _p(Cf), N, 0, _p(Cn), N, _p(Ct), Mp, _p(bias), None, 0, None)
+    want = elu(Av @ Bv.T + bias)
+    np.testing.assert_allclose(Cf, want, rtol=1e-5, atol=2e-5)      # (bf16: the operands ARE bf16 values, products exact, fp32 accumulation)
+    got_n, got_t = _from_elems(Cn, bf), _from_elems(Ct, bf)
+    np.testing.assert_allclose(got_n, Cf.astype(np.float64), rtol=8e-3 if bf else 0, atol=0)          # the copies are the fp32 result, rounded
+    np.testing.assert_allclose(got_t[:, :M], Cf.astype(np.float64).T, rtol=8e-3 if bf else 0, atol=0)
+    assert not got_t[:, M:].any()                                                                     # padding columns are never written
+
+
+@pytest.mark.parametrize("bf", [0, 1])
+def test_narrow_tile_shape(lib, bf):
+    rng = np.random.default_rng(5)
+    M, N, K = 140, 100, 128
+    A, Av = _elems(rng.standard_normal((M, K)), bf)
+    B, Bv = _elems(rng.standard_normal((N, K)), bf)
+    bias = np.zeros(N, np.float32)
+    Cf = np.zeros((M, N), np.float32)
+    Ct = np.zeros((N, 192), np.int16 if bf else np.float32)
+    lib.emu_gemm_nt_narrow(bf, _p(A), K, _p(B), K, M, N, K, _p(Cf), N, _p(Ct), 192, _p(bias))
+    np.testing.assert_allclose(Cf, elu(Av @ Bv.T), rtol=1e-5, atol=5e-5)
+    np.testing.assert_allclose(_from_elems(Ct, bf)[:, :M], Cf.astype(np.float64).T, rtol=8e-3 if bf else 0)
+
+
+@pytest.mark.parametrize("bf", [0, 1])
+def test_data_gradient_product(lib, bf):
+    """dX = (dY W) * ELU'(H): A = dY [M][Nl], B = W^T [Kl][Nl]; outputs: element copy + transposed copy, no fp32 array"""
+    rng = np.random.default_rng(7)
+    M, Nl, Kl = 160, 128, 200
+    A, Av = _elems(rng.standard_normal((M, Nl)) * 0.3, bf)
+    B, Bv = _elems(rng.standard_normal((Kl, Nl)) * 0.3, bf)
+    H = rng.standard_normal((M, Kl)).astype(np.float32)
+    Mp = 192
+    Cn = np.zeros((M, Kl), np.int16 if bf else np.float32)
+    Ct = np.zeros((Kl, Mp), np.int16 if bf else np.float32)
+    lib.emu_gemm_nt(bf, EPI_NN, _p(A), Nl, _p(B), Nl, M, Kl, Nl, Nl, 1, None, 0, 0, _p(Cn), Kl, _p(Ct), Mp, None, _p(H), Kl, None)
+    want = (Av @ Bv.T) * np.where(H > 0, 1.0, H.astype(np.float64) + 1.0)
+    np.testing.assert_allclose(_from_elems(Cn, bf), want, rtol=8e-3 if bf else 1e-5, atol=1e-3 if bf else 2e-5)
+    np.testing.assert_array_equal(_from_elems(Ct, bf)[:, :M], _from_elems(Cn, bf).T)
+    assert not _from_elems(Ct, bf)[:, M:].any()
+
+
+@pytest.mark.parametrize("bf", [0, 1])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_weight_gradient_product_with_row_sums(lib, bf, splits):
+    """G = dY^T X over the minibatch rows: A = dY^T [Nl][MBp], B = X^T [Kl][ld], split over the rows; the row sums of A (bias gradient)
+    come from the ones-MFMA of the first column block"""
+    rng = np.random.default_rng(11 + splits)
+    KC = 64 if bf else 32
+    Nl, Kl, MB = 128, 140, 3 * KC - 8                      # ragged minibatch: the last chunk is zero padded in A
+    MBp = (MB + KC - 1) // KC * KC
+    A0 = np.zeros((Nl, MBp)); A0[:, :MB] = rng.standard_normal((Nl, MB)) * 0.5
+    ldb = MBp + 64
+    B0 = rng.standard_normal((Kl, ldb))                     # what follows the window in a transposed dataset: finite, multiplied by A's zeros
+    A, Av = _elems(A0, bf)
+    B, Bv = _elems(B0, bf)
+    kc = ((MBp + splits - 1) // splits + KC - 1) // KC * KC
+    pz = Nl * Kl + Nl
+    part = np.full((splits, pz), np.nan, np.float32)
+    lib.emu_gemm_nt(bf, EPI_TN, _p(A), MBp, _p(B), ldb, Nl, Kl, MBp, kc, splits, _p(part), Kl, pz, None, 0, None, 0, None, None, 0,
+                    C.c_void_p(part.ctypes.data + 4 * Nl * Kl))
+    assert np.isfinite(part).all()
+    tot = part.astype(np.float64).sum(0)
+    G, rs = tot[:Nl * Kl].reshape(Nl, Kl), tot[Nl * Kl:]
+    np.testing.assert_allclose(G, Av @ Bv[:, :MBp].T, rtol=1e-5, atol=5e-5)
+    np.testing.assert_allclose(rs, Av.sum(1), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("bf", [0, 1])
+def test_stage_kernel(lib, bf):
+    rng = np.random.default_rng(3)
+    R, K, lds = 150, 100, 104
+    KC = 64 if bf else 32
+    Kp = (K + KC - 1) // KC * KC
+    src = rng.standard_normal((R, lds)).astype(np.float32)
+    ldt = 200
+    dn = np.full((R, Kp), 77, np.int16 if bf else np.float32)
+    dt = np.zeros((Kp, ldt), np.int16 if bf else np.float32)
+    lib.emu_stage(bf, _p(src), lds, R, K, Kp, _p(dn), Kp, _p(dt), ldt)
+    _, want = _elems(src[:, :K], bf)
+    n, t = _from_elems(dn, bf), _from_elems(dt, bf)
+    np.testing.assert_array_equal(n[:, :K], want)
+    assert not n[:, K:].any()
+    np.testing.assert_array_equal(t[:K, :R], want.T)
+    assert not t[K:].any() and not t[:, R:].any()

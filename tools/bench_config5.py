@@ -10,11 +10,14 @@ The 8-GPU form of configs[4] cannot be run here (gpurun boxes have one GPU; no 8
 one GPU, so this is the whole loop at its full env count on 1/8 of the hardware.
 
 Stage lengths: an episode is 75 / 75 / 150 / 125 env steps, i.e. 10 / 10 / 19 / 16 epochs of horizon 8; shorter runs finish no episode,
-harvest nothing and log no T-value outcome, so the defaults are search 20, orient 10, grasp 20, insert 16 epochs.  What is a stand-in and says
-so in the JSON: (1) in the first forward pass no transition value has been fitted yet (as in the reference, whose first
-transition_value_trainer call comes after it), so the harvest gates are opened (0.0) and the physical criteria alone decide; (2) a grasp
-policy of 20 epochs carries no brick to the insertion side (the reference's is from epoch 19 000), so the grasp terminal states InsertSim
-starts from are harvested by two episodes of the scripted controller on the trained task; groups it leaves empty get synthetic states.
+harvest nothing and log no T-value outcome, so the defaults are search 20, orient 10, grasp 20 epochs; InsertSim (GEMM-shaped update: 57 ms
+per epoch) trains 300 epochs forward so that its backward leg logs successful insertions for the first transition-value fit.  What is a
+stand-in and says so in the JSON: (1) in the first forward pass no transition value has been fitted yet (as in the reference, whose first
+transition_value_trainer call comes after it), so the harvest gates are opened (0.0) and the physical criteria alone decide; once a value
+exists the gates are 0.5 / 0.28, the chain benchmark's (a value fitted to a few hundred epochs of outcomes does not reach the reference's
+0.99 / 0.8); (2) a grasp policy of 20 + 20 epochs carries two or three bricks to the insertion side (the reference's is from epoch 19 000),
+so the grasp terminal states InsertSim starts from, and the successful outcomes of the backward grasp leg's fit, come from two episodes of
+the scripted controller on the trained task; groups it leaves empty get synthetic states.
 
     python tools/bench_config5.py [--num_envs 4096] [--out profiles/r4_config5_biopt_n4096.json] [--fp32]
 """
@@ -28,7 +31,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEFAULT_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 16}
+# forward InsertSim trains long enough to insert at all (its update is GEMM-shaped: 300 epochs take 17 s) - the first transition-value fit
+# needs more than 100 successful insertions from the backward leg that follows
+DEFAULT_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 300, "insert_backward": 32}
 
 
 def run(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=300, workdir=None):
@@ -43,7 +48,8 @@ def run(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=3
     t0 = time.time()
     try:
         paths, tv = bo.block_assembly(rounds=1, num_envs=num_envs, tvalue_rollout=tvalue_rollout, mixed_precision=mixed_precision, report=report,
-                                      stage_epochs=stage_epochs, grasp_harvest_stand_in=True, gates={"orient": 0.0, "grasp": 0.0})
+                                      stage_epochs=stage_epochs, grasp_harvest_stand_in=True, gates={"orient": 0.0, "grasp": 0.0},
+                                      gates_after_fit={"orient": 0.5, "grasp": 0.28})
     finally:
         os.chdir(cwd)
     torch.cuda.synchronize()
@@ -59,8 +65,10 @@ def run(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=3
            "value": steps / train_s, "unit": "env-steps/s", "env_steps": steps, "training_wall_s": train_s, "loop_wall_s_incl_setup_and_fits": wall,
            "n_gpus": 1, "configs4_on_8_gpus": "not run: no multi-GPU box has ever been available to this build (gpurun: 1 GPU)",
            "stage_epochs": stage_epochs, "tvalue_fit_iterations": tvalue_rollout,
-           "stand_ins": ["harvest gates 0.0 in this first round: no transition value has been fitted before the first forward pass",
-                         "grasp terminal states harvested by evaluation.scripted_grasp_controller on the trained task when the 20-epoch policy harvested none"],
+           "stand_ins": ["harvest gates 0.0 in the forward pass of this first round: no transition value has been fitted before it; 0.5 / 0.28 "
+                         "(not the reference's 0.99 / 0.8) in the backward legs",
+                         "grasp terminal states, and the successes of the backward grasp leg's fit, from evaluation.scripted_grasp_controller on the "
+                         "trained task when the 20-epoch policy produced (almost) none"],
            "runs": runs, "handoffs": hand, "checkpoints": paths, "tvalue_fitted": tv is not None}
     return out, paths, tv
 

@@ -50,7 +50,7 @@ def main():
 
     hdr = "%-34s %8s %6s %9s %8s %11s %11s %9s %8s" % ("edge", "floats", "fmt", "producers", "layout", "us/round", "ticks/round", "torn", "timeouts")
     lines.append(hdr)
-    print(hdr)
+    print(hdr, flush=True)
     edges = [("x3 (3 nets x 4 x 256)", 3072), ("x2 / dY1 (3 x 4 x 512)", 6144), ("dY0 Gram ~ (36 per CU)", 9216), ("x1 (3 x 4 x 1024)", 12288)]
     for name, words in edges:
         for fmt in (0, 1):
@@ -64,7 +64,7 @@ def main():
                     ln = "%-34s %8d %6s %9s %8s %11.3f %11.1f %9d %8d" % (name, words, "8B" if fmt == 0 else "16B", ("all", "own-xcd", "oth-xcd")[src],
                                                                          ("contig", "interl")[pattern], us, ticks, bad, tmo)
                     lines.append(ln)
-                    print(ln)
+                    print(ln, flush=True)
     # point-to-point
     lib_pp = lib.sdxpk_pingpong_bench
     for peer, what in ((8, "CU 0 <-> CU 8 (same XCD under b % 8 placement)"), (1, "CU 0 <-> CU 1 (different XCD)"), (129, "CU 0 <-> CU 129")):
@@ -84,7 +84,7 @@ def main():
         ln = "ping-pong %-52s %8.3f us per round trip (%.3f one way)" % (what, best, best / 2)
         rows.append(dict(pingpong=what, us_round_trip=best))
         lines.append(ln)
-        print(ln)
+        print(ln, flush=True)
     if a.out:
         with open(a.out, "w") as fh:
             fh.write("# python tools/bench_exchange.py --rounds %d  (csrc/sdxp_exbench.hip; one MI355X; us/round from HIP events over the launch,\n"
