@@ -46,7 +46,8 @@ extern "C" {
 #define SDX_OBS_FRAME 132
 #define SDX_STATE_FRAME 188
 #define SDX_PILE_HARVEST_SLOTS 512 /* Orient's ring of pile states per brick-type group (the reference keeps 10 000: OR:1485)     */
-#define SDX_TV_LOG_SLOTS 65536 /* rows of each T-value dataset ring (success / failure)                          */
+#define SDX_TV_LOG_SLOTS 1048576 /* rows of each T-value dataset ring (success / failure): large enough that the runs of the chain
+                                  * never wrap it (a wrapped ring's surviving rows depend on the order the slots were claimed in)      */
 #define SDX_HARVEST_SLOTS 5001 /* ring of grasp terminal states per brick-type group (GS:1440: index wraps after 5000) */
 #define SDX_TV_PARAMS 42562 /* GraspInsertTValue 4-256-128-64-2 weights+biases (terminal_value_function.py:30-46) */
 #define SDX_RETRI_TV_PARAMS 1257346 /* RetriGraspTValue 650-1024-512-128-2 weights+biases (terminal_value_function.py:12-28) */
@@ -98,9 +99,9 @@ typedef enum {
   SDX_T_HARVEST_OBJ = 30,  /* f32 [8,5001,13]   saved_grasp_object_ternimal_states                       GS:391-417 */
   SDX_T_HARVEST_COUNT = 31,/* i32 [8]           terminal states harvested so far (ring index = count % 5001) GS:1417,1440 */
   SDX_T_INSERT_AUX = 32,   /* f32 [N,8]         InsertSim: [0:3] rot_err (IS:1539), [3] |brick - site|, [4] rot_dist (IS:1656-1660) */
-  SDX_T_TV_SUCCESS = 33,   /* f32 [65536,4]     camera-frame target quaternions of successful episode ends (ring)   GS:1404-1412, IS:1392-1400 */
-  SDX_T_TV_FAILURE = 34,   /* f32 [65536,4]     ... of failed ones                                                  GS:1420-1438, IS:1401-1410 */
-  SDX_T_TV_COUNT = 35,     /* i32 [2]           rows logged so far: [success, failure] (ring index = count % 65536)                      */
+  SDX_T_TV_SUCCESS = 33,   /* f32 [SDX_TV_LOG_SLOTS,4] camera-frame target quaternions of successful episode ends (ring)   GS:1404-1412, IS:1392-1400 */
+  SDX_T_TV_FAILURE = 34,   /* f32 [SDX_TV_LOG_SLOTS,4] ... of failed ones                                                  GS:1420-1438, IS:1401-1410 */
+  SDX_T_TV_COUNT = 35,     /* i32 [2]           rows logged so far: [success, failure] (ring index = count % SDX_TV_LOG_SLOTS)                      */
   SDX_T_PILE_HARVEST = 36, /* f32 [8,S,132,13]  Orient: brick states of finished episodes that left the target brick reachable (ring per
                             *                    brick-type group; S = 512 for task_kind 1 (Orient) and 3 (Search, SE:1398-1420), else 1) = the saved piles the next task starts from    OR:1463-1488, GS:412-413 */
   SDX_T_PILE_HARVEST_COUNT = 37, /* i32 [8]     pile states harvested so far (ring index = count % S)                                    */
@@ -124,7 +125,12 @@ typedef enum {
                             *                    env's entry when it resets the env; a caller that teleports bodies by hand may zero it too */
   SDX_T_CAM_ROT = 45,      /* f32 [N,4]         camera_view_segmentation_target_rot: the target brick's quaternion in the camera frame, the input of
                             *                    GraspInsertTValue (GS:1196-1201, OR:1201); written by sdx_compute_observations / sdx_post_physics */
-  SDX_T_COUNT = 46
+  SDX_T_TV_KEYS = 46,      /* i64 [2,SDX_TV_LOG_SLOTS]  (step << 24 | env) of the append that filled each slot of the success / failure ring.  Ring
+                            *                    slots are claimed with atomics, i.e. in hardware order; sorting a ring's rows by these keys gives the
+                            *                    order a serial loop over steps and envs produces (what seqdex_amd.sim.ring_rows does) */
+  SDX_T_HARVEST_KEYS = 47, /* i64 [8,SDX_HARVEST_SLOTS] the same for the grasp terminal-state rings */
+  SDX_T_PILE_HARVEST_KEYS = 48, /* i64 [8,slots] the same for the pile rings of Orient / Search */
+  SDX_T_COUNT = 49
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the

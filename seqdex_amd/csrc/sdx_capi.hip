@@ -152,9 +152,12 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(tv_succ, (size_t)SDX_TV_LOG_SLOTS * 4);
   ALLOC(tv_fail, (size_t)SDX_TV_LOG_SLOTS * 4);
   ALLOC(tv_count, 2);
+  ALLOC(tv_key, (size_t)2 * SDX_TV_LOG_SLOTS);
+  ALLOC(harvest_key, (size_t)8 * SDX_HARVEST_SLOTS);
   B.pile_slots = (scene->task_kind == 1 || scene->task_kind == 3) ? SDX_PILE_HARVEST_SLOTS : 1;   // Orient and Search harvest piles
   ALLOC(pile_harvest, (size_t)8 * B.pile_slots * SDX_NBRICK * 13);
   ALLOC(pile_harvest_count, 8);
+  ALLOC(pile_key, (size_t)8 * B.pile_slots);
   ALLOC(seg_stats, (size_t)N * 4);
   ALLOC(seg_image, scene->task_kind == 3 ? (size_t)N * 128 * 128 : 1);
   ALLOC(seg_pix, (size_t)N * 4);
@@ -211,6 +214,9 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_TV_COUNT, B.tv_count, SDX_I32, {2});
   set_tensor(h, SDX_T_PILE_HARVEST, B.pile_harvest, SDX_F32, {8, B.pile_slots, SDX_NBRICK, 13});
   set_tensor(h, SDX_T_PILE_HARVEST_COUNT, B.pile_harvest_count, SDX_I32, {8});
+  set_tensor(h, SDX_T_TV_KEYS, B.tv_key, SDX_I64, {2, SDX_TV_LOG_SLOTS});
+  set_tensor(h, SDX_T_HARVEST_KEYS, B.harvest_key, SDX_I64, {8, SDX_HARVEST_SLOTS});
+  set_tensor(h, SDX_T_PILE_HARVEST_KEYS, B.pile_key, SDX_I64, {8, B.pile_slots});
   if (scene->task_kind == 3) set_tensor(h, SDX_T_SEG_IMAGE, B.seg_image, SDX_I16, {N, 128, 128});
   else set_tensor(h, SDX_T_SEG_IMAGE, B.seg_image, SDX_I16, {1, 1, 1});   // placeholder: the camera belongs to Search
   set_tensor(h, SDX_T_SEG_PIXELS, B.seg_pix, SDX_F32, {N, 4});
@@ -445,6 +451,14 @@ extern "C" int sdx_step(sdx_handle h, const float* actions_dev, void* stream) {
   sdxk_physics(h->d_const, &h->buf, st);   // controlFrequencyInv = 1 (EG:18)
   sdxk_post_physics(h->d_const, &h->buf, 1, st);
   return check_launch(h, "sdx_step");
+}
+// Not part of include/seqdex.h: the scripted stand-in for a trained grasp policy that the chain benchmark and its tests drive the grasp
+// stage with (seqdex_amd/scripts/evaluation.py), as one launch instead of ~40 torch operations per env step.
+extern "C" void sdxk_scripted_grasp(const SdxConst*, const SdxBuf*, float*, float*, hipStream_t);
+extern "C" int sdxk_scripted_grasp_actions(sdx_handle h, float* close_state_dev, float* actions_out_dev, void* stream) {
+  if (!h || !close_state_dev || !actions_out_dev) return SDX_ERR_INVALID;
+  sdxk_scripted_grasp(h->d_const, &h->buf, close_state_dev, actions_out_dev, (hipStream_t)stream);
+  return check_launch(h, "sdxk_scripted_grasp_actions");
 }
 extern "C" int sdx_reset_idx(sdx_handle h, const uint8_t* env_mask_dev, const int32_t* pile_choice_dev, void* stream) {
   if (!h || !env_mask_dev) return SDX_ERR_INVALID;

@@ -57,6 +57,9 @@ struct SdxBuf {
   int32_t pile_slots;
   float *tv_succ, *tv_fail;   // [SDX_TV_LOG_SLOTS,4] camera-frame target quaternions logged at episode ends (T-value datasets)
   int32_t* tv_count;       // [2] rows logged: success, failure
+  // (step << 24 | env) of the append that filled a ring slot: the slots are claimed with atomics, i.e. in hardware scheduling order; the
+  // hosts that consume a ring sort its rows by these keys, which is the order a serial loop over steps and envs would have produced
+  unsigned long long *tv_key, *harvest_key, *pile_key;   // [2, SDX_TV_LOG_SLOTS], [8, SDX_HARVEST_SLOTS], [8, pile_slots]
   float* jac_full;         // [N,23,6,23] or nullptr: the whole-hand Jacobian (GS:241), written by k_kinematics only
   int32_t* cstats;         // [4] since create: largest contact count of one env-substep; env-substeps that lost contacts (still over SDX_MAXC
                            // after the rebuild); env-substeps whose list was rebuilt without speculative contacts; env-substeps whose pair list overflowed

@@ -76,12 +76,14 @@ __device__ __forceinline__ void control_ik_solve(const float* J, const float* dp
 // T-value datasets (the reference's HDF5 groups data/success_dataset, data/failure_dataset, GS:470-480): the camera-frame
 // quaternion of the target brick (camera_view_segmentation_target_rot of the last compute_observations) of a finished episode goes to
 // the success or the failure ring.  Wave-uniform call; lane 0 claims the slot.
+__device__ __forceinline__ unsigned long long ring_key(const SdxBuf& B, int e) { return ((unsigned long long)B.step_count[0] << 24) | (unsigned)e; }
 __device__ __forceinline__ void tv_log(const SdxBuf& B, int e, int lane, bool success) {
   int slot = 0;
   if (lane == 0) slot = atomicAdd(&B.tv_count[success ? 0 : 1], 1) % SDX_TV_LOG_SLOTS;
   slot = __shfl(slot, 0, SDX_WAVE);
   float* dst = (success ? B.tv_succ : B.tv_fail) + (size_t)slot * 4;
   if (lane < 4) dst[lane] = B.cam_rot[(size_t)e * 4 + lane];
+  if (lane == 4) B.tv_key[(size_t)(success ? 0 : 1) * SDX_TV_LOG_SLOTS + slot] = ring_key(B, e);
 }
 
 // ------------------------------------------------------------------------------------------------ K1 + K2
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
         const size_t o = (size_t)(e & 7) * SDX_HARVEST_SLOTS + slot;
         if (lane < 46) B.harvest_hand[o * 46 + lane] = B.dof[(size_t)e * 46 + lane];      // GS:1415
         if (lane < 13) B.harvest_obj[o * 13 + lane] = tg[lane];                            // GS:1416
+        if (lane == 63) B.harvest_key[o] = ring_key(B, e);
       }
     }
     // BlockAssemblyOrient, OR:1463-1488: an episode that ends with the hand withdrawn (finger distance > 0.3), the target brick still
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
         float* dst = B.pile_harvest + ((size_t)(e & 7) * B.pile_slots + slot) * SDX_NBRICK * 13;
         const float* srcb = root_e + SDX_ACTOR_BRICK0 * 13;
         for (int i = lane; i < SDX_NBRICK * 13; i += SDX_WAVE) dst[i] = srcb[i];
+        if (lane == 0) B.pile_key[(size_t)(e & 7) * B.pile_slots + slot] = ring_key(B, e);
       }
     }
     // BlockAssemblySearch, SE:1289,1306-1343: the episode succeeded when enough pixels of the target brick are visible to the fixed
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(SDX_WAVE) void k_pre_physics(const SdxConst* __rest
         float* dst = B.pile_harvest + ((size_t)(e & 7) * B.pile_slots + slot) * SDX_NBRICK * 13;
         const float* srcb = root_e + SDX_ACTOR_BRICK0 * 13;
         for (int i = lane; i < SDX_NBRICK * 13; i += SDX_WAVE) dst[i] = srcb[i];
+        if (lane == 0) B.pile_key[(size_t)(e & 7) * B.pile_slots + slot] = ring_key(B, e);
       }
     }
     __builtin_amdgcn_wave_barrier();   // the harvests above read rows that the restore below rewrites with another lane assignment
@@ -866,6 +871,45 @@ __global__ __launch_bounds__(SDX_WAVE) void k_search_set_hand(const SdxConst* __
     if (lane < 3) B.init_pos[e * 3 + lane] = tg[lane];                                          // SE:1494
     if (lane < 4) B.init_rot[e * 4 + lane] = tg[3 + lane];                                      // SE:1495
   }
+}
+// STAND-IN for a trained BlockAssemblyGraspSim policy (the chain benchmark / tests; seqdex_amd/scripts/evaluation.py::scripted_grasp_controller
+// documents why): a reach - descend - pinch sequence on the task's own action interface (GS:1586-1609).  One thread per env; `close_at`
+// [N] is the controller's only state (the progress value at which the env's fingers started to close), owned by the caller.
+__global__ __launch_bounds__(256) void k_scripted_grasp(const SdxConst* __restrict__ C, SdxBuf B, float* __restrict__ close_at, float* __restrict__ act) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B.N) return;
+  const sdx_scene_desc& sc = C->sc;
+  const float prog = (float)B.progress[e];
+  const float* hb = B.rb + ((size_t)e * SDX_BODIES + sc.hand_base_body) * 13;
+  const float* br = B.root + ((size_t)e * SDX_ACTORS + seg_actor(e)) * 13;
+  float cl = prog < 2.0f ? 1e9f : close_at[e];                                  // a new episode
+  // the pinch point between thumb and fingers sits (0.125, 0.02, -0.2) from the hand base in the prepare orientation (FK of the scene)
+  const float rx = hb[0] - br[0], ry = hb[1] - br[1], rz = hb[2] - br[2];
+  const float horiz = sqrtf((rx + 0.125f) * (rx + 0.125f) + (ry + 0.02f) * (ry + 0.02f));
+  const float above = horiz > 0.05f ? 0.25f : 0.195f;                           // stay above the pile while travelling
+  float* a = act + (size_t)e * SDX_NDOF;
+  a[0] = clampf(2.5f * (br[0] - 0.125f - hb[0]) / 0.64f, -1.0f, 1.0f);
+  a[1] = clampf(2.5f * (br[1] - 0.02f - hb[1]) / 0.64f, -1.0f, 1.0f);
+  a[2] = clampf(2.5f * (br[2] + above - hb[2]) / 0.64f, -1.0f, 1.0f);
+  // hold the wrist at the prepare pose's orientation (palm down): a[3:6] x 0.2 = orientation error for the IK (GS:1596, OR:1922-1925)
+  const float q0x = 0.7107f, q0y = -0.7033f, q0z = 0.0113f, q0w = -0.0091f;
+  const float qx = hb[3], qy = hb[4], qz = hb[5], qw = hb[6];
+  const float rw = q0w * qw + (q0x * qx + q0y * qy + q0z * qz);                 // q0 * conj(q)
+  const float cx = q0y * qz - q0z * qy, cy = q0z * qx - q0x * qz, cz = q0x * qy - q0y * qx;
+  const float sg = rw > 0.0f ? 1.0f : (rw < 0.0f ? -1.0f : 0.0f);
+  a[3] = clampf(2.0f * (-q0w * qx + qw * q0x - cx) * sg / 0.2f, -1.0f, 1.0f);
+  a[4] = clampf(2.0f * (-q0w * qy + qw * q0y - cy) * sg / 0.2f, -1.0f, 1.0f);
+  a[5] = clampf(2.0f * (-q0w * qz + qw * q0z - cz) * sg / 0.2f, -1.0f, 1.0f);
+  a[6] = 0.0f;
+  const bool arrived = horiz < 0.012f && fabsf(rz - 0.195f) < 0.012f;
+  if (arrived || prog >= 58.0f) cl = fminf(cl, prog);                           // at the latest at step 58
+  close_at[e] = cl;
+  const float frac = clampf(0.3f + (prog - cl) / 14.0f * 0.6f, 0.3f, 0.9f);
+  for (int j = 7; j < SDX_NDOF; ++j) a[j] = 2.0f * frac - 1.0f;
+  a[7] = 0.0f; a[11] = 0.0f; a[15] = 0.0f;                                      // abduction joints of the three fingers stay centred
+}
+extern "C" void sdxk_scripted_grasp(const SdxConst* C, const SdxBuf* B, float* close_at, float* act, hipStream_t st) {
+  hipLaunchKernelGGL(k_scripted_grasp, dim3((B->N + 255) / 256), dim3(256), 0, st, C, *B, close_at, act);
 }
 extern "C" void sdxk_search_set_hand(const SdxConst* C, const SdxBuf* B, const uint8_t* mask, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_search_set_hand, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, mask, mode);

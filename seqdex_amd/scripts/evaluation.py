@@ -85,44 +85,81 @@ def main_rlgames(task, num_envs, play=True, use_t_value=True, policy_path="", st
 def scripted_grasp_controller(task, step):
     """STAND-IN for a trained BlockAssemblyGraspSim policy (the reference's released checkpoint is from epoch 19 000, README.md:90; nothing of
     that length can be trained inside a test): a hand-written reach - descend - pinch sequence on the task's own action interface
-    (GS:1586-1609: a[0:3] x 0.64 = hand-base displacement for the IK, a[7:23] = finger targets scaled to the joint limits).  After step 75 the
-    task itself lifts the hand and carries it to the insertion side with the fingers frozen (GS:1600-1609).  Used by tools/bench_config3.py and
-    tests/test_gpu_chain.py so that the grasp stage harvests REAL terminal states of this engine; success is far below a trained policy's."""
-    s, n = task.sim, task.num_envs
-    if not hasattr(task, "_sg_seg"):
-        sc = s.scene
-        task._sg_seg = torch.as_tensor([sc.seg_index(i) for i in range(n)], device=task.device, dtype=torch.long)
-        task._sg_env = torch.arange(n, device=task.device)
-        # the wrist orientation to hold = the hand base's at the prepare pose: (0.7107, -0.7033, 0.0113, -0.0091) by the scene's FK (palm down)
-        task._sg_q0 = torch.tensor([0.7107, -0.7033, 0.0113, -0.0091], device=task.device)
-    prog = s.PROGRESS.to(torch.float32)
-    hb = s.RB[:, s.scene.hand_base_body, 0:3]
-    brick = s.ROOT.view(n, 142, 13)[task._sg_env, task._sg_seg, 0:3]
-    # the pinch point between thumb and fingers sits (0.125, 0.02, -0.2) from the hand base in the prepare orientation (FK of the scene)
+    (GS:1586-1609: a[0:3] x 0.64 = hand-base displacement for the IK, a[3:6] x 0.2 = wrist orientation error, a[7:23] = finger targets scaled
+    to the joint limits): hand base above the target brick with the wrist held at the prepare pose's orientation, descend, pinch when
+    arrived (at the latest at step 58).  After step 75 the task itself lifts the hand and carries it to the insertion side with the fingers
+    frozen (GS:1600-1609).  Used by tools/bench_config3.py, tools/bench_config5.py and tests/test_gpu_chain.py so that the grasp stage
+    harvests REAL terminal states of this engine; success is far below a trained policy's.  One kernel launch per env step
+    (csrc/sdx_task.hip::k_scripted_grasp; round 3 computed the same in ~40 torch operations inside the timed loop)."""
+    import ctypes as C
+    s = task.sim
     if not hasattr(task, "_sg_close"):
-        task._sg_close = torch.full((n,), 1e9, device=task.device)      # progress value at which the env's fingers started to close
-    task._sg_close = torch.where(prog < 2, torch.full_like(prog, 1e9), task._sg_close)          # a new episode
-    rel = hb - brick
-    horiz = torch.sqrt((rel[:, 0] + 0.125) ** 2 + (rel[:, 1] + 0.02) ** 2)
-    above = torch.where(horiz > 0.05, torch.full_like(prog, 0.25), torch.full_like(prog, 0.195))   # stay above the pile while travelling
-    target = brick + torch.stack([torch.full_like(prog, -0.125), torch.full_like(prog, -0.02), above], dim=1)
-    a = torch.zeros(n, 23, device=task.device)
-    a[:, 0:3] = torch.clamp(2.5 * (target - hb) / 0.64, -1.0, 1.0)
-    # hold the wrist at the prepare pose's orientation (palm down): a[3:6] x 0.2 = orientation error for the IK (GS:1596, OR:1922-1925)
-    q = s.RB[:, s.scene.hand_base_body, 3:7]
-    q0 = task._sg_q0
-    qr_w = q0[3] * q[:, 3] + (q0[:3] * q[:, :3]).sum(1)                                              # q0 * conj(q)
-    qr_v = -q0[3] * q[:, :3] + q[:, 3:4] * q0[:3] - torch.cross(q0[:3].expand_as(q[:, :3]), q[:, :3], dim=1)
-    a[:, 3:6] = torch.clamp(2.0 * qr_v * torch.sign(qr_w).unsqueeze(1) / 0.2, -1.0, 1.0)
-    arrived = (horiz < 0.012) & ((rel[:, 2] - 0.195).abs() < 0.012)
-    task._sg_close = torch.where(arrived | (prog >= 58), torch.minimum(task._sg_close, prog), task._sg_close)   # at the latest at step 58
-    frac = torch.clamp(0.3 + (prog - task._sg_close) / 14.0 * 0.6, min=0.3, max=0.9)
-    a[:, 7:23] = (2.0 * frac - 1.0).unsqueeze(1)
-    a[:, [7, 11, 15]] = 0.0                                            # abduction joints of the three fingers stay centred
-    return a
+        task._sg_close = torch.full((task.num_envs,), 1e9, device=task.device)      # progress value at which the env's fingers started to close
+        task._sg_act = torch.zeros(task.num_envs, 23, device=task.device)
+        s.lib.sdxk_scripted_grasp_actions.restype = C.c_int
+        s.lib.sdxk_scripted_grasp_actions.argtypes = [C.c_void_p] * 4
+    rc = s.lib.sdxk_scripted_grasp_actions(s.h, C.c_void_p(task._sg_close.data_ptr()), C.c_void_p(task._sg_act.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream(task.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("sdxk_scripted_grasp_actions failed (%d)" % rc)
+    return task._sg_act
 
 
-def fill_missing_pile_groups(harvest, counts, min_piles, seed, max_missing=2):
+def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None):
+    """stage 0 of the chain (untimed; the backward pass of scripts/bi_optimization.py:120-121 in small): BlockAssemblyInsertSim trains
+    `epochs` epochs with its shipped schedule from synthetic grasp states, its episode outcomes fill the T-value rings, GraspInsertTValue
+    is fitted to them -> the transition value that gates the harvests of the chain, and the insert policy of its last stage.
+    Deterministic run to run: training is (fixed-order reductions, counter-based noise) and the fit reads the outcome rings in serial
+    (step, env) order (SdxSim.ring_rows), not in the order the slots were claimed in.
+    Returns (flat T-value weights or None, insert checkpoint path or "", statistics)."""
+    from ..tasks.block_assembly_insert_sim import BlockAssemblyInsertSim
+    from ..tvalue_trainer import TValue_Trainer, flat_from_state_dict
+    cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG["BlockAssemblyInsertSim"])))
+    cfg["env"]["numEnvs"] = n
+    tr = yaml.safe_load(open(os.path.join(ROOT, TRAIN_CFG["BlockAssemblyInsertSim"])))
+    task = BlockAssemblyInsertSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed)
+    env = RLgamesVecTaskPython(task, "cuda:0")
+    tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=seed)
+    agent = A2CAgent("run", tr["params"])
+    t0 = time.time()
+    for _ in range(epochs):
+        agent.train_epoch()
+    torch.cuda.synchronize()
+    st = {"epochs": epochs, "wall_s": time.time() - t0, "game_reward": agent.game_rewards.get_mean()[0],
+          "outcomes_logged(success, failure)": task.sim.TV_COUNT.cpu().tolist()}
+    path = ""
+    if save_to:
+        agent.save(save_to)
+        path = save_to + ".pth"
+    tv = None
+    try:
+        trn = TValue_Trainer.from_task(task, seed=seed)
+        trn.init_TValue_function("BlockAssemblyInsertSim", fit_iters)
+        # Only about 0.3 % of all brick orientations are ones InsertSim succeeds from.  The fit goes on (at most three more rounds) until it
+        # rates at least 0.05 % of 20 000 random orientations above the chain's Orient gate: below that Orient's harvest can come out empty.
+        g = torch.Generator().manual_seed(0)
+        q = torch.randn(20000, 4, generator=g)
+        q = (q / q.norm(dim=1, keepdim=True)).to(task.sim.device)
+        rounds, cover = 0, 0.0
+        while rounds < 4:
+            trn.train_rollout()
+            rounds += 1
+            out = torch.cat([trn.predict(q[i:i + 1024]) for i in range(0, q.shape[0], 1024)])     # (sdxtv_predict takes at most one batch)
+            cover = float((torch.sigmoid(out)[:, 1] > 0.5).float().mean())
+            if cover >= 5e-4:
+                break
+        st["tvalue_fit"] = {"iterations": fit_iters * rounds, "loss": trn.losses[-1], "held_out_success_rate": trn.valid_t_value_success_rate,
+                            "random_orientations_rated_above_0.5": cover}
+        tv = flat_from_state_dict(trn.state_dict()).numpy()
+        trn.close()
+    except ValueError as ex:
+        st["tvalue_fit"] = "skipped: %s" % ex
+    agent.ppo.close()
+    task.sim.close()
+    return tv, path, st
+
+
+def fill_missing_pile_groups(harvest, counts, min_piles, seed, max_missing=2, keys=None):
     """Brick-type groups Orient could not fill (the gate of a briefly fitted T-value can miss the orientations one brick type settles in)
     start GraspSim from settled piles instead - the states GraspSim generates for itself when it is given none (piles.generate_piles) - as
     InsertSim's groups without a harvested grasp state fall back to its synthetic ones.  harvest [8, slots, 132, 13], counts [8].
@@ -134,6 +171,10 @@ def fill_missing_pile_groups(harvest, counts, min_piles, seed, max_missing=2):
         return None, []
     k = int(cnt[cnt >= min_piles].min())
     piles = harvest[:, :k].clone()
+    if keys is not None:                                   # serial (step, env) order of the appends, as pile_terminal_states() hands them on
+        for t in range(8):
+            if cnt[t] >= k:
+                piles[t] = harvest[t, :int(cnt[t])].index_select(0, torch.argsort(keys[t, :int(cnt[t])], stable=True))[:k]
     settled = torch.as_tensor(generate_piles(k, device=str(piles.device), seed=seed)).to(piles.device)
     for t in lacking:
         piles[t] = settled[t]
@@ -175,7 +216,7 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     st["tvalue_gate"] = orient_tvalue_gate
     piles = orient.pile_terminal_states()
     if synthetic_fallback:
-        filled, lacking = fill_missing_pile_groups(orient.sim.PILE_HARVEST, orient.sim.PILE_HARVEST_COUNT, min_piles, seed)
+        filled, lacking = fill_missing_pile_groups(orient.sim.PILE_HARVEST, orient.sim.PILE_HARVEST_COUNT, min_piles, seed, keys=orient.sim.PILE_HARVEST_KEYS)
         if lacking:
             piles, st["settled_stand_in_groups"] = filled, lacking
     orient.sim.close()

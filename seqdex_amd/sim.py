@@ -76,6 +76,17 @@ class SdxSim:
             return t[name.upper()]
         raise AttributeError(name)
 
+    def ring_rows(self, rows, keys, count):
+        """the filled rows of one ring in SERIAL order: `rows` [slots, ...] and `keys` [slots] views of a ring and its key tensor
+        (SDX_T_*_KEYS: step << 24 | env of the append), `count` appends so far.  The kernels claim ring slots with atomics, so the slot order
+        is the hardware's; sorted by key the rows come out as a loop over steps and envs would have written them - the same on every
+        run.  (A ring that has wrapped keeps whichever `slots` rows landed last in each slot: size the run so that it does not.)"""
+        k = int(min(int(count), rows.shape[0]))
+        if k == 0:
+            return rows[:0].clone()
+        order = torch.argsort(keys[:k], stable=True)
+        return rows[:k].index_select(0, order)
+
     # ------------------------------------------------------------------ C ABI calls
     def load_initial_states(self, piles):
         if torch.is_tensor(piles):

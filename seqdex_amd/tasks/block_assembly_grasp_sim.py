@@ -118,9 +118,9 @@ class BlockAssemblyGraspSim:
         object root states [K_t, 1, 13] and hand joint states [K_t, 23, 2] per brick-type group (K_t = filled ring slots)."""
         s = self.sim
         cnt = s.HARVEST_COUNT.cpu().numpy()
-        k = np.minimum(cnt, _abi.HARVEST_SLOTS)
-        obj = [s.HARVEST_OBJ[t, :int(k[t])].clone().unsqueeze(1) for t in range(8)]
-        hand = [s.HARVEST_HAND[t, :int(k[t])].clone() for t in range(8)]
+        # serial (step, env) order of the appends (SdxSim.ring_rows): InsertSim's resets index these lists by position
+        obj = [s.ring_rows(s.HARVEST_OBJ[t], s.HARVEST_KEYS[t], cnt[t]).unsqueeze(1) for t in range(8)]
+        hand = [s.ring_rows(s.HARVEST_HAND[t], s.HARVEST_KEYS[t], cnt[t]) for t in range(8)]
         return obj, hand
 
     def save_grasp_terminal_states(self, path):

@@ -13,6 +13,8 @@ Same robot, bin and brick pile as BlockAssemblyGraspSim; what the Orient task ch
 Not reproduced: the 36-brick floor of this scene (the GraspSim slab is used), the density 2000 of the fixed
 bricks (they are static here anyway).
 """
+import torch
+
 from .. import _abi
 from .block_assembly_grasp_sim import BlockAssemblyGraspSim
 
@@ -41,7 +43,10 @@ class BlockAssemblyOrient(BlockAssemblyGraspSim):
         s = self.sim
         cnt = np.minimum(s.PILE_HARVEST_COUNT.cpu().numpy(), s.PILE_HARVEST.shape[1])
         k = int(cnt.min())
-        return s.PILE_HARVEST[:, :k].clone() if k > 0 else None
+        if k == 0:
+            return None
+        # serial (step, env) order of the appends (SdxSim.ring_rows), the first k of every group: GraspSim's resets index these by position
+        return torch.stack([s.ring_rows(s.PILE_HARVEST[t], s.PILE_HARVEST_KEYS[t], cnt[t])[:k] for t in range(8)])
 
     def save_pile_terminal_states(self, path):
         """the harvested piles as the reference's pickle (list[8] of [K_t, 132, 13]; OR:1505-1510, SE:1349-1350): what
@@ -50,4 +55,4 @@ class BlockAssemblyOrient(BlockAssemblyGraspSim):
         from ..piles import save_pile_pickle
         s = self.sim
         cnt = np.minimum(s.PILE_HARVEST_COUNT.cpu().numpy(), s.PILE_HARVEST.shape[1])
-        save_pile_pickle(path, [s.PILE_HARVEST[t] for t in range(8)], counts=cnt)
+        save_pile_pickle(path, [s.ring_rows(s.PILE_HARVEST[t], s.PILE_HARVEST_KEYS[t], cnt[t]) for t in range(8)], counts=cnt)

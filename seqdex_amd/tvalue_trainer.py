@@ -63,8 +63,9 @@ class TValue_Trainer:
         """datasets = the SDX_T_TV_SUCCESS / SDX_T_TV_FAILURE rings that the task's reset kernels filled (GS:1404-1438, IS:1392-1410)"""
         s = task.sim
         cnt = s.TV_COUNT.cpu().numpy()
-        n = np.minimum(cnt, s.TV_SUCCESS.shape[0])
-        return cls((s.TV_SUCCESS[:int(n[0])].clone(), s.TV_FAILURE[:int(n[1])].clone()), device=str(s.device), **kw)
+        # rows in serial (step, env) order, not in the order the ring slots happened to be claimed in: the fit's sampler indexes the
+        # datasets by position, so the same outcomes must sit at the same positions on every run
+        return cls((s.ring_rows(s.TV_SUCCESS, s.TV_KEYS[0], cnt[0]), s.ring_rows(s.TV_FAILURE, s.TV_KEYS[1], cnt[1])), device=str(s.device), **kw)
 
     def init_TValue_function(self, task_name="grasping_insertion", rollout=100000, state_dict=None, batch_size=1024, lr=0.001):
         self.batch_size, self.succ_batch_size, self.fail_batch_size = batch_size, batch_size // 2, batch_size // 2   # TT:190-192

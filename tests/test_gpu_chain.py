@@ -15,16 +15,11 @@ def test_chain_hand_offs_at_1024_envs():
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from seqdex_amd.scripts.evaluation import block_assembly_chain, scripted_grasp_controller
-    from tools.bench_config3 import prepare_tvalue_and_insert_policy
-    # stage 0: the transition value of the chain's gates, fitted to InsertSim's own episode outcomes (bi_optimization.py:120-121)
-    # (the outcome rings fill in a run-dependent order and so does the fit: a second training run with another seed if the first fit rates
-    # almost no orientation above the Orient gate)
-    for seed in (22, 23):
-        tv, _, prep = prepare_tvalue_and_insert_policy(N, 1000, fit_iters=2000, seed=seed)
-        assert tv is not None, prep                               # both outcome classes were logged and the fit ran
-        if prep["tvalue_fit"]["random_orientations_rated_above_0.5"] >= 5e-4:
-            break
+    from seqdex_amd.scripts.evaluation import block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller
+    # stage 0: the transition value of the chain's gates, fitted to InsertSim's own episode outcomes (bi_optimization.py:120-121).  One
+    # seed, no retry: training is deterministic and the fit reads the outcome rings in serial (step, env) order (SdxSim.ring_rows)
+    tv, _, prep = prepare_tvalue_and_insert_policy(N, 1000, fit_iters=2000, seed=22)
+    assert tv is not None, prep                                   # both outcome classes were logged and the fit ran
     # gates at 0.5 / 0.28 instead of 0.99 (OR:1203) / 0.8 (GS:1406): a T-value fitted to a thousand epochs of outcomes tops out near 0.85 and
     # sits at its floor sigmoid(-1) = 0.27 for most orientations; two grasp episodes
     try:

@@ -121,7 +121,7 @@ def test_insert_task_logs_tvalue_datasets_and_trainer_consumes_them(scene):
     task.sim.TV_COUNT[0] = 160
     tr = TValue_Trainer.from_task(task, seed=2)
     try:
-        assert tr.num_success_data == 60 and tr.num_failure_data == int(min(cnt[1], 65536))
+        assert tr.num_success_data == 60 and tr.num_failure_data == int(min(cnt[1], 1048576))
         tr.init_TValue_function(rollout=200)
         tr.train_rollout(validate_every=200)
         assert np.isfinite(tr.losses[-1]) and tr.losses[-1] < 0.69

@@ -18,64 +18,10 @@ import sys
 import time
 
 import torch
-import yaml
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from seqdex_amd.a2c_agent import A2CAgent  # noqa: E402
-from seqdex_amd.config import TASK_CFG, TRAIN_CFG  # noqa: E402
-from seqdex_amd.scripts.evaluation import block_assembly_chain, scripted_grasp_controller  # noqa: E402
-from seqdex_amd.tasks.block_assembly_insert_sim import BlockAssemblyInsertSim  # noqa: E402
-from seqdex_amd.tvalue_trainer import TValue_Trainer, flat_from_state_dict  # noqa: E402
-from seqdex_amd.vec_task_rlgames import RLgamesVecTaskPython  # noqa: E402
-
-
-def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None):
-    """stage 0: returns (flat T-value weights or None, insert checkpoint path or "", statistics)"""
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd", TASK_CFG["BlockAssemblyInsertSim"])))
-    cfg["env"]["numEnvs"] = n
-    tr = yaml.safe_load(open(os.path.join(ROOT, "seqdex_amd", TRAIN_CFG["BlockAssemblyInsertSim"])))
-    task = BlockAssemblyInsertSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed)
-    env = RLgamesVecTaskPython(task, "cuda:0")
-    tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=seed)
-    agent = A2CAgent("run", tr["params"])
-    t0 = time.time()
-    for _ in range(epochs):
-        agent.train_epoch()
-    torch.cuda.synchronize()
-    st = {"epochs": epochs, "wall_s": time.time() - t0, "game_reward": agent.game_rewards.get_mean()[0],
-          "outcomes_logged(success, failure)": task.sim.TV_COUNT.cpu().tolist()}
-    path = ""
-    if save_to:
-        agent.save(save_to)
-        path = save_to + ".pth"
-    tv = None
-    try:
-        trn = TValue_Trainer.from_task(task, seed=seed)
-        trn.init_TValue_function("BlockAssemblyInsertSim", fit_iters)
-        # The outcome rings fill through atomics, so their order - and with it the fit - differs from run to run; only about 0.3 % of all brick
-        # orientations are ones InsertSim succeeds from.  The fit goes on (at most three more rounds) until it rates at least 0.05 % of
-        # 20 000 random orientations above the chain's Orient gate: below that Orient's harvest can come out empty.
-        g = torch.Generator().manual_seed(0)
-        q = torch.randn(20000, 4, generator=g)
-        q = (q / q.norm(dim=1, keepdim=True)).to(task.sim.device)
-        rounds, cover = 0, 0.0
-        while rounds < 4:
-            trn.train_rollout()
-            rounds += 1
-            out = torch.cat([trn.predict(q[i:i + 1024]) for i in range(0, q.shape[0], 1024)])     # (sdxtv_predict takes at most one batch)
-            cover = float((torch.sigmoid(out)[:, 1] > 0.5).float().mean())
-            if cover >= 5e-4:
-                break
-        st["tvalue_fit"] = {"iterations": fit_iters * rounds, "loss": trn.losses[-1], "held_out_success_rate": trn.valid_t_value_success_rate,
-                            "random_orientations_rated_above_0.5": cover}
-        tv = flat_from_state_dict(trn.state_dict()).numpy()
-        trn.close()
-    except ValueError as ex:
-        st["tvalue_fit"] = "skipped: %s" % ex
-    agent.ppo.close()
-    task.sim.close()
-    return tv, path, st
+from seqdex_amd.scripts.evaluation import block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller  # noqa: E402
 
 
 if __name__ == "__main__":
@@ -83,10 +29,7 @@ if __name__ == "__main__":
     prep = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1200
     import tempfile
     tmp = tempfile.mkdtemp(prefix="sdx_config3_")          # the stage-0 checkpoint (30 MB) is a hand-off inside this run, not an artefact
-    for seed in (22, 23):        # a second stage 0 if the first fit rates almost no orientation above the Orient gate (run-dependent ring order)
-        tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, seed=seed, save_to=os.path.join(tmp, "config3_insert_policy"))
-        if tv is None or prep_st["tvalue_fit"]["random_orientations_rated_above_0.5"] >= 5e-4:
-            break
+    tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, seed=22, save_to=os.path.join(tmp, "config3_insert_policy"))
     print("stage 0:", json.dumps(prep_st), file=sys.stderr, flush=True)
     res, hand = block_assembly_chain(n, tv, policies={"insert": insert_ckpt}, controllers={"grasp": scripted_grasp_controller},
                                      synthetic_fallback=True, orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28,
