@@ -25,6 +25,8 @@
 //     EPI_TN split partials of G = dY^T X and, on the first column block, the row sums of A (= the bias gradient) from one more
 //     MFMA per step against a constant fragment of ones.
 #pragma once
+#include <cstdlib>
+
 #include "sdx_gemm.h"
 
 #define EPI_FWD 1
@@ -99,60 +101,68 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtBatch nb) {
   for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int i = 0; i < 16; ++i) accb[u][i] = 0.0f;
-  const bool do_rs = EPI == EPI_TN && blockIdx.x == 0 && (wave & 1) == 0;
+  // EPI_TN: the workgroups of the first column block also accumulate A x ones (row sums of A).  The choice is made ONCE, outside the
+  // reduction loop, between two copies of the loop: a branch between the MFMAs of a 2-accumulator wave (the 128 x 64 tile in fp32) gave
+  // wrong sums in the waves that skipped the extra MFMAs on gfx950 (tools/diag_gemm_nt.py; the accumulator whose MFMA sits right before
+  // the taken branch was off by a few per cent) - the loop bodies below are branch-free.
+  const bool do_rs = EPI == EPI_TN && blockIdx.x == 0;
   // fragment addresses: row (l & 31) of a 32-row block, piece (2 t + (l >> 5)) ^ key, key = ((l & 31) >> 1) & 7 (block bases are multiples of 32)
   const int roff = (lane & 31) * 128;
   const int off0 = ((lane >> 5) ^ ((lane >> 1) & 7)) << 4;
-  if (nc > 0) issue(0, 0);
-  for (int c = 0; c < nc; ++c) {
-    SDX_WAIT_VMCNT0();                                // this wave's pieces of chunk c have landed ...
-    __syncthreads();                                  // ... everybody's have, and everybody is done reading the other stage
-    if (c + 1 < nc) issue(c + 1, (c + 1) & 1);
-    const char* sa = smem + (c & 1) * STAGE + wm * 128 + roff;
-    const char* sb = smem + (c & 1) * STAGE + TM * 128 + wn * 128 + roff;
+  auto chunks = [&](auto rs_tag) {
+    constexpr bool RS = decltype(rs_tag)::value;
+    if (nc > 0) issue(0, 0);
+    for (int c = 0; c < nc; ++c) {
+      SDX_WAIT_VMCNT0();                                // this wave's pieces of chunk c have landed ...
+      __syncthreads();                                  // ... everybody's have, and everybody is done reading the other stage
+      if (c + 1 < nc) issue(c + 1, (c + 1) & 1);
+      const char* sa = smem + (c & 1) * STAGE + wm * 128 + roff;
+      const char* sb = smem + (c & 1) * STAGE + TM * 128 + wn * 128 + roff;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int off = off0 ^ (t << 5);
-      if constexpr (BF != 0) {
-        bf16x8 a[2], b[WTN];
+      for (int t = 0; t < 4; ++t) {
+        const int off = off0 ^ (t << 5);
+        if constexpr (BF != 0) {
+          bf16x8 a[2], b[WTN];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) a[u] = *reinterpret_cast<const bf16x8*>(sa + u * 4096 + off);
+          for (int u = 0; u < 2; ++u) a[u] = *reinterpret_cast<const bf16x8*>(sa + u * 4096 + off);
 #pragma unroll
-        for (int v = 0; v < WTN; ++v) b[v] = *reinterpret_cast<const bf16x8*>(sb + v * 4096 + off);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int v = 0; v < WTN; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[v], acc[u][v], 0, 0, 0);
-        if (EPI == EPI_TN && do_rs) {
-          bf16x8 one;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) one[i] = (__bf16)1.0f;
-#pragma unroll
-          for (int u = 0; u < 2; ++u) accb[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], one, accb[u], 0, 0, 0);
-        }
-      } else {
-        f32x4 a[2], b[WTN];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) a[u] = *reinterpret_cast<const f32x4*>(sa + u * 4096 + off);
-#pragma unroll
-        for (int v = 0; v < WTN; ++v) b[v] = *reinterpret_cast<const f32x4*>(sb + v * 4096 + off);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+          for (int v = 0; v < WTN; ++v) b[v] = *reinterpret_cast<const bf16x8*>(sb + v * 4096 + off);
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int v = 0; v < WTN; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], b[v][q], acc[u][v], 0, 0, 0);
-          if (EPI == EPI_TN && do_rs) {
+            for (int v = 0; v < WTN; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[v], acc[u][v], 0, 0, 0);
+          if constexpr (RS) {
+            bf16x8 one;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) accb[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], 1.0f, accb[u], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) one[i] = (__bf16)1.0f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) accb[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], one, accb[u], 0, 0, 0);
+          }
+        } else {
+          f32x4 a[2], b[WTN];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) a[u] = *reinterpret_cast<const f32x4*>(sa + u * 4096 + off);
+#pragma unroll
+          for (int v = 0; v < WTN; ++v) b[v] = *reinterpret_cast<const f32x4*>(sb + v * 4096 + off);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int v = 0; v < WTN; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], b[v][q], acc[u][v], 0, 0, 0);
+            if constexpr (RS) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) accb[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], 1.0f, accb[u], 0, 0, 0);
+            }
           }
         }
       }
     }
-  }
+  };
+  if (do_rs) chunks(std::true_type{}); else chunks(std::false_type{});   // (workgroup-uniform: every wave of a workgroup runs the same copy)
   // ---- epilogue.  C/D layout: lane l holds column (l & 31), rows (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 0..15, of each 32 x 32 block
   typedef typename std::conditional<BF != 0, __bf16, float>::type elem_t;
-  if (EPI == EPI_TN && do_rs && (lane & 31) == 0) {   // every column of A x ones is the row sum: lanes 0 and 32 hold all 32 rows
+  if (EPI == EPI_TN && do_rs && (wave & 1) == 0 && (lane & 31) == 0) {   // every column of A x ones is the row sum: lanes 0 and 32 of the waves at column 0 hold all rows
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -254,7 +264,8 @@ static void gemm_nt(const NtArgs* gs, int count, int splits, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt<BF, EPI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 192 * 128);
     attr = true;
   }
-  if (b2 >= 512) {
+  static const int forced = getenv("SDXP_NT_TILE") ? atoi(getenv("SDXP_NT_TILE")) : 0;   // 1: 128 x 64, 2: 128 x 128 (timing / diagnosis)
+  if (forced == 2 || (forced == 0 && b2 >= 512)) {
     dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, splits * count);
     hipLaunchKernelGGL((k_gemm_nt<BF, EPI, 2>), grid, dim3(256), 2 * 256 * 128, st, nb);
   } else {
