@@ -86,10 +86,15 @@ struct SdxBuf {
 #define SDX_READLANE(x, lane) __shfl((x), (lane), 64)
 #define SDX_UNIFORM(x) (x)
 #define SDX_WAIT_VMCNT0() ((void)0)
+#define SDX_LDS_BARRIER() __syncthreads()
 #define SDX_AS_GLOBAL(p) (p)
 #define SDX_AS_LDS(p) (p)
 #else
 #define SDX_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // this wave's outstanding global_load_lds pieces have landed
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)),
+// which turns an epilogue of [stores, barrier, stores, ...] into a chain of write round trips.  The asm statements are compiler fences for
+// memory accesses ("memory" clobber); s_waitcnt lgkmcnt(0) completes this wave's ds_write / ds_read before the others pass the barrier.
+#define SDX_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define SDX_AS_GLOBAL(p) ((const __attribute__((address_space(1))) void*)(p))
 #define SDX_AS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define SDX_OPAQUE(x) asm volatile("" : "+v"(x))

@@ -322,9 +322,11 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
       for (int net = 0; net < 3; ++net) {
         const int kp = ws->kp[net][l];
         const void* A = l == 0 ? (const void*)((const char*)ws->xn[xsel[net]] + r0 * kp * ES) : (const void*)ws->hn[net][l - 1];
-        g[net] = {A, l == 0 ? kp : D.units[l - 1], ws->wn[net][l], kp, MB, D.units[l], kp, kp, ws->h[net][l], D.units[l], 0,
+        // bf16 runs keep the outputs of layers 0 and 1 in bf16 only (both orientations): the next layer, the weight gradient and the
+        // ELU' of the backward pass read those; the last trunk layer stays fp32 for the fp32 heads
+        g[net] = {A, l == 0 ? kp : D.units[l - 1], ws->wn[net][l], kp, MB, D.units[l], kp, kp, (D.bf16 && l < 2) ? nullptr : ws->h[net][l], D.units[l], 0,
                   (D.bf16 && l < 2) ? ws->hn[net][l] : nullptr, D.units[l], l < 2 ? ws->ht[net][l] : nullptr, ws->MBp,
-                  P[net] + boff(net, l), nullptr, 0, nullptr};
+                  P[net] + boff(net, l), nullptr, 0, nullptr, 0, nullptr};
       }
       if (D.bf16) gemm_nt<1, EPI_FWD>(g, 3, 1, st); else gemm_nt<0, EPI_FWD>(g, 3, 1, st);
     }
@@ -387,7 +389,7 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
         float* part = ws->part + (size_t)net * region;
         const void* Xt = l == 0 ? (const void*)((const char*)ws->xt[xsel[net]] + r0 * ES) : (const void*)ws->ht[net][l - 1];
         gw[net] = {ws->dyt[net][l], ws->MBp, Xt, l == 0 ? ws->Rp : ws->MBp, Nl, Kl, ws->MBp, kc, part, Kl, pz, nullptr, 0, nullptr, 0,
-                   nullptr, nullptr, 0, part + (size_t)Nl * Kl};
+                   nullptr, nullptr, 0, nullptr, 0, part + (size_t)Nl * Kl};
         rb.part[net] = part; rb.pz[net] = pz; rb.n[net] = pz; rb.out[net] = G[net] + woff(net, l);
       }
       if (D.bf16) gemm_nt<1, EPI_TN>(gw, 3, S, st); else gemm_nt<0, EPI_TN>(gw, 3, S, st);   // G_l = dY_l^T X_l, b_l = row sums of dY_l^T
@@ -397,7 +399,7 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
         const int Kl = D.units[l - 1];
         for (int net = 0; net < 3; ++net)
           gx[net] = {ws->dyn[net][l], Nl, ws->wt[net][l], Nl, MB, Kl, Nl, Nl, nullptr, 0, 0, l - 1 >= 1 ? ws->dyn[net][l - 1] : nullptr, Kl,
-                     ws->dyt[net][l - 1], ws->MBp, nullptr, ws->h[net][l - 1], Kl, nullptr};
+                     ws->dyt[net][l - 1], ws->MBp, nullptr, ws->hn[net][l - 1], Kl, ws->ht[net][l - 1], ws->MBp, nullptr};
         if (D.bf16) gemm_nt<1, EPI_NN>(gx, 3, 1, st); else gemm_nt<0, EPI_NN>(gx, 3, 1, st);   // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
       }
     }

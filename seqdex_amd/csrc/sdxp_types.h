@@ -79,7 +79,7 @@ struct SdxpDev {
 
 // workspace of the large-minibatch update path (sdxp_bigmb.hip), allocated by sdxp_capi.hip
 struct SdxpBigWs {
-  float* h[3][3];             // trunk outputs  [MB][units[l]] (fp32: the heads and the ELU' of the backward pass read these)
+  float* h[3][3];             // trunk outputs  [MB][units[l]] in fp32 (the heads read l = 2; bf16 NT runs do not write l = 0, 1: see hn)
   float* dy[3][3];            // dLoss/d(pre-activation) [MB][units[l]] (NT path: only l = 2, written by the head kernels)
   float* mu;                  // [MB][24]
   float* dmu;                 // [MB][24]

@@ -7,9 +7,9 @@
 
 // one product: A [M][lda], B [N][ldb] in the element type (fp32 or bf16 bit patterns as uint16), K a multiple of the chunk
 extern "C" int emu_gemm_nt(int bf, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int kchunk, int splits,
-                           float* Cf, int ldc, long long cz, void* Cn, int ldn, void* Ct, int ldt, const float* bias, const float* H, int ldh,
-                           float* rowsum) {
-  NtArgs g = {A, lda, B, ldb, M, N, K, kchunk, Cf, ldc, (size_t)cz, Cn, ldn, Ct, ldt, bias, H, ldh, rowsum};
+                           float* Cf, int ldc, long long cz, void* Cn, int ldn, void* Ct, int ldt, const float* bias, const void* H, int ldh,
+                           const void* Ht, int ldht, float* rowsum) {
+  NtArgs g = {A, lda, B, ldb, M, N, K, kchunk, Cf, ldc, (size_t)cz, Cn, ldn, Ct, ldt, bias, H, ldh, Ht, ldht, rowsum};
   NtArgs gs[3] = {g, g, g};
   if (bf) {
     if (epi == EPI_FWD) gemm_nt<1, EPI_FWD>(gs, 1, splits, nullptr);
@@ -26,12 +26,12 @@ extern "C" int emu_gemm_nt(int bf, int epi, const void* A, int lda, const void* 
 extern "C" int emu_gemm_nt_narrow(int bf, const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* Cf, int ldc, void* Ct,
                                   int ldt, const float* bias) {
   NtBatch nb;
-  NtArgs g = {A, lda, B, ldb, M, N, K, K, Cf, ldc, 0, nullptr, 0, Ct, ldt, bias, nullptr, 0, nullptr};
+  NtArgs g = {A, lda, B, ldb, M, N, K, K, Cf, ldc, 0, nullptr, 0, Ct, ldt, bias, nullptr, 0, nullptr, 0, nullptr};
   nb.a[0] = nb.a[1] = nb.a[2] = g;
   nb.splits = 1;
-  dim3 grid((N + 63) / 64, (M + 127) / 128, 1);
-  if (bf) hipLaunchKernelGGL((k_gemm_nt<1, EPI_FWD, 1>), grid, dim3(256), 2 * 192 * 128, nullptr, nb);
-  else hipLaunchKernelGGL((k_gemm_nt<0, EPI_FWD, 1>), grid, dim3(256), 2 * 192 * 128, nullptr, nb);
+  const int nx = (N + 63) / 64, ny = (M + 127) / 128;
+  if (bf) hipLaunchKernelGGL((k_gemm_nt<1, EPI_FWD, 1>), dim3(nx * ny), dim3(256), 2 * 192 * 128, nullptr, nb, nx, ny);
+  else hipLaunchKernelGGL((k_gemm_nt<0, EPI_FWD, 1>), dim3(nx * ny), dim3(256), 2 * 192 * 128, nullptr, nb, nx, ny);
   return 0;
 }
 extern "C" int emu_stage(int bf, const float* src, int lds, int R, int K, int Kp, void* dn, int ldn, void* dt, int ldt) {
@@ -41,5 +41,20 @@ extern "C" int emu_stage(int bf, const float* src, int lds, int R, int K, int Kp
   dim3 grid((Kp + 63) / 64, (R + 63) / 64, 1);
   if (bf) hipLaunchKernelGGL((k_stage<1>), grid, dim3(256), 0, nullptr, sb);
   else hipLaunchKernelGGL((k_stage<0>), grid, dim3(256), 0, nullptr, sb);
+  return 0;
+}
+
+// the 128 x 128 tile shape forced (the launcher only picks it for grids of 512 workgroups and more): forward or data-gradient product
+extern "C" int emu_gemm_nt_wide(int bf, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* Cf, int ldc, void* Cn,
+                                int ldn, void* Ct, int ldt, const float* bias, const void* H, int ldh, const void* Ht, int ldht) {
+  NtBatch nb;
+  NtArgs g = {A, lda, B, ldb, M, N, K, K, Cf, ldc, 0, Cn, ldn, Ct, ldt, bias, H, ldh, Ht, ldht, nullptr};
+  nb.a[0] = nb.a[1] = nb.a[2] = g;
+  nb.splits = 1;
+  const int nx = (N + 127) / 128, ny = (M + 127) / 128;
+  if (bf && epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt<1, EPI_FWD, 2>), dim3(nx * ny), dim3(256), 2 * 256 * 128, nullptr, nb, nx, ny);
+  else if (bf) hipLaunchKernelGGL((k_gemm_nt<1, EPI_NN, 2>), dim3(nx * ny), dim3(256), 2 * 256 * 128, nullptr, nb, nx, ny);
+  else if (epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt<0, EPI_FWD, 2>), dim3(nx * ny), dim3(256), 2 * 256 * 128, nullptr, nb, nx, ny);
+  else hipLaunchKernelGGL((k_gemm_nt<0, EPI_NN, 2>), dim3(nx * ny), dim3(256), 2 * 256 * 128, nullptr, nb, nx, ny);
   return 0;
 }

@@ -22,9 +22,10 @@ def lib():
     from tests import hipemu
     l = C.CDLL(hipemu.build_gemm())
     vp, i, fp = C.c_void_p, C.c_int, C.c_void_p
-    l.emu_gemm_nt.argtypes = [i, i, vp, i, vp, i, i, i, i, i, i, fp, i, C.c_longlong, vp, i, vp, i, fp, fp, i, fp]
+    l.emu_gemm_nt.argtypes = [i, i, vp, i, vp, i, i, i, i, i, i, fp, i, C.c_longlong, vp, i, vp, i, fp, vp, i, vp, i, fp]
     l.emu_gemm_nt_narrow.argtypes = [i, vp, i, vp, i, i, i, i, fp, i, vp, i, fp]
     l.emu_stage.argtypes = [i, fp, i, i, i, i, vp, i, vp, i]
+    l.emu_gemm_nt_wide.argtypes = [i, i, vp, i, vp, i, i, i, i, fp, i, vp, i, vp, i, fp, vp, i, vp, i]
     return l
 
 
@@ -64,7 +65,7 @@ def test_forward_product_all_outputs(lib, bf, M, N, K):
     Cf = np.full((M, N), np.nan, np.float32)
     Cn = np.zeros((M, N), np.int16 if bf else np.float32)
     Ct = np.zeros((N, Mp), np.int16 if bf else np.float32)
-    lib.emu_gemm_nt(bf, EPI_FWD, _p(A), K, _p(B), K, M, N, K, K, 1, _p(Cf), N, 0, _p(Cn), N, _p(Ct), Mp, _p(bias), None, 0, None)
+    lib.emu_gemm_nt(bf, EPI_FWD, _p(A), K, _p(B), K, M, N, K, K, 1, _p(Cf), N, 0, _p(Cn), N, _p(Ct), Mp, _p(bias), None, 0, None, 0, None)
     want = elu(Av @ Bv.T + bias)
     np.testing.assert_allclose(Cf, want, rtol=1e-5, atol=2e-5)      # (bf16: the operands ARE bf16 values, products exact, fp32 accumulation)
     got_n, got_t = _from_elems(Cn, bf), _from_elems(Ct, bf)
@@ -88,18 +89,45 @@ def test_narrow_tile_shape(lib, bf):
 
 
 @pytest.mark.parametrize("bf", [0, 1])
+@pytest.mark.parametrize("epi", [EPI_FWD, EPI_NN])
+def test_wide_tile_shape_all_copies(lib, bf, epi):
+    """the 128 x 128 tile: two passes of the transposed epilogue (64 columns each), 19 workgroups through the XCD remap, ragged edges"""
+    rng = np.random.default_rng(17 + bf + epi)
+    M, N, K = 270, 300, 128
+    A, Av = _elems(rng.standard_normal((M, K)) * 0.4, bf)
+    B, Bv = _elems(rng.standard_normal((N, K)) * 0.4, bf)
+    bias = rng.standard_normal(N).astype(np.float32)
+    H, Hv = _elems(rng.standard_normal((M, N)), bf)
+    Mp = 320
+    Ht = np.zeros((N, Mp), H.dtype); Ht[:, :M] = H.T                         # the layer output's transposed copy, as the forward product leaves it
+    Cf = np.full((M, N), np.nan, np.float32)
+    Cn = np.zeros((M, N + 4), np.int16 if bf else np.float32)               # a row stride that is not a multiple of 8: scalar stores
+    Ct = np.zeros((N, Mp), np.int16 if bf else np.float32)
+    lib.emu_gemm_nt_wide(bf, epi, _p(A), K, _p(B), K, M, N, K, _p(Cf) if epi == EPI_FWD else None, N, _p(Cn), N + 4, _p(Ct), Mp,
+                         _p(bias), _p(H), N, _p(Ht), Mp)
+    want = elu(Av @ Bv.T + bias) if epi == EPI_FWD else (Av @ Bv.T) * np.where(Hv > 0, 1.0, Hv + 1.0)
+    if epi == EPI_FWD:
+        np.testing.assert_allclose(Cf, want, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(_from_elems(Cn, bf)[:, :N], want, rtol=8e-3 if bf else 1e-5, atol=1e-3 if bf else 2e-5)
+    assert not _from_elems(Cn, bf)[:, N:].any()
+    np.testing.assert_array_equal(_from_elems(Ct, bf)[:, :M], _from_elems(Cn, bf)[:, :N].T)
+    assert not _from_elems(Ct, bf)[:, M:].any()
+
+
+@pytest.mark.parametrize("bf", [0, 1])
 def test_data_gradient_product(lib, bf):
     """dX = (dY W) * ELU'(H): A = dY [M][Nl], B = W^T [Kl][Nl]; outputs: element copy + transposed copy, no fp32 array"""
     rng = np.random.default_rng(7)
     M, Nl, Kl = 160, 128, 200
     A, Av = _elems(rng.standard_normal((M, Nl)) * 0.3, bf)
     B, Bv = _elems(rng.standard_normal((Kl, Nl)) * 0.3, bf)
-    H = rng.standard_normal((M, Kl)).astype(np.float32)
+    H, Hv = _elems(rng.standard_normal((M, Kl)), bf)         # the layer output in the element type of the run
     Mp = 192
+    Ht = np.zeros((Kl, Mp), H.dtype); Ht[:, :M] = H.T
     Cn = np.zeros((M, Kl), np.int16 if bf else np.float32)
     Ct = np.zeros((Kl, Mp), np.int16 if bf else np.float32)
-    lib.emu_gemm_nt(bf, EPI_NN, _p(A), Nl, _p(B), Nl, M, Kl, Nl, Nl, 1, None, 0, 0, _p(Cn), Kl, _p(Ct), Mp, None, _p(H), Kl, None)
-    want = (Av @ Bv.T) * np.where(H > 0, 1.0, H.astype(np.float64) + 1.0)
+    lib.emu_gemm_nt(bf, EPI_NN, _p(A), Nl, _p(B), Nl, M, Kl, Nl, Nl, 1, None, 0, 0, _p(Cn), Kl, _p(Ct), Mp, None, _p(H), Kl, _p(Ht), Mp, None)
+    want = (Av @ Bv.T) * np.where(Hv > 0, 1.0, Hv + 1.0)
     np.testing.assert_allclose(_from_elems(Cn, bf), want, rtol=8e-3 if bf else 1e-5, atol=1e-3 if bf else 2e-5)
     np.testing.assert_array_equal(_from_elems(Ct, bf)[:, :M], _from_elems(Cn, bf).T)
     assert not _from_elems(Ct, bf)[:, M:].any()
@@ -122,7 +150,7 @@ def test_weight_gradient_product_with_row_sums(lib, bf, splits):
     kc = ((MBp + splits - 1) // splits + KC - 1) // KC * KC
     pz = Nl * Kl + Nl
     part = np.full((splits, pz), np.nan, np.float32)
-    lib.emu_gemm_nt(bf, EPI_TN, _p(A), MBp, _p(B), ldb, Nl, Kl, MBp, kc, splits, _p(part), Kl, pz, None, 0, None, 0, None, None, 0,
+    lib.emu_gemm_nt(bf, EPI_TN, _p(A), MBp, _p(B), ldb, Nl, Kl, MBp, kc, splits, _p(part), Kl, pz, None, 0, None, 0, None, None, 0, None, 0,
                     C.c_void_p(part.ctypes.data + 4 * Nl * Kl))
     assert np.isfinite(part).all()
     tot = part.astype(np.float64).sum(0)

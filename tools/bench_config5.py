@@ -10,8 +10,10 @@ The 8-GPU form of configs[4] cannot be run here (gpurun boxes have one GPU; no 8
 one GPU, so this is the whole loop at its full env count on 1/8 of the hardware.
 
 Stage lengths: an episode is 75 / 75 / 150 / 125 env steps, i.e. 10 / 10 / 19 / 16 epochs of horizon 8; shorter runs finish no episode,
-harvest nothing and log no T-value outcome, so the defaults are search 20, orient 10, grasp 20 epochs; InsertSim (GEMM-shaped update: 57 ms
-per epoch) trains 300 epochs forward so that its backward leg logs successful insertions for the first transition-value fit.  What is a
+harvest nothing and log no T-value outcome, so the defaults are search 20, orient 10, grasp 20, insert 48 (+ 32 backward) epochs.  A
+transition-value refit needs more than 100 successful and at least one failed outcome (the trainer holds out 100 success rows): legs whose
+few-epoch policy logged only one class are skipped and say so with their counts (InsertSim: no insertion yet; Orient: every episode passes
+the lowered gate); the grasp leg's fit runs on the stand-in's outcomes.  What is a
 stand-in and says so in the JSON: (1) in the first forward pass no transition value has been fitted yet (as in the reference, whose first
 transition_value_trainer call comes after it), so the harvest gates are opened (0.0) and the physical criteria alone decide; once a value
 exists the gates are 0.5 / 0.28, the chain benchmark's (a value fitted to a few hundred epochs of outcomes does not reach the reference's
@@ -31,9 +33,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# forward InsertSim trains long enough to insert at all (its update is GEMM-shaped: 300 epochs take 17 s) - the first transition-value fit
-# needs more than 100 successful insertions from the backward leg that follows
-DEFAULT_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 300, "insert_backward": 32}
+# (InsertSim's update is GEMM-shaped - 50 ms per epoch at 4096 envs - so three episodes cost 2.5 s; an insert policy of that age inserts
+# nothing yet, and 300 epochs from scripted-grasp states gave 10 insertions in 1.2 M episodes: the first refit is skipped, with its reason)
+DEFAULT_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 48, "insert_backward": 32}
 
 
 def run(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=300, workdir=None):

@@ -32,7 +32,7 @@ for bf in (0, 1):
         kc = ((K + S - 1) // S + KC - 1) // KC * KC
         pz = M * N + M
         part = torch.full((S, pz), float("nan"), device=dev)
-        a = NtArgs(A.data_ptr(), K, B.data_ptr(), K, M, N, K, kc, part.data_ptr(), N, pz, None, 0, None, 0, None, None, 0, part.data_ptr() + 4 * M * N)
+        a = NtArgs(A.data_ptr(), K, B.data_ptr(), K, M, N, K, kc, part.data_ptr(), N, pz, None, 0, None, 0, None, None, 0, None, 0, part.data_ptr() + 4 * M * N)
         arr = (NtArgs * 3)(a, a, a)
         assert lib.sdxpk_gemm_nt_launch(bf, EPI_TN, arr, 1, S, None) == 0
         torch.cuda.synchronize()
@@ -50,7 +50,7 @@ for bf in (0, 1):
     for (M, N, K) in ((8192, 256, 512), (64, 128, 64), (300, 100, 96 if not bf else 128)):
         A = rnd(M, K).to(dt).contiguous(); B = (rnd(N, K) / K ** 0.5).to(dt).contiguous(); bias = rnd(N)
         Cf = torch.full((M, N), float("nan"), device=dev); Ct = torch.zeros(N, (M + 63) // 64 * 64, device=dev, dtype=dt)
-        a = NtArgs(A.data_ptr(), K, B.data_ptr(), K, M, N, K, K, Cf.data_ptr(), N, 0, None, 0, Ct.data_ptr(), Ct.shape[1], bias.data_ptr(), None, 0, None)
+        a = NtArgs(A.data_ptr(), K, B.data_ptr(), K, M, N, K, K, Cf.data_ptr(), N, 0, None, 0, Ct.data_ptr(), Ct.shape[1], bias.data_ptr(), None, 0, None, 0, None)
         arr = (NtArgs * 3)(a, a, a)
         assert lib.sdxpk_gemm_nt_launch(bf, EPI_FWD, arr, 1, 1, None) == 0
         torch.cuda.synchronize()
