@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtBatch nb, int nx, int ny) 
                 hm[p][0] = h0.x; hm[p][1] = h0.y; hm[p][2] = h0.z; hm[p][3] = h0.w; hm[p][4] = h1.x; hm[p][5] = h1.y; hm[p][6] = h1.z; hm[p][7] = h1.w;
               }
             } else {
-              for (int e = 0; e < 8 && col + e < g.N; ++e) hm[p][e] = (float)hp[e];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (col + e < g.N) hm[p][e] = (float)hp[e];
             }
           }
         }
@@ -284,7 +285,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtBatch nb, int nx, int ny) 
           if (Cf) {
             float* d = Cf + (size_t)row * g.ldc + col;
             if ((g.ldc & 3) == 0) { *reinterpret_cast<float4*>(d) = make_float4(xs[0], xs[1], xs[2], xs[3]); *reinterpret_cast<float4*>(d + 4) = make_float4(xs[4], xs[5], xs[6], xs[7]); }
-            else { for (int e = 0; e < 8; ++e) d[e] = xs[e]; }
+            else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) d[e] = xs[e];
+            }
           }
           if (Cn) {
             elem_t* d = Cn + (size_t)row * g.ldn + col;
@@ -294,17 +298,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtBatch nb, int nx, int ny) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) p8[e] = (__bf16)xs[e];
                 *reinterpret_cast<bf16x8*>(d) = p8;
-              } else { for (int e = 0; e < 8; ++e) d[e] = (elem_t)xs[e]; }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = (elem_t)xs[e];
+              }
             } else {
               if ((g.ldn & 3) == 0) { *reinterpret_cast<float4*>(d) = make_float4(xs[0], xs[1], xs[2], xs[3]); *reinterpret_cast<float4*>(d + 4) = make_float4(xs[4], xs[5], xs[6], xs[7]); }
-              else { for (int e = 0; e < 8; ++e) d[e] = xs[e]; }
+              else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = xs[e];
+              }
             }
           }
         } else {
-          for (int e = 0; e < 8 && col + e < g.N; ++e) {
-            if (Cf) Cf[(size_t)row * g.ldc + col + e] = xs[e];
-            if (Cn) Cn[(size_t)row * g.ldn + col + e] = (elem_t)xs[e];
-          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (col + e < g.N) {
+              if (Cf) Cf[(size_t)row * g.ldc + col + e] = xs[e];
+              if (Cn) Cn[(size_t)row * g.ldn + col + e] = (elem_t)xs[e];
+            }
         }
       }
       if (Ct) SDX_LDS_BARRIER();                     // the transposed image reuses the same LDS
@@ -352,7 +364,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtBatch nb, int nx, int ny) 
                   ht[it][0] = h4.x; ht[it][1] = h4.y; ht[it][2] = h4.z; ht[it][3] = h4.w;
                 }
               } else {
-                for (int e = 0; e < EPP && row + e < g.M; ++e) ht[it][e] = (float)hp[e];
+#pragma unroll
+                for (int e = 0; e < EPP; ++e) if (row + e < g.M) ht[it][e] = (float)hp[e];
               }
             }
           }
@@ -384,7 +397,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtBatch nb, int nx, int ny) 
               *reinterpret_cast<float4*>(d) = make_float4(xs[0], xs[1], xs[2], xs[3]);
             }
           } else {
-            for (int e = 0; e < EPP && row + e < g.M; ++e) d[e] = (elem_t)xs[e];
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) if (row + e < g.M) d[e] = (elem_t)xs[e];
           }
         }
         if (pass + 1 < WTN) SDX_LDS_BARRIER();
