@@ -99,10 +99,50 @@ struct PLds {
 // tags only grow, and the data dependencies of the step (x1 -> x2 -> x3 -> dY1 -> dY0 -> next x1) guarantee that a word is not
 // overwritten before every CU has consumed it ("persistent update kernel").
 typedef unsigned long long u64;
-constexpr size_t LL_X1 = 0, LL_X2 = LL_X1 + 3 * MB * U0, LL_X3 = LL_X2 + 3 * MB * U1, LL_DY1 = LL_X3 + 3 * MB * U2,
-                 LL_DY0 = LL_DY1 + 3 * MB * U1, LL_HW = LL_DY0 + 3 * MB * U0, LL_G0 = LL_HW + (ACT + 2) * U2,
-                 LL_END = LL_G0 + 32 * NWG;   // LL_G0: [30 Gram entries (net, lower triangle)][CU]: every CU's share of dY0 dY0^T
+// Round 4: the five edges on the step's dependency chain (x1, x2, x3, dY1 and the dY0 Gram) travel as 16-BYTE words (v0, v1, v2, tag):
+// the same (sample, unit) of the THREE networks in one word, written and read by one dwordx4 access per lane (device scope, sc1).  The
+// all-gather alone, measured (tools/bench_exchange.py, profiles/r4_exchange_edge_floor.txt): x1 (12 288 floats) 6.0 us as 8-byte
+// words, 3.6 us packed; x2 / dY1 3.3 -> 2.1; the Gram 4.7 -> 2.5; x3 (3 072 floats) 2.0 either way; no torn word in ~1e10 checked
+// gathers (a 16-byte access of one lane is not architecturally single-copy atomic: the tag sits in the LAST dword, and the benchmark
+// verifies every payload against its tag; RCCL's LL128 protocol relies on the same hardware behaviour).  The head matrix (LL_HW:
+// published a phase ahead, gathered row- and column-wise by different consumers) keeps its 8-byte words.
+// Layout of D.ll: 16-byte words LQ_* first, then the 8-byte head words at LL_HW (u64 index).
+constexpr unsigned LQ_X1 = 0, LQ_X2 = LQ_X1 + MB * U0, LQ_X3 = LQ_X2 + MB * U1, LQ_DY1 = LQ_X3 + MB * U2, LQ_DY0 = LQ_DY1 + MB * U1,
+                   LQ_G0 = LQ_DY0 + MB * U0, LQ_END = LQ_G0 + 16 * NWG;   // LQ_G0: [10 Gram entries (lower triangle)][CU], the 3 nets per word
+constexpr size_t LL_HW = 2 * (size_t)LQ_END, LL_END = LL_HW + (ACT + 2) * U2;
 static_assert(LL_END <= SDXP_LL_WORDS, "exchange buffer too small");
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lq_rsrc(void* ll) { return __builtin_amdgcn_make_buffer_rsrc(ll, 0, SDXP_LL_WORDS * 8, 0x00020000); }
+__device__ __forceinline__ void lq_store(__amdgpu_buffer_rsrc_t q, unsigned idx, float a, float b, float c, unsigned tag) {
+  u32x4 w;
+  w.x = __float_as_uint(a); w.y = __float_as_uint(b); w.z = __float_as_uint(c); w.w = tag;
+  __builtin_amdgcn_raw_buffer_store_b128(w, q, idx * 16u, 0, 16);   // buffer_store_dwordx4 ... sc1
+}
+// gather N packed words idx0 + i * stride carrying `tag` -> the three networks' values; wave-uniform retry as ll_gather
+template <int N>
+__device__ __forceinline__ bool lq_gather(__amdgpu_buffer_rsrc_t q, unsigned idx0, unsigned stride, unsigned tag, float (&o0)[N], float (&o1)[N], float (&o2)[N],
+                                          unsigned* failflag) {
+  unsigned spins = 0;
+  for (;;) {
+    u32x4 w[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(q, (idx0 + i * stride) * 16u, 0, 16);   // buffer_load_dwordx4 ... sc1
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ok = ok && w[i].w == tag;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { o0[i] = __uint_as_float(w[i].x); o1[i] = __uint_as_float(w[i].y); o2[i] = __uint_as_float(w[i].z); }
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 255u) == 0) {
+      const unsigned f = __hip_atomic_load(failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spins > (1u << 20) || __builtin_amdgcn_readfirstlane(f) != 0) {
+        __hip_atomic_store(failflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
 __device__ __forceinline__ void ll_store(u64* p, float v, unsigned tag) {
   __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -225,7 +265,8 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
   if (tid == 0) S.fail = 0;
   if (tid == 0) S.tlast = __builtin_amdgcn_s_memtime();
   const int A = ACT;
-  u64* const LL = D.ll;   // exchange words, layout LL_*: [net][s][unit] per activation / gradient, then the head matrix
+  u64* const LL = D.ll;   // 8-byte exchange words of the head matrix (LL_HW)
+  const __amdgpu_buffer_rsrc_t LQ = lq_rsrc(D.ll);   // 16-byte packed words of the chain edges, layout LQ_*: [s][unit], the three networks per word
 
   // ------------------------------------------------------------------ resident parameters
   // layer 0 rows: row n0 = 4g + (wave>>1), half h0 = wave&1 of K; net 0/1: K = OBS, net 2: K = ST
@@ -359,20 +400,27 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       // squared-norm Gram of dY0: every CU published the 4x4 Gram of ITS four columns per net (30 numbers) at the end of the
       // previous step; thread (entry v, lane c16 of its 16-lane row) adds the shares of CUs c16, c16 + 16, ..., a DPP row reduction does the rest
       {
-        const int v = tid >> 4, c16 = tid & 15;
-        float t = 0.0f;
-        if (v < 30) {
-          float w[16];
-          // lane c16 takes CUs c16, c16 + 16, ...: the 16 lanes of a row read 16 consecutive words per load (coalesced)
-          if (!ll_gather<16>(LL + LL_G0 + (size_t)v * NWG + c16, 16, tag_prev, w, failflag)) S.fail = 1;
+        // thread (entry e = tid / 32 of the lower triangle, lane c32 of its half-wave): the three networks' shares of CUs c32, c32 + 32, ...;
+        // every CU adds the same numbers in the same order, so the replicated control state stays bit-identical across CUs
+        const int e = tid >> 5, c32 = tid & 31;
+        float t[3] = {0.0f, 0.0f, 0.0f};
+        if (e < 10) {
+          float w0[8], w1[8], w2[8];
+          if (!lq_gather<8>(LQ, LQ_G0 + (unsigned)e * NWG + c32, 32, tag_prev, w0, w1, w2, failflag)) S.fail = 1;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) t += w[j];
+          for (int j = 0; j < 8; ++j) { t[0] += w0[j]; t[1] += w1[j]; t[2] += w2[j]; }
         }
-        t = dpp_add<0xB1, 0xF>(t); t = dpp_add<0x4E, 0xF>(t); t = dpp_add<0x141, 0xF>(t); t = dpp_add<0x140, 0xF>(t);   // 16-lane row sums
-        if (v < 30 && c16 == 0) {
-          const int net = v / 10, e = v % 10;                     // e = hi (hi + 1) / 2 + lo
+#pragma unroll
+        for (int net = 0; net < 3; ++net) {
+          float x = t[net];
+          x = dpp_add<0xB1, 0xF>(x); x = dpp_add<0x4E, 0xF>(x); x = dpp_add<0x141, 0xF>(x); x = dpp_add<0x140, 0xF>(x);   // 16-lane row sums
+          x = dpp_add<0x142, 0xA>(x);                                                                                       // + the other row of the half-wave (valid in lanes 16..31, 48..63)
+          t[net] = x;
+        }
+        if (e < 10 && c32 == 31) {                                 // e = hi (hi + 1) / 2 + lo
           const int hi = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), lo = e - hi * (hi + 1) / 2;
-          S.gd[net][0][hi * 4 + lo] = t; S.gd[net][0][lo * 4 + hi] = t;
+#pragma unroll
+          for (int net = 0; net < 3; ++net) { S.gd[net][0][hi * 4 + lo] = t[net]; S.gd[net][0][lo * 4 + hi] = t[net]; }
         }
         __syncthreads();
       }
@@ -483,10 +531,13 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         for (int s = 0; s < MB; ++s) { S.fpart[(0 * MB + s) * NWV + wave] = pa[s]; S.fpart[(1 * MB + s) * NWV + wave] = pc[s]; S.fpart[(2 * MB + s) * NWV + wave] = pv[s]; }
       }
       __syncthreads();
-      if (tid < 3 * MB * 4) {
-        const int net = tid / (MB * 4), s = (tid / 4) % MB, r = tid % 4;
-        const float y = S.fpart[(net * MB + s) * NWV + 2 * r] + S.fpart[(net * MB + s) * NWV + 2 * r + 1] + S.bias[net * 4 + r];
-        ll_store(LL + LL_X1 + (size_t)(net * MB + s) * U0 + 4 * g + r, elu(y), tag);
+      if (tid < MB * 4) {   // (sample s, owned row r): the three networks' outputs in one packed word
+        const int s = tid / 4, r = tid % 4;
+        float y[3];
+#pragma unroll
+        for (int net = 0; net < 3; ++net)
+          y[net] = elu(S.fpart[(net * MB + s) * NWV + 2 * r] + S.fpart[(net * MB + s) * NWV + 2 * r + 1] + S.bias[net * 4 + r]);
+        lq_store(LQ, LQ_X1 + (unsigned)s * U0 + 4 * g + r, y[0], y[1], y[2], tag);
       }
       TS(2)
       if constexpr (!SINGLE) {
@@ -545,13 +596,11 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     if (!last) {
       __syncthreads();   // every wave is done with the old S.x1
       // ================================================================== phase B: gather x1, forward L1
+      {
+        float v0[8], v1[8], v2[8];   // word tid + NTH j = (sample, unit) s U0 + unit: S.x1[net] is [MB][U0], i.e. the same flat index
+        if (!lq_gather<8>(LQ, LQ_X1 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float v[12];
-        const int i0 = tid + NTH * 12 * h;
-        if (!ll_gather<12>(LL + LL_X1 + i0, NTH, tag, v, failflag)) S.fail = 1;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) (&S.x1[0][0][0])[i0 + NTH * j] = v[j];
+        for (int j = 0; j < 8; ++j) { (&S.x1[0][0][0])[tid + NTH * j] = v0[j]; (&S.x1[1][0][0])[tid + NTH * j] = v1[j]; (&S.x1[2][0][0])[tid + NTH * j] = v2[j]; }
       }
       TS(4)
       __syncthreads();
@@ -580,10 +629,15 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         }
       }
       __syncthreads();
-      if (tid < 3 * MB * 2) {
-        const int net = tid / (MB * 2), s = (tid / 2) % MB, r = tid % 2;
-        const float* q = &S.fpart[(net * MB + s) * NWV + 4 * r];
-        ll_store(LL + LL_X2 + (size_t)(net * MB + s) * U1 + 2 * g + r, elu(q[0] + q[1] + q[2] + q[3] + S.bias[12 + net * 2 + r]), tag);
+      if (tid < MB * 2) {
+        const int s = tid / 2, r = tid % 2;
+        float y[3];
+#pragma unroll
+        for (int net = 0; net < 3; ++net) {
+          const float* q = &S.fpart[(net * MB + s) * NWV + 4 * r];
+          y[net] = elu(q[0] + q[1] + q[2] + q[3] + S.bias[12 + net * 2 + r]);
+        }
+        lq_store(LQ, LQ_X2 + (unsigned)s * U1 + 2 * g + r, y[0], y[1], y[2], tag);
       }
       TS(5)
       if constexpr (!SINGLE) {
@@ -670,10 +724,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       pf_osg = __hip_atomic_load(&D.mb_sigmas[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     {
-      float v[12];
-      if (!ll_gather<12>(LL + LL_X2 + tid, NTH, tag, v, failflag)) S.fail = 1;
+      float v0[4], v1[4], v2[4];
+      if (!lq_gather<4>(LQ, LQ_X2 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) (&S.x2[0][0][0])[tid + NTH * j] = v[j];
+      for (int j = 0; j < 4; ++j) { (&S.x2[0][0][0])[tid + NTH * j] = v0[j]; (&S.x2[1][0][0])[tid + NTH * j] = v1[j]; (&S.x2[2][0][0])[tid + NTH * j] = v2[j]; }
     }
     TS(7)
     __syncthreads();
@@ -696,13 +750,18 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
     }
     __syncthreads();
-    if (tid < 3 * MB) {
-      const int net = tid / MB, s = tid % MB;
-      const float* q = &S.fpart[(net * MB + s) * NWV];
-      float y = S.bias[18 + net];
+    if (tid < MB) {
+      const int s = tid;
+      float y[3];
 #pragma unroll
-      for (int w = 0; w < NWV; ++w) y += q[w];
-      ll_store(LL + LL_X3 + (size_t)(net * MB + s) * U2 + g, elu(y), tag);
+      for (int net = 0; net < 3; ++net) {
+        const float* q = &S.fpart[(net * MB + s) * NWV];
+        float t = S.bias[18 + net];
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t += q[w];
+        y[net] = elu(t);
+      }
+      lq_store(LQ, LQ_X3 + (unsigned)s * U2 + g, y[0], y[1], y[2], tag);
     }
     TS(8)
     if constexpr (!SINGLE)
@@ -749,10 +808,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       for (int j = 0; j < 12; ++j) wc[j] = t[j];
     }
     {
-      float v[6];
-      if (!ll_gather<6>(LL + LL_X3 + tid, NTH, tag, v, failflag)) S.fail = 1;
+      float v0[2], v1[2], v2[2];
+      if (!lq_gather<2>(LQ, LQ_X3 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) (&S.x3[0][0][0])[tid + NTH * j] = v[j];
+      for (int j = 0; j < 2; ++j) { (&S.x3[0][0][0])[tid + NTH * j] = v0[j]; (&S.x3[1][0][0])[tid + NTH * j] = v1[j]; (&S.x3[2][0][0])[tid + NTH * j] = v2[j]; }
     }
     TS(10)
     __syncthreads();
@@ -926,11 +985,15 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
           p[(net * MB + s) * 2 + 1] = c2c == 1 ? v : 0.0f;
         }
       block_sum<24>(S, p, S.part, tid, wave, lane);
-      if (tid < 24) {
-        const int net = tid / 8, s = (tid / 2) % MB, c = tid % 2;
-        const float v = S.part[tid] * elu_g(S.x2[net][s][2 * g + c]);
-        ll_store(LL + LL_DY1 + (size_t)(net * MB + s) * U1 + 2 * g + c, v, tag);
-        S.dyown[net][s][4 + c] = v;
+      if (tid < MB * 2) {   // S.part: [(net MB + s) 2 + c]
+        const int s = tid / 2, c = tid % 2;
+        float v[3];
+#pragma unroll
+        for (int net = 0; net < 3; ++net) {
+          v[net] = S.part[(net * MB + s) * 2 + c] * elu_g(S.x2[net][s][2 * g + c]);
+          S.dyown[net][s][4 + c] = v[net];
+        }
+        lq_store(LQ, LQ_DY1 + (unsigned)s * U1 + 2 * g + c, v[0], v[1], v[2], tag);
       }
     }
     TS(14)
@@ -992,10 +1055,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     refresh();
     // ================================================================== phase E: gather dY1, backward L1
     {
-      float v[12];
-      if (!ll_gather<12>(LL + LL_DY1 + tid, NTH, tag, v, failflag)) S.fail = 1;
+      float v0[4], v1[4], v2[4];
+      if (!lq_gather<4>(LQ, LQ_DY1 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) (&S.dy1[0][0][0])[tid + NTH * j] = v[j];
+      for (int j = 0; j < 4; ++j) { (&S.dy1[0][0][0])[tid + NTH * j] = v0[j]; (&S.dy1[1][0][0])[tid + NTH * j] = v1[j]; (&S.dy1[2][0][0])[tid + NTH * j] = v2[j]; }
     }
     TS(16)
     __syncthreads();
@@ -1010,25 +1073,34 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
           for (int c = 0; c < 4; ++c) p[(net * MB + s) * 4 + c] = d * c1[net][c];
         }
       block_sum<48>(S, p, S.part, tid, wave, lane);
-      if (tid < 48) {
-        const int net = tid / 16, s = (tid / 4) % MB, c = tid % 4;
-        const float v = S.part[tid] * elu_g(S.x1[net][s][4 * g + c]);
-        if constexpr (SINGLE) ll_store(LL + LL_DY0 + (size_t)(net * MB + s) * U0 + 4 * g + c, v, tag);
-        S.dyown[net][s][c] = v;
+      if (tid < MB * 4) {   // S.part: [(net MB + s) 4 + c]
+        const int s = tid / 4, c = tid % 4;
+        float v[3];
+#pragma unroll
+        for (int net = 0; net < 3; ++net) {
+          v[net] = S.part[(net * MB + s) * 4 + c] * elu_g(S.x1[net][s][4 * g + c]);
+          S.dyown[net][s][c] = v[net];
+        }
+        if constexpr (SINGLE) lq_store(LQ, LQ_DY0 + (unsigned)s * U0 + 4 * g + c, v[0], v[1], v[2], tag);
       }
       if constexpr (!SINGLE) {
         // the other CUs need dY0 only for the gradient norm: publish this CU's share of the Gram dY0 dY0^T (its four columns).
-        // Lanes 0..47 of wave 0 wrote dyown above; the same wave reads it back (LDS keeps program order within a wave)
+        // Lanes 0..15 of wave 0 wrote dyown above; the same wave reads it back (LDS keeps program order within a wave)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tid < 30) {
-          const int net = tid / 10, e = tid % 10;
+        if (tid < 10) {
+          const int e = tid;
           const int hi = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), lo = e - hi * (hi + 1) / 2;
-          float gsum = 0.0f;
+          float gsum[3];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) gsum += S.dyown[net][hi][c] * S.dyown[net][lo][c];
-          ll_store(LL + LL_G0 + (size_t)tid * NWG + g, gsum, tag);
+          for (int net = 0; net < 3; ++net) {
+            float t = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t += S.dyown[net][hi][c] * S.dyown[net][lo][c];
+            gsum[net] = t;
+          }
+          lq_store(LQ, LQ_G0 + (unsigned)e * NWG + g, gsum[0], gsum[1], gsum[2], tag);
         }
       }
     }
@@ -1049,10 +1121,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         for (int j = i; j < MB * U1; j += stride) { F[D.foff.x[net][2] + j] = (&S.x2[net][0][0])[j]; F[D.foff.dy[net][1] + j] = (&S.dy1[net][0][0])[j]; }
         for (int j = i; j < MB * U2; j += stride) { F[D.foff.h[net] + j] = (&S.x3[net][0][0])[j]; F[D.foff.dy[net][2] + j] = (&S.dy2[net][0][0])[j]; }
       }
-      if (i < 3 * MB * U0) {   // dY0: every CU produced four columns of it; the first 24 CUs collect the words
-        float v[1];
-        if (!ll_gather<1>(LL + LL_DY0 + i, 1, tag, v, failflag)) S.fail = 1;
-        F[D.foff.dy[i / (MB * U0)][0] + i % (MB * U0)] = v[0];
+      if (i < MB * U0) {   // dY0: every CU produced four columns of it; the first 8 CUs collect the packed words
+        float v0[1], v1[1], v2[1];
+        if (!lq_gather<1>(LQ, LQ_DY0 + i, 1, tag, v0, v1, v2, failflag)) S.fail = 1;
+        F[D.foff.dy[0][0] + i] = v0[0]; F[D.foff.dy[1][0] + i] = v1[0]; F[D.foff.dy[2][0] + i] = v2[0];
       }
       if (g == 0) {
         if (tid < MB * 34) {

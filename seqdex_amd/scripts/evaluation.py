@@ -21,7 +21,7 @@ import torch
 import yaml
 
 from ..a2c_agent import A2CAgent
-from ..config import TASK_CFG, TRAIN_CFG
+from ..config import TASK_CFG, TRAIN_CFG, set_seed
 from ..vec_task_rlgames import RLgamesVecTaskPython
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,6 +41,7 @@ def main_rlgames(task, num_envs, play=True, use_t_value=True, policy_path="", st
     every chunk, at most `max_steps`).  `controller(task, step) -> actions [N, 23]` replaces the policy (a scripted stand-in; the
     returned statistics say so).  Returns (task object - the caller closes task.sim -, statistics)."""
     assert play, "the chain evaluation only plays"
+    set_seed(seed)        # as the launcher does for every run (TR:70, CF:35-59): RLgamesVecTaskPython.reset draws its noise step from torch's global generator
     cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG[task])))
     cfg["env"]["numEnvs"] = num_envs
     cfg["env"]["test"] = True
@@ -109,11 +110,13 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to
     """stage 0 of the chain (untimed; the backward pass of scripts/bi_optimization.py:120-121 in small): BlockAssemblyInsertSim trains
     `epochs` epochs with its shipped schedule from synthetic grasp states, its episode outcomes fill the T-value rings, GraspInsertTValue
     is fitted to them -> the transition value that gates the harvests of the chain, and the insert policy of its last stage.
-    Deterministic run to run: training is (fixed-order reductions, counter-based noise) and the fit reads the outcome rings in serial
-    (step, env) order (SdxSim.ring_rows), not in the order the slots were claimed in.
+    Deterministic run to run: torch's global generator is seeded like the launcher does (it feeds VecTask.reset()'s noise step), training
+    is (fixed-order reductions, counter-based noise) and the fit reads the outcome rings in serial (step, env) order (SdxSim.ring_rows),
+    not in the order the slots were claimed in.
     Returns (flat T-value weights or None, insert checkpoint path or "", statistics)."""
     from ..tasks.block_assembly_insert_sim import BlockAssemblyInsertSim
     from ..tvalue_trainer import TValue_Trainer, flat_from_state_dict
+    set_seed(seed)        # TR:70: torch's global generator feeds VecTask.reset()'s noise step (VR:179-192)
     cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG["BlockAssemblyInsertSim"])))
     cfg["env"]["numEnvs"] = n
     tr = yaml.safe_load(open(os.path.join(ROOT, TRAIN_CFG["BlockAssemblyInsertSim"])))

@@ -56,6 +56,7 @@ def run(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=3
         os.chdir(cwd)
     torch.cuda.synchronize()
     wall = time.time() - t0
+    paths = {k: os.path.join(tmp, v) for k, v in paths.items()}          # (logs/<task>/nn/<task>.pth relative to the work directory)
     runs = [r for r in report if "task" in r]
     hand = [r for r in report if "handoff" in r]
     steps = sum(r["env_steps"] for r in runs)
