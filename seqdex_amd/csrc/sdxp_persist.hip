@@ -781,6 +781,43 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     // ================================================================== phase D: gather x3 and the heads, losses, backward to dY1
     float wh[HR][4];   // this wave's head rows for the forward (row = wave + 8 j, columns lane + 64 e)
     float wc[13];      // this lane's head column for the backward (column c2n, rows 13 c2c .. 13 c2c + 12)
+    // The head words were published a phase ago (shadow of x2), so they are normally all there: every load of the row AND the column
+    // view is issued before the first tag is looked at - one round trip instead of five chained ones (round 4; the phase clock had 2.4 us
+    // between the x3 publish and the head forward, 0.7 of them the x3 edge itself).  If a word is missing the per-view gathers below wait.
+    bool hw_done = false;
+    if (step != 0) {
+      u64 ww[HR][4], cw[13];
+      const u64 absent = (u64)tag_prev << 32;        // rows past the 25 head rows: value 0 with the expected tag
+#pragma unroll
+      for (int j = 0; j < HR; ++j) {
+        const int row = wave + 8 * j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ww[j][e] = row < A + 2 ? __hip_atomic_load(LL + LL_HW + (size_t)row * U2 + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : absent;
+      }
+#pragma unroll
+      for (int j = 0; j < 13; ++j) {
+        const int row = 13 * c2c + j;
+        cw[j] = row < A + 2 ? __hip_atomic_load(LL + LL_HW + (size_t)row * U2 + c2n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : absent;
+      }
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < HR; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(ww[j][e] >> 32) == tag_prev;
+#pragma unroll
+      for (int j = 0; j < 13; ++j) ok = ok && (unsigned)(cw[j] >> 32) == tag_prev;
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+#pragma unroll
+        for (int j = 0; j < HR; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wh[j][e] = __uint_as_float((unsigned)ww[j][e]);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) wc[j] = __uint_as_float((unsigned)cw[j]);
+        hw_done = true;
+      }
+    }
+    if (!hw_done) {
 #pragma unroll
     for (int j = 0; j < HR; ++j) {
       const int row = wave + 8 * j;
@@ -806,6 +843,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       if (!ll_gather<12>(LL + LL_HW + (size_t)13 * U2 + c2n, U2, tag_prev, t, failflag)) S.fail = 1;
 #pragma unroll
       for (int j = 0; j < 12; ++j) wc[j] = t[j];
+    }
     }
     {
       float v0[2], v1[2], v2[2];
