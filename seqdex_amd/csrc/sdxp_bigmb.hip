@@ -69,6 +69,22 @@ __global__ __launch_bounds__(256) void k_vhead_wgrad(const float* __restrict__ d
   if (k == 0) out[(size_t)blockIdx.x * oz + U] = sb;
 }
 
+// out[q][i] = sum_z part[q][z * pz + i] for the two value heads (q = 0, 1): one wave per output element, lanes stride over the VS
+// partials, fixed-order wave reduction (deterministic).  Round 3 used 2 blocks whose threads walked 128 partials one after the other
+// (23 us of dependent loads per head for 257 numbers).
+__global__ __launch_bounds__(256) void k_vhead_reduce(const float* __restrict__ p0, const float* __restrict__ p1, size_t pz, int VS, int n,
+                                                      float* __restrict__ o0, float* __restrict__ o1) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= 2 * n) return;
+  const float* part = w < n ? p0 : p1;
+  const int i = w < n ? w : w - n;
+  float a = 0.0f;
+  for (int z = lane; z < VS; z += 64) a += part[(size_t)z * pz + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) (w < n ? o0 : o1)[i] = a;
+}
+
 // ------------------------------------------------------------------------------------------------ losses
 // thread = sample s of the minibatch (dataset row r0 + s).  Formulas as k_head of sdxp_kernels.hip (RC:1796-1830, 2114-2126):
 // Gaussian neglogp, clipped surrogate, (clipped) value losses of the critic and the central value, bound loss, KL to the stored
@@ -366,8 +382,8 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
     hipLaunchKernelGGL(k_vhead_wgrad, dim3(VS), dim3(256), 0, st, ws->dv, ws->h[1][2], U2, MB, 64, vp0, (size_t)U2 + 1);
     hipLaunchKernelGGL(k_vhead_wgrad, dim3(VS), dim3(256), 0, st, ws->dv + MB, ws->h[2][2], U2, MB, 64, vp1, (size_t)U2 + 1);
     hipLaunchKernelGGL(k_reduce_parts, dim3(32), dim3(256), 0, st, ws->part, pz, S, pz, D.ac_g + D.off.mu_w);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, vp0, (size_t)U2 + 1, VS, (size_t)U2 + 1, D.ac_g + D.off.v_w);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(2), dim3(256), 0, st, vp1, (size_t)U2 + 1, VS, (size_t)U2 + 1, D.cv_g + D.coff.v_w);
+    hipLaunchKernelGGL(k_vhead_reduce, dim3((2 * (U2 + 1) + 3) / 4), dim3(256), 0, st, vp0, vp1, (size_t)U2 + 1, VS, U2 + 1, D.ac_g + D.off.v_w,
+                       D.cv_g + D.coff.v_w);
   }
   // ---- trunk backward, layer by layer for the three networks at once
   if (ws->nt) {
@@ -377,12 +393,25 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
         a[net] = {ws->dy[net][2], U2, MB, U2, U2, D.bf16 ? ws->dyn[net][2] : nullptr, U2, ws->dyt[net][2], ws->MBp};
       stage(D, a, 3, st);
     }
-    const int kc = (((ws->MBp + S - 1) / S) + ws->KC - 1) / ws->KC * ws->KC;          // reduction rows per split, a whole number of chunks
     for (int l = 2; l >= 0; --l) {
       const int Nl = D.units[l];
+      // splits of this layer's weight-gradient product over the minibatch rows: as few as still give the 512 workgroup slots about a
+      // round and a half of 128 x 64-or-wider tiles (every split costs a pass over [W | b] in the partial reduction), at least 4 chunks each
+      int Sl;
+      {
+        int Kmax = 0;
+        for (int net = 0; net < 3; ++net) Kmax = Kof(net, l) > Kmax ? Kof(net, l) : Kmax;
+        const int tiles = 3 * ((Nl + 127) / 128) * ((Kmax + 127) / 128);
+        Sl = (768 + tiles - 1) / tiles;
+        const int smax = ws->MBp / (4 * ws->KC) > 0 ? ws->MBp / (4 * ws->KC) : 1;
+        if (Sl > smax) Sl = smax;
+        if (Sl > S) Sl = S;
+        if (Sl < 1) Sl = 1;
+      }
+      const int kc = (((ws->MBp + Sl - 1) / Sl) + ws->KC - 1) / ws->KC * ws->KC;        // reduction rows per split, a whole number of chunks
       NtArgs gw[3];
       ReduceBatch rb;
-      rb.S = S;
+      rb.S = Sl;
       for (int net = 0; net < 3; ++net) {
         const int Kl = Kof(net, l);
         const size_t pz = (size_t)Nl * Kl + Nl;                           // [W_l | b_l] contiguous in the flat layout
@@ -392,7 +421,7 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
                    nullptr, nullptr, 0, nullptr, 0, part + (size_t)Nl * Kl};
         rb.part[net] = part; rb.pz[net] = pz; rb.n[net] = pz; rb.out[net] = G[net] + woff(net, l);
       }
-      if (D.bf16) gemm_nt<1, EPI_TN>(gw, 3, S, st); else gemm_nt<0, EPI_TN>(gw, 3, S, st);   // G_l = dY_l^T X_l, b_l = row sums of dY_l^T
+      if (D.bf16) gemm_nt<1, EPI_TN>(gw, 3, Sl, st); else gemm_nt<0, EPI_TN>(gw, 3, Sl, st);   // G_l = dY_l^T X_l, b_l = row sums of dY_l^T
       hipLaunchKernelGGL(k_reduce_parts3, dim3(256, 3), dim3(256), 0, st, rb);
       if (l > 0) {
         NtArgs gx[3];

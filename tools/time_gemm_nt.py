@@ -91,7 +91,9 @@ def main():
             return max(e1_, e2_)
         total_us += run("forward L%d  [%d x %d x (%d|%d|%d)] x 3 nets" % (l, MB, N, *ins[l]), EPI_FWD, args, fl, check=chk_f); total_fl += fl
         # ---- weight gradient: G = dY^T X, split over the rows
-        S = min(16, max(1, (MB + 511) // 512))
+        # splits as sdxpk_big_step picks them per layer: about a round and a half of tiles on the 512 workgroup slots, >= 4 chunks per split
+        tiles = 3 * ((N + 127) // 128) * ((max(ins[l]) + 127) // 128)
+        S = max(1, min((768 + tiles - 1) // tiles, max(1, MB // (4 * KC)), min(16, max(1, (MB + 511) // 512))))
         kc = ((MB + S - 1) // S + KC - 1) // KC * KC
         dYt, Xt, parts, args = [], [], [], []
         for net in range(3):
