@@ -337,9 +337,17 @@ def main():
           # the bound the kernel actually sits at: a chain of CU-to-CU exchange edges per optimiser step plus the
           # arithmetic that cannot leave the chain; weights and moments live in VGPRs, so HBM carries ~5 % of the algorithmic bytes
           pc_ = PMC.get("k_update_persistent_phase_clock", {})
+          fl_ = PMC.get("k_update_persistent_exchange_floor", {})
+          edge_floor = sum(fl_.get("edge_floor_us", {}).values()) if fl_ else None
+          floor = (edge_floor + pc_["on_chain_us"]) if (edge_floor and pc_.get("on_chain_us")) else None
           roof_upd["bound_actual"] = {"kind": "exchange-latency", "exchange_edges_per_optimiser_step": pc_.get("edges", 5),
                                       "us_wait_on_edges_per_step": pc_.get("edge_wait_us"), "us_on_chain_arithmetic_per_step": pc_.get("on_chain_us"),
-                                      "us_per_optimiser_step_measured": upd_ms_step * 1e3, "quoted_from": pc_.get("source")}
+                                      "us_shadow_work_per_step": pc_.get("shadow_us"),
+                                      "us_per_optimiser_step_measured": upd_ms_step * 1e3, "quoted_from": pc_.get("source"),
+                                      # the denominator: the tagged-word all-gather measured alone, per edge, + the on-chain phases
+                                      "edge_floor_us": fl_.get("edge_floor_us"), "floor_us_per_step": floor,
+                                      "frac_of_floor": (floor / (upd_ms_step * 1e3)) if floor else None, "floor_quoted_from": fl_.get("source"),
+                                      "floor_note": fl_.get("note")}
     dominant = roof_upd if upd_t > step_t else roof_phys
     out = {
         "metric": "env-steps/sec BlockAssemblyGraspSim num_envs=%d/GPU" % n, "value": value, "unit": "env-steps/s",

@@ -449,3 +449,38 @@ def test_persistent_update_at_1024_envs_matches_the_oracle_step_for_step():
         else:
             os.environ["SDXP_MAX_STEPS"] = old
         agent.close()
+
+
+def test_contact_capacity_holds_under_a_200_epoch_policy():
+    """the capacity rule changes the physics exactly where a trained hand digs into the pile -
+    the contact list of an env-substep that would exceed 1 536 points is rebuilt without its speculative contacts.  After 200 training
+    epochs at 1 024 envs with the shipped schedule (the partially trained policy of SURVEY.md 8(d) config 2) no env-substep may have been
+    rebuilt ([2]), lost a contact ([1]) or overflowed its candidate pair list ([3])."""
+    import yaml
+    from seqdex_amd.a2c_agent import A2CAgent
+    from seqdex_amd.config import TASK_CFG, TRAIN_CFG
+    from seqdex_amd.tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
+    from seqdex_amd.vec_task_rlgames import RLgamesVecTaskPython
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seqdex_amd")
+    n = 1024
+    cfg = yaml.safe_load(open(os.path.join(root, TASK_CFG["BlockAssemblyGraspSim"])))
+    cfg["env"]["numEnvs"] = n
+    tr = yaml.safe_load(open(os.path.join(root, TRAIN_CFG["BlockAssemblyGraspSim"])))
+    torch.manual_seed(22)
+    task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=0, headless=True, seed=22, piles_per_type=64)
+    env = RLgamesVecTaskPython(task, "cuda:0")
+    tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=22)
+    agent = A2CAgent("run", tr["params"])
+    try:
+        for _ in range(200):
+            agent.train_epoch()
+        torch.cuda.synchronize()
+        st = task.sim.CONTACT_STATS.cpu().numpy()
+        print("after 200 epochs: largest contact list %d of 1536, env-substeps over capacity %d, rebuilt %d, pair-list overflows %d" % tuple(st))
+        assert st[1] == 0 and st[3] == 0, st
+        assert st[2] == 0, st
+        assert 600 < st[0] <= 1536, st
+        assert bool(torch.isfinite(agent.ppo.t["AC_PARAMS"]).all())
+    finally:
+        agent.ppo.close()
+        task.sim.close()
