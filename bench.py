@@ -161,12 +161,20 @@ def gemm_roofline(agent, n, horizon, upd_ms_per_epoch):
     flops_step = 6.0 * agent.minibatch_size * p
     ms_step = upd_ms_per_epoch / nsteps
     ach = flops_step / (ms_step * 1e-3) / 1e12
+    # what the step executes: no data gradient reaches the network inputs, so layer 0 (2 x obs_dim + state_dim inputs x 1024 units) has a
+    # forward and a weight-gradient product only: 6 P - 2 P_layer0 per sample (about 5.2 P)
+    c = agent.ppo.cfg
+    executed = flops_step - 2.0 * agent.minibatch_size * (2 * c.obs_dim + c.state_dim) * int(c.units[0])
     bf = bool(agent.config.get("mixed_precision", False))
     peak = BF16_MFMA_PEAK_TFLOPS if bf else FP32_MFMA_PEAK_TFLOPS
     return {"kernel": "k_gemm<NT|NN|TN> %s MFMA (forward, data gradient, weight gradient of 3 networks; whole optimiser step incl. "
                       "losses, reductions, clip + Adam in the time)" % ("bf16" if bf else "fp32"), "bound": "mfma", "achieved": ach, "peak": peak,
             "unit": "TFLOP/s", "frac": ach / peak, "avg_launch_ms": ms_step, "us_per_optimiser_step": ms_step * 1e3,
-            "algorithmic_flops_per_step": flops_step, "optimiser_steps_per_epoch": nsteps, "traffic": None}
+            "algorithmic_flops_per_step": flops_step, "executed_flops_per_step": executed,
+            "achieved_on_executed_flops": executed / (ms_step * 1e-3) / 1e12,
+            "flops_note": "achieved / frac use SURVEY 8(d)'s accounting (update = 3 x forward = 6 flops per weight and sample, as every round "
+                          "before); the step does not compute the layer-0 data gradient, achieved_on_executed_flops is the rate on the flops it runs",
+            "optimiser_steps_per_epoch": nsteps, "traffic": None}
 
 
 def large_minibatch_variant(train, env, n, horizon, args):

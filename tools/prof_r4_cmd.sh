@@ -36,6 +36,7 @@ EOF
 fi
 
 [ "${1:-all}" = "bench" ] && exit 0
+timeout 120 python tools/time_gemm_nt.py --mb 32768 --bf16 --out $O/bigmb_products_bf16_mb32768.txt 2>&1 | tail -10
 pass() {  # name, rocprof args..., -- command
   name=$1; shift
   timeout -k 5 240 rocprofv3 "$@" > $O/prof_$name.log 2>&1; echo "$name rc=$?"
