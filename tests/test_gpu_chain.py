@@ -15,16 +15,17 @@ def test_chain_hand_offs_at_1024_envs():
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from seqdex_amd.scripts.evaluation import block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller
+    from seqdex_amd.scripts.evaluation import CHAIN_GRASP_GATES, CHAIN_ORIENT_GATES, block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller
     # stage 0: the transition value of the chain's gates, fitted to InsertSim's own episode outcomes (bi_optimization.py:120-121).  One
     # seed, no retry: training is deterministic and the fit reads the outcome rings in serial (step, env) order (SdxSim.ring_rows)
     tv, _, prep = prepare_tvalue_and_insert_policy(N, 1000, fit_iters=2000, seed=22)
     assert tv is not None, prep                                   # both outcome classes were logged and the fit ran
-    # gates at 0.5 / 0.28 instead of 0.99 (OR:1203) / 0.8 (GS:1406): a T-value fitted to a thousand epochs of outcomes tops out near 0.85 and
-    # sits at its floor sigmoid(-1) = 0.27 for most orientations; two grasp episodes
+    # gates: descending ladders starting at 0.5 / 0.28 instead of 0.99 (OR:1203) / 0.8 (GS:1406): a T-value fitted to a thousand epochs of
+    # outcomes tops out near 0.85 and sits at its floor sigmoid(-1) = 0.27 for most orientations, and WHICH orientations it accepts moves
+    # with any change of the training arithmetic (block_assembly_chain, stage 1); the last rung opens the gate; two grasp episodes
     try:
-        res, hand = block_assembly_chain(N, tv, controllers={"grasp": scripted_grasp_controller}, synthetic_fallback=True, orient_tvalue_gate=0.5,
-                                         grasp_tvalue_gate=0.28, stage_steps={"grasp": 320})
+        res, hand = block_assembly_chain(N, tv, controllers={"grasp": scripted_grasp_controller}, synthetic_fallback=True, orient_tvalue_gate=CHAIN_ORIENT_GATES,
+                                         grasp_tvalue_gate=CHAIN_GRASP_GATES, stage_steps={"grasp": 320})
     except RuntimeError as ex:
         pytest.fail("%s; stage 0 was %s" % (ex, prep))
     ins = hand["insert_task"]

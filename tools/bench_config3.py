@@ -21,7 +21,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from seqdex_amd.scripts.evaluation import block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller  # noqa: E402
+from seqdex_amd.scripts.evaluation import CHAIN_GRASP_GATES, CHAIN_ORIENT_GATES, block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller  # noqa: E402
 
 
 if __name__ == "__main__":
@@ -32,7 +32,7 @@ if __name__ == "__main__":
     tv, insert_ckpt, prep_st = prepare_tvalue_and_insert_policy(n, prep, seed=22, save_to=os.path.join(tmp, "config3_insert_policy"))
     print("stage 0:", json.dumps(prep_st), file=sys.stderr, flush=True)
     res, hand = block_assembly_chain(n, tv, policies={"insert": insert_ckpt}, controllers={"grasp": scripted_grasp_controller},
-                                     synthetic_fallback=True, orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28,
+                                     synthetic_fallback=True, orient_tvalue_gate=CHAIN_ORIENT_GATES, grasp_tvalue_gate=CHAIN_GRASP_GATES,
                                      stage_steps={"grasp": 320}, with_search="--with-search" in sys.argv)
     ins = hand["insert_task"]
     res["insert"]["synthetic_groups"] = ins.synthetic_groups

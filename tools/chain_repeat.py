@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from seqdex_amd.scripts.evaluation import block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller  # noqa: E402
+from seqdex_amd.scripts.evaluation import CHAIN_GRASP_GATES, CHAIN_ORIENT_GATES, block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller  # noqa: E402
 
 
 def digest(t):
@@ -35,7 +35,7 @@ def main():
         t0 = time.time()
         tv, _, prep = prepare_tvalue_and_insert_policy(a.num_envs, a.prep_epochs, fit_iters=2000, seed=22)
         res, hand = block_assembly_chain(a.num_envs, tv, controllers={"grasp": scripted_grasp_controller}, synthetic_fallback=True,
-                                         orient_tvalue_gate=0.5, grasp_tvalue_gate=0.28, stage_steps={"grasp": 320})
+                                         orient_tvalue_gate=CHAIN_ORIENT_GATES, grasp_tvalue_gate=CHAIN_GRASP_GATES, stage_steps={"grasp": 320})
         ins = hand["insert_task"]
         row = {"rep": rep, "wall_s": time.time() - t0, "tvalue_sha": hashlib.sha256(np.asarray(tv).tobytes()).hexdigest()[:16],
                "outcomes_logged": prep["outcomes_logged(success, failure)"], "tvalue_fit": prep["tvalue_fit"],

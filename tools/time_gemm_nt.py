@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--out", default="")
+    ap.add_argument("--ablate", action="store_true", help="also time the L1 forward / data-gradient products with some or all of their output copies switched off (what the epilogue costs)")
     a = ap.parse_args()
     lib = _abi.load_library()
     lib.sdxpk_gemm_nt_launch.restype = C.c_int
@@ -90,6 +91,14 @@ def main():
             e2_ = float((Ht[2].float().t() - ref).abs().max() / ref.abs().max()) if l < 2 else 0.0
             return max(e1_, e2_)
         total_us += run("forward L%d  [%d x %d x (%d|%d|%d)] x 3 nets" % (l, MB, N, *ins[l]), EPI_FWD, args, fl, check=chk_f); total_fl += fl
+        if a.ablate and l == 1:
+            for tag, keep in (("no output copy (reduction loop alone)", ()), ("[i][j] copy only", ("Cf", "Cn")), ("transposed copy only", ("Ct",))):
+                ab = [NtArgs.from_buffer_copy(bytes(x)) for x in args]
+                for x in ab:
+                    for f in ("Cf", "Cn", "Ct"):
+                        if f not in keep:
+                            setattr(x, f, None)
+                run("  ablation, forward L1: " + tag, EPI_FWD, ab, fl)
         # ---- weight gradient: G = dY^T X, split over the rows
         # splits as sdxpk_big_step picks them per layer: about a round and a half of tiles on the 512 workgroup slots, >= 4 chunks per split
         tiles = 3 * ((N + 127) // 128) * ((max(ins[l]) + 127) // 128)
@@ -131,6 +140,11 @@ def main():
                 e = float((dXt[2].float().t() - ref).abs().max() / ref.abs().max())
                 return max(e, float((dXn[2].float() - ref).abs().max() / ref.abs().max())) if l > 1 else e
             total_us += run("data grad L%d->L%d [%d x %d x %d] x 3 nets" % (l, l - 1, MB, Kl, N), EPI_NN, args, fl, check=chk_d); total_fl += fl
+            if a.ablate and l == 1:
+                ab = [NtArgs.from_buffer_copy(bytes(x)) for x in args]
+                for x in ab:
+                    x.Cn = None; x.Ct = None
+                run("  ablation, data grad L1->L0: no output copy (reduction loop alone)", EPI_NN, ab, fl)
     ln = "all eight trunk products of one optimiser step: %.1f us, %.1f TFLOP/s = %.1f %% of the %s dense peak (%.0f)" % (
         total_us, total_fl / total_us / 1e6, 100 * total_fl / total_us / 1e6 / peak, "bf16" if a.bf16 else "fp32", peak)
     lines.append(ln)
