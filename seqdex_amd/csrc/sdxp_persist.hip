@@ -218,14 +218,16 @@ __device__ __forceinline__ void block_sum(PLds& S, const float (&v)[N], float* o
 #pragma unroll
     for (int j = 0; j < N4; ++j) r[4 * j + (lane & 3)] = u2[j];
   }
-  __syncthreads();
+  // LDS-only barriers (sdx_common.h): __syncthreads() also waits for the wave's outstanding global accesses - in the shadows that is the
+  // acknowledgement of the exchange words just published and the next minibatch's prefetched rows; nothing here is ordered through HBM
+  SDX_LDS_BARRIER();
   if (tid < N) {
     float t = 0.0f;
 #pragma unroll
     for (int w = 0; w < 4 * NWV; ++w) t += S.red[w][tid];
     out[tid] = t;
   }
-  __syncthreads();
+  SDX_LDS_BARRIER();
 }
 
 static_assert(sizeof(PLds) + 512 <= 160 * 1024, "PLds (+ the static logstd bank) must fit the 160 KiB LDS of a gfx950 CU");
@@ -780,44 +782,51 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     refresh();
     // ================================================================== phase D: gather x3 and the heads, losses, backward to dY1
     float wh[HR][4];   // this wave's head rows for the forward (row = wave + 8 j, columns lane + 64 e)
-    float wc[13];      // this lane's head column for the backward (column c2n, rows 13 c2c .. 13 c2c + 12)
-    // The head words were published a phase ago (shadow of x2), so they are normally all there: every load of the row AND the column
-    // view is issued before the first tag is looked at - one round trip instead of five chained ones (round 4; the phase clock had 2.4 us
-    // between the x3 publish and the head forward, 0.7 of them the x3 edge itself).  If a word is missing the per-view gathers below wait.
-    bool hw_done = false;
-    if (step != 0) {
-      u64 ww[HR][4], cw[13];
-      const u64 absent = (u64)tag_prev << 32;        // rows past the 25 head rows: value 0 with the expected tag
+    // The head words were published a phase ago (shadow of x2), so they are normally all there.  Row view (head forward): all 16 loads
+    // of a lane are issued before the first tag is looked at, and they share their round trip with the first look at the lane's x3
+    // words (round 3: five chained gathers, then the x3 gather: 2.4 us between the x3 publish and the head forward, 0.7 of them the
+    // x3 edge itself).  If a word is missing the polling gathers below wait.  The column view is first used by the heads' backward:
+    // it is requested after the head forward, under the loss phase (both views at once - 58 registers in flight - spilled).
+    bool row_done = false;
+    {
+      // first look at this lane's two x3 words, issued BEFORE the head-word loads: both round trips overlap; if the x3 words of a slow
+      // producer are not there yet, the polling gather below continues after the head words have been taken
+      u32x4 w3[2];
 #pragma unroll
-      for (int j = 0; j < HR; ++j) {
-        const int row = wave + 8 * j;
+      for (int i = 0; i < 2; ++i) w3[i] = __builtin_amdgcn_raw_buffer_load_b128(LQ, (LQ_X3 + tid + i * NTH) * 16u, 0, 16);
+      if (step != 0) {
+        u64 ww[HR][4];
+        const u64 absent = (u64)tag_prev << 32;        // rows past the 25 head rows: value 0 with the expected tag
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          ww[j][e] = row < A + 2 ? __hip_atomic_load(LL + LL_HW + (size_t)row * U2 + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : absent;
-      }
+        for (int j = 0; j < HR; ++j) {
+          const int row = wave + 8 * j;
 #pragma unroll
-      for (int j = 0; j < 13; ++j) {
-        const int row = 13 * c2c + j;
-        cw[j] = row < A + 2 ? __hip_atomic_load(LL + LL_HW + (size_t)row * U2 + c2n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : absent;
-      }
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < HR; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(ww[j][e] >> 32) == tag_prev;
-#pragma unroll
-      for (int j = 0; j < 13; ++j) ok = ok && (unsigned)(cw[j] >> 32) == tag_prev;
-      if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+          for (int e = 0; e < 4; ++e)
+            ww[j][e] = row < A + 2 ? __hip_atomic_load(LL + LL_HW + (size_t)row * U2 + lane + 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : absent;
+        }
+        bool ok = true;
 #pragma unroll
         for (int j = 0; j < HR; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) wh[j][e] = __uint_as_float((unsigned)ww[j][e]);
+          for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(ww[j][e] >> 32) == tag_prev;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
 #pragma unroll
-        for (int j = 0; j < 13; ++j) wc[j] = __uint_as_float((unsigned)cw[j]);
-        hw_done = true;
+          for (int j = 0; j < HR; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wh[j][e] = __uint_as_float((unsigned)ww[j][e]);
+          row_done = true;
+        }
       }
+      float v0[2], v1[2], v2[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { v0[i] = __uint_as_float(w3[i].x); v1[i] = __uint_as_float(w3[i].y); v2[i] = __uint_as_float(w3[i].z); }
+      if (__builtin_amdgcn_ballot_w64(!(w3[0].w == tag && w3[1].w == tag)) != 0) {
+        if (!lq_gather<2>(LQ, LQ_X3 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { (&S.x3[0][0][0])[tid + NTH * j] = v0[j]; (&S.x3[1][0][0])[tid + NTH * j] = v1[j]; (&S.x3[2][0][0])[tid + NTH * j] = v2[j]; }
     }
-    if (!hw_done) {
+    if (!row_done) {
 #pragma unroll
     for (int j = 0; j < HR; ++j) {
       const int row = wave + 8 * j;
@@ -831,25 +840,6 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         } else if (!ll_gather<4>(LL + LL_HW + (size_t)row * U2 + lane, 64, tag_prev, wh[j], failflag)) S.fail = 1;   // lane-contiguous words
       }
     }
-#pragma unroll
-    for (int j = 0; j < 13; ++j) wc[j] = 0.0f;
-    if (step == 0) {
-#pragma unroll
-      for (int j = 0; j < 13; ++j) { const int row = 13 * c2c + j; if (row < A + 2) wc[j] = P_of(head_net(row))[head_woff(row) + c2n]; }
-    } else if (c2c == 0) {
-      if (!ll_gather<13>(LL + LL_HW + c2n, U2, tag_prev, wc, failflag)) S.fail = 1;
-    } else {
-      float t[12];
-      if (!ll_gather<12>(LL + LL_HW + (size_t)13 * U2 + c2n, U2, tag_prev, t, failflag)) S.fail = 1;
-#pragma unroll
-      for (int j = 0; j < 12; ++j) wc[j] = t[j];
-    }
-    }
-    {
-      float v0[2], v1[2], v2[2];
-      if (!lq_gather<2>(LQ, LQ_X3 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) { (&S.x3[0][0][0])[tid + NTH * j] = v0[j]; (&S.x3[1][0][0])[tid + NTH * j] = v1[j]; (&S.x3[2][0][0])[tid + NTH * j] = v2[j]; }
     }
     TS(10)
     __syncthreads();
@@ -914,6 +904,26 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     }
     __syncthreads();
     TS(11)
+    // Column view of the head words (this lane's column c2n, rows 13 c2c .. 13 c2c + 12; first used by the heads' backward): requested
+    // here, under the loss phase.  No tags: between them the row views of the eight waves cover every head word, each wave has seen
+    // its words' tags (fast path or polling gather) before the barrier in front of the head forward, and the words are not rewritten
+    // before every CU has finished this step - so the low halves (the values) are read as plain agent-scope dwords, 13 registers.
+    // (the per-sample scalars prefetched in phase C are taken NOW: the loads below sit behind lane-dependent conditions, and after such a
+    // merge the compiler's counter model waits for everything outstanding at the next use of any loaded register - that use would be
+    // pf_adv in the loss phase, i.e. the column loads' whole round trip: 0.6 us on the chain)
+    SDX_OPAQUE(pf_adv); SDX_OPAQUE(pf_nlp); SDX_OPAQUE(pf_ret); SDX_OPAQUE(pf_val);
+    float wc[13];      // (row 25 = 13 + 12 does not exist: its slot repeats row 24 and is never used)
+    if (step == 0) {
+#pragma unroll
+      for (int j = 0; j < 13; ++j) { const int row = min(13 * c2c + j, A + 1); wc[j] = P_of(head_net(row))[head_woff(row) + c2n]; }
+    } else {           // 13 unconditional loads, nothing between them that looks at a loaded value
+      const unsigned* hwv = reinterpret_cast<const unsigned*>(LL + LL_HW) + 2 * c2n;
+#pragma unroll
+      for (int j = 0; j < 13; ++j) {
+        const int row = min(13 * c2c + j, A + 1);
+        wc[j] = __uint_as_float(__hip_atomic_load(hwv + (size_t)row * (2 * U2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+    }
     const float invM = 1.0f / (float)MB;
     {
       float r_nlp = 0.0f, r_kl = 0.0f, r_bl = 0.0f, r_ent = 0.0f;
@@ -959,7 +969,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         S.stat[s][5] = closs[1]; S.stat[s][6] = r_ent;
       }
     }
-    __syncthreads();
+    SDX_LDS_BARRIER();   // LDS traffic only: the column view's loads stay in flight (a __syncthreads() would wait for them)
     if (tid < MB * 32) {
       const int s = tid / 32, a = tid % 32;
       float dmu = 0.0f;
@@ -977,7 +987,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       if (a < A) for (int s = 0; s < MB; ++s) dls += S.gnlp[s] * (1.0f - S.z[s][a] * S.z[s][a]) * invM;
       S.dls[a] = dls;
     }
-    __syncthreads();
+    SDX_LDS_BARRIER();   // LDS traffic only: the column view's loads stay in flight (a __syncthreads() would wait for them)
     TS(12)
     // backward through the heads: lane (column k, row half) forms its part of dX3[.][k], the halves meet in LDS; elu' applied here
     {
