@@ -143,6 +143,23 @@ __device__ __forceinline__ bool lq_gather(__amdgpu_buffer_rsrc_t q, unsigned idx
     }
   }
 }
+// first look at N packed words, issued some work ahead of where they are needed (lq_peek), and the test whether all of them already
+// carried `tag` (lq_take): when a shadow phase outlasts its exchange edge the words are there, and the round trip of the gather
+// (about 0.6 us) runs under the shadow's last piece of work instead of after it.  A miss falls back to the polling lq_gather.
+template <int N>
+__device__ __forceinline__ void lq_peek(__amdgpu_buffer_rsrc_t q, unsigned idx0, unsigned stride, u32x4 (&w)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(q, (idx0 + i * stride) * 16u, 0, 16);
+}
+template <int N>
+__device__ __forceinline__ bool lq_take(const u32x4 (&w)[N], unsigned tag, float (&o0)[N], float (&o1)[N], float (&o2)[N]) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i) ok = ok && w[i].w == tag;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { o0[i] = __uint_as_float(w[i].x); o1[i] = __uint_as_float(w[i].y); o2[i] = __uint_as_float(w[i].z); }
+  return __builtin_amdgcn_ballot_w64(!ok) == 0;
+}
 __device__ __forceinline__ void ll_store(u64* p, float v, unsigned tag) {
   __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -656,6 +673,8 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
     }
     refresh();
+    u32x4 px2[4];
+    bool px2_issued = false;
     if (pending) {
       // ---- (shadow of x2) Adam of layer 2 (row and column copies), of this CU's head elements, of the remaining biases and logstd
       const float gs_ac = S.scal[0], gs_cv = S.scal[1];
@@ -663,6 +682,9 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       float dep = 0.0f;
 #pragma unroll
       for (int net = 0; net < 3; ++net) {
+        // first look at this lane's x2 words before the last network's update: the shadow has outlasted the edge by then (2.2 us of
+        // its 2.8 against an edge of 2.1), what follows hides the round trip
+        if (net == 2 && !last) { lq_peek<4>(LQ, LQ_X2 + tid, NTH, px2); px2_issued = true; }
         const float gs = net == 2 ? gs_cv : gs_ac, lrb = net == 2 ? cv_lr_bc1 : ac_lr_bc1, isq = net == 2 ? cv_isq : ac_isq;
         float d2r[MB], dn2[MB];
         const int o_n = opaque(c2n, dep);
@@ -727,7 +749,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     }
     {
       float v0[4], v1[4], v2[4];
-      if (!lq_gather<4>(LQ, LQ_X2 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
+      if (!(px2_issued && lq_take<4>(px2, tag, v0, v1, v2)) && !lq_gather<4>(LQ, LQ_X2 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { (&S.x2[0][0][0])[tid + NTH * j] = v0[j]; (&S.x2[1][0][0])[tid + NTH * j] = v1[j]; (&S.x2[2][0][0])[tid + NTH * j] = v2[j]; }
     }
@@ -1045,6 +1067,8 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
     }
     TS(14)
+    u32x4 pdy1[4];
+    bool pdy1_issued = false;
     // ---- (shadow of dY1) loss statistics + LR rule, Grams of x3 and dY2, head / logstd terms of the squared gradient norm
     if (tid == 0) {
       PLds::Ctl& C = S.ctl;
@@ -1087,7 +1111,9 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         if (j < A) { float sb = 0; for (int a = 0; a < MB; ++a) sb += S.dmu[a][j]; t = sb * sb + S.dls[j] * S.dls[j]; }
         S.part[tid] = t;
       }
-      __syncthreads();
+      SDX_LDS_BARRIER();
+      // first look at this lane's dY1 words (the shadow has outlasted the edge: 3.0 us against 2.1); the sums below hide the round trip
+      lq_peek<4>(LQ, LQ_DY1 + tid, NTH, pdy1); pdy1_issued = true;
       if (tid < 3) {
         const int net = tid;
         float acc = 0.0f;
@@ -1096,7 +1122,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         else { float sb = 0; for (int a = 0; a < MB; ++a) sb += S.dv[net - 1][a]; acc += sb * sb; }
         S.ctl.n2h[net] = acc;
       }
-      __syncthreads();
+      SDX_LDS_BARRIER();
     }
     }
     TS(15)
@@ -1104,7 +1130,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     // ================================================================== phase E: gather dY1, backward L1
     {
       float v0[4], v1[4], v2[4];
-      if (!lq_gather<4>(LQ, LQ_DY1 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
+      if (!(pdy1_issued && lq_take<4>(pdy1, tag, v0, v1, v2)) && !lq_gather<4>(LQ, LQ_DY1 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { (&S.dy1[0][0][0])[tid + NTH * j] = v0[j]; (&S.dy1[1][0][0])[tid + NTH * j] = v1[j]; (&S.dy1[2][0][0])[tid + NTH * j] = v2[j]; }
     }

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-./tools/gpu/probe/mfma4x4
 mkdir -p gpurun_out/r4h
 timeout 600 python -m pytest tests/test_gpu_ppo_parity.py tests/test_gpu_fullsize_properties.py -q -m gpu -k "update_matches or persistent or fault or explicit or step_for_step or replicas or reproduc or emulated or nccl" 2>&1 | grep -E "passed|failed|^E  " | head -8
 SDXP_PERSIST_STAMPS=1 timeout 120 python tools/prof_persist.py 1024 2>&1 | grep -v amdgpu | tee gpurun_out/r4h/phase_clock.txt | head -24
