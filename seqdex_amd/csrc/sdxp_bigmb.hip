@@ -85,6 +85,17 @@ __global__ __launch_bounds__(256) void k_vhead_reduce(const float* __restrict__ 
   if (lane == 0) (w < n ? o0 : o1)[i] = a;
 }
 
+// out[i] = sum_z part[z * pz + i], i < n: one wave per output element, lanes stride over the S partials (fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_wave_reduce(const float* __restrict__ part, size_t pz, int S, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  float a = 0.0f;
+  for (int z = lane; z < S; z += 64) a += part[(size_t)z * pz + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) out[i] = a;
+}
+
 // ------------------------------------------------------------------------------------------------ losses
 // thread = sample s of the minibatch (dataset row r0 + s).  Formulas as k_head of sdxp_kernels.hip (RC:1796-1830, 2114-2126):
 // Gaussian neglogp, clipped surrogate, (clipped) value losses of the critic and the central value, bound loss, KL to the stored
@@ -258,7 +269,9 @@ extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB) {
   const size_t l1 = (size_t)D->units[1] * D->units[0] + D->units[1], l2 = (size_t)D->units[2] * D->units[1] + D->units[2];
   if (l1 > mx) mx = l1;
   if (l2 > mx) mx = l2;
-  const size_t hp = (size_t)((MB + 255) / 256) * BIGP + (size_t)2 * ((MB + 63) / 64) * (D->units[2] + 1) + (size_t)S * (32 * (D->units[2] + 1));
+  int Sh = MB / 256;                 // splits of the policy head's weight gradient (sdxpk_big_step)
+  Sh = Sh < S ? S : (Sh > 128 ? 128 : Sh);
+  const size_t hp = (size_t)((MB + 255) / 256) * BIGP + (size_t)2 * ((MB + 63) / 64) * (D->units[2] + 1) + (size_t)Sh * (32 * (D->units[2] + 1));
   const size_t need = (size_t)S * mx;
   return need > hp ? need : hp;      // per network; the workspace holds three such regions
 }
@@ -372,16 +385,20 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
     hipLaunchKernelGGL(k_vhead_back, dim3(512), dim3(256), 0, st, ws->dv, D.ac + D.off.v_w, ws->h[1][2], U2, MB, ws->dy[1][2]);
     hipLaunchKernelGGL(k_vhead_back, dim3(512), dim3(256), 0, st, ws->dv + MB, D.cv + D.coff.v_w, ws->h[2][2], U2, MB, ws->dy[2][2]);
     // mu head: G[A][U2] = dmu^T h3, bias = row sums of dmu^T; contiguous [mu_w | mu_b] in the flat layout
+    // (a 23-row product: its only parallelism is the reduction over the minibatch rows, so it is split 256 rows at a time - 32 .. 128
+    // splits instead of the trunk's 8 .. 16: 94 us -> about 15 at 32 768 rows - and the partials are summed by one wave per output)
     const size_t pz = (size_t)A * U2 + A;
-    GemmArgs gw = {ws->dmu, 24, ws->h[0][2], U2, ws->part, U2, pz, A, U2, MB, rchunk, nullptr, nullptr, 0, ws->part + (size_t)A * U2};
-    gemm<1, 1, 4>(&gw, 1, S, st);
+    int Sh = MB / 256;
+    Sh = Sh < S ? S : (Sh > 128 ? 128 : Sh);
+    GemmArgs gw = {ws->dmu, 24, ws->h[0][2], U2, ws->part, U2, pz, A, U2, MB, (MB + Sh - 1) / Sh, nullptr, nullptr, 0, ws->part + (size_t)A * U2};
+    gemm<1, 1, 4>(&gw, 1, Sh, st);
     // value heads: [v_w | v_b] contiguous; 64-row splits
     const int VS = (MB + 63) / 64;
-    float* vp0 = ws->part + (size_t)S * pz;
+    float* vp0 = ws->part + (size_t)Sh * pz;
     float* vp1 = vp0 + (size_t)VS * (U2 + 1);
     hipLaunchKernelGGL(k_vhead_wgrad, dim3(VS), dim3(256), 0, st, ws->dv, ws->h[1][2], U2, MB, 64, vp0, (size_t)U2 + 1);
     hipLaunchKernelGGL(k_vhead_wgrad, dim3(VS), dim3(256), 0, st, ws->dv + MB, ws->h[2][2], U2, MB, 64, vp1, (size_t)U2 + 1);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(32), dim3(256), 0, st, ws->part, pz, S, pz, D.ac_g + D.off.mu_w);
+    hipLaunchKernelGGL(k_wave_reduce, dim3(((int)pz + 3) / 4), dim3(256), 0, st, ws->part, pz, Sh, (int)pz, D.ac_g + D.off.mu_w);
     hipLaunchKernelGGL(k_vhead_reduce, dim3((2 * (U2 + 1) + 3) / 4), dim3(256), 0, st, vp0, vp1, (size_t)U2 + 1, VS, U2 + 1, D.ac_g + D.off.v_w,
                        D.cv_g + D.coff.v_w);
   }
