@@ -1069,8 +1069,11 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     TS(14)
     u32x4 pdy1[4];
     bool pdy1_issued = false;
-    // ---- (shadow of dY1) loss statistics + LR rule, Grams of x3 and dY2, head / logstd terms of the squared gradient norm
-    if (tid == 0) {
+    // ---- (shadow of dY1) loss statistics + LR rule, Gram of x3, head / logstd terms of the squared gradient norm.  Spread over the
+    // waves: the x3 Gram's per-thread part only occupies threads 0..255, so the serial pieces - the statistics / LR rule, the products
+    // dmu_a . dmu_b and the column sums of the head terms - run on waves 4..6 in front of the SAME block reduction instead of in two more
+    // barrier-separated phases after it (3.1 -> about 2 us: this shadow was the longest overrun of its edge, section 4b of DESIGN.md).
+    if (tid == 384) {
       PLds::Ctl& C = S.ctl;
       float t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
       for (int s = 0; s < MB; ++s) { t1 += S.stat[s][1]; t2 += S.stat[s][2]; t3 += S.stat[s][3]; t4 += S.stat[s][4]; t5 += S.stat[s][5]; t6 += S.stat[s][6]; }
@@ -1084,46 +1087,37 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
     }
     if constexpr (!SINGLE) {
-    {
       float p[33];
 #pragma unroll
       for (int i = 0; i < 33; ++i) p[i] = 0.0f;
       if (tid < U2) {
 #pragma unroll
         for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.x3[net][0][tid], S.x3[net][1][tid], S.x3[net][2][tid], S.x3[net][3][tid]);
-      }
-      block_sum<33>(S, p, S.part, tid, wave, lane);
-      if (tid < 48) S.gx[tid >> 4][3][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-      __syncthreads();
-    }
-    // squared-norm contributions of the heads and logstd
-    {
-      // thread (net, a, b) forms one Gram product; reduce through LDS
-      if (tid < 48) {
-        const int net = tid / 16, a = (tid / 4) % 4, b = tid % 4;
+      } else if (tid >= 256 && tid < 256 + 48) {       // thread (net, a, b): the heads' gradient product that multiplies G_x3[a][b]
+        const int t = tid - 256, net = t / 16, a = (t / 4) % 4, b = t % 4;
         float dd = 0.0f;
         if (net == 0) { for (int j = 0; j < A; ++j) dd += S.dmu[a][j] * S.dmu[b][j]; }
         else dd = S.dv[net - 1][a] * S.dv[net - 1][b];
-        S.part[tid] = dd * S.gx[net][3][a * 4 + b];
-      } else if (tid >= 64 && tid < 64 + 32) {
-        const int j = tid - 64;
+        S.part[128 + t] = dd;
+      } else if (tid >= 320 && tid < 320 + 32) {       // bias of the policy head and logstd: |sum_s dmu_s[j]|^2 + dlogstd[j]^2
+        const int j = tid - 320;
         float t = 0.0f;
         if (j < A) { float sb = 0; for (int a = 0; a < MB; ++a) sb += S.dmu[a][j]; t = sb * sb + S.dls[j] * S.dls[j]; }
-        S.part[tid] = t;
+        S.part[192 + j] = t;
       }
-      SDX_LDS_BARRIER();
-      // first look at this lane's dY1 words (the shadow has outlasted the edge: 3.0 us against 2.1); the sums below hide the round trip
-      lq_peek<4>(LQ, LQ_DY1 + tid, NTH, pdy1); pdy1_issued = true;
-      if (tid < 3) {
-        const int net = tid;
+      block_sum<33>(S, p, S.part, tid, wave, lane);    // (its barriers also publish S.part[128 ..] above)
+      if (tid < 48) S.gx[tid >> 4][3][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
+      else if (tid >= 64 && tid < 67) {                // squared-norm contributions of the heads and logstd
+        const int net = tid - 64;
         float acc = 0.0f;
-        for (int i = 0; i < 16; ++i) acc += S.part[net * 16 + i];
-        if (net == 0) { for (int j = 0; j < A; ++j) acc += S.part[64 + j]; }
+        for (int i = 0; i < 16; ++i) acc += S.part[128 + net * 16 + i] * S.part[net * 11 + tri16(i)];
+        if (net == 0) { for (int j = 0; j < A; ++j) acc += S.part[192 + j]; }
         else { float sb = 0; for (int a = 0; a < MB; ++a) sb += S.dv[net - 1][a]; acc += sb * sb; }
         S.ctl.n2h[net] = acc;
       }
+      // first look at this lane's dY1 words (the polling gather of phase E takes over if a producer is late)
+      lq_peek<4>(LQ, LQ_DY1 + tid, NTH, pdy1); pdy1_issued = true;
       SDX_LDS_BARRIER();
-    }
     }
     TS(15)
     refresh();
