@@ -195,6 +195,10 @@ __device__ __forceinline__ void gram_acc(float* p, float a, float b, float c, fl
   const float sb = a + b + c + d;
   p[10] += sb * sb;
 }
+__device__ __forceinline__ void gram_acc10(float* p, float a, float b, float c, float d) {   // the 10 entries only (inputs: no bias term)
+  p[0] += a * a; p[1] += b * a; p[2] += b * b; p[3] += c * a; p[4] += c * b; p[5] += c * c;
+  p[6] += d * a; p[7] += d * b; p[8] += d * c; p[9] += d * d;
+}
 __device__ __forceinline__ int tri16(int i) { const int a = i >> 2, b = i & 3, hi = a > b ? a : b, lo = a > b ? b : a; return hi * (hi + 1) / 2 + lo; }
 // sums over each 32-lane half of the wave; valid in lanes 16..31 and 48..63
 __device__ __forceinline__ float half_sum(float v) {
@@ -209,11 +213,12 @@ template <int CTRL, int BANK>
 __device__ __forceinline__ float dpp_mov(float old, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xF, BANK, false));
 }
+// the two halving levels + the two levels inside the 16-lane DPP row: u2[j] = sum over the row's lanes of value 4 j + (lane & 3)
 template <int N>
-__device__ __forceinline__ void block_sum(PLds& S, const float (&v)[N], float* out, int tid, int wave, int lane) {
+__device__ __forceinline__ void row_butterfly(const float (&v)[N], float (&u2)[(N + 3) / 4], int lane) {
   constexpr int N4 = (N + 3) / 4;
   const bool b0 = lane & 1, b1 = lane & 2;
-  float u1[2 * N4], u2[N4];
+  float u1[2 * N4];
 #pragma unroll
   for (int j = 0; j < 2 * N4; ++j) {
     const float e = 2 * j < N ? v[2 * j] : 0.0f, o = 2 * j + 1 < N ? v[2 * j + 1] : 0.0f;
@@ -230,21 +235,33 @@ __device__ __forceinline__ void block_sum(PLds& S, const float (&v)[N], float* o
     t += dpp_mov<0x128, 0xF>(0.0f, t);                       // lane ^ 8 (row_ror:8): sum over the 16-lane row
     u2[j] = t;
   }
+}
+template <int N4>
+__device__ __forceinline__ void rows_store(PLds& S, const float (&u2)[N4], int off, int wave, int lane) {
   if ((lane & 15) < 4) {
-    float* r = S.red[wave * 4 + (lane >> 4)];
+    float* r = S.red[wave * 4 + (lane >> 4)] + off;
 #pragma unroll
     for (int j = 0; j < N4; ++j) r[4 * j + (lane & 3)] = u2[j];
   }
-  // LDS-only barriers (sdx_common.h): __syncthreads() also waits for the wave's outstanding global accesses - in the shadows that is the
-  // acknowledgement of the exchange words just published and the next minibatch's prefetched rows; nothing here is ordered through HBM
+}
+// LDS-only barriers (sdx_common.h): __syncthreads() also waits for the wave's outstanding global accesses - in the shadows that is the
+// acknowledgement of the exchange words just published and the next minibatch's prefetched rows; nothing here is ordered through HBM
+__device__ __forceinline__ void rows_reduce(PLds& S, int n, float* out, int tid) {
   SDX_LDS_BARRIER();
-  if (tid < N) {
+  if (tid < n) {
     float t = 0.0f;
 #pragma unroll
     for (int w = 0; w < 4 * NWV; ++w) t += S.red[w][tid];
     out[tid] = t;
   }
   SDX_LDS_BARRIER();
+}
+template <int N>
+__device__ __forceinline__ void block_sum(PLds& S, const float (&v)[N], float* out, int tid, int wave, int lane) {
+  float u2[(N + 3) / 4];
+  row_butterfly<N>(v, u2, lane);
+  rows_store<(N + 3) / 4>(S, u2, 0, wave, lane);
+  rows_reduce(S, N, out, tid);
 }
 
 static_assert(sizeof(PLds) + 512 <= 160 * 1024, "PLds (+ the static logstd bank) must fit the 160 KiB LDS of a gfx950 CU");
@@ -659,18 +676,8 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         lq_store(LQ, LQ_X2 + (unsigned)s * U1 + 2 * g + r, y[0], y[1], y[2], tag);
       }
       TS(5)
-      if constexpr (!SINGLE) {
-      // ---- (shadow of x2) Gram of x1
-      float p[33];
-#pragma unroll
-      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
-#pragma unroll
-      for (int h = 0; h < U0 / NTH; ++h)
-#pragma unroll
-        for (int net = 0; net < 3; ++net) { const int k = tid + NTH * h; gram_acc(&p[net * 11], S.x1[net][0][k], S.x1[net][1][k], S.x1[net][2][k], S.x1[net][3][k]); }
-      block_sum<33>(S, p, S.part, tid, wave, lane);
-      if (tid < 48) S.gx[tid >> 4][1][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-      }
+      // (the Gram of x1 used to sit here: this shadow was 2.7 us against an edge of 2.1; it now shares ONE block reduction with the
+      // Gram of x2 in the shadow of x3 - 60 values through the butterfly instead of 2 x 33 through two of them)
     }
     refresh();
     u32x4 px2[4];
@@ -788,18 +795,37 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       lq_store(LQ, LQ_X3 + (unsigned)s * U2 + g, y[0], y[1], y[2], tag);
     }
     TS(8)
-    if constexpr (!SINGLE)
-    {   // ---- (shadow of x3) Gram of x2
-      float p[33];
-#pragma unroll
-      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
-#pragma unroll
-      for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.x2[net][0][tid], S.x2[net][1][tid], S.x2[net][2][tid], S.x2[net][3][tid]);
-      block_sum<33>(S, p, S.part, tid, wave, lane);
-      if (tid < 48) S.gx[tid >> 4][2][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-    }
+    // (this minibatch's actions and old (mu, sigma) go to LDS before the Grams: three registers fewer across the 60-value reduction)
     if (tid < MB * 32) { S.act[tid / 32][tid % 32] = pf_act; S.omu[tid / 32][tid % 32] = pf_omu; S.osg[tid / 32][tid % 32] = pf_osg; }
     if (tid >= 128 && tid < 128 + 32) S.ls[tid - 128] = (tid - 128 < A) ? s_b2[0][tid - 128] : 0.0f;
+    if constexpr (!SINGLE)
+    {   // ---- (shadow of x3) Grams of x2 and x1 (S.x1 stays valid until the next step's gather).  Two butterflies, ONE pass through LDS
+        // and its two barriers: out[0..29] = [x2: net][10], out[32..61] = [x1: net][10]
+      float ua[8], ub[8];
+      {
+        float p[30];
+#pragma unroll
+        for (int i = 0; i < 30; ++i) p[i] = 0.0f;
+#pragma unroll
+        for (int net = 0; net < 3; ++net) gram_acc10(&p[net * 10], S.x2[net][0][tid], S.x2[net][1][tid], S.x2[net][2][tid], S.x2[net][3][tid]);
+        row_butterfly<30>(p, ua, lane);
+      }
+      rows_store<8>(S, ua, 0, wave, lane);
+      {
+        float p[30];
+#pragma unroll
+        for (int i = 0; i < 30; ++i) p[i] = 0.0f;
+#pragma unroll
+        for (int h = 0; h < U0 / NTH; ++h)
+#pragma unroll
+          for (int net = 0; net < 3; ++net) { const int k = tid + NTH * h; gram_acc10(&p[net * 10], S.x1[net][0][k], S.x1[net][1][k], S.x1[net][2][k], S.x1[net][3][k]); }
+        row_butterfly<30>(p, ub, lane);
+      }
+      rows_store<8>(S, ub, 32, wave, lane);
+      rows_reduce(S, 64, S.part, tid);
+      if (tid < 48) S.gx[tid >> 4][2][tid & 15] = S.part[(tid >> 4) * 10 + tri16(tid & 15)];
+      else if (tid >= 64 && tid < 64 + 48) { const int t = tid - 64; S.gx[t >> 4][1][t & 15] = S.part[32 + (t >> 4) * 10 + tri16(t & 15)]; }
+    }
     TS(9)
     refresh();
     // ================================================================== phase D: gather x3 and the heads, losses, backward to dY1
