@@ -2,13 +2,12 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/r4z
+O=gpurun_out/r4zz
 mkdir -p $O
 timeout 120 python -m pytest tests/test_gpu_fullsize_properties.py -q -m gpu -s -k "pump_energy" 2>&1 | grep -E "fastest|bricks outside|passed|failed|^E " | head
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -15 > $O/gputests.txt; tail -6 $O/gputests.txt
 timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
 timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-large-minibatch > $O/bench_protocol.json 2>> $O/bench.err; echo "protocol rc $?"
-timeout 400 python bench.py --pretrain-epochs 200 --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch > $O/bench_trained200.json 2>> $O/bench.err; echo "trained200 rc $?"
 SDX_FORCE_MULTI_RANK=1 timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-large-minibatch > $O/bench_fmr.json 2>> $O/bench.err; echo "fmr rc $?"
 python - <<PY
 import json
