@@ -90,10 +90,12 @@ def test_narrow_tile_shape(lib, bf):
 
 @pytest.mark.parametrize("bf", [0, 1])
 @pytest.mark.parametrize("epi", [EPI_FWD, EPI_NN])
-def test_wide_tile_shape_all_copies(lib, bf, epi):
-    """the 128 x 128 tile: two passes of the transposed epilogue (64 columns each), 19 workgroups through the XCD remap, ragged edges"""
+@pytest.mark.parametrize("M", [270, 272])
+def test_wide_tile_shape_all_copies(lib, bf, epi, M):
+    """the 128 x 128 tile: two passes of the transposed epilogue (64 columns each), 19 workgroups through the XCD remap, ragged edges
+    (M = 270) and whole 16-byte pieces along the rows (M = 272)"""
     rng = np.random.default_rng(17 + bf + epi)
-    M, N, K = 270, 300, 128
+    N, K = 300, 128
     A, Av = _elems(rng.standard_normal((M, K)) * 0.4, bf)
     B, Bv = _elems(rng.standard_normal((N, K)) * 0.4, bf)
     bias = rng.standard_normal(N).astype(np.float32)
