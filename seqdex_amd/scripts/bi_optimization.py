@@ -203,6 +203,56 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
     return paths, tv
 
 
+# (InsertSim's update is GEMM-shaped - 50 ms per epoch at 4096 envs - so three episodes cost 2.5 s; an insert policy of that age inserts
+# nothing yet, and 300 epochs from scripted-grasp states gave 10 insertions in 1.2 M episodes: the first refit is skipped, with its reason)
+CONFIG5_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 48, "insert_backward": 32}
+
+
+def one_round_at_size(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=300, workdir=None):
+    """BASELINE.json configs[4] on ONE GPU: one round of block_assembly() at `num_envs` envs (Search and the backward Orient leg at the
+    reference's 128, bi_optimization.py:111,124) with `mixed_precision` in every stage's PPO YAML and each task's shipped minibatch size;
+    epochs per stage long enough for episodes to finish (CONFIG5_EPOCHS).  Returns (report dict with per-stage rates and every hand-off,
+    checkpoint paths, fitted transition value or None).  tools/bench_config5.py is its command line, tests/test_gpu_bi_optimization_fullsize.py
+    its test; what is a stand-in is listed in the report (`stand_ins`)."""
+    import tempfile
+    import time
+    stage_epochs = dict(CONFIG5_EPOCHS, **(stage_epochs or {}))
+    cwd = os.getcwd()
+    tmp = workdir or tempfile.mkdtemp(prefix="sdx_config5_")     # logs/<task>/nn/<task>.pth checkpoints are hand-offs inside the run
+    os.chdir(tmp)
+    report = []
+    torch.cuda.synchronize()
+    t0 = time.time()
+    try:
+        paths, tv = block_assembly(rounds=1, num_envs=num_envs, tvalue_rollout=tvalue_rollout, mixed_precision=mixed_precision, report=report,
+                                   stage_epochs=stage_epochs, grasp_harvest_stand_in=True, gates={"orient": 0.0, "grasp": 0.0},
+                                   gates_after_fit={"orient": 0.5, "grasp": 0.28})
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    paths = {k: os.path.join(tmp, v) for k, v in paths.items()}          # (logs/<task>/nn/<task>.pth relative to the work directory)
+    runs = [r for r in report if "task" in r]
+    hand = [r for r in report if "handoff" in r]
+    steps = sum(r["env_steps"] for r in runs)
+    train_s = sum(r["wall_s"] for r in runs)
+    out = {"config": "BASELINE.json configs[4] on one GPU: bi-optimisation loop Search -> Orient -> GraspSim -> InsertSim + three backward legs, "
+                     "num_envs=%d (Search 128, backward Orient 128), %s, shipped minibatch sizes" % (num_envs, "mixed_precision: True (bf16 MFMA on "
+                     "GEMM-shaped updates)" if mixed_precision else "fp32"),
+           "metric": "env-steps/s over the seven training runs of one round (rollout + PPO update; task construction and T-value fits excluded)",
+           "value": steps / train_s, "unit": "env-steps/s", "env_steps": steps, "training_wall_s": train_s, "loop_wall_s_incl_setup_and_fits": wall,
+           "n_gpus": 1, "configs4_on_8_gpus": "not run: no multi-GPU box has ever been available to this build (gpurun: 1 GPU)",
+           "stage_epochs": stage_epochs, "tvalue_fit_iterations": tvalue_rollout,
+           "stand_ins": ["harvest gates 0.0 in the forward pass of this first round: no transition value has been fitted before it; 0.5 / 0.28 "
+                         "(not the reference's 0.99 / 0.8) in the backward legs",
+                         "grasp terminal states, and the successes of the backward grasp leg's fit, from evaluation.scripted_grasp_controller on the "
+                         "trained task when the 20-epoch policy produced (almost) none"],
+           "runs": runs, "handoffs": hand, "checkpoints": paths, "tvalue_fitted": tv is not None}
+    return out, paths, tv
+
+
+
+
 if __name__ == "__main__":
     p = argparse.ArgumentParser()
     p.add_argument("--tasks", type=str, default="BlockAssembly")

@@ -15,11 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 def test_bi_optimization_round_at_4096_envs_with_the_bf16_policy(tmp_path):
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import bench_config5
+    from seqdex_amd.scripts.bi_optimization import one_round_at_size
     t0 = time.time()
-    res, paths, tv = bench_config5.run(4096, True, workdir=str(tmp_path))
+    res, paths, tv = one_round_at_size(4096, True, workdir=str(tmp_path))
     wall = time.time() - t0
     print(json.dumps({k: v for k, v in res.items() if k not in ("runs", "handoffs")}))
     if os.environ.get("SDX_TEST_ARTIFACTS"):                      # the builder's GPU calls keep the full report (profiles/r4_config5_*)

@@ -27,53 +27,10 @@ import argparse
 import json
 import os
 import sys
-import tempfile
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-
-# (InsertSim's update is GEMM-shaped - 50 ms per epoch at 4096 envs - so three episodes cost 2.5 s; an insert policy of that age inserts
-# nothing yet, and 300 epochs from scripted-grasp states gave 10 insertions in 1.2 M episodes: the first refit is skipped, with its reason)
-DEFAULT_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 48, "insert_backward": 32}
-
-
-def run(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=300, workdir=None):
-    import torch
-    from seqdex_amd.scripts import bi_optimization as bo
-    stage_epochs = dict(DEFAULT_EPOCHS, **(stage_epochs or {}))
-    cwd = os.getcwd()
-    tmp = workdir or tempfile.mkdtemp(prefix="sdx_config5_")     # logs/<task>/nn/<task>.pth checkpoints are hand-offs inside the run
-    os.chdir(tmp)
-    report = []
-    torch.cuda.synchronize()
-    t0 = time.time()
-    try:
-        paths, tv = bo.block_assembly(rounds=1, num_envs=num_envs, tvalue_rollout=tvalue_rollout, mixed_precision=mixed_precision, report=report,
-                                      stage_epochs=stage_epochs, grasp_harvest_stand_in=True, gates={"orient": 0.0, "grasp": 0.0},
-                                      gates_after_fit={"orient": 0.5, "grasp": 0.28})
-    finally:
-        os.chdir(cwd)
-    torch.cuda.synchronize()
-    wall = time.time() - t0
-    paths = {k: os.path.join(tmp, v) for k, v in paths.items()}          # (logs/<task>/nn/<task>.pth relative to the work directory)
-    runs = [r for r in report if "task" in r]
-    hand = [r for r in report if "handoff" in r]
-    steps = sum(r["env_steps"] for r in runs)
-    train_s = sum(r["wall_s"] for r in runs)
-    out = {"config": "BASELINE.json configs[4] on one GPU: bi-optimisation loop Search -> Orient -> GraspSim -> InsertSim + three backward legs, "
-                     "num_envs=%d (Search 128, backward Orient 128), %s, shipped minibatch sizes" % (num_envs, "mixed_precision: True (bf16 MFMA on "
-                     "GEMM-shaped updates)" if mixed_precision else "fp32"),
-           "metric": "env-steps/s over the seven training runs of one round (rollout + PPO update; task construction and T-value fits excluded)",
-           "value": steps / train_s, "unit": "env-steps/s", "env_steps": steps, "training_wall_s": train_s, "loop_wall_s_incl_setup_and_fits": wall,
-           "n_gpus": 1, "configs4_on_8_gpus": "not run: no multi-GPU box has ever been available to this build (gpurun: 1 GPU)",
-           "stage_epochs": stage_epochs, "tvalue_fit_iterations": tvalue_rollout,
-           "stand_ins": ["harvest gates 0.0 in the forward pass of this first round: no transition value has been fitted before it; 0.5 / 0.28 "
-                         "(not the reference's 0.99 / 0.8) in the backward legs",
-                         "grasp terminal states, and the successes of the backward grasp leg's fit, from evaluation.scripted_grasp_controller on the "
-                         "trained task when the 20-epoch policy produced (almost) none"],
-           "runs": runs, "handoffs": hand, "checkpoints": paths, "tvalue_fitted": tv is not None}
-    return out, paths, tv
+from seqdex_amd.scripts.bi_optimization import CONFIG5_EPOCHS as DEFAULT_EPOCHS, one_round_at_size as run  # noqa: E402,F401
 
 
 if __name__ == "__main__":
