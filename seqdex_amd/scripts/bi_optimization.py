@@ -176,7 +176,7 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
         if report is not None:
             report[-1].update(outcomes_success_failure=insert.sim.TV_COUNT.cpu().tolist())
         insert.sim.close()
-        orient_kw, grasp_kw = gate_kw()                                                   # a transition value exists from here on
+        orient_kw, grasp_kw = gate_kw()                                                   # a transition value may exist from here on
         paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, use_t_value=True, policy_path=paths["grasp"],
                                              max_iterations=se("grasp_backward"), tvalue_state=tv, keep=True,
                                              task_kwargs=dict(grasp_kw, initial_piles=piles), leg="backward", **mp)
@@ -190,6 +190,7 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
         if report is not None:
             report[-1].update(outcomes_by=outcomes_by, outcomes_success_failure=grasp.sim.TV_COUNT.cpu().tolist())
         grasp.sim.close()
+        orient_kw, grasp_kw = gate_kw()                                                   # (the insert leg's fit may have been skipped and this one not)
         paths["orient"], orient = main_rlgames("BlockAssemblyOrient", min(num_envs, orient_backward_envs), use_t_value=True, policy_path=paths["orient"],
                                                max_iterations=se("orient_backward"), tvalue_state=tv, keep=True,
                                                task_kwargs=dict(orient_kw, initial_piles=dug), leg="backward", **mp)   # :123
