@@ -92,3 +92,32 @@ def test_without_fallback_the_chain_refuses_as_the_reference_does(monkeypatch):
     with pytest.raises(RuntimeError, match="harvested no grasp terminal state"):
         ev.block_assembly_chain(64, None, synthetic_fallback=False, orient_tvalue_gate=0.99, grasp_tvalue_gate=0.8)
     assert calls == [("orient", 0.99), ("grasp", 0.8)]
+
+
+def test_checkpoint_driven_evaluation_plays_the_stages_in_order_and_hands_their_states_on(monkeypatch):
+    """block_assembly(): scripts/evaluation.py:111-119 - every stage restored from its checkpoint through the launcher's command line, the
+    pile / grasp states of a stage are what the next one is constructed with; Search only when a checkpoint is given, at <= 128 envs"""
+    from seqdex_amd.scripts import evaluation as ev
+    calls = []
+    dug, piles = torch.zeros(8, 9, 132, 13), torch.ones(8, 11, 132, 13)
+    states = ([torch.zeros(2, 1, 13)] * 8, [torch.zeros(2, 23, 2)] * 8)
+
+    def fake_play(task, num_envs, play=True, use_t_value=False, policy_path="", games=0, task_kwargs=None, minibatch_size=0):
+        calls.append((task, num_envs, use_t_value, policy_path, games, dict(task_kwargs or {}), minibatch_size))
+        sim = _Sim(HARVEST_COUNT=torch.full((8,), 2, dtype=torch.int32))
+        obj = types.SimpleNamespace(sim=sim, extras={"success_buf": torch.tensor([1.0, 0.0])}, grasp_states_source="given",
+                                    pile_terminal_states=lambda: dug if task == "BlockAssemblySearch" else piles, grasp_terminal_states=lambda: states)
+        return 1.5, 75.0, obj
+
+    monkeypatch.setattr(ev, "play_checkpoint", fake_play)
+    out = ev.block_assembly("o.pth", "g.pth", "i.pth", num_envs=512, games=64, insert_minibatch=1024, search_path="s.pth")
+    assert [c[0] for c in calls] == ["BlockAssemblySearch", "BlockAssemblyOrient", "BlockAssemblyGraspSim", "BlockAssemblyInsertSim"]
+    assert [c[1] for c in calls] == [128, 512, 512, 512] and [c[3] for c in calls] == ["s.pth", "o.pth", "g.pth", "i.pth"]
+    assert all(c[2] for c in calls) and all(c[4] == 64 for c in calls)                     # use_t_value on, --games for every stage
+    assert calls[1][5]["initial_piles"] is dug and calls[2][5]["initial_piles"] is piles and calls[3][5]["grasp_states"] is states
+    assert calls[3][6] == 1024 and calls[0][6] == 0
+    assert out["BlockAssemblySearch"]["piles_handed_on"] == 9 and out["BlockAssemblyOrient"]["piles_handed_on"] == 11
+    assert out["BlockAssemblyGraspSim"]["grasp_states_handed_on"] == 16 and out["BlockAssemblyInsertSim"]["insert_success_rate"] == 0.5
+    calls.clear()
+    ev.block_assembly("o.pth", "g.pth", "i.pth", num_envs=64)                              # no Search checkpoint: three stages, Orient settles its own piles
+    assert [c[0] for c in calls] == ["BlockAssemblyOrient", "BlockAssemblyGraspSim", "BlockAssemblyInsertSim"] and calls[0][5]["initial_piles"] is None

@@ -201,3 +201,21 @@ def test_chain_fills_missing_pile_groups_from_settled_piles(monkeypatch):
     assert fill_missing_pile_groups(harvest, torch.full((8,), 12), 8, seed=5) == (None, [])
     assert fill_missing_pile_groups(harvest, torch.tensor([0, 0, 0, 12, 12, 12, 12, 12]), 8, seed=5) == (None, [])
     assert calls == [(9, 5)]
+
+
+def test_ring_rows_returns_the_appends_in_serial_step_env_order():
+    """SdxSim.ring_rows: ring slots are claimed with atomics, i.e. in hardware order; the (step << 24 | env) keys
+    written with every append give back the order a serial loop over steps and envs produces - what makes the chain identical run to run"""
+    import torch
+    from seqdex_amd.sim import SdxSim
+    key = lambda step, env: (step << 24) | env
+    keys = torch.tensor([key(3, 7), key(1, 900), key(3, 2), key(1, 4), key(2, 0), 0, 0, 0], dtype=torch.int64)
+    rows = torch.arange(8, dtype=torch.float32).view(8, 1).repeat(1, 3)                     # row i carries the value i
+    got = SdxSim.ring_rows(None, rows, keys, 5)
+    assert got[:, 0].tolist() == [3.0, 1.0, 4.0, 2.0, 0.0]                                  # (1,4) (1,900) (2,0) (3,2) (3,7)
+    assert SdxSim.ring_rows(None, rows, keys, 0).shape == (0, 3)
+    full = SdxSim.ring_rows(None, rows, torch.arange(8, 0, -1), 100)                       # more appends than slots: every slot is filled
+    assert full[:, 0].tolist() == [7.0, 6.0, 5.0, 4.0, 3.0, 2.0, 1.0, 0.0]
+    g = SdxSim.ring_rows(None, rows, keys, 5)
+    g[0, 0] = -1.0
+    assert rows[3, 0] == 3.0                                                                # a copy, not a view of the ring
