@@ -407,6 +407,131 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtBatch nb, int nx, int ny) 
   }
 }
 
+// ---- fp32 weight gradient straight from the [row][feature] arrays ("TT": both operands reduction-major).  G[n][k] = sum_r A[r][n] B[r][k]
+// over the rows [z kchunk, min(K, (z + 1) kchunk)) of split z: A = dY_l [rows][N_l], B = the layer input [rows][K_l], i.e. the arrays
+// the forward and data-gradient products write and read anyway.  With it an fp32 run needs NO transposed copy of an activation or
+// gradient (the forward / data-gradient epilogues write one image instead of two, the data gradient reads the layer output once).
+//   * a chunk is 32 rows; the tile's A part is 32 x 128 floats (512-byte row pieces), B 32 x (64 WTN) floats; global_load_lds_dwordx4,
+//     lane-linear = row-major LDS image; rows past the split's end come from a page of zeros (a per-lane address select: the loop body
+//     stays branch-free, see the note on branches between MFMAs above);
+//   * v_mfma_f32_32x32x2_f32 takes one reduction index per half-wave: lane (i, h) reads A[2 t + h][i] and B[2 t + h][j] as single dwords -
+//     32 consecutive floats per half-wave, conflict-free - 4 reads per 4 MFMAs, all 64 of a chunk requested up front;
+//   * NtArgs: A / lda, B / ldb as above, M = N_l (rows of G), N = K_l (columns of G), K = number of rows, kchunk a multiple of 32;
+//     Cf / ldc / cz split partials, rowsum = column sums of A (the bias gradient), as EPI_TN.
+template <int WTN>
+__global__ __launch_bounds__(256, 2) void k_gemm_tt(NtBatch nb, int nx, int ny, const float* zeros) {
+  constexpr int TM = 128, TN = 64 * WTN, RC = 32;
+  constexpr int ASTAGE = RC * TM * 4, BSTAGE = RC * TN * 4, STAGE = ASTAGE + BSTAGE;
+  constexpr int NA = ASTAGE / 1024 / 4, NB = BSTAGE / 1024 / 4;          // global_load_lds instructions per wave per chunk
+  constexpr int RPB = 1024 / (TN * 4);                                    // B rows per instruction (2 for the 128-wide tile, 4 for 64)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int total = (int)gridDim.x;
+  int wg;
+  {
+    const int id = (int)blockIdx.x, q = total >> 3, r = total & 7, xcd = id & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int bx = wg % nx, by = (wg / nx) % ny, bz = wg / (nx * ny);
+  const NtArgs& g = nb.a[bz / nb.splits];
+  const int zs = bz % nb.splits;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = by * TM, j0 = bx * TN;
+  if (i0 >= g.M || j0 >= g.N) return;
+  const int rbeg = zs * g.kchunk, rend = min(g.K, rbeg + g.kchunk);
+  const int nc = (rend - rbeg + RC - 1) / RC;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (32 * WTN);
+  // loader: instruction p of the A part covers rows 2 p, 2 p + 1 of the chunk (lane: row lane >> 5, 16-byte piece lane & 31); columns past
+  // the array's width are clamped into it (their products belong to outputs that are never stored)
+  const float* Ab = static_cast<const float*>(g.A);
+  const float* Bb = static_cast<const float*>(g.B);
+  int arow[NA], brow[NB];
+  const int acol = min(i0 + 4 * (lane & 31), g.lda - 4);
+  const int bcol = min(j0 + 4 * (lane & (TN / 4 - 1)), g.ldb - 4);
+#pragma unroll
+  for (int p = 0; p < NA; ++p) arow[p] = 2 * (wave * NA + p) + (lane >> 5);
+#pragma unroll
+  for (int p = 0; p < NB; ++p) brow[p] = RPB * (wave * NB + p) + lane / (TN / 4);
+  auto issue = [&](int c, int s) {
+    char* sa = smem + s * STAGE;
+    const int r0 = rbeg + c * RC;
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int r = r0 + arow[p];
+      const float* src = r < rend ? Ab + (size_t)r * g.lda + acol : zeros;
+      __builtin_amdgcn_global_load_lds(SDX_AS_GLOBAL(src), SDX_AS_LDS(sa + (wave * NA + p) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int r = r0 + brow[p];
+      const float* src = r < rend ? Bb + (size_t)r * g.ldb + bcol : zeros;
+      __builtin_amdgcn_global_load_lds(SDX_AS_GLOBAL(src), SDX_AS_LDS(sa + ASTAGE + (wave * NB + p) * 1024), 16, 0, 0);
+    }
+  };
+  f32x16 acc[2][WTN];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < WTN; ++v)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[u][v][i] = 0.0f;
+  float rs[2] = {0.0f, 0.0f};
+  const bool do_rs = bx == 0;
+  const int foff = ((lane >> 5) * TM + wm + (lane & 31)) * 4, goff = ((lane >> 5) * TN + wn + (lane & 31)) * 4;
+  auto chunks = [&](auto rs_tag) {
+    constexpr bool RS = decltype(rs_tag)::value;
+    if (nc > 0) issue(0, 0);
+    for (int c = 0; c < nc; ++c) {
+      SDX_WAIT_VMCNT0();
+      __syncthreads();
+      if (c + 1 < nc) issue(c + 1, (c + 1) & 1);
+      const char* sa = smem + (c & 1) * STAGE + foff;
+      const char* sb = smem + (c & 1) * STAGE + ASTAGE + goff;
+      float a[16][2], b[16][WTN];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) a[t][u] = *reinterpret_cast<const float*>(sa + t * (2 * TM * 4) + u * 128);
+#pragma unroll
+        for (int v = 0; v < WTN; ++v) b[t][v] = *reinterpret_cast<const float*>(sb + t * (2 * TN * 4) + v * 128);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < WTN; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][u], b[t][v], acc[u][v], 0, 0, 0);
+        if constexpr (RS) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) rs[u] += a[t][u];
+        }
+      }
+    }
+  };
+  if (do_rs) chunks(std::true_type{}); else chunks(std::false_type{});
+  if (do_rs) {                                       // lanes l and l + 32 hold the sums over the even / odd rows of column (l & 31)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float t = rs[u] + __shfl_xor(rs[u], 32, 64);
+      const int row = i0 + wm + 32 * u + (lane & 31);
+      if ((wave & 1) == 0 && lane < 32 && row < g.M) g.rowsum[(size_t)zs * g.cz + row] = t;
+    }
+  }
+  float* Cf = g.Cf + (size_t)zs * g.cz;
+#pragma unroll
+  for (int v = 0; v < WTN; ++v) {
+    const int col = j0 + wn + 32 * v + (lane & 31);
+    if (col >= g.N) continue;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M) Cf[(size_t)row * g.ldc + col] = acc[u][v][r];
+      }
+  }
+}
+
 // ---- staging: src fp32 [R][K] (row stride lds) -> dn [R][ldn] in the element type with columns K .. Kp zeroed, and / or its transpose
 // dt [Kp][ldt] (rows K .. Kp zeroed; columns R .. ldt are never written: they stay as allocated, i.e. zero).  64 x 64 tiles through LDS.
 struct StageArgs { const float* src; int lds, R, K, Kp; void* dn; int ldn; void* dt; int ldt; };
@@ -461,4 +586,28 @@ static void gemm_nt(const NtArgs* gs, int count, int splits, hipStream_t st) {
   const int nz = splits * count;
   if (wide) hipLaunchKernelGGL((k_gemm_nt<BF, EPI, 2>), dim3(nx2 * ny * nz), dim3(256), 2 * 256 * 128, st, nb, nx2, ny);
   else hipLaunchKernelGGL((k_gemm_nt<BF, EPI, 1>), dim3(nx1 * ny * nz), dim3(256), 2 * 192 * 128, st, nb, nx1, ny);
+}
+
+// launcher of k_gemm_tt: tile choice as gemm_nt; `zeros`: 16-byte aligned device memory holding at least 16 zero bytes
+static void gemm_tt(const NtArgs* gs, int count, int splits, const float* zeros, hipStream_t st) {
+  NtBatch nb;
+  int Mx = 0, Nx = 0;
+  for (int q = 0; q < 3; ++q) {
+    nb.a[q] = gs[q < count ? q : 0];
+    if (q < count) { Mx = gs[q].M > Mx ? gs[q].M : Mx; Nx = gs[q].N > Nx ? gs[q].N : Nx; }
+  }
+  nb.splits = splits;
+  const int ny = (Mx + 127) / 128, nx2 = (Nx + 127) / 128, nx1 = (Nx + 63) / 64;
+  const long b2 = (long)nx2 * ny * splits * count;
+  static const int forced = getenv("SDXP_NT_TILE") ? atoi(getenv("SDXP_NT_TILE")) : 0;
+  const bool wide = forced ? forced == 2 : (b2 >= 512 && nx2 * 128 <= nx1 * 64 * 1.10);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 256 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tt<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 192 * 4);
+    attr = true;
+  }
+  const int nz = splits * count;
+  if (wide) hipLaunchKernelGGL((k_gemm_tt<2>), dim3(nx2 * ny * nz), dim3(256), 2 * 32 * 256 * 4, st, nb, nx2, ny, zeros);
+  else hipLaunchKernelGGL((k_gemm_tt<1>), dim3(nx1 * ny * nz), dim3(256), 2 * 32 * 192 * 4, st, nb, nx1, ny, zeros);
 }

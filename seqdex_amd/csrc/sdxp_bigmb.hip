@@ -354,7 +354,7 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
         // bf16 runs keep the outputs of layers 0 and 1 in bf16 only (both orientations): the next layer, the weight gradient and the
         // ELU' of the backward pass read those; the last trunk layer stays fp32 for the fp32 heads
         g[net] = {A, l == 0 ? kp : D.units[l - 1], ws->wn[net][l], kp, MB, D.units[l], kp, kp, (D.bf16 && l < 2) ? nullptr : ws->h[net][l], D.units[l], 0,
-                  (D.bf16 && l < 2) ? ws->hn[net][l] : nullptr, D.units[l], l < 2 ? ws->ht[net][l] : nullptr, ws->MBp,
+                  (D.bf16 && l < 2) ? ws->hn[net][l] : nullptr, D.units[l], (l < 2 && !ws->tt) ? ws->ht[net][l] : nullptr, ws->MBp,
                   P[net] + boff(net, l), nullptr, 0, nullptr, 0, nullptr};
       }
       if (D.bf16) gemm_nt<1, EPI_FWD>(g, 3, 1, st); else gemm_nt<0, EPI_FWD>(g, 3, 1, st);
@@ -404,7 +404,7 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
   }
   // ---- trunk backward, layer by layer for the three networks at once
   if (ws->nt) {
-    {   // the head kernels left dLoss/d(pre-activation of trunk layer 2) in fp32: element-type copy + transpose
+    if (!ws->tt) {   // the head kernels left dLoss/d(pre-activation of trunk layer 2) in fp32: element-type copy + transpose
       StageArgs a[3];
       for (int net = 0; net < 3; ++net)
         a[net] = {ws->dy[net][2], U2, MB, U2, U2, D.bf16 ? ws->dyn[net][2] : nullptr, U2, ws->dyt[net][2], ws->MBp};
@@ -433,19 +433,32 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
         const int Kl = Kof(net, l);
         const size_t pz = (size_t)Nl * Kl + Nl;                           // [W_l | b_l] contiguous in the flat layout
         float* part = ws->part + (size_t)net * region;
-        const void* Xt = l == 0 ? (const void*)((const char*)ws->xt[xsel[net]] + r0 * ES) : (const void*)ws->ht[net][l - 1];
-        gw[net] = {ws->dyt[net][l], ws->MBp, Xt, l == 0 ? ws->Rp : ws->MBp, Nl, Kl, ws->MBp, kc, part, Kl, pz, nullptr, 0, nullptr, 0,
-                   nullptr, nullptr, 0, nullptr, 0, part + (size_t)Nl * Kl};
+        if (ws->tt) {   // fp32: dY_l [MB][N_l] and the layer input [MB][K_l] as the other products leave them (k_gemm_tt)
+          const int kp = ws->kp[net][0];
+          const void* X = l == 0 ? (const void*)((const char*)ws->xn[xsel[net]] + r0 * kp * ES) : (const void*)ws->h[net][l - 1];
+          gw[net] = {ws->dy[net][l], Nl, X, l == 0 ? kp : D.units[l - 1], Nl, Kl, MB, kc, part, Kl, pz, nullptr, 0, nullptr, 0,
+                     nullptr, nullptr, 0, nullptr, 0, part + (size_t)Nl * Kl};
+        } else {
+          const void* Xt = l == 0 ? (const void*)((const char*)ws->xt[xsel[net]] + r0 * ES) : (const void*)ws->ht[net][l - 1];
+          gw[net] = {ws->dyt[net][l], ws->MBp, Xt, l == 0 ? ws->Rp : ws->MBp, Nl, Kl, ws->MBp, kc, part, Kl, pz, nullptr, 0, nullptr, 0,
+                     nullptr, nullptr, 0, nullptr, 0, part + (size_t)Nl * Kl};
+        }
         rb.part[net] = part; rb.pz[net] = pz; rb.n[net] = pz; rb.out[net] = G[net] + woff(net, l);
       }
-      if (D.bf16) gemm_nt<1, EPI_TN>(gw, 3, Sl, st); else gemm_nt<0, EPI_TN>(gw, 3, Sl, st);   // G_l = dY_l^T X_l, b_l = row sums of dY_l^T
+      if (ws->tt) gemm_tt(gw, 3, Sl, ws->zeros, st);
+      else if (D.bf16) gemm_nt<1, EPI_TN>(gw, 3, Sl, st); else gemm_nt<0, EPI_TN>(gw, 3, Sl, st);   // G_l = dY_l^T X_l, b_l = row sums of dY_l^T
       hipLaunchKernelGGL(k_reduce_parts3, dim3(256, 3), dim3(256), 0, st, rb);
       if (l > 0) {
         NtArgs gx[3];
         const int Kl = D.units[l - 1];
-        for (int net = 0; net < 3; ++net)
-          gx[net] = {ws->dyn[net][l], Nl, ws->wt[net][l], Nl, MB, Kl, Nl, Nl, nullptr, 0, 0, l - 1 >= 1 ? ws->dyn[net][l - 1] : nullptr, Kl,
-                     ws->dyt[net][l - 1], ws->MBp, nullptr, ws->hn[net][l - 1], Kl, ws->ht[net][l - 1], ws->MBp, nullptr};
+        for (int net = 0; net < 3; ++net) {
+          if (ws->tt)   // one image: dY_{l-1} [MB][K_l] (layer 0 included: its weight gradient reads it), ELU' from the layer output itself
+            gx[net] = {ws->dy[net][l], Nl, ws->wt[net][l], Nl, MB, Kl, Nl, Nl, nullptr, 0, 0, ws->dy[net][l - 1], Kl,
+                       nullptr, 0, nullptr, ws->h[net][l - 1], Kl, nullptr, 0, nullptr};
+          else
+            gx[net] = {ws->dyn[net][l], Nl, ws->wt[net][l], Nl, MB, Kl, Nl, Nl, nullptr, 0, 0, l - 1 >= 1 ? ws->dyn[net][l - 1] : nullptr, Kl,
+                       ws->dyt[net][l - 1], ws->MBp, nullptr, ws->hn[net][l - 1], Kl, ws->ht[net][l - 1], ws->MBp, nullptr};
+        }
         if (D.bf16) gemm_nt<1, EPI_NN>(gx, 3, 1, st); else gemm_nt<0, EPI_NN>(gx, 3, 1, st);   // dY_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
       }
     }

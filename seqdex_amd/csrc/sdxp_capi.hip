@@ -221,6 +221,11 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     PAL(w.part, 3 * w.part_region);
     PAL(w.dpart, (size_t)w.nsplit * cfg->state_dim * 2);
     w.nt = sdxpk_big_nt_enabled(&D, cfg->minibatch);
+    w.tt = 0; w.zeros = nullptr;
+    {
+      const char* e = getenv("SDXP_BIGMB_TT");
+      if (w.nt && !D.bf16 && !(e && e[0] == '0')) { w.tt = 1; PAL(w.zeros, 64); }
+    }
     if (w.nt) {   // staged operands of the NT products (sdx_gemm_nt.h); hipMemset by palloc: the padding the kernels never write stays zero
       const size_t ES = D.bf16 ? 2 : 4;
       char* q;

@@ -101,4 +101,8 @@ struct SdxpBigWs {
   void* ht[3][2];             // ... transposed [units[l]][MBp]
   void* dyn[3][3];            // gradients [MB][units[l]], l = 1, 2 (fp32 runs, l = 2: dy[net][2] itself)
   void* dyt[3][3];            // ... transposed [units[l]][MBp], l = 0, 1, 2
+  // ---- fp32 runs: weight gradients read the [row][feature] arrays themselves (k_gemm_tt): no transposed copy of an activation or a
+  // gradient is written or read (ht / dyt / xt stay unused); SDXP_BIGMB_TT=0 keeps the transposed-copy form
+  int tt;
+  float* zeros;               // 64 zero floats: the rows a ragged last chunk lacks
 };

@@ -58,3 +58,20 @@ extern "C" int emu_gemm_nt_wide(int bf, int epi, const void* A, int lda, const v
   else hipLaunchKernelGGL((k_gemm_nt<0, EPI_NN, 2>), dim3(nx * ny), dim3(256), 2 * 256 * 128, nullptr, nb, nx, ny);
   return 0;
 }
+
+// fp32 weight gradient from [row][feature] operands (k_gemm_tt): G[n][k] = sum_r A[r][n] B[r][k] in `splits` row ranges of kchunk rows;
+// tile: 0 = the launcher's choice, 1 = 128 x 64, 2 = 128 x 128
+extern "C" int emu_gemm_tt(const float* A, int lda, const float* B, int ldb, int M, int N, int K, int kchunk, int splits, float* Cf, int ldc,
+                           long long cz, float* rowsum, int tile) {
+  static float zeros[64] = {0};
+  NtArgs g = {A, lda, B, ldb, M, N, K, kchunk, Cf, ldc, (size_t)cz, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, rowsum};
+  NtArgs gs[3] = {g, g, g};
+  if (tile == 0) { gemm_tt(gs, 1, splits, zeros, nullptr); return 0; }
+  NtBatch nb;
+  nb.a[0] = nb.a[1] = nb.a[2] = g;
+  nb.splits = splits;
+  const int ny = (M + 127) / 128;
+  if (tile == 2) { const int nx = (N + 127) / 128; hipLaunchKernelGGL((k_gemm_tt<2>), dim3(nx * ny * splits), dim3(256), 2 * 32 * 256 * 4, nullptr, nb, nx, ny, zeros); }
+  else { const int nx = (N + 63) / 64; hipLaunchKernelGGL((k_gemm_tt<1>), dim3(nx * ny * splits), dim3(256), 2 * 32 * 192 * 4, nullptr, nb, nx, ny, zeros); }
+  return 0;
+}

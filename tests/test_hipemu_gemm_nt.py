@@ -26,6 +26,7 @@ def lib():
     l.emu_gemm_nt_narrow.argtypes = [i, vp, i, vp, i, i, i, i, fp, i, vp, i, fp]
     l.emu_stage.argtypes = [i, fp, i, i, i, i, vp, i, vp, i]
     l.emu_gemm_nt_wide.argtypes = [i, i, vp, i, vp, i, i, i, i, fp, i, vp, i, vp, i, fp, vp, i, vp, i]
+    l.emu_gemm_tt.argtypes = [vp, i, vp, i, i, i, i, i, i, fp, i, C.c_longlong, vp, i]
     return l
 
 
@@ -178,3 +179,28 @@ def test_stage_kernel(lib, bf):
     assert not n[:, K:].any()
     np.testing.assert_array_equal(t[:K, :R], want.T)
     assert not t[K:].any() and not t[:, R:].any()
+
+
+@pytest.mark.parametrize("tile", [1, 2, 0])
+@pytest.mark.parametrize("R,Nl,Kl,ldb,splits", [(200, 128, 100, 128, 2), (96, 256, 396, 416, 1), (328, 128, 130, 160, 3)])
+def test_weight_gradient_from_row_major_operands(lib, tile, R, Nl, Kl, ldb, splits):
+    """k_gemm_tt (fp32): G = dY^T X read from dY [rows][N_l] and X [rows][K_l] as the other products leave them - no transposed copies.
+    Ragged rows (the last chunk comes partly from the page of zeros), columns past the operand's width clamped into it, row splits,
+    both tiles, column sums of dY (the bias gradient) beside the MFMAs."""
+    rng = np.random.default_rng(R + Kl + tile)
+    A = (rng.standard_normal((R, Nl)) * 0.3).astype(np.float32)
+    B = np.full((R, ldb), np.nan, np.float32)                       # padding columns hold garbage in the real buffers of layers > 0 ...
+    B[:, :Kl] = rng.standard_normal((R, Kl)).astype(np.float32)
+    B[:, Kl:] = 7.0                                                 # ... here a finite marker: products with it belong to outputs that are never stored
+    kchunk = ((R + splits - 1) // splits + 31) // 32 * 32
+    pz = Nl * Kl + Nl
+    part = np.full((splits, pz), np.nan, np.float32)
+    lib.emu_gemm_tt(_p(A), Nl, _p(B), ldb, Nl, Kl, R, kchunk, splits, _p(part), Kl, pz, C.c_void_p(part.ctypes.data + 4 * Nl * Kl), tile)
+    assert np.isfinite(part).all()
+    tot = part.sum(0)
+    want = A.astype(np.float64).T @ B[:, :Kl].astype(np.float64)
+    np.testing.assert_allclose(tot[:Nl * Kl].reshape(Nl, Kl), want, rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(tot[Nl * Kl:], A.astype(np.float64).sum(0), rtol=1e-5, atol=3e-5)
+    for z in range(splits):                                         # every split covers exactly its own rows
+        r0, r1 = z * kchunk, min(R, (z + 1) * kchunk)
+        np.testing.assert_allclose(part[z, :Nl * Kl].reshape(Nl, Kl), A[r0:r1].astype(np.float64).T @ B[r0:r1, :Kl].astype(np.float64), rtol=1e-5, atol=3e-5)
