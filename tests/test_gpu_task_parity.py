@@ -222,5 +222,21 @@ def test_terminal_state_harvesting(scene):
             got_h = {tuple(np.round(hh[grp, k].ravel(), 5)) for k in range(2)}
             want_h = {tuple(np.round(dof_before[e].cpu().numpy().ravel(), 5)) for e in envs}
             assert got_h == want_h
+        # round 4: every append also writes (step << 24 | env); read in key order the rows are in serial (step, env) order whatever slot
+        # the atomics handed out (SdxSim.ring_rows: what the hand-off lists and the T-value trainer consume)
+        keys = s.HARVEST_KEYS.cpu().numpy()
+        for grp, envs in ((0, (0, 8)), (4, (4, 12))):
+            k = keys[grp, :2]
+            assert sorted((k & 0xFFFFFF).tolist()) == list(envs) and len(set((k >> 24).tolist())) == 1 and int(k[0] >> 24) >= 1
+            rows = s.ring_rows(s.HARVEST_OBJ[grp], s.HARVEST_KEYS[grp], 2).cpu().numpy()
+            np.testing.assert_array_equal(rows[0], tgt_before[envs[0]].cpu().numpy())       # the lower env first
+            np.testing.assert_array_equal(rows[1], tgt_before[envs[1]].cpu().numpy())
+        tvc = s.TV_COUNT.cpu().numpy()
+        assert tvc.tolist() == [4, 12]                                           # every finished episode logged its outcome: 4 harvested, 12 not
+        tk = s.TV_KEYS.cpu().numpy()
+        assert sorted((tk[0, :4] & 0xFFFFFF).tolist()) == [0, 4, 8, 12]
+        assert sorted((tk[1, :12] & 0xFFFFFF).tolist()) == [e for e in range(16) if e % 4 != 0]
+        succ = s.ring_rows(s.TV_SUCCESS, s.TV_KEYS[0], 4)
+        assert succ.shape == (4, 4) and bool(torch.isfinite(succ).all())
     finally:
         s.close()
