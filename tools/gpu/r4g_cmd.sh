@@ -1,3 +1,5 @@
+# (the SDXP_NT_STAGGER sweep below belonged to an experiment that was measured - no effect - and removed from csrc/sdx_gemm_nt.h: DESIGN.md section 12;
+# kept as the record of what was run)
 mkdir -p gpurun_out/r4g
 for q in 0 8 16 32; do echo "== bf16 stagger $q"; SDXP_NT_STAGGER=$q timeout 120 python tools/time_gemm_nt.py --mb 32768 --bf16 2>&1 | grep -E "forward|data grad|all eight" | cut -c1-110; done
 for q in 0 16 32 64; do echo "== fp32 stagger $q"; SDXP_NT_STAGGER=$q timeout 120 python tools/time_gemm_nt.py --mb 32768 2>&1 | grep -E "forward|data grad|all eight" | cut -c1-110; done
