@@ -212,6 +212,10 @@ def large_minibatch_variant(train, env, n, horizon, args):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON: whatever a library prints through C stdio (RCCL's version banner when a communicator is set up
+    # or torn down: it used to land behind the JSON line of a multi-rank run) goes to stderr with everything else
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import yaml
     rank = int(os.environ.get("RANK", "0"))
@@ -392,7 +396,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, sim._desc, root, dof, tg, horizon, agent.minibatch_size, agent.mini_epochs_num)
         except Exception as ex:   # the checker is optional for the measurement itself
             out["cpu_baseline"] = {"value": None, "error": str(ex)}
-    print(json.dumps(out))
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
