@@ -26,16 +26,20 @@
 extern "C" {
 #endif
 
-#define SDX_ABI_VERSION 7
+#define SDX_ABI_VERSION 8
 
 /* ---- fixed scene dimensions of BlockAssemblyGraspSim (GS:523-1058) ---- */
 #define SDX_NLINK 24        /* robot bodies after collapse_fixed_joints (GS:543); body 0 is the fixed base  */
 #define SDX_NDOF 23         /* 7 arm + 16 hand revolute DOF (GS:561, 580-590)                               */
-#define SDX_MAX_RBOX 32     /* robot collision boxes                                                         */
+#define SDX_MAX_RBOX 40     /* robot collision boxes (URDF boxes, slab compounds of the fingertip / palm hulls, bounding boxes of the arm) */
 #define SDX_NBRICK 132      /* 72 free (GS:717-746) + 60 fixed floor bricks (GS:748-808)                     */
 #define SDX_NFREE 72
 #define SDX_NBRICK_TYPES 8  /* GS:706                                                                        */
-#define SDX_MAX_STATIC 8    /* table, 5 bin walls, merged brick floor, base plate                            */
+#define SDX_MAX_STATIC 8    /* static bodies one env sees: table, 5 bin walls, merged brick floor, base plate                        */
+#define SDX_MAX_STATIC_TAB 10 /* rows of the static-body table: the 8 above + the two other base-plate variants of InsertSim          */
+#define SDX_MAX_STATIC_SUB 112 /* boxes of all static bodies: 7 single boxes + up to 3 base plates of 1 + 16 x 2 boxes (body, studs)  */
+#define SDX_MAX_SUB 2       /* boxes of a free brick's collision compound: slabs of its convex hull (GS:717-731: one hull per brick) */
+#define SDX_MAX_SUB_HOLLOW 8 /* boxes of the hollow compound (4 walls + the slabs above the cavity) of the brick being inserted    */
 #define SDX_ACTORS 142      /* hand, object, goal, table, 5 bin boxes, 132 bricks, base plate                */
 #define SDX_BODIES 165      /* 24 hand links + one body per other actor                                      */
 #define SDX_ACTOR_BRICK0 9  /* first brick actor inside an env                                               */
@@ -154,16 +158,37 @@ typedef struct {
   float rbox_center[SDX_MAX_RBOX][3];
   float rbox_quat[SDX_MAX_RBOX][4];
   float rbox_half[SDX_MAX_RBOX][3];
-  /* bricks */
+  /* bricks.  Collision shape of a brick = a COMPOUND of axis-aligned boxes in the brick's frame: the slabs of
+   * the mesh's convex hull for a free brick (the reference loads every brick as ONE convex hull, GS:717-731), or - for each env's target
+   * brick when seg_hollow != 0 - the hollow compound of the mesh itself (walls, roof, upper part: what V-HACD resolves, IS:698-709),
+   * whose underside takes the studs of a base plate.  brick_half / brick_center = the bounding box of either compound (broadphase,
+   * segmentation camera); the body's reference point is its centre of mass brick_com. */
   float brick_half[SDX_NBRICK_TYPES][3];
-  float brick_center[SDX_NBRICK_TYPES][3];   /* box centre in the brick's mesh frame */
-  float brick_mass[SDX_NBRICK_TYPES];
-  float brick_inertia[SDX_NBRICK_TYPES][3];  /* principal, about the box centre */
+  float brick_center[SDX_NBRICK_TYPES][3];   /* centre of the bounding box in the brick's mesh frame */
+  float brick_com[SDX_NBRICK_TYPES][3];      /* centre of mass (centroid of the convex hull) in the mesh frame */
+  float brick_mass[SDX_NBRICK_TYPES];        /* 567 x hull volume */
+  float brick_inertia[SDX_NBRICK_TYPES][3];  /* diagonal of the hull's inertia tensor about the centre of mass, mesh axes (the xz products
+                                              * of the four wedge-shaped types, <= 0.37 Ixx, are dropped) */
+  int32_t brick_nsub[SDX_NBRICK_TYPES];
+  float brick_sub_center[SDX_NBRICK_TYPES][SDX_MAX_SUB][3];   /* mesh frame */
+  float brick_sub_half[SDX_NBRICK_TYPES][SDX_MAX_SUB][3];
+  int32_t seg_hollow;                        /* != 0: the target brick of every env collides as its hollow compound */
+  int32_t hollow_nsub[SDX_NBRICK_TYPES];
+  float hollow_sub_center[SDX_NBRICK_TYPES][SDX_MAX_SUB_HOLLOW][3];
+  float hollow_sub_half[SDX_NBRICK_TYPES][SDX_MAX_SUB_HOLLOW][3];
   int32_t brick_type[SDX_NBRICK];
-  /* static boxes (world frame, axis aligned) */
+  /* static bodies (world frame, axis aligned).  Rows 0..n_static-1 of the table are what an env sees; a body is a compound of the
+   * boxes static_sub_*[first .. first + n) and static_center / static_half is its bounding box (a single-box body: the box itself).
+   * The studs of a compound (boxes 1.. of a body) are SAMPLED like a brick's boxes (both directions of a pair), a body box only
+   * receives the other shape's samples. */
   int32_t n_static;
-  float static_center[SDX_MAX_STATIC][3];
-  float static_half[SDX_MAX_STATIC][3];
+  float static_center[SDX_MAX_STATIC_TAB][3];
+  float static_half[SDX_MAX_STATIC_TAB][3];
+  int32_t static_sub_first[SDX_MAX_STATIC_TAB];
+  int32_t static_sub_n[SDX_MAX_STATIC_TAB];
+  int32_t n_static_sub;
+  float static_sub_center[SDX_MAX_STATIC_SUB][3];
+  float static_sub_half[SDX_MAX_STATIC_SUB][3];
   /* default actor states for everything that is not a brick (written into ROOT at create) */
   float object_init_state[13];         /* GS:687-689,927-929 */
   float goal_reset_pos[3];             /* goal_init_state + goal_displacement, GS:694-700,1348 */
@@ -214,11 +239,10 @@ typedef struct {
   float target_euler[3];               /* Orient: fixed wrist orientation of the tracking IK, OR:477 */
   float seg_mass_scale;                /* mass (and inertia) factor of each env's target brick: 1 (GS:980-981), 50 in Orient (OR:977) */
   /* task_kind 2 = BlockAssemblyInsertSim (IS = tasks/block_assembly/allegro_hand_block_assembly_insert_sim.py): the base plate is
-   * one of 4x4x{1,2,4} chosen by env % 3 (IS:971-977).  Only the z extent of static box `static_var_slot` differs between the
-   * variants; -1 = every env uses static_center/static_half as they are. */
+   * one of 4x4x{1,2,4} chosen by env % 3 (IS:971-977): env e sees row static_var_row[e % 3] of the static-body table in slot
+   * `static_var_slot`; -1 = every env sees rows 0..n_static-1 as they are. */
   int32_t static_var_slot;
-  float static_var_center_z[3];
-  float static_var_half_z[3];
+  int32_t static_var_row[3];
   /* task_kind 3 = BlockAssemblySearch (SE = tasks/block_assembly/allegro_hand_block_assembly_search.py): the fixed segmentation camera
    * (128 x 128; set_camera_location SE:875; Isaac Gym's default horizontal field of view 90 degrees) */
   float seg_cam_pos[3];

@@ -269,6 +269,8 @@ static void add_contact(env_t* e, int a, int b, v3 p, v3 n, real sep) {
  * has no meaningful meeting face and every sample keeps its own signed distance, as in round 1.
  * (Round 1 used the sample's nearest face and plain table order: two equal bricks stacked flush pushed each other sideways, the
  * speculative samples beside B used up the 4 slots, and the upper brick tipped over one edge or sank through.) */
+#define EXT_C 0.92387953f /* cos, sin of 22.5 degrees: the directions along which the manifold's extreme face samples are picked */
+#define EXT_S 0.38268343f
 #define FACE_TOL 1e-4f
 #define FACE_DEPTH 4.0f
 #define WARM_SPEED 0.25f /* m/s: relative speed at the contact point (before the solve) above which a contact starts cold */
@@ -326,25 +328,10 @@ static int sample_class(const dir_t* D, v3 pb, v3 h, real offset) {
   return vdot(o, o) < offset * offset ? 2 : 0;
 }
 
-/* incl: samples closer than this are contacts - the contact offset, or 0 when the list is rebuilt after a capacity overflow (collide()) */
-static int sample_dir(const box_t* A, const box_t* B, real offset, real incl, int idx[4]) {
-  int c1 = 0, c2 = 0, other[4];
+static void emit_mask(env_t* e, const box_t* A, const box_t* B, int ida, int idb, unsigned mask, real offset, unsigned pkey) {
   dir_t D = dir_setup(A, B, offset);
-  if (D.smax >= incl) return -1; /* separated: neither direction has a sample inside the threshold */
-  for (int s = 0; s < NSAMP && c1 < 4; ++s) {
-    v3 pb = sample_point(&D, s);
-    int cls = sample_class(&D, pb, B->h, incl);
-    if (cls == 1) idx[c1++] = s;
-    else if (cls == 2 && c2 < 4) other[c2++] = s;
-  }
-  for (int i = 0; i < c2 && c1 < 4; ++i) idx[c1++] = other[i];
-  return c1;
-}
-
-static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb, const int idx[4], int k, real offset, unsigned pkey) {
-  dir_t D = dir_setup(A, B, offset);
-  for (int i = 0; i < k; ++i) {
-    int s = idx[i];
+  for (int s = 0; s < NSAMP; ++s) {
+    if (!((mask >> s) & 1u)) continue;
     v3 pb = sample_point(&D, s);
     v3 g;
     real sd;
@@ -356,56 +343,164 @@ static void emit_dir(env_t* e, const box_t* A, const box_t* B, int ida, int idb,
   }
 }
 
-/* pair of boxes; bstatic != 0: B is a static box (only A's samples are tested); boxa / boxb: box ids (brick 0..71, robot box 72 + r,
- * static 128 + s) - with the direction bit and the sample index they identify a contact from one solve to the next */
-static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int idb, int bstatic, real offset, int boxa, int boxb) {
-  int i1[4], i2[4];
+/* ---- compound shapes.  A brick collides as a compound of axis-aligned boxes in its own frame: the slabs of its
+ * convex hull (sdx_scene_desc.brick_sub_*), or - the env's target brick when seg_hollow is set - the hollow compound of its mesh
+ * (hollow_sub_*).  A static body is a compound too (static_sub_*: the studded base plate; every other static is one box).  A robot box is
+ * one box.  The body's bounding box (brick_half about brick_center) serves the broadphase only. */
+static int brick_is_hollow(const sdx_scene_desc* sc, const env_t* e, int i) { return sc->seg_hollow && i == e->seg_brick; }
+static int brick_nsub(const sdx_scene_desc* sc, const env_t* e, int i) {
+  int t = sc->brick_type[i];
+  return brick_is_hollow(sc, e, i) ? sc->hollow_nsub[t] : sc->brick_nsub[t];
+}
+static box_t brick_sub(const sdx_scene_desc* sc, const env_t* e, int i, int k) {
+  int t = sc->brick_type[i];
+  const float* c = brick_is_hollow(sc, e, i) ? sc->hollow_sub_center[t][k] : sc->brick_sub_center[t][k];
+  const float* h = brick_is_hollow(sc, e, i) ? sc->hollow_sub_half[t][k] : sc->brick_sub_half[t][k];
+  box_t B = {vadd(e->bp[i], qrot(e->bq[i], vsub(ld3(c), ld3(sc->brick_com[t])))), e->bq[i], ld3(h)};
+  return B;
+}
+static box_t brick_bound(const sdx_scene_desc* sc, const env_t* e, int i) {
+  int t = sc->brick_type[i];
+  box_t B = {vadd(e->bp[i], qrot(e->bq[i], vsub(ld3(sc->brick_center[t]), ld3(sc->brick_com[t])))), e->bq[i], ld3(sc->brick_half[t])};
+  return B;
+}
+/* row of the static-body table that slot s shows to env `env_index`: InsertSim's base plate is one of three by env % 3 */
+static int static_row(const sdx_scene_desc* sc, int s, int env_index) {
+  return s == sc->static_var_slot ? sc->static_var_row[env_index % 3] : s;
+}
+static box_t static_bound(const sdx_scene_desc* sc, int s, int env_index) {
+  int r = static_row(sc, s, env_index);
+  box_t S = {ld3(sc->static_center[r]), {0, 0, 0, 1}, ld3(sc->static_half[r])};
+  return S;
+}
+static box_t static_sub(const sdx_scene_desc* sc, int s, int env_index, int k) {
+  int r = static_row(sc, s, env_index), b = sc->static_sub_first[r] + k;
+  box_t S = {ld3(sc->static_sub_center[b]), {0, 0, 0, 1}, ld3(sc->static_sub_half[b])};
+  return S;
+}
+
+/* pair of boxes -> <= 4 contacts.  Samples of A are classified against B (direction 1) and, when sample_b, samples
+ * of B against A (direction 2; sample_b == 0: B is the body box of a static).  incl (e->incl): samples closer than this are contacts -
+ * the contact offset, or 0 when the list is rebuilt after a capacity overflow.  The 4 slots go to
+ *   1. FACE samples of both directions, chosen at the extremes of the patch the boxes meet on: every face sample has lateral coordinates
+ *      (a, b) in B's frame (B's axes without the axis of direction 1's reference face; a sample of B: its own table entry x hB); the
+ *      samples that reach furthest along the four directions at 22.5 degrees + k x 90 degrees of the (a, b) plane (first in
+ *      enumeration order - direction 1 in table order, then direction 2 - wins a tie; the tilt makes the four corners of an
+ *      axis-aligned patch win one direction each), then the remaining face samples in that enumeration order;
+ *   2. the other samples (edge / corner regions, speculative contacts) of direction 1, then of direction 2, in table order.
+ * (Until round 4: per direction the first four in table order, face samples first, two slots reserved for direction 2 - on the narrower
+ * boxes of a compound that picked four points at one end of the patch, or gave a slot to a speculative sample beside it.)
+ * pkey: the pair's part of the contact identity (enumeration index of the body pair << 15 | index of the box pair inside it << 6) - with
+ * the direction bit and the sample index it identifies a contact from one solve to the next */
+static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int idb, int sample_b, real offset, unsigned pkey) {
   const real incl = e->incl;
-  int c1 = sample_dir(A, B, offset, incl, i1);
-  if (c1 < 0) return;
-  int c2 = bstatic ? 0 : sample_dir(B, A, offset, incl, i2);
-  if (c2 < 0) return;
-  int m2 = c2 < 2 ? c2 : 2;
-  int k1 = c1 < 4 - m2 ? c1 : 4 - m2;
-  int k2 = c2 < 4 - k1 ? c2 : 4 - k1;
-  unsigned pk = ((unsigned)boxa << 14) | ((unsigned)boxb << 6); /* 22 bits with the direction bit and the 5-bit sample index; bits 24.. of a cached key hold the contact's age */
-  emit_dir(e, A, B, ida, idb, i1, k1, offset, pk);
-  if (k2 > 0) emit_dir(e, B, A, idb, ida, i2, k2, offset, pk | 0x20u);
+  dir_t D1 = dir_setup(A, B, offset), D2;
+  if (D1.smax >= incl) return; /* separated: no sample of either direction can be inside the threshold */
+  if (sample_b) {
+    D2 = dir_setup(B, A, offset);
+    if (D2.smax >= incl) return;
+  }
+  const int kref = D1.kax >= 0 ? D1.kax : 2;
+  unsigned face[2] = {0, 0}, other[2] = {0, 0};
+  int ei[4] = {-1, -1, -1, -1};
+  real ext[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+  for (int d = 0; d < (sample_b ? 2 : 1); ++d) {
+    const dir_t* D = d ? &D2 : &D1;
+    const box_t* T = d ? A : B; /* the box the samples are tested against */
+    for (int s = 0; s < NSAMP; ++s) {
+      v3 pb = sample_point(D, s);
+      int cls = sample_class(D, pb, T->h, incl);
+      if (cls == 2) other[d] |= 1u << s;
+      if (cls != 1) continue;
+      face[d] |= 1u << s;
+      v3 p = d ? V(SAMP[s][0] * B->h.x, SAMP[s][1] * B->h.y, SAMP[s][2] * B->h.z) : pb; /* the sample in B's frame */
+      real a = kref == 0 ? p.y : p.x, b = kref == 2 ? p.y : p.z;
+      real k0 = EXT_C * a + EXT_S * b, k1 = EXT_C * b - EXT_S * a;
+      real key[4] = {k0, k1, -k0, -k1};
+      for (int k = 0; k < 4; ++k)
+        if (key[k] > ext[k]) { ext[k] = key[k]; ei[k] = 32 * d + s; }
+    }
+  }
+  unsigned sel[2] = {0, 0};
+  int n = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (ei[k] < 0) continue;
+    int d = ei[k] >> 5, sidx = ei[k] & 31;
+    if (!((sel[d] >> sidx) & 1u)) { sel[d] |= 1u << sidx; ++n; }
+  }
+  for (int pass = 0; pass < 2; ++pass) /* remaining face samples, then the other samples */
+    for (int d = 0; d < 2; ++d) {
+      unsigned m = (pass ? other[d] : face[d]) & ~sel[d];
+      for (int sidx = 0; sidx < NSAMP && n < 4; ++sidx)
+        if ((m >> sidx) & 1u) { sel[d] |= 1u << sidx; ++n; }
+    }
+  emit_mask(e, A, B, ida, idb, sel[0], offset, pkey);
+  if (sel[1]) emit_mask(e, B, A, idb, ida, sel[1], offset, pkey | 0x20u);
 }
 
 static real box_radius(v3 h) { return sqrtf(vdot(h, h)); }
 
-/* static box s as env `env_index` sees it: InsertSim's base plate height depends on env % 3 (sdx_scene_desc.static_var_*) */
-static box_t static_box(const sdx_scene_desc* sc, int s, int env_index) {
-  box_t S = {ld3(sc->static_center[s]), {0, 0, 0, 1}, ld3(sc->static_half[s])};
-  if (s == sc->static_var_slot) {
-    S.c.z = sc->static_var_center_z[env_index % 3];
-    S.h.z = sc->static_var_half_z[env_index % 3];
+/* largest face-axis separation of the box pair (both directions when the second one is sampled): < offset for every pair that can
+ * produce a contact */
+static real pair_sigma(const box_t* A, const box_t* B, int sample_b, real offset) {
+  real sg = dir_setup(A, B, offset).smax;
+  if (sample_b) sg = fmaxf(sg, dir_setup(B, A, offset).smax);
+  return sg;
+}
+
+/* one body pair of the enumeration (index idx).  kind_a: 0 brick, 1 robot box; kind_b: 0 brick, 2 static slot.
+ * CONVEX pairs - both sides stand for one convex shape: a brick as the slab compound of its hull, a robot box, a single-box static -
+ * contribute the contacts of ONE box pair, the one with the smallest separation bound sigma (ties: the first in enumeration order; none
+ * when every pair is separated by the contact offset): a pair of convex shapes has one contact patch, and as the configuration changes the
+ * winning pair of boxes changes with it.  COMPOUND pairs - a hollow brick (its underside takes studs) or the studded base plate on either
+ * side - contribute every box pair.  The studs of a static compound (boxes 1..) are sampled like a brick's boxes, a static BODY box (box 0)
+ * only receives the other shape's samples. */
+static void collide_bodies(const sdx_scene_desc* sc, env_t* e, int idx, int kind_a, int ia, int kind_b, int ib, const box_t* R, int rlink) {
+  const real off = sc->contact_offset;
+  int na = kind_a == 0 ? brick_nsub(sc, e, ia) : 1;
+  int nb = kind_b == 0 ? brick_nsub(sc, e, ib) : sc->static_sub_n[static_row(sc, ib, e->env_index)];
+  int convex = !(kind_a == 0 && brick_is_hollow(sc, e, ia)) && !(kind_b == 0 && brick_is_hollow(sc, e, ib)) && !(kind_b == 2 && nb > 1);
+  int only = -1;
+  if (convex) {
+    real best = off;
+    for (int s = 0; s < na * nb; ++s) {
+      int a = s / nb, b = s % nb;
+      box_t A = kind_a == 0 ? brick_sub(sc, e, ia, a) : *R;
+      box_t B = kind_b == 0 ? brick_sub(sc, e, ib, b) : static_sub(sc, ib, e->env_index, b);
+      real sg = pair_sigma(&A, &B, kind_b == 0 || b > 0, off);
+      if (sg < best) { best = sg; only = s; }
+    }
+    if (only < 0) return;
   }
-  return S;
+  for (int a = 0; a < na; ++a)
+    for (int b = 0; b < nb; ++b) {
+      if (convex && a * nb + b != only) continue;
+      box_t A = kind_a == 0 ? brick_sub(sc, e, ia, a) : *R;
+      box_t B = kind_b == 0 ? brick_sub(sc, e, ib, b) : static_sub(sc, ib, e->env_index, b);
+      collide_pair(e, &A, &B, kind_a == 0 ? ia : NF + rlink, kind_b == 0 ? ib : BODY_STATIC, kind_b == 0 || b > 0, off,
+                   ((unsigned)idx << 15) | ((unsigned)(a * nb + b) << 6));
+    }
 }
 
 static void collide_pass(const sdx_scene_desc* sc, env_t* e, real incl) {
   const real off = sc->contact_offset;
+  const int ns = sc->n_static, n1 = NF * ns, n2 = NF * (NF - 1) / 2, per = NF + ns;
   e->nc = 0;
   e->overflow = 0;
   e->incl = incl;
   box_t bb[NF];
   real br[NF];
   for (int i = 0; i < NF; ++i) {
-    int t = sc->brick_type[i];
-    bb[i].c = e->bp[i];
-    bb[i].q = e->bq[i];
-    bb[i].h = ld3(sc->brick_half[t]);
+    bb[i] = brick_bound(sc, e, i);
     br[i] = box_radius(bb[i].h);
   }
   /* (1) brick vs static */
   for (int i = 0; i < NF; ++i)
-    for (int s = 0; s < sc->n_static; ++s) {
-      box_t S = static_box(sc, s, e->env_index);
+    for (int s = 0; s < ns; ++s) {
+      box_t S = static_bound(sc, s, e->env_index);
       v3 g;
       if (box_sdf(vsub(bb[i].c, S.c), S.h, &g) > br[i] + off) continue;
-      collide_pair(e, &bb[i], &S, i, BODY_STATIC, 1, off, i, 128 + s);
+      collide_bodies(sc, e, i * ns + s, 0, i, 2, s, NULL, 0);
     }
   /* (2) brick vs brick */
   for (int i = 0; i < NF; ++i)
@@ -413,7 +508,7 @@ static void collide_pass(const sdx_scene_desc* sc, env_t* e, real incl) {
       v3 d = vsub(bb[i].c, bb[j].c);
       real rr = br[i] + br[j] + off;
       if (vdot(d, d) > rr * rr) continue;
-      collide_pair(e, &bb[i], &bb[j], i, j, 0, off, i, j);
+      collide_bodies(sc, e, n1 + (j - 1) * j / 2 + i, 0, i, 0, j, NULL, 0);
     }
   /* (3) robot box vs brick, (4) robot box vs static */
   for (int r = 0; r < sc->n_rbox; ++r) {
@@ -425,13 +520,13 @@ static void collide_pass(const sdx_scene_desc* sc, env_t* e, real incl) {
       v3 d = vsub(R.c, bb[i].c);
       real rr = rr0 + br[i] + off;
       if (vdot(d, d) > rr * rr) continue;
-      collide_pair(e, &R, &bb[i], NF + k, i, 0, off, NF + r, i);
+      collide_bodies(sc, e, n1 + n2 + r * per + i, 1, r, 0, i, &R, k);
     }
-    for (int s = 0; s < sc->n_static; ++s) {
-      box_t S = static_box(sc, s, e->env_index);
+    for (int s = 0; s < ns; ++s) {
+      box_t S = static_bound(sc, s, e->env_index);
       v3 g;
       if (box_sdf(vsub(R.c, S.c), S.h, &g) > rr0 + off) continue;
-      collide_pair(e, &R, &S, NF + k, BODY_STATIC, 1, off, NF + r, 128 + s);
+      collide_bodies(sc, e, n1 + n2 + r * per + NF + s, 1, r, 2, s, &R, k);
     }
   }
 }
@@ -574,13 +669,13 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
       for (int k = 0; k < nold; ++k) {
         int q = pos + k;
         if (q >= nold) q -= nold;
-        if ((e->wkey[q] & 0xffffffu) == e->ckey[c]) { found = q; break; }
+        if ((e->wkey[q] & 0x0fffffffu) == e->ckey[c]) { found = q; break; }
       }
       if (found < 0) continue;
       pos = found;
-      /* bits 24..31 of a cached key: the number of consecutive solves the contact had existed before that solve (saturating) */
-      unsigned age = (e->wkey[found] >> 24) + 1u;
-      if (age > 255u) age = 255u;
+      /* bits 28..31 of a cached key: the number of consecutive solves the contact had existed before that solve (saturating at 15: the
+       * ramp is over after warm_age <= 16 solves) */
+      unsigned age = (e->wkey[found] >> 28) + 1u;
       e->cage[c] = (unsigned char)age;
       if (e->csep[c] < -WARM_DEPTH * sc->contact_offset) continue; /* deep penetration is recovery, not rest: cold */
       {
@@ -668,7 +763,7 @@ static void solve(const sdx_scene_desc* sc, env_t* e, real h) {
   if (e->wcount && sc->warm_start > 0) { /* the cache for the next solve */
     *e->wcount = e->nc;
     for (int c = 0; c < e->nc; ++c) {
-      e->wkey[c] = e->ckey[c] | ((unsigned)e->cage[c] << 24);
+      e->wkey[c] = e->ckey[c] | ((unsigned)(e->cage[c] > 15 ? 15 : e->cage[c]) << 28);
       for (int r = 0; r < 3; ++r) e->wlam[r * SDXO_MAXC + c] = e->lam[c][r];
     }
   }
@@ -686,7 +781,7 @@ static void load_env(const sdx_scene_desc* sc, env_t* e, int env_index, const fl
   for (int i = 0; i < NF; ++i) {
     const float* s = root + (SDX_ACTOR_BRICK0 + i) * 13;
     e->bq[i] = qnormalize(ld4(s + 3));
-    e->bp[i] = vadd(ld3(s), qrot(e->bq[i], ld3(sc->brick_center[sc->brick_type[i]])));
+    e->bp[i] = vadd(ld3(s), qrot(e->bq[i], ld3(sc->brick_com[sc->brick_type[i]])));
     e->bv[i] = ld3(s + 7); /* COM velocity = origin velocity + w x (R c); the stored root velocity is the COM's */
     e->bw[i] = ld3(s + 10);
   }
@@ -751,7 +846,7 @@ static void store_env(const sdx_scene_desc* sc, env_t* e, real h, float* root, f
   }
   for (int i = 0; i < NF; ++i) {
     float* s = root + (SDX_ACTOR_BRICK0 + i) * 13;
-    st3(s, vsub(e->bp[i], qrot(e->bq[i], ld3(sc->brick_center[sc->brick_type[i]]))));
+    st3(s, vsub(e->bp[i], qrot(e->bq[i], ld3(sc->brick_com[sc->brick_type[i]]))));
     st4(s + 3, e->bq[i]);
     st3(s + 7, e->bv[i]);
     st3(s + 10, e->bw[i]);
@@ -865,6 +960,20 @@ int sdxo_contacts(const sdx_scene_desc* sc, const float* root_env, const float* 
   int total = e->nc + e->overflow;
   free(e);
   return total;
+}
+
+/* debug: identity keys of the contact list sdxo_contacts returns for the same state (enumeration index of the body pair << 15 | box pair
+ * inside it << 6 | direction << 5 | sample) */
+int sdxo_contact_keys(const sdx_scene_desc* sc, const float* root_env, const float* dof_env, unsigned* out, int cap) {
+  env_t* e = (env_t*)calloc(1, sizeof(env_t));
+  float tg[ND] = {0};
+  load_env(sc, e, 0, root_env, dof_env, tg);
+  fk(sc, e);
+  collide(sc, e);
+  int n = e->nc < cap ? e->nc : cap;
+  for (int c = 0; c < n; ++c) out[c] = e->ckey[c];
+  free(e);
+  return n;
 }
 
 int sdxo_max_contacts(void) { return SDXO_MAXC; }

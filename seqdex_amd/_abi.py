@@ -7,8 +7,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDX_LIB_PATH") or os.path.join(HERE, "lib", "libseqdex_hip.so")   # SDX_LIB_PATH: an experimental build of the same library (kernel A/B timing)
 
-SDX_ABI_VERSION = 7
-NLINK, NDOF, MAX_RBOX, NBRICK, NFREE, NBRICK_TYPES, MAX_STATIC = 24, 23, 32, 132, 72, 8, 8
+SDX_ABI_VERSION = 8
+NLINK, NDOF, MAX_RBOX, NBRICK, NFREE, NBRICK_TYPES, MAX_STATIC = 24, 23, 40, 132, 72, 8, 8
+MAX_STATIC_TAB, MAX_STATIC_SUB, MAX_SUB, MAX_SUB_HOLLOW = 10, 112, 2, 8
 ACTORS, BODIES, ACTOR_BRICK0, BODY_BRICK0 = 142, 165, 9, 32
 NUM_OBS, NUM_STATES, NUM_ACTIONS, OBS_FRAME, STATE_FRAME = 396, 564, 23, 132, 188
 HARVEST_SLOTS = 5001      # SDX_HARVEST_SLOTS
@@ -30,10 +31,16 @@ class SceneDesc(C.Structure):
         ("link_mass", f32 * NLINK), ("link_com", (f32 * 3) * NLINK), ("link_inertia", (f32 * 6) * NLINK),
         ("n_rbox", i32), ("rbox_link", i32 * MAX_RBOX),
         ("rbox_center", (f32 * 3) * MAX_RBOX), ("rbox_quat", (f32 * 4) * MAX_RBOX), ("rbox_half", (f32 * 3) * MAX_RBOX),
-        ("brick_half", (f32 * 3) * NBRICK_TYPES), ("brick_center", (f32 * 3) * NBRICK_TYPES),
+        ("brick_half", (f32 * 3) * NBRICK_TYPES), ("brick_center", (f32 * 3) * NBRICK_TYPES), ("brick_com", (f32 * 3) * NBRICK_TYPES),
         ("brick_mass", f32 * NBRICK_TYPES), ("brick_inertia", (f32 * 3) * NBRICK_TYPES),
+        ("brick_nsub", i32 * NBRICK_TYPES), ("brick_sub_center", ((f32 * 3) * MAX_SUB) * NBRICK_TYPES),
+        ("brick_sub_half", ((f32 * 3) * MAX_SUB) * NBRICK_TYPES),
+        ("seg_hollow", i32), ("hollow_nsub", i32 * NBRICK_TYPES), ("hollow_sub_center", ((f32 * 3) * MAX_SUB_HOLLOW) * NBRICK_TYPES),
+        ("hollow_sub_half", ((f32 * 3) * MAX_SUB_HOLLOW) * NBRICK_TYPES),
         ("brick_type", i32 * NBRICK),
-        ("n_static", i32), ("static_center", (f32 * 3) * MAX_STATIC), ("static_half", (f32 * 3) * MAX_STATIC),
+        ("n_static", i32), ("static_center", (f32 * 3) * MAX_STATIC_TAB), ("static_half", (f32 * 3) * MAX_STATIC_TAB),
+        ("static_sub_first", i32 * MAX_STATIC_TAB), ("static_sub_n", i32 * MAX_STATIC_TAB), ("n_static_sub", i32),
+        ("static_sub_center", (f32 * 3) * MAX_STATIC_SUB), ("static_sub_half", (f32 * 3) * MAX_STATIC_SUB),
         ("object_init_state", f32 * 13), ("goal_reset_pos", f32 * 3),
         ("static_actor_pos", (f32 * 3) * 6), ("base_plate_pos", f32 * 3),
         ("fixed_brick_pos", (f32 * 3) * (NBRICK - NFREE)), ("free_spawn_pos", (f32 * 3) * NFREE),
@@ -47,7 +54,7 @@ class SceneDesc(C.Structure):
         ("dt", f32), ("substeps", i32), ("solver_iters", i32), ("contact_offset", f32), ("gravity", f32 * 3),
         ("friction", f32), ("baumgarte", f32), ("max_depenetration_vel", f32), ("jacobi_relax", f32), ("warm_start", f32), ("warm_age", f32), ("robot_angular_damping", f32), ("grasp_tvalue_gate", f32), ("orient_tvalue_gate", f32),
         ("task_kind", i32), ("target_euler", f32 * 3), ("seg_mass_scale", f32),
-        ("static_var_slot", i32), ("static_var_center_z", f32 * 3), ("static_var_half_z", f32 * 3),
+        ("static_var_slot", i32), ("static_var_row", i32 * 3),
         ("seg_cam_pos", f32 * 3), ("seg_cam_target", f32 * 3), ("seg_cam_hfov_deg", f32),
         ("search_default_arm", f32 * 7), ("search_finger_pose", f32 * 16),
     ]

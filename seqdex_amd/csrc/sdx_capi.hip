@@ -79,6 +79,23 @@ static void qrot_host(const float q[4], const float v[3], float out[3]) {
 extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t device, uint64_t seed, sdx_handle* out) {
   if (!scene || !out || num_envs <= 0) { g_create_err = "sdx_create: bad argument"; return SDX_ERR_INVALID; }
   if (scene->abi_version != SDX_ABI_VERSION) { g_create_err = "sdx_create: scene.abi_version mismatch"; return SDX_ERR_INVALID; }
+  {   // the shape tables k_physics indexes without further checks
+    const int ns = scene->n_static, nr = scene->n_rbox;
+    bool ok = ns >= 0 && ns <= SDX_MAX_STATIC && nr >= 0 && nr <= SDX_MAX_RBOX && scene->n_static_sub >= 0 && scene->n_static_sub <= SDX_MAX_STATIC_SUB;
+    // candidate body pairs of the broadphase: <= 16 per lane of the 512-thread workgroup (the pair rank's 13 bits)
+    ok = ok && SDX_NFREE * ns + SDX_NFREE * (SDX_NFREE - 1) / 2 + nr * (SDX_NFREE + ns) <= 16 * 512;
+    for (int t = 0; ok && t < SDX_NBRICK_TYPES; ++t)
+      ok = scene->brick_nsub[t] >= 1 && scene->brick_nsub[t] <= SDX_MAX_SUB && scene->hollow_nsub[t] >= 0 && scene->hollow_nsub[t] <= SDX_MAX_SUB_HOLLOW &&
+           (!scene->seg_hollow || scene->hollow_nsub[t] >= 1);
+    for (int r = 0; ok && r < SDX_MAX_STATIC_TAB; ++r) {
+      const bool used = r < ns || (scene->static_var_slot >= 0 && (r == scene->static_var_row[0] || r == scene->static_var_row[1] || r == scene->static_var_row[2]));
+      if (used) ok = scene->static_sub_n[r] >= 1 && scene->static_sub_n[r] <= 63 && scene->static_sub_first[r] >= 0 &&
+                     scene->static_sub_first[r] + scene->static_sub_n[r] <= scene->n_static_sub;
+    }
+    if (scene->static_var_slot >= ns) ok = false;
+    for (int k = 0; ok && scene->static_var_slot >= 0 && k < 3; ++k) ok = scene->static_var_row[k] >= 0 && scene->static_var_row[k] < SDX_MAX_STATIC_TAB;
+    if (!ok) { g_create_err = "sdx_create: scene shape tables out of range (n_static, n_rbox, brick / static compounds)"; return SDX_ERR_INVALID; }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_create_err = "sdx_create: no HIP device visible; libseqdex_hip has no CPU fallback";

@@ -4,7 +4,7 @@
 // lives in the closed Isaac Gym / PhysX binary.  The step is OUR definition ("SDX-1"), restated independently in
 // plain C in oracle/physics_oracle.c:
 //   A FK  B joint-space inertia + implicit-PD matrix, Cholesky inverse  C implicit PD drive, velocity-product terms, gravity
-//   D sampled-SDF box/box contacts (<= 4 per pair)  E active-set mass-split Jacobi on accumulated impulses
+//   D sampled-SDF box/box contacts (<= 4 per pair of boxes; every shape a compound of boxes)  E active-set mass-split Jacobi on accumulated impulses
 //   F semi-implicit Euler;  then outputs: rigid-body states, end-effector Jacobian, net arm contact forces.
 //
 // Shape of the kernel (rewritten in round 2, restructured in round 3):
@@ -18,8 +18,9 @@
 //     rebuilds its link's twist | barrier;
 //   * everything serial (FK levels, Cholesky in registers, drive, twists) runs on wave 0 with wave-synchronous hand-offs instead of
 //     workgroup barriers; the other waves meet it at the next barrier;
-//   * broadphase: every lane tests its strided candidates into a bit mask, ONE block scan places all hits; narrowphase: lane = pair picks
-//     the samples, lane = contact computes their geometry.
+//   * broadphase: every lane tests its strided candidate BODY pairs (bounding boxes) into a bit mask, ONE block scan places all hits; the
+//     surviving body pairs are expanded into the box pairs of the two compounds (consecutive candidates per lane, separating-axis test);
+//     narrowphase: lane = box pair picks the samples, lane = contact computes their geometry.
 #include <stdlib.h>
 
 #include "sdx_common.h"
@@ -68,13 +69,21 @@ struct PhysLds {
   alignas(16) float bv[NBODY][4];
   alignas(16) float bw[NBODY][4];
   float bq[NF][4];
-  float bh[NF][3], brad[NF];
-  float bim[NF], bii[NF][3];   // inverse mass / inverse principal inertia (target brick already scaled by 1 / seg_mass_scale)
+  float bim[NF];               // inverse mass (target brick already scaled by 1 / seg_mass_scale)
   float bK[NF][6];             // world inverse inertia R diag(1/I) R^T of the substep (xx yy zz xy xz yz)
+  // collision compounds by brick TYPE, in the brick's centre-of-mass frame: tsc / tsh the boxes (slabs of the convex
+  // hull), tbc / tbh the bounding box, trad a radius about the centre of mass that contains it; hsc / hsh / hn: the hollow compound of
+  // THIS env's target brick (walls, roof, upper part) when the scene asks for it (seg_hollow), else hn = 0
+  unsigned char btype[NF];
+  int tn[SDX_NBRICK_TYPES], hn;
+  float tsc[SDX_NBRICK_TYPES][SDX_MAX_SUB][3], tsh[SDX_NBRICK_TYPES][SDX_MAX_SUB][3];
+  float tbc[SDX_NBRICK_TYPES][3], tbh[SDX_NBRICK_TYPES][3], trad[SDX_NBRICK_TYPES], tii[SDX_NBRICK_TYPES][3];
+  float hsc[SDX_MAX_SUB_HOLLOW][3], hsh[SDX_MAX_SUB_HOLLOW][3];
   // robot collision boxes in the world
   float rc[SDX_MAX_RBOX][3], rq[SDX_MAX_RBOX][4], rh[SDX_MAX_RBOX][3], rrad[SDX_MAX_RBOX];
   int rbl[SDX_MAX_RBOX];
-  float sth[SDX_MAX_STATIC][3], stc[SDX_MAX_STATIC][3];   // static boxes as THIS env sees them
+  float sth[SDX_MAX_STATIC][3], stc[SDX_MAX_STATIC][3];   // bounding boxes of the static bodies as THIS env sees them
+  int ssf[SDX_MAX_STATIC], ssn[SDX_MAX_STATIC];           // their boxes: rows [ssf, ssf + ssn) of sdx_scene_desc.static_sub_* (read from HBM: only the studded base plate has more than one)
   int acount[2][NF + 2];   // ACTIVE contacts per brick, [NF] on the whole robot, [NF + 1] = 0 (static world): one set is read while the other is counted; integer atomics
   int ecount[NF + NL];  // CSR build: contact sides per body
   float Qc[NL][12];     // per iteration: generalised impulse the contacts of link k apply to the s-th dof of its path (<= 11 dofs)
@@ -84,17 +93,23 @@ struct PhysLds {
   int wsum[16];
   // contacts: geometry in LDS for the whole solve
   float cp[3][MAXC], cn[3][MAXC];
-  // three rows that are, in turn: the narrowphase's staging of (separation, body ids) + the candidate pair list; L^-1 of the mass
+  // (before the narrowphase has produced them, cp / cn hold the list of candidate BOX pairs and the body pairs' offsets into it: S_SP0 ...)
+  // three rows that are, in turn: the narrowphase's staging of (separation, body ids) + the candidate body-pair list; L^-1 of the mass
   // matrix; the unsorted CSR fill order during the solver set-up; and the per-contact impulse P of the current iteration
   float P[3][MAXC];
   unsigned short ent[2 * MAXC];   // CSR entries: contact index | side << 15, grouped by body (bricks, then links), ascending contact index
 };
 #define S_T(S) (reinterpret_cast<float (*)[HP]>(&(S).P[0][0]))                       // L^-1 (mass matrix phase)
-#define S_PAIRS(S) (reinterpret_cast<uint32_t*>(&(S).P[2][0]))                       // candidate pairs (collide)
+#define S_PAIRS(S) (reinterpret_cast<uint32_t*>(&(S).P[2][0]))                       // candidate body pairs (collide)
+#define MAXSP (2 * MAXC)                                                             // candidate box pairs per env
+#define S_SP0(S) (reinterpret_cast<uint32_t*>(&(S).cp[0][0]))                        // box pair: box a | sub a << 7 | box b << 11 | sub b << 19
+#define S_SP1(S) (reinterpret_cast<uint32_t*>(&(S).cn[0][0]))                        // ... its identity: rank of the body pair << 9 | index of the box pair inside it
+#define S_OFF(S) (reinterpret_cast<int*>(&(S).cn[0][0]) + MAXSP)                     // body pair -> first candidate box pair (exclusive prefix sum)
 #define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[0][0]))                  // unsorted CSR entries (solver set-up)
 #define S_EBODY2(S) (reinterpret_cast<unsigned char*>(&(S).P[1][0]))                 // ... and the body each one belongs to
 static_assert(ND * HP <= MAXC, "L^-1 must fit one row");
 static_assert(MAXP <= MAXC, "the pair list must fit one row");
+static_assert(MAXSP + MAXP + 1 <= 3 * MAXC, "box pairs and body-pair offsets fit the rows of cn");
 static_assert(2 * MAXC * sizeof(unsigned short) == MAXC * sizeof(uint32_t), "contact keys alias the CSR entries");
 static_assert(sizeof(PhysLds) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
 
@@ -143,25 +158,56 @@ __device__ __forceinline__ void tangents(f3 n, f3* t1, f3* t2) {
   *t2 = F3(b, sg + n.y * n.y * a, -n.y);
 }
 
-// box id: 0..71 brick, 72..103 robot box, 128.. static
-__device__ __forceinline__ Box load_box(const PhysLds& S, int id) {
+// ---- shapes.  Box id: 0..71 brick, 72..111 robot box, 128..135 static body; a brick and a static body are COMPOUNDS of boxes (sub index),
+// a robot box is one box.  load_bound: the bounding box of a body (broadphase, first separating-axis pass); load_box: one box of it.
+#define RBOX0 NF
+#define STATIC0 128
+static_assert(RBOX0 + SDX_MAX_RBOX <= STATIC0 && STATIC0 + SDX_MAX_STATIC <= 256, "box ids fit 8 bits (7 for the first box of a pair)");
+__device__ __forceinline__ bool brick_hollow(const PhysLds& S, int i) { return S.hn > 0 && i == S.seg_brick; }
+__device__ __forceinline__ int box_nsub(const PhysLds& S, int id) {
+  if (id < NF) return brick_hollow(S, id) ? S.hn : S.tn[S.btype[id]];
+  if (id < STATIC0) return 1;
+  return S.ssn[id - STATIC0];
+}
+__device__ __forceinline__ Box load_bound(const PhysLds& S, int id) {
   Box b;
   if (id < NF) {
-    b.c = ld3(S.bp[id]); b.q = ld4(S.bq[id]); b.h = ld3(S.bh[id]);
-  } else if (id < 128) {
-    const int r = id - NF;
+    const int t = S.btype[id];
+    b.q = ld4(S.bq[id]); b.c = ld3(S.bp[id]) + qrot(b.q, ld3(S.tbc[t])); b.h = ld3(S.tbh[t]);
+  } else if (id < STATIC0) {
+    const int r = id - RBOX0;
     b.c = ld3(S.rc[r]); b.q = ld4(S.rq[r]); b.h = ld3(S.rh[r]);
   } else {
-    const int s = id - 128;
-    b.c = ld3(S.stc[s]); b.h = ld3(S.sth[s]); b.q.x = 0; b.q.y = 0; b.q.z = 0; b.q.w = 1;
+    const int st = id - STATIC0;
+    b.c = ld3(S.stc[st]); b.h = ld3(S.sth[st]); b.q.x = 0; b.q.y = 0; b.q.z = 0; b.q.w = 1;
   }
   return b;
 }
+__device__ __forceinline__ Box load_box(const SdxConst* C, const PhysLds& S, int id, int sub) {
+  Box b;
+  if (id < NF) {
+    const int t = S.btype[id];
+    const bool hol = brick_hollow(S, id);
+    b.q = ld4(S.bq[id]);
+    b.c = ld3(S.bp[id]) + qrot(b.q, hol ? ld3(S.hsc[sub]) : ld3(S.tsc[t][sub]));
+    b.h = hol ? ld3(S.hsh[sub]) : ld3(S.tsh[t][sub]);
+    return b;
+  }
+  if (id >= STATIC0 && S.ssn[id - STATIC0] > 1) {   // a box of a static compound (the studded base plate): the table lives in HBM
+    const int r = S.ssf[id - STATIC0] + sub;
+    b.c = ld3(C->sc.static_sub_center[r]); b.h = ld3(C->sc.static_sub_half[r]); b.q.x = 0; b.q.y = 0; b.q.z = 0; b.q.w = 1;
+    return b;
+  }
+  return load_bound(S, id);
+}
 __device__ __forceinline__ int box_body(const PhysLds& S, int id) {
   if (id < NF) return id;
-  if (id < 128) return NF + S.rbl[id - NF];
+  if (id < STATIC0) return NF + S.rbl[id - RBOX0];
   return BODY_W;
 }
+// the second direction of a pair (samples of B against A) exists unless B is the body box of a static (the studs
+// of a static compound, boxes 1.., are sampled like a brick's boxes)
+__device__ __forceinline__ bool samples_b(int bid, int bsub) { return bid < STATIC0 || bsub > 0; }
 
 // ---- contact manifold of one direction (samples of A against box B); oracle: dir_setup / sample_contact
 // Reference face = the face axis of B with the smallest overlap of the two boxes' extents (separating-axis test over B's three face
@@ -204,48 +250,89 @@ __device__ __forceinline__ float sample_contact(const Dir& D, f3 pb, f3 h, f3* g
   return box_sdf(pb, h, g);
 }
 
-// samples of A against B; returns count (<= 4; -1: separated), indices packed 8 bits each.  The 28 samples are unrolled with their table
-// entries as immediates (corners are three adds), in a copy of B's frame whose z axis is the reference face axis (no per-sample
-// selects), and the classes land in two bit masks: face samples / other samples inside the contact offset (squared distance, no sqrt).
-constexpr float kSamp[SDX_NSAMP][3] = {
-    {1, 1, 1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1},
-    {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
-    {-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0},
-    {-0.5f, -1, -1}, {0.5f, -1, -1}, {-0.5f, 1, -1}, {0.5f, 1, -1}, {-0.5f, -1, 1}, {0.5f, -1, 1}, {-0.5f, 1, 1}, {0.5f, 1, 1}};
 __device__ __forceinline__ f3 face_frame(f3 v, int kax) {   // component kax moves to z
   return kax == 0 ? F3(v.y, v.z, v.x) : kax == 1 ? F3(v.x, v.z, v.y) : v;
 }
-// incl: samples closer than this are contacts - the contact offset, or 0 when the list is rebuilt after a capacity overflow (collide())
-__device__ __forceinline__ int sample_dir(const Box& A, const Box& B, float off, float incl, uint32_t* packed) {
-  const Dir D = dir_setup(A, B, off);
-  *packed = 0;
-  if (D.smax >= incl) return -1;   // separated: neither direction has a sample inside the threshold
+// ---- the <= 4 contacts of a pair of boxes (oracle: collide_pair).  classify_dir: the 28 samples of box A against box
+// T in the face frame of that direction -> face samples / other samples inside `incl` as bit masks (incl: the contact offset, or 0 when
+// the list is rebuilt after a capacity overflow), and for the face samples the running extremes along the four directions at 22.5 degrees +
+// k x 90 degrees of the lateral plane (a, b) of the PAIR's reference frame - box B's axes without the axis kref of direction 1's
+// reference face.  DIR2: the samples are B's own (a, b = table entry x hB, no transform); their ids are 32 + s.
+#define EXT_C 0.92387953f
+#define EXT_S 0.38268343f
+template <bool DIR2>
+__device__ __forceinline__ bool classify_dir(const Box& A, const Box& T, float off, float incl, int* kref, f3 hB, uint32_t* mface_out,
+                                             uint32_t* mother_out, float (&ext)[4], int (&ei)[4]) {
+  const Dir D = dir_setup(A, T, off);
+  if (D.smax >= incl) return false;   // separated: no sample of either direction can be inside the threshold
+  if (!DIR2) *kref = D.kax >= 0 ? D.kax : 2;
   const f3 t = face_frame(D.t, D.kax), ex = face_frame(D.ex, D.kax), ey = face_frame(D.ey, D.kax), ez = face_frame(D.ez, D.kax);
-  const f3 h = face_frame(B.h, D.kax);
+  const f3 h = face_frame(T.h, D.kax);
   const float ftol = D.kax >= 0 ? FACE_TOL : -1e30f, off2 = incl * incl;
+  const int kr = *kref;
+  const float ha = kr == 0 ? hB.y : hB.x, hb = kr == 2 ? hB.y : hB.z;
   uint32_t mface = 0, mother = 0;
-#pragma unroll
+  // (the sample index is wave-uniform: the table entries arrive through scalar loads.  Fully unrolled with the entries as immediates -
+  // round 3's form of the per-direction loop - the two instances of this loop cost the WHOLE kernel 220 spilled VGPRs, 18 scratch
+  // operations inside the solver's iteration loop among them)
+#ifndef SDX_CLASSIFY_UNROLL
+#define SDX_CLASSIFY_UNROLL 4
+#endif
+  constexpr int CU = SDX_CLASSIFY_UNROLL;
+#pragma unroll CU
   for (int s = 0; s < SDX_NSAMP; ++s) {
-    const f3 pb = ((t + ex * kSamp[s][0]) + ey * kSamp[s][1]) + ez * kSamp[s][2];
+    const float* kSamp_s = c_samp[s];
+#define KS(s_, c_) kSamp_s[c_]
+    const f3 pb = ((t + ex * KS(s, 0)) + ey * KS(s, 1)) + ez * KS(s, 2);
     const float dx = fabsf(pb.x) - h.x, dy = fabsf(pb.y) - h.y, dz = fabsf(pb.z) - h.z;
     const float lat = fmaxf(dx, dy);
-    const bool face = lat <= ftol;
     const float sdf = D.sgn * pb.z - h.z;
     const float ox = fmaxf(dx, 0.0f), oy = fmaxf(dy, 0.0f), oz = fmaxf(dz, 0.0f);
     const bool near = fmaxf(lat, dz) <= 0.0f || ox * ox + oy * oy + oz * oz < off2;
-    if (face ? sdf < incl : false) mface |= 1u << s;
-    if (face ? false : near) mother |= 1u << s;
+    const bool face = lat <= ftol;
+    const bool isf = face && sdf < incl;
+    if (isf) mface |= 1u << s;
+    if (!face && near) mother |= 1u << s;
+    // lateral coordinates in the pair's reference frame
+    const float a = DIR2 ? (kr == 0 ? KS(s, 1) : KS(s, 0)) * ha : pb.x;
+    const float b = DIR2 ? (kr == 2 ? KS(s, 1) : KS(s, 2)) * hb : pb.y;
+    const float k0 = EXT_C * a + EXT_S * b, k1 = EXT_C * b - EXT_S * a;
+    const int id = (DIR2 ? 32 : 0) + s;
+    if (isf && k0 > ext[0]) { ext[0] = k0; ei[0] = id; }
+    if (isf && k1 > ext[1]) { ext[1] = k1; ei[1] = id; }
+    if (isf && -k0 > ext[2]) { ext[2] = -k0; ei[2] = id; }
+    if (isf && -k1 > ext[3]) { ext[3] = -k1; ei[3] = id; }
   }
-  int c = 0;
-  uint32_t pk = 0;
+#undef KS
+  *mface_out = mface;
+  *mother_out = mother;
+  return true;
+}
+// the 4 slots of the pair: the extreme face samples of both directions, then the remaining face samples (direction 1 in table order, then
+// direction 2), then the other samples (edge / corner regions, speculative contacts) the same way.  Returns the number of contacts;
+// sel1 / sel2: the chosen samples of the two directions.
+__device__ __forceinline__ int pair_contacts(const Box& A, const Box& B, bool second, float off, float incl, uint32_t* sel1, uint32_t* sel2) {
+  float ext[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+  int ei[4] = {-1, -1, -1, -1};
+  uint32_t f1 = 0, o1 = 0, f2 = 0, o2 = 0;
+  int kref = 2;
+  *sel1 = 0; *sel2 = 0;
+  if (!classify_dir<false>(A, B, off, incl, &kref, B.h, &f1, &o1, ext, ei)) return 0;
+  if (second && !classify_dir<true>(B, A, off, incl, &kref, B.h, &f2, &o2, ext, ei)) return 0;
+  uint32_t s1 = 0, s2 = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (mface) { pk |= (uint32_t)(__ffs(mface) - 1) << (8 * c); mface &= mface - 1; ++c; }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (mother && c < 4) { pk |= (uint32_t)(__ffs(mother) - 1) << (8 * c); mother &= mother - 1; ++c; }
-  *packed = pk;
-  return c;
+  for (int k = 0; k < 4; ++k)
+    if (ei[k] >= 0) { if (ei[k] < 32) s1 |= 1u << ei[k]; else s2 |= 1u << (ei[k] - 32); }
+  int n = __popc(s1) + __popc(s2);
+  uint32_t m;
+#define SDX_FILL(mask, sel)                                   \
+  m = (mask) & ~(sel);                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)               \
+    if (m && n < 4) { (sel) |= m & (0u - m); m &= m - 1; ++n; }
+  SDX_FILL(f1, s1) SDX_FILL(f2, s2) SDX_FILL(o1, s1) SDX_FILL(o2, s2)
+#undef SDX_FILL
+  *sel1 = s1; *sel2 = s2;
+  return n;
 }
 
 #define S_CKEY(S) (reinterpret_cast<uint32_t*>(&(S).ent[0]))   // identity of contact c until the solver's set-up has read it (the CSR lives here later)
@@ -256,7 +343,8 @@ __device__ __forceinline__ f3 point_vel(const PhysLds& S, int id, f3 p) {   // i
 __device__ __forceinline__ float brick_w(const PhysLds& S, int i, f3 p, f3 d) {
   const f3 rxd = cross(p - ld3(S.bp[i]), d);
   const f3 l = qrot(qconj(ld4(S.bq[i])), rxd);
-  return S.bim[i] + l.x * l.x * S.bii[i][0] + l.y * l.y * S.bii[i][1] + l.z * l.z * S.bii[i][2];
+  const float* ii = S.tii[S.btype[i]];   // mass / principal inertia of the type: inverse inertia = inverse mass x that
+  return S.bim[i] * (1.0f + l.x * l.x * ii[0] + l.y * l.y * ii[1] + l.z * l.z * ii[2]);
 }
 
 // ---------------------------------------------------------------- A: FK, on wave 0 only (lane = link; levels by wave-synchronous hand-off)
@@ -488,15 +576,15 @@ __device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int t
   __syncthreads();
 }
 
-// ---------------------------------------------------------------- block-level exclusive scan of a small count k (0..15), thread order
-template <int NT>
+// ---------------------------------------------------------------- block-level exclusive scan of a small count k (NBITS bits), thread order
+template <int NT, int NBITS = 4>
 __device__ __forceinline__ int block_scan_small(PhysLds& S, int k, int tid, int* total) {
   constexpr int NW = NT / 64;
   const int lane = tid & 63, wave = tid >> 6;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int pre = 0, wt = 0;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < NBITS; ++b) {
     const uint64_t bal = __ballot((k >> b) & 1);
     pre += __popcll(bal & lt) << b;
     wt += __popcll(bal) << b;
@@ -518,21 +606,27 @@ __device__ __forceinline__ int block_scan_small(PhysLds& S, int k, int tid, int*
 __device__ __forceinline__ bool box_near(const PhysLds& S, f3 ca, float ra, f3 cb, f4 qb, f3 hb, float off) {
   return box_sdf_val(qrot(qconj(qb), ca - cb), hb) <= ra + off;
 }
-// pair index -> (box a | box b << 8); box ids: 0..71 brick, 72..103 robot box, 128.. static
+// pair index -> (box a | box b << 8); box ids: 0..71 brick, 72..111 robot box, 128.. static body
 __device__ __forceinline__ uint32_t pair_code(int idx, int n1, int n2, int ns, int per) {
-  if (idx < n1) return (uint32_t)(idx / ns) | ((uint32_t)(128 + idx % ns) << 8);
+  if (idx < n1) return (uint32_t)(idx / ns) | ((uint32_t)(STATIC0 + idx % ns) << 8);
   if (idx < n1 + n2) {
     int i, j;
     tri_index(idx - n1, &i, &j);   // lower triangle without the diagonal: bricks (j, i + 1), j <= i
     return (uint32_t)j | ((uint32_t)(i + 1) << 8);
   }
   const int t = idx - n1 - n2, r = t / per, u = t % per;
-  return (uint32_t)(NF + r) | ((uint32_t)(u < NF ? u : 128 + u - NF) << 8);
+  return (uint32_t)(RBOX0 + r) | ((uint32_t)(u < NF ? u : STATIC0 + u - NF) << 8);
+}
+// (bricks: sphere of radius trad about the centre of mass - it contains the bounding box, whose centre lies a few millimetres off)
+__device__ __forceinline__ bool brick_near(const PhysLds& S, f3 ca, float ra, int j, float off) {   // centre / radius against brick j's bounding box
+  const f4 qj = ld4(S.bq[j]);
+  const int tj = S.btype[j];
+  return box_sdf_val(qrot(qconj(qj), ca - ld3(S.bp[j])) - ld3(S.tbc[tj]), ld3(S.tbh[tj])) <= ra + off;
 }
 __device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int n2, int ns, int per, float off) {
   if (idx < n1) {
-    const int i = idx / ns, s = idx % ns;
-    return box_sdf_val(ld3(S.bp[i]) - ld3(S.stc[s]), ld3(S.sth[s])) <= S.brad[i] + off;
+    const int i = idx / ns, st = idx % ns;
+    return box_sdf_val(ld3(S.bp[i]) - ld3(S.stc[st]), ld3(S.sth[st])) <= S.trad[S.btype[i]] + off;
   }
   if (idx < n1 + n2) {
     int i, j;
@@ -540,9 +634,10 @@ __device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int
     i += 1;
     const f3 ci = ld3(S.bp[i]), cj = ld3(S.bp[j]);
     const f3 d = ci - cj;
-    const float rr = S.brad[i] + S.brad[j] + off;
+    const float ri = S.trad[S.btype[i]], rj = S.trad[S.btype[j]];
+    const float rr = ri + rj + off;
     if (dot(d, d) > rr * rr) return false;
-    return box_near(S, ci, S.brad[i], cj, ld4(S.bq[j]), ld3(S.bh[j]), off) || box_near(S, cj, S.brad[j], ci, ld4(S.bq[i]), ld3(S.bh[i]), off);
+    return brick_near(S, ci, ri, j, off) || brick_near(S, cj, rj, i, off);
   }
   const int t = idx - n1 - n2, r = t / per, u = t % per;
   if (S.rbl[r] == 0) return false;   // the fixed base never generates contacts
@@ -551,12 +646,13 @@ __device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int
   if (u < NF) {
     const f3 cb = ld3(S.bp[u]);
     const f3 d = rc - cb;
-    const float rr = rr0 + S.brad[u] + off;
+    const float rb = S.trad[S.btype[u]];
+    const float rr = rr0 + rb + off;
     if (dot(d, d) > rr * rr) return false;
-    return box_near(S, rc, rr0, cb, ld4(S.bq[u]), ld3(S.bh[u]), off) || box_near(S, cb, S.brad[u], rc, ld4(S.rq[r]), ld3(S.rh[r]), off);
+    return brick_near(S, rc, rr0, u, off) || box_near(S, cb, rb, rc, ld4(S.rq[r]), ld3(S.rh[r]), off);
   }
-  const int s = u - NF;
-  return box_sdf_val(rc - ld3(S.stc[s]), ld3(S.sth[s])) <= rr0 + off;
+  const int st = u - NF;
+  return box_sdf_val(rc - ld3(S.stc[st]), ld3(S.sth[st])) <= rr0 + off;
 }
 
 template <int NT>
@@ -564,8 +660,8 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   const sdx_scene_desc& sc = C->sc;
   const float off = sc.contact_offset;
   const int ns = sc.n_static;
-  // ---- broadphase: lane tid tests candidates tid, tid + NT, ...; hits as a bit mask; ONE block scan places them (lane-major order)
-  const int n1 = NF * ns, n2 = NF * (NF - 1) / 2, per = NF + ns, n3 = sc.n_rbox * per, ntot = n1 + n2 + n3;
+  // ---- broadphase over BODY pairs: lane tid tests candidates tid, tid + NT, ...; hits as a bit mask; ONE block scan places them (lane-major order)
+  const int n1 = NF * ns, n2 = NF * (NF - 1) / 2, per = NF + ns, n3 = sc.n_rbox * per, ntot = n1 + n2 + n3;   // ntot <= 16 NT (sdxk_physics checks)
   uint32_t mask = 0;
   {
     int it = 0;
@@ -576,8 +672,8 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   SSTAMP(32);
   int np;
   {
-    // at most 15 candidates per lane: (72 * 8 + 72 * 71 / 2 + 32 * 80) / 512 < 12 (4 bits of the pair rank)
-    int pos = block_scan_small<NT>(S, __popc(mask), tid, &np);
+    // at most 16 candidates per lane: (72 * 8 + 72 * 71 / 2 + 40 * 80) / 512 < 13 (5 bits of the count, 4 bits of the pair rank)
+    int pos = block_scan_small<NT, 5>(S, __popc(mask), tid, &np);
     uint32_t m = mask;
     while (m) {
       const int it = __ffs(m) - 1;
@@ -588,46 +684,138 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       ++pos;
     }
   }
-  const int pairs_lost = np > MAXP;   // more candidate pairs than the list holds: the excess (lane-major order) is not tested
+  int pairs_lost = np > MAXP;   // more candidate pairs than the list holds: the excess (lane-major order) is not tested
   if (np > MAXP) np = MAXP;
   __syncthreads();
-  // ---- separating-axis pass: a pair that a face axis of either box separates by the whole contact offset cannot produce a contact
-  // (sample_dir would return -1 for it); about half of the sphere-vs-box candidates leave the list here, so that the sampling below
-  // runs once over <= NT pairs instead of twice.  Lane tid looks at the consecutive pairs tid * q .. tid * q + q - 1: order preserved.
+  // ---- separating-axis pass over the bounding boxes: a body pair that a face axis of either bounding box separates by the whole contact
+  // offset cannot produce a contact (its boxes lie inside the bounding boxes); about half of the sphere-vs-box candidates leave the list
+  // here.  Lane tid looks at the consecutive pairs tid * q .. tid * q + q - 1 (order preserved).  A survivor is either
+  //   CONVEX - both sides stand for one convex shape (a brick as the slab compound of its hull, a robot box, a single-box static): it
+  //   contributes ONE box pair, the one with the smallest separation bound sigma = the largest face-axis separation of its directions
+  //   (oracle: collide_bodies); the lane finds it here and leaves its index in bits 29..30 of the pair word, bit 31 set; or
+  //   COMPOUND - a hollow brick or the studded base plate on either side: every (box of A) x (box of B) is a candidate.
+  // The exclusive prefix sum S_OFF of the candidate counts maps a body pair to its first candidate box pair.
+  int nbp;   // candidate box pairs
   {
     constexpr int QMAX = (MAXP + NT - 1) / NT;
-    static_assert(QMAX <= 3, "three survivor slots per lane");
+    static_assert(QMAX <= 2, "two survivor slots per lane");
+    static_assert(SDX_MAX_SUB * SDX_MAX_SUB <= 4, "the winning box pair of a convex body pair in two bits");
     const int q = (np + NT - 1) / NT;
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
-    int kept = 0;
-#pragma unroll
+    uint32_t c0 = 0, c1 = 0;
+    int kept = 0, n0 = 0, nb1 = 0;
+#pragma unroll 1
     for (int k = 0; k < QMAX; ++k) {
       const int pi = tid * q + k;
       if (k < q && pi < np) {
-        const uint32_t pr = S_PAIRS(S)[pi];
-        const int bb = (pr >> 8) & 0xff;
-        const Box A = load_box(S, pr & 0xff), Bx = load_box(S, bb);
-        bool sep = dir_setup(A, Bx, off).smax >= off;
-        if (!sep && bb < 128) sep = dir_setup(Bx, A, off).smax >= off;
+        uint32_t pr = S_PAIRS(S)[pi];
+        const int ba = pr & 0xff, bb = (pr >> 8) & 0xff;
+        bool sep;
+        {
+          const Box A = load_bound(S, ba), Bx = load_bound(S, bb);
+          sep = dir_setup(A, Bx, off).smax >= off;
+          if (!sep && bb < STATIC0) sep = dir_setup(Bx, A, off).smax >= off;
+        }
         if (!sep) {
-          if (kept == 0) c0 = pr; else if (kept == 1) c1 = pr; else c2 = pr;
-          ++kept;
+          const int na = box_nsub(S, ba), nbx = box_nsub(S, bb);
+          int cnt = na * nbx;
+          const bool convex = !(ba < NF && brick_hollow(S, ba)) && !(bb < NF && brick_hollow(S, bb)) && !(bb >= STATIC0 && nbx > 1);
+          if (convex && cnt > 1) {
+            float best = off;
+            int only = -1;
+#pragma unroll 1
+            for (int sidx = 0; sidx < cnt; ++sidx) {
+              const int sa = sidx / nbx, sb = sidx - sa * nbx;
+              const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
+              float sg = dir_setup(A, Bx, off).smax;
+              if (samples_b(bb, sb)) sg = fmaxf(sg, dir_setup(Bx, A, off).smax);
+              if (sg < best) { best = sg; only = sidx; }
+            }
+            cnt = only >= 0 ? 1 : 0;
+            pr |= ((uint32_t)(only & 3) << 29) | 0x80000000u;
+          } else if (convex) {
+            pr |= 0x80000000u;   // a single box on either side: the bounding boxes ARE the boxes
+          }
+          if (cnt > 0) {
+            if (kept == 0) { c0 = pr; n0 = cnt; } else { c1 = pr; nb1 = cnt; }
+            ++kept;
+          }
         }
       }
     }
     int np2;
-    const int pos = block_scan_small<NT>(S, kept, tid, &np2);   // its barrier comes after every lane's reads of the old list
-    if (kept > 0) S_PAIRS(S)[pos] = c0;
-    if (kept > 1) S_PAIRS(S)[pos + 1] = c1;
-    if (kept > 2) S_PAIRS(S)[pos + 2] = c2;
+    const int pos = block_scan_small<NT, 2>(S, kept, tid, &np2);   // its barrier comes after every lane's reads of the old list
+    // counts: <= 2 x (8 boxes of a hollow brick x 33 of a base plate) per lane: 10 bits
+    const int boff = block_scan_small<NT, 10>(S, n0 + nb1, tid, &nbp);
+    if (kept > 0) { S_PAIRS(S)[pos] = c0; S_OFF(S)[pos] = boff; }
+    if (kept > 1) { S_PAIRS(S)[pos + 1] = c1; S_OFF(S)[pos + 1] = boff + n0; }
     np = np2;
+    if (tid == 0) S_OFF(S)[np2] = nbp;
     __syncthreads();
   }
   SSTAMP(33);
-  // ---- narrowphase in two parts.  (1) lane = candidate pair: the <= 4 + 4 samples of the two directions that become contacts; a block prefix
-  // sum of the counts gives every contact its place in pair order, and the lane leaves ONE word per contact there: (pair, direction, sample).
-  // (2) lane = contact (below): geometry of that sample.  (Rounds 1-2 emitted from the pair lanes, which kept both boxes alive across the scan
-  // and ran up to eight emissions in a row on one lane while its neighbours idled: 36 spilled registers, 120 MB of scratch writes per launch.)
+  // ---- expansion: candidate box pair t = S_OFF[p] + (sub a * nsub(b) + sub b) of body pair p.  Lane tid tests the CONSECUTIVE candidates
+  // tid * q2 .. (so the survivors come out in ascending (pair rank, box pair) order: the order of the warm-start keys) with the
+  // separating-axis test of the two boxes; survivors as a bit mask, one block scan, then the lane walks its range again and writes
+  // (box a | sub a << 7 | box b << 11 | sub b << 19) and (pair rank << 9 | box pair index) per survivor.
+  int nsp;
+  {
+    if (nbp > 32 * NT) { nbp = 32 * NT; pairs_lost = 1; }
+    const int q2 = (nbp + NT - 1) / NT;
+    const int t0 = tid * q2, t1 = min(t0 + q2, nbp);
+    int p = 0;
+    if (t0 < t1) {   // the body pair that holds candidate t0: last p with S_OFF[p] <= t0
+      int lo = 0, hi = np;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (S_OFF(S)[mid] <= t0) lo = mid; else hi = mid; }
+      p = lo;
+    }
+    uint32_t keep = 0;
+    {
+      int pp = p, pend = t0 < t1 ? S_OFF(S)[pp + 1] : 0;
+      uint32_t pr = t0 < t1 ? S_PAIRS(S)[pp] : 0;
+      int nbs = t0 < t1 ? box_nsub(S, (pr >> 8) & 0xff) : 1;
+#pragma unroll 1
+      for (int t = t0; t < t1; ++t) {
+        while (t >= pend) { ++pp; pend = S_OFF(S)[pp + 1]; pr = S_PAIRS(S)[pp]; nbs = box_nsub(S, (pr >> 8) & 0xff); }
+        bool sep = false;
+        if (!(pr >> 31)) {   // (a convex pair's only candidate has passed its test in the pass above)
+          const int sidx = t - S_OFF(S)[pp];
+          const int ba = pr & 0xff, bb = (pr >> 8) & 0xff, sa = sidx / nbs, sb = sidx - sa * nbs;
+          const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
+          sep = dir_setup(A, Bx, off).smax >= off;
+          if (!sep && samples_b(bb, sb)) sep = dir_setup(Bx, A, off).smax >= off;
+        }
+        if (!sep) keep |= 1u << (t - t0);
+      }
+    }
+    const int pos0 = block_scan_small<NT, 6>(S, __popc(keep), tid, &nsp);
+    {
+      int pos = pos0, pp = p, pend = t0 < t1 ? S_OFF(S)[pp + 1] : 0;
+      uint32_t pr = t0 < t1 ? S_PAIRS(S)[pp] : 0;
+      int nbs = t0 < t1 ? box_nsub(S, (pr >> 8) & 0xff) : 1;
+      uint32_t m = keep;
+#pragma unroll 1
+      while (m) {
+        const int t = t0 + __ffs(m) - 1;
+        m &= m - 1;
+        while (t >= pend) { ++pp; pend = S_OFF(S)[pp + 1]; pr = S_PAIRS(S)[pp]; nbs = box_nsub(S, (pr >> 8) & 0xff); }
+        const int sidx = (pr >> 31) ? (int)((pr >> 29) & 3u) : t - S_OFF(S)[pp];
+        const int ba = pr & 0xff, bb = (pr >> 8) & 0xff, sa = sidx / nbs, sb = sidx - sa * nbs;
+        if (pos < MAXSP) {
+          S_SP0(S)[pos] = (uint32_t)ba | ((uint32_t)sa << 7) | ((uint32_t)bb << 11) | ((uint32_t)sb << 19);
+          S_SP1(S)[pos] = (((pr >> 16) & 0x1fffu) << 9) | (uint32_t)sidx;
+        }
+        ++pos;
+      }
+    }
+    if (nsp > MAXSP) { nsp = MAXSP; pairs_lost = 1; }
+    __syncthreads();
+  }
+  SSTAMP(37);
+  // ---- narrowphase in two parts.  (1) lane = candidate box pair: the <= 4 samples of the two directions that become contacts
+  // (pair_contacts); a block prefix sum of the counts gives every contact its place in pair order, and the lane leaves TWO words per
+  // contact there: (boxes, direction, sample) and the contact's identity.  (2) lane = contact (below): geometry of that sample.
+  // (Rounds 1-2 emitted from the pair lanes, which kept both boxes alive across the scan and ran up to eight emissions in a row on one lane
+  // while its neighbours idled: 36 spilled registers, 120 MB of scratch writes per launch.)
   // Capacity rule (oracle: collide()): a list that would exceed MAXC contacts is rebuilt without its speculative
   // part - only samples that touch or penetrate (inclusion threshold 0 instead of the contact offset); what still does not fit is
   // dropped in enumeration order and counted.  The second pass is the same code in a run-time loop (block-uniform trip count).
@@ -636,29 +824,33 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     nc = 0;
-    for (int base = 0; base < np; base += NT) {
+#pragma unroll 1
+    for (int base = 0; base < nsp; base += NT) {
       const int pi = base + tid;
-      int k1 = 0, k2 = 0;
-      uint32_t p1 = 0, p2 = 0;
-      if (pi < np) {
-        const uint32_t pr = S_PAIRS(S)[pi];
-        const int ba = pr & 0xff, bb = (pr >> 8) & 0xff;
-        const Box A = load_box(S, ba), Bx = load_box(S, bb);
-        const int c1 = sample_dir(A, Bx, off, incl, &p1);
-        const int c2 = (bb >= 128 || c1 < 0) ? 0 : sample_dir(Bx, A, off, incl, &p2);
-        if (c1 >= 0 && c2 >= 0) {
-          const int m2 = c2 < 2 ? c2 : 2;
-          k1 = c1 < 4 - m2 ? c1 : 4 - m2;
-          k2 = c2 < 4 - k1 ? c2 : 4 - k1;
-        }
+      uint32_t s1 = 0, s2 = 0, w0 = 0, w1 = 0;
+      int k = 0;
+      if (pi < nsp) {
+        w0 = S_SP0(S)[pi]; w1 = S_SP1(S)[pi];
+        const int ba = w0 & 0x7f, sa = (w0 >> 7) & 0xf, bb = (w0 >> 11) & 0xff, sb = (w0 >> 19) & 0x3f;
+        const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
+        k = pair_contacts(A, Bx, samples_b(bb, sb), off, incl, &s1, &s2);
       }
       int tot;
-      const int pre = block_scan_small<NT>(S, k1 + k2, tid, &tot);
+      int c = nc + block_scan_small<NT, 3>(S, k, tid, &tot);
+      // (the descriptors go to the impulse rows P[0] / P[1]: the box pair list in cp / cn stays intact for the second pass)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ca = nc + pre + i, cb = nc + pre + k1 + i;
-        if (i < k1 && ca < MAXC) S.P[0][ca] = __int_as_float(pi | (int)(((p1 >> (8 * i)) & 0xff) << 11));
-        if (i < k2 && cb < MAXC) S.P[0][cb] = __int_as_float(pi | (1 << 10) | (int)(((p2 >> (8 * i)) & 0xff) << 11));
+        if (s1) {
+          const int sm = __ffs(s1) - 1;
+          s1 &= s1 - 1;
+          if (c < MAXC) { S.P[0][c] = __int_as_float((int)(w0 | ((uint32_t)sm << 26))); S.P[1][c] = __int_as_float((int)((w1 << 6) | (uint32_t)sm)); }
+          ++c;
+        } else if (s2) {
+          const int sm = __ffs(s2) - 1;
+          s2 &= s2 - 1;
+          if (c < MAXC) { S.P[0][c] = __int_as_float((int)(w0 | (1u << 25) | ((uint32_t)sm << 26))); S.P[1][c] = __int_as_float((int)((w1 << 6) | 0x20u | (uint32_t)sm)); }
+          ++c;
+        }
       }
       nc += tot;
     }
@@ -666,18 +858,18 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     incl = 0.0f;      // (the scans' barriers order this pass's LDS writes before the next pass's)
     rebuilt = 1;
   }
-  __syncthreads();
-  // ---- (2) lane = contact: point, normal, separation of sample s of box A against box B (oracle: emit_dir)
+  __syncthreads();   // the box pair list in cp / cn is dead from here on
+  // ---- (2) lane = contact: point, normal, separation of sample s of box A against box B (oracle: emit_mask); the descriptor of contact c
+  // sits in P[0][c] / P[1][c], which the same lane overwrites with the results
   {
     const int ncc = nc < MAXC ? nc : MAXC;
 #pragma unroll 1
     for (int c = tid; c < ncc; c += NT) {
-      const int d = __float_as_int(S.P[0][c]);
-      const uint32_t pr = S_PAIRS(S)[d & 1023];
-      const int dirb = (d >> 10) & 1, sidx = d >> 11;
-      const int b0 = pr & 0xff, b1 = (pr >> 8) & 0xff;
-      const int ba = dirb ? b1 : b0, bb = dirb ? b0 : b1;
-      const Box A = load_box(S, ba), Bx = load_box(S, bb);
+      const uint32_t d = (uint32_t)__float_as_int(S.P[0][c]), key = (uint32_t)__float_as_int(S.P[1][c]);
+      const int dirb = (d >> 25) & 1, sidx = d >> 26;
+      const int b0 = d & 0x7f, s0 = (d >> 7) & 0xf, b1 = (d >> 11) & 0xff, sb1 = (d >> 19) & 0x3f;
+      const int ba = dirb ? b1 : b0, bb = dirb ? b0 : b1, sa = dirb ? sb1 : s0, sb = dirb ? s0 : sb1;
+      const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
       const Dir D = dir_setup(A, Bx, off);
       const f3 pb = ((D.t + D.ex * c_samp[sidx][0]) + D.ey * c_samp[sidx][1]) + D.ez * c_samp[sidx][2];
       f3 g;
@@ -689,7 +881,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       S.cn[0][c] = n.x; S.cn[1][c] = n.y; S.cn[2][c] = n.z;
       S.P[0][c] = sd;                                       // staged for the owner lane of contact c (solver set-up)
       S.P[1][c] = __int_as_float(box_body(S, ba) | (box_body(S, bb) << 8));
-      S_CKEY(S)[c] = ((pr >> 16) << 6) | ((uint32_t)dirb << 5) | (uint32_t)sidx;   // (pair rank << 6 | direction << 5) | sample
+      S_CKEY(S)[c] = key;   // (pair rank << 9 | box pair) << 6 | direction << 5 | sample: 28 bits
     }
   }
   if (tid == 0) {
@@ -773,7 +965,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   for (int i = tid; i < NB; i += NT) { S.ecount[i] = 0; S.efill[i] = 0; }
   if (last_substep) for (int i = tid; i < NL * 3; i += NT) (&S.cf[0][0])[i] = 0.0f;
   __syncthreads();   // also: every lane has read its (separation, ids, key) out of the staging rows, which the fill list reuses below
-  // warm-start match: the old keys ascend in their pair rank (bits 6..), so the pair's first old contact is a lower bound away; the
+  // warm-start match: the old keys ascend in their pair part (bits 6..27: body pair rank, box pair), so the pair's first old contact is a lower bound away; the
   // <= 4 contacts of a pair are then compared exactly.  wmatch packs the matched positions (11 bits each, 0x7ff = none); the
   // impulses themselves are fetched where the lam registers are born.  The new keys replace the old ones in HBM right away (the
   // old ones are in LDS now; the old impulses stay untouched until the end of this solve).
@@ -789,20 +981,19 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         int lo = 0, hi = nold;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
-          if ((((uint32_t)__float_as_int(S.P[2][mid]) & 0xffffffu) >> 6) < (key >> 6)) lo = mid + 1; else hi = mid;
+          if ((((uint32_t)__float_as_int(S.P[2][mid]) & 0x0fffffffu) >> 6) < (key >> 6)) lo = mid + 1; else hi = mid;
         }
         int found = 0x7ff;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int i = lo + u;
           const uint32_t ok = i < nold ? (uint32_t)__float_as_int(S.P[2][i]) : 0xffffffffu;
-          if ((ok & 0xffffffu) == key) { found = i; age = (ok >> 24) + 1u; }
+          if ((ok & 0x0fffffffu) == key) { found = i; age = (ok >> 28) + 1u; }
         }
         wmatch = (wmatch & ~(0x7ffull << (11 * q))) | ((uint64_t)found << (11 * q));
       }
-      if (age > 255u) age = 255u;
       wage |= age << (8 * q);
-      wkey[c] = key | (age << 24);   // bits 24..31: the number of consecutive solves this contact has existed before (saturating)
+      wkey[c] = key | ((age < 15u ? age : 15u) << 28);   // bits 28..31: the number of consecutive solves this contact has existed before (saturating at 15: the ramp is over after warm_age <= 16 solves)
     }
   }
 #pragma unroll
@@ -996,7 +1187,8 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     if (gbody < NF && gsub == 0) {
       const f4 q = ld4(S.bq[gbody]);
       const f3 ex = qrot(q, F3(1, 0, 0)), ey = qrot(q, F3(0, 1, 0)), ez = qrot(q, F3(0, 0, 1));   // columns of R
-      const float i0 = S.bii[gbody][0], i1 = S.bii[gbody][1], i2 = S.bii[gbody][2];
+      const float* ii = S.tii[S.btype[gbody]];
+      const float i0 = S.bim[gbody] * ii[0], i1 = S.bim[gbody] * ii[1], i2 = S.bim[gbody] * ii[2];
       S.bK[gbody][0] = i0 * ex.x * ex.x + i1 * ey.x * ey.x + i2 * ez.x * ez.x;
       S.bK[gbody][1] = i0 * ex.y * ex.y + i1 * ey.y * ey.y + i2 * ez.y * ez.y;
       S.bK[gbody][2] = i0 * ex.z * ex.z + i1 * ey.z * ey.z + i2 * ez.z * ez.z;
@@ -1262,13 +1454,27 @@ __device__ __forceinline__ void load_constants(const SdxConst* C, PhysLds& S, in
   }
   if (tid <= NL) S.par[tid] = tid < NL ? (tid == 0 ? 0 : sc.parent[tid]) : NL;
   if (tid == 0) { S.qd[ND] = 0.0f; st3(S.la[NL], F3(0, 0, 0)); st3(S.lal[NL], F3(0, 0, 0)); }
+  const int segt = sc.brick_type[segb];
   for (int i = tid; i < NF; i += NT) {
     const int t = sc.brick_type[i];
-    st3(S.bh[i], ld3(sc.brick_half[t]));
-    S.brad[i] = C->brick_radius[t];
-    const float isc = i == segb ? 1.0f / sc.seg_mass_scale : 1.0f;
-    S.bim[i] = isc / sc.brick_mass[t];
-    S.bii[i][0] = isc / sc.brick_inertia[t][0]; S.bii[i][1] = isc / sc.brick_inertia[t][1]; S.bii[i][2] = isc / sc.brick_inertia[t][2];
+    S.btype[i] = (unsigned char)t;
+    S.bim[i] = (i == segb ? 1.0f / sc.seg_mass_scale : 1.0f) / sc.brick_mass[t];
+  }
+  // collision compounds of the 8 brick types (centre-of-mass frame) and the hollow compound of this env's target brick
+  if (tid < SDX_NBRICK_TYPES) {
+    const int t = tid;
+    const f3 com = ld3(sc.brick_com[t]), bc = ld3(sc.brick_center[t]) - com, bh = ld3(sc.brick_half[t]);
+    S.tn[t] = sc.brick_nsub[t];
+    st3(S.tbc[t], bc); st3(S.tbh[t], bh);
+    S.trad[t] = sqrtf(dot(bc, bc)) + C->brick_radius[t];
+    S.tii[t][0] = sc.brick_mass[t] / sc.brick_inertia[t][0]; S.tii[t][1] = sc.brick_mass[t] / sc.brick_inertia[t][1];
+    S.tii[t][2] = sc.brick_mass[t] / sc.brick_inertia[t][2];
+    for (int k = 0; k < SDX_MAX_SUB; ++k) { st3(S.tsc[t][k], ld3(sc.brick_sub_center[t][k]) - com); st3(S.tsh[t][k], ld3(sc.brick_sub_half[t][k])); }
+  }
+  if (tid >= 64 && tid < 64 + SDX_MAX_SUB_HOLLOW) {
+    const int k = tid - 64;
+    st3(S.hsc[k], ld3(sc.hollow_sub_center[segt][k]) - ld3(sc.brick_com[segt])); st3(S.hsh[k], ld3(sc.hollow_sub_half[segt][k]));
+    if (k == 0) S.hn = sc.seg_hollow ? sc.hollow_nsub[segt] : 0;
   }
   if (tid < SDX_MAX_RBOX) {
     const bool on = tid < sc.n_rbox;
@@ -1276,10 +1482,10 @@ __device__ __forceinline__ void load_constants(const SdxConst* C, PhysLds& S, in
     st3(S.rh[tid], on ? ld3(sc.rbox_half[tid]) : F3(0, 0, 0));
     S.rrad[tid] = on ? C->rbox_radius[tid] : 0.0f;
   }
-  if (tid < SDX_MAX_STATIC) {   // InsertSim's base plate has one of three heights by env % 3 (sdx_scene_desc.static_var_*)
-    f3 c = ld3(sc.static_center[tid]), hh = ld3(sc.static_half[tid]);
-    if (tid == sc.static_var_slot) { const int k = e % 3; c.z = sc.static_var_center_z[k]; hh.z = sc.static_var_half_z[k]; }
-    st3(S.stc[tid], c); st3(S.sth[tid], hh);
+  if (tid < SDX_MAX_STATIC) {   // InsertSim's base plate is one of three by env % 3: a row of the static-body table each (sdx_scene_desc.static_var_*)
+    const int row = tid == sc.static_var_slot ? sc.static_var_row[e % 3] : tid;
+    st3(S.stc[tid], ld3(sc.static_center[row])); st3(S.sth[tid], ld3(sc.static_half[row]));
+    S.ssf[tid] = sc.static_sub_first[row]; S.ssn[tid] = tid < sc.n_static ? sc.static_sub_n[row] : 1;
   }
 }
 
@@ -1306,7 +1512,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     const float* s = root_e + (SDX_ACTOR_BRICK0 + i) * 13;
     const f4 q = qnormalize(ld4(s + 3));
     st4(S.bq[i], q);
-    st3(S.bp[i], ld3(s) + qrot(q, ld3(sc.brick_center[sc.brick_type[i]])));
+    st3(S.bp[i], ld3(s) + qrot(q, ld3(sc.brick_com[sc.brick_type[i]])));
     st3(S.bv[i], ld3(s + 7));
     st3(S.bw[i], ld3(s + 10));
   }
@@ -1407,7 +1613,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     const int k = i / 13, c = i % 13;
     float v;
     if (c < 3) {
-      const f3 o = ld3(S.bp[k]) - qrot(ld4(S.bq[k]), ld3(sc.brick_center[sc.brick_type[k]]));
+      const f3 o = ld3(S.bp[k]) - qrot(ld4(S.bq[k]), ld3(sc.brick_com[sc.brick_type[k]]));
       v = c == 0 ? o.x : c == 1 ? o.y : o.z;
     } else if (c < 7) v = S.bq[k][c - 3];
     else if (c < 10) v = S.bv[k][c - 7];

@@ -103,14 +103,32 @@ class Scene:
         for t, bt in enumerate(self.brick_types):
             d.brick_half[t][:] = bt["half"]
             d.brick_center[t][:] = bt["center"]
+            d.brick_com[t][:] = bt["com"]
             d.brick_mass[t] = bt["mass"]
             d.brick_inertia[t][:] = bt["inertia_diag"]
+            assert len(bt["sub"]) <= _abi.MAX_SUB and len(bt["hollow"]) <= _abi.MAX_SUB_HOLLOW
+            d.brick_nsub[t] = len(bt["sub"])
+            for k, bx in enumerate(bt["sub"]):
+                d.brick_sub_center[t][k][:] = bx["center"]
+                d.brick_sub_half[t][k][:] = bx["half"]
+            d.hollow_nsub[t] = len(bt["hollow"])
+            for k, bx in enumerate(bt["hollow"]):
+                d.hollow_sub_center[t][k][:] = bx["center"]
+                d.hollow_sub_half[t][k][:] = bx["half"]
+        d.seg_hollow = 0
         d.brick_type[:] = self.brick_type
         d.n_static = len(self.statics)
         assert d.n_static <= _abi.MAX_STATIC
+        nsub = 0
         for s, st in enumerate(self.statics):
             d.static_center[s][:] = st["center"]
             d.static_half[s][:] = st["half"]
+            boxes = [(st["center"], st["half"])]
+            if st["name"] == "base_plate":           # body + studs (tools/compile_scene.py::plate_compound), GS:810-838
+                pp = raw["base_plate_pos"]
+                boxes = [([pp[i] + bx["center"][i] for i in range(3)], bx["half"]) for bx in raw["base_plate"]["sub"]]
+            nsub = self._add_static_subs(d, s, boxes, nsub)
+        d.n_static_sub = nsub
         d.object_init_state[:] = self.object_init_state
         d.goal_reset_pos[:] = self.goal_reset_pos
         for s in range(6):                      # table + 5 bin walls are the first six statics
@@ -149,6 +167,7 @@ class Scene:
         d.target_euler[:] = [0.0, 3.1415, 1.571]          # OR:477
         d.seg_mass_scale = 1.0                            # GS:980-981 (x1); Orient x50 (OR:977)
         d.static_var_slot = -1
+        d.static_var_row[:] = [0, 0, 0]
         d.seg_cam_pos[:] = [0.35, 0.19, 1.0]              # gym.set_camera_location(camera, env, Vec3(0.35, 0.19, 1.0), Vec3(0.2, 0.19, 0)), SE:875
         d.seg_cam_target[:] = [0.2, 0.19, 0.0]
         d.seg_cam_hfov_deg = 90.0                         # gymapi.CameraProperties default horizontal_fov
@@ -160,30 +179,49 @@ class Scene:
             else:
                 setattr(d, k_, v)
         if d.task_kind == 2:
-            self._place_insert_plates(d)
+            self._place_insert_plates(d, overrides.get("seg_hollow", 1))
         return d
+
+    @staticmethod
+    def _add_static_subs(d, row, boxes, nsub):
+        assert nsub + len(boxes) <= _abi.MAX_STATIC_SUB
+        d.static_sub_first[row], d.static_sub_n[row] = nsub, len(boxes)
+        for c, h in boxes:
+            d.static_sub_center[nsub][:] = c
+            d.static_sub_half[nsub][:] = h
+            nsub += 1
+        return nsub
 
     INSERT_PLATE_MARGIN = 0.004
 
-    def _place_insert_plates(self, d):
+    def _place_insert_plates(self, d, seg_hollow=1):
         """BlockAssemblyInsertSim: the base plate actor sits at (0.25, -0.2, 0.618) (IS:1438-1440; the torch_rand_int(0, 1) offsets
-        are always 0) and is one of 4x4x{1,2,4} by env % 3 (IS:971-977).  The plate is square, so the 0 / 90 degree yaw drawn at each
-        reset (IS:1435-1436) leaves its axis-aligned collision box unchanged; see tools/compile_scene.py for the stud-less body box."""
+        are always 0) and is one of 4x4x{1,2,4} by env % 3 (IS:971-977): three rows of the static-body table, each a stud compound
+        (tools/compile_scene.py::plate_compound), shown in the base plate's slot by env % 3.  The plate and its 4 x 4 studs are
+        symmetric under the 0 / 90 degree yaw drawn at each reset (IS:1435-1436).  The hollow compound of the target brick (walls,
+        roof) takes the studs: seg_hollow = 1 (the reference runs V-HACD on the bricks of this task, IS:698-709)."""
         raw = self.raw
         ps = [i for i, st in enumerate(self.statics) if st["name"] == "base_plate"][0]
         pos = raw["insert_plate_pos"]
         d.base_plate_pos[:] = pos
-        p0 = raw["insert_plates"][0]
-        d.static_center[ps][:] = [pos[0] + p0["center"][0], pos[1] + p0["center"][1], pos[2] + p0["center"][2]]
         # bricks that end flush with the plate edge (the 1x4 brick spans it; the 1x3 brick of the env % 8 == 5 rule ends on it) would
         # touch the plate's SIDE faces with their corner samples and get no vertical support from the sampled box contacts
         # (DESIGN.md section 3); the body box is widened by 4 mm per side so that those corners land on the top face
         m = self.INSERT_PLATE_MARGIN
-        d.static_half[ps][:] = [p0["half"][0] + m, p0["half"][1] + m, p0["half"][2]]
+        nsub = d.static_sub_first[ps]                       # the plate is the last static: its boxes are replaced, the variants follow
+        assert ps == d.n_static - 1
         d.static_var_slot = ps
         for k, pl in enumerate(raw["insert_plates"]):
-            d.static_var_center_z[k] = pos[2] + pl["center"][2]
-            d.static_var_half_z[k] = pl["half"][2]
+            row = ps if k == 0 else d.n_static + k - 1
+            assert row < _abi.MAX_STATIC_TAB
+            d.static_center[row][:] = [pos[i] + pl["center"][i] for i in range(3)]
+            d.static_half[row][:] = [pl["half"][0] + m, pl["half"][1] + m, pl["half"][2]]
+            boxes = [([pos[i] + bx["center"][i] for i in range(3)], list(bx["half"])) for bx in pl["sub"]]
+            boxes[0] = (boxes[0][0], [boxes[0][1][0] + m, boxes[0][1][1] + m, boxes[0][1][2]])
+            nsub = self._add_static_subs(d, row, boxes, nsub)
+            d.static_var_row[k] = row
+        d.n_static_sub = nsub
+        d.seg_hollow = seg_hollow
 
 
 def load_scene(path=None):

@@ -45,7 +45,19 @@ def test_scene_constants(scene):
     np.testing.assert_allclose(scene.lower[3], -3.0718); np.testing.assert_allclose(scene.upper[3], -0.0698)
     assert [scene.seg_index(i) - 9 for i in range(8)] == [0, 1, 2, 0, 0, 5, 6, 0]                # GS:962-965
     d = scene.to_desc()
-    assert d.n_rbox == 31 and d.n_static == 8 and d.substeps == 2 and d.solver_iters == 16
+    assert d.n_rbox == 40 and d.n_static == 8 and d.substeps == 2 and d.solver_iters == 16     # 31 shapes + 8 fingertip slabs + 1 palm slab
+    # collision compounds (round 5): every brick type two slabs of its hull inside the bounding box, the base plate body + 16 studs of 2 boxes
+    for t in range(8):
+        assert d.brick_nsub[t] == 2 and 6 <= d.hollow_nsub[t] <= 8
+        c, h = np.array(d.brick_center[t]), np.array(d.brick_half[t])
+        for k in range(2):
+            sc_, sh_ = np.array(d.brick_sub_center[t][k]), np.array(d.brick_sub_half[t][k])
+            assert (sc_ - sh_ >= c - h - 1e-6).all() and (sc_ + sh_ <= c + h + 1e-6).all()
+        assert abs(d.brick_sub_center[t][1][2] + d.brick_sub_half[t][1][2] - 0.0387) < 2e-4        # the upper slab ends at the stud tops
+        assert abs(d.brick_sub_center[t][0][2] - d.brick_sub_half[t][0][2] + 0.01875) < 1e-4       # the lower one starts at the body's bottom
+    assert d.seg_hollow == 0 and d.static_sub_n[7] == 33 and d.n_static_sub == 7 + 33 and [d.static_sub_n[s] for s in range(7)] == [1] * 7
+    studs = np.array([list(d.static_sub_center[d.static_sub_first[7] + 1 + 2 * i]) for i in range(16)])
+    assert sorted(set(np.round(studs[:, 0] - 0.25, 4))) == [-0.045, -0.015, 0.015, 0.045]        # the 4 x 4 stud grid, 30 mm pitch
     assert abs(d.kp[0] - 400) < 1e-6 and abs(d.kp[7] - 50) < 1e-6 and abs(d.effort[7] - 5) < 1e-6   # GS:580-590
     masses = [b["mass"] for b in scene.brick_types]
     assert 0.02 < min(masses) and max(masses) < 0.12                                              # 567 kg/m3 x hull volume
@@ -74,10 +86,16 @@ def test_insert_sim_scene_desc_places_three_plate_variants(scene):
     np.testing.assert_allclose(list(d.base_plate_pos), [0.25, -0.2, 0.618], atol=1e-7)
     np.testing.assert_allclose(list(d.static_center[7])[:2], [0.25, -0.2], atol=1e-7)
     assert abs(d.static_half[7][0] - (0.06 + scene.INSERT_PLATE_MARGIN)) < 1e-6
+    assert d.seg_hollow == 1 and list(d.static_var_row) == [7, 8, 9] and d.n_static_sub == 7 + 3 * 33
     for k in range(3):
-        top = d.static_var_center_z[k] + d.static_var_half_z[k]
+        row = d.static_var_row[k]
+        assert d.static_sub_n[row] == 33
+        b0 = d.static_sub_first[row]                                           # box 0 = the plate's body, 1.. = its studs (shaft, tip)
+        top = d.static_sub_center[b0][2] + d.static_sub_half[b0][2]
         assert abs(top + 0.01875 - (0.618 + 0.0375 * (1 + k))) < 6e-4          # body top + half a brick body = site height
-        assert abs(d.static_var_center_z[k] - d.static_var_half_z[k] - (0.618 - 0.01875)) < 1e-6
+        assert abs(d.static_sub_center[b0][2] - d.static_sub_half[b0][2] - (0.618 - 0.01875)) < 1e-6
+        assert abs(d.static_sub_center[b0 + 2][2] + d.static_sub_half[b0 + 2][2] - (top + 0.0387 - 0.01875)) < 1e-4   # stud tips 19.95 mm above
+        assert abs(d.static_center[row][2] + d.static_half[row][2] - (top + 0.0387 - 0.01875)) < 1e-4                 # ... = the bounding box's top
     g = scene.to_desc()                                                       # GraspSim keeps its single plate
     assert g.static_var_slot == -1 and abs(g.static_center[7][1] + 0.19) < 1e-6
 

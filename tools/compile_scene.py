@@ -13,13 +13,17 @@ What it derives (reference call sites it replaces in brackets):
   * per-link mass / COM / inertia: URDF <inertial> where present, otherwise
     density 1000 x convex-hull volume of the collision mesh with the inertia of
     the mesh's bounding box (our documented convention, SURVEY.md §7 hard parts);
-  * per-link collision boxes: URDF <box> shapes verbatim, meshes replaced by
-    their link-frame axis-aligned bounding box (DESIGN.md §3 "all shapes are boxes");
+  * per-link collision boxes: URDF <box> shapes verbatim; the fingertip and palm meshes as SLAB COMPOUNDS of their convex
+    hull (hull_slabs below); the arm / mount / camera meshes, which never touch a brick, as their link-frame bounding box;
   * PD drive gains / effort / velocity limits [GS:580-590];
-  * the 8 brick types: bounding box, box centre offset, mass = 567 x hull volume
-    [assets/urdf/blender/urdf/*.urdf], and the base plate box;
-  * static scene boxes: table, 5 bin walls [GS:629-685], the 60-brick fixed floor
-    merged into one slab [GS:748-808], base plate [GS:827-838];
+  * the 8 brick types [assets/urdf/blender/urdf/*.urdf]: mass = 567 x hull volume, centre of mass and inertia of the convex
+    hull (what PhysX derives for a single-hull shape, GS:717-731), the bounding box, a slab compound of the hull ("sub" boxes:
+    the collision shape of a free brick) and the HOLLOW compound of the mesh itself - four walls, roof, upper part - which is the
+    shape of the brick being inserted where the reference runs V-HACD on it (IS:698-709);
+  * the base plates 4x4x{1,2,4}_real as stud compounds: body + 16 studs of two boxes each (shaft, chamfered tip) - what the
+    V-HACD hulls of GS:810-838 / IS:740-767 resolve;
+  * static scene boxes: table, 5 bin walls [GS:629-685], the 60-brick fixed floor merged into one slab [GS:748-808] (its
+    studs are not resolved: 180 of them; a hull-shaped brick cannot sink between them);
   * default poses / constants used by the task [GS:249-311, 887-889].
 """
 import json
@@ -115,7 +119,84 @@ def box_inertia(m, full):
     return np.diag([m / 12 * (y * y + z * z), m / 12 * (x * x + z * z), m / 12 * (x * x + y * y)])
 
 
+# ------------------------------------------------------------------ convex hulls: mass properties, slab compounds
+def hull_mass_props(v):
+    """volume, centroid and inertia tensor about the centroid (unit density) of the convex hull of the points v"""
+    h = ConvexHull(v)
+    c0 = v[h.vertices].mean(0)
+    vol, cen, cov = 0.0, np.zeros(3), np.zeros((3, 3))
+    for s in h.simplices:
+        P = v[s] - c0
+        w = abs(np.dot(P[0], np.cross(P[1], P[2]))) / 6.0          # tetrahedron (c0, a, b, c)
+        vol += w
+        cen += w * P.sum(0) / 4.0
+        S = P.sum(0)
+        cov += w / 20.0 * (np.outer(S, S) + P.T @ P)
+    cen /= vol
+    cov -= vol * np.outer(cen, cen)
+    return vol, cen + c0, np.trace(cov) * np.eye(3) - cov
+
+
+def _hull_sections(v, zs):
+    """bounding rectangle (lo, hi) of the convex hull's cross-section at every height of zs"""
+    tri = v[ConvexHull(v).simplices]
+    out = []
+    for z in zs:
+        pts = []
+        for i in range(3):
+            p, q = tri[:, i], tri[:, (i + 1) % 3]
+            m = ((p[:, 2] - z) * (q[:, 2] - z) <= 0) & (np.abs(p[:, 2] - q[:, 2]) > 1e-12)
+            t = ((z - p[m, 2]) / (q[m, 2] - p[m, 2]))[:, None]
+            pts.append(p[m] + t * (q[m] - p[m]))
+        pts = np.concatenate(pts)
+        out.append((pts[:, :2].min(0), pts[:, :2].max(0)))
+    return out
+
+
+def hull_slabs(v, kmax=4, tol=0.03, ngrid=48):
+    """The collision compound of a convex mesh: its hull cut into <= kmax slabs along z, every slab replaced by the box whose
+    footprint is the bounding rectangle of the hull's section at the slab's mid height.  Break heights: the subset of (mesh
+    vertex levels + a uniform grid) that minimises the area between the staircase and the true section rectangles; the smallest
+    number of slabs whose error is below `tol` of the volume.  Returns (relative error, [(centre, half)])."""
+    import itertools
+    z0, z1 = v[:, 2].min(), v[:, 2].max()
+    fine = z0 + (np.arange(256) + 0.5) / 256 * (z1 - z0)
+    sec = _hull_sections(v, fine)
+    lo, hi = np.array([s[0] for s in sec]), np.array([s[1] for s in sec])
+    area = (hi - lo).prod(1)
+    lev = np.unique(np.round(v[:, 2], 4))
+    cand = sorted(set(np.round(np.concatenate([lev[(lev > z0 + 1e-4) & (lev < z1 - 1e-4)],
+                                               z0 + np.arange(1, ngrid) / ngrid * (z1 - z0)]), 5)))
+
+    def cost(br):
+        e, boxes = 0.0, []
+        edges = [z0] + list(br) + [z1]
+        for a, b in zip(edges[:-1], edges[1:]):
+            m = (fine >= a) & (fine < b)
+            if not m.any():
+                return 1e9, None
+            i = int(np.argmin(np.abs(fine - 0.5 * (a + b))))
+            bl, bh = lo[i], hi[i]
+            inter = np.clip(np.minimum(hi[m], bh) - np.maximum(lo[m], bl), 0, None).prod(1)
+            e += (area[m] + (bh - bl).prod() - 2 * inter).sum()
+            boxes.append((np.array([(bl[0] + bh[0]) / 2, (bl[1] + bh[1]) / 2, 0.5 * (a + b)]),
+                          np.array([(bh[0] - bl[0]) / 2, (bh[1] - bl[1]) / 2, (b - a) / 2])))
+        return e / area.sum(), boxes
+
+    best = None
+    for k in range(1, kmax + 1):
+        best = min((cost(br) for br in itertools.combinations(cand, k - 1)), key=lambda x: x[0])
+        if best[0] <= tol:
+            break
+    return best
+
+
 # ----------------------------------------------------------------------------- robot
+# meshes resolved as slab compounds (file -> number of slabs): the four fingertips (tapered, 26 mm at the base to 19 x 12 mm below
+# the rounded end: the bounding box is 1.9 x the hull's volume) and the palm.  31 + 8 + 1 = 40 boxes = SDX_MAX_RBOX
+SLAB_MESHES = {"modified_tip.STL": 3, "base_link.STL": 2}
+
+
 def compile_robot():
     root = ET.parse(ROBOT_URDF).getroot()
     urdf_dir = os.path.dirname(ROBOT_URDF)
@@ -145,8 +226,14 @@ def compile_robot():
                 verts = load_mesh(resolve_mesh(g.get("filename"), urdf_dir)) * scale
                 vb = verts @ Rb.T + tb  # in body frame
                 lo, hi = vb.min(0), vb.max(0)
-                boxes.append({"center": ((lo + hi) / 2).tolist(), "quat": [0, 0, 0, 1],
-                              "half": ((hi - lo) / 2).tolist(), "src": "mesh_aabb:" + os.path.basename(g.get("filename"))})
+                base = os.path.basename(g.get("filename"))
+                if base in SLAB_MESHES:      # the shapes that touch bricks: slabs of the hull along the body frame's z axis
+                    _, slabs = hull_slabs(vb, kmax=SLAB_MESHES[base], tol=0.0)
+                    for sc_, sh_ in slabs:
+                        boxes.append({"center": sc_.tolist(), "quat": [0, 0, 0, 1], "half": sh_.tolist(), "src": "mesh_slab:" + base})
+                else:
+                    boxes.append({"center": ((lo + hi) / 2).tolist(), "quat": [0, 0, 0, 1],
+                                  "half": ((hi - lo) / 2).tolist(), "src": "mesh_aabb:" + base})
                 vol = ConvexHull(verts).volume
                 mesh_vol_mass.append((1000.0 * vol, (lo + hi) / 2, hi - lo))
         ins = link.findall("inertial")
@@ -221,37 +308,82 @@ def compile_robot():
 BRICK_NAMES = ['1x2', '1x2_curve', '1x3_curve_soft', '1x3_curve', '1x1', '1x3', '1x4', '2x2_curve_soft']  # GS:706
 
 
+BODY_TOP = 0.01875        # top of a brick's body = stud base (mesh level, all types); the body bottom is at -BODY_TOP
+STUD_SHAFT_TOP = 0.0348   # the stud cylinders (radius 0.0125) end here; a chamfer narrows them to radius 0.009 at the top (0.0387)
+STUD_R, STUD_R_TOP = 0.0125, 0.009
+CAVITY_ROOF = 0.01        # the underside is hollow up to this level; walls 1.25 - 1.3 mm (mesh levels, all types)
+
+
+def _stud_centres(v):
+    """stud axes of a mesh: the cells of the 30 mm grid that carry vertices of the studs' top level"""
+    top = v[np.abs(v[:, 2] - v[:, 2].max()) < 1e-4][:, :2]
+    lo, hi = v[:, :2].min(0), v[:, :2].max(0)
+    out = []
+    for i in range(int(round((hi[0] - lo[0]) / 0.03))):
+        for j in range(int(round((hi[1] - lo[1]) / 0.03))):
+            c = np.array([lo[0] + 0.03 * (i + 0.5), lo[1] + 0.03 * (j + 0.5)])
+            if (np.linalg.norm(top - c, axis=1) < STUD_R_TOP + 1e-3).any():
+                out.append(c)
+    return out
+
+
 def compile_bricks():
     out = []
     for name in BRICK_NAMES:
         v = load_stl(os.path.join(REF, "blender/origin_obj", name, name + ".stl")) * 0.01
         lo, hi = v.min(0), v.max(0)
-        vol = ConvexHull(v).volume
+        vol, com, I = hull_mass_props(v)
         mass = 567.0 * vol
         full = hi - lo
+        err, slabs = hull_slabs(v, kmax=2, tol=0.03)   # two slabs: every further one multiplies the contacts of a brick pair (<= 4 per pair of boxes)
+        # hollow compound (mesh frame): four walls up to the cavity roof, then the hull slabs above the roof
+        wall = float(np.abs(v[np.abs(v[:, 2] - CAVITY_ROOF) < 1e-4][:, 1]).max())      # inner half width of the cavity
+        t = float(hi[1]) - wall
+        zc, zh = (lo[2] + CAVITY_ROOF) / 2, (CAVITY_ROOF - lo[2]) / 2
+        hollow = [(np.array([hi[0] - t / 2, 0.0, zc]), np.array([t / 2, full[1] / 2, zh])),
+                  (np.array([lo[0] + t / 2, 0.0, zc]), np.array([t / 2, full[1] / 2, zh])),
+                  (np.array([0.0, hi[1] - t / 2, zc]), np.array([full[0] / 2 - t, t / 2, zh])),
+                  (np.array([0.0, lo[1] + t / 2, zc]), np.array([full[0] / 2 - t, t / 2, zh]))]
+        for c, h in slabs:
+            a, b = max(c[2] - h[2], CAVITY_ROOF), c[2] + h[2]
+            if b > a + 1e-6:
+                hollow.append((np.array([c[0], c[1], (a + b) / 2]), np.array([h[0], h[1], (b - a) / 2])))
         out.append({"name": name, "half": (full / 2).tolist(), "center": ((lo + hi) / 2).tolist(), "mass": mass,
-                    "inertia_diag": np.diag(box_inertia(mass, full)).tolist(), "hull_volume": vol})
+                    "com": com.tolist(), "inertia_diag": (567.0 * np.diag(I)).tolist(), "inertia_offdiag_xz": float(567.0 * I[0, 2]),
+                    "inertia_diag_bbox": np.diag(box_inertia(mass, full)).tolist(), "hull_volume": vol, "slab_error": float(err),
+                    "sub": [{"center": c.tolist(), "half": h.tolist()} for c, h in slabs],
+                    "hollow": [{"center": c.tolist(), "half": h.tolist()} for c, h in hollow], "wall": t})
     v = load_stl(os.path.join(REF, "blender/assets_for_insertion/origin_obj/4x4x1_real/4x4x1_real.stl")) * 0.01
     lo, hi = v.min(0), v.max(0)
-    plate = {"name": "4x4x1_real", "half": ((hi - lo) / 2).tolist(), "center": ((lo + hi) / 2).tolist()}
+    plate = {"name": "4x4x1_real", "half": ((hi - lo) / 2).tolist(), "center": ((lo + hi) / 2).tolist(), "sub": plate_compound(v)}
     return out, plate
 
 
+def plate_compound(v):
+    """a base plate as body + studs (mesh frame): the body box up to the stud base, every stud as its shaft (the square around the
+    cylinder) and its chamfered tip (the square around the mean of the chamfer's radii)"""
+    lo, hi = v.min(0), v.max(0)
+    top = float(hi[2]) - (0.0387 - BODY_TOP)                              # stud base of THIS plate (the 4x4x2 / x4 plates are taller)
+    sub = [{"center": [float(lo[0] + hi[0]) / 2, float(lo[1] + hi[1]) / 2, (top + float(lo[2])) / 2],
+            "half": [float(hi[0] - lo[0]) / 2, float(hi[1] - lo[1]) / 2, (top - float(lo[2])) / 2]}]
+    s1, s2 = STUD_SHAFT_TOP - BODY_TOP, 0.0387 - STUD_SHAFT_TOP
+    rt = 0.5 * (STUD_R + STUD_R_TOP)
+    for c in _stud_centres(v):
+        sub.append({"center": [float(c[0]), float(c[1]), top + s1 / 2], "half": [STUD_R, STUD_R, s1 / 2]})
+        sub.append({"center": [float(c[0]), float(c[1]), top + s1 + s2 / 2], "half": [rt, rt, s2 / 2]})
+    return sub
+
+
 def compile_insert_plates():
-    """InsertSim's three base plates (IS:750-767, env % 3).  A brick seats with its origin 0.0375 (1 + k) above the plate origin
-    (IS:1123-1125), i.e. its body rests on the plate BODY; the studs that the V-HACD hulls engage are not representable by a box, so
-    the collision box is the body without the stud layer (stud height = the bricks' own: bounding-box top minus the 0.01875 body top)."""
-    stud = None
+    """InsertSim's three base plates (IS:750-767, env % 3) as stud compounds.  A brick seats with its origin 0.0375 (1 + k) above the
+    plate origin (IS:1123-1125): its walls stand on the plate BODY, the plate's studs inside its hollow underside."""
     out = []
     for name in ["4x4x1_real", "4x4x2_real", "4x4x4_real"]:
         v = load_stl(os.path.join(REF, "blender/assets_for_insertion/origin_obj", name, name + ".stl")) * 0.01
         lo, hi = v.min(0), v.max(0)
-        if stud is None:
-            stud = float(hi[2] - 0.01875)
-        top = float(hi[2]) - stud
-        out.append({"name": name, "half": [float(hi[0] - lo[0]) / 2, float(hi[1] - lo[1]) / 2, (top - float(lo[2])) / 2],
-                    "center": [float(lo[0] + hi[0]) / 2, float(lo[1] + hi[1]) / 2, (top + float(lo[2])) / 2],
-                    "bbox_lo": lo.tolist(), "bbox_hi": hi.tolist()})
+        sub = plate_compound(v)
+        out.append({"name": name, "half": ((hi - lo) / 2).tolist(), "center": ((lo + hi) / 2).tolist(),
+                    "bbox_lo": lo.tolist(), "bbox_hi": hi.tolist(), "sub": sub})
     return out
 
 
@@ -282,7 +414,7 @@ def main():
     y_lo = 0.175 + 0.19 - 0.039 * 9 - b0["half"][1]
     sbox("brick_floor", ((x_lo + x_hi) / 2, (y_lo + y_hi) / 2, zc), (x_hi - x_lo, y_hi - y_lo, 2 * zh))
     pc = np.array([0.25, -0.19, 0.618]) + np.array(plate["center"])
-    sbox("base_plate", pc.tolist(), [2 * h for h in plate["half"]])
+    sbox("base_plate", pc.tolist(), [2 * h for h in plate["half"]])      # bounding box; the stud compound is scene["base_plate"]["sub"]
 
     # fixed-brick root states (actor order inside the 132-brick block: 72 free then 60 fixed), deterministic
     # stand-in for the build-time random.shuffle at GS:755-759: pattern [0,0,0,1,2,2] rotated by row index.
@@ -312,7 +444,7 @@ def main():
     cam_q = mat_to_quat_xyzw(rpy_to_mat(0.0, -3.141 + 0.5, 1.571))
 
     scene = {
-        "format": "seqdex_amd.scene.v1",
+        "format": "seqdex_amd.scene.v2",
         "provenance": "derived by tools/compile_scene.py from reference assets (URDF/STL/OBJ); numbers only",
         "robot": {"base_pos": [-0.35, 0.0, 0.6], "base_quat": [0, 0, 0, 1], "bodies": bodies, "dof": dof,
                   "hand_base_body": 7, "fingertip_bodies": None, "arm_contact_bodies": [1, 2, 3, 4, 5, 6]},
@@ -333,7 +465,8 @@ def main():
     for i, b in enumerate(bodies):
         print(i, b["name"], "parent", b["parent"], "m=%.4f" % b["mass"], "nbox", len(b["boxes"]), b.get("joint"))
     for b in bricks:
-        print(b["name"], "half", np.round(b["half"], 4), "c", np.round(b["center"], 4), "m=%.4f" % b["mass"])
+        print(b["name"], "half", np.round(b["half"], 4), "c", np.round(b["center"], 4), "m=%.4f" % b["mass"], "com", np.round(b["com"], 4),
+              "slabs", len(b["sub"]), "err %.3f" % b["slab_error"], "hollow", len(b["hollow"]), "Ixz/Ixx %.2f" % (b["inertia_offdiag_xz"] / b["inertia_diag"][0]))
     for s in statics:
         print(s["name"], np.round(s["center"], 4), np.round(s["half"], 4))
 
