@@ -269,8 +269,6 @@ static void add_contact(env_t* e, int a, int b, v3 p, v3 n, real sep) {
  * has no meaningful meeting face and every sample keeps its own signed distance, as in round 1.
  * (Round 1 used the sample's nearest face and plain table order: two equal bricks stacked flush pushed each other sideways, the
  * speculative samples beside B used up the 4 slots, and the upper brick tipped over one edge or sank through.) */
-#define EXT_C 0.92387953f /* cos, sin of 22.5 degrees: the directions along which the manifold's extreme face samples are picked */
-#define EXT_S 0.38268343f
 #define FACE_TOL 1e-4f
 #define FACE_DEPTH 4.0f
 #define WARM_SPEED 0.25f /* m/s: relative speed at the contact point (before the solve) above which a contact starts cold */
@@ -382,16 +380,22 @@ static box_t static_sub(const sdx_scene_desc* sc, int s, int env_index, int k) {
 /* pair of boxes -> <= 4 contacts.  Samples of A are classified against B (direction 1) and, when sample_b, samples
  * of B against A (direction 2; sample_b == 0: B is the body box of a static).  incl (e->incl): samples closer than this are contacts -
  * the contact offset, or 0 when the list is rebuilt after a capacity overflow.  The 4 slots go to
- *   1. FACE samples of both directions, chosen at the extremes of the patch the boxes meet on: every face sample has lateral coordinates
- *      (a, b) in B's frame (B's axes without the axis of direction 1's reference face; a sample of B: its own table entry x hB); the
- *      samples that reach furthest along the four directions at 22.5 degrees + k x 90 degrees of the (a, b) plane (first in
- *      enumeration order - direction 1 in table order, then direction 2 - wins a tie; the tilt makes the four corners of an
- *      axis-aligned patch win one direction each), then the remaining face samples in that enumeration order;
+ *   1. FACE samples of both directions, chosen to SPAN the patch the boxes meet on.  Every face sample has lateral coordinates (a, b) in
+ *      B's frame (B's axes without the axis of direction 1's reference face; a sample of B: its own table entry x hB).  p1 = the sample
+ *      furthest along (1, 0.1) (the slight tilt decides between the two corners of an axis-aligned edge); p2 = the sample furthest from
+ *      p1; p3 / p4 = the samples furthest to the left / to the right of the line p1 p2 (more than MANIFOLD_EPS off it).  Ties: the first
+ *      in enumeration order (direction 1 in table order, then direction 2).  Remaining slots: the other face samples in that order;
  *   2. the other samples (edge / corner regions, speculative contacts) of direction 1, then of direction 2, in table order.
  * (Until round 4: per direction the first four in table order, face samples first, two slots reserved for direction 2 - on the narrower
  * boxes of a compound that picked four points at one end of the patch, or gave a slot to a speculative sample beside it.)
  * pkey: the pair's part of the contact identity (enumeration index of the body pair << 15 | index of the box pair inside it << 6) - with
  * the direction bit and the sample index it identifies a contact from one solve to the next */
+#define MANIFOLD_EPS 1e-7f /* m^2: twice the area of the triangle (p1, p2, p) below which p counts as lying on the line p1 p2 */
+static void face_coords(const dir_t* D1, const box_t* B, int kref, int d, int s, real* a, real* b) {
+  v3 p = d ? V(SAMP[s][0] * B->h.x, SAMP[s][1] * B->h.y, SAMP[s][2] * B->h.z) : sample_point(D1, s); /* the sample in B's frame */
+  *a = kref == 0 ? p.y : p.x;
+  *b = kref == 2 ? p.y : p.z;
+}
 static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int idb, int sample_b, real offset, unsigned pkey) {
   const real incl = e->incl;
   dir_t D1 = dir_setup(A, B, offset), D2;
@@ -402,31 +406,46 @@ static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int 
   }
   const int kref = D1.kax >= 0 ? D1.kax : 2;
   unsigned face[2] = {0, 0}, other[2] = {0, 0};
-  int ei[4] = {-1, -1, -1, -1};
-  real ext[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
   for (int d = 0; d < (sample_b ? 2 : 1); ++d) {
     const dir_t* D = d ? &D2 : &D1;
     const box_t* T = d ? A : B; /* the box the samples are tested against */
     for (int s = 0; s < NSAMP; ++s) {
-      v3 pb = sample_point(D, s);
-      int cls = sample_class(D, pb, T->h, incl);
+      int cls = sample_class(D, sample_point(D, s), T->h, incl);
+      if (cls == 1) face[d] |= 1u << s;
       if (cls == 2) other[d] |= 1u << s;
-      if (cls != 1) continue;
-      face[d] |= 1u << s;
-      v3 p = d ? V(SAMP[s][0] * B->h.x, SAMP[s][1] * B->h.y, SAMP[s][2] * B->h.z) : pb; /* the sample in B's frame */
-      real a = kref == 0 ? p.y : p.x, b = kref == 2 ? p.y : p.z;
-      real k0 = EXT_C * a + EXT_S * b, k1 = EXT_C * b - EXT_S * a;
-      real key[4] = {k0, k1, -k0, -k1};
-      for (int k = 0; k < 4; ++k)
-        if (key[k] > ext[k]) { ext[k] = key[k]; ei[k] = 32 * d + s; }
     }
   }
   unsigned sel[2] = {0, 0};
   int n = 0;
-  for (int k = 0; k < 4; ++k) {
-    if (ei[k] < 0) continue;
-    int d = ei[k] >> 5, sidx = ei[k] & 31;
-    if (!((sel[d] >> sidx) & 1u)) { sel[d] |= 1u << sidx; ++n; }
+  if (face[0] | face[1]) {
+    int p1 = -1, p2 = -1, p3 = -1, p4 = -1;
+    real best = -1e30f, a1 = 0, b1 = 0, a2 = 0, b2 = 0, a, b;
+    for (int id = 0; id < 64; ++id)
+      if ((face[id >> 5] >> (id & 31)) & 1u) {
+        face_coords(&D1, B, kref, id >> 5, id & 31, &a, &b);
+        real k = a + 0.1f * b;
+        if (k > best) { best = k; p1 = id; a1 = a; b1 = b; }
+      }
+    best = 0.0f;
+    for (int id = 0; id < 64; ++id)
+      if ((face[id >> 5] >> (id & 31)) & 1u) {
+        face_coords(&D1, B, kref, id >> 5, id & 31, &a, &b);
+        real k = (a - a1) * (a - a1) + (b - b1) * (b - b1);
+        if (k > best) { best = k; p2 = id; a2 = a; b2 = b; }
+      }
+    if (p2 >= 0) {
+      real hi = MANIFOLD_EPS, lo = -MANIFOLD_EPS;
+      for (int id = 0; id < 64; ++id)
+        if ((face[id >> 5] >> (id & 31)) & 1u) {
+          face_coords(&D1, B, kref, id >> 5, id & 31, &a, &b);
+          real k = (a2 - a1) * (b - b1) - (b2 - b1) * (a - a1);
+          if (k > hi) { hi = k; p3 = id; }
+          if (k < lo) { lo = k; p4 = id; }
+        }
+    }
+    int pk[4] = {p1, p2, p3, p4};
+    for (int k = 0; k < 4; ++k)
+      if (pk[k] >= 0) { sel[pk[k] >> 5] |= 1u << (pk[k] & 31); ++n; }
   }
   for (int pass = 0; pass < 2; ++pass) /* remaining face samples, then the other samples */
     for (int d = 0; d < 2; ++d) {

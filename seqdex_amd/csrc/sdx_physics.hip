@@ -79,6 +79,7 @@ struct PhysLds {
   float tsc[SDX_NBRICK_TYPES][SDX_MAX_SUB][3], tsh[SDX_NBRICK_TYPES][SDX_MAX_SUB][3];
   float tbc[SDX_NBRICK_TYPES][3], tbh[SDX_NBRICK_TYPES][3], trad[SDX_NBRICK_TYPES], tii[SDX_NBRICK_TYPES][3];
   float hsc[SDX_MAX_SUB_HOLLOW][3], hsh[SDX_MAX_SUB_HOLLOW][3];
+  float samp[SDX_NSAMP][3];    // copy of c_samp for per-lane sample indices (the manifold selection of pair_contacts)
   // robot collision boxes in the world
   float rc[SDX_MAX_RBOX][3], rq[SDX_MAX_RBOX][4], rh[SDX_MAX_RBOX][3], rrad[SDX_MAX_RBOX];
   int rbl[SDX_MAX_RBOX];
@@ -255,22 +256,21 @@ __device__ __forceinline__ f3 face_frame(f3 v, int kax) {   // component kax mov
 }
 // ---- the <= 4 contacts of a pair of boxes (oracle: collide_pair).  classify_dir: the 28 samples of box A against box
 // T in the face frame of that direction -> face samples / other samples inside `incl` as bit masks (incl: the contact offset, or 0 when
-// the list is rebuilt after a capacity overflow), and for the face samples the running extremes along the four directions at 22.5 degrees +
-// k x 90 degrees of the lateral plane (a, b) of the PAIR's reference frame - box B's axes without the axis kref of direction 1's
-// reference face.  DIR2: the samples are B's own (a, b = table entry x hB, no transform); their ids are 32 + s.
-#define EXT_C 0.92387953f
-#define EXT_S 0.38268343f
+// the list is rebuilt after a capacity overflow).  Direction 1 also returns what the selection below needs to place a sample in the
+// PAIR's reference frame: the reference axis kref and the face-frame rows (x, y) of the sample basis.
+struct FaceBasis { float tx, ty, exx, exy, eyx, eyy, ezx, ezy; };
 template <bool DIR2>
-__device__ __forceinline__ bool classify_dir(const Box& A, const Box& T, float off, float incl, int* kref, f3 hB, uint32_t* mface_out,
-                                             uint32_t* mother_out, float (&ext)[4], int (&ei)[4]) {
+__device__ __forceinline__ bool classify_dir(const PhysLds& S, const Box& A, const Box& T, float off, float incl, int* kref, FaceBasis* fb,
+                                             uint32_t* mface_out, uint32_t* mother_out) {
   const Dir D = dir_setup(A, T, off);
   if (D.smax >= incl) return false;   // separated: no sample of either direction can be inside the threshold
-  if (!DIR2) *kref = D.kax >= 0 ? D.kax : 2;
   const f3 t = face_frame(D.t, D.kax), ex = face_frame(D.ex, D.kax), ey = face_frame(D.ey, D.kax), ez = face_frame(D.ez, D.kax);
+  if (!DIR2) {
+    *kref = D.kax >= 0 ? D.kax : 2;
+    fb->tx = t.x; fb->ty = t.y; fb->exx = ex.x; fb->exy = ex.y; fb->eyx = ey.x; fb->eyy = ey.y; fb->ezx = ez.x; fb->ezy = ez.y;
+  }
   const f3 h = face_frame(T.h, D.kax);
   const float ftol = D.kax >= 0 ? FACE_TOL : -1e30f, off2 = incl * incl;
-  const int kr = *kref;
-  const float ha = kr == 0 ? hB.y : hB.x, hb = kr == 2 ? hB.y : hB.z;
   uint32_t mface = 0, mother = 0;
   // (the sample index is wave-uniform: the table entries arrive through scalar loads.  Fully unrolled with the entries as immediates -
   // round 3's form of the per-direction loop - the two instances of this loop cost the WHOLE kernel 220 spilled VGPRs, 18 scratch
@@ -281,49 +281,91 @@ __device__ __forceinline__ bool classify_dir(const Box& A, const Box& T, float o
   constexpr int CU = SDX_CLASSIFY_UNROLL;
 #pragma unroll CU
   for (int s = 0; s < SDX_NSAMP; ++s) {
-    const float* kSamp_s = c_samp[s];
-#define KS(s_, c_) kSamp_s[c_]
-    const f3 pb = ((t + ex * KS(s, 0)) + ey * KS(s, 1)) + ez * KS(s, 2);
+    const float* ks = c_samp[s];
+    const f3 pb = ((t + ex * ks[0]) + ey * ks[1]) + ez * ks[2];
     const float dx = fabsf(pb.x) - h.x, dy = fabsf(pb.y) - h.y, dz = fabsf(pb.z) - h.z;
     const float lat = fmaxf(dx, dy);
     const float sdf = D.sgn * pb.z - h.z;
     const float ox = fmaxf(dx, 0.0f), oy = fmaxf(dy, 0.0f), oz = fmaxf(dz, 0.0f);
     const bool near = fmaxf(lat, dz) <= 0.0f || ox * ox + oy * oy + oz * oz < off2;
     const bool face = lat <= ftol;
-    const bool isf = face && sdf < incl;
-    if (isf) mface |= 1u << s;
+    if (face && sdf < incl) mface |= 1u << s;
     if (!face && near) mother |= 1u << s;
-    // lateral coordinates in the pair's reference frame
-    const float a = DIR2 ? (kr == 0 ? KS(s, 1) : KS(s, 0)) * ha : pb.x;
-    const float b = DIR2 ? (kr == 2 ? KS(s, 1) : KS(s, 2)) * hb : pb.y;
-    const float k0 = EXT_C * a + EXT_S * b, k1 = EXT_C * b - EXT_S * a;
-    const int id = (DIR2 ? 32 : 0) + s;
-    if (isf && k0 > ext[0]) { ext[0] = k0; ei[0] = id; }
-    if (isf && k1 > ext[1]) { ext[1] = k1; ei[1] = id; }
-    if (isf && -k0 > ext[2]) { ext[2] = -k0; ei[2] = id; }
-    if (isf && -k1 > ext[3]) { ext[3] = -k1; ei[3] = id; }
   }
-#undef KS
   *mface_out = mface;
   *mother_out = mother;
   return true;
 }
-// the 4 slots of the pair: the extreme face samples of both directions, then the remaining face samples (direction 1 in table order, then
-// direction 2), then the other samples (edge / corner regions, speculative contacts) the same way.  Returns the number of contacts;
-// sel1 / sel2: the chosen samples of the two directions.
-__device__ __forceinline__ int pair_contacts(const Box& A, const Box& B, bool second, float off, float incl, uint32_t* sel1, uint32_t* sel2) {
-  float ext[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
-  int ei[4] = {-1, -1, -1, -1};
+// The 4 slots of the pair.  Face samples first, chosen to SPAN the patch the boxes meet on: every face sample has lateral coordinates
+// (a, b) in B's frame (B's axes without the axis kref of direction 1's reference face; a sample of B: its own table entry x hB);
+// p1 = the sample furthest along (1, 0.1), p2 = the one furthest from p1, p3 / p4 = the ones furthest to the left / right of the line
+// p1 p2; ties: the first in enumeration order (direction 1 in table order, then direction 2).  Then the remaining face samples in that
+// order, then the other samples (edge / corner regions, speculative contacts) the same way.  Returns the number of contacts; sel1 / sel2:
+// the chosen samples of the two directions.
+#define MANIFOLD_EPS 1e-7f
+__device__ __forceinline__ int pair_contacts(const PhysLds& S, const Box& A, const Box& B, bool second, float off, float incl, uint32_t* sel1, uint32_t* sel2) {
   uint32_t f1 = 0, o1 = 0, f2 = 0, o2 = 0;
   int kref = 2;
+  FaceBasis fb;
   *sel1 = 0; *sel2 = 0;
-  if (!classify_dir<false>(A, B, off, incl, &kref, B.h, &f1, &o1, ext, ei)) return 0;
-  if (second && !classify_dir<true>(B, A, off, incl, &kref, B.h, &f2, &o2, ext, ei)) return 0;
+  if (!classify_dir<false>(S, A, B, off, incl, &kref, &fb, &f1, &o1)) return 0;
+  if (second && !classify_dir<true>(S, B, A, off, incl, &kref, &fb, &f2, &o2)) return 0;
   uint32_t s1 = 0, s2 = 0;
+  int n = 0;
+  const uint64_t fm = (uint64_t)f1 | ((uint64_t)f2 << 32);
+  if (fm) {
+    const float ha = kref == 0 ? B.h.y : B.h.x, hb = kref == 2 ? B.h.y : B.h.z;
+    // (a, b) of candidate id (direction << 5 | sample); the table entries come from the LDS copy of the sample table (per-lane index)
+#define SDX_COORDS(id, a, b)                                                                                    \
+    {                                                                                                           \
+      const float* ks = S.samp[(id) & 31];                                                                      \
+      const float kx = ks[0], ky = ks[1], kz = ks[2];                                                           \
+      if ((id) < 32) { a = ((fb.tx + fb.exx * kx) + fb.eyx * ky) + fb.ezx * kz; b = ((fb.ty + fb.exy * kx) + fb.eyy * ky) + fb.ezy * kz; } \
+      else { a = (kref == 0 ? ky : kx) * ha; b = (kref == 2 ? ky : kz) * hb; }                                  \
+    }
+    int p1 = -1, p2 = -1, p3 = -1, p4 = -1;
+    float a1 = 0.0f, b1 = 0.0f, a2 = 0.0f, b2 = 0.0f, best = -1e30f;
+    uint64_t m = fm;
+#pragma unroll 1
+    while (m) {
+      const int id = __ffsll((unsigned long long)m) - 1;
+      m &= m - 1;
+      float a, b;
+      SDX_COORDS(id, a, b)
+      const float k = a + 0.1f * b;
+      if (k > best) { best = k; p1 = id; a1 = a; b1 = b; }
+    }
+    best = 0.0f;
+    m = fm;
+#pragma unroll 1
+    while (m) {
+      const int id = __ffsll((unsigned long long)m) - 1;
+      m &= m - 1;
+      float a, b;
+      SDX_COORDS(id, a, b)
+      const float k = (a - a1) * (a - a1) + (b - b1) * (b - b1);
+      if (k > best) { best = k; p2 = id; a2 = a; b2 = b; }
+    }
+    if (p2 >= 0) {
+      float hi = MANIFOLD_EPS, lo = -MANIFOLD_EPS;
+      m = fm;
+#pragma unroll 1
+      while (m) {
+        const int id = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        float a, b;
+        SDX_COORDS(id, a, b)
+        const float k = (a2 - a1) * (b - b1) - (b2 - b1) * (a - a1);
+        if (k > hi) { hi = k; p3 = id; }
+        if (k < lo) { lo = k; p4 = id; }
+      }
+    }
+#undef SDX_COORDS
+    const int pk[4] = {p1, p2, p3, p4};
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (ei[k] >= 0) { if (ei[k] < 32) s1 |= 1u << ei[k]; else s2 |= 1u << (ei[k] - 32); }
-  int n = __popc(s1) + __popc(s2);
+    for (int k = 0; k < 4; ++k)
+      if (pk[k] >= 0) { if (pk[k] < 32) s1 |= 1u << pk[k]; else s2 |= 1u << (pk[k] - 32); ++n; }
+  }
   uint32_t m;
 #define SDX_FILL(mask, sel)                                   \
   m = (mask) & ~(sel);                                        \
@@ -833,7 +875,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
         w0 = S_SP0(S)[pi]; w1 = S_SP1(S)[pi];
         const int ba = w0 & 0x7f, sa = (w0 >> 7) & 0xf, bb = (w0 >> 11) & 0xff, sb = (w0 >> 19) & 0x3f;
         const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
-        k = pair_contacts(A, Bx, samples_b(bb, sb), off, incl, &s1, &s2);
+        k = pair_contacts(S, A, Bx, samples_b(bb, sb), off, incl, &s1, &s2);
       }
       int tot;
       int c = nc + block_scan_small<NT, 3>(S, k, tid, &tot);
@@ -1471,6 +1513,7 @@ __device__ __forceinline__ void load_constants(const SdxConst* C, PhysLds& S, in
     S.tii[t][2] = sc.brick_mass[t] / sc.brick_inertia[t][2];
     for (int k = 0; k < SDX_MAX_SUB; ++k) { st3(S.tsc[t][k], ld3(sc.brick_sub_center[t][k]) - com); st3(S.tsh[t][k], ld3(sc.brick_sub_half[t][k])); }
   }
+  if (tid >= 128 && tid < 128 + SDX_NSAMP * 3) (&S.samp[0][0])[tid - 128] = (&c_samp[0][0])[tid - 128];
   if (tid >= 64 && tid < 64 + SDX_MAX_SUB_HOLLOW) {
     const int k = tid - 64;
     st3(S.hsc[k], ld3(sc.hollow_sub_center[segt][k]) - ld3(sc.brick_com[segt])); st3(S.hsh[k], ld3(sc.hollow_sub_half[segt][k]));

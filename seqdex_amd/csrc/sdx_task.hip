@@ -873,23 +873,32 @@ __global__ __launch_bounds__(SDX_WAVE) void k_search_set_hand(const SdxConst* __
   }
 }
 // STAND-IN for a trained BlockAssemblyGraspSim policy (the chain benchmark / tests; seqdex_amd/scripts/evaluation.py::scripted_grasp_controller
-// documents why): a reach - descend - pinch sequence on the task's own action interface (GS:1586-1609).  One thread per env; `close_at`
-// [N] is the controller's only state (the progress value at which the env's fingers started to close), owned by the caller.
-__global__ __launch_bounds__(256) void k_scripted_grasp(const SdxConst* __restrict__ C, SdxBuf B, float* __restrict__ close_at, float* __restrict__ act) {
+// documents why): a reach - descend - pinch - hold sequence on the task's own action interface (GS:1586-1609).  One thread per env; `state`
+// [2 N + 8] is the controller's only memory, owned by the caller: per env [0] the progress value at which the env's fingers started to close,
+// [1] the progress value at which the hand stopped following the brick (1e9: not yet); then eight parameters: the finger closure the pinch
+// ends at (fraction of the joint range), the number of steps the pinch takes, the hand's rise per step while it holds (action units), the
+// height of the hand base above the brick's origin at the pinch, the pinch point's x / y offset from the hand base, two spare.
+// Round 5: once the pinch is complete the hand stops following the brick - a gripped brick moves with the hand, following it was a positive
+// feedback that carried hand and brick away - and raises it a little; after step 75 the task itself lifts the hand (GS:1600-1609).
+__global__ __launch_bounds__(256) void k_scripted_grasp(const SdxConst* __restrict__ C, SdxBuf B, float* __restrict__ state, float* __restrict__ act) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= B.N) return;
   const sdx_scene_desc& sc = C->sc;
+  const float* par = state + 2 * (size_t)B.N;
+  const float frac_end = par[0], pinch_steps = par[1], rise = par[2], zpinch = par[3], xo = par[4], yo = par[5];
   const float prog = (float)B.progress[e];
   const float* hb = B.rb + ((size_t)e * SDX_BODIES + sc.hand_base_body) * 13;
   const float* br = B.root + ((size_t)e * SDX_ACTORS + seg_actor(e)) * 13;
-  float cl = prog < 2.0f ? 1e9f : close_at[e];                                  // a new episode
-  // the pinch point between thumb and fingers sits (0.125, 0.02, -0.2) from the hand base in the prepare orientation (FK of the scene)
+  float cl = prog < 2.0f ? 1e9f : state[2 * e];                                 // a new episode
+  float hold = prog < 2.0f ? 1e9f : state[2 * e + 1];
+  // the pinch point between thumb and fingers sits (0.125, 0.02, -0.2) from the hand base in the prepare orientation (FK of the scene):
+  // the defaults of (xo, yo, zpinch) = (0.125, 0.02, 0.195)
   const float rx = hb[0] - br[0], ry = hb[1] - br[1], rz = hb[2] - br[2];
-  const float horiz = sqrtf((rx + 0.125f) * (rx + 0.125f) + (ry + 0.02f) * (ry + 0.02f));
-  const float above = horiz > 0.05f ? 0.25f : 0.195f;                           // stay above the pile while travelling
+  const float horiz = sqrtf((rx + xo) * (rx + xo) + (ry + yo) * (ry + yo));
+  const float above = horiz > 0.05f ? 0.25f : zpinch;                           // stay above the pile while travelling
   float* a = act + (size_t)e * SDX_NDOF;
-  a[0] = clampf(2.5f * (br[0] - 0.125f - hb[0]) / 0.64f, -1.0f, 1.0f);
-  a[1] = clampf(2.5f * (br[1] - 0.02f - hb[1]) / 0.64f, -1.0f, 1.0f);
+  a[0] = clampf(2.5f * (br[0] - xo - hb[0]) / 0.64f, -1.0f, 1.0f);
+  a[1] = clampf(2.5f * (br[1] - yo - hb[1]) / 0.64f, -1.0f, 1.0f);
   a[2] = clampf(2.5f * (br[2] + above - hb[2]) / 0.64f, -1.0f, 1.0f);
   // hold the wrist at the prepare pose's orientation (palm down): a[3:6] x 0.2 = orientation error for the IK (GS:1596, OR:1922-1925)
   const float q0x = 0.7107f, q0y = -0.7033f, q0z = 0.0113f, q0w = -0.0091f;
@@ -901,15 +910,18 @@ __global__ __launch_bounds__(256) void k_scripted_grasp(const SdxConst* __restri
   a[4] = clampf(2.0f * (-q0w * qy + qw * q0y - cy) * sg / 0.2f, -1.0f, 1.0f);
   a[5] = clampf(2.0f * (-q0w * qz + qw * q0z - cz) * sg / 0.2f, -1.0f, 1.0f);
   a[6] = 0.0f;
-  const bool arrived = horiz < 0.012f && fabsf(rz - 0.195f) < 0.012f;
+  const bool arrived = horiz < 0.012f && fabsf(rz - zpinch) < 0.012f;
   if (arrived || prog >= 58.0f) cl = fminf(cl, prog);                           // at the latest at step 58
-  close_at[e] = cl;
-  const float frac = clampf(0.3f + (prog - cl) / 14.0f * 0.6f, 0.3f, 0.9f);
+  const float frac = clampf(0.3f + (prog - cl) / pinch_steps * (frac_end - 0.3f), 0.3f, frac_end);
+  if (prog >= cl + pinch_steps) hold = fminf(hold, prog);
+  if (prog >= hold) { a[0] = 0.0f; a[1] = 0.0f; a[2] = rise; }                  // stop following the brick; raise the hand
+  state[2 * e] = cl;
+  state[2 * e + 1] = hold;
   for (int j = 7; j < SDX_NDOF; ++j) a[j] = 2.0f * frac - 1.0f;
   a[7] = 0.0f; a[11] = 0.0f; a[15] = 0.0f;                                      // abduction joints of the three fingers stay centred
 }
-extern "C" void sdxk_scripted_grasp(const SdxConst* C, const SdxBuf* B, float* close_at, float* act, hipStream_t st) {
-  hipLaunchKernelGGL(k_scripted_grasp, dim3((B->N + 255) / 256), dim3(256), 0, st, C, *B, close_at, act);
+extern "C" void sdxk_scripted_grasp(const SdxConst* C, const SdxBuf* B, float* state, float* act, hipStream_t st) {
+  hipLaunchKernelGGL(k_scripted_grasp, dim3((B->N + 255) / 256), dim3(256), 0, st, C, *B, state, act);
 }
 extern "C" void sdxk_search_set_hand(const SdxConst* C, const SdxBuf* B, const uint8_t* mask, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_search_set_hand, dim3(B->N), dim3(SDX_WAVE), 0, st, C, *B, mask, mode);

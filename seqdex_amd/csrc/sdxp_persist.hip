@@ -104,7 +104,8 @@ typedef unsigned long long u64;
 // all-gather alone, measured (tools/bench_exchange.py, profiles/r4_exchange_edge_floor.txt): x1 (12 288 floats) 6.0 us as 8-byte
 // words, 3.6 us packed; x2 / dY1 3.3 -> 2.1; the Gram 4.7 -> 2.5; x3 (3 072 floats) 2.0 either way; no torn word in ~1e10 checked
 // gathers (a 16-byte access of one lane is not architecturally single-copy atomic: the tag sits in the LAST dword, and the benchmark
-// verifies every payload against its tag; RCCL's LL128 protocol relies on the same hardware behaviour).  The head matrix (LL_HW:
+// verifies every payload against its tag; RCCL's LL128 protocol relies on the same hardware behaviour).  Since round 5 the last dword
+// carries tag ^ fold(payload) (lq_fold below): a torn word is rejected and polled again instead of being trusted to never occur.  The head matrix (LL_HW:
 // published a phase ahead, gathered row- and column-wise by different consumers) keeps its 8-byte words.
 // Layout of D.ll: 16-byte words LQ_* first, then the 8-byte head words at LL_HW (u64 index).
 constexpr unsigned LQ_X1 = 0, LQ_X2 = LQ_X1 + MB * U0, LQ_X3 = LQ_X2 + MB * U1, LQ_DY1 = LQ_X3 + MB * U2, LQ_DY0 = LQ_DY1 + MB * U1,
@@ -113,9 +114,15 @@ constexpr size_t LL_HW = 2 * (size_t)LQ_END, LL_END = LL_HW + (ACT + 2) * U2;
 static_assert(LL_END <= SDXP_LL_WORDS, "exchange buffer too small");
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lq_rsrc(void* ll) { return __builtin_amdgcn_make_buffer_rsrc(ll, 0, SDXP_LL_WORDS * 8, 0x00020000); }
+// Tearing is DETECTABLE: the last dword is not the bare tag but tag ^ fold(payload); a consumer accepts a word only when
+// last ^ fold(the payload it read) equals the tag it waits for.  A word whose dwords come from two different stores (new tag over a
+// stale payload or the reverse) fails the test unless the mixed payload folds to the same value (2^-32, or the stale dwords equal the new
+// ones - then nothing is lost) and is simply polled again, like a word that has not arrived.
+__device__ __forceinline__ unsigned lq_fold(unsigned x, unsigned y, unsigned z) { return x ^ __builtin_rotateleft32(y, 11) ^ __builtin_rotateleft32(z, 22); }
+__device__ __forceinline__ bool lq_ok(const u32x4& w, unsigned tag) { return (w.w ^ lq_fold(w.x, w.y, w.z)) == tag; }
 __device__ __forceinline__ void lq_store(__amdgpu_buffer_rsrc_t q, unsigned idx, float a, float b, float c, unsigned tag) {
   u32x4 w;
-  w.x = __float_as_uint(a); w.y = __float_as_uint(b); w.z = __float_as_uint(c); w.w = tag;
+  w.x = __float_as_uint(a); w.y = __float_as_uint(b); w.z = __float_as_uint(c); w.w = tag ^ lq_fold(w.x, w.y, w.z);
   __builtin_amdgcn_raw_buffer_store_b128(w, q, idx * 16u, 0, 16);   // buffer_store_dwordx4 ... sc1
 }
 // gather N packed words idx0 + i * stride carrying `tag` -> the three networks' values; wave-uniform retry as ll_gather
@@ -129,7 +136,7 @@ __device__ __forceinline__ bool lq_gather(__amdgpu_buffer_rsrc_t q, unsigned idx
     for (int i = 0; i < N; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(q, (idx0 + i * stride) * 16u, 0, 16);   // buffer_load_dwordx4 ... sc1
     bool ok = true;
 #pragma unroll
-    for (int i = 0; i < N; ++i) ok = ok && w[i].w == tag;
+    for (int i = 0; i < N; ++i) ok = ok && lq_ok(w[i], tag);
 #pragma unroll
     for (int i = 0; i < N; ++i) { o0[i] = __uint_as_float(w[i].x); o1[i] = __uint_as_float(w[i].y); o2[i] = __uint_as_float(w[i].z); }
     if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;
@@ -155,7 +162,7 @@ template <int N>
 __device__ __forceinline__ bool lq_take(const u32x4 (&w)[N], unsigned tag, float (&o0)[N], float (&o1)[N], float (&o2)[N]) {
   bool ok = true;
 #pragma unroll
-  for (int i = 0; i < N; ++i) ok = ok && w[i].w == tag;
+  for (int i = 0; i < N; ++i) ok = ok && lq_ok(w[i], tag);
 #pragma unroll
   for (int i = 0; i < N; ++i) { o0[i] = __uint_as_float(w[i].x); o1[i] = __uint_as_float(w[i].y); o2[i] = __uint_as_float(w[i].z); }
   return __builtin_amdgcn_ballot_w64(!ok) == 0;
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       float v0[2], v1[2], v2[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) { v0[i] = __uint_as_float(w3[i].x); v1[i] = __uint_as_float(w3[i].y); v2[i] = __uint_as_float(w3[i].z); }
-      if (__builtin_amdgcn_ballot_w64(!(w3[0].w == tag && w3[1].w == tag)) != 0) {
+      if (__builtin_amdgcn_ballot_w64(!(lq_ok(w3[0], tag) && lq_ok(w3[1], tag))) != 0) {
         if (!lq_gather<2>(LQ, LQ_X3 + tid, NTH, tag, v0, v1, v2, failflag)) S.fail = 1;
       }
 #pragma unroll

@@ -87,19 +87,32 @@ def main_rlgames(task, num_envs, play=True, use_t_value=True, policy_path="", st
     return t_obj, stats
 
 
+# closure, pinch steps, rise per step, pinch height, pinch offset x / y.  Round 5 (profiles/r5_scripted_lift_scan.txt): the pinch height decides -
+# 0.195 above the brick's origin (rounds 3-4) the fingertips close over the studs and 18 % of 1 024 envs hold the brick 5 cm up; at 0.155 they
+# close on the brick's body: 54 %
+SG_DEFAULTS = [0.9, 8.0, 0.05, 0.155, 0.125, 0.02]
+
+
 def scripted_grasp_controller(task, step):
     """STAND-IN for a trained BlockAssemblyGraspSim policy (the reference's released checkpoint is from epoch 19 000, README.md:90; nothing of
     that length can be trained inside a test): a hand-written reach - descend - pinch sequence on the task's own action interface
     (GS:1586-1609: a[0:3] x 0.64 = hand-base displacement for the IK, a[3:6] x 0.2 = wrist orientation error, a[7:23] = finger targets scaled
     to the joint limits): hand base above the target brick with the wrist held at the prepare pose's orientation, descend, pinch when
-    arrived (at the latest at step 58).  After step 75 the task itself lifts the hand and carries it to the insertion side with the fingers
-    frozen (GS:1600-1609).  Used by tools/bench_config3.py, tools/bench_config5.py and tests/test_gpu_chain.py so that the grasp stage
+    arrived (at the latest at step 58); once the pinch is complete the hand stops following the brick (a gripped brick moves with the hand)
+    and raises it a little.  After step 75 the task itself lifts the hand and carries it to the insertion side with the fingers frozen
+    (GS:1600-1609).  SDX_SG_PARAMS="closure,steps,rise,height,x,y" overrides the pinch's end closure / duration, the rise per step, the height
+    of the hand base above the brick at the pinch and the pinch point's offset from the hand base (tools/lift_diag.py).  Used by tools/bench_config3.py, tools/bench_config5.py and tests/test_gpu_chain.py so that the grasp stage
     harvests REAL terminal states of this engine; success is far below a trained policy's.  One kernel launch per env step
     (csrc/sdx_task.hip::k_scripted_grasp; round 3 computed the same in ~40 torch operations inside the timed loop)."""
     import ctypes as C
     s = task.sim
     if not hasattr(task, "_sg_close"):
-        task._sg_close = torch.full((task.num_envs,), 1e9, device=task.device)      # progress value at which the env's fingers started to close
+        # per env: the progress values at which the fingers started to close / the hand stopped following the brick; then the parameters
+        par = SG_DEFAULTS[:]
+        for i, x in enumerate(os.environ.get("SDX_SG_PARAMS", "").split(",")):
+            if x.strip():
+                par[i] = float(x)
+        task._sg_close = torch.cat([torch.full((2 * task.num_envs,), 1e9), torch.tensor(par + [0.0, 0.0])]).to(task.device).contiguous()
         task._sg_act = torch.zeros(task.num_envs, 23, device=task.device)
         s.lib.sdxk_scripted_grasp_actions.restype = C.c_int
         s.lib.sdxk_scripted_grasp_actions.argtypes = [C.c_void_p] * 4
@@ -108,6 +121,36 @@ def scripted_grasp_controller(task, step):
     if rc != 0:
         raise RuntimeError("sdxk_scripted_grasp_actions failed (%d)" % rc)
     return task._sg_act
+
+
+def scripted_lift_statistics(num_envs=1024, seed=22, piles_per_type=16):
+    """can the hand lift a brick?  One episode of BlockAssemblyGraspSim under the scripted controller; per env the
+    largest height the target brick reached above its initial one WHILE finger_dist < 0.5 (GS:1164-1165; the reward's own "in the hand"
+    threshold, GS:1725), first episode only.  Returns a dict with the fraction of envs that held it >= 5 cm up."""
+    from ..tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
+    cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG["BlockAssemblyGraspSim"])))
+    cfg["env"]["numEnvs"] = num_envs
+    task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed, piles_per_type=piles_per_type)
+    try:
+        s, n, dev = task.sim, num_envs, task.device
+        seg = torch.as_tensor([s.scene.seg_index(i) for i in range(n)], device=dev)
+        ar = torch.arange(n, device=dev)
+        task.step(torch.zeros(n, 23, device=dev))                              # the reset step
+        z0 = s.INIT_POS[:, 2].clone()
+        held = torch.zeros(n, device=dev)
+        first = torch.ones(n, dtype=torch.bool, device=dev)
+        for step in range(1, int(task.max_episode_length)):
+            task.step(scripted_grasp_controller(task, step))
+            first &= s.PROGRESS > 1                                            # a reset env is out of its first episode
+            dz = s.ROOT.view(n, 142, 13)[ar, seg, 2] - z0
+            held = torch.where(first & (s.FINGER_DIST < 0.5), torch.maximum(held, dz), held)
+        torch.cuda.synchronize()
+        ok = held > 0.05
+        return {"n": n, "held_5cm_frac": float(ok.float().mean()), "held_2cm_frac": float((held > 0.02).float().mean()),
+                "held_max_m": float(held.max()), "per_type_held_5cm": [int(ok[ar % 8 == g].sum()) for g in range(8)],
+                "contact_stats": s.CONTACT_STATS.cpu().tolist()}
+    finally:
+        task.sim.close()
 
 
 def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None):

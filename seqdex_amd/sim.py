@@ -40,14 +40,15 @@ class SdxError(RuntimeError):
 class SdxSim:
     """One simulator+task instance on one GPU (one process per GPU; envs shard across ranks)."""
 
-    def __init__(self, num_envs, device="cuda:0", seed=22, scene=None, **desc_overrides):
+    def __init__(self, num_envs, device="cuda:0", seed=22, scene=None, desc=None, **desc_overrides):
+        """desc: a ready sdx_scene_desc (Scene.to_desc(...), possibly edited by the caller) instead of the scene's default one"""
         if not torch.cuda.is_available():
             raise SdxError("seqdex_amd needs a ROCm GPU (gfx950); there is no CPU fallback for the product path")
         self.lib = _abi.load_library()
         self.scene = scene or load_scene()
         self.device = torch.device(device)
         self.num_envs = int(num_envs)
-        self._desc = self.scene.to_desc(**desc_overrides)
+        self._desc = desc if desc is not None else self.scene.to_desc(**desc_overrides)
         h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         rc = self.lib.sdx_create(C.byref(self._desc), self.num_envs, idx, C.c_uint64(seed), C.byref(h))

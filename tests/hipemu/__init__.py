@@ -123,3 +123,11 @@ def simulate(desc, root, dof, targets, warm=None):
     w = (None, None, None) if warm is None else (_p(warm.count), _p(warm.key), _p(warm.lam))
     lib().emu_simulate(C.byref(desc), C.c_int(n), _p(root), _p(dof), _p(tg), _p(rb), _p(contact), _p(jac), _p(nc), None, *w)
     return rb, contact, jac, nc
+
+
+def contact_stats(reset=True):
+    """SDX_T_CONTACT_STATS of the emulated k_physics launches since the last reset: [largest contact count, substeps that lost contacts,
+    substeps rebuilt without speculative contacts, substeps whose pair lists overflowed]"""
+    out = np.zeros(4, np.int32)
+    lib().emu_cstats(_p(out), C.c_int(1 if reset else 0))
+    return out

@@ -13,6 +13,11 @@ extern "C" void sdxk_physics(const SdxConst* C, const SdxBuf* B, hipStream_t st)
 extern "C" void sdxk_kinematics(const SdxConst* C, const SdxBuf* B, hipStream_t st);
 extern "C" size_t sdxk_physics_lds_bytes();
 
+static int32_t g_cstats[4];   // SDX_T_CONTACT_STATS of the emulated launches since the last emu_cstats(reset = 1)
+extern "C" void emu_cstats(int32_t* out, int reset) {
+  memcpy(out, g_cstats, sizeof(g_cstats));
+  if (reset) memset(g_cstats, 0, sizeof(g_cstats));
+}
 // wcount / wkey / wlam: the warm-start cache of the N envs ([N], [N, SDX_MAXC], [N, 3, SDX_MAXC]); NULL = an empty cache for this call
 extern "C" int emu_simulate(const sdx_scene_desc* sc, int N, float* root, float* dof, const float* targets, float* rb, float* contact,
                             float* jac, int* ncontacts, long long* dbg, int* wcount, unsigned* wkey, float* wlam) {
@@ -33,6 +38,7 @@ extern "C" int emu_simulate(const sdx_scene_desc* sc, int N, float* root, float*
     wcount = tc.data(); wkey = tk.data(); wlam = tl.data();
   }
   B.wcount = wcount; B.wkey = wkey; B.wlam = wlam;
+  B.cstats = g_cstats;
   sdxk_physics(&K, &B, nullptr);
   return (int)sdxk_physics_lds_bytes();
 }

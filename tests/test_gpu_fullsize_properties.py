@@ -343,9 +343,11 @@ def test_resting_penetration_within_the_contact_offset_at_1024_envs(scene):
     rng = np.random.default_rng(11)
     root, dof, tg = base_state(scene, n)
     floor_top = scene.statics[6]["center"][2] + scene.statics[6]["half"][2]
-    # brick i has type i % 8.  The 1 x 1 brick (type 4: 3 cm foot, 5.7 cm tall) is not used as the LOWER brick: a tower on it is a stability
-    # question (tests/test_physics_oracle.py::STACKS), not a resting-depth one
-    ia = rng.choice([0, 1, 2, 3, 5, 6, 7], n); ib = 8 + rng.integers(0, 8, n)
+    # brick i has type i % 8.  Lower bricks: the straight 1x2 / 1x3 / 1x4 (the upper brick stands on their 26 mm wide stud row).  Not the
+    # 1 x 1 brick (type 4: 3 cm foot, 5.7 cm tall): a tower on it is a stability question (tests/test_physics_oracle.py::STACKS), not a
+    # resting-depth one; not the half-studded wedge types 1, 2, 3, 7: what is put on them rests on their true profile since round 5
+    # (tests/test_physics_oracle.py::test_bricks_rest_on_the_true_profile)
+    ia = rng.choice([0, 5, 6], n); ib = 8 + rng.integers(0, 8, n)
     # first half: the stacks a LEGO scene is made of - axis-aligned or crossed at 90 degrees, shifted by up to a quarter of the lower brick;
     # second half: arbitrary yaw (centred), where only a few of the 28 sample points of either box land on the other one
     yaw = np.where(np.arange(n) < n // 2, rng.integers(-1, 2, n) * (np.pi / 2), rng.uniform(-np.pi / 2, np.pi / 2, n)).astype(np.float32)
@@ -354,8 +356,8 @@ def test_resting_penetration_within_the_contact_offset_at_1024_envs(scene):
         ta, tb = scene.brick_types[scene.brick_type[ia[e]]], scene.brick_types[scene.brick_type[ib[e]]]
         za[e] = floor_top + ta["half"][2] - ta["center"][2]
         zb[e] = za[e] + ta["center"][2] + ta["half"][2] + tb["half"][2] - tb["center"][2]
-        # keep the upper brick's centre well inside the lower brick's top face (a stable stack by construction)
-        off[e] = rng.uniform(-0.25, 0.25, 2) * np.array([ta["half"][0], ta["half"][1]]) * (1.0 if e < n // 2 and abs(yaw[e]) < 0.1 else 0.0)
+        # keep the upper brick's centre well inside the lower brick's stud row (a stable stack by construction)
+        off[e] = rng.uniform(-1, 1, 2) * np.array([0.25 * ta["half"][0], 0.12 * ta["half"][1]]) * (1.0 if e < n // 2 and abs(yaw[e]) < 0.1 else 0.0)
         root[e, 9 + ia[e], 0:3] = [0.25, 0.19, za[e] + 0.001]
         root[e, 9 + ib[e], 0:3] = [0.25 + off[e, 0], 0.19 + off[e, 1], zb[e] + 0.004]
         root[e, 9 + ib[e], 3:7] = [0, 0, np.sin(yaw[e] / 2), np.cos(yaw[e] / 2)]
@@ -385,8 +387,8 @@ def test_resting_penetration_within_the_contact_offset_at_1024_envs(scene):
         up = np.abs(r[env, 9 + ib, 6] ** 2 + r[env, 9 + ib, 5] ** 2 - 1.0)         # still a pure yaw: upright
         assert up[lego].max() < 2e-3
         vlin = np.linalg.norm(r[env, 9 + ib, 7:10], axis=-1)[lego]; vang = np.linalg.norm(r[env, 9 + ib, 10:13], axis=-1)[lego]
-        # at rest; a few shifted stacks keep rocking about the edge of the lower brick (1 % above 0.1 rad/s, none above 1 rad/s)
-        assert vlin.max() < 0.05 and np.quantile(vang, 0.98) < 0.1 and vang.max() < 1.0, (float(vlin.max()), float(np.quantile(vang, 0.98)), float(vang.max()))
+        # at rest; a few shifted stacks keep rocking about the edge of the lower brick's stud row (2 % above 0.1 rad/s, none above 1 rad/s)
+        assert vlin.max() < 0.05 and np.quantile(vang, 0.98) < 0.15 and vang.max() < 1.0, (float(vlin.max()), float(np.quantile(vang, 0.98)), float(vang.max()))
         st = s.CONTACT_STATS.cpu().numpy()
         assert st[1] == 0 and st[2] == 0 and st[3] == 0
     finally:

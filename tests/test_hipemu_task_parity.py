@@ -144,7 +144,8 @@ def test_search_128_observations_against_oracle(scene):
 def test_scripted_grasp_controller_kernel_against_its_numpy_statement(scene):
     """k_scripted_grasp (csrc/sdx_task.hip), the stand-in grasp policy of the chain benchmark: the kernel SOURCE on the emulator against the
     formulas it stands for - reach above the target brick, hold the wrist at the prepare orientation, descend, close the fingers from the
-    step the hand arrived at (at the latest 58) - over random hand / brick states and every phase of an episode."""
+    step the hand arrived at (at the latest 58), then stop following the brick and raise the hand - over random hand / brick states and
+    every phase of an episode."""
     import ctypes as C
     n = 64
     s = EmuSim(n, seed=3)
@@ -156,7 +157,7 @@ def test_scripted_grasp_controller_kernel_against_its_numpy_statement(scene):
         seg = np.array([scene.seg_index(e) for e in range(n)])
         for e in range(n):                                        # hand base within a few centimetres of the pinch pose above the brick, or far away
             br = rng.uniform([0.1, 0.0, 0.55], [0.4, 0.4, 0.7]).astype(np.float32)
-            off = np.array([-0.125, -0.02, 0.195], np.float32) if e % 3 == 0 else rng.uniform(-0.2, 0.3, 3).astype(np.float32)
+            off = np.array([-0.12, -0.025, 0.19], np.float32) if e % 3 == 0 else rng.uniform(-0.2, 0.3, 3).astype(np.float32)
             jit = rng.uniform(-0.01, 0.01, 3).astype(np.float32) if e % 6 == 0 else np.zeros(3, np.float32)
             root[e, seg[e], 0:3] = torch.from_numpy(br)
             rb[e, hbi, 0:3] = torch.from_numpy(br + off + jit)
@@ -166,8 +167,10 @@ def test_scripted_grasp_controller_kernel_against_its_numpy_statement(scene):
         prog = rng.integers(0, 80, n).astype(np.int32)
         prog[:4] = [0, 1, 58, 70]
         s.PROGRESS.copy_(torch.from_numpy(prog).to(s.PROGRESS.dtype))
-        close = torch.from_numpy(np.where(rng.random(n) < 0.5, 1e9, rng.integers(10, 60, n)).astype(np.float32))
-        close0 = close.numpy().copy()
+        st0 = np.stack([np.where(rng.random(n) < 0.5, 1e9, rng.integers(10, 60, n)), np.where(rng.random(n) < 0.7, 1e9, rng.integers(30, 70, n))], 1)
+        par = np.array([0.85, 12.0, 0.04, 0.19, 0.12, 0.025, 0.0, 0.0])
+        close = torch.from_numpy(np.concatenate([st0.reshape(-1), par]).astype(np.float32))
+        close0 = st0.astype(np.float32)
         act = torch.zeros(n, 23)
         s.lib.sdxk_scripted_grasp_actions.restype = C.c_int
         s.lib.sdxk_scripted_grasp_actions.argtypes = [C.c_void_p] * 4
@@ -175,13 +178,14 @@ def test_scripted_grasp_controller_kernel_against_its_numpy_statement(scene):
         hb = rb[:, hbi].numpy().astype(np.float64)
         br = np.stack([root[e, seg[e]].numpy() for e in range(n)]).astype(np.float64)
         p = prog.astype(np.float64)
-        cl = np.where(p < 2, 1e9, close0.astype(np.float64))
+        cl = np.where(p < 2, 1e9, close0[:, 0].astype(np.float64))
+        hold = np.where(p < 2, 1e9, close0[:, 1].astype(np.float64))
         r = hb[:, 0:3] - br[:, 0:3]
-        horiz = np.hypot(r[:, 0] + 0.125, r[:, 1] + 0.02)
-        above = np.where(horiz > 0.05, 0.25, 0.195)
+        horiz = np.hypot(r[:, 0] + par[4], r[:, 1] + par[5])
+        above = np.where(horiz > 0.05, 0.25, par[3])
         want = np.zeros((n, 23))
-        want[:, 0] = np.clip(2.5 * (br[:, 0] - 0.125 - hb[:, 0]) / 0.64, -1, 1)
-        want[:, 1] = np.clip(2.5 * (br[:, 1] - 0.02 - hb[:, 1]) / 0.64, -1, 1)
+        want[:, 0] = np.clip(2.5 * (br[:, 0] - par[4] - hb[:, 0]) / 0.64, -1, 1)
+        want[:, 1] = np.clip(2.5 * (br[:, 1] - par[5] - hb[:, 1]) / 0.64, -1, 1)
         want[:, 2] = np.clip(2.5 * (br[:, 2] + above - hb[:, 2]) / 0.64, -1, 1)
         q0 = np.array([0.7107, -0.7033, 0.0113, -0.0091])
         q = hb[:, 3:7]
@@ -189,13 +193,18 @@ def test_scripted_grasp_controller_kernel_against_its_numpy_statement(scene):
         cr = np.cross(np.broadcast_to(q0[0:3], (n, 3)), q[:, 0:3])
         sg = np.sign(rw)
         want[:, 3:6] = np.clip(2.0 * (-q0[3] * q[:, 0:3] + q[:, 3:4] * q0[0:3] - cr) * sg[:, None] / 0.2, -1, 1)
-        arrived = (horiz < 0.012) & (np.abs(r[:, 2] - 0.195) < 0.012)
+        arrived = (horiz < 0.012) & (np.abs(r[:, 2] - par[3]) < 0.012)
         cl = np.where(arrived | (p >= 58), np.minimum(cl, p), cl)
-        frac = np.clip(0.3 + (p - cl) / 14.0 * 0.6, 0.3, 0.9)
+        frac = np.clip(0.3 + (p - cl) / par[1] * (par[0] - 0.3), 0.3, par[0])
+        hold = np.where(p >= cl + par[1], np.minimum(hold, p), hold)
+        want[p >= hold, 0:3] = [0.0, 0.0, par[2]]
         want[:, 7:] = (2.0 * frac - 1.0)[:, None]
         want[:, [7, 11, 15]] = 0.0
         np.testing.assert_allclose(act.numpy(), want, rtol=2e-5, atol=2e-5)
-        np.testing.assert_allclose(close.numpy(), cl.astype(np.float32), rtol=0, atol=0)
+        out = close.numpy()[:2 * n].reshape(n, 2)
+        np.testing.assert_allclose(out[:, 0], cl.astype(np.float32), rtol=0, atol=0)
+        np.testing.assert_allclose(out[:, 1], hold.astype(np.float32), rtol=0, atol=0)
         assert arrived.sum() >= 4 and (~arrived).sum() >= 20 and (cl < 1e8).sum() >= 10          # the cases the sample is meant to hold
+        assert (p >= hold).sum() >= 8 and (p < hold).sum() >= 20
     finally:
         s.close()

@@ -253,10 +253,11 @@ def stacked_pair_state(scene, ia, ib, yaw=0.0, dx=0.0, dy=0.0):
 # (straight bricks only: since round 5 a brick collides as the slab compound of its convex hull, and a brick put on the half-studded
 # wedge types 1, 2, 3, 7 rests on their true profile - test_bricks_rest_on_the_true_profile below)
 STACKS = [(6, 14, 0.0, 0.0, 0.0), (6, 14, 0.0, 0.001, 0.0), (4, 12, 0.0, 0.0, 0.0), (5, 13, 0.0, 0.0, 0.0),
-          (6, 14, np.pi / 2, 0.0, 0.0), (5, 13, np.pi / 2, 0.0, 0.0), (6, 14, np.pi / 4, 0.0, 0.0), (6, 4, 0.3, 0.005, 0.003)]
-# ... and three tall stacks of 1-stud-wide bricks loaded off their axis (the upper brick stands on the 26 mm wide stud row of the lower
-# one), which only the warm-started solver - the default - holds: shifted by a quarter length, 3 mm / 2 mm off, turned by 1 rad
-STACKS_WARM = STACKS + [(6, 14, 0.0, 0.03, 0.0), (6, 14, 0.0, 0.003, 0.002), (6, 14, 1.0, 0.01, 0.0)]
+          (6, 14, np.pi / 2, 0.0, 0.0), (5, 13, np.pi / 2, 0.0, 0.0), (6, 14, np.pi / 4, 0.0, 0.0), (6, 4, 0.0, 0.005, 0.003)]
+# ... and four tall stacks of 1-stud-wide bricks loaded off their axis (the upper brick stands on the 26 mm wide stud row of the lower
+# one), which only the warm-started solver - the default - holds: shifted by a quarter length, 3 mm / 2 mm off, turned by 1 rad, a 1x1
+# turned by 0.3 rad
+STACKS_WARM = STACKS + [(6, 14, 0.0, 0.03, 0.0), (6, 14, 0.0, 0.003, 0.002), (6, 14, 1.0, 0.01, 0.0), (6, 4, 0.3, 0.005, 0.003)]
 WARM = 0.8
 
 
@@ -341,3 +342,105 @@ def test_joint_limit_holds(scene, desc):
     for _ in range(90):
         po.simulate(desc, root, dof, tg2)
     assert dof[0, j, 0] == np.float32(scene.lower[j]) and dof[0, j, 1] == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ compound shapes (round 5)
+def _floor_top(scene):
+    return scene.statics[6]["center"][2] + scene.statics[6]["half"][2]
+
+
+def test_contacts_follow_the_hull_not_the_bounding_box(scene, desc):
+    """a 1x1 brick hovering 3 mm above the SLOPE of the 1x3 wedge brick (type 3: stud on one third, then a ramp down to 6 mm; as a compound: a full-length slab up
+    to the stud base and a slab over the studded end that thins towards the ramp) is deep inside the wedge's bounding box and touches nothing; the same brick 1 mm above the stud has four contacts with it"""
+    root, dof, tg = base_state(scene)
+    w, b = 3, 4                                         # brick 3 = type 3 (1x3_curve), brick 4 = type 4 (1x1)
+    tw, tb = scene.brick_types[3], scene.brick_types[4]
+    z0 = _floor_top(scene) + tw["half"][2] - tw["center"][2]
+    root[0, 9 + w, 0:3] = [0.25, 0.19, z0]
+    low = tw["sub"][0]["center"][2] + tw["sub"][0]["half"][2]            # top of the lower slab = the ramp's level in the compound
+    top = tw["center"][2] + tw["half"][2]                               # stud tops = top of the bounding box
+    assert top - low > 0.015
+    bottom = tb["center"][2] - tb["half"][2]
+    root[0, 9 + b, 0:3] = [0.25 + 0.028, 0.19, z0 + low + 0.003 - bottom]   # over the ramp end, 3 mm above the lower slab
+    c, n = po.contacts(desc, root[0], dof[0])
+    assert n == 4 and set(c[:, 1]) == {255.0}                           # only the wedge on the floor
+    root[0, 9 + b, 0:3] = [0.25 - 0.03, 0.19, z0 + top + 0.001 - bottom]    # over the stud, 1 mm above it
+    c, n = po.contacts(desc, root[0], dof[0])
+    pair = c[((c[:, 0] == w) & (c[:, 1] == b)) | ((c[:, 0] == b) & (c[:, 1] == w))]        # (either direction of the pair)
+    assert n == 8 and len(pair) == 4 and np.allclose(pair[:, 8], 0.001, atol=2e-5) and np.allclose(np.abs(pair[:, 7]), 1.0)
+
+
+def test_bricks_rest_on_the_true_profile(scene):
+    """dynamics on the compound shapes: (a) a 1x1 brick put on the stud of the 1x3 wedge stands there, one put over the ramp ends
+    > 15 mm lower, leaning on the ramp; (b) a 1x2 brick lying on its side rests on its BODY's side face - 15 mm from its axis - with
+    four contacts (the stud row is 2.1 mm narrower and stays clear of the floor)."""
+    desc = scene.to_desc()
+    tw, tb = scene.brick_types[3], scene.brick_types[4]
+    z0 = _floor_top(scene) + tw["half"][2] - tw["center"][2]
+    top = tw["center"][2] + tw["half"][2]
+    bottom = tb["center"][2] - tb["half"][2]
+    ends = []
+    for dx in (-0.03, 0.03):
+        root, dof, tg = base_state(scene)
+        root[0, 9 + 3, 0:3] = [0.25, 0.19, z0 + 0.001]
+        root[0, 9 + 4, 0:3] = [0.25 + dx, 0.19, z0 + top + 0.003 - bottom]
+        warm = po.WarmState(1)
+        for _ in range(150):
+            po.simulate(desc, root, dof, tg, warm)
+        ends.append(root[0, 9 + 4].copy())
+        assert np.abs(root[0, 9 + 3, 0:2] - [0.25, 0.19]).max() < 3e-3 and np.abs(root[0, 9 + 4, 7:13]).max() < 0.05
+    on_stud, on_ramp = ends
+    assert abs(on_stud[2] - (z0 + top - bottom)) < 1.5e-3 and abs(on_stud[6]) > 0.999         # standing on the stud, upright
+    assert on_stud[2] - on_ramp[2] > 0.015                                                     # the other one went down the ramp
+    # (b)
+    root, dof, tg = base_state(scene)
+    t0 = scene.brick_types[0]
+    s = np.sqrt(0.5)
+    root[0, 9, 3:7] = [s, 0, 0, s]                                      # rolled 90 degrees about x: the -y side face down
+    root[0, 9, 0:3] = [0.25, 0.19, _floor_top(scene) + t0["half"][1] + 0.002]
+    warm = po.WarmState(1)
+    for _ in range(90):
+        rb, contact, jac, nc = po.simulate(desc, root, dof, tg, warm)
+    assert nc[0] == 4 and abs(root[0, 9, 2] - (_floor_top(scene) + 0.015)) < 1e-3
+    assert abs(abs(root[0, 9, 3:7] @ np.array([s, 0, 0, s], np.float32)) - 1) < 1e-3
+
+
+def seated_brick_state(scene, desc, brick_type=7):
+    """InsertSim scene of env 0 (plate 4x4x1): the target brick (brick 0, here a 2x2) 2 mm above its seat over the four centre studs"""
+    root, dof, tg = base_state(scene)
+    desc.brick_type[0] = brick_type
+    site_z = 0.618 + 0.0375                                             # IS:1123-1125
+    root[0, 9, 0:3] = [0.25, -0.2, site_z + 0.002]
+    return root, dof, tg, site_z
+
+
+def test_hollow_brick_engages_the_studs_of_the_base_plate(scene):
+    """SURVEY.md section 8(a) rows A0 / P3 (GS:810-838, IS:698-709, 740-767): the target brick of BlockAssemblyInsertSim collides as the
+    hollow compound of its mesh, the base plate as body + studs.  A 2x2 brick put over four studs drops onto the plate's BODY (its walls
+    around the studs); pushed sideways with 1 N (gravity tilted by its weight) it moves by the clearance of 1.25 mm and stops; pulled upwards
+    it comes off freely; as a plain hull (seg_hollow = 0) it would stand 20 mm higher, on the stud tops."""
+    desc = scene.to_desc(task_kind=2)
+    root, dof, tg, site_z = seated_brick_state(scene, desc)
+    m = scene.brick_types[7]["mass"]
+    warm = po.WarmState(1)
+    for _ in range(40):
+        rb, contact, jac, nc = po.simulate(desc, root, dof, tg, warm)
+    assert abs(root[0, 9, 2] - site_z) < 1e-3 and np.abs(root[0, 9, 0:2] - [0.25, -0.2]).max() < 3e-4 and nc[0] >= 16
+    desc.gravity[0] = 1.0 / m                                           # 1 N along +x
+    for _ in range(90):
+        po.simulate(desc, root, dof, tg, warm)
+    assert 5e-4 < root[0, 9, 0] - 0.25 < 2.2e-3 and abs(root[0, 9, 1] + 0.2) < 5e-4            # against the studs, after the 1.25 mm of play
+    assert abs(root[0, 9, 2] - site_z) < 1e-3 and np.abs(root[0, 9, 7:10]).max() < 5e-3 and abs(root[0, 9, 6]) > 0.9999
+    desc.gravity[0] = 0.0
+    desc.gravity[2] = 2.0                                               # pulled upwards: nothing holds it
+    for _ in range(30):
+        po.simulate(desc, root, dof, tg, warm)
+    assert root[0, 9, 2] - site_z > 0.02 and np.abs(root[0, 9, 0:2] - [0.25, -0.2]).max() < 3e-3
+    # the same brick as a plain hull stands on the stud tops
+    hull = scene.to_desc(task_kind=2, seg_hollow=0)
+    root, dof, tg, site_z = seated_brick_state(scene, hull)
+    root[0, 9, 2] += 0.02
+    warm = po.WarmState(1)
+    for _ in range(60):
+        po.simulate(hull, root, dof, tg, warm)
+    assert abs(root[0, 9, 2] - (site_z + 0.0387 - 0.01875)) < 1e-3
