@@ -128,6 +128,17 @@ class PPOOracle:
     def neglogp(x, mean, std, logstd):
         return 0.5 * (((x - mean) / std) ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * x.shape[-1] + logstd.sum(-1)
 
+    @staticmethod
+    def ac_loss(a_loss, c_loss, critic_coef, entropy, entropy_coef, b_loss, bounds_loss_coef):
+        """composition of the losses (RC:2129-2132): a + 0.5 c critic_coef - entropy entropy_coef + b bounds_loss_coef"""
+        return a_loss + 0.5 * c_loss * critic_coef - entropy * entropy_coef + b_loss * bounds_loss_coef
+
+    @staticmethod
+    def normalize_advantages(returns, values):
+        """RC:1639-1651: (A - mean) / (std_unbiased + 1e-8) over the whole batch, A = returns - values"""
+        adv = returns - values
+        return (adv - adv.mean()) / (adv.std() + 1e-8)
+
     @torch.no_grad()
     def values(self, states):
         return self.cv(self.rms(states)).squeeze(-1)
@@ -158,7 +169,7 @@ class PPOOracle:
         nmb = ds["obs"].shape[0] // mbs
         adv = ds["returns"] - ds["values"]
         if c.get("normalize_advantage", True):
-            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+            adv = self.normalize_advantages(ds["returns"], ds["values"])
         ds["advantages"] = adv
         stats = dict(a=[], c=[], b=[], kl=[], cv=[], lr=[], gnorm=[], cv_gnorm=[])
         # central value first (RC:1323-1324)
@@ -192,7 +203,7 @@ class PPOOracle:
                 a_loss = torch.max(-A * ratio, -A * torch.clamp(ratio, 1 - c["e_clip"], 1 + c["e_clip"]))
                 c_loss = self._critic_loss(ds["values"][sl], v, ds["returns"][sl])
                 b_loss = (torch.clamp_min(mu - 1.1, 0.0) ** 2 + torch.clamp_max(mu + 1.1, 0.0) ** 2).sum(-1)
-                loss = a_loss.mean() + 0.5 * c_loss.mean() * c["critic_coef"] + b_loss.mean() * c["bounds_loss_coef"]
+                loss = self.ac_loss(a_loss.mean(), c_loss.mean(), c["critic_coef"], torch.zeros(()), 0.0, b_loss.mean(), c["bounds_loss_coef"])
                 for p in self.ac_params:
                     p.grad = None
                 loss.backward()

@@ -731,67 +731,90 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   __syncthreads();
   // ---- separating-axis pass over the bounding boxes: a body pair that a face axis of either bounding box separates by the whole contact
   // offset cannot produce a contact (its boxes lie inside the bounding boxes); about half of the sphere-vs-box candidates leave the list
-  // here.  Lane tid looks at the consecutive pairs tid * q .. tid * q + q - 1 (order preserved).  A survivor is either
-  //   CONVEX - both sides stand for one convex shape (a brick as the slab compound of its hull, a robot box, a single-box static): it
-  //   contributes ONE box pair, the one with the smallest separation bound sigma = the largest face-axis separation of its directions
-  //   (oracle: collide_bodies); the lane finds it here and leaves its index in bits 29..30 of the pair word, bit 31 set; or
-  //   COMPOUND - a hollow brick or the studded base plate on either side: every (box of A) x (box of B) is a candidate.
-  // The exclusive prefix sum S_OFF of the candidate counts maps a body pair to its first candidate box pair.
-  int nbp;   // candidate box pairs
+  // here.  Lane tid looks at the consecutive pairs tid * q .. tid * q + q - 1 (order preserved).
   {
     constexpr int QMAX = (MAXP + NT - 1) / NT;
     static_assert(QMAX <= 2, "two survivor slots per lane");
-    static_assert(SDX_MAX_SUB * SDX_MAX_SUB <= 4, "the winning box pair of a convex body pair in two bits");
     const int q = (np + NT - 1) / NT;
     uint32_t c0 = 0, c1 = 0;
-    int kept = 0, n0 = 0, nb1 = 0;
-#pragma unroll 1
+    int kept = 0;
+#pragma unroll
     for (int k = 0; k < QMAX; ++k) {
       const int pi = tid * q + k;
       if (k < q && pi < np) {
-        uint32_t pr = S_PAIRS(S)[pi];
-        const int ba = pr & 0xff, bb = (pr >> 8) & 0xff;
-        bool sep;
-        {
-          const Box A = load_bound(S, ba), Bx = load_bound(S, bb);
-          sep = dir_setup(A, Bx, off).smax >= off;
-          if (!sep && bb < STATIC0) sep = dir_setup(Bx, A, off).smax >= off;
-        }
+        const uint32_t pr = S_PAIRS(S)[pi];
+        const int bb = (pr >> 8) & 0xff;
+        const Box A = load_bound(S, pr & 0xff), Bx = load_bound(S, bb);
+        bool sep = dir_setup(A, Bx, off).smax >= off;
+        if (!sep && bb < STATIC0) sep = dir_setup(Bx, A, off).smax >= off;
         if (!sep) {
-          const int na = box_nsub(S, ba), nbx = box_nsub(S, bb);
-          int cnt = na * nbx;
-          const bool convex = !(ba < NF && brick_hollow(S, ba)) && !(bb < NF && brick_hollow(S, bb)) && !(bb >= STATIC0 && nbx > 1);
-          if (convex && cnt > 1) {
-            float best = off;
-            int only = -1;
-#pragma unroll 1
-            for (int sidx = 0; sidx < cnt; ++sidx) {
-              const int sa = sidx / nbx, sb = sidx - sa * nbx;
-              const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
-              float sg = dir_setup(A, Bx, off).smax;
-              if (samples_b(bb, sb)) sg = fmaxf(sg, dir_setup(Bx, A, off).smax);
-              if (sg < best) { best = sg; only = sidx; }
-            }
-            cnt = only >= 0 ? 1 : 0;
-            pr |= ((uint32_t)(only & 3) << 29) | 0x80000000u;
-          } else if (convex) {
-            pr |= 0x80000000u;   // a single box on either side: the bounding boxes ARE the boxes
-          }
-          if (cnt > 0) {
-            if (kept == 0) { c0 = pr; n0 = cnt; } else { c1 = pr; nb1 = cnt; }
-            ++kept;
-          }
+          if (kept == 0) c0 = pr; else c1 = pr;
+          ++kept;
         }
       }
     }
     int np2;
     const int pos = block_scan_small<NT, 2>(S, kept, tid, &np2);   // its barrier comes after every lane's reads of the old list
-    // counts: <= 2 x (8 boxes of a hollow brick x 33 of a base plate) per lane: 10 bits
-    const int boff = block_scan_small<NT, 10>(S, n0 + nb1, tid, &nbp);
-    if (kept > 0) { S_PAIRS(S)[pos] = c0; S_OFF(S)[pos] = boff; }
-    if (kept > 1) { S_PAIRS(S)[pos + 1] = c1; S_OFF(S)[pos + 1] = boff + n0; }
+    if (kept > 0) S_PAIRS(S)[pos] = c0;
+    if (kept > 1) S_PAIRS(S)[pos + 1] = c1;
     np = np2;
-    if (tid == 0) S_OFF(S)[np2] = nbp;
+    __syncthreads();
+  }
+  // ---- box pairs of the surviving body pairs, FOUR lanes per body pair.  A survivor is either
+  //   CONVEX - both sides stand for one convex shape (a brick as the slab compound of its hull, a robot box, a single-box static): it
+  //   contributes ONE box pair, the one with the smallest separation bound sigma = the largest face-axis separation of its directions
+  //   (oracle: collide_bodies; ties: the first).  Lane `sub` of the quad computes sigma of box pair `sub`, a DPP minimum over the quad finds
+  //   the winner, whose index goes to bits 29..30 of the pair word, bit 31 set (no box pair below the contact offset: the pair gets 0
+  //   candidates); or
+  //   COMPOUND - a hollow brick or the studded base plate on either side: every (box of A) x (box of B) is a candidate.
+  // The exclusive prefix sum S_OFF of the candidate counts maps a body pair to its first candidate box pair.
+  int nbp;   // candidate box pairs
+  {
+    static_assert(SDX_MAX_SUB * SDX_MAX_SUB <= 4, "the box pairs of a convex body pair: one per lane of a quad, the winner in two bits");
+    const int sub = tid & 3;
+#pragma unroll 1
+    for (int base = 0; base < np; base += NT / 4) {
+      const int pi = base + (tid >> 2);
+      const bool on = pi < np;
+      const uint32_t pr = on ? S_PAIRS(S)[pi] : 0u;
+      const int ba = pr & 0xff, bb = (pr >> 8) & 0xff;
+      const int na = on ? box_nsub(S, ba) : 1, nbx = on ? box_nsub(S, bb) : 1;
+      int cnt = na * nbx;
+      const bool convex = on && !(ba < NF && brick_hollow(S, ba)) && !(bb < NF && brick_hollow(S, bb)) && !(bb >= STATIC0 && nbx > 1);
+      float sg = 1e30f;
+      if (convex && sub < cnt) {
+        const int sa = sub / nbx, sb = sub - sa * nbx;
+        const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
+        sg = dir_setup(A, Bx, off).smax;
+        if (samples_b(bb, sb)) sg = fmaxf(sg, dir_setup(Bx, A, off).smax);
+      }
+      // minimum of (sigma, sub) over the quad (every lane of the wave executes the two DPP steps)
+      int wi = sub;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const float og = st == 0 ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0xB1, 0xF, 0xF, true))
+                                 : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0x4E, 0xF, 0xF, true));
+        const int oi = st == 0 ? __builtin_amdgcn_update_dpp(0, wi, 0xB1, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, wi, 0x4E, 0xF, 0xF, true);
+        const bool take = og < sg || (og == sg && oi < wi);
+        sg = take ? og : sg;
+        wi = take ? oi : wi;
+      }
+      if (on && sub == 0) {
+        if (convex) {
+          cnt = sg < off ? 1 : 0;
+          S_PAIRS(S)[pi] = pr | ((uint32_t)(wi & 3) << 29) | 0x80000000u;
+        }
+        S_OFF(S)[pi] = cnt;
+      }
+    }
+    __syncthreads();
+    // exclusive prefix sum of the counts, two body pairs per lane
+    const int i0 = 2 * tid, i1 = 2 * tid + 1;
+    const int n0 = i0 < np ? S_OFF(S)[i0] : 0, n1 = i1 < np ? S_OFF(S)[i1] : 0;
+    const int boff = block_scan_small<NT, 10>(S, n0 + n1, tid, &nbp);   // <= 2 x (8 boxes of a hollow brick x 33 of a base plate) per lane: 10 bits
+    if (i0 < np) S_OFF(S)[i0] = boff;
+    if (i1 < np) S_OFF(S)[i1] = boff + n0;
+    if (tid == 0) S_OFF(S)[np] = nbp;
     __syncthreads();
   }
   SSTAMP(33);
@@ -877,6 +900,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
         const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
         k = pair_contacts(S, A, Bx, samples_b(bb, sb), off, incl, &s1, &s2);
       }
+      if (pass == 0 && base == 0) SSTAMP(38);
       int tot;
       int c = nc + block_scan_small<NT, 3>(S, k, tid, &tot);
       // (the descriptors go to the impulse rows P[0] / P[1]: the box pair list in cp / cn stays intact for the second pass)
@@ -901,6 +925,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     rebuilt = 1;
   }
   __syncthreads();   // the box pair list in cp / cn is dead from here on
+  SSTAMP(39);
   // ---- (2) lane = contact: point, normal, separation of sample s of box A against box B (oracle: emit_mask); the descriptor of contact c
   // sits in P[0][c] / P[1][c], which the same lane overwrites with the results
   {

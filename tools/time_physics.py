@@ -38,7 +38,7 @@ ph = {"fk+inertia": d[1] - d[0], "mass_matrix": d[2] - d[1], "drive": d[3] - d[2
       "integrate": d[6] - d[5], "mm_entries": d[34] - d[1], "mm_cholesky": d[35] - d[34], "mm_linv": d[36] - d[35], "mm_hinv": d[2] - d[36], "solve_setup": d[17] - d[16], "it_AC": d[20] - d[18],
       "setup_load": d[23] - d[16], "setup_count": d[24] - d[23], "setup_prefix": d[25] - d[24], "setup_fill": d[26] - d[25],
       "setup_rank": d[27] - d[26], "setup_link_inertia": d[29] - d[28], "setup_weights": d[30] - d[29],
-      "setup_tail": d[17] - d[30], "broad_mask": d[32] - d[3], "broad_scan": d[33] - d[32], "expand_box_pairs": d[37] - d[33], "narrow": d[4] - d[37],
+      "setup_tail": d[17] - d[30], "broad_mask": d[32] - d[3], "broad_scan": d[33] - d[32], "expand_box_pairs": d[37] - d[33], "narrow": d[4] - d[37], "narrow_classify_first_chunk": d[38] - d[37], "narrow_rest_of_part1": d[39] - d[38], "narrow_part2_geometry": d[4] - d[39],
       "it_D": (d[21] if d[21] > d[20] else d[22]) - d[20], "it_robot": (d[22] - d[21]) if d[21] > d[20] else 0, "it_total": d[22] - d[18]}
 cf = s.CONTACT.view(n, 165, 3)[:, :24].abs().sum(dim=(1, 2)).cpu().numpy()
 denv = int(os.environ.get("SDX_DEBUG_ENV", "0"))
