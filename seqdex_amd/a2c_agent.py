@@ -432,7 +432,13 @@ class A2CAgent:
         elif isinstance(opt, dict) and "state" in opt:               # torch.optim.Adam.state_dict() (rl_games, and save() since round 4)
             from .rlgames_checkpoint import flat_from_torch_adam
             obs_cols, _ = self._checkpoint_widths()
-            mv = flat_from_torch_adam(opt, cfg.obs_dim, cfg.act_dim, tuple(cfg.units), obs_cols=obs_cols)
+            try:
+                mv = flat_from_torch_adam(opt, cfg.obs_dim, cfg.act_dim, tuple(cfg.units), obs_cols=obs_cols)
+            except ValueError as ex:             # an optimiser state of another layout: say so, start from fresh moments AND a fresh step counter
+                print("restore: optimizer state NOT restored (%s); Adam moments and step counter start from zero" % ex)
+                mv = None
+                t["AC_ADAM_M"].zero_(); t["AC_ADAM_V"].zero_()
+                torch_adam_step = 0
             if mv is not None:
                 t["AC_ADAM_M"].copy_(mv[0]); t["AC_ADAM_V"].copy_(mv[1])
                 torch_adam_step = mv[2]

@@ -66,6 +66,7 @@ struct sdxp_agent {
   bool big = false;              // minibatch_size > 8: GEMM-shaped update path (sdxp_bigmb.hip)
   SdxpBigWs bigws;
   int big_me = 0, big_next = 0;  // multi-rank big path: mini-epoch / expected minibatch of the next sdxp_backward call
+  long max_steps = 0;            // SDXP_MAX_STEPS read ONCE at sdxp_create (0: no limit): debug limit of optimiser steps per sdxp_update
   std::string err;
 };
 
@@ -134,6 +135,10 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     gp_create_err = "sdxp_create: obs_dim / state_dim above 1024 are not supported by the rollout's first-layer kernel"; return SDX_ERR_INVALID;
   }
   sdxp_agent* h = new sdxp_agent();
+  if (const char* ms = getenv("SDXP_MAX_STEPS")) {
+    h->max_steps = atol(ms);
+    if (h->max_steps > 0) fprintf(stderr, "libseqdex_hip: SDXP_MAX_STEPS=%ld - DEBUG LIMIT: every sdxp_update of this handle stops after %ld optimiser steps\n", h->max_steps, h->max_steps);
+  }
   h->device = device;
   h->cfg = *cfg;
   PCHK(h, hipSetDevice(device));
@@ -468,7 +473,8 @@ extern "C" int sdxp_update(sdxp_handle h, void* stream) {
   long total = (long)h->cfg.mini_epochs * h->D.num_minibatches;
   // debug step limit (tests/test_gpu_fullsize_properties.py pins the N = 1024 persistent update to the oracle step for step): the
   // update phase stops after SDXP_MAX_STEPS optimiser steps, in minibatch order, on whichever path the handle uses
-  if (const char* ms = getenv("SDXP_MAX_STEPS")) { const long lim = atol(ms); if (lim > 0 && lim < total) total = lim; }
+  // (read once, at sdxp_create, and announced on stderr there: a stray variable cannot silently truncate the epochs of a production run)
+  if (h->max_steps > 0 && h->max_steps < total) total = h->max_steps;
   if (h->fail_host && *h->fail_host) {
     h->use_persist = false;   // a grid barrier of the persistent kernel timed out earlier: fall back for good
     *h->fail_host = 0;

@@ -126,12 +126,13 @@ def flat_from_rlgames(model, vf, obs_dim, state_dim, act_dim=23, units=(1024, 51
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # torch.optim.Adam state of the actor-critic (rl_games: weights['optimizer'] = self.optimizer.state_dict(), params = list(model.parameters()))
-def ac_parameter_order():
+def ac_parameter_order(units=(1024, 512, 256)):
     """names of the actor-critic parameters in `model.parameters()` order: nn.Module yields a module's OWN parameters before those of
-    its children, so the `sigma` Parameter of the network comes first, then the children in registration order (header)"""
+    its children, so the `sigma` Parameter of the network comes first, then the children in registration order (header).  `units`: the
+    trunk's layer widths (one Linear per entry); separate critic and fixed sigma, as the shipped YAMLs build it."""
     names = ["a2c_network.sigma"]
     for trunk in ("actor_mlp", "critic_mlp"):
-        for i in range(3):
+        for i in range(len(units)):
             names += ["a2c_network.%s.%d.weight" % (trunk, 2 * i), "a2c_network.%s.%d.bias" % (trunk, 2 * i)]
     return names + ["a2c_network.value.weight", "a2c_network.value.bias", "a2c_network.mu.weight", "a2c_network.mu.bias"]
 
@@ -140,7 +141,7 @@ def torch_adam_from_flat(m_flat, v_flat, step, lr, obs_dim, act_dim=23, units=(1
     """flat Adam moments of the actor-critic -> torch.optim.Adam.state_dict() over `model.parameters()` (what rl_games stores and loads)"""
     mn, _ = rlgames_from_flat(m_flat, _dummy_cv(units), obs_dim, 4, act_dim, units, obs_cols=obs_cols)
     vn, _ = rlgames_from_flat(v_flat, _dummy_cv(units), obs_dim, 4, act_dim, units, obs_cols=obs_cols)
-    order = ac_parameter_order()
+    order = ac_parameter_order(units)
     state = {i: {"step": torch.tensor(float(step)), "exp_avg": mn[k], "exp_avg_sq": vn[k]} for i, k in enumerate(order)}
     group = {"lr": float(lr), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
              "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(order)))}
@@ -156,21 +157,39 @@ def _dummy_cv(units):
 
 
 def flat_from_torch_adam(opt_sd, obs_dim, act_dim=23, units=(1024, 512, 256), obs_cols=None):
-    """torch.optim.Adam.state_dict() of the actor-critic (parameters in `ac_parameter_order`) -> (m_flat, v_flat, step) or None when the
-    state is empty (a checkpoint saved before the first optimiser step) or does not have one entry per parameter"""
-    order = ac_parameter_order()
+    """torch.optim.Adam.state_dict() of the actor-critic (parameters in `ac_parameter_order(units)`) -> (m_flat, v_flat, step); None when the
+    state is EMPTY (a checkpoint saved before the first optimiser step).  A non-empty state that does not have one entry per parameter of
+    this layout (another network shape, a shared critic, a learned sigma) cannot be mapped: ValueError - the caller decides whether to go
+    on with fresh moments, it is not done silently."""
+    order = ac_parameter_order(units)
     st = opt_sd.get("state", {})
-    if len(st) != len(order):
+    if len(st) == 0:
         return None
     ids = opt_sd["param_groups"][0]["params"] if opt_sd.get("param_groups") else sorted(st)
-    if len(ids) != len(order):
-        return None
+    if len(st) != len(order) or len(ids) != len(order):
+        raise ValueError("optimizer state with %d entries (%d parameter ids) does not fit the actor-critic layout of units %s (%d parameters: "
+                         "separate critic, fixed sigma)" % (len(st), len(ids), tuple(units), len(order)))
     m = {k: st[i]["exp_avg"] for k, i in zip(order, ids)}
     v = {k: st[i]["exp_avg_sq"] for k, i in zip(order, ids)}
+    shapes = _ac_shapes(obs_dim, act_dim, units, obs_cols)
+    for k in order:
+        if tuple(m[k].shape) != shapes[k] or tuple(v[k].shape) != shapes[k]:
+            raise ValueError("optimizer state of %s has shape %s, the layout needs %s" % (k, tuple(m[k].shape), shapes[k]))
     mf = _ac_flat_only(m, obs_dim, act_dim, units, obs_cols)
     vf = _ac_flat_only(v, obs_dim, act_dim, units, obs_cols)
     step = int(round(float(torch.as_tensor(st[ids[0]]["step"]))))
     return mf, vf, step
+
+
+def _ac_shapes(obs_dim, act_dim, units, obs_cols):
+    """parameter name -> shape of the actor-critic in the rl_games layout (first layers `obs_cols` wide)"""
+    out = {"a2c_network.sigma": (act_dim,), "a2c_network.mu.weight": (act_dim, units[-1]), "a2c_network.mu.bias": (act_dim,),
+           "a2c_network.value.weight": (1, units[-1]), "a2c_network.value.bias": (1,)}
+    for trunk in ("actor_mlp", "critic_mlp"):
+        for i, (o, inn) in enumerate(_layers(obs_dim, units)):
+            out["a2c_network.%s.%d.weight" % (trunk, 2 * i)] = (o, (obs_cols or inn) if i == 0 else inn)
+            out["a2c_network.%s.%d.bias" % (trunk, 2 * i)] = (o,)
+    return out
 
 
 def _ac_flat_only(model, obs_dim, act_dim, units, obs_cols):

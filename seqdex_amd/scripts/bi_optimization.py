@@ -153,8 +153,14 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
             scripted_episodes(grasp)
             cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
             harvest_by = "evaluation.scripted_grasp_controller, two episodes on the trained task (STAND-IN: the policy of %d epochs harvested nothing)" % se("grasp")
-        some = cnt.max() > 0 and (cnt.min() > 0 or grasp_harvest_stand_in)
+        # the harvest is handed on as it is: a brick-type group that harvested nothing makes BlockAssemblyInsertSim raise (as IS:1449
+        # samples an empty list) unless grasp_harvest_stand_in asks for synthetic stand-ins for exactly those groups; only a harvest that
+        # is empty altogether leaves the task to synthesise all its start states, and the report says so (a partial harvest
+        # used to be discarded silently)
+        some = cnt.max() > 0
         grasp_states = grasp.grasp_terminal_states() if some else None                    # hand-off GS:1447-1450 -> IS:372-375
+        if not some:
+            print("bi_optimization: GraspSim harvested no terminal state - BlockAssemblyInsertSim starts from synthetic states")
         _handoff(report, "GraspSim -> InsertSim: grasp terminal states (8 x [K, 1, 13], 8 x [K, 23, 2])",
                  None if grasp_states is None else [t for t in list(grasp_states[0]) + list(grasp_states[1]) if t.numel()],
                  "InsertSim synthesises its start states")

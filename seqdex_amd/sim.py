@@ -55,6 +55,7 @@ class SdxSim:
         if rc != 0:
             raise SdxError("sdx_create failed (%d): %s" % (rc, self.lib.sdx_last_error(None).decode()))
         self.h = h
+        self.ring_wrapped = False     # set by ring_rows() when a ring it reads has wrapped (its rows are then in claim order, not serial order)
         self._tensors = {}
         for name, tid in _abi.T.items():
             self._tensors[name] = self._wrap(tid)
@@ -81,7 +82,11 @@ class SdxSim:
         """the filled rows of one ring in SERIAL order: `rows` [slots, ...] and `keys` [slots] views of a ring and its key tensor
         (SDX_T_*_KEYS: step << 24 | env of the append), `count` appends so far.  The kernels claim ring slots with atomics, so the slot order
         is the hardware's; sorted by key the rows come out as a loop over steps and envs would have written them - the same on every
-        run.  (A ring that has wrapped keeps whichever `slots` rows landed last in each slot: size the run so that it does not.)"""
+        run.  A ring that has WRAPPED (count > slots) keeps whichever rows landed last in each slot - which ones depends on the order the
+        slots were claimed in, the serial-order guarantee is gone: `self.ring_wrapped` records it (callers that promise determinism
+        assert it stayed False; size the run so that it does)."""
+        if int(count) > rows.shape[0] and self is not None:
+            self.ring_wrapped = True
         k = int(min(int(count), rows.shape[0]))
         if k == 0:
             return rows[:0].clone()

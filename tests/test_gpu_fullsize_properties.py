@@ -402,13 +402,13 @@ def test_persistent_update_at_1024_envs_matches_the_oracle_step_for_step():
     test at N = 16 uses (tests/test_gpu_ppo_parity.py).  The whole-epoch check stays aggregate (test above)."""
     from test_gpu_ppo_parity import make_pair, rollout
     n, steps = 1024, 640
-    agent, orc = make_pair(n, seed=3)
     old = os.environ.get("SDXP_MAX_STEPS")
+    os.environ["SDXP_MAX_STEPS"] = str(steps)          # read once, by sdxp_create (and announced on stderr)
+    agent, orc = make_pair(n, seed=3)
     try:
         if agent.update_impl() != "persistent":
             pytest.skip("persistent update kernel not selected on this device (needs >= 256 CUs)")
         ds = rollout(agent, orc, n, torch.Generator().manual_seed(21))
-        os.environ["SDXP_MAX_STEPS"] = str(steps)
         assert agent.update_checked() == "persistent"
         torch.cuda.synchronize()
         st = orc.update(ds, max_steps=steps)

@@ -232,8 +232,12 @@ def test_ring_rows_returns_the_appends_in_serial_step_env_order():
     got = SdxSim.ring_rows(None, rows, keys, 5)
     assert got[:, 0].tolist() == [3.0, 1.0, 4.0, 2.0, 0.0]                                  # (1,4) (1,900) (2,0) (3,2) (3,7)
     assert SdxSim.ring_rows(None, rows, keys, 0).shape == (0, 3)
-    full = SdxSim.ring_rows(None, rows, torch.arange(8, 0, -1), 100)                       # more appends than slots: every slot is filled
+    import types
+    me = types.SimpleNamespace(ring_wrapped=False)
+    assert SdxSim.ring_rows(me, rows, keys, 5).shape == (5, 3) and me.ring_wrapped is False
+    full = SdxSim.ring_rows(me, rows, torch.arange(8, 0, -1), 100)                         # more appends than slots: every slot is filled
     assert full[:, 0].tolist() == [7.0, 6.0, 5.0, 4.0, 3.0, 2.0, 1.0, 0.0]
+    assert me.ring_wrapped is True                                                          # ... and the caller can tell that the serial order is gone
     g = SdxSim.ring_rows(None, rows, keys, 5)
     g[0, 0] = -1.0
     assert rows[3, 0] == 3.0                                                                # a copy, not a view of the ring
