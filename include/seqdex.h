@@ -122,8 +122,8 @@ typedef enum {
                             *                    [1] substeps in which an env still exceeded the per-env capacity (1536) after the rebuild of [2] and lost
                             *                    the excess in enumeration order - must stay 0 for results to mean anything, bench.py and the full-size
                             *                    tests check it; [2] substeps whose contact list was rebuilt without its speculative contacts (samples
-                            *                    that neither touch nor penetrate) because it would not fit; [3] substeps whose candidate pair list
-                            *                    exceeded its 1024 slots (the excess pairs were not tested: their contacts are MISSING) - like [1] it
+                            *                    that neither touch nor penetrate) because it would not fit; [3] substeps in which a pair list overflowed
+                            *                    (body pairs > 1535, candidate box pairs > 16384, surviving box pairs > 3072: the excess was not tested, its contacts are MISSING) - like [1] it
                             *                    must stay 0, the full-size tests assert it and bench.py flags it */
   SDX_T_WARM_COUNT = 44,   /* i32 [N]           contacts in each env's warm-start cache (scene.warm_start); the engine clears an
                             *                    env's entry when it resets the env; a caller that teleports bodies by hand may zero it too */

@@ -7,7 +7,7 @@
 
 #define SDX_WAVE 64
 #define SDX_MAXC 1536        // contact points per env = 3 rows per lane x 512 lanes of k_physics
-#define SDX_MAXP 1024        // candidate box pairs per env (LDS)
+#define SDX_MAXP 1535        // candidate body pairs per env (one impulse row of LDS; 1 024 through round 4: a trained grasp policy overflowed it in 20 of 3e8 env-substeps)
 #define SDX_CFIELDS 17       // ab, p3, n3, sep, lam3, wA3, wB3
 #define SDX_NSAMP 28
 #define SDX_BODY_STATIC 255

@@ -111,6 +111,7 @@ struct PhysLds {
 static_assert(ND * HP <= MAXC, "L^-1 must fit one row");
 static_assert(MAXP <= MAXC, "the pair list must fit one row");
 static_assert(MAXSP + MAXP + 1 <= 3 * MAXC, "box pairs and body-pair offsets fit the rows of cn");
+static_assert(3 * 8 * 33 < 1024, "box-pair counts of three body pairs per lane in 10 bits");
 static_assert(2 * MAXC * sizeof(unsigned short) == MAXC * sizeof(uint32_t), "contact keys alias the CSR entries");
 static_assert(sizeof(PhysLds) <= 80 * 1024, "two workgroups per CU need <= 80 KiB of LDS each");
 
@@ -734,9 +735,9 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   // here.  Lane tid looks at the consecutive pairs tid * q .. tid * q + q - 1 (order preserved).
   {
     constexpr int QMAX = (MAXP + NT - 1) / NT;
-    static_assert(QMAX <= 2, "two survivor slots per lane");
+    static_assert(QMAX <= 3, "three survivor slots per lane");
     const int q = (np + NT - 1) / NT;
-    uint32_t c0 = 0, c1 = 0;
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
     int kept = 0;
 #pragma unroll
     for (int k = 0; k < QMAX; ++k) {
@@ -748,7 +749,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
         bool sep = dir_setup(A, Bx, off).smax >= off;
         if (!sep && bb < STATIC0) sep = dir_setup(Bx, A, off).smax >= off;
         if (!sep) {
-          if (kept == 0) c0 = pr; else c1 = pr;
+          if (kept == 0) c0 = pr; else if (kept == 1) c1 = pr; else c2 = pr;
           ++kept;
         }
       }
@@ -757,6 +758,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     const int pos = block_scan_small<NT, 2>(S, kept, tid, &np2);   // its barrier comes after every lane's reads of the old list
     if (kept > 0) S_PAIRS(S)[pos] = c0;
     if (kept > 1) S_PAIRS(S)[pos + 1] = c1;
+    if (kept > 2) S_PAIRS(S)[pos + 2] = c2;
     np = np2;
     __syncthreads();
   }
@@ -808,12 +810,14 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       }
     }
     __syncthreads();
-    // exclusive prefix sum of the counts, two body pairs per lane
-    const int i0 = 2 * tid, i1 = 2 * tid + 1;
-    const int n0 = i0 < np ? S_OFF(S)[i0] : 0, n1 = i1 < np ? S_OFF(S)[i1] : 0;
-    const int boff = block_scan_small<NT, 10>(S, n0 + n1, tid, &nbp);   // <= 2 x (8 boxes of a hollow brick x 33 of a base plate) per lane: 10 bits
+    // exclusive prefix sum of the counts, three body pairs per lane
+    static_assert(MAXP <= 3 * NT, "three body pairs per lane");
+    const int i0 = 3 * tid, i1 = 3 * tid + 1, i2 = 3 * tid + 2;
+    const int n0 = i0 < np ? S_OFF(S)[i0] : 0, n1 = i1 < np ? S_OFF(S)[i1] : 0, n2 = i2 < np ? S_OFF(S)[i2] : 0;
+    const int boff = block_scan_small<NT, 10>(S, n0 + n1 + n2, tid, &nbp);   // <= 3 x (8 boxes of a hollow brick x 33 of a base plate) per lane: 10 bits
     if (i0 < np) S_OFF(S)[i0] = boff;
     if (i1 < np) S_OFF(S)[i1] = boff + n0;
+    if (i2 < np) S_OFF(S)[i2] = boff + n0 + n1;
     if (tid == 0) S_OFF(S)[np] = nbp;
     __syncthreads();
   }

@@ -153,9 +153,58 @@ def scripted_lift_statistics(num_envs=1024, seed=22, piles_per_type=16):
         task.sim.close()
 
 
-def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None):
+GRASP_TRAIN_MINIBATCH = 2048     # the minibatch size GraspSim LEARNS with on this engine (profiles/r5_grasp_train_curve_*.txt); the YAML ships 4
+
+
+def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_MINIBATCH, tvalue_state=None, initial_piles=None, piles_per_type=16):
+    """A BlockAssemblyGraspSim policy of THIS engine (round 5; the reference's is its released 19 000-epoch checkpoint, README.md:90):
+    `epochs` epochs at n envs, horizon 8, 5 mini-epochs, adaptive learning rate as shipped - but minibatches of 2 048 rows instead of the
+    shipped 4, with which the shipped schedule does not leave reward 2 (profiles/r5_grasp_train_curve_shipped_minibatch4.txt); episode reward
+    ~ 2 000 after 1 500 epochs = 30 s (the reference's checkpoint name says 1 531).  tvalue_state: the transition value that gates the
+    harvest of grasp terminal states (GS:1404-1417; None: the gate is opened - what a forward leg of the bi-optimisation loop does before
+    any T-value exists).  Returns (checkpoint path or "", the task (caller closes task.sim; its rings hold the harvested states), statistics)."""
+    from ..tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
+    from ..tvalue_trainer import LAYERS
+    set_seed(seed)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG["BlockAssemblyGraspSim"])))
+    cfg["env"]["numEnvs"] = n
+    tr = yaml.safe_load(open(os.path.join(ROOT, TRAIN_CFG["BlockAssemblyGraspSim"])))
+    tr["params"]["config"]["minibatch_size"] = minibatch
+    tr["params"]["config"]["central_value_config"]["minibatch_size"] = minibatch
+    task = BlockAssemblyGraspSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed, initial_piles=initial_piles, piles_per_type=piles_per_type)
+    if tvalue_state is None:              # open gate: output (0, 10) for every orientation -> sigmoid = 1
+        parts = []
+        for i, (_, out, inn) in enumerate(LAYERS):
+            parts.append(np.zeros(out * inn, np.float32))
+            b = np.zeros(out, np.float32)
+            if i == len(LAYERS) - 1:
+                b[1] = 10.0
+            parts.append(b)
+        task.sim.set_tvalue_weights(np.concatenate(parts))
+    else:
+        task.sim.set_tvalue_weights(tvalue_state)
+    env = RLgamesVecTaskPython(task, "cuda:0")
+    tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=seed)
+    agent = A2CAgent("run", tr["params"])
+    t0 = time.time()
+    for _ in range(epochs):
+        agent.train_epoch()
+    torch.cuda.synchronize()
+    st = {"epochs": epochs, "minibatch_size": minibatch, "wall_s": time.time() - t0, "game_reward": float(agent.game_rewards.get_mean()[0]),
+          "game_length": float(agent.game_lengths.get_mean()[0]), "grasp_states_harvested_per_type": task.sim.HARVEST_COUNT.cpu().tolist(),
+          "tvalue_gate": "open" if tvalue_state is None else "given", "contact_stats": task.sim.CONTACT_STATS.cpu().tolist()}
+    path = ""
+    if save_to:
+        agent.save(save_to)
+        path = save_to + ".pth"
+    agent.ppo.close()
+    return path, task, st
+
+
+def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None, grasp_states=None):
     """stage 0 of the chain (untimed; the backward pass of scripts/bi_optimization.py:120-121 in small): BlockAssemblyInsertSim trains
-    `epochs` epochs with its shipped schedule from synthetic grasp states, its episode outcomes fill the T-value rings, GraspInsertTValue
+    `epochs` epochs with its shipped schedule from synthetic grasp states (or, grasp_states given, from grasp terminal states a grasp
+    policy harvested), its episode outcomes fill the T-value rings, GraspInsertTValue
     is fitted to them -> the transition value that gates the harvests of the chain, and the insert policy of its last stage.
     Deterministic run to run: torch's global generator is seeded like the launcher does (it feeds VecTask.reset()'s noise step), training
     is (fixed-order reductions, counter-based noise) and the fit reads the outcome rings in serial (step, env) order (SdxSim.ring_rows),
@@ -167,7 +216,7 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to
     cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG["BlockAssemblyInsertSim"])))
     cfg["env"]["numEnvs"] = n
     tr = yaml.safe_load(open(os.path.join(ROOT, TRAIN_CFG["BlockAssemblyInsertSim"])))
-    task = BlockAssemblyInsertSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed)
+    task = BlockAssemblyInsertSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed, grasp_states=grasp_states)
     env = RLgamesVecTaskPython(task, "cuda:0")
     tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=seed)
     agent = A2CAgent("run", tr["params"])
@@ -175,8 +224,8 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to
     for _ in range(epochs):
         agent.train_epoch()
     torch.cuda.synchronize()
-    st = {"epochs": epochs, "wall_s": time.time() - t0, "game_reward": agent.game_rewards.get_mean()[0],
-          "outcomes_logged(success, failure)": task.sim.TV_COUNT.cpu().tolist()}
+    st = {"epochs": epochs, "wall_s": time.time() - t0, "game_reward": agent.game_rewards.get_mean()[0], "grasp_states": task.grasp_states_source,
+          "outcomes_logged(success, failure)": task.sim.TV_COUNT.cpu().tolist(), "insert_success_buf_mean": float(task.extras["success_buf"].float().mean())}
     path = ""
     if save_to:
         agent.save(save_to)
@@ -232,13 +281,18 @@ def fill_missing_pile_groups(harvest, counts, min_piles, seed, max_missing=2, ke
 
 
 def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, controllers=None, min_piles=8, seed=22, stage_steps=None,
-                         synthetic_fallback=False, orient_tvalue_gate=0.99, grasp_tvalue_gate=0.8, with_search=False):
+                         synthetic_fallback=False, orient_tvalue_gate=0.99, grasp_tvalue_gate=0.8, with_search=False, min_grasp_states=0,
+                         max_grasp_steps=None, orient_fallback=None):
     """Orient -> GraspSim -> InsertSim played back to back on one GPU.  policies / controllers / stage_steps: dicts keyed "orient",
     "grasp", "insert".  Orient plays until every brick-type group has `min_piles` harvested pile states (OR:1483-1488 fills rings of
     10 000; at most 8 episodes here).  orient_tvalue_gate: the threshold Orient binarises the transition value at (0.99, OR:1203), or
     a descending ladder of thresholds (see stage 1 below); a T-value fitted to a few hundred epochs of outcomes never gets that
     confident, so the chain benchmark lowers it (and GraspSim's 0.8, GS:1406) and says so.
+    min_grasp_states > 0: GraspSim plays (in horizon-sized chunks, at most max_grasp_steps env steps) until every brick-type group has that
+    many harvested grasp states - a learned grasp policy under the reference's gate 0.8 harvests a state every few dozen episodes.
+    orient_fallback: overrides synthetic_fallback for Orient's hand-off only (settled piles for the groups Orient harvested nothing for).
     Returns (statistics, hand-off tensors for inspection)."""
+    orient_fallback = synthetic_fallback if orient_fallback is None else orient_fallback
     policies, controllers, stage_steps = policies or {}, controllers or {}, stage_steps or {}
     out, hand = {"num_envs": num_envs, "min_piles_per_type": min_piles}, {}
     t_begin = time.time()
@@ -272,7 +326,7 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
         st["piles_harvested_per_type"] = orient.sim.PILE_HARVEST_COUNT.cpu().tolist()
         st["tvalue_gate"] = gate
         piles = orient.pile_terminal_states()
-        if synthetic_fallback:
+        if orient_fallback:
             filled, lacking = fill_missing_pile_groups(orient.sim.PILE_HARVEST, orient.sim.PILE_HARVEST_COUNT, min_piles, seed, keys=orient.sim.PILE_HARVEST_KEYS)
             if lacking:
                 piles, st["settled_stand_in_groups"] = filled, lacking
@@ -294,6 +348,8 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     for gi, gate in enumerate(gladder):
         grasp, st = main_rlgames("BlockAssemblyGraspSim", num_envs, policy_path=policies.get("grasp", ""), tvalue_state=tvalue_state,
                                  controller=controllers.get("grasp"), seed=seed, steps=stage_steps.get("grasp"),
+                                 until=(lambda t: int(t.sim.HARVEST_COUNT.min()) >= min_grasp_states) if min_grasp_states > 0 else None,
+                                 max_steps=max_grasp_steps,
                                  task_kwargs={"initial_piles": piles, "harvest_tvalue_gate": gate})
         cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
         gtried.append({"tvalue_gate": gate, "grasp_states_harvested_per_type": cnt.tolist()})
@@ -331,6 +387,37 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
     out["chain_env_steps"] = steps
     out["chain_env_steps_per_s"] = steps / play                      # the three rollouts back to back (task construction excluded)
     out["chain_env_steps_per_s_incl_setup"] = steps / out["chain_wall_s"]
+    return out, hand
+
+
+CHAIN_LEARNED_ORIENT_GATES = (0.99, 0.9, 0.8, 0.5, 0.3, 0.0)     # starts at the reference's threshold (OR:1203)
+
+
+def block_assembly_chain_learned(num_envs=1024, grasp_epochs=1500, insert_epochs=1500, seed=22, workdir=None, min_grasp_states=1, max_grasp_steps=16000):
+    """BASELINE.json configs[2] on LEARNED policies (round 5) - no scripted stage, no synthetic grasp states:
+      stage 0  BlockAssemblyInsertSim trains `insert_epochs` epochs with its shipped schedule from synthetic grasp states (the backward leg of
+               bi_optimization.py:120-121 in small); GraspInsertTValue is fitted to its episode outcomes (thousands of successes since the
+               studs engage) -> the transition value of the gates and the insert policy of the last stage;
+      stage g  a BlockAssemblyGraspSim policy of this engine is trained `grasp_epochs` epochs (minibatch 2 048) with that transition value
+               gating its harvest at the reference's 0.8 (GS:1406);
+      chain    Orient (random-initialised policy - its arm is scripted by the task - under a ladder of gates that starts at the reference's 0.99;
+               the rung used is reported; a group it harvests nothing for starts GraspSim from settled piles, named in the statistics) ->
+               GraspSim (the learned policy, gate 0.8, played until every brick-type group has `min_grasp_states` harvested states) ->
+               InsertSim (the learned insert policy, started from those states only: a group without one raises, as IS:1449 fails).
+    Returns (statistics, hand-off tensors; the caller closes hand["insert_task"].sim)."""
+    import tempfile
+    workdir = workdir or tempfile.mkdtemp(prefix="sdx_chain_learned_")
+    tv, ipath, ist = prepare_tvalue_and_insert_policy(num_envs, insert_epochs, seed=seed, save_to=os.path.join(workdir, "insert"))
+    if tv is None:
+        raise RuntimeError("stage 0 logged too few insert outcomes of a class for a transition value: %s" % ist)
+    gpath, gtask, gst = train_grasp_policy(num_envs, grasp_epochs, seed=seed, save_to=os.path.join(workdir, "grasp"), tvalue_state=tv)
+    gtask.sim.close()
+    res, hand = block_assembly_chain(num_envs, tv, policies={"grasp": gpath, "insert": ipath}, synthetic_fallback=False, orient_fallback=True,
+                                     orient_tvalue_gate=CHAIN_LEARNED_ORIENT_GATES, grasp_tvalue_gate=0.8, stage_steps={"grasp": 160},
+                                     min_grasp_states=min_grasp_states, max_grasp_steps=max_grasp_steps, seed=seed)
+    out = {"stage0_insert_policy_and_tvalue(untimed)": ist, "grasp_policy(untimed)": gst, "chain": res,
+           "stand_ins": ["Orient plays its random initialisation under T-value gate %s (reference: a trained Orient policy under 0.99)" % res["orient"]["tvalue_gate"]]
+           + (["settled piles for Orient's brick-type groups %s" % res["orient"]["settled_stand_in_groups"]] if res["orient"].get("settled_stand_in_groups") else [])}
     return out, hand
 
 

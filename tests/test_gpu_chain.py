@@ -1,5 +1,5 @@
-"""BASELINE.json configs[2] on the GPU: the Orient -> GraspSim -> InsertSim chain at 1 024 envs (seqdex_amd/scripts/evaluation.py, after the
-reference's scripts/evaluation.py:111-119).  Checks the hand-offs themselves: Orient's harvested piles are what GraspSim resets from,
+"""BASELINE.json configs[2] on the GPU: the Orient -> GraspSim -> InsertSim chain at 1 024 envs on learned grasp / insert policies
+(seqdex_amd/scripts/evaluation.py, after the reference's scripts/evaluation.py:111-119).  Checks the hand-offs themselves: Orient's harvested piles are what GraspSim resets from,
 GraspSim's harvested terminal states are what InsertSim resets from - bit for bit (OR:1463-1488 -> GS:412-413,1507-1513; GS:1404-1417 ->
 IS:372-375,1449-1456)."""
 import numpy as np
@@ -12,36 +12,33 @@ N = 1024
 
 
 def test_chain_hand_offs_at_1024_envs():
-    import os
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from seqdex_amd.scripts.evaluation import CHAIN_GRASP_GATES, CHAIN_ORIENT_GATES, block_assembly_chain, prepare_tvalue_and_insert_policy, scripted_grasp_controller
-    # stage 0: the transition value of the chain's gates, fitted to InsertSim's own episode outcomes (bi_optimization.py:120-121).  One
-    # seed, no retry: training is deterministic and the fit reads the outcome rings in serial (step, env) order (SdxSim.ring_rows)
-    tv, _, prep = prepare_tvalue_and_insert_policy(N, 1000, fit_iters=2000, seed=22)
-    assert tv is not None, prep                                   # both outcome classes were logged and the fit ran
-    # gates: descending ladders starting at 0.5 / 0.28 instead of 0.99 (OR:1203) / 0.8 (GS:1406): a T-value fitted to a thousand epochs of
-    # outcomes tops out near 0.85 and sits at its floor sigmoid(-1) = 0.27 for most orientations, and WHICH orientations it accepts moves
-    # with any change of the training arithmetic (block_assembly_chain, stage 1); the last rung opens the gate; two grasp episodes
-    try:
-        res, hand = block_assembly_chain(N, tv, controllers={"grasp": scripted_grasp_controller}, synthetic_fallback=True, orient_tvalue_gate=CHAIN_ORIENT_GATES,
-                                         grasp_tvalue_gate=CHAIN_GRASP_GATES, stage_steps={"grasp": 320})
-    except RuntimeError as ex:
-        pytest.fail("%s; stage 0 was %s" % (ex, prep))
+    """round 5: the chain on LEARNED grasp and insert policies - no scripted grasp stage, no synthetic grasp states.
+    Stage 0 trains the insert policy (1 500 epochs, 31 s) and fits the transition value to its outcomes; a GraspSim policy is trained
+    (1 500 epochs of 2 048-row minibatches, 31 s) under that value's gate; then Orient -> GraspSim -> InsertSim are played
+    (evaluation.py::block_assembly_chain_learned).  GraspSim harvests under the reference's gate 0.8 (GS:1406); Orient plays its random
+    initialisation under a ladder that starts at the reference's 0.99 (OR:1203) - the rung used is in the statistics."""
+    from seqdex_amd.scripts.evaluation import block_assembly_chain_learned
+    out, hand = block_assembly_chain_learned(N, 1500, 1500)
+    res = out["chain"]
     ins = hand["insert_task"]
     try:
+        assert out["grasp_policy(untimed)"]["game_reward"] > 500, out["grasp_policy(untimed)"]      # it learned to lift (1 588 measured; 2 through round 4)
+        st0 = out["stage0_insert_policy_and_tvalue(untimed)"]
+        assert st0["outcomes_logged(success, failure)"][0] > 1000 and isinstance(st0["tvalue_fit"], dict), st0   # studs engage: thousands of insertions
         # ---- hand-off 1: Orient harvested >= 8 piles for (nearly) every brick-type group, and GraspSim started from them
         # (at most two groups may have fallen back to settled piles when this run's T-value fit missed their orientations; the statistics name them)
         short = [t for t, c in enumerate(res["orient"]["piles_harvested_per_type"]) if c < 8]
         assert len(short) <= 2 and res["orient"].get("settled_stand_in_groups", []) == short, res["orient"]
+        assert res["orient"]["tvalue_gate"] >= 0.5, res["orient"]                                    # the ladder stopped in its upper half (0.8 measured)
         piles = hand["piles"]
         assert piles.shape[0] == 8 and piles.shape[1] >= 8 and tuple(piles.shape[2:]) == (132, 13)
         assert torch.isfinite(piles).all() and float(piles[..., 3:7].norm(dim=-1).min()) > 0.99     # every slot is a filled pile state
-        # ---- hand-off 2: the grasp stage harvested real terminal states for most groups (scripted stand-in policy) ...
+        # ---- hand-off 2: the LEARNED grasp policy harvested real terminal states for every brick-type group under the reference's gate ...
         cnt = np.array(res["grasp"]["grasp_states_harvested_per_type"])
-        assert (cnt > 0).sum() >= 3 and cnt.sum() >= 20, cnt
-        real = [t for t in range(8) if cnt[t] > 0]
-        assert sorted(ins.synthetic_groups) == [t for t in range(8) if cnt[t] == 0]
+        assert res["grasp"]["tvalue_gate"] == 0.8 and "grasp.pth" in res["grasp"]["policy"]
+        assert (cnt > 0).all() and cnt.sum() >= 20, cnt
+        assert ins.synthetic_groups == [] and ins.grasp_states_source == "given"
+        real = list(range(8))
         # ... and InsertSim's reset rows ARE those states: reset every env, then compare the target brick and the hand joint by joint
         s = ins.sim
         mask = torch.ones(N, dtype=torch.uint8, device=s.ROOT.device)
@@ -62,7 +59,7 @@ def test_chain_hand_offs_at_1024_envs():
             assert any((hand_h[t][k, :, 0] == dof[e, :, 0]).all() for k in hit), e      # ... with that state's hand joints
             assert (row[7:13] == 0).all() and (dof[e, :, 1] == 0).all()                # velocities zeroed (IS:1452-1456)
             checked += 1
-        assert checked >= N // 4
+        assert checked == N
         assert res["chain_env_steps_per_s"] > 0 and res["insert"]["steps_per_env"] >= 125
     finally:
         ins.sim.close()
