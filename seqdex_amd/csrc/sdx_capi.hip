@@ -83,7 +83,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
     const int ns = scene->n_static, nr = scene->n_rbox;
     bool ok = ns >= 0 && ns <= SDX_MAX_STATIC && nr >= 0 && nr <= SDX_MAX_RBOX && scene->n_static_sub >= 0 && scene->n_static_sub <= SDX_MAX_STATIC_SUB;
     // candidate body pairs of the broadphase: <= 16 per lane of the 512-thread workgroup (the pair rank's 13 bits)
-    ok = ok && SDX_NFREE * ns + SDX_NFREE * (SDX_NFREE - 1) / 2 + nr * (SDX_NFREE + ns) <= 16 * 512;
+    ok = ok && SDX_NFREE * SDX_MAX_STATIC + SDX_NFREE * (SDX_NFREE - 1) / 2 + nr * (SDX_NFREE + SDX_MAX_STATIC) <= 16 * 512;   // (the enumeration runs over all static slots)
     for (int t = 0; ok && t < SDX_NBRICK_TYPES; ++t)
       ok = scene->brick_nsub[t] >= 1 && scene->brick_nsub[t] <= SDX_MAX_SUB && scene->hollow_nsub[t] >= 0 && scene->hollow_nsub[t] <= SDX_MAX_SUB_HOLLOW &&
            (!scene->seg_hollow || scene->hollow_nsub[t] >= 1);

@@ -83,6 +83,7 @@ struct SdxBuf {
 #define SDX_PIN4(a) ((void)0)
 #define SDX_PIN8(a) ((void)0)
 #define SDX_RCP(x) (1.0f / (x))
+#define SDX_SQRT_FAST(x) sqrtf(x)
 #define SDX_READLANE(x, lane) __shfl((x), (lane), 64)
 #define SDX_UNIFORM(x) (x)
 #define SDX_WAIT_VMCNT0() ((void)0)
@@ -106,6 +107,7 @@ struct SdxBuf {
 // operands already loaded for them are spilled
 #define SDX_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
 #define SDX_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+#define SDX_SQRT_FAST(x) __builtin_amdgcn_sqrtf(x)   // v_sqrt_f32, 1 ulp: for integer results that are corrected afterwards
 #define SDX_RCP(x) __builtin_amdgcn_rcpf(x)   // v_rcp_f32, 1 ulp: the solver's step lengths do not need IEEE division (12 instructions)
 // value of x in a lane known at compile time (v_readlane_b32: the result is wave-uniform, no LDS crossbar); every lane of the wave must be active
 #define SDX_READLANE(x, lane) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (lane)))

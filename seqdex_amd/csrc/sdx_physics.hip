@@ -252,6 +252,11 @@ __device__ __forceinline__ float sample_contact(const Dir& D, f3 pb, f3 h, f3* g
   return box_sdf(pb, h, g);
 }
 
+constexpr float kSamp[SDX_NSAMP][3] = {   // c_samp as compile-time constants: immediates of the fully unrolled classification loop
+    {1, 1, 1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1},
+    {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
+    {-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0},
+    {-0.5f, -1, -1}, {0.5f, -1, -1}, {-0.5f, 1, -1}, {0.5f, 1, -1}, {-0.5f, -1, 1}, {0.5f, -1, 1}, {-0.5f, 1, 1}, {0.5f, 1, 1}};
 __device__ __forceinline__ f3 face_frame(f3 v, int kax) {   // component kax moves to z
   return kax == 0 ? F3(v.y, v.z, v.x) : kax == 1 ? F3(v.x, v.z, v.y) : v;
 }
@@ -273,17 +278,19 @@ __device__ __forceinline__ bool classify_dir(const PhysLds& S, const Box& A, con
   const f3 h = face_frame(T.h, D.kax);
   const float ftol = D.kax >= 0 ? FACE_TOL : -1e30f, off2 = incl * incl;
   uint32_t mface = 0, mother = 0;
-  // (the sample index is wave-uniform: the table entries arrive through scalar loads.  Fully unrolled with the entries as immediates -
-  // round 3's form of the per-direction loop - the two instances of this loop cost the WHOLE kernel 220 spilled VGPRs, 18 scratch
-  // operations inside the solver's iteration loop among them)
+  // Fully unrolled with the table entries as immediates: 18 instructions per sample (rolled four at a time with the entries from
+  // scalar loads: 56, and this loop is VALU-issue bound: 30 k cycles per chunk of 512 box pairs against 11 k).  The loop body must stay
+  // this small: with the running extremes of an earlier manifold rule inside it the two unrolled instances cost the WHOLE kernel 220
+  // spilled VGPRs, 18 scratch operations inside the solver's iteration loop among them; as it is: 24 spills, none in a loop
+  // (python tools/isa_check.py; -DSDX_CLASSIFY_UNROLL=4 is the rolled form)
 #ifndef SDX_CLASSIFY_UNROLL
-#define SDX_CLASSIFY_UNROLL 4
+#define SDX_CLASSIFY_UNROLL SDX_NSAMP
 #endif
   constexpr int CU = SDX_CLASSIFY_UNROLL;
 #pragma unroll CU
   for (int s = 0; s < SDX_NSAMP; ++s) {
-    const float* ks = c_samp[s];
-    const f3 pb = ((t + ex * ks[0]) + ey * ks[1]) + ez * ks[2];
+    const float k0 = CU == SDX_NSAMP ? kSamp[s][0] : c_samp[s][0], k1 = CU == SDX_NSAMP ? kSamp[s][1] : c_samp[s][1], k2 = CU == SDX_NSAMP ? kSamp[s][2] : c_samp[s][2];
+    const f3 pb = ((t + ex * k0) + ey * k1) + ez * k2;
     const float dx = fabsf(pb.x) - h.x, dy = fabsf(pb.y) - h.y, dz = fabsf(pb.z) - h.z;
     const float lat = fmaxf(dx, dy);
     const float sdf = D.sgn * pb.z - h.z;
@@ -538,9 +545,9 @@ __device__ __forceinline__ void twists_wave0(PhysLds& S, int tid) {
 }
 
 __device__ __forceinline__ void tri_index(int idx, int* i, int* j) {   // idx -> (i, j), j <= i, row-major lower triangle
-  int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-  while ((r + 1) * (r + 2) / 2 <= idx) ++r;
-  while (r * (r + 1) / 2 > idx) --r;
+  int r = (int)((SDX_SQRT_FAST(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);   // within one of the exact row: two branch-free corrections
+  r += (r + 1) * (r + 2) / 2 <= idx;
+  r -= r * (r + 1) / 2 > idx;
   *i = r;
   *j = idx - r * (r + 1) / 2;
 }
@@ -650,6 +657,8 @@ __device__ __forceinline__ bool box_near(const PhysLds& S, f3 ca, float ra, f3 c
   return box_sdf_val(qrot(qconj(qb), ca - cb), hb) <= ra + off;
 }
 // pair index -> (box a | box b << 8); box ids: 0..71 brick, 72..111 robot box, 128.. static body
+// (ns, per are compile-time constants at the call sites - the enumeration runs over all SDX_MAX_STATIC slots, unused ones never are
+// candidates - so that the divisions below are multiplications: a division by a run-time integer is ~30 instructions, twice per candidate)
 __device__ __forceinline__ uint32_t pair_code(int idx, int n1, int n2, int ns, int per) {
   if (idx < n1) return (uint32_t)(idx / ns) | ((uint32_t)(STATIC0 + idx % ns) << 8);
   if (idx < n1 + n2) {
@@ -666,9 +675,10 @@ __device__ __forceinline__ bool brick_near(const PhysLds& S, f3 ca, float ra, in
   const int tj = S.btype[j];
   return box_sdf_val(qrot(qconj(qj), ca - ld3(S.bp[j])) - ld3(S.tbc[tj]), ld3(S.tbh[tj])) <= ra + off;
 }
-__device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int n2, int ns, int per, float off) {
+__device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int n2, int ns, int per, int ns_used, float off) {
   if (idx < n1) {
     const int i = idx / ns, st = idx % ns;
+    if (st >= ns_used) return false;
     return box_sdf_val(ld3(S.bp[i]) - ld3(S.stc[st]), ld3(S.sth[st])) <= S.trad[S.btype[i]] + off;
   }
   if (idx < n1 + n2) {
@@ -695,6 +705,7 @@ __device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int
     return brick_near(S, rc, rr0, u, off) || box_near(S, cb, rb, rc, ld4(S.rq[r]), ld3(S.rh[r]), off);
   }
   const int st = u - NF;
+  if (st >= ns_used) return false;
   return box_sdf_val(rc - ld3(S.stc[st]), ld3(S.sth[st])) <= rr0 + off;
 }
 
@@ -702,14 +713,16 @@ template <int NT>
 __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, long long* dbg) {
   const sdx_scene_desc& sc = C->sc;
   const float off = sc.contact_offset;
-  const int ns = sc.n_static;
+  constexpr int ns = SDX_MAX_STATIC, per = NF + SDX_MAX_STATIC;
+  const int ns_used = sc.n_static;
   // ---- broadphase over BODY pairs: lane tid tests candidates tid, tid + NT, ...; hits as a bit mask; ONE block scan places them (lane-major order)
-  const int n1 = NF * ns, n2 = NF * (NF - 1) / 2, per = NF + ns, n3 = sc.n_rbox * per, ntot = n1 + n2 + n3;   // ntot <= 16 NT (sdxk_physics checks)
+  constexpr int n1 = NF * ns, n2 = NF * (NF - 1) / 2;
+  const int n3 = sc.n_rbox * per, ntot = n1 + n2 + n3;   // ntot <= 16 NT (sdx_create checks)
   uint32_t mask = 0;
   {
     int it = 0;
     for (int idx = tid; idx < ntot; idx += NT, ++it) {
-      if (candidate(S, idx, n1, n2, ns, per, off)) mask |= 1u << it;
+      if (candidate(S, idx, n1, n2, ns, per, ns_used, off)) mask |= 1u << it;
     }
   }
   SSTAMP(32);
