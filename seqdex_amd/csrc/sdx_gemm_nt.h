@@ -175,14 +175,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(NtBatch nb, int nx, int ny) 
 #pragma unroll
               for (int v = 0; v < WTN; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][u][q], b[t][v][q], acc[u][v], 0, 0, 0);
         }
+#ifdef SDX_GEMM_NT_BRANCHY          // diagnostic build only: the round-4 form with a (workgroup-uniform) branch between the MFMAs of a k step
+        if (do_rs) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) rs[u] += frag_sum(a[t][u]);
+        }
+#else
         if constexpr (RS) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) rs[u] += frag_sum(a[t][u]);
         }
+#endif
       }
     }
   };
+#ifdef SDX_GEMM_NT_BRANCHY
+  chunks(std::false_type{});
+#else
   if (do_rs) chunks(std::true_type{}); else chunks(std::false_type{});   // (workgroup-uniform: every wave of a workgroup runs the same copy)
+#endif
   // ---- epilogue.  C/D layout: lane l holds column (l & 31), rows (r & 3) + 8 (r >> 2) + 4 (l >> 5), r = 0..15, of each 32 x 32 block
   if constexpr (EPI == EPI_TN) {
     if (do_rs) {                                     // lanes l and l + 32 hold the two halves of row (l & 31)'s sum over this split's k range

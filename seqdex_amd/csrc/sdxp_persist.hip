@@ -118,7 +118,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lq_rsrc(void* ll) { return __b
 // last ^ fold(the payload it read) equals the tag it waits for.  A word whose dwords come from two different stores (new tag over a
 // stale payload or the reverse) fails the test unless the mixed payload folds to the same value (2^-32, or the stale dwords equal the new
 // ones - then nothing is lost) and is simply polled again, like a word that has not arrived.
-__device__ __forceinline__ unsigned lq_fold(unsigned x, unsigned y, unsigned z) { return x ^ __builtin_rotateleft32(y, 11) ^ __builtin_rotateleft32(z, 22); }
+// (fold = x ^ y ^ z: one v_xor3_b32.  With rotations of y and z in it - to decorrelate equal values of two networks - the checks cost the
+// step 0.6 us on its dependent chain, 31.4 instead of 30.8; two networks' values that are equal before AND after a step are unchanged ones)
+__device__ __forceinline__ unsigned lq_fold(unsigned x, unsigned y, unsigned z) { return x ^ y ^ z; }
 __device__ __forceinline__ bool lq_ok(const u32x4& w, unsigned tag) { return (w.w ^ lq_fold(w.x, w.y, w.z)) == tag; }
 __device__ __forceinline__ void lq_store(__amdgpu_buffer_rsrc_t q, unsigned idx, float a, float b, float c, unsigned tag) {
   u32x4 w;

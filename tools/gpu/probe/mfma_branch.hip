@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void k(const float* __restrict__ A, const float
     const float a0 = a0p[kk], a1 = a1p[kk], b = bp[kk];
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
 #ifndef NO_BRANCH
-    if (do_rs) { rs0 += a0; rs1 += a1; }  // VALU work between the two MFMAs, skipped by block 1
+    if (do_rs) { asm volatile("" ::: "memory"); rs0 += a0; rs1 += a1; }  // VALU work between the two MFMAs, skipped by block 1 (the empty asm keeps the compiler from predicating it)
 #endif
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
   }
@@ -50,14 +50,14 @@ int main() {
       ref[i * 32 + j] = (float)s;     // small integers: exact in fp32
     }
   float *dA, *dB, *dC, *dR;
-  hipMalloc(&dA, hA.size() * 4); hipMalloc(&dB, hB.size() * 4); hipMalloc(&dC, hC.size() * 4); hipMalloc(&dR, 256 * 4);
-  hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
-  hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMalloc(&dA, hA.size() * 4); (void)hipMalloc(&dB, hB.size() * 4); (void)hipMalloc(&dC, hC.size() * 4); (void)hipMalloc(&dR, 256 * 4);
+  (void)hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
   int total = 0;
   for (int rep = 0; rep < 50; ++rep) {
-    hipMemset(dC, 0, hC.size() * 4);
+    (void)hipMemset(dC, 0, hC.size() * 4);
     hipLaunchKernelGGL(k, dim3(2), dim3(64), 0, 0, dA, dB, dC, dR);
-    hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost);
     for (int blk = 0; blk < 2; ++blk) {
       int bad0 = 0, bad1 = 0;
       for (int i = 0; i < 64; ++i)
