@@ -156,7 +156,42 @@ def scripted_lift_statistics(num_envs=1024, seed=22, piles_per_type=16):
 GRASP_TRAIN_MINIBATCH = 2048     # the minibatch size GraspSim LEARNS with on this engine (profiles/r5_grasp_train_curve_*.txt); the YAML ships 4
 
 
-def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_MINIBATCH, tvalue_state=None, initial_piles=None, piles_per_type=16):
+def policy_lift_statistics(task, agent, steps=304):
+    """what a TRAINED grasp policy physically does (round 5, the check behind the training curves): `steps` deterministic env steps (two
+    episodes) of `agent` on `task`; per env the largest height of the target brick above its initial one while finger_dist < 0.5, whether at
+    least two fingertip links (thumb among them) carried a net contact force > 0.5 N at that moment (held BY contacts, not by a brick lying
+    on the hand), and the brick's speed relative to the hand base then.  Sampled after every env step of the horizon-sized chunks."""
+    s, n, dev = task.sim, task.num_envs, task.device
+    seg = torch.as_tensor([s.scene.seg_index(i) for i in range(n)], device=dev)
+    ar = torch.arange(n, device=dev)
+    tips = list(s.scene.fingertip_bodies)
+    held = torch.zeros(n, device=dev)
+    grip = torch.zeros(n, dtype=torch.bool, device=dev)
+    rel = torch.zeros(n, device=dev)
+    eps = torch.zeros(n, agent.ppo.cfg.act_dim, device=agent.ppo.device)
+    if agent.obs is None:
+        agent.obs = agent.env_reset()
+        agent.dones = agent.vec_env.task.reset_buf
+    for k in range(steps):
+        a = agent.ppo.act(k % agent.horizon_length, agent.obs["obs"], agent.obs["states"], agent.dones, eps)
+        agent.obs, rew, agent.dones, _ = agent.vec_env.step(a)
+        b = s.ROOT.view(n, 142, 13)[ar, seg]
+        dz = b[:, 2] - s.INIT_POS[:, 2]
+        cf = s.CONTACT.view(n, 165, 3)[:, tips].norm(dim=-1)
+        g2 = (cf[:, 3] > 0.5) & ((cf[:, :3] > 0.5).sum(1) >= 1)
+        better = (s.FINGER_DIST < 0.5) & (dz > held) & (s.PROGRESS > 1)
+        held = torch.where(better, dz, held)
+        grip = torch.where(better, g2, grip)
+        rel = torch.where(better, (b[:, 7:10] - s.RB[:, s.scene.hand_base_body, 7:10]).norm(dim=-1), rel)
+    torch.cuda.synchronize()
+    ok = held > 0.05
+    return {"steps": steps, "held_5cm_frac": float(ok.float().mean()), "held_15cm_frac": float((held > 0.15).float().mean()), "held_max_m": float(held.max()),
+            "of_those_gripped_by_thumb_and_a_finger": float((ok & grip).float().sum() / ok.float().sum().clamp(min=1)),
+            "brick_speed_relative_to_hand_at_the_top_mean_m_s": float(rel[ok].mean()) if bool(ok.any()) else None,
+            "per_type_held_5cm": [int(ok[ar % 8 == g].sum()) for g in range(8)]}
+
+
+def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_MINIBATCH, tvalue_state=None, initial_piles=None, piles_per_type=16, lift_statistics=False):
     """A BlockAssemblyGraspSim policy of THIS engine (round 5; the reference's is its released 19 000-epoch checkpoint, README.md:90):
     `epochs` epochs at n envs, horizon 8, 5 mini-epochs, adaptive learning rate as shipped - but minibatches of 2 048 rows instead of the
     shipped 4, with which the shipped schedule does not leave reward 2 (profiles/r5_grasp_train_curve_shipped_minibatch4.txt); episode reward
@@ -193,6 +228,8 @@ def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_M
     st = {"epochs": epochs, "minibatch_size": minibatch, "wall_s": time.time() - t0, "game_reward": float(agent.game_rewards.get_mean()[0]),
           "game_length": float(agent.game_lengths.get_mean()[0]), "grasp_states_harvested_per_type": task.sim.HARVEST_COUNT.cpu().tolist(),
           "tvalue_gate": "open" if tvalue_state is None else "given", "contact_stats": task.sim.CONTACT_STATS.cpu().tolist()}
+    if lift_statistics:
+        st["deterministic_play"] = policy_lift_statistics(task, agent)
     path = ""
     if save_to:
         agent.save(save_to)
