@@ -305,8 +305,9 @@ def main():
                  "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes,
                  "warm_start_cache_bytes_per_launch": cache_bytes,
-                 "bound_actual": "latency: barrier-separated LDS-resident phases (VALU issue about 1/3 busy, LDS about 40 %, waves parked 60 % of "
-                                 "their cycles; profiles/r3_kphysics_pmc_*.csv); the working set never leaves LDS, so the HBM roofline is nominal",
+                 "bound_actual": "latency: barrier-separated LDS-resident phases (VALU issue about 1/3 busy with 66 % of the lanes active, bank conflicts "
+                                 "32 % of the LDS-active cycles, waves parked 65 % of their cycles; profiles/r5_kphysics_pmc_{sq,lds}.csv); the working set "
+                                 "never leaves LDS, so the HBM roofline is nominal",
                  "contacts_per_env_mean": nc_mean, "contacts_per_env_max": int(sim.NCONTACTS.max().item()),
                  "contact_capacity_per_env": 1536, "contacts_per_env_max_since_create": cstats[0],
                  "env_substeps_over_capacity_since_create": cstats[1], "env_substeps_rebuilt_without_speculative_contacts": cstats[2],

@@ -6,7 +6,8 @@
  * CF:185-217 + cfg/allegro_hand_block_assembly_grasp_sim.yaml:155-167, scene GS:523-1058).  There is no
  * reference-side test or golden vector for it, so this file DEFINES the step (from the scene constants
  * A0/A1 of SURVEY.md §8(a)) and is pinned only by the known-answer tests we author in
- * tests/test_physics_oracle.py (free fall, resting contact, PD response, FK/Jacobian finite differences).
+ * tests/test_physics_oracle.py (free fall, resting contact, PD response, FK/Jacobian finite differences, stacks,
+ * the compound-shape cases: hull profile, seated hollow brick on studs).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this code.
  *
@@ -14,8 +15,11 @@
  *   A  forward kinematics of the 24-body tree, link twists
  *   B  joint-space inertia M(q) (composite sums, once per step), H = M + diag(armature + h kd + h^2 kp), Hinv
  *   C  implicit PD drive (P1):  qd += Hinv h clamp(kp(q*-q) - (kd + h kp) qd, +-effort);  bricks: v += h g
- *   D  contacts (P3): boxes only; sample points of one box against the analytic SDF of the other,
- *      both directions, <= 4 contacts per pair, kept when separation < contact_offset
+ *   D  contacts (P3): every body is a compound of boxes (hull slabs of a brick, the hollow target brick of InsertSim,
+ *      studded base plates, robot boxes).  Body pairs by bounding box; a pair of convex bodies
+ *      contributes the box pair with the smallest separation bound, a pair with a compound side all of its box pairs;
+ *      sample points of one box against the analytic SDF of the other, both directions, <= 4 contacts per box pair
+ *      chosen to span the patch, kept when separation < contact_offset
  *   E  solve (P4): `solver_iters` mass-split Jacobi iterations on accumulated impulses, normal +
  *      2 friction rows, robot side in reduced coordinates (qd = qd* + Hinv J^T lambda)
  *   F  integrate (P5): semi-implicit Euler, joint limit / velocity clamps, quaternion renormalisation

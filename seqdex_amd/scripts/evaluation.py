@@ -10,6 +10,7 @@ same content (the pickle forms exist too: seqdex_amd/piles.py, BlockAssemblyGras
 configs[2] is this chain at num_envs = 1024 on one GPU; tools/bench_config3.py times it, tests/test_gpu_chain.py checks the hand-offs.
 
     python -m seqdex_amd.scripts.evaluation --tasks BlockAssembly [--num_envs 512] [--search s.pth] --orient o.pth --grasp g.pth --insert i.pth [--games 512]
+    python -m seqdex_amd.scripts.evaluation --mode chain_learned [--num_envs 1024]
     python -m seqdex_amd.scripts.evaluation --mode chain [--tvalue tv.pt] [--synthetic_fallback --orient_tvalue_gate 0.5 --grasp_tvalue_gate 0.28]
 """
 import argparse
@@ -516,10 +517,11 @@ def block_assembly(orient_path, grasp_path, insert_path, num_envs=512, games=0, 
 if __name__ == "__main__":
     p = argparse.ArgumentParser(description="scripts/evaluation.py of the reference: play the BlockAssembly sub-policies back to back")
     p.add_argument("--tasks", type=str, default="BlockAssembly")
-    p.add_argument("--mode", choices=["checkpoint", "chain"], default="checkpoint",
+    p.add_argument("--mode", choices=["checkpoint", "chain", "chain_learned"], default="checkpoint",
                    help="checkpoint: every stage restored from its rl_games .pth through the launcher and played for --games episodes "
                         "(evaluation.py:111-119; a stage without a checkpoint plays its random initialisation); chain: the device-tensor "
-                        "hand-off chain of block_assembly_chain with the harvest gates below")
+                        "hand-off chain of block_assembly_chain with the harvest gates below; chain_learned: block_assembly_chain_learned "
+                        "(trains the insert policy, the transition value and a grasp policy first: about a minute at 1 024 envs)")
     p.add_argument("--num_envs", type=int, default=512)
     for st_ in ("search", "orient", "grasp", "insert"):
         p.add_argument("--%s" % st_, "--%s_policy" % st_, dest=st_, type=str, default="", help="rl_games checkpoint (.pth) of the %s stage" % st_)
@@ -534,7 +536,12 @@ if __name__ == "__main__":
     a = p.parse_args()
     if a.tasks != "BlockAssembly":
         raise Exception("Unrecognized task!")                        # evaluation.py:121-129 (ToolPositioning: not built)
-    if a.mode == "checkpoint":
+    if a.mode == "chain_learned":
+        import json
+        res, h = block_assembly_chain_learned(a.num_envs)
+        h["insert_task"].sim.close()
+        print(json.dumps(res))
+    elif a.mode == "checkpoint":
         block_assembly(a.orient, a.grasp, a.insert, num_envs=a.num_envs, games=a.games, insert_minibatch=a.insert_minibatch,
                        search_path=a.search if (a.search or a.with_search) else None)
     else:
