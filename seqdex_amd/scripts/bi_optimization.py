@@ -99,8 +99,11 @@ def _handoff(report, name, tensor_or_none, fallback):
 
 
 def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, insert_minibatch=0, mixed_precision=False, report=None,
-                   stage_epochs=None, search_envs=128, orient_backward_envs=128, grasp_harvest_stand_in=False, gates=None, gates_after_fit=None):
+                   stage_epochs=None, search_envs=128, orient_backward_envs=128, grasp_harvest_stand_in=False, gates=None, gates_after_fit=None,
+                   grasp_minibatch=0):
     """insert_minibatch: override of the insert schedule's minibatch_size 4096 for runs with fewer than 512 envs.
+    grasp_minibatch: override of the grasp schedule's minibatch_size 4 (both GraspSim legs): on this engine the shipped 4-row minibatches
+    with the adaptive LR do not learn to lift within thousands of epochs, 2 048-row minibatches do within hundreds.
     stage_epochs: {"search" | "orient" | "grasp" | "insert": max_iterations} overriding `epochs` per task (an episode is 75 / 75 / 150 / 125
     env steps = 10 / 10 / 19 / 16 epochs of horizon 8: shorter runs finish no episode, harvest nothing and log no T-value outcome).
     (keys "<task>_backward" override the backward leg of a task.)
@@ -146,7 +149,8 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
         _handoff(report, "Orient -> GraspSim: pile terminal states [8, K, 132, 13]", piles, "GraspSim settles its own piles")
         orient.sim.close()
         paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, max_iterations=se("grasp"), policy_path=paths.get("grasp", ""),
-                                             tvalue_state=tv, keep=True, task_kwargs=dict(grasp_kw, initial_piles=piles), leg="forward", **mp)
+                                             tvalue_state=tv, keep=True, task_kwargs=dict(grasp_kw, initial_piles=piles), leg="forward",
+                                             minibatch_size=grasp_minibatch, **mp)
         cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
         harvest_by = "the trained grasp policy"
         if cnt.min() == 0 and grasp_harvest_stand_in:
@@ -185,7 +189,7 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
         orient_kw, grasp_kw = gate_kw()                                                   # a transition value may exist from here on
         paths["grasp"], grasp = main_rlgames("BlockAssemblyGraspSim", num_envs, use_t_value=True, policy_path=paths["grasp"],
                                              max_iterations=se("grasp_backward"), tvalue_state=tv, keep=True,
-                                             task_kwargs=dict(grasp_kw, initial_piles=piles), leg="backward", **mp)
+                                             task_kwargs=dict(grasp_kw, initial_piles=piles), leg="backward", minibatch_size=grasp_minibatch, **mp)
         outcomes_by = "the fine-tuned grasp policy"
         if grasp_harvest_stand_in and int(grasp.sim.TV_COUNT[0]) <= 100:
             scripted_episodes(grasp)
@@ -213,17 +217,23 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
 # (InsertSim's update is GEMM-shaped - 50 ms per epoch at 4096 envs - so three episodes cost 2.5 s; an insert policy of that age inserts
 # nothing yet, and 300 epochs from scripted-grasp states gave 10 insertions in 1.2 M episodes: the first refit is skipped, with its reason)
 CONFIG5_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 48, "insert_backward": 32}
+# round 5: the grasp stage long enough, and on minibatches large enough, for the policy to LEARN to lift: its own
+# terminal states go to InsertSim and its own outcomes to the transition-value fit - no scripted stand-in
+CONFIG5_LEARNED_EPOCHS = dict(CONFIG5_EPOCHS, grasp=400, grasp_backward=100)
+CONFIG5_GRASP_MINIBATCH = 2048
 
 
-def one_round_at_size(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=300, workdir=None):
+def one_round_at_size(num_envs=4096, mixed_precision=True, stage_epochs=None, tvalue_rollout=300, workdir=None, grasp_minibatch=0):
     """BASELINE.json configs[4] on ONE GPU: one round of block_assembly() at `num_envs` envs (Search and the backward Orient leg at the
     reference's 128, bi_optimization.py:111,124) with `mixed_precision` in every stage's PPO YAML and each task's shipped minibatch size;
     epochs per stage long enough for episodes to finish (CONFIG5_EPOCHS).  Returns (report dict with per-stage rates and every hand-off,
     checkpoint paths, fitted transition value or None).  tools/bench_config5.py is its command line, tests/test_gpu_bi_optimization_fullsize.py
-    its test; what is a stand-in is listed in the report (`stand_ins`)."""
+    its test; what is a stand-in is listed in the report (`stand_ins`).
+    grasp_minibatch > 0 (CONFIG5_GRASP_MINIBATCH): the GraspSim legs train on minibatches of that size for CONFIG5_LEARNED_EPOCHS; the
+    scripted stand-in stays armed but is reported only when it had to play."""
     import tempfile
     import time
-    stage_epochs = dict(CONFIG5_EPOCHS, **(stage_epochs or {}))
+    stage_epochs = dict(CONFIG5_LEARNED_EPOCHS if grasp_minibatch else CONFIG5_EPOCHS, **(stage_epochs or {}))
     cwd = os.getcwd()
     tmp = workdir or tempfile.mkdtemp(prefix="sdx_config5_")     # logs/<task>/nn/<task>.pth checkpoints are hand-offs inside the run
     os.chdir(tmp)
@@ -233,7 +243,7 @@ def one_round_at_size(num_envs=4096, mixed_precision=True, stage_epochs=None, tv
     try:
         paths, tv = block_assembly(rounds=1, num_envs=num_envs, tvalue_rollout=tvalue_rollout, mixed_precision=mixed_precision, report=report,
                                    stage_epochs=stage_epochs, grasp_harvest_stand_in=True, gates={"orient": 0.0, "grasp": 0.0},
-                                   gates_after_fit={"orient": 0.5, "grasp": 0.28})
+                                   gates_after_fit={"orient": 0.5, "grasp": 0.28}, grasp_minibatch=grasp_minibatch)
     finally:
         os.chdir(cwd)
     torch.cuda.synchronize()
@@ -244,8 +254,9 @@ def one_round_at_size(num_envs=4096, mixed_precision=True, stage_epochs=None, tv
     steps = sum(r["env_steps"] for r in runs)
     train_s = sum(r["wall_s"] for r in runs)
     out = {"config": "BASELINE.json configs[4] on one GPU: bi-optimisation loop Search -> Orient -> GraspSim -> InsertSim + three backward legs, "
-                     "num_envs=%d (Search 128, backward Orient 128), %s, shipped minibatch sizes" % (num_envs, "mixed_precision: True (bf16 MFMA on "
-                     "GEMM-shaped updates)" if mixed_precision else "fp32"),
+                     "num_envs=%d (Search 128, backward Orient 128), %s, %s" % (num_envs, "mixed_precision: True (bf16 MFMA on "
+                     "GEMM-shaped updates)" if mixed_precision else "fp32", "shipped minibatch sizes" if not grasp_minibatch else
+                     "shipped minibatch sizes except GraspSim's: %d instead of 4 (DESIGN.md section 17)" % grasp_minibatch),
            "metric": "env-steps/s over the seven training runs of one round (rollout + PPO update; task construction and T-value fits excluded)",
            "value": steps / train_s, "unit": "env-steps/s", "env_steps": steps, "training_wall_s": train_s, "loop_wall_s_incl_setup_and_fits": wall,
            "n_gpus": 1, "configs4_on_8_gpus": "not run: no multi-GPU box has ever been available to this build (gpurun: 1 GPU)",
@@ -253,7 +264,8 @@ def one_round_at_size(num_envs=4096, mixed_precision=True, stage_epochs=None, tv
            "stand_ins": ["harvest gates 0.0 in the forward pass of this first round: no transition value has been fitted before it; 0.5 / 0.28 "
                          "(not the reference's 0.99 / 0.8) in the backward legs",
                          "grasp terminal states, and the successes of the backward grasp leg's fit, from evaluation.scripted_grasp_controller on the "
-                         "trained task when the 20-epoch policy produced (almost) none"],
+                         "trained task when the %d-epoch policy produced (almost) none: %s" % (stage_epochs["grasp"], "; ".join(
+                             "%s = %s" % (k, h[k]) for h in hand for k in ("harvested_by", "outcomes_by") if k in h))],
            "runs": runs, "handoffs": hand, "checkpoints": paths, "tvalue_fitted": tv is not None}
     return out, paths, tv
 
@@ -268,7 +280,9 @@ if __name__ == "__main__":
     p.add_argument("--epochs", type=int, default=0, help="max_iterations of every training run (0 = the YAML's max_epochs)")
     p.add_argument("--tvalue_rollout", type=int, default=10000)
     p.add_argument("--mixed_precision", action="store_true", help="rl_games' mixed_precision key for every stage (bf16 MFMA on GEMM-shaped updates)")
+    p.add_argument("--grasp_minibatch", type=int, default=0, help="minibatch_size of the GraspSim legs instead of the shipped 4 (2048 learns to lift "
+                   "on this engine, the shipped 4 does not: DESIGN.md section 17)")
     a = p.parse_args()
     if a.tasks != "BlockAssembly":
         raise Exception("Unrecognized task!")                                           # bi_optimization.py:141-143 (ToolPositioning: not built)
-    block_assembly(a.rounds, a.num_envs, a.epochs, a.tvalue_rollout, mixed_precision=a.mixed_precision)
+    block_assembly(a.rounds, a.num_envs, a.epochs, a.tvalue_rollout, mixed_precision=a.mixed_precision, grasp_minibatch=a.grasp_minibatch)

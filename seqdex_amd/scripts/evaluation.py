@@ -239,7 +239,7 @@ def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_M
     return path, task, st
 
 
-def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None, grasp_states=None):
+def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None, grasp_states=None, restore="", synthetic_fallback=False, fit=True):
     """stage 0 of the chain (untimed; the backward pass of scripts/bi_optimization.py:120-121 in small): BlockAssemblyInsertSim trains
     `epochs` epochs with its shipped schedule from synthetic grasp states (or, grasp_states given, from grasp terminal states a grasp
     policy harvested), its episode outcomes fill the T-value rings, GraspInsertTValue
@@ -247,6 +247,9 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to
     Deterministic run to run: torch's global generator is seeded like the launcher does (it feeds VecTask.reset()'s noise step), training
     is (fixed-order reductions, counter-based noise) and the fit reads the outcome rings in serial (step, env) order (SdxSim.ring_rows),
     not in the order the slots were claimed in.
+    restore: an insert checkpoint to go on from (the forward leg of a later bi-optimisation round: the policy that learned on synthetic
+    states is fine-tuned on the states a grasp policy harvested); synthetic_fallback: brick-type groups without a harvested state start from
+    synthetic states (named in the statistics); fit=False: no transition-value fit (returns None for it).
     Returns (flat T-value weights or None, insert checkpoint path or "", statistics)."""
     from ..tasks.block_assembly_insert_sim import BlockAssemblyInsertSim
     from ..tvalue_trainer import TValue_Trainer, flat_from_state_dict
@@ -254,21 +257,33 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to
     cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG["BlockAssemblyInsertSim"])))
     cfg["env"]["numEnvs"] = n
     tr = yaml.safe_load(open(os.path.join(ROOT, TRAIN_CFG["BlockAssemblyInsertSim"])))
-    task = BlockAssemblyInsertSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed, grasp_states=grasp_states)
+    task = BlockAssemblyInsertSim(cfg, device_type="cuda", device_id=0, headless=True, seed=seed, grasp_states=grasp_states,
+                                  synthetic_fallback=synthetic_fallback)
     env = RLgamesVecTaskPython(task, "cuda:0")
     tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=seed)
     agent = A2CAgent("run", tr["params"])
+    if restore:
+        agent.restore(restore)
+        agent.epoch_num = 0
     t0 = time.time()
     for _ in range(epochs):
         agent.train_epoch()
     torch.cuda.synchronize()
-    st = {"epochs": epochs, "wall_s": time.time() - t0, "game_reward": agent.game_rewards.get_mean()[0], "grasp_states": task.grasp_states_source,
-          "outcomes_logged(success, failure)": task.sim.TV_COUNT.cpu().tolist(), "insert_success_buf_mean": float(task.extras["success_buf"].float().mean())}
+    sb = task.extras["success_buf"].float()
+    real = torch.tensor([(e % 8) not in task.synthetic_groups for e in range(n)], device=sb.device)
+    st = {"epochs": epochs, "wall_s": time.time() - t0, "game_reward": float(agent.game_rewards.get_mean()[0]), "grasp_states": task.grasp_states_source,
+          "restored_from": restore or None, "outcomes_logged(success, failure)": task.sim.TV_COUNT.cpu().tolist(),
+          "insert_success_buf_mean": float(sb.mean()),
+          "insert_success_buf_mean_of_the_groups_with_given_states": float(sb[real].mean()) if bool(real.any()) else None}
     path = ""
     if save_to:
         agent.save(save_to)
         path = save_to + ".pth"
     tv = None
+    if not fit:
+        agent.ppo.close()
+        task.sim.close()
+        return None, path, st
     try:
         trn = TValue_Trainer.from_task(task, seed=seed)
         trn.init_TValue_function("BlockAssemblyInsertSim", fit_iters)
@@ -431,13 +446,18 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
 CHAIN_LEARNED_ORIENT_GATES = (0.99, 0.9, 0.8, 0.5, 0.3, 0.0)     # starts at the reference's threshold (OR:1203)
 
 
-def block_assembly_chain_learned(num_envs=1024, grasp_epochs=1500, insert_epochs=1500, seed=22, workdir=None, min_grasp_states=1, max_grasp_steps=16000):
+def block_assembly_chain_learned(num_envs=1024, grasp_epochs=1500, insert_epochs=1500, seed=22, workdir=None, min_grasp_states=1, max_grasp_steps=16000,
+                                 insert_refit_epochs=1500):
     """BASELINE.json configs[2] on LEARNED policies (round 5) - no scripted stage, no synthetic grasp states:
       stage 0  BlockAssemblyInsertSim trains `insert_epochs` epochs with its shipped schedule from synthetic grasp states (the backward leg of
                bi_optimization.py:120-121 in small); GraspInsertTValue is fitted to its episode outcomes (thousands of successes since the
                studs engage) -> the transition value of the gates and the insert policy of the last stage;
       stage g  a BlockAssemblyGraspSim policy of this engine is trained `grasp_epochs` epochs (minibatch 2 048) with that transition value
                gating its harvest at the reference's 0.8 (GS:1406);
+      stage r  (insert_refit_epochs > 0; the forward leg of the next bi-optimisation round, bi_optimization.py:115-118) the grasp policy is
+               played from settled piles under the same gate, and the insert policy of stage 0 is fine-tuned on the states it harvested
+               (brick-type groups without one keep synthetic states, named): a policy that has only seen synthetic hand poses inserts
+               from 0.3 % of the learned grasp states, the fine-tuned one from several per cent;
       chain    Orient (random-initialised policy - its arm is scripted by the task - under a ladder of gates that starts at the reference's 0.99;
                the rung used is reported; a group it harvests nothing for starts GraspSim from settled piles, named in the statistics) ->
                GraspSim (the learned policy, gate 0.8, played until every brick-type group has `min_grasp_states` harvested states) ->
@@ -450,10 +470,24 @@ def block_assembly_chain_learned(num_envs=1024, grasp_epochs=1500, insert_epochs
         raise RuntimeError("stage 0 logged too few insert outcomes of a class for a transition value: %s" % ist)
     gpath, gtask, gst = train_grasp_policy(num_envs, grasp_epochs, seed=seed, save_to=os.path.join(workdir, "grasp"), tvalue_state=tv)
     gtask.sim.close()
+    rst = None
+    if insert_refit_epochs > 0:
+        g0, st0 = main_rlgames("BlockAssemblyGraspSim", num_envs, policy_path=gpath, tvalue_state=tv, steps=160, seed=seed + 1,
+                               until=lambda t: int(t.sim.HARVEST_COUNT.min()) >= 64, max_steps=max_grasp_steps, task_kwargs={"harvest_tvalue_gate": 0.8})
+        cnt0 = g0.sim.HARVEST_COUNT.cpu().tolist()
+        if max(cnt0) > 0:
+            s0 = g0.grasp_terminal_states()
+            g0.sim.close()
+            _, ipath, rst = prepare_tvalue_and_insert_policy(num_envs, insert_refit_epochs, seed=seed, save_to=os.path.join(workdir, "insert_refit"),
+                                                             grasp_states=s0, restore=ipath, synthetic_fallback=True, fit=False)
+            rst["grasp_states_harvested_per_type(settled piles, gate 0.8, %d steps per env)" % st0["steps_per_env"]] = cnt0
+        else:
+            g0.sim.close()
+            rst = {"skipped": "the grasp policy harvested no state under gate 0.8 in %d steps per env" % st0["steps_per_env"]}
     res, hand = block_assembly_chain(num_envs, tv, policies={"grasp": gpath, "insert": ipath}, synthetic_fallback=False, orient_fallback=True,
                                      orient_tvalue_gate=CHAIN_LEARNED_ORIENT_GATES, grasp_tvalue_gate=0.8, stage_steps={"grasp": 160},
                                      min_grasp_states=min_grasp_states, max_grasp_steps=max_grasp_steps, seed=seed)
-    out = {"stage0_insert_policy_and_tvalue(untimed)": ist, "grasp_policy(untimed)": gst, "chain": res,
+    out = {"stage0_insert_policy_and_tvalue(untimed)": ist, "grasp_policy(untimed)": gst, "insert_policy_refit(untimed)": rst, "chain": res,
            "stand_ins": ["Orient plays its random initialisation under T-value gate %s (reference: a trained Orient policy under 0.99)" % res["orient"]["tvalue_gate"]]
            + (["settled piles for Orient's brick-type groups %s" % res["orient"]["settled_stand_in_groups"]] if res["orient"].get("settled_stand_in_groups") else [])}
     return out, hand

@@ -38,8 +38,10 @@ if __name__ == "__main__":
     ap.add_argument("--num_envs", type=int, default=4096)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--out", default="")
+    ap.add_argument("--grasp_minibatch", type=int, default=0, help="GraspSim legs on minibatches of this size for CONFIG5_LEARNED_EPOCHS (2048: the "
+                    "policy learns to lift and no scripted stand-in plays; 0 = the shipped 4 and 20 epochs)")
     a = ap.parse_args()
-    res, _, _ = run(a.num_envs, not a.fp32)
+    res, _, _ = run(a.num_envs, not a.fp32, grasp_minibatch=a.grasp_minibatch)
     print(json.dumps(res), flush=True)
     if a.out:
         with open(a.out, "w") as fh:
