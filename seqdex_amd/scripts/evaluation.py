@@ -239,7 +239,7 @@ def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_M
     return path, task, st
 
 
-def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=3000, seed=22, save_to=None, grasp_states=None, restore="", synthetic_fallback=False, fit=True):
+def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=10000, seed=22, save_to=None, grasp_states=None, restore="", synthetic_fallback=False, fit=True):
     """stage 0 of the chain (untimed; the backward pass of scripts/bi_optimization.py:120-121 in small): BlockAssemblyInsertSim trains
     `epochs` epochs with its shipped schedule from synthetic grasp states (or, grasp_states given, from grasp terminal states a grasp
     policy harvested), its episode outcomes fill the T-value rings, GraspInsertTValue
