@@ -114,10 +114,46 @@ class A2CAgent:
             self._broadcast_parameters()
 
     # ------------------------------------------------------------------ multi-GPU (RCCL over xGMI)
-    def _broadcast_parameters(self):
+    def _collectives(self):
+        """the three collectives of the multi-rank path.  Backend "nccl" (RCCL) takes the library's device tensors as they are, on the current
+        stream.  Any other backend (gloo: the world-size-2 CPU tests, and two ranks SHARING one GPU - RCCL refuses two ranks on one device -
+        tests/test_gpu_two_ranks_one_gpu.py) gets them staged through the host: device -> host copy, collective, copy back (synchronous;
+        a validation path, never the measured one)."""
         import torch.distributed as dist
+        if getattr(self, "_coll", None) is None:
+            staged = dist.get_backend() != "nccl"
+
+            def all_reduce(t):
+                if staged and t.is_cuda:
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t)
+
+            def all_gather(out, inp):
+                if staged and inp.is_cuda:
+                    h = torch.empty(out.shape, dtype=out.dtype)
+                    dist.all_gather_into_tensor(h, inp.cpu())
+                    out.copy_(h)
+                else:
+                    dist.all_gather_into_tensor(out, inp)
+
+            def broadcast(t, src):
+                if staged and t.is_cuda:
+                    h = t.cpu()
+                    dist.broadcast(h, src)
+                    t.copy_(h)
+                else:
+                    dist.broadcast(t, src)
+
+            self._coll = type("Collectives", (), {"all_reduce": staticmethod(all_reduce), "all_gather": staticmethod(all_gather),
+                                                  "broadcast": staticmethod(broadcast), "host_staged": staged})
+        return self._coll
+
+    def _broadcast_parameters(self):
         for k in ("AC_PARAMS", "CV_PARAMS"):
-            dist.broadcast(self.ppo.t[k], 0)
+            self._collectives().broadcast(self.ppo.t[k], 0)
 
     # ------------------------------------------------------------------ rl_games-shaped API
     def set_eval(self):
@@ -183,8 +219,7 @@ class A2CAgent:
         st = ppo.t["STATS"]
         acc = st[self._stats_off["acc"]:self._stats_off["acc"] + 8].clone()    # per-minibatch sums of the HEAD kernel: [1]a [2]c [3]b [4]kl [6]entropy
         if self.multi_gpu and self.rank_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(ppo.t["ALL_GRADS"])
+            self._collectives().all_reduce(ppo.t["ALL_GRADS"])
             ppo.apply(0, float("-inf"))
         else:
             ppo.apply(0)
@@ -249,7 +284,7 @@ class A2CAgent:
         the scalar KL are summed over ranks with RCCL (torch.distributed backend "nccl") on the current stream; the
         division by world_size, clip_grad_norm_, Adam and the LR rule run in sdxp_apply (rl_games multi-GPU semantics,
         SURVEY.md App. C; PS:308-310)."""
-        import torch.distributed as dist
+        dist = self._collectives()
         ppo = self.ppo
         nmb = self.batch_size // self.minibatch_size
         if "FACTORS" in ppo.t and hasattr(ppo, "backward_factors") and self.minibatch_size <= 8:
@@ -260,7 +295,7 @@ class A2CAgent:
             def steps(k):
                 for _ in range(k):
                     ppo.backward_factors(0)          # the minibatch is the one under the DEVICE cursor; the argument is only range-checked
-                    dist.all_gather_into_tensor(fact_all, fact)
+                    dist.all_gather(fact_all, fact)
                     ppo.apply_factors()
 
             ppo.backward_factors(-1)
@@ -274,7 +309,7 @@ class A2CAgent:
             # default: on at world size 1 (where it is measured: 77.5 -> 70.4 us per step); at world size > 1 the capture contains a real
             # RCCL collective, which this build could never run (gpurun boxes have one GPU), so it is opt-in there: SDX_MULTI_RANK_GRAPH=1
             want = os.environ.get("SDX_MULTI_RANK_GRAPH", "1" if self.rank_size == 1 else "0") == "1"
-            if chunk and want and getattr(self, "_mr_graph", None) is not False:
+            if chunk and want and not dist.host_staged and getattr(self, "_mr_graph", None) is not False:
                 if getattr(self, "_mr_graph", None) is None:
                     steps(chunk)                     # eagerly once: communicator set-up, lazy module loads, function attributes
                     done = chunk
