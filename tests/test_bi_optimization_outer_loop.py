@@ -29,7 +29,8 @@ def _patch(monkeypatch, grasp_counts=(3, 1, 2, 5, 4, 1, 2, 6), fits=(False, True
     def fake_main(task, num_envs, use_t_value=False, policy_path="", max_iterations=0, task_kwargs=None, tvalue_state=None, keep=False,
                   minibatch_size=0, mixed_precision=False, report=None, leg=""):
         runs.append(dict(task=task, num_envs=num_envs, use_t_value=use_t_value, policy_path=policy_path, epochs=max_iterations,
-                         task_kwargs=dict(task_kwargs or {}), tvalue=tvalue_state, leg=leg, mixed_precision=mixed_precision))
+                         task_kwargs=dict(task_kwargs or {}), tvalue=tvalue_state, leg=leg, mixed_precision=mixed_precision,
+                         minibatch_size=minibatch_size))
         if report is not None:
             report.append({"leg": leg, "task": task, "num_envs": num_envs, "epochs": max_iterations})
         sim = _Sim(TV_COUNT=torch.tensor([150, 9000]), HARVEST_COUNT=torch.tensor(np.array(grasp_counts, dtype=np.int32)))
@@ -101,3 +102,15 @@ def test_a_grasp_stage_without_states_hands_none_on(monkeypatch):
     assert runs[3]["task_kwargs"]["grasp_states"] is None and runs[3]["task_kwargs"]["synthetic_fallback"] is False
     h = [r for r in report if "handoff" in r][2]
     assert h["empty"] and h["source"] == "InsertSim synthesises its start states"
+
+
+def test_grasp_minibatch_override_reaches_both_grasp_legs_and_nothing_else(monkeypatch):
+    """round 5: the GraspSim legs may train on larger minibatches than the shipped 4 (which do not learn on this engine, DESIGN.md section 17);
+    every other stage keeps its own schedule, and the per-stage epoch table takes "grasp_backward" for the backward leg"""
+    bo, runs, fits, *_ = _patch(monkeypatch)
+    bo.block_assembly(rounds=1, num_envs=4096, grasp_minibatch=bo.CONFIG5_GRASP_MINIBATCH, stage_epochs=bo.CONFIG5_LEARNED_EPOCHS)
+    assert [r["minibatch_size"] for r in runs] == [0, 0, 2048, 0, 0, 2048, 0]
+    assert [r["epochs"] for r in runs] == [20, 10, 400, 48, 32, 100, 10]
+    runs.clear()
+    bo.block_assembly(rounds=1, num_envs=4096, stage_epochs=bo.CONFIG5_EPOCHS)
+    assert [r["minibatch_size"] for r in runs] == [0] * 7 and [r["epochs"] for r in runs] == [20, 10, 20, 48, 32, 20, 10]
