@@ -192,13 +192,15 @@ def policy_lift_statistics(task, agent, steps=304):
             "per_type_held_5cm": [int(ok[ar % 8 == g].sum()) for g in range(8)]}
 
 
-def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_MINIBATCH, tvalue_state=None, initial_piles=None, piles_per_type=16, lift_statistics=False):
+def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_MINIBATCH, tvalue_state=None, initial_piles=None, piles_per_type=16, lift_statistics=False,
+                       restore=""):
     """A BlockAssemblyGraspSim policy of THIS engine (round 5; the reference's is its released 19 000-epoch checkpoint, README.md:90):
     `epochs` epochs at n envs, horizon 8, 5 mini-epochs, adaptive learning rate as shipped - but minibatches of 2 048 rows instead of the
     shipped 4, with which the shipped schedule does not leave reward 2 (profiles/r5_grasp_train_curve_shipped_minibatch4.txt); episode reward
     ~ 2 000 after 1 500 epochs = 30 s (the reference's checkpoint name says 1 531).  tvalue_state: the transition value that gates the
     harvest of grasp terminal states (GS:1404-1417; None: the gate is opened - what a forward leg of the bi-optimisation loop does before
-    any T-value exists).  Returns (checkpoint path or "", the task (caller closes task.sim; its rings hold the harvested states), statistics)."""
+    any T-value exists).  restore: a grasp checkpoint to go on from (a later round of the bi-optimisation loop fine-tunes the policy under the
+    refitted value).  Returns (checkpoint path or "", the task (caller closes task.sim; its rings hold the harvested states), statistics)."""
     from ..tasks.block_assembly_grasp_sim import BlockAssemblyGraspSim
     from ..tvalue_trainer import LAYERS
     set_seed(seed)
@@ -222,11 +224,14 @@ def train_grasp_policy(n, epochs, seed=22, save_to=None, minibatch=GRASP_TRAIN_M
     env = RLgamesVecTaskPython(task, "cuda:0")
     tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=seed)
     agent = A2CAgent("run", tr["params"])
+    if restore:
+        agent.restore(restore)
+        agent.epoch_num = 0
     t0 = time.time()
     for _ in range(epochs):
         agent.train_epoch()
     torch.cuda.synchronize()
-    st = {"epochs": epochs, "minibatch_size": minibatch, "wall_s": time.time() - t0, "game_reward": float(agent.game_rewards.get_mean()[0]),
+    st = {"epochs": epochs, "restored_from": restore or None, "minibatch_size": minibatch, "wall_s": time.time() - t0, "game_reward": float(agent.game_rewards.get_mean()[0]),
           "game_length": float(agent.game_lengths.get_mean()[0]), "grasp_states_harvested_per_type": task.sim.HARVEST_COUNT.cpu().tolist(),
           "tvalue_gate": "open" if tvalue_state is None else "given", "contact_stats": task.sim.CONTACT_STATS.cpu().tolist()}
     if lift_statistics:
