@@ -134,7 +134,11 @@ typedef enum {
                             *                    order a serial loop over steps and envs produces (what seqdex_amd.sim.ring_rows does) */
   SDX_T_HARVEST_KEYS = 47, /* i64 [8,SDX_HARVEST_SLOTS] the same for the grasp terminal-state rings */
   SDX_T_PILE_HARVEST_KEYS = 48, /* i64 [8,slots] the same for the pile rings of Orient / Search */
-  SDX_T_COUNT = 49
+  SDX_T_WARM_KEYS = 49,    /* i32 [N,1536]     diagnostic view of the warm-start cache: identity of each cached contact of the last solve (body-pair rank
+                            *                    13 bits | box pair 9 | direction 1 | sample 5, age in the 4 bits above), ascending; rows are valid up to
+                            *                    SDX_T_WARM_COUNT; [1] when scene.warm_start == 0 (the cold solver keeps no cache) */
+  SDX_T_WARM_LAMBDA = 50,  /* f32 [N,3,1536]   the accumulated impulses (normal, two tangents) of those contacts */
+  SDX_T_COUNT = 51
 } sdx_tensor_id;
 
 /* Compact scene constants (row A0/A1 of SURVEY.md §8(a)); produced by tools/compile_scene.py from the

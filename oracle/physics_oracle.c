@@ -395,6 +395,11 @@ static box_t static_sub(const sdx_scene_desc* sc, int s, int env_index, int k) {
  * pkey: the pair's part of the contact identity (enumeration index of the body pair << 15 | index of the box pair inside it << 6) - with
  * the direction bit and the sample index it identifies a contact from one solve to the next */
 #define MANIFOLD_EPS 1e-7f /* m^2: twice the area of the triangle (p1, p2, p) below which p counts as lying on the line p1 p2 */
+/* ties go to the first candidate in enumeration order: a later one replaces the incumbent only when it is better by more than these margins
+ * (p1's score in m; squared distance / line offset in m^2) - the samples of one box edge are equally far from a line parallel to it and
+ * coincident samples of the two directions score the same, so that rounding would decide otherwise */
+#define MANIFOLD_TIE_L 1e-6f
+#define MANIFOLD_TIE_A 1e-8f
 static void face_coords(const dir_t* D1, const box_t* B, int kref, int d, int s, real* a, real* b) {
   v3 p = d ? V(SAMP[s][0] * B->h.x, SAMP[s][1] * B->h.y, SAMP[s][2] * B->h.z) : sample_point(D1, s); /* the sample in B's frame */
   *a = kref == 0 ? p.y : p.x;
@@ -428,14 +433,14 @@ static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int 
       if ((face[id >> 5] >> (id & 31)) & 1u) {
         face_coords(&D1, B, kref, id >> 5, id & 31, &a, &b);
         real k = a + 0.1f * b;
-        if (k > best) { best = k; p1 = id; a1 = a; b1 = b; }
+        if (k > best + MANIFOLD_TIE_L) { best = k; p1 = id; a1 = a; b1 = b; }
       }
     best = 0.0f;
     for (int id = 0; id < 64; ++id)
       if ((face[id >> 5] >> (id & 31)) & 1u) {
         face_coords(&D1, B, kref, id >> 5, id & 31, &a, &b);
         real k = (a - a1) * (a - a1) + (b - b1) * (b - b1);
-        if (k > best) { best = k; p2 = id; a2 = a; b2 = b; }
+        if (k > best + MANIFOLD_TIE_A) { best = k; p2 = id; a2 = a; b2 = b; }
       }
     if (p2 >= 0) {
       real hi = MANIFOLD_EPS, lo = -MANIFOLD_EPS;
@@ -443,8 +448,8 @@ static void collide_pair(env_t* e, const box_t* A, const box_t* B, int ida, int 
         if ((face[id >> 5] >> (id & 31)) & 1u) {
           face_coords(&D1, B, kref, id >> 5, id & 31, &a, &b);
           real k = (a2 - a1) * (b - b1) - (b2 - b1) * (a - a1);
-          if (k > hi) { hi = k; p3 = id; }
-          if (k < lo) { lo = k; p4 = id; }
+          if (k > hi + MANIFOLD_TIE_A) { hi = k; p3 = id; }
+          if (k < lo - MANIFOLD_TIE_A) { lo = k; p4 = id; }
         }
     }
     int pk[4] = {p1, p2, p3, p4};

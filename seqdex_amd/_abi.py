@@ -81,7 +81,7 @@ T = dict(ROOT=0, DOF=1, RB=2, CONTACT=3, JAC_EEF=4, TARGETS=5, PREV_TARGETS=6, O
          STATES_CLAMPED=10, REW=11, RESET=12, PROGRESS=13, RANDOMIZE=14, ACTIONS=15, INIT_POS=16, INIT_ROT=17,
          SUCCESSES=18, META_REW=19, CONS_SUCCESSES=20, FINGER_DIST=21, TVALUE=22, ARM_CONTACTS=23, STUDENT_OBS=24,
          SUCCESS_BUF=25, PILE_CHOICE=26, NCONTACTS=27, DEBUG=28, HARVEST_HAND=29, HARVEST_OBJ=30,
-         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35, PILE_HARVEST=36, PILE_HARVEST_COUNT=37, SEG_IMAGE=38, SEG_PIXELS=39, EMERGENCE=40, JACOBIAN=41, TVALUE_OBS=42, CONTACT_STATS=43, WARM_COUNT=44, CAM_ROT=45, TV_KEYS=46, HARVEST_KEYS=47, PILE_HARVEST_KEYS=48)
+         HARVEST_COUNT=31, INSERT_AUX=32, TV_SUCCESS=33, TV_FAILURE=34, TV_COUNT=35, PILE_HARVEST=36, PILE_HARVEST_COUNT=37, SEG_IMAGE=38, SEG_PIXELS=39, EMERGENCE=40, JACOBIAN=41, TVALUE_OBS=42, CONTACT_STATS=43, WARM_COUNT=44, CAM_ROT=45, TV_KEYS=46, HARVEST_KEYS=47, PILE_HARVEST_KEYS=48, WARM_KEYS=49, WARM_LAMBDA=50)
 # sdxp_tensor_id
 TP = dict(AC_PARAMS=0, AC_GRADS=1, CV_PARAMS=2, CV_GRADS=3, MB_OBS=4, MB_STATES=5, MB_ACTIONS=6, MB_MUS=7,
           MB_SIGMAS=8, MB_NEGLOGP=9, MB_VALUES=10, MB_REWARDS=11, MB_DONES=12, RETURNS=13, ADVANTAGES=14,

@@ -240,6 +240,13 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_EMERGENCE, B.emergence, SDX_F32, {N});
   set_tensor(h, SDX_T_CONTACT_STATS, B.cstats, SDX_I32, {4});
   set_tensor(h, SDX_T_WARM_COUNT, B.wcount, SDX_I32, {N});
+  if (scene->warm_start > 0.0f) {
+    set_tensor(h, SDX_T_WARM_KEYS, B.wkey, SDX_I32, {N, SDX_MAXC});
+    set_tensor(h, SDX_T_WARM_LAMBDA, B.wlam, SDX_F32, {N, 3, SDX_MAXC});
+  } else {
+    set_tensor(h, SDX_T_WARM_KEYS, B.wkey, SDX_I32, {1});
+    set_tensor(h, SDX_T_WARM_LAMBDA, B.wlam, SDX_F32, {1});
+  }
   set_tensor(h, SDX_T_CAM_ROT, B.cam_rot, SDX_F32, {N, 4});
   set_tensor(h, SDX_T_JACOBIAN, B.jac_full, SDX_F32, {N, SDX_NLINK - 1, 6, SDX_NDOF});
   if (scene->task_kind == 3) set_tensor(h, SDX_T_TVALUE_OBS, B.tvt_buf, SDX_F32, {N, 652});

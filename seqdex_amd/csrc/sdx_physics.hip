@@ -307,10 +307,16 @@ __device__ __forceinline__ bool classify_dir(const PhysLds& S, const Box& A, con
 // The 4 slots of the pair.  Face samples first, chosen to SPAN the patch the boxes meet on: every face sample has lateral coordinates
 // (a, b) in B's frame (B's axes without the axis kref of direction 1's reference face; a sample of B: its own table entry x hB);
 // p1 = the sample furthest along (1, 0.1), p2 = the one furthest from p1, p3 / p4 = the ones furthest to the left / right of the line
-// p1 p2; ties: the first in enumeration order (direction 1 in table order, then direction 2).  Then the remaining face samples in that
+// p1 p2; ties: the first in enumeration order (direction 1 in table order, then direction 2) - a later candidate replaces the incumbent
+// only when it beats it by more than MANIFOLD_TIE_L (1 um, p1's score) / MANIFOLD_TIE_A (1e-8 m^2, squared distance and line offset): samples
+// of one box edge are all equally far from a line parallel to it, and coincident samples of the two directions score the same, so that
+// without the margin rounding decides (seen on the device: one such pair per 8 golden envs chose another sample than the oracle, and
+// 16 Jacobi iterations spread that over eight bricks).  Then the remaining face samples in that
 // order, then the other samples (edge / corner regions, speculative contacts) the same way.  Returns the number of contacts; sel1 / sel2:
 // the chosen samples of the two directions.
 #define MANIFOLD_EPS 1e-7f
+#define MANIFOLD_TIE_L 1e-6f
+#define MANIFOLD_TIE_A 1e-8f
 __device__ __forceinline__ int pair_contacts(const PhysLds& S, const Box& A, const Box& B, bool second, float off, float incl, uint32_t* sel1, uint32_t* sel2) {
   uint32_t f1 = 0, o1 = 0, f2 = 0, o2 = 0;
   int kref = 2;
@@ -341,7 +347,7 @@ __device__ __forceinline__ int pair_contacts(const PhysLds& S, const Box& A, con
       float a, b;
       SDX_COORDS(id, a, b)
       const float k = a + 0.1f * b;
-      if (k > best) { best = k; p1 = id; a1 = a; b1 = b; }
+      if (k > best + MANIFOLD_TIE_L) { best = k; p1 = id; a1 = a; b1 = b; }
     }
     best = 0.0f;
     m = fm;
@@ -352,7 +358,7 @@ __device__ __forceinline__ int pair_contacts(const PhysLds& S, const Box& A, con
       float a, b;
       SDX_COORDS(id, a, b)
       const float k = (a - a1) * (a - a1) + (b - b1) * (b - b1);
-      if (k > best) { best = k; p2 = id; a2 = a; b2 = b; }
+      if (k > best + MANIFOLD_TIE_A) { best = k; p2 = id; a2 = a; b2 = b; }
     }
     if (p2 >= 0) {
       float hi = MANIFOLD_EPS, lo = -MANIFOLD_EPS;
@@ -364,8 +370,8 @@ __device__ __forceinline__ int pair_contacts(const PhysLds& S, const Box& A, con
         float a, b;
         SDX_COORDS(id, a, b)
         const float k = (a2 - a1) * (b - b1) - (b2 - b1) * (a - a1);
-        if (k > hi) { hi = k; p3 = id; }
-        if (k < lo) { lo = k; p4 = id; }
+        if (k > hi + MANIFOLD_TIE_A) { hi = k; p3 = id; }
+        if (k < lo - MANIFOLD_TIE_A) { lo = k; p4 = id; }
       }
     }
 #undef SDX_COORDS

@@ -54,8 +54,9 @@ def _one_step(s, root, dof, targets):
 def test_one_step_teacher_forcing(state, scene, warm_start):
     """same start state, one simulate() on each side.  Contact-rich piles amplify fp32 rounding through the
     discrete contact set (and, since the face manifold of DESIGN.md section 3.D, through its separating-axis choice), so the bar is: identical
-    contact counts, robot pose to 1e-4 (velocities 5e-4 / 1e-3), brick poses to 2e-5 m for >= 97% and brick velocities to 2e-3 m/s for
-    >= 96% of the bricks (rounds 1-4, one box per brick and the table-order manifold: 99% / 98%), no brick further than 5 mm off."""
+    contact counts, robot pose to 1e-4 (velocities 5e-4 / 1e-3), brick poses to 2e-5 m for >= 99% and brick velocities to 2e-3 m/s for
+    >= 98% of the bricks, at most 2 bricks further than 1e-4 m off and none further than 1 mm (measured over 16 steps: 99.6 - 100 % within
+    2e-5 m, identical contact sets, one step in which a sample on the contact offset fell on the other side: 1 brick 0.12 mm off)."""
     from seqdex_amd.sim import SdxSim
     n = state["root"].shape[0]
     s = SdxSim(n, warm_start=warm_start)      # default: cold solver; 0.8: the optional warm start of DESIGN.md section 3.E
@@ -77,14 +78,15 @@ def test_one_step_teacher_forcing(state, scene, warm_start):
             np.testing.assert_allclose(g_rb[:, :24, 7:], o_rb[:, :24, 7:], rtol=1e-3, atol=4e-3)    # link twists (fingertips sum the joint velocity differences)
             np.testing.assert_allclose(g_jac, o_jac, rtol=1e-4, atol=1e-4)
             dp = np.abs(g_root[:, 9:81, 0:7] - o_root[:, 9:81, 0:7]).max(-1)       # a brick whose velocity differs by 4e-3 m/s is 3e-5 m off
-            # since round 5 a convex pair of compounds contributes the box pair with the smallest separation bound, and the manifold the
-            # face samples that span the contact patch: more discrete choices than the table-order manifold of rounds 2-4, and the 16 Jacobi
-            # iterations of a jammed pile amplify whatever fma rounding changes (tests/test_hipemu_physics.py: the same kernel source with
-            # the oracle's rounding agrees to 2e-5 on every brick).  Bar: 97 % of the 576 bricks within 2e-5 m (97.4 % measured), at most 12
-            # beyond 1e-4, none beyond 5 mm
-            assert (dp >= 1e-4).sum() <= 12 and dp.max() < 5e-3 and (dp < 2e-5).mean() >= 0.97, (float(dp.max()), float((dp < 2e-5).mean()), int((dp >= 1e-4).sum()))
+            # round 5: a convex pair of compounds contributes the box pair with the smallest separation bound, and the manifold the face
+            # samples that span the contact patch.  The first version of that rule broke ties by strict comparison: one box pair in the 8
+            # golden envs (two samples of one box edge, equally far from the line p1 p2) chose another sample on the device than in the
+            # oracle and 16 Jacobi iterations spread it over eight bricks, up to 1.9 mm (tests/helpers/parity_keys.py lists the differing
+            # contacts).  With the tie margins of the rule (a later candidate must win by 1 um / 1e-8 m^2) the contact SETS of device and
+            # oracle are identical and the bar is back near rounds 1-4's: 99 % of the 576 bricks within 2e-5 m, at most 2 beyond 1e-4, none beyond 1 mm
+            assert (dp >= 1e-4).sum() <= 2 and dp.max() < 1e-3 and (dp < 2e-5).mean() >= 0.99, (float(dp.max()), float((dp < 2e-5).mean()), int((dp >= 1e-4).sum()))
             dv = np.abs(g_root[:, 9:81, 7:13] - o_root[:, 9:81, 7:13]).max(-1)
-            assert (dv < 2e-3).mean() >= 0.96, float((dv < 2e-3).mean())
+            assert (dv < 2e-3).mean() >= 0.98, float((dv < 2e-3).mean())
             np.testing.assert_allclose(g_contact[:, :24], o_contact[:, :24], rtol=5e-3, atol=5e-2)
             np.testing.assert_array_equal(g_root[:, 81:141], root[:, 81:141])     # fixed bricks untouched
             root, dof = o_root, o_dof                                              # teacher forcing
