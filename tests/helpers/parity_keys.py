@@ -14,42 +14,7 @@ sys.path.insert(0, ROOT)
 from oracle import physics_oracle as po  # noqa: E402
 from seqdex_amd.sim import SdxSim  # noqa: E402
 
-NF, NSMAX, NT = 72, 8, 512
-N2 = NF * (NF - 1) // 2
-
-
-def tri(idx):      # idx -> (i, j), j <= i, row-major lower triangle
-    i = int((np.sqrt(8.0 * idx + 1.0) - 1.0) * 0.5)
-    while i * (i + 1) // 2 > idx:
-        i -= 1
-    while (i + 1) * (i + 2) // 2 <= idx:
-        i += 1
-    return i, idx - i * (i + 1) // 2
-
-
-def pair_of_enumeration(e, ns):
-    n1, per = NF * ns, NF + ns
-    if e < n1:
-        return ("brick", e // ns), ("static", e % ns)
-    if e < n1 + N2:
-        i, j = tri(e - n1)
-        return ("brick", j), ("brick", i + 1)
-    t = e - n1 - N2
-    r, u = t // per, t % per
-    return ("rbox", r), (("brick", u) if u < NF else ("static", u - NF))
-
-
-def decode_gpu(key):
-    k = int(key) & 0x0fffffff
-    rank, bp, d, smp = k >> 15, (k >> 6) & 0x1ff, (k >> 5) & 1, k & 31
-    tid, it = rank // 16, rank % 16
-    return pair_of_enumeration(it * NT + tid, NSMAX) + (bp, d, smp)
-
-
-def decode_oracle(key, ns):
-    k = int(key) & 0x0fffffff
-    return pair_of_enumeration(k >> 15, ns) + ((k >> 6) & 0x1ff, (k >> 5) & 1, k & 31)
-
+from tests.helpers.contact_keys import decode_kernel as decode_gpu, decode_oracle  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 state = np.load(os.path.join(ROOT, "tests", "golden", "P1_settled_state.npz"))
