@@ -452,7 +452,7 @@ CHAIN_LEARNED_ORIENT_GATES = (0.99, 0.9, 0.8, 0.5, 0.3, 0.0)     # starts at the
 
 
 def block_assembly_chain_learned(num_envs=1024, grasp_epochs=1500, insert_epochs=1500, seed=22, workdir=None, min_grasp_states=1, max_grasp_steps=16000,
-                                 insert_refit_epochs=1500):
+                                 insert_refit_epochs=4000):
     """BASELINE.json configs[2] on LEARNED policies (round 5) - no scripted stage, no synthetic grasp states:
       stage 0  BlockAssemblyInsertSim trains `insert_epochs` epochs with its shipped schedule from synthetic grasp states (the backward leg of
                bi_optimization.py:120-121 in small); GraspInsertTValue is fitted to its episode outcomes (thousands of successes since the

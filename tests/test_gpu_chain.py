@@ -14,7 +14,7 @@ N = 1024
 def test_chain_hand_offs_at_1024_envs():
     """round 5: the chain on LEARNED grasp and insert policies - no scripted grasp stage, no synthetic grasp states.
     Stage 0 trains the insert policy (1 500 epochs, 31 s) and fits the transition value to its outcomes; a GraspSim policy is trained
-    (1 500 epochs of 2 048-row minibatches, 31 s) under that value's gate; the insert policy is fine-tuned (1 500 epochs, 30 s) on states that
+    (1 500 epochs of 2 048-row minibatches, 31 s) under that value's gate; the insert policy is fine-tuned (4 000 epochs, 81 s) on states that
     grasp policy harvested from settled piles (the forward leg of the next bi-optimisation round); then Orient -> GraspSim -> InsertSim are played
     (evaluation.py::block_assembly_chain_learned).  GraspSim harvests under the reference's gate 0.8 (GS:1406); Orient plays its random
     initialisation under a ladder that starts at the reference's 0.99 (OR:1203) - the rung used is in the statistics."""
@@ -29,8 +29,9 @@ def test_chain_hand_offs_at_1024_envs():
         rf = out["insert_policy_refit(untimed)"]
         # fine-tuned on learned grasp states: the policy learns to keep hold of a brick it did not pinch itself and to carry it to the site
         # (episode reward 12 - 35; the policy that only knew synthetic hand poses: 0.05, it opens the hand and the episode ends after 4 steps)
-        # and inserts in SOME episodes - how many is not stable: 13.8 % and 0.8 % of the last episodes in two builds of the library that
-        # differ in a tie rule of the contact manifold
+        # and inserts in some episodes - how many depends on the build and on the training length: after 1 500 epochs 13.8 % and 0.8 % of the
+        # last episodes in two builds of the library that differ in a tie rule of the contact manifold, after 4 000 (the default) 10.9 % in the
+        # closing build
         assert rf["restored_from"] and rf["game_reward"] > 3.0 and rf["outcomes_logged(success, failure)"][0] > 200, rf
         # ---- hand-off 1: Orient harvested >= 8 piles for (nearly) every brick-type group, and GraspSim started from them
         # (at most two groups may have fallen back to settled piles when this run's T-value fit missed their orientations; the statistics name them)
@@ -68,7 +69,7 @@ def test_chain_hand_offs_at_1024_envs():
             checked += 1
         assert checked == N
         assert res["chain_env_steps_per_s"] > 0 and res["insert"]["steps_per_env"] >= 125
-        # (the share of the chain's InsertSim episodes that insert is reported, not asserted: 16.9 % and 0.3 % in the two builds above)
+        # (the share of the chain's InsertSim episodes that insert is reported, not asserted: 4.3 % in the closing build)
         print("chain: InsertSim episodes that insert: %.4f; insert policy fine-tuned to %.4f" % (res["insert"]["success_buf_mean"], rf["insert_success_buf_mean"]))
     finally:
         ins.sim.close()

@@ -1,7 +1,7 @@
 """BASELINE.json configs[2] on LEARNED policies (seqdex_amd/scripts/evaluation.py::block_assembly_chain_learned): insert
 policy + transition value from stage 0, a GraspSim policy of this engine trained under that transition value's gate, then Orient ->
 GraspSim -> InsertSim with no scripted stage and no synthetic grasp states.  Prints one JSON line.
-usage: python tools/chain_learned.py [N] [grasp_epochs] [insert_epochs] [--out file]"""
+usage: python tools/chain_learned.py [N] [grasp_epochs] [insert_epochs] [--refit insert_refit_epochs] [--out file]"""
 import json
 import os
 import sys
@@ -12,12 +12,13 @@ sys.path.insert(0, ROOT)
 from seqdex_amd.scripts.evaluation import block_assembly_chain_learned  # noqa: E402
 
 if __name__ == "__main__":
-    pos = [a for a in sys.argv[1:] if a.isdigit()]
+    pos = [a for i, a in enumerate(sys.argv[1:], 1) if a.isdigit() and sys.argv[i - 1] not in ("--refit", "--out")]
     n = int(pos[0]) if len(pos) > 0 else 1024
     ge = int(pos[1]) if len(pos) > 1 else 1500
     ie = int(pos[2]) if len(pos) > 2 else 1500
     t0 = time.time()
-    out, hand = block_assembly_chain_learned(n, ge, ie)
+    refit = int(sys.argv[sys.argv.index("--refit") + 1]) if "--refit" in sys.argv else 1500
+    out, hand = block_assembly_chain_learned(n, ge, ie, insert_refit_epochs=refit)
     ins = hand["insert_task"]
     out["chain"]["insert"]["synthetic_groups"] = ins.synthetic_groups
     out["chain"]["insert"]["insert_success_buf_mean"] = float(ins.extras["success_buf"].float().mean())
