@@ -6,7 +6,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import physics_oracle as po  # noqa: E402
 from seqdex_amd.scene import load_scene  # noqa: E402
 
@@ -49,6 +49,6 @@ for step in range(60):
     rb, contact, jac, nc = po.simulate(d, root, dof, tg2)
 print("link7", rb[:, 7, :3])
 print("contacts", nc, "arm contact |f|", np.linalg.norm(contact[:, 1:24], axis=-1).max(axis=1))
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "P1_settled_state.npz")
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden", "P1_settled_state.npz")
 np.savez_compressed(out, root=root, dof=dof, targets=tg2)
 print("wrote", out, os.path.getsize(out))

@@ -1,6 +1,6 @@
 """resting penetration of settled piles at scale: N envs dropped as in tools/drop_bricks.py, then the contact list of sampled envs (the
 oracle's collide() on the device state: TEST/DIAGNOSTIC use of the oracle) -> distribution of the separations.
-python tools/pile_penetration.py N steps variant..."""
+python tests/helpers/pile_penetration.py N steps variant..."""
 import json
 import os
 import sys
@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import physics_oracle as po  # noqa: E402
 from seqdex_amd.sim import SdxSim  # noqa: E402
