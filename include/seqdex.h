@@ -226,7 +226,8 @@ typedef struct {
   float warm_start;                    /* every solve starts from this fraction of the impulses the same contacts
                                         * (pair, direction, sample) ended the previous solve with; 0 = start from zero */
   float warm_age;                      /* the fraction ramps up linearly with the number of consecutive solves a contact has existed and
-                                        * reaches warm_start after warm_age of them (0: no ramp); DESIGN.md section 3.E */
+                                        * reaches warm_start after warm_age of them (0: no ramp; at most 16: the age is a 4-bit saturating counter, sdx_create
+                                        * rejects larger values); DESIGN.md section 3.E */
   float robot_angular_damping;         /* asset_options.angular_damping of the arm-hand asset (GS:546: 0.01 1/s): every substep scales the joint
                                         * velocities by (1 - h x damping) - for a chain of revolute joints the joint-space image of PhysX's
                                         * per-link angular damping */

@@ -95,6 +95,8 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
     if (scene->static_var_slot >= ns) ok = false;
     for (int k = 0; ok && scene->static_var_slot >= 0 && k < 3; ++k) ok = scene->static_var_row[k] >= 0 && scene->static_var_row[k] < SDX_MAX_STATIC_TAB;
     if (!ok) { g_create_err = "sdx_create: scene shape tables out of range (n_static, n_rbox, brick / static compounds)"; return SDX_ERR_INVALID; }
+    // the warm start's contact age is a 4-bit saturating counter in the cache key (k_physics solve()): a ramp longer than 16 solves would never end
+    if (!(scene->warm_age >= 0.0f && scene->warm_age <= 16.0f)) { g_create_err = "sdx_create: warm_age must lie in [0, 16] (the contact age saturates at 16 solves)"; return SDX_ERR_INVALID; }
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {

@@ -120,11 +120,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lq_rsrc(void* ll) { return __b
 // ones - then nothing is lost) and is simply polled again, like a word that has not arrived.
 // (fold = x ^ y ^ z: one v_xor3_b32.  With rotations of y and z in it - to decorrelate equal values of two networks - the checks cost the
 // step 0.6 us on its dependent chain, 31.4 instead of 30.8; two networks' values that are equal before AND after a step are unchanged ones)
+// Tags advance by 1 per step, so the XOR of two consecutive bare tags is 1, 3, 7, ...: a torn word (new payload over a stale last dword) whose
+// payload fold moved by exactly that - one network's value changing by an ulp - would pass.  The tag is therefore spread over all
+// 32 bits before it meets the fold (lq_tag: one scalar multiply per gather, off the dependent chain): consecutive tags now differ in ~16
+// pseudo-random bit positions, which a slowly varying payload does not reproduce.
 __device__ __forceinline__ unsigned lq_fold(unsigned x, unsigned y, unsigned z) { return x ^ y ^ z; }
-__device__ __forceinline__ bool lq_ok(const u32x4& w, unsigned tag) { return (w.w ^ lq_fold(w.x, w.y, w.z)) == tag; }
+__device__ __forceinline__ unsigned lq_tag(unsigned tag) { return tag * 0x9E3779B1u; }
+__device__ __forceinline__ bool lq_ok(const u32x4& w, unsigned tag) { return (w.w ^ lq_fold(w.x, w.y, w.z)) == lq_tag(tag); }
 __device__ __forceinline__ void lq_store(__amdgpu_buffer_rsrc_t q, unsigned idx, float a, float b, float c, unsigned tag) {
   u32x4 w;
-  w.x = __float_as_uint(a); w.y = __float_as_uint(b); w.z = __float_as_uint(c); w.w = tag ^ lq_fold(w.x, w.y, w.z);
+  w.x = __float_as_uint(a); w.y = __float_as_uint(b); w.z = __float_as_uint(c); w.w = lq_tag(tag) ^ lq_fold(w.x, w.y, w.z);
   __builtin_amdgcn_raw_buffer_store_b128(w, q, idx * 16u, 0, 16);   // buffer_store_dwordx4 ... sc1
 }
 // gather N packed words idx0 + i * stride carrying `tag` -> the three networks' values; wave-uniform retry as ll_gather

@@ -48,6 +48,9 @@ class SdxSim:
         self.scene = scene or load_scene()
         self.device = torch.device(device)
         self.num_envs = int(num_envs)
+        if desc is not None and desc_overrides:
+            raise SdxError("SdxSim: pass either a ready `desc` or overrides for Scene.to_desc(), not both (%s would be ignored)"
+                           % ", ".join(sorted(desc_overrides)))
         self._desc = desc if desc is not None else self.scene.to_desc(**desc_overrides)
         h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -86,6 +89,11 @@ class SdxSim:
         slots were claimed in, the serial-order guarantee is gone: `self.ring_wrapped` records it (callers that promise determinism
         assert it stayed False; size the run so that it does)."""
         if int(count) > rows.shape[0] and self is not None:
+            if not self.ring_wrapped:      # said once per simulator: every consumer of the ring (terminal states, piles, T-value data sets) is affected
+                import warnings
+                warnings.warn("seqdex_amd: a terminal-state ring wrapped (%d appends into %d slots): its rows are in slot-claim order, not in serial "
+                              "(step, env) order - the run is no longer bit-reproducible; harvest more often or size the run to the ring"
+                              % (int(count), rows.shape[0]), RuntimeWarning, stacklevel=2)
             self.ring_wrapped = True
         k = int(min(int(count), rows.shape[0]))
         if k == 0:
