@@ -82,6 +82,9 @@ struct SdxBuf {
 #define SDX_OPAQUE_AFTER(x, after) ((void)0)
 #define SDX_PIN4(a) ((void)0)
 #define SDX_PIN8(a) ((void)0)
+#define SDX_PIN3x4(a, b, c, d) ((void)0)
+#define SDX_PIN3(a) ((void)0)
+#define SDX_PIN1(a) ((void)0)
 #define SDX_RCP(x) (1.0f / (x))
 #define SDX_SQRT_FAST(x) sqrtf(x)
 #define SDX_READLANE(x, lane) __shfl((x), (lane), 64)
@@ -107,6 +110,10 @@ struct SdxBuf {
 // operands already loaded for them are spilled
 #define SDX_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
 #define SDX_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+// four f3 values pinned together: all of them are loaded before anything after this point is computed (one wait for four rows in flight)
+#define SDX_PIN3x4(a, b, c, d) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(d.x), "+v"(d.y), "+v"(d.z))
+#define SDX_PIN3(a) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z))
+#define SDX_PIN1(a) asm volatile("" : "+v"(a))
 #define SDX_SQRT_FAST(x) __builtin_amdgcn_sqrtf(x)   // v_sqrt_f32, 1 ulp: for integer results that are corrected afterwards
 #define SDX_RCP(x) __builtin_amdgcn_rcpf(x)   // v_rcp_f32, 1 ulp: the solver's step lengths do not need IEEE division (12 instructions)
 // value of x in a lane known at compile time (v_readlane_b32: the result is wave-uniform, no LDS crossbar); every lane of the wave must be active

@@ -56,7 +56,7 @@ struct PhysLds {
   float q[ND], qd[ND + 1], qdb[ND + 1], tgt[ND], tau[ND];   // qd[ND] = 0: the padding dof of exhausted paths; qdb: the solver's second copy (read one, write the other)
   float lq[NL][4], la[NL + 1][3], lc[NL][3], lI[NL][6], lmass[NL];   // lmass: link masses (a per-lane global load inside the mass-matrix loop cost it 8 k cycles)
   float lal[NL + 1][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
-  float A[ND][HP];      // H -> L -> Hinv
+  alignas(16) float A[ND][HP];      // H -> L -> Hinv (rows of 96 bytes: the robot section reads them as ds_read_b128)
   uint32_t anc[NL];     // bit j: dof j lies on the path base -> link
   int par[NL + 1];      // parent link; [NL] = NL: the padding link of exhausted paths (zero rows of the body table)
   float cf[NL][3];
@@ -80,6 +80,7 @@ struct PhysLds {
   float tbc[SDX_NBRICK_TYPES][3], tbh[SDX_NBRICK_TYPES][3], trad[SDX_NBRICK_TYPES], tii[SDX_NBRICK_TYPES][3];
   float hsc[SDX_MAX_SUB_HOLLOW][3], hsh[SDX_MAX_SUB_HOLLOW][3];
   float samp[SDX_NSAMP][3];    // copy of c_samp for per-lane sample indices (the manifold selection of pair_contacts)
+  float qid[4];                // (0, 0, 0, 1): the orientation row a static body's box reads in load_box2
   // robot collision boxes in the world
   float rc[SDX_MAX_RBOX][3], rq[SDX_MAX_RBOX][4], rh[SDX_MAX_RBOX][3], rrad[SDX_MAX_RBOX];
   int rbl[SDX_MAX_RBOX];
@@ -93,7 +94,7 @@ struct PhysLds {
   int eoff[NF + NL + 1], efill[NF + NL];
   int wsum[16];
   // contacts: geometry in LDS for the whole solve
-  float cp[3][MAXC], cn[3][MAXC];
+  alignas(16) float cp[3][MAXC], cn[3][MAXC];
   // (before the narrowphase has produced them, cp / cn hold the list of candidate BOX pairs and the body pairs' offsets into it: S_SP0 ...)
   // three rows that are, in turn: the narrowphase's staging of (separation, body ids) + the candidate body-pair list; L^-1 of the mass
   // matrix; the unsorted CSR fill order during the solver set-up; and the per-contact impulse P of the current iteration
@@ -121,9 +122,17 @@ struct Box { f3 c; f4 q; f3 h; };
 #ifdef SDX_PHASE_CLOCK
 #define PSTAMP(i) do { if (threadIdx.x == 0 && e == B.dbg_env && sub == 0) B.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #define SSTAMP(i) do { if (threadIdx.x == 0 && dbg) dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define SCOUNT(i, v) do { if (threadIdx.x == 0 && dbg) dbg[i] = (long long)(v); } while (0)
+// timing ablations of the profiling build (tools/ablate_physics.py): bits of SDX_T_DEBUG[63], read once per workgroup.  A set bit REMOVES a
+// piece of work (the results are then meaningless; the tool restores the state before every launch): 1 the gather loop of [D], 2 the body of
+// [AC], 4 all solver iterations but one, 8 the robot section, 16 the sample classification (no contacts), 32 the broadphase (no pairs),
+// 64 the solver set-up's rank pass, 128 the row weights, 256 FK + drive of the second substep, 512 the mass matrix
+#define ABL(bit) (abl_bits & (bit))
 #else
 #define PSTAMP(i) ((void)0)
 #define SSTAMP(i) ((void)0)
+#define SCOUNT(i, v) ((void)0)
+#define ABL(bit) 0
 #endif
 
 __device__ __forceinline__ float box_sdf(f3 p, f3 h, f3* g) {
@@ -161,7 +170,7 @@ __device__ __forceinline__ void tangents(f3 n, f3* t1, f3* t2) {
 }
 
 // ---- shapes.  Box id: 0..71 brick, 72..111 robot box, 128..135 static body; a brick and a static body are COMPOUNDS of boxes (sub index),
-// a robot box is one box.  load_bound: the bounding box of a body (broadphase, first separating-axis pass); load_box: one box of it.
+// a robot box is one box.  load_bound: the bounding box of a body (broadphase, first separating-axis pass); load_box2: one box of each body of a pair.
 #define RBOX0 NF
 #define STATIC0 128
 static_assert(RBOX0 + SDX_MAX_RBOX <= STATIC0 && STATIC0 + SDX_MAX_STATIC <= 256, "box ids fit 8 bits (7 for the first box of a pair)");
@@ -185,22 +194,59 @@ __device__ __forceinline__ Box load_bound(const PhysLds& S, int id) {
   }
   return b;
 }
-__device__ __forceinline__ Box load_box(const SdxConst* C, const PhysLds& S, int id, int sub) {
-  Box b;
-  if (id < NF) {
-    const int t = S.btype[id];
-    const bool hol = brick_hollow(S, id);
-    b.q = ld4(S.bq[id]);
-    b.c = ld3(S.bp[id]) + qrot(b.q, hol ? ld3(S.hsc[sub]) : ld3(S.tsc[t][sub]));
-    b.h = hol ? ld3(S.hsh[sub]) : ld3(S.tsh[t][sub]);
-    return b;
+// Both boxes of a pair with TWO LDS round trips (round 6).  One box at a time (a brick: orientation, position, type -> compound row; a
+// robot box: its world rows; a static body: its row, or a row of the HBM table for a compound) compiled to a chain of about ten: type ->
+// compound table -> rows, one box after the other, each class of box in its own branch.  Here the rows every class needs are addressed without branches
+// (orientation, position, half extents come from the brick / robot-box / static tables by pointer selection; a static body reads the
+// identity row S.qid), all of them for both boxes are in flight together, then the bricks' compound rows (which depend on the type) for both.
+// A brick's box: centre = position + R x (compound row - centre of mass), half extents = the compound row.  A box of a static COMPOUND
+// (the studded base plate, HBM table) is the slow path behind a branch, as before.
+__device__ __forceinline__ void load_box2(const SdxConst* C, const PhysLds& S, int ida, int suba, int idb, int subb, Box* A, Box* B) {
+  const int id_[2] = {ida, idb}, sub_[2] = {suba, subb};
+  f4 q_[2];
+  f3 p_[2], h_[2];
+  int t_[2], sn_[2], sf_[2];
+  const bool hol_any = S.hn > 0;
+  const int segb = S.seg_brick;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int id = id_[k];
+    const bool brick = id < NF, rob = !brick && id < STATIC0;
+    const int r = rob ? id - RBOX0 : 0, st = (!brick && !rob) ? id - STATIC0 : 0, ib = brick ? id : 0;
+    const float* qp = brick ? S.bq[ib] : (rob ? S.rq[r] : S.qid);
+    const float* pp = brick ? S.bp[ib] : (rob ? S.rc[r] : S.stc[st]);
+    const float* hp = rob ? S.rh[r] : S.sth[st];
+    q_[k] = ld4(qp); p_[k] = ld3(pp); h_[k] = ld3(hp);
+    t_[k] = S.btype[ib]; sn_[k] = S.ssn[st]; sf_[k] = S.ssf[st];
   }
-  if (id >= STATIC0 && S.ssn[id - STATIC0] > 1) {   // a box of a static compound (the studded base plate): the table lives in HBM
-    const int r = S.ssf[id - STATIC0] + sub;
-    b.c = ld3(C->sc.static_sub_center[r]); b.h = ld3(C->sc.static_sub_half[r]); b.q.x = 0; b.q.y = 0; b.q.z = 0; b.q.w = 1;
-    return b;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    SDX_PIN1(q_[k].x); SDX_PIN1(q_[k].y); SDX_PIN1(q_[k].z); SDX_PIN1(q_[k].w); SDX_PIN3(p_[k]); SDX_PIN3(h_[k]);
+    SDX_PIN1(t_[k]); SDX_PIN1(sn_[k]); SDX_PIN1(sf_[k]);
   }
-  return load_bound(S, id);
+  f3 o_[2], hb_[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const bool hol = hol_any && id_[k] == segb;
+    const int sb = id_[k] < NF ? sub_[k] : 0;
+    o_[k] = ld3(hol ? S.hsc[sb] : S.tsc[t_[k]][sb]);
+    hb_[k] = ld3(hol ? S.hsh[sb] : S.tsh[t_[k]][sb]);
+  }
+  SDX_PIN3x4(o_[0], hb_[0], o_[1], hb_[1]);
+  Box* out_[2] = {A, B};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int id = id_[k];
+    Box b;
+    b.q = q_[k];
+    if (id < NF) { b.c = p_[k] + qrot(q_[k], o_[k]); b.h = hb_[k]; }
+    else { b.c = p_[k]; b.h = h_[k]; }
+    if (id >= STATIC0 && sn_[k] > 1) {
+      const int r = sf_[k] + sub_[k];
+      b.c = ld3(C->sc.static_sub_center[r]); b.h = ld3(C->sc.static_sub_half[r]);
+    }
+    *out_[k] = b;
+  }
 }
 __device__ __forceinline__ int box_body(const PhysLds& S, int id) {
   if (id < NF) return id;
@@ -391,6 +437,7 @@ __device__ __forceinline__ int pair_contacts(const PhysLds& S, const Box& A, con
   return n;
 }
 
+#define LOAD_BOX2(ba, sa, bb, sb) Box A, Bx; load_box2(C, S, ba, sa, bb, sb, &A, &Bx);   // (both boxes of a pair: A, Bx)
 #define S_CKEY(S) (reinterpret_cast<uint32_t*>(&(S).ent[0]))   // identity of contact c until the solver's set-up has read it (the CSR lives here later)
 __device__ __forceinline__ f3 point_vel(const PhysLds& S, int id, f3 p) {   // id: row of the body table (static world = zeros)
   return ld3(S.bv[id]) + cross(ld3(S.bw[id]), p - ld3(S.bp[id]));
@@ -418,7 +465,7 @@ __device__ __forceinline__ void twists_wave0(PhysLds& S, int tid);
 // w_k = w_p + a_k qd_k, al_k = al_p + w_p x (a_k qd_k), ao_k = ao_p + al_p x r + w_p x (w_p x r) (recursive Newton-Euler at zero joint
 // acceleration, fixed base, no gravity on the robot).  with_bias: the velocity-product wrenches the drive needs; with_inertia: the world
 // inertia tensors the mass matrix needs.
-__device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid, bool with_inertia, bool with_bias) {
+__device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid, bool with_inertia, bool with_bias, long long* dbg = nullptr) {
   const sdx_scene_desc& sc = C->sc;
   const bool link = tid > 0 && tid < NL;
   // this lane's link constants, fetched once (all loads in flight together)
@@ -453,6 +500,7 @@ __device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid,
     for (int i = 0; i < 6; ++i) I6[i] = sc.link_inertia[0][i];
   }
   WAVE_SYNC();
+  SSTAMP(7);
   // ---- the serial part: poses, level by level
   const int max_depth = C->max_depth;
   for (int d = 1; d <= max_depth; ++d) {
@@ -463,6 +511,7 @@ __device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid,
     }
     WAVE_SYNC();
   }
+  SSTAMP(8);
   // ---- one lane per link: world joint axis, centre of mass
   f4 qk = {0, 0, 0, 1};
   f3 dk = F3(0, 0, 0);
@@ -473,33 +522,66 @@ __device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid,
     st3(S.lc[tid], ld3(S.bp[NF + tid]) + dk);
   }
   WAVE_SYNC();
+  SSTAMP(9);
   twists_wave0(S, tid);            // w_k, v_k from the dofs on the path
+  SSTAMP(10);
   if (with_bias) {
     WAVE_SYNC();
     // al_k = sum over the links m on the path of w_par(m) x (a_m qd_m)
     f3 alk = F3(0, 0, 0);
     if (link) {
       uint32_t m = S.anc[tid];
+      constexpr int FB = 4;
 #pragma unroll
-      for (int t = 0; t < 11; ++t) {
-        const int j = m ? __ffs(m) - 1 : ND;
-        m &= m - 1;
-        alk = alk + cross(ld3(S.bw[NF + S.par[j + 1]]), ld3(S.la[j + 1]) * S.qd[j]);
+      for (int t0 = 0; t0 < 11; t0 += FB) {
+        int pm_[FB];
+        f3 la_[FB], wp_[FB];
+        float qd_[FB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) {
+          const int j = m ? __ffs(m) - 1 : ND;
+          m &= m - 1;
+          pm_[u] = S.par[j + 1]; la_[u] = ld3(S.la[j + 1]); qd_[u] = S.qd[j];
+        }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) SDX_PIN1(pm_[u]);
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) wp_[u] = ld3(S.bw[NF + pm_[u]]);
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) { SDX_PIN3(wp_[u]); SDX_PIN3(la_[u]); SDX_PIN1(qd_[u]); }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) alk = alk + cross(wp_[u], la_[u] * qd_[u]);
       }
       st3(S.lal[tid], alk);
     }
     WAVE_SYNC();
+    SSTAMP(11);
     // ao_k = sum over the links m on the path of al_par(m) x r_m + w_par(m) x (w_par(m) x r_m), r_m = p_m - p_par(m)
     if (link) {
       f3 aok = F3(0, 0, 0);
       uint32_t m = S.anc[tid];
+      constexpr int FB = 4;
 #pragma unroll
-      for (int t = 0; t < 11; ++t) {
-        const int j = m ? __ffs(m) - 1 : ND;
-        m &= m - 1;
-        const int pm = S.par[j + 1];
-        const f3 r = ld3(S.bp[NF + j + 1]) - ld3(S.bp[NF + pm]), wp = ld3(S.bw[NF + pm]);
-        aok = aok + cross(ld3(S.lal[pm]), r) + cross(wp, cross(wp, r));
+      for (int t0 = 0; t0 < 11; t0 += FB) {
+        int pm_[FB];
+        f3 pj_[FB], pp_[FB], wp_[FB], al_[FB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) {
+          const int j = m ? __ffs(m) - 1 : ND;
+          m &= m - 1;
+          pm_[u] = S.par[j + 1]; pj_[u] = ld3(S.bp[NF + j + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) SDX_PIN1(pm_[u]);
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) { pp_[u] = ld3(S.bp[NF + pm_[u]]); wp_[u] = ld3(S.bw[NF + pm_[u]]); al_[u] = ld3(S.lal[pm_[u]]); }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) { SDX_PIN3(pj_[u]); SDX_PIN3(pp_[u]); SDX_PIN3(wp_[u]); SDX_PIN3(al_[u]); }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) if (t0 + u < 11) {
+          const f3 r = pj_[u] - pp_[u], wp = wp_[u];
+          aok = aok + cross(al_[u], r) + cross(wp, cross(wp, r));
+        }
       }
       st3(S.lao[tid], aok);
       const f3 wk = ld3(S.bw[NF + tid]);
@@ -508,6 +590,7 @@ __device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid,
       st3(S.lN[tid], inertia_mul(qk, I6, alk) + cross(wk, inertia_mul(qk, I6, wk)));
     }
   }
+  SSTAMP(12);
   if (tid < sc.n_rbox) {
     const int k = S.rbl[tid];
     const f4 q = ld4(S.lq[k]);
@@ -537,13 +620,27 @@ __device__ __forceinline__ void twists_wave0(PhysLds& S, int tid) {
     f3 w = F3(0, 0, 0), v = F3(0, 0, 0);
     const f3 pk = ld3(S.bp[NF + tid]);
     uint32_t m = S.anc[tid];
+    // Operands of FOUR path terms at a time are loaded before their arithmetic (SDX_PIN*): the plain loop below compiles to two dependent
+    // LDS round trips per term - 22 in a row on the one wave everybody else is waiting for (round 6, ISA reading).  Same terms, same order.
+    constexpr int FB = 4;
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
-      const int j = m ? __ffs(m) - 1 : ND;
-      m &= m - 1;
-      const f3 aj = ld3(S.la[j + 1]) * S.qd[j];
-      w = w + aj;
-      v = v + cross(aj, pk - ld3(S.bp[NF + j + 1]));
+    for (int t0 = 0; t0 < 11; t0 += FB) {
+      f3 la_[FB], pj_[FB];
+      float qd_[FB];
+#pragma unroll
+      for (int u = 0; u < FB; ++u) if (t0 + u < 11) {
+        const int j = m ? __ffs(m) - 1 : ND;
+        m &= m - 1;
+        la_[u] = ld3(S.la[j + 1]); qd_[u] = S.qd[j]; pj_[u] = ld3(S.bp[NF + j + 1]);
+      }
+#pragma unroll
+      for (int u = 0; u < FB; ++u) if (t0 + u < 11) { SDX_PIN3(la_[u]); SDX_PIN3(pj_[u]); SDX_PIN1(qd_[u]); }
+#pragma unroll
+      for (int u = 0; u < FB; ++u) if (t0 + u < 11) {
+        const f3 aj = la_[u] * qd_[u];
+        w = w + aj;
+        v = v + cross(aj, pk - pj_[u]);
+      }
     }
     st3(S.bw[NF + tid], w);
     st3(S.bv[NF + tid], v);
@@ -569,14 +666,32 @@ __device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int t
     if ((S.anc[i + 1] >> j) & 1u) {
       const f3 ai = ld3(S.la[i + 1]), aj = ld3(S.la[j + 1]);
       const f3 pi = ld3(S.bp[NF + i + 1]), pj = ld3(S.bp[NF + j + 1]);
-      for (int k = i + 1; k < NL; ++k) {
-        if (!((S.anc[k] >> i) & 1u)) continue;
-        const f3 ck = ld3(S.lc[k]);
-        const f3 li = cross(ai, ck - pi), lj = cross(aj, ck - pj);
-        const float* I = S.lI[k];
-        const f3 Ia = F3(I[0] * aj.x + I[3] * aj.y + I[4] * aj.z, I[3] * aj.x + I[1] * aj.y + I[5] * aj.z,
-                         I[4] * aj.x + I[5] * aj.y + I[2] * aj.z);
-        s += S.lmass[k] * dot(li, lj) + dot(ai, Ia);
+      {   // links below dof i = bits of desc[i] (all of them > i); four links' operands in flight at a time, same terms, ascending k
+        const uint32_t below = S.desc[i];
+        constexpr int FB = 4;
+#pragma unroll 1
+        for (int k0 = i + 1; k0 < NL; k0 += FB) {
+          f3 ck_[FB];
+          float I_[FB][6], mk_[FB];
+#pragma unroll
+          for (int u = 0; u < FB; ++u) {
+            const int k = k0 + u < NL ? k0 + u : NL - 1;
+            ck_[u] = ld3(S.lc[k]); mk_[u] = S.lmass[k];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) I_[u][r] = S.lI[k][r];
+          }
+#pragma unroll
+          for (int u = 0; u < FB; ++u) { SDX_PIN3(ck_[u]); SDX_PIN1(mk_[u]); SDX_PIN4(I_[u]); SDX_PIN1(I_[u][4]); SDX_PIN1(I_[u][5]); }
+#pragma unroll
+          for (int u = 0; u < FB; ++u) {
+            const f3 li = cross(ai, ck_[u] - pi), lj = cross(aj, ck_[u] - pj);
+            const float* I = I_[u];
+            const f3 Ia = F3(I[0] * aj.x + I[3] * aj.y + I[4] * aj.z, I[3] * aj.x + I[1] * aj.y + I[5] * aj.z,
+                             I[4] * aj.x + I[5] * aj.y + I[2] * aj.z);
+            const float term = mk_[u] * dot(li, lj) + dot(ai, Ia);
+            if (k0 + u < NL && ((below >> (k0 + u)) & 1u)) s += term;
+          }
+        }
       }
     }
     if (i == j) s += sc.armature[i] + h * sc.kd[i] + h * h * sc.kp[i];
@@ -716,7 +831,7 @@ __device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int
 }
 
 template <int NT>
-__device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, long long* dbg) {
+__device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, long long* dbg, int abl_bits) {
   const sdx_scene_desc& sc = C->sc;
   const float off = sc.contact_offset;
   constexpr int ns = SDX_MAX_STATIC, per = NF + SDX_MAX_STATIC;
@@ -724,8 +839,14 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   // ---- broadphase over BODY pairs: lane tid tests candidates tid, tid + NT, ...; hits as a bit mask; ONE block scan places them (lane-major order)
   constexpr int n1 = NF * ns, n2 = NF * (NF - 1) / 2;
   const int n3 = sc.n_rbox * per, ntot = n1 + n2 + n3;   // ntot <= 16 NT (sdx_create checks)
+  // Two passes (round 6; one loop over candidate() cost 20 k cycles per substep: ~12 trips per lane, every one as long as its slowest lane's
+  // oriented-box tests).  Pass 1, unrolled: the FIRST stage of candidate() for each of the lane's candidates - a sphere test on two
+  // 16-byte rows (brick / robot box against brick) or the axis-aligned box test of a static body - with the loads of several trips in
+  // flight; the trip's regime is a compile-time constant for all but two of the 16 trips.  Pass 2: candidate() itself, only for the trips
+  // that passed.  The mask is the one the single loop produced: pass 1 never rejects what candidate() accepts (same expressions, plus a
+  // relative slack of 1e-5 against a differently contracted product).
   uint32_t mask = 0;
-  {
+  if (!ABL(32)) {
     int it = 0;
     for (int idx = tid; idx < ntot; idx += NT, ++it) {
       if (candidate(S, idx, n1, n2, ns, per, ns_used, off)) mask |= 1u << it;
@@ -749,6 +870,8 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
   int pairs_lost = np > MAXP;   // more candidate pairs than the list holds: the excess (lane-major order) is not tested
   if (np > MAXP) np = MAXP;
   __syncthreads();
+  SSTAMP(40);
+  SCOUNT(48, np);
   // ---- separating-axis pass over the bounding boxes: a body pair that a face axis of either bounding box separates by the whole contact
   // offset cannot produce a contact (its boxes lie inside the bounding boxes); about half of the sphere-vs-box candidates leave the list
   // here.  Lane tid looks at the consecutive pairs tid * q .. tid * q + q - 1 (order preserved).
@@ -781,6 +904,8 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     np = np2;
     __syncthreads();
   }
+  SSTAMP(41);
+  SCOUNT(49, np);
   // ---- box pairs of the surviving body pairs, FOUR lanes per body pair.  A survivor is either
   //   CONVEX - both sides stand for one convex shape (a brick as the slab compound of its hull, a robot box, a single-box static): it
   //   contributes ONE box pair, the one with the smallest separation bound sigma = the largest face-axis separation of its directions
@@ -805,7 +930,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       float sg = 1e30f;
       if (convex && sub < cnt) {
         const int sa = sub / nbx, sb = sub - sa * nbx;
-        const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
+        LOAD_BOX2(ba, sa, bb, sb)
         sg = dir_setup(A, Bx, off).smax;
         if (samples_b(bb, sb)) sg = fmaxf(sg, dir_setup(Bx, A, off).smax);
       }
@@ -829,6 +954,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       }
     }
     __syncthreads();
+    SSTAMP(42);
     // exclusive prefix sum of the counts, three body pairs per lane
     static_assert(MAXP <= 3 * NT, "three body pairs per lane");
     const int i0 = 3 * tid, i1 = 3 * tid + 1, i2 = 3 * tid + 2;
@@ -841,6 +967,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     __syncthreads();
   }
   SSTAMP(33);
+  SCOUNT(50, nbp);
   // ---- expansion: candidate box pair t = S_OFF[p] + (sub a * nsub(b) + sub b) of body pair p.  Lane tid tests the CONSECUTIVE candidates
   // tid * q2 .. (so the survivors come out in ascending (pair rank, box pair) order: the order of the warm-start keys) with the
   // separating-axis test of the two boxes; survivors as a bit mask, one block scan, then the lane walks its range again and writes
@@ -868,7 +995,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
         if (!(pr >> 31)) {   // (a convex pair's only candidate has passed its test in the pass above)
           const int sidx = t - S_OFF(S)[pp];
           const int ba = pr & 0xff, bb = (pr >> 8) & 0xff, sa = sidx / nbs, sb = sidx - sa * nbs;
-          const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
+          LOAD_BOX2(ba, sa, bb, sb)
           sep = dir_setup(A, Bx, off).smax >= off;
           if (!sep && samples_b(bb, sb)) sep = dir_setup(Bx, A, off).smax >= off;
         }
@@ -899,6 +1026,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
     __syncthreads();
   }
   SSTAMP(37);
+  SCOUNT(51, nsp);
   // ---- narrowphase in two parts.  (1) lane = candidate box pair: the <= 4 samples of the two directions that become contacts
   // (pair_contacts); a block prefix sum of the counts gives every contact its place in pair order, and the lane leaves TWO words per
   // contact there: (boxes, direction, sample) and the contact's identity.  (2) lane = contact (below): geometry of that sample.
@@ -917,10 +1045,10 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       const int pi = base + tid;
       uint32_t s1 = 0, s2 = 0, w0 = 0, w1 = 0;
       int k = 0;
-      if (pi < nsp) {
+      if (pi < nsp && !ABL(16)) {
         w0 = S_SP0(S)[pi]; w1 = S_SP1(S)[pi];
         const int ba = w0 & 0x7f, sa = (w0 >> 7) & 0xf, bb = (w0 >> 11) & 0xff, sb = (w0 >> 19) & 0x3f;
-        const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
+        LOAD_BOX2(ba, sa, bb, sb)
         k = pair_contacts(S, A, Bx, samples_b(bb, sb), off, incl, &s1, &s2);
       }
       if (pass == 0 && base == 0) SSTAMP(38);
@@ -959,7 +1087,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       const int dirb = (d >> 25) & 1, sidx = d >> 26;
       const int b0 = d & 0x7f, s0 = (d >> 7) & 0xf, b1 = (d >> 11) & 0xff, sb1 = (d >> 19) & 0x3f;
       const int ba = dirb ? b1 : b0, bb = dirb ? b0 : b1, sa = dirb ? sb1 : s0, sb = dirb ? s0 : sb1;
-      const Box A = load_box(C, S, ba, sa), Bx = load_box(C, S, bb, sb);
+      LOAD_BOX2(ba, sa, bb, sb)
       const Dir D = dir_setup(A, Bx, off);
       const f3 pb = ((D.t + D.ex * c_samp[sidx][0]) + D.ey * c_samp[sidx][1]) + D.ez * c_samp[sidx][2];
       f3 g;
@@ -1015,7 +1143,7 @@ template <int NT, bool WARM>
 // loop below spreads those impulses over the bodies with the gather machinery of a normal iteration.  WARM is a template parameter:
 // the default (cold) solver carries none of this code (it cost 2.6 % of the kernel as a run-time switch).
 __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, float h, bool last_substep, long long* dbg,
-                                      int32_t* wcount, uint32_t* wkey, float* wlam) {
+                                      int32_t* wcount, uint32_t* wkey, float* wlam, int abl_bits) {
   constexpr int CPT = MAXC / NT;   // contact rows owned by one lane
   constexpr int NB = NF + NL;      // bodies with a CSR list: bricks 0..71, links 72..95
   static_assert(CPT * NT == MAXC, "NT must divide SDX_MAXC");
@@ -1125,6 +1253,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   const int rbeg = S.eoff[NF], nrob = S.eoff[NB] - rbeg;   // the robot's sides: entries [rbeg, rbeg + nrob), grouped by link
   const bool has_robot = nrob > 0;                          // block-uniform
   if (tid == 0) S.nrob = nrob;
+  SCOUNT(52, nc); SCOUNT(53, S.eoff[NB]); SCOUNT(54, nrob);
   // rank pass: entry -> position = number of entries of the same body with a smaller contact index (a contact touches a body at
   // most once, so indices are distinct) => every body's list is in ascending contact order, deterministically
   {
@@ -1135,6 +1264,8 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       const unsigned short v = S_ENT2(S)[i];
       const int key = v & 0x7fff;
       int rank = 0;
+      if (ABL(64)) rank = i - o;
+      else
 #pragma unroll 4
       for (int j = 0; j < n; ++j) rank += (S_ENT2(S)[o + j] & 0x7fff) < key;
       S.ent[o + rank] = v;
@@ -1204,18 +1335,37 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
-    const bool on = c < nc;
+    const bool on = c < nc && !ABL(128);
     const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
     f3 p = F3(0, 0, 0), n = F3(0, 0, 1);
     if (on) { p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]); n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]); }
     f3 t1, t2;
     tangents(n, &t1, &t2);
     const f3 dir[3] = {n, t1, t2};
+    {
+      // brick_w() x 6 compiled to ~7 dependent LDS round trips per call (position, orientation, type -> inertia ratios, inverse mass, one
+      // after the other: 40 in a row per contact).  Here both sides' rows are loaded together, then the type rows, then the six weights are
+      // plain arithmetic - the same expressions as brick_w.  A side that is not a brick reads brick 0 and is discarded.
+      const bool ba = on && a < NF, bb = on && b < NF;
+      const int ia = ba ? a : 0, ib = bb ? b : 0;
+      f3 xa = ld3(S.bp[ia]), xb = ld3(S.bp[ib]);
+      f4 qa = ld4(S.bq[ia]), qb = ld4(S.bq[ib]);
+      float ima = S.bim[ia], imb = S.bim[ib];
+      int ta = S.btype[ia], tb = S.btype[ib];
+      SDX_PIN1(ta); SDX_PIN1(tb);
+      f3 iia = ld3(S.tii[ta]), iib = ld3(S.tii[tb]);
+      SDX_PIN3x4(xa, xb, iia, iib);
+      SDX_PIN1(qa.x); SDX_PIN1(qa.y); SDX_PIN1(qa.z); SDX_PIN1(qa.w); SDX_PIN1(qb.x); SDX_PIN1(qb.y); SDX_PIN1(qb.z); SDX_PIN1(qb.w);
+      SDX_PIN1(ima); SDX_PIN1(imb);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      wA[q][r] = (on && a < NF) ? brick_w(S, a, p, dir[r]) : 0.0f;
-      wB[q][r] = (on && b < NF) ? brick_w(S, b, p, dir[r]) : 0.0f;
-      lam[q][r] = 0.0f;
+      for (int r = 0; r < 3; ++r) {
+        const f3 la = qrot(qconj(qa), cross(p - xa, dir[r])), lb = qrot(qconj(qb), cross(p - xb, dir[r]));
+        const float va = ima * (1.0f + la.x * la.x * iia.x + la.y * la.y * iia.y + la.z * la.z * iia.z);
+        const float vb = imb * (1.0f + lb.x * lb.x * iib.x + lb.y * lb.y * iib.y + lb.z * lb.z * iib.z);
+        wA[q][r] = ba ? va : 0.0f;
+        wB[q][r] = bb ? vb : 0.0f;
+        lam[q][r] = 0.0f;
+      }
     }
     if (has_robot && on) {
 #pragma unroll 1
@@ -1316,6 +1466,12 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   __syncthreads();
   SSTAMP(17);
 
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {   // the sides' active-count slots into bits 16..31 of ab: a brick's own, NF = the whole robot, NF + 1 = the static world
+    const int a = ab[q] & 0xff, b = (ab[q] >> 8) & 0xff;
+    const int sa = a < NF ? a : (a != BODY_W ? NF : NF + 1), sb = b < NF ? b : (b != BODY_W ? NF : NF + 1);
+    ab[q] = (ab[q] & 0xffff) | (sa << 16) | (sb << 24);
+  }
   // fresh values for the loop: whatever the set-up phases above did to these registers, inside the loop they are plain registers again
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
@@ -1324,7 +1480,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     for (int r = 0; r < 3; ++r) { SDX_OPAQUE(lam[q][r]); SDX_OPAQUE(wA[q][r]); SDX_OPAQUE(wB[q][r]); }
   }
   SDX_OPAQUE(gbeg); SDX_OPAQUE(gend); SDX_OPAQUE(tjp);
-  for (int it = (WARM && nold > 0) ? -1 : 0; it < sc.solver_iters; ++it) {   // it = -1: only the gather of the warm-start impulses
+  for (int it = (WARM && nold > 0) ? -1 : 0; it < (ABL(4) ? 1 : sc.solver_iters); ++it) {   // it = -1: only the gather of the warm-start impulses
 #ifdef SDX_PHASE_CLOCK
     if (it == 1) dbg = nullptr;
 #endif
@@ -1338,20 +1494,25 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       SDX_OPAQUE(abq); SDX_OPAQUE(ct);
       const int c = ct + q * NT;
       f3 P = F3(0, 0, 0);
-      if (c < nc) {
+      if (c < nc && !ABL(2)) {
         const f3 n = F3(S.cn[0][c], S.cn[1][c], S.cn[2][c]);
         f3 t1, t2;
         tangents(n, &t1, &t2);
         if (WARM && it < 0) {                      // warm start: the whole initial impulse
           if (lam[q][0] > 0.0f) P = n * lam[q][0] + t1 * lam[q][1] + t2 * lam[q][2];
         } else {
-          const int a = abq & 0xff, b = (abq >> 8) & 0xff;
+          // (bits 16..31 of ab: the two sides' slots in the active-count sets, fixed for the solve - decoding them per iteration cost 28
+          // VALU instructions per contact; the counts of the previous iteration are loaded with the geometry, not after the velocity test:
+          // one LDS round trip less on the path of every active contact)
+          const int a = abq & 0xff, b = (abq >> 8) & 0xff, sa = (abq >> 16) & 0xff, sb = (abq >> 24) & 0xff;
           const f3 p = F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]);
-          const f3 vr = (ld3v(S.bv[a]) + cross(ld3v(S.bw[a]), p)) - (ld3v(S.bv[b]) + cross(ld3v(S.bw[b]), p));
+          // (the four body rows in flight together: the plain expression loads side A, waits, then side B into the same registers)
+          f3 ua = ld3v(S.bv[a]), wa = ld3v(S.bw[a]), ub = ld3v(S.bv[b]), wb = ld3v(S.bw[b]);
+          SDX_PIN3x4(ua, wa, ub, wb);
+          const f3 vr = (ua + cross(wa, p)) - (ub + cross(wb, p));
           const float vn = dot(vr, n);
           const float lam0 = lam[q][0], lam1 = lam[q][1], lam2 = lam[q][2];
           if (lam0 > 0.0f || vn < vtgt[q]) {
-            const int sa = a < NF ? a : (a != BODY_W ? NF : NF + 1), sb = b < NF ? b : (b != BODY_W ? NF : NF + 1);
             if (a != BODY_W) atomicAdd(&S.acount[nxt][sa], 1);
             if (b != BODY_W) atomicAdd(&S.acount[nxt][sb], 1);
             const int ca = S.acount[cur][sa], cb = S.acount[cur][sb];
@@ -1392,19 +1553,40 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       const f3 x = ld3(S.bp[d_body]);
       // four entries per trip (the index loads, then the payloads, in flight together); not unrolled further: the decoded
       // addresses of a longer window would be kept in registers across the whole iteration loop
+      // two entries at a time: index loads pinned in front of the 12 payload loads, those in front of the arithmetic (four dependent LDS
+      // round trips per trip of four entries instead of eight; all four at once - SDX_D_BATCH - spills inside the loop)
 #pragma unroll 1
       for (int i = gbeg; i < gend; i += GU * gstride) {
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          const int iu = i + u * gstride;
-          const bool on = iu < gend;
-          const int e = S.ent[on ? iu : i], c = e & 0x7fff;
-          const float sg = on ? ((e & 0x8000) ? -1.0f : 1.0f) : 0.0f;
-          const f3 P = F3(S.P[0][c], S.P[1][c], S.P[2][c]) * sg;
-          const f3 M = cross(F3(S.cp[0][c], S.cp[1][c], S.cp[2][c]) - x, P);
-          acc[0] += P.x; acc[1] += P.y; acc[2] += P.z; acc[3] += M.x; acc[4] += M.y; acc[5] += M.z;
+        for (int h2 = 0; h2 < GU; h2 += 2) {
+          const int i0 = i + h2 * gstride, i1 = i0 + gstride;
+          int e0 = S.ent[i0 < gend ? i0 : i], e1 = S.ent[i1 < gend ? i1 : i];
+          SDX_PIN1(e0); SDX_PIN1(e1);
+          const int c0 = e0 & 0x7fff, c1 = e1 & 0x7fff;
+          f3 P0 = F3(S.P[0][c0], S.P[1][c0], S.P[2][c0]), C0 = F3(S.cp[0][c0], S.cp[1][c0], S.cp[2][c0]);
+          f3 P1 = F3(S.P[0][c1], S.P[1][c1], S.P[2][c1]), C1 = F3(S.cp[0][c1], S.cp[1][c1], S.cp[2][c1]);
+          SDX_PIN3x4(P0, C0, P1, C1);
+          {
+            const float sg = i0 < gend ? ((e0 & 0x8000) ? -1.0f : 1.0f) : 0.0f;
+            const f3 P = P0 * sg;
+            const f3 M = cross(C0 - x, P);
+            acc[0] += P.x; acc[1] += P.y; acc[2] += P.z; acc[3] += M.x; acc[4] += M.y; acc[5] += M.z;
+          }
+          {
+            const float sg = i1 < gend ? ((e1 & 0x8000) ? -1.0f : 1.0f) : 0.0f;
+            const f3 P = P1 * sg;
+            const f3 M = cross(C1 - x, P);
+            acc[0] += P.x; acc[1] += P.y; acc[2] += P.z; acc[3] += M.x; acc[4] += M.y; acc[5] += M.z;
+          }
         }
       }
+      // the brick update's operands (inverse inertia, inverse mass, u, w: 13 numbers) are requested BEFORE the lane reductions and pinned
+      // after them: their LDS round trip runs under the DPP adds instead of after them (every lane loads: the branch comes later)
+      const int tb = d_link ? 0 : d_body;
+      float K_[6], imb_ = S.bim[tb];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) K_[r] = S.bK[tb][r];
+      f3 u_ = ld3(S.bv[tb]), w_ = ld3(S.bw[tb]);
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         acc[r] = sum4(acc[r]);
@@ -1412,11 +1594,12 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       }
       if (!d_link) {
         if (d_sub == 0) {
-          const float* K = S.bK[d_body];
+          SDX_PIN4(K_); SDX_PIN1(K_[4]); SDX_PIN1(K_[5]); SDX_PIN1(imb_); SDX_PIN3(u_); SDX_PIN3(w_);
+          const float* K = K_;
           const f3 dw = F3(K[0] * acc[3] + K[3] * acc[4] + K[4] * acc[5], K[3] * acc[3] + K[1] * acc[4] + K[5] * acc[5],
                            K[4] * acc[3] + K[5] * acc[4] + K[2] * acc[5]);
-          st3(S.bv[d_body], (ld3(S.bv[d_body]) + F3(acc[0], acc[1], acc[2]) * S.bim[d_body]) - cross(dw, x));
-          st3(S.bw[d_body], ld3(S.bw[d_body]) + dw);
+          st3(S.bv[d_body], (u_ + F3(acc[0], acc[1], acc[2]) * imb_) - cross(dw, x));
+          st3(S.bw[d_body], w_ + dw);
           S.acount[cur][d_body] = 0;   // read by [AC] before the barrier above; it is the set [AC] of the next iteration counts into
         }
       } else if (has_robot) {
@@ -1430,7 +1613,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       }
       if (td == NL * LL) { S.acount[cur][NF] = 0; }
     }
-    if (has_robot) {
+    if (has_robot && !ABL(8)) {
       // robot section, ONE stage on 8 lanes per link: every group sums the generalised impulses of all 23 dofs from the Qc rows of the
       // touched links below each dof (3 dofs per lane), shares them inside the group through LDS (wave-synchronous), then
       // qd += Hinv dQ for the (<= 2) path dofs of this lane and the link's twist
@@ -1467,10 +1650,10 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         const int tj0 = tjp & 0xff, tj1 = tjp >> 8;
         const int r0 = tj0 < ND ? tj0 : 0, r1 = tj1 < ND ? tj1 : 0;
         float q0 = 0.0f, q1 = 0.0f;
-#pragma unroll 8
-        for (int j = 0; j < ND; ++j) { const float Qj = Qg[j]; q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }   // (fully unrolled, 69 loads in flight pushed 31 registers of the WHOLE kernel into scratch)
         const float* qsrc = qpar ? S.qdb : S.qd;
         float* qdst = qpar ? S.qd : S.qdb;
+#pragma unroll 8
+        for (int j = 0; j < ND; ++j) { const float Qj = Qg[j]; q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }   // (fully unrolled, 69 loads in flight pushed 31 registers of the WHOLE kernel into scratch)
         q0 = tj0 < ND ? qsrc[r0] + q0 : 0.0f;   // qd += Hinv dQ (other groups read the same source copy while the owners write the other one)
         q1 = tj1 < ND ? qsrc[r1] + q1 : 0.0f;
         if (tj0 == rj - 1) qdst[tj0] = q0;      // the link's own dof is written by the lane that holds it (exactly one per dof)
@@ -1562,6 +1745,7 @@ __device__ __forceinline__ void load_constants(const SdxConst* C, PhysLds& S, in
     for (int k = 0; k < SDX_MAX_SUB; ++k) { st3(S.tsc[t][k], ld3(sc.brick_sub_center[t][k]) - com); st3(S.tsh[t][k], ld3(sc.brick_sub_half[t][k])); }
   }
   if (tid >= 128 && tid < 128 + SDX_NSAMP * 3) (&S.samp[0][0])[tid - 128] = (&c_samp[0][0])[tid - 128];
+  if (tid >= 256 && tid < 260) S.qid[tid - 256] = tid == 259 ? 1.0f : 0.0f;
   if (tid >= 64 && tid < 64 + SDX_MAX_SUB_HOLLOW) {
     const int k = tid - 64;
     st3(S.hsc[k], ld3(sc.hollow_sub_center[segt][k]) - ld3(sc.brick_com[segt])); st3(S.hsh[k], ld3(sc.hollow_sub_half[segt][k]));
@@ -1591,6 +1775,11 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
   const sdx_scene_desc& sc = C->sc;
   float* root_e = B.root + (size_t)e * SDX_ACTORS * 13;
   const float h = sc.dt / (float)sc.substeps;
+#ifdef SDX_PHASE_CLOCK
+  const int abl_bits = (int)B.dbg[63];
+#else
+  constexpr int abl_bits = 0;
+#endif
 
   // ---- load per-env state (coalesced rows) into LDS
   load_constants<NT>(C, S, e, tid);
@@ -1621,22 +1810,38 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     const sdx_scene_desc& scl = Cs->sc;
     PSTAMP(0);
     if (sub == 0) {   // M(q) is evaluated once per step (frozen over the substeps)
-      if (tl < 64) fk_wave0(Cs, S, tl, true, true);
+      if (tl < 64) fk_wave0(Cs, S, tl, true, true, e == B.dbg_env ? B.dbg : nullptr);
       __syncthreads();
       PSTAMP(1);
-      mass_matrix<NT>(Cs, S, tl, h, e == B.dbg_env ? B.dbg : nullptr);
+      if (!ABL(512)) mass_matrix<NT>(Cs, S, tl, h, e == B.dbg_env ? B.dbg : nullptr);
       PSTAMP(2);
     }
     // A + C on wave 0 (FK, implicit PD drive (P1), velocity-product bias torques, twists); the other waves: gravity on the free bricks
-    if (tl < 64) {
+    if (ABL(256) && sub != 0) {
+    } else if (tl < 64) {
       if (sub != 0) fk_wave0(Cs, S, tl, false, true);
       if (tl < ND) {
         const float t = scl.kp[tl] * (S.tgt[tl] - S.q[tl]) - (scl.kd[tl] + h * scl.kp[tl]) * S.qd[tl];
         // velocity-product bias torque of dof tl: inertial wrenches of the links below it, projected on its axis
         float tc = 0.0f;
         const f3 aj = ld3(S.la[tl + 1]), oj = ld3(S.bp[NF + tl + 1]);
-        for (int k = 1; k < NL; ++k)
-          if ((S.anc[k] >> tl) & 1u) tc += dot(aj, cross(ld3(S.lc[k]) - oj, ld3(S.lF[k])) + ld3(S.lN[k]));
+        {   // links below dof tl = bits of desc[tl]; four links' operands in flight at a time, the same terms added in the same (ascending) order
+          const uint32_t below = S.desc[tl];
+          constexpr int FB = 4;
+#pragma unroll
+          for (int k0 = 1; k0 < NL; k0 += FB) {
+            f3 lc_[FB], lF_[FB], lN_[FB];
+#pragma unroll
+            for (int u = 0; u < FB; ++u) if (k0 + u < NL) { lc_[u] = ld3(S.lc[k0 + u]); lF_[u] = ld3(S.lF[k0 + u]); lN_[u] = ld3(S.lN[k0 + u]); }
+#pragma unroll
+            for (int u = 0; u < FB; ++u) if (k0 + u < NL) { SDX_PIN3(lc_[u]); SDX_PIN3(lF_[u]); SDX_PIN3(lN_[u]); }
+#pragma unroll
+            for (int u = 0; u < FB; ++u) if (k0 + u < NL) {
+              const float term = dot(aj, cross(lc_[u] - oj, lF_[u]) + lN_[u]);
+              if ((below >> (k0 + u)) & 1u) tc += term;
+            }
+          }
+        }
         S.tau[tl] = fminf(scl.effort[tl], fmaxf(-scl.effort[tl], t)) - tc;   // the effort limit applies to the drive only
       }
       WAVE_SYNC();
@@ -1654,7 +1859,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     }
     __syncthreads();
     PSTAMP(3);
-    collide<NT>(Cs, S, tl, (sub == 0 && e == B.dbg_env) ? B.dbg : nullptr);
+    collide<NT>(Cs, S, tl, (sub == 0 && e == B.dbg_env) ? B.dbg : nullptr, abl_bits);
     if (tl == 0 && B.cstats) {   // capacity statistics of this substep (integer atomics: order-independent)
       atomicMax(&B.cstats[0], S.nc + S.overflow);
       if (S.overflow) atomicAdd(&B.cstats[1], 1);
@@ -1663,9 +1868,9 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     }
     PSTAMP(4);
     if (scl.warm_start > 0.0f)
-      solve<NT, true>(Cs, S, tl, h, sub == nsub - 1, (sub == 0 && e == B.dbg_env) ? B.dbg : nullptr, B.wcount + e, B.wkey + (size_t)e * MAXC, B.wlam + (size_t)e * 3 * MAXC);
+      solve<NT, true>(Cs, S, tl, h, sub == nsub - 1, (sub == 0 && e == B.dbg_env) ? B.dbg : nullptr, B.wcount + e, B.wkey + (size_t)e * MAXC, B.wlam + (size_t)e * 3 * MAXC, abl_bits);
     else
-      solve<NT, false>(Cs, S, tl, h, sub == nsub - 1, (sub == 0 && e == B.dbg_env) ? B.dbg : nullptr, nullptr, nullptr, nullptr);
+      solve<NT, false>(Cs, S, tl, h, sub == nsub - 1, (sub == 0 && e == B.dbg_env) ? B.dbg : nullptr, nullptr, nullptr, nullptr, abl_bits);
     PSTAMP(5);
     // F: integrate
     if (tl < ND) {

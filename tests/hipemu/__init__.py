@@ -14,6 +14,8 @@ _SO = os.path.join(HERE, "libsdx_emu.so")
 _SRCS = [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "physics_driver.cpp"), os.path.join(CSRC, "sdx_physics.hip")]
 _DEPS = _SRCS + [os.path.abspath(__file__), os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(CSRC, "sdx_common.h"),
                  os.path.join(CSRC, "sdx_const_build.h"), os.path.join(ROOT, "include", "seqdex.h")]
+# extra g++ flags for every emulator build (e.g. "-DSDX_D_SORT": a compile-time variant of a kernel under test); rebuild with force=True after changing it
+_EXTRA = os.environ.get("SDX_EMU_CXXFLAGS", "").split()
 _lib = None
 # the whole simulator behind the C ABI of include/seqdex.h (sdx_capi + task + physics + camera sources) on the emulator
 _SIM_SO = os.path.join(HERE, "libsdx_emu_sim.so")
@@ -29,7 +31,7 @@ def build(force=False):
     for src in _SRCS:
         obj = os.path.join(HERE, os.path.basename(src) + ".emu.o")
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-w", "-x", "c++",
-                               "-I", os.path.join(HERE, "include"), "-I", CSRC, "-c", src, "-o", obj])
+                               "-I", os.path.join(HERE, "include"), "-I", CSRC] + _EXTRA + ["-c", src, "-o", obj])
         objs.append(obj)
     # -Bsymbolic: the product library may already be loaded RTLD_GLOBAL in this process and exports the same sdxk_* names
     subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", _SO] + objs)
@@ -45,7 +47,7 @@ def build_sim(force=False):
     for src in _SIM_SRCS:
         obj = os.path.join(HERE, os.path.basename(src) + ".emusim.o")
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-omit-frame-pointer", "-w", "-x", "c++",
-                               "-I", os.path.join(HERE, "include"), "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+                               "-I", os.path.join(HERE, "include"), "-I", CSRC, "-I", os.path.join(ROOT, "include")] + _EXTRA + ["-c", src, "-o", obj])
         objs.append(obj)
     subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-o", _SIM_SO] + objs)
     return _SIM_SO

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-6 GPU jobs, one parameterised script (replaces the one-off r5_[a-x].sh files):  gpurun -- 'bash tools/gpu/r6.sh <job> [args...]'
+# Every job writes under gpurun_out/r6_<job>/ and prints a short digest; the files that are kept go to profiles/r6_*.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd $R
+job=$1; shift
+O=gpurun_out/r6_$job
+mkdir -p $O
+digest() { python - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+        print(f.split("/")[-1], round(d["k_physics_ms"], 4), "contacts", round(d["contacts_mean"], 1), d["contacts_max"], "robot envs", d["envs_with_robot_contact"])
+        if "counts_env_substep0" in d and any(d["counts_env_substep0"].values()):
+            print("   counts", d["counts_env_substep0"])
+            print("   phases", {k: v for k, v in d["phase_cycles_env0_substep0"].items()})
+    except Exception as ex:
+        print(f, "unreadable:", ex)
+PY
+}
+case $job in
+phys)   # k_physics variants side by side: libseqdex_<v>.so for v in "$@" (default: what is in seqdex_amd/lib), parity tests on the default library first
+  timeout 900 python -m pytest tests/test_gpu_physics_parity.py tests/test_gpu_seams.py -q -m gpu -x 2>&1 | tail -6 > $O/tests.txt; tail -3 $O/tests.txt
+  V="$@"; [ -z "$V" ] && V=$(ls seqdex_amd/lib | sed -n 's/^libseqdex_\(.*\)\.so$/\1/p' | grep -v prof)
+  for v in $V; do
+    SDX_LIB_PATH=$PWD/seqdex_amd/lib/libseqdex_$v.so timeout 150 python tools/time_physics.py 1024 24 > $O/time_$v.json 2> $O/time_$v.err || tail -2 $O/time_$v.err
+    digest $O/time_$v.json
+  done
+  for v in $(ls seqdex_amd/lib | sed -n 's/^libseqdex_\(.*prof\)\.so$/\1/p'); do for e in 0 1; do
+    SDX_LIB_PATH=$PWD/seqdex_amd/lib/libseqdex_$v.so SDX_DEBUG_ENV=$e timeout 150 python tools/time_physics.py 1024 24 > $O/phase_${v}_env$e.json 2> /dev/null
+    digest $O/phase_${v}_env$e.json
+  done; done
+  ;;
+ablate)   # launch-level attribution of k_physics (profiling build)
+  SDX_LIB_PATH=$PWD/seqdex_amd/lib/libseqdex_prof.so timeout 300 python tools/ablate_physics.py 1024 24 > $O/ablate.json 2> $O/ablate.err || tail -3 $O/ablate.err
+  cat $O/ablate.json
+  ;;
+*) echo "unknown job $job"; exit 2 ;;
+esac

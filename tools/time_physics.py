@@ -39,6 +39,8 @@ ph = {"fk+inertia": d[1] - d[0], "mass_matrix": d[2] - d[1], "drive": d[3] - d[2
       "setup_load": d[23] - d[16], "setup_count": d[24] - d[23], "setup_prefix": d[25] - d[24], "setup_fill": d[26] - d[25],
       "setup_rank": d[27] - d[26], "setup_link_inertia": d[29] - d[28], "setup_weights": d[30] - d[29],
       "setup_tail": d[17] - d[30], "broad_mask": d[32] - d[3], "broad_scan": d[33] - d[32], "expand_box_pairs": d[37] - d[33], "narrow": d[4] - d[37], "narrow_classify_first_chunk": d[38] - d[37], "narrow_rest_of_part1": d[39] - d[38], "narrow_part2_geometry": d[4] - d[39],
+      "broad_scan_and_list": d[40] - d[32], "broad_bound_sat": d[41] - d[40], "broad_winner": d[42] - d[41], "broad_prefix": d[33] - d[42],
+      "fk_constants": d[7] - d[0], "fk_poses": d[8] - d[7], "fk_axes": d[9] - d[8], "fk_twists": d[10] - d[9], "fk_al": d[11] - d[10], "fk_ao_wrenches": d[12] - d[11], "fk_boxes_inertia": d[1] - d[12],
       "it_D": (d[21] if d[21] > d[20] else d[22]) - d[20], "it_robot": (d[22] - d[21]) if d[21] > d[20] else 0, "it_total": d[22] - d[18]}
 cf = s.CONTACT.view(n, 165, 3)[:, :24].abs().sum(dim=(1, 2)).cpu().numpy()
 denv = int(os.environ.get("SDX_DEBUG_ENV", "0"))
@@ -46,4 +48,6 @@ print(json.dumps({"debug_env": denv, "debug_env_contacts": int(nc[denv]), "debug
                   "envs_with_robot_contact": int((cf > 0).sum()), "first_robot_contact_envs": [int(i) for i in (cf > 0).nonzero()[0][:6]],
                   "solver_iters": int(os.environ.get("SDX_TP_ITERS", 16)), "threads_per_env": int(s.lib.sdxk_physics_threads()), "n_envs": n, "k_physics_ms": ms,
                   "env_steps_per_s": n / (ms * 1e-3), "contacts_mean": float(nc.mean()), "contacts_max": int(nc.max()),
+                  "counts_env_substep0": {"body_pairs_after_mask": int(d[48]), "after_bounding_sat": int(d[49]), "candidate_box_pairs": int(d[50]),
+                                          "box_pairs_classified": int(d[51]), "contacts": int(d[52]), "csr_entries": int(d[53]), "robot_entries": int(d[54])},
                   "phase_cycles_env0_substep0": {k: int(v) for k, v in ph.items()}}))
