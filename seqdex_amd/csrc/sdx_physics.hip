@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       // two entries at a time: index loads pinned in front of the 12 payload loads, those in front of the arithmetic (four dependent LDS
       // round trips per trip of four entries instead of eight; all four at once - SDX_D_BATCH - spills inside the loop)
 #pragma unroll 1
-      for (int i = gbeg; i < gend; i += GU * gstride) {
+      for (int i = gbeg; i < (ABL(1) ? gbeg : gend); i += GU * gstride) {
 #pragma unroll
         for (int h2 = 0; h2 < GU; h2 += 2) {
           const int i0 = i + h2 * gstride, i1 = i0 + gstride;

@@ -214,6 +214,276 @@ __global__ __launch_bounds__(64) void k_big_fin(SdxpDev D, int nblocks, int MB, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused heads (round 6)
+// Everything between the last trunk layer's outputs and the trunk's backward pass in ONE launch (+ one reduction): the policy head
+// mu = H_a Wmu^T + b and the two value heads, the per-sample losses of k_big_head, the head gradients dmu / dv, the data gradients
+// dY_2 = (dmu Wmu) * ELU'(H_a), dv w * ELU'(H) of the three networks, and the heads' weight-gradient partials.  Round 5 ran this as 13
+// launches (one 23-column GEMM forward, two row-dot kernels, the loss kernel, its fold, a 23-deep GEMM backward, two value-head backward
+// kernels, a split GEMM + two split kernels for the weight gradients, two reductions): 126 us of a 630 us optimiser step at 2 048
+// rows for 1 % of its flops (profiles/r6_bigmb_kernel_stats_mb2048_before.csv).  A workgroup owns HR = 32 consecutive minibatch rows (times
+// `nrb` such blocks, one after the other, for large minibatches): the three trunk outputs of those rows (96 KB), Wmu and the value
+// weights live in LDS; rows are padded to 260 floats so that 16-byte reads of 8 different rows cover the 32 banks once.
+//   phase 1  thread = (row, 3 actions): mu, 16-byte LDS reads along k; wave 0 also does the two value heads
+//   phase 2  thread = row (32 lanes): the loss formulas of k_big_head, dmu / dv into LDS, loss sums folded over the 32 lanes
+//   phase 3  thread = trunk column k: dY_2 of the three networks for the 32 rows (Wmu's column in registers, dmu broadcast from LDS) and
+//            the column's weight-gradient sums, which stay in registers across the workgroup's row blocks
+// Partials per workgroup: [40 loss sums | G_mu [A][256] | b_mu [A] | g_v [256] b_v | g_cv [256] b_cv]; k_big_heads_reduce folds them over
+// the workgroups in index order (deterministic) into the flat gradients and does k_big_fin's bookkeeping.
+#define HR 32
+#define HU 256              // trunk output width the fused kernel is written for (units[2] of both shipped YAMLs); else the 13-launch path
+#define HLD 260             // padded LDS row
+#define HPZ (BIGP + 23 * HU + 23 + 2 * (HU + 1))
+struct HeadsLds {
+  float H[3][HR][HLD];
+  float Wm[23][HLD];
+  float wv[2][HU];
+  float bmu[24], bv[4];   // (bv padded: mu / dmu rows stay 16-byte aligned)
+  float mu[HR][24], dmu[HR][24];
+  float v[2][HR], dv[2][HR];
+  float red[BIGP], redw[4][BIGP];
+};
+__global__ __launch_bounds__(256) void k_big_heads(SdxpDev D, size_t r0, int MB, int nrb, const float* __restrict__ Ha, const float* __restrict__ Hc,
+                                                   const float* __restrict__ Hcv, float* __restrict__ dYa, float* __restrict__ dYc,
+                                                   float* __restrict__ dYcv, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char heads_smem[];
+  HeadsLds& L = *reinterpret_cast<HeadsLds*>(heads_smem);
+  const int t = threadIdx.x, A = D.act_dim;
+  const float* Hsrc[3] = {Ha, Hc, Hcv};
+  // weights of the heads (once per workgroup)
+  for (int i = t; i < 23 * (HU / 4); i += 256) {
+    const int a = i / (HU / 4), k4 = i % (HU / 4);
+    float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a < A) w = *reinterpret_cast<const float4*>(D.ac + D.off.mu_w + (size_t)a * HU + 4 * k4);
+    *reinterpret_cast<float4*>(&L.Wm[a][4 * k4]) = w;
+  }
+  L.wv[0][t] = D.ac[D.off.v_w + t];
+  L.wv[1][t] = D.cv[D.coff.v_w + t];
+  if (t < 24) L.bmu[t] = t < A ? D.ac[D.off.mu_b + t] : 0.0f;
+  if (t == 32) L.bv[0] = D.ac[D.off.v_b];
+  if (t == 33) L.bv[1] = D.cv[D.coff.v_b];
+  if (t < BIGP) L.red[t] = 0.0f;
+  // phase-3 accumulators of column t, kept across the row blocks
+  float G[23], gv0 = 0.0f, gv1 = 0.0f, bsum = 0.0f;   // bsum: thread a < 23: sum of dmu[.][a]; threads 23, 24: sum of dv[0 / 1][.]
+#pragma unroll
+  for (int a = 0; a < 23; ++a) G[a] = 0.0f;
+  const float invM = 1.0f / (float)MB;
+  const float* ls_p = D.ac + D.off.logstd;
+  for (int rb = 0; rb < nrb; ++rb) {
+    const int s0 = (blockIdx.x * nrb + rb) * HR;
+    if (s0 >= MB) break;                                  // block-uniform
+    __syncthreads();                                      // the previous block's phase 3 is done with H / dmu / dv
+    // ---- phase 0: the three trunk outputs of rows s0 .. s0 + 31 (coalesced 16-byte loads; rows past the minibatch read as zeros)
+    for (int i = t; i < 3 * HR * (HU / 4); i += 256) {
+      const int net = i / (HR * (HU / 4)), rr = (i / (HU / 4)) % HR, k4 = i % (HU / 4);
+      float4 h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (s0 + rr < MB) h = *reinterpret_cast<const float4*>(Hsrc[net] + (size_t)(s0 + rr) * HU + 4 * k4);
+      *reinterpret_cast<float4*>(&L.H[net][rr][4 * k4]) = h;
+    }
+    __syncthreads();
+    // ---- phase 1: heads forward
+    {
+      const int rr = t >> 3, g = t & 7;
+      float acc[3] = {0.0f, 0.0f, 0.0f};
+      const int a0 = g, a1 = g + 8, a2 = g + 16 < 23 ? g + 16 : 22;
+#pragma unroll 4
+      for (int k4 = 0; k4 < HU / 4; ++k4) {
+        const float4 h = *reinterpret_cast<const float4*>(&L.H[0][rr][4 * k4]);
+        const float4 w0 = *reinterpret_cast<const float4*>(&L.Wm[a0][4 * k4]), w1 = *reinterpret_cast<const float4*>(&L.Wm[a1][4 * k4]),
+                     w2 = *reinterpret_cast<const float4*>(&L.Wm[a2][4 * k4]);
+        acc[0] += h.x * w0.x; acc[0] += h.y * w0.y; acc[0] += h.z * w0.z; acc[0] += h.w * w0.w;
+        acc[1] += h.x * w1.x; acc[1] += h.y * w1.y; acc[1] += h.z * w1.z; acc[1] += h.w * w1.w;
+        acc[2] += h.x * w2.x; acc[2] += h.y * w2.y; acc[2] += h.z * w2.z; acc[2] += h.w * w2.w;
+      }
+      L.mu[rr][a0] = acc[0] + L.bmu[a0];
+      L.mu[rr][a1] = acc[1] + L.bmu[a1];
+      if (g + 16 < 23) L.mu[rr][a2] = acc[2] + L.bmu[a2];
+      if (g == 7) L.mu[rr][23] = 0.0f;
+      if (t < 2 * HR) {
+        const int net = t >> 5, r2 = t & 31;
+        float a = 0.0f;
+#pragma unroll 4
+        for (int k4 = 0; k4 < HU / 4; ++k4) {
+          const float4 h = *reinterpret_cast<const float4*>(&L.H[1 + net][r2][4 * k4]);
+          const float4 w = *reinterpret_cast<const float4*>(&L.wv[net][4 * k4]);
+          a += h.x * w.x; a += h.y * w.y; a += h.z * w.z; a += h.w * w.w;
+        }
+        L.v[net][r2] = a + L.bv[net];
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: losses and head gradients (formulas: k_big_head; RC:1796-1830, 2114-2126).  Thread = (row rr, action group g): the
+    // actions g, g + 8, g + 16 of row s0 + rr; the per-row sums over the actions are folded over the 8 lanes of the row (xor 1, 2, 4),
+    // the per-action sums over the rows over the wave's 8 rows (xor 8, 16, 32), then over the 4 waves in index order
+    {
+      const int rr = t >> 3, g = t & 7, s = s0 + rr, wave = t >> 6;
+      const bool live = s < MB;
+      const size_t r = r0 + (live ? s : 0);
+      float nlp = 0.0f, kl = 0.0f, bl = 0.0f, ent = 0.0f;
+      float zq[3], sgq[3], mq[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int a = g + 8 * j;
+        zq[j] = 0.0f; sgq[j] = 1.0f; mq[j] = 0.0f;
+        if (live && a < A) {
+          const float ls = ls_p[a], sg = expf(ls), m = L.mu[rr][a];
+          const float z = (D.mb_actions[r * A + a] - m) / sg;
+          nlp += 0.5f * z * z + ls;
+          const float omu = D.mb_mus[r * A + a], osg = D.mb_sigmas[r * A + a];
+          kl += logf(osg / sg + 1e-5f) + (sg * sg + (omu - m) * (omu - m)) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
+          const float hi = fmaxf(m - 1.1f, 0.0f), lo = fminf(m + 1.1f, 0.0f);
+          bl += hi * hi + lo * lo;
+          ent += 0.5f + 0.5f * 1.8378770664093453f + ls;
+          zq[j] = z; sgq[j] = sg; mq[j] = m;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { nlp += __shfl_xor(nlp, o, 64); kl += __shfl_xor(kl, o, 64); bl += __shfl_xor(bl, o, 64); ent += __shfl_xor(ent, o, 64); }
+      nlp += 0.5f * 1.8378770664093453f * (float)A;
+      float gnlp = 0.0f;
+      float stat[6] = {0, 0, 0, 0, 0, 0};
+      if (live) {
+        const float adv = D.adv[r];
+        const float ratio = expf(D.mb_neglogp[r] - nlp);
+        const float L1 = -adv * ratio, L2 = -adv * clampf(ratio, 1.0f - D.e_clip, 1.0f + D.e_clip);
+        const bool inr = ratio >= 1.0f - D.e_clip && ratio <= 1.0f + D.e_clip;
+        gnlp = (L1 > L2 || inr) ? adv * ratio : 0.0f;
+        if (g == 0) {
+          const float R = D.returns[r], vo = D.mb_values[r];
+          float closs[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float v = L.v[j][rr];
+            const float vcl = vo + clampf(v - vo, -D.e_clip, D.e_clip);
+            const float c1 = (v - R) * (v - R), c2 = (vcl - R) * (vcl - R);
+            float d;
+            if (D.clip_value) {
+              closs[j] = fmaxf(c1, c2);
+              const bool inv = fabsf(v - vo) <= D.e_clip;
+              d = (c1 > c2 || inv) ? 2.0f * (v - R) : 0.0f;
+            } else { closs[j] = c1; d = 2.0f * (v - R); }
+            L.dv[j][rr] = (j == 0 ? 0.5f * D.critic_coef : 1.0f) * d * invM;
+          }
+          stat[0] = fmaxf(L1, L2); stat[1] = closs[0]; stat[2] = bl; stat[3] = kl; stat[4] = closs[1]; stat[5] = ent;
+        }
+      } else if (g == 0) { L.dv[0][rr] = 0.0f; L.dv[1][rr] = 0.0f; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int a = g + 8 * j;
+        float d = 0.0f, dls = 0.0f;
+        if (live && a < A) {
+          const float z = zq[j], sg = sgq[j], m = mq[j];
+          const float hi = fmaxf(m - 1.1f, 0.0f), lo = fminf(m + 1.1f, 0.0f);
+          d = gnlp * (-(z / sg)) * invM + D.bounds_coef * (2.0f * hi + 2.0f * lo) * invM;
+          dls = gnlp * (1.0f - z * z) * invM;
+          D.mb_mus[r * A + a] = m;
+          D.mb_sigmas[r * A + a] = sg;
+        }
+        if (a < 24) L.dmu[rr][a] = d;
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) dls += __shfl_xor(dls, o, 64);
+        if (a < 24 && (t & 56) == 0) L.redw[wave][a] = dls;   // lanes 0 .. 7 of the wave hold the sums over its 8 rows
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float x = stat[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if ((t & 63) == 0) L.redw[wave][32 + j] = x;
+      }
+    }
+    __syncthreads();
+    if (t < BIGP && (t < 24 || (t >= 32 && t < 38))) L.red[t] += (L.redw[0][t] + L.redw[1][t]) + (L.redw[2][t] + L.redw[3][t]);
+    // ---- phase 3: thread = trunk column t
+    {
+      float wcol[23];
+#pragma unroll
+      for (int a = 0; a < 23; ++a) wcol[a] = L.Wm[a][t];
+      const float wv0 = L.wv[0][t], wv1 = L.wv[1][t];
+      const int nrow = MB - s0 < HR ? MB - s0 : HR;
+      for (int rr = 0; rr < nrow; ++rr) {
+        float d[24];
+#pragma unroll
+        for (int q4 = 0; q4 < 6; ++q4) {
+          const float4 x = *reinterpret_cast<const float4*>(&L.dmu[rr][4 * q4]);   // every lane reads the same row: LDS broadcast
+          d[4 * q4] = x.x; d[4 * q4 + 1] = x.y; d[4 * q4 + 2] = x.z; d[4 * q4 + 3] = x.w;
+        }
+        const float ha = L.H[0][rr][t], hc = L.H[1][rr][t], hcv = L.H[2][rr][t];
+        float x = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 23; ++a) { x += d[a] * wcol[a]; G[a] += d[a] * ha; }
+        const size_t o = (size_t)(s0 + rr) * HU + t;
+        dYa[o] = x * belu_grad_from_out(ha);
+        const float d0 = L.dv[0][rr], d1 = L.dv[1][rr];
+        dYc[o] = d0 * wv0 * belu_grad_from_out(hc);
+        dYcv[o] = d1 * wv1 * belu_grad_from_out(hcv);
+        gv0 += d0 * hc; gv1 += d1 * hcv;
+      }
+      if (t < 23) for (int rr = 0; rr < nrow; ++rr) bsum += L.dmu[rr][t];
+      else if (t < 25) for (int rr = 0; rr < nrow; ++rr) bsum += L.dv[t - 23][rr];
+    }
+  }
+  __syncthreads();
+  float* P = part + (size_t)blockIdx.x * HPZ;
+  if (t < BIGP) P[t] = L.red[t];
+#pragma unroll
+  for (int a = 0; a < 23; ++a) P[BIGP + a * HU + t] = G[a];
+  if (t < 23) P[BIGP + 23 * HU + t] = bsum;
+  P[BIGP + 23 * HU + 23 + t] = gv0;
+  P[BIGP + 23 * HU + 23 + HU + 1 + t] = gv1;
+  if (t == 23) P[BIGP + 23 * HU + 23 + HU] = bsum;
+  if (t == 24) P[BIGP + 23 * HU + 23 + HU + 1 + HU] = bsum;
+}
+// fold of the heads' partials over the workgroups (index order: deterministic) into the flat gradients + what k_big_fin does
+__global__ __launch_bounds__(256) void k_big_heads_reduce(SdxpDev D, int nblocks, int MB, const float* __restrict__ part) {
+  __shared__ float s_t[BIGP];
+  const int i = blockIdx.x * 256 + threadIdx.x, A = D.act_dim;
+  float x = 0.0f;
+  if (i < HPZ) {
+    float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, x3 = 0.0f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {   // (four loads in flight; the sum itself stays in block order)
+      x0 = part[(size_t)b * HPZ + i]; x1 = part[(size_t)(b + 1) * HPZ + i]; x2 = part[(size_t)(b + 2) * HPZ + i]; x3 = part[(size_t)(b + 3) * HPZ + i];
+      x = (((x + x0) + x1) + x2) + x3;
+    }
+    for (; b < nblocks; ++b) x += part[(size_t)b * HPZ + i];
+  }
+  const int gi = i - BIGP;
+  if (i >= BIGP && i < HPZ) {
+    if (gi < 23 * HU + 23) {   // [mu_w | mu_b] is contiguous in the flat layout; rows a >= act_dim of the partials are zeros and have no slot
+      const int a = gi < 23 * HU ? gi / HU : gi - 23 * HU;
+      if (a < A) D.ac_g[D.off.mu_w + (gi < 23 * HU ? (size_t)gi : (size_t)A * HU + a)] = x;
+    } else if (gi < 23 * HU + 23 + HU + 1) D.ac_g[D.off.v_w + (gi - (23 * HU + 23))] = x;
+    else D.cv_g[D.coff.v_w + (gi - (23 * HU + 23 + HU + 1))] = x;
+  }
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x < BIGP) s_t[threadIdx.x] = x;
+  __syncthreads();
+  const int j = threadIdx.x;
+  if (j < A) D.ac_g[D.off.logstd + j] = s_t[j] - D.entropy_coef;   // d(-coef * mean entropy)/d logstd = -coef
+  if (j == 0) {
+    SdxpCtrl* ctl = D.ctrl;
+    const float invM = 1.0f / (float)MB;
+    const float kl = s_t[35] * invM;
+    for (int q = 0; q < 6; ++q) ctl->acc[1 + q] = s_t[32 + q];
+    ctl->sum_a_loss += s_t[32] * invM; ctl->sum_c_loss += s_t[33] * invM; ctl->sum_b_loss += s_t[34] * invM;
+    ctl->sum_kl += kl; ctl->sum_cv_loss += s_t[36] * invM; ctl->sum_entropy += s_t[37] * invM;
+    ctl->n_mb += 1; ctl->last_kl = kl;
+    D.ac_g[D.g_tail] = kl;
+    ctl->gn2_ac = 0.0f; ctl->gn2_cv = 0.0f; ctl->ac_pending = 0; ctl->cv_pending = 0;
+    ctl->prev_mb = ctl->mb_index; ctl->prev_mini_epoch = ctl->mini_epoch;
+    int mbn = ctl->mb_index + 1;
+    if (mbn >= D.num_minibatches) { mbn = 0; ctl->mini_epoch += 1; }
+    ctl->mb_index = mbn;
+    ctl->step += 1;
+  }
+}
+static int heads_nrb(int MB) { int n = MB / (HR * 512); return n < 1 ? 1 : n; }
+static int heads_blocks(int MB) { const int nrb = heads_nrb(MB); return (MB + HR * nrb - 1) / (HR * nrb); }
+static bool heads_fused_ok(const SdxpDev& D) {
+  static const int off = getenv("SDXP_BIGMB_FUSED_HEADS") ? atoi(getenv("SDXP_BIGMB_FUSED_HEADS")) == 0 : 0;   // =0: the 13-launch head section (diagnosis)
+  return !off && D.units[2] == HU && D.act_dim <= 23;
+}
+
 // ------------------------------------------------------------------------------------------------ central-value input statistics
 // partial column sums / sums of squares (fp64) of rows [r0 + z * rchunk, ...) of mb_states
 __global__ __launch_bounds__(256) void k_big_colstats(SdxpDev D, size_t r0, int MB, int rchunk, double* __restrict__ part) {
@@ -273,7 +543,9 @@ extern "C" size_t sdxpk_big_part_floats(const SdxpDev* D, int MB) {
   Sh = Sh < S ? S : (Sh > 128 ? 128 : Sh);
   const size_t hp = (size_t)((MB + 255) / 256) * BIGP + (size_t)2 * ((MB + 63) / 64) * (D->units[2] + 1) + (size_t)Sh * (32 * (D->units[2] + 1));
   const size_t need = (size_t)S * mx;
-  return need > hp ? need : hp;      // per network; the workspace holds three such regions
+  const size_t hf = ((size_t)heads_blocks(MB) * HPZ + 2) / 3;   // fused heads: their partials span the three regions
+  const size_t m1 = need > hp ? need : hp;
+  return m1 > hf ? m1 : hf;          // per network; the workspace holds three such regions
 }
 extern "C" int sdxpk_big_nsplit(int MB) { return big_splits(MB); }
 // The NT path (sdx_gemm_nt.h: staged operands, global_load_lds, two LDS stages) serves the trunk products unless SDXP_BIGMB_NT=0 asks for
@@ -369,6 +641,14 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
     }
     gemm<0, 0, 1>(g, 3, 1, st, D.bf16 != 0);
   }
+  if (heads_fused_ok(D)) {
+    static bool attr = false;
+    if (!attr) { attr = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_heads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadsLds)); }
+    const int nrb = heads_nrb(MB), nb = heads_blocks(MB);
+    hipLaunchKernelGGL(k_big_heads, dim3(nb), dim3(256), sizeof(HeadsLds), st, D, r0, MB, nrb, ws->h[0][2], ws->h[1][2], ws->h[2][2], ws->dy[0][2], ws->dy[1][2],
+                       ws->dy[2][2], ws->part);
+    hipLaunchKernelGGL(k_big_heads_reduce, dim3((HPZ + 255) / 256), dim3(256), 0, st, D, nb, MB, ws->part);
+  } else {
   {  // heads
     GemmArgs g = {ws->h[0][2], U2, D.ac + D.off.mu_w, U2, ws->mu, 24, 0, MB, A, U2, U2, D.ac + D.off.mu_b, nullptr, 0, nullptr};
     gemm<0, 0, 2>(&g, 1, 1, st);
@@ -401,6 +681,7 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
     hipLaunchKernelGGL(k_wave_reduce, dim3(((int)pz + 3) / 4), dim3(256), 0, st, ws->part, pz, Sh, (int)pz, D.ac_g + D.off.mu_w);
     hipLaunchKernelGGL(k_vhead_reduce, dim3((2 * (U2 + 1) + 3) / 4), dim3(256), 0, st, vp0, vp1, (size_t)U2 + 1, VS, U2 + 1, D.ac_g + D.off.v_w,
                        D.cv_g + D.coff.v_w);
+  }
   }
   // ---- trunk backward, layer by layer for the three networks at once
   if (ws->nt) {

@@ -125,11 +125,12 @@ def test_update_matches_autograd_adam(adaptive):
         agent.close()
 
 
-@pytest.mark.parametrize("mbsize,critic_coef", [(64, 4.0), (96, 1.0)])
+@pytest.mark.parametrize("mbsize,critic_coef", [(64, 4.0), (96, 1.0), (48, 1.0)])
 def test_large_minibatch_update_matches_autograd_adam(mbsize, critic_coef):
     """minibatch_size > 8 (the insert policy's schedule, cfg/lego/ppo_continuous_insert.yaml: 4096, critic_coef 4) takes the GEMM-shaped
     step of sdxp_bigmb.hip (fp32 MFMA forward / data-gradient / weight-gradient GEMMs, explicit flat gradients, clip + Adam): the
-    whole update phase against torch.autograd + Adam.  96 does not divide the 64-wide tiles: edge handling."""
+    whole update phase against torch.autograd + Adam.  96 does not divide the 64-wide tiles: edge handling; 48 leaves the fused head kernel
+    (k_big_heads: 32 rows per block) a half-empty second block."""
     n = 48
     agent, orc = make_pair(n, minibatch=mbsize, cv_minibatch=mbsize, critic_coef=critic_coef)
     try:

@@ -37,5 +37,20 @@ ablate)   # launch-level attribution of k_physics (profiling build)
   SDX_LIB_PATH=$PWD/seqdex_amd/lib/libseqdex_prof.so timeout 300 python tools/ablate_physics.py 1024 24 > $O/ablate.json 2> $O/ablate.err || tail -3 $O/ablate.err
   cat $O/ablate.json
   ;;
+bigmb_trace)   # per-kernel times of the large-minibatch update at minibatch $1 (default 2048): bench line + rocprofv3 kernel trace
+  MB=${1:-2048}; shift
+  timeout 300 python bench.py --minibatch $MB --steps 5 --warmup 2 --no-cpu-baseline "$@" > $O/bench_mb$MB.json 2> $O/bench_mb$MB.err; echo "bench rc $?"
+  python - <<PY
+import json
+d = json.loads([l for l in open("$O/bench_mb$MB.json") if l.startswith("{")][0])
+print("value %.0f ms/step %.2f update_path %s" % (d["value"], d["ms_per_step"], d.get("update_path")), json.dumps(d.get("roofline_update"))[:600])
+PY
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $O/prof -o r6 -- python bench.py --minibatch $MB --steps 2 --warmup 1 --no-cpu-baseline "$@" > $O/prof.log 2>&1; echo "prof rc $?"
+  db=$(find $O/prof -name "*_results.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py stats $db $O/kernel_stats_mb$MB.csv; rm -rf $O/prof
+  head -40 $O/kernel_stats_mb$MB.csv | cut -c1-150
+  ;;
+ppo_tests)   # PPO parity tests on the device (-k "$1" optional)
+  timeout 1200 python -m pytest tests/test_gpu_ppo_parity.py -q -m gpu -x ${1:+-k "$1"} 2>&1 | tail -15 > $O/tests.txt; tail -8 $O/tests.txt
+  ;;
 *) echo "unknown job $job"; exit 2 ;;
 esac
