@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64) void k_big_fin(SdxpDev D, int nblocks, int MB, 
 //   phase 2  thread = row (32 lanes): the loss formulas of k_big_head, dmu / dv into LDS, loss sums folded over the 32 lanes
 //   phase 3  thread = trunk column k: dY_2 of the three networks for the 32 rows (Wmu's column in registers, dmu broadcast from LDS) and
 //            the column's weight-gradient sums, which stay in registers across the workgroup's row blocks
-// Partials per workgroup: [40 loss sums | G_mu [A][256] | b_mu [A] | g_v [256] b_v | g_cv [256] b_cv]; k_big_heads_reduce folds them over
+// Partials per workgroup: [40: d logstd sums 0 .. 22, loss sums 24 .. 29 | G_mu [A][256] | b_mu [A] | g_v [256] b_v | g_cv [256] b_cv]; k_big_heads_reduce folds them over
 // the workgroups in index order (deterministic) into the flat gradients and does k_big_fin's bookkeeping.
 #define HR 32
 #define HU 256              // trunk output width the fused kernel is written for (units[2] of both shipped YAMLs); else the 13-launch path
@@ -242,7 +242,7 @@ struct HeadsLds {
   float v[2][HR], dv[2][HR];
   float red[BIGP], redw[4][BIGP];
 };
-__global__ __launch_bounds__(256) void k_big_heads(SdxpDev D, size_t r0, int MB, int nrb, const float* __restrict__ Ha, const float* __restrict__ Hc,
+__global__ __launch_bounds__(512) void k_big_heads(SdxpDev D, size_t r0, int MB, int nrb, const float* __restrict__ Ha, const float* __restrict__ Hc,
                                                    const float* __restrict__ Hcv, float* __restrict__ dYa, float* __restrict__ dYc,
                                                    float* __restrict__ dYcv, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char heads_smem[];
@@ -250,19 +250,19 @@ __global__ __launch_bounds__(256) void k_big_heads(SdxpDev D, size_t r0, int MB,
   const int t = threadIdx.x, A = D.act_dim;
   const float* Hsrc[3] = {Ha, Hc, Hcv};
   // weights of the heads (once per workgroup)
-  for (int i = t; i < 23 * (HU / 4); i += 256) {
+  constexpr int NTH = 512;   // 8 waves: two per SIMD (one workgroup per CU: 130 KB of LDS)
+  for (int i = t; i < 23 * (HU / 4); i += NTH) {
     const int a = i / (HU / 4), k4 = i % (HU / 4);
     float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (a < A) w = *reinterpret_cast<const float4*>(D.ac + D.off.mu_w + (size_t)a * HU + 4 * k4);
     *reinterpret_cast<float4*>(&L.Wm[a][4 * k4]) = w;
   }
-  L.wv[0][t] = D.ac[D.off.v_w + t];
-  L.wv[1][t] = D.cv[D.coff.v_w + t];
+  if (t < HU) { L.wv[0][t] = D.ac[D.off.v_w + t]; L.wv[1][t] = D.cv[D.coff.v_w + t]; }
   if (t < 24) L.bmu[t] = t < A ? D.ac[D.off.mu_b + t] : 0.0f;
   if (t == 32) L.bv[0] = D.ac[D.off.v_b];
   if (t == 33) L.bv[1] = D.cv[D.coff.v_b];
   if (t < BIGP) L.red[t] = 0.0f;
-  // phase-3 accumulators of column t, kept across the row blocks
+  // phase-3 accumulators of column (t & 255) over the row half (t >> 8) of every block, kept across the row blocks
   float G[23], gv0 = 0.0f, gv1 = 0.0f, bsum = 0.0f;   // bsum: thread a < 23: sum of dmu[.][a]; threads 23, 24: sum of dv[0 / 1][.]
 #pragma unroll
   for (int a = 0; a < 23; ++a) G[a] = 0.0f;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_big_heads(SdxpDev D, size_t r0, int MB,
     if (s0 >= MB) break;                                  // block-uniform
     __syncthreads();                                      // the previous block's phase 3 is done with H / dmu / dv
     // ---- phase 0: the three trunk outputs of rows s0 .. s0 + 31 (coalesced 16-byte loads; rows past the minibatch read as zeros)
-    for (int i = t; i < 3 * HR * (HU / 4); i += 256) {
+    for (int i = t; i < 3 * HR * (HU / 4); i += NTH) {
       const int net = i / (HR * (HU / 4)), rr = (i / (HU / 4)) % HR, k4 = i % (HU / 4);
       float4 h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (s0 + rr < MB) h = *reinterpret_cast<const float4*>(Hsrc[net] + (size_t)(s0 + rr) * HU + 4 * k4);
@@ -282,11 +282,11 @@ __global__ __launch_bounds__(256) void k_big_heads(SdxpDev D, size_t r0, int MB,
     __syncthreads();
     // ---- phase 1: heads forward
     {
-      const int rr = t >> 3, g = t & 7;
+      const int rr = (t & 255) >> 3, g = t & 7, kh = t >> 8;   // the two halves of k on the two halves of the workgroup
       float acc[3] = {0.0f, 0.0f, 0.0f};
       const int a0 = g, a1 = g + 8, a2 = g + 16 < 23 ? g + 16 : 22;
 #pragma unroll 4
-      for (int k4 = 0; k4 < HU / 4; ++k4) {
+      for (int k4 = kh * (HU / 8); k4 < (kh + 1) * (HU / 8); ++k4) {
         const float4 h = *reinterpret_cast<const float4*>(&L.H[0][rr][4 * k4]);
         const float4 w0 = *reinterpret_cast<const float4*>(&L.Wm[a0][4 * k4]), w1 = *reinterpret_cast<const float4*>(&L.Wm[a1][4 * k4]),
                      w2 = *reinterpret_cast<const float4*>(&L.Wm[a2][4 * k4]);
@@ -294,27 +294,34 @@ __global__ __launch_bounds__(256) void k_big_heads(SdxpDev D, size_t r0, int MB,
         acc[1] += h.x * w1.x; acc[1] += h.y * w1.y; acc[1] += h.z * w1.z; acc[1] += h.w * w1.w;
         acc[2] += h.x * w2.x; acc[2] += h.y * w2.y; acc[2] += h.z * w2.z; acc[2] += h.w * w2.w;
       }
-      L.mu[rr][a0] = acc[0] + L.bmu[a0];
-      L.mu[rr][a1] = acc[1] + L.bmu[a1];
-      if (g + 16 < 23) L.mu[rr][a2] = acc[2] + L.bmu[a2];
-      if (g == 7) L.mu[rr][23] = 0.0f;
-      if (t < 2 * HR) {
-        const int net = t >> 5, r2 = t & 31;
-        float a = 0.0f;
-#pragma unroll 4
-        for (int k4 = 0; k4 < HU / 4; ++k4) {
+      if (kh == 1) { L.dmu[rr][a0] = acc[0]; L.dmu[rr][a1] = acc[1]; if (g + 16 < 23) L.dmu[rr][a2] = acc[2]; }   // (dmu as staging: phase 2 rewrites it)
+      // value heads: (net, row, 8 slices of k) on the upper half's first 512 ... = all 512 threads: 2 x 32 x 8
+      float av = 0.0f;
+      {
+        const int net = t >> 8, r2 = (t & 255) >> 3, ks = t & 7;
+#pragma unroll
+        for (int k4 = ks * (HU / 32); k4 < (ks + 1) * (HU / 32); ++k4) {
           const float4 h = *reinterpret_cast<const float4*>(&L.H[1 + net][r2][4 * k4]);
           const float4 w = *reinterpret_cast<const float4*>(&L.wv[net][4 * k4]);
-          a += h.x * w.x; a += h.y * w.y; a += h.z * w.z; a += h.w * w.w;
+          av += h.x * w.x; av += h.y * w.y; av += h.z * w.z; av += h.w * w.w;
         }
-        L.v[net][r2] = a + L.bv[net];
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) av += __shfl_xor(av, o, 64);
+        if (ks == 0) L.v[net][r2] = av + L.bv[net];
+      }
+      __syncthreads();
+      if (kh == 0) {
+        L.mu[rr][a0] = (acc[0] + L.dmu[rr][a0]) + L.bmu[a0];
+        L.mu[rr][a1] = (acc[1] + L.dmu[rr][a1]) + L.bmu[a1];
+        if (g + 16 < 23) L.mu[rr][a2] = (acc[2] + L.dmu[rr][a2]) + L.bmu[a2];
+        if (g == 7) L.mu[rr][23] = 0.0f;
       }
     }
     __syncthreads();
     // ---- phase 2: losses and head gradients (formulas: k_big_head; RC:1796-1830, 2114-2126).  Thread = (row rr, action group g): the
     // actions g, g + 8, g + 16 of row s0 + rr; the per-row sums over the actions are folded over the 8 lanes of the row (xor 1, 2, 4),
     // the per-action sums over the rows over the wave's 8 rows (xor 8, 16, 32), then over the 4 waves in index order
-    {
+    if (t < 256) {
       const int rr = t >> 3, g = t & 7, s = s0 + rr, wave = t >> 6;
       const bool live = s < MB;
       const size_t r = r0 + (live ? s : 0);
@@ -395,23 +402,25 @@ __global__ __launch_bounds__(256) void k_big_heads(SdxpDev D, size_t r0, int MB,
     if (t < BIGP && (t < 24 || (t >= 32 && t < 38))) L.red[t] += (L.redw[0][t] + L.redw[1][t]) + (L.redw[2][t] + L.redw[3][t]);
     // ---- phase 3: thread = trunk column t
     {
+      const int col = t & 255, rh = t >> 8;
       float wcol[23];
 #pragma unroll
-      for (int a = 0; a < 23; ++a) wcol[a] = L.Wm[a][t];
-      const float wv0 = L.wv[0][t], wv1 = L.wv[1][t];
+      for (int a = 0; a < 23; ++a) wcol[a] = L.Wm[a][col];
+      const float wv0 = L.wv[0][col], wv1 = L.wv[1][col];
       const int nrow = MB - s0 < HR ? MB - s0 : HR;
-      for (int rr = 0; rr < nrow; ++rr) {
+      const int rbeg = rh * (HR / 2), rend = nrow < (rh + 1) * (HR / 2) ? nrow : (rh + 1) * (HR / 2);
+      for (int rr = rbeg; rr < rend; ++rr) {
         float d[24];
 #pragma unroll
         for (int q4 = 0; q4 < 6; ++q4) {
           const float4 x = *reinterpret_cast<const float4*>(&L.dmu[rr][4 * q4]);   // every lane reads the same row: LDS broadcast
           d[4 * q4] = x.x; d[4 * q4 + 1] = x.y; d[4 * q4 + 2] = x.z; d[4 * q4 + 3] = x.w;
         }
-        const float ha = L.H[0][rr][t], hc = L.H[1][rr][t], hcv = L.H[2][rr][t];
+        const float ha = L.H[0][rr][col], hc = L.H[1][rr][col], hcv = L.H[2][rr][col];
         float x = 0.0f;
 #pragma unroll
         for (int a = 0; a < 23; ++a) { x += d[a] * wcol[a]; G[a] += d[a] * ha; }
-        const size_t o = (size_t)(s0 + rr) * HU + t;
+        const size_t o = (size_t)(s0 + rr) * HU + col;
         dYa[o] = x * belu_grad_from_out(ha);
         const float d0 = L.dv[0][rr], d1 = L.dv[1][rr];
         dYc[o] = d0 * wv0 * belu_grad_from_out(hc);
@@ -423,32 +432,37 @@ __global__ __launch_bounds__(256) void k_big_heads(SdxpDev D, size_t r0, int MB,
     }
   }
   __syncthreads();
-  float* P = part + (size_t)blockIdx.x * HPZ;
-  if (t < BIGP) P[t] = L.red[t];
+  // the upper row half's column sums through LDS (the H rows are dead), added to the lower half's in a fixed order
+  float* X = &L.H[0][0][0];   // [25][256]
+  if (t >= 256) {
 #pragma unroll
-  for (int a = 0; a < 23; ++a) P[BIGP + a * HU + t] = G[a];
+    for (int a = 0; a < 23; ++a) X[a * HU + (t & 255)] = G[a];
+    X[23 * HU + (t & 255)] = gv0; X[24 * HU + (t & 255)] = gv1;
+  }
+  __syncthreads();
+  if (t >= 256) return;
+  float* P = part + (size_t)blockIdx.x * HPZ;
+  if (t < BIGP) P[t] = t < 24 ? L.red[t] : (t < 30 ? L.red[t + 8] : 0.0f);   // [0..22] d logstd, [24..29] the six loss sums: all inside the reduction's first block of 32 elements
+#pragma unroll
+  for (int a = 0; a < 23; ++a) P[BIGP + a * HU + t] = G[a] + X[a * HU + t];
   if (t < 23) P[BIGP + 23 * HU + t] = bsum;
-  P[BIGP + 23 * HU + 23 + t] = gv0;
-  P[BIGP + 23 * HU + 23 + HU + 1 + t] = gv1;
+  P[BIGP + 23 * HU + 23 + t] = gv0 + X[23 * HU + t];
+  P[BIGP + 23 * HU + 23 + HU + 1 + t] = gv1 + X[24 * HU + t];
   if (t == 23) P[BIGP + 23 * HU + 23 + HU] = bsum;
   if (t == 24) P[BIGP + 23 * HU + 23 + HU + 1 + HU] = bsum;
 }
 // fold of the heads' partials over the workgroups (index order: deterministic) into the flat gradients + what k_big_fin does
 __global__ __launch_bounds__(256) void k_big_heads_reduce(SdxpDev D, int nblocks, int MB, const float* __restrict__ part) {
   __shared__ float s_t[BIGP];
-  const int i = blockIdx.x * 256 + threadIdx.x, A = D.act_dim;
+  // eight lanes per output element: lane l sums the workgroups b = l, l + 8, ... in order, the eight sums are added in a fixed tree
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), l = threadIdx.x & 7, A = D.act_dim;
   float x = 0.0f;
-  if (i < HPZ) {
-    float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, x3 = 0.0f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {   // (four loads in flight; the sum itself stays in block order)
-      x0 = part[(size_t)b * HPZ + i]; x1 = part[(size_t)(b + 1) * HPZ + i]; x2 = part[(size_t)(b + 2) * HPZ + i]; x3 = part[(size_t)(b + 3) * HPZ + i];
-      x = (((x + x0) + x1) + x2) + x3;
-    }
-    for (; b < nblocks; ++b) x += part[(size_t)b * HPZ + i];
-  }
+  if (i < HPZ) for (int b = l; b < nblocks; b += 8) x += part[(size_t)b * HPZ + i];
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) x += __shfl_xor(x, o, 64);
+  if (l != 0) { if (blockIdx.x != 0) return; }   // (block 0's helper lanes stay for its barrier)
   const int gi = i - BIGP;
-  if (i >= BIGP && i < HPZ) {
+  if (l == 0 && i >= BIGP && i < HPZ) {
     if (gi < 23 * HU + 23) {   // [mu_w | mu_b] is contiguous in the flat layout; rows a >= act_dim of the partials are zeros and have no slot
       const int a = gi < 23 * HU ? gi / HU : gi - 23 * HU;
       if (a < A) D.ac_g[D.off.mu_w + (gi < 23 * HU ? (size_t)gi : (size_t)A * HU + a)] = x;
@@ -456,17 +470,17 @@ __global__ __launch_bounds__(256) void k_big_heads_reduce(SdxpDev D, int nblocks
     else D.cv_g[D.coff.v_w + (gi - (23 * HU + 23 + HU + 1))] = x;
   }
   if (blockIdx.x != 0) return;
-  if (threadIdx.x < BIGP) s_t[threadIdx.x] = x;
+  if (l == 0 && i < 32) s_t[i] = x;    // block 0 folds elements 0 .. 31: the d logstd sums 0 .. 22 and the six loss sums 24 .. 29
   __syncthreads();
   const int j = threadIdx.x;
   if (j < A) D.ac_g[D.off.logstd + j] = s_t[j] - D.entropy_coef;   // d(-coef * mean entropy)/d logstd = -coef
   if (j == 0) {
     SdxpCtrl* ctl = D.ctrl;
     const float invM = 1.0f / (float)MB;
-    const float kl = s_t[35] * invM;
-    for (int q = 0; q < 6; ++q) ctl->acc[1 + q] = s_t[32 + q];
-    ctl->sum_a_loss += s_t[32] * invM; ctl->sum_c_loss += s_t[33] * invM; ctl->sum_b_loss += s_t[34] * invM;
-    ctl->sum_kl += kl; ctl->sum_cv_loss += s_t[36] * invM; ctl->sum_entropy += s_t[37] * invM;
+    const float kl = s_t[27] * invM;
+    for (int q = 0; q < 6; ++q) ctl->acc[1 + q] = s_t[24 + q];
+    ctl->sum_a_loss += s_t[24] * invM; ctl->sum_c_loss += s_t[25] * invM; ctl->sum_b_loss += s_t[26] * invM;
+    ctl->sum_kl += kl; ctl->sum_cv_loss += s_t[28] * invM; ctl->sum_entropy += s_t[29] * invM;
     ctl->n_mb += 1; ctl->last_kl = kl;
     D.ac_g[D.g_tail] = kl;
     ctl->gn2_ac = 0.0f; ctl->gn2_cv = 0.0f; ctl->ac_pending = 0; ctl->cv_pending = 0;
@@ -645,9 +659,9 @@ extern "C" void sdxpk_big_step(const SdxpDev* Dp, const SdxpBigWs* ws, int mb, i
     static bool attr = false;
     if (!attr) { attr = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_heads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadsLds)); }
     const int nrb = heads_nrb(MB), nb = heads_blocks(MB);
-    hipLaunchKernelGGL(k_big_heads, dim3(nb), dim3(256), sizeof(HeadsLds), st, D, r0, MB, nrb, ws->h[0][2], ws->h[1][2], ws->h[2][2], ws->dy[0][2], ws->dy[1][2],
+    hipLaunchKernelGGL(k_big_heads, dim3(nb), dim3(512), sizeof(HeadsLds), st, D, r0, MB, nrb, ws->h[0][2], ws->h[1][2], ws->h[2][2], ws->dy[0][2], ws->dy[1][2],
                        ws->dy[2][2], ws->part);
-    hipLaunchKernelGGL(k_big_heads_reduce, dim3((HPZ + 255) / 256), dim3(256), 0, st, D, nb, MB, ws->part);
+    hipLaunchKernelGGL(k_big_heads_reduce, dim3((HPZ + 31) / 32), dim3(256), 0, st, D, nb, MB, ws->part);
   } else {
   {  // heads
     GemmArgs g = {ws->h[0][2], U2, D.ac + D.off.mu_w, U2, ws->mu, 24, 0, MB, A, U2, U2, D.ac + D.off.mu_b, nullptr, 0, nullptr};

@@ -52,5 +52,17 @@ PY
 ppo_tests)   # PPO parity tests on the device (-k "$1" optional)
   timeout 1200 python -m pytest tests/test_gpu_ppo_parity.py -q -m gpu -x ${1:+-k "$1"} 2>&1 | tail -15 > $O/tests.txt; tail -8 $O/tests.txt
   ;;
+bench)   # the default bench line (+ args)
+  timeout 600 python bench.py "$@" > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
+  python - <<PY
+import json
+d = json.loads([l for l in open("$O/bench.json") if l.startswith("{")][0])
+r = d.get("roofline_update") or {}
+print("value %.0f ms/step %.2f us/opt-step %.2f fps_step %.0f fps_inf %.0f physics ms %.4f" % (d["value"], d["ms_per_step"], r.get("us_per_optimiser_step", 0), d.get("fps_step", 0), d.get("fps_step_and_inference", 0), (d.get("roofline_physics") or {}).get("avg_launch_ms", 0)))
+v = d.get("large_minibatch_variant") or {}
+print("large-minibatch variant:", {k: v.get(k) for k in ("value", "minibatch", "ms_per_step")}, json.dumps(v.get("roofline"))[:400])
+print("cpu_baseline:", json.dumps(d.get("cpu_baseline"))[:300])
+PY
+  ;;
 *) echo "unknown job $job"; exit 2 ;;
 esac
