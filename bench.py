@@ -177,14 +177,17 @@ def gemm_roofline(agent, n, horizon, upd_ms_per_epoch):
             "optimiser_steps_per_epoch": nsteps, "traffic": None}
 
 
-def large_minibatch_variant(train, env, n, horizon, args):
+def large_minibatch_variant(train, env, n, horizon, args, mbs=None):
+    """mbs: minibatch_size of the variant; None = one minibatch of n x horizon samples per mini-epoch (BASELINE.md's labelled row);
+    2048 = the schedule DESIGN.md section 17 recommends for training on this engine (the shipped 4 does not learn to lift here)"""
     import copy
     import torch
     from seqdex_amd.a2c_agent import A2CAgent
     tr = copy.deepcopy({k: v for k, v in train["params"].items() if k != "config"})
     pc = {k: v for k, v in train["params"]["config"].items() if k not in ("vec_env", "env_info")}
     pc = copy.deepcopy(pc)
-    mbs = n * horizon
+    whole = mbs is None
+    mbs = n * horizon if whole else int(mbs)
     pc["minibatch_size"] = mbs
     pc["central_value_config"]["minibatch_size"] = mbs
     pc["mixed_precision"] = bool(args.mixed_precision)
@@ -201,8 +204,10 @@ def large_minibatch_variant(train, env, n, horizon, args):
         play_t += r[1]; upd_t += r[2]
     torch.cuda.synchronize()
     dt = time.time() - t0
-    return {"label": "NOT the shipped schedule: minibatch_size %d instead of 4 (BASELINE.md protocol row; the insert policy ships 4096)%s"
-                     % (mbs, "; bf16 trunk GEMMs, fp32 master weights / accumulation (configs[4])" if args.mixed_precision else ""),
+    return {"label": "NOT the shipped schedule: minibatch_size %d instead of 4 (%s)%s"
+                     % (mbs, "BASELINE.md protocol row; the insert policy ships 4096" if whole else
+                        "the schedule that learns to lift on this engine: DESIGN.md section 17, profiles/r6_grasp_seeds_mb2048.json",
+                        "; bf16 trunk GEMMs, fp32 master weights / accumulation (configs[4])" if args.mixed_precision else ""),
             "minibatch_size": mbs, "dtype": "bf16 (trunk GEMM operands) / f32" if args.mixed_precision else "f32", "value": n * horizon * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3,
             "update_ms_per_epoch": upd_t / args.steps * 1e3, "rollout_ms_per_epoch": play_t / args.steps * 1e3,
         "update_path": ("multi-rank: hipGraph of [forward/backward -> RCCL all-gather of the rank-MB factors -> rebuild + clip + Adam]" if agent.multi_gpu
@@ -389,6 +394,10 @@ def main():
             out["large_minibatch_variant"] = large_minibatch_variant(train, env, n, horizon, args)
         except Exception as ex:
             out["large_minibatch_variant"] = {"value": None, "error": str(ex)}
+        try:    # the same epoch at 2 048-row minibatches (20 optimiser steps per epoch at 1 024 envs): the schedule users are told to train with
+            out["large_minibatch_2048"] = large_minibatch_variant(train, env, n, horizon, args, mbs=2048)
+        except Exception as ex:
+            out["large_minibatch_2048"] = {"value": None, "error": str(ex)}
     if not args.no_cpu_baseline:
         try:
             root = sim.ROOT.view(n, 142, 13).cpu().numpy().copy()

@@ -56,7 +56,7 @@ struct PhysLds {
   float q[ND], qd[ND + 1], qdb[ND + 1], tgt[ND], tau[ND];   // qd[ND] = 0: the padding dof of exhausted paths; qdb: the solver's second copy (read one, write the other)
   float lq[NL][4], la[NL + 1][3], lc[NL][3], lI[NL][6], lmass[NL];   // lmass: link masses (a per-lane global load inside the mass-matrix loop cost it 8 k cycles)
   float lal[NL + 1][3], lao[NL][3], lF[NL][3], lN[NL][3];   // velocity-product terms: angular / origin accelerations at zero qdd, inertial wrenches
-  alignas(16) float A[ND][HP];      // H -> L -> Hinv (rows of 96 bytes: the robot section reads them as ds_read_b128)
+  alignas(16) float A[ND][HP];      // H -> L -> Hinv
   uint32_t anc[NL];     // bit j: dof j lies on the path base -> link
   int par[NL + 1];      // parent link; [NL] = NL: the padding link of exhausted paths (zero rows of the body table)
   float cf[NL][3];
@@ -505,9 +505,11 @@ __device__ __forceinline__ void fk_wave0(const SdxConst* C, PhysLds& S, int tid,
   const int max_depth = C->max_depth;
   for (int d = 1; d <= max_depth; ++d) {
     if (link && dep == d) {
-      const f4 qp = ld4(S.lq[par]);
+      f4 qp = ld4(S.lq[par]);
+      f3 pp = ld3(S.bp[NF + par]);
+      SDX_PIN1(qp.x); SDX_PIN1(qp.y); SDX_PIN1(qp.z); SDX_PIN1(qp.w); SDX_PIN3(pp);   // (the parent's two rows in one LDS round trip per level)
       st4(S.lq[tid], qnormalize(qmul(qp, ql)));
-      st3(S.bp[NF + tid], ld3(S.bp[NF + par]) + qrot(qp, jp));
+      st3(S.bp[NF + tid], pp + qrot(qp, jp));
     }
     WAVE_SYNC();
   }
@@ -717,16 +719,30 @@ __device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int t
       for (int k = j + 1; k < ND; ++k) a[k] -= lij * SDX_READLANE(lij, k);
     }
     SSTAMP(35);
-    // T = L^-1, lane = column c: t[i] = ([i == c] - sum_{k < i} L[i][k] t[k]) / L[i][i], t[k] = 0 above the diagonal; L[i][k] from lane i
+    // T = L^-1, lane = column c: t[i] = ([i == c] - sum_{k < i} L[i][k] t[k]) / L[i][i], t[k] = 0 above the diagonal.  L[i][k] is the same
+    // for every lane: row i of L goes through LDS (lane i writes its row into the free second impulse row, every lane reads it back as
+    // 16-byte broadcast loads that do not depend on the recurrence and run ahead of it).  Round 5 fetched each L[i][k] with a v_readlane
+    // in front of its fma: 253 readlane -> fma pairs in one dependent chain, 9 k cycles; the sums and their order are the same.
     const int c = tid;
+    float* Lrow = &S.P[1][0];   // [ND][HP]
+    if (tid < ND) {
+#pragma unroll
+      for (int k = 0; k < ND; ++k) Lrow[tid * HP + k] = a[k];
+    }
+    WAVE_SYNC();
     float t[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
+      float li[HP];
+#pragma unroll
+      for (int k4 = 0; k4 <= i / 4; ++k4) {
+        const f4v x = *reinterpret_cast<const f4v*>(Lrow + i * HP + 4 * k4);
+        li[4 * k4] = x.x; li[4 * k4 + 1] = x.y; li[4 * k4 + 2] = x.z; li[4 * k4 + 3] = x.w;
+      }
       float sacc = (i == c) ? 1.0f : 0.0f;
 #pragma unroll
-      for (int k = 0; k < i; ++k) sacc -= SDX_READLANE(a[k], i) * t[k];
-      const float lii = SDX_READLANE(a[i], i);
-      t[i] = i >= c ? sacc / lii : 0.0f;
+      for (int k = 0; k < i; ++k) sacc -= li[k] * t[k];
+      t[i] = i >= c ? sacc / li[i] : 0.0f;
     }
     if (tid < ND) {
 #pragma unroll
@@ -1089,7 +1105,7 @@ __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, 
       const int ba = dirb ? b1 : b0, bb = dirb ? b0 : b1, sa = dirb ? sb1 : s0, sb = dirb ? s0 : sb1;
       LOAD_BOX2(ba, sa, bb, sb)
       const Dir D = dir_setup(A, Bx, off);
-      const f3 pb = ((D.t + D.ex * c_samp[sidx][0]) + D.ey * c_samp[sidx][1]) + D.ez * c_samp[sidx][2];
+      const f3 pb = ((D.t + D.ex * S.samp[sidx][0]) + D.ey * S.samp[sidx][1]) + D.ez * S.samp[sidx][2];   // (the LDS copy: a per-lane index into __constant__ memory is a global load)
       f3 g;
       const float sd = sample_contact(D, pb, Bx.h, &g);
       const f3 n = qrot(Bx.q, g);
@@ -1189,6 +1205,28 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   // old ones are in LDS now; the old impulses stay untouched until the end of this solve).
   uint64_t wmatch = ~0ull;
   uint32_t wage = 0;   // 8 bits per contact: consecutive solves it has existed (0: new in this solve)
+  // lower bound of every slot's pair part among the old keys: a branch-free bisection whose trip count depends on nold only, so the lane's
+  // CPT searches advance together - one LDS round trip per halving for all of them (round 6; one search after the other was 10 dependent
+  // round trips per slot)
+  int wlo[CPT];
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) wlo[q] = 0;
+  if (WARM && nold > 0) {
+    int nrem = nold;
+    while (nrem > 1) {
+      const int half = nrem >> 1;
+      uint32_t kv[CPT];
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) kv[q] = (uint32_t)__float_as_int(S.P[2][wlo[q] + half - 1]);
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) SDX_PIN1(kv[q]);
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) wlo[q] = ((kv[q] & 0x0fffffffu) >> 6) < (ckey[q] >> 6) ? wlo[q] + half : wlo[q];
+      nrem -= half;
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) wlo[q] += (((uint32_t)__float_as_int(S.P[2][wlo[q]]) & 0x0fffffffu) >> 6) < (ckey[q] >> 6) ? 1 : 0;
+  }
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
@@ -1196,11 +1234,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       const uint32_t key = ckey[q];
       uint32_t age = 0;
       if (nold > 0) {
-        int lo = 0, hi = nold;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if ((((uint32_t)__float_as_int(S.P[2][mid]) & 0x0fffffffu) >> 6) < (key >> 6)) lo = mid + 1; else hi = mid;
-        }
+        const int lo = wlo[q];
         int found = 0x7ff;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1305,9 +1339,23 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       if (((touched >> k) & 1u) && q < m) {
         const int* pj = reinterpret_cast<const int*>(W + W_J) + k * 11;
         const float* t = W + W_T + k * 66 + r * 11;
-        const float* Aq = S.A[pj[q]];
+        // (all 11 slots' operands in flight together - slots past the path read slot 0 and are not added; the run-time loop over the m
+        // slots was two dependent LDS round trips per slot)
+        int pjq = pj[q], pjv[11];
+        float tv[11], av[11];
+#pragma unroll
+        for (int sidx = 0; sidx < 11; ++sidx) { pjv[sidx] = pj[sidx < m ? sidx : 0]; tv[sidx] = t[sidx < m ? sidx : 0]; }
+        SDX_PIN1(pjq);
+#pragma unroll
+        for (int sidx = 0; sidx < 11; ++sidx) SDX_PIN1(pjv[sidx]);
+        const float* Aq = S.A[pjq];
+#pragma unroll
+        for (int sidx = 0; sidx < 11; ++sidx) av[sidx] = Aq[pjv[sidx]];   // Hinv is symmetric: row j_q instead of column j_q
+#pragma unroll
+        for (int sidx = 0; sidx < 11; ++sidx) { SDX_PIN1(av[sidx]); SDX_PIN1(tv[sidx]); }
         float acc = 0.0f;
-        for (int sidx = 0; sidx < m; ++sidx) acc += t[sidx] * Aq[pj[sidx]];   // Hinv is symmetric: row j_q instead of column j_q
+#pragma unroll
+        for (int sidx = 0; sidx < 11; ++sidx) if (sidx < m) acc += tv[sidx] * av[sidx];
         W[W_U + idx] = acc;
       }
     }
@@ -1321,8 +1369,14 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         const int m = __popc(S.anc[k]);
         const float* u = W + W_U + k * 66 + i * 11;
         const float* t = W + W_T + k * 66 + j * 11;
+        float uv[11], tv[11];
+#pragma unroll
+        for (int sidx = 0; sidx < 11; ++sidx) { uv[sidx] = u[sidx < m ? sidx : 0]; tv[sidx] = t[sidx < m ? sidx : 0]; }
+#pragma unroll
+        for (int sidx = 0; sidx < 11; ++sidx) { SDX_PIN1(uv[sidx]); SDX_PIN1(tv[sidx]); }
         float acc = 0.0f;
-        for (int sidx = 0; sidx < m; ++sidx) acc += u[sidx] * t[sidx];
+#pragma unroll
+        for (int sidx = 0; sidx < 11; ++sidx) if (sidx < m) acc += uv[sidx] * tv[sidx];
         W[W_L + idx] = acc;
       }
     }

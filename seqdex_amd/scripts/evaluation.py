@@ -316,6 +316,65 @@ def prepare_tvalue_and_insert_policy(n, epochs, fit_iters=10000, seed=22, save_t
     return tv, path, st
 
 
+def train_orient_policy(n, epochs, tvalue_state, gate=0.99, seed=22, save_to=None, minibatch=GRASP_TRAIN_MINIBATCH, initial_piles=None):
+    """A BlockAssemblyOrient policy of THIS engine (round 6, VERDICT r5 item 6: the chain's Orient stage played a random initialisation):
+    `epochs` epochs at n envs with the task's shipped schedule but 2 048-row minibatches (as train_grasp_policy; the shipped 4-row schedule
+    does not learn on this engine), under the transition value `tvalue_state` binarised at `gate` (OR:1203: 0.99).
+    Returns (checkpoint path or "", statistics: game reward, piles harvested per brick-type group, outcomes logged, mean T-value of the
+    last step)."""
+    from ..tasks.block_assembly_orient import BlockAssemblyOrient
+    set_seed(seed)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, TASK_CFG["BlockAssemblyOrient"])))
+    cfg["env"]["numEnvs"] = n
+    tr = yaml.safe_load(open(os.path.join(ROOT, TRAIN_CFG["BlockAssemblyOrient"])))
+    tr["params"]["config"]["minibatch_size"] = minibatch
+    tr["params"]["config"]["central_value_config"]["minibatch_size"] = minibatch
+    task = BlockAssemblyOrient(cfg, device_type="cuda", device_id=0, headless=True, seed=seed, tvalue_gate=gate, piles_per_type=64, initial_piles=initial_piles)
+    task.sim.set_tvalue_weights(tvalue_state)
+    env = RLgamesVecTaskPython(task, "cuda:0")
+    tr["params"]["config"].update(num_actors=n, vec_env=env, env_info=env.get_env_info(), seed=seed)
+    agent = A2CAgent("run", tr["params"])
+    t0 = time.time()
+    first = None
+    for ep in range(epochs):
+        agent.train_epoch()
+        if ep == min(99, epochs - 1):
+            first = float(agent.game_rewards.get_mean()[0])
+    torch.cuda.synchronize()
+    st = {"epochs": epochs, "minibatch_size": minibatch, "tvalue_gate": gate, "wall_s": time.time() - t0, "game_reward_after_100_epochs": first,
+          "game_reward": float(agent.game_rewards.get_mean()[0]), "game_length": float(agent.game_lengths.get_mean()[0]),
+          "piles_harvested_per_type(during training)": task.sim.PILE_HARVEST_COUNT.cpu().tolist(),
+          "outcomes_logged(success, failure)": task.sim.TV_COUNT.cpu().tolist(), "tvalue_mean_last_step": float(task.sim.TVALUE.mean()),
+          "tvalue_max_last_step": float(task.sim.TVALUE.max())}
+    path = ""
+    if save_to:
+        agent.save(save_to)
+        path = save_to + ".pth"
+    agent.ppo.close()
+    task.sim.close()
+    return path, st
+
+
+def tvalue_over_random_orientations(tvalue_state, count=200000, seed=0):
+    """what a fitted GraspInsertTValue says about `count` uniformly random orientations (torch on the CPU; a statistic for reports):
+    maximum and the shares above the gates the chain uses"""
+    from ..tvalue_trainer import LAYERS
+    w = torch.from_numpy(np.asarray(tvalue_state, np.float32))
+    off, x = 0, None
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(count, 4, generator=g)
+    x = q / q.norm(dim=1, keepdim=True)
+    for i, (_, out, inn) in enumerate(LAYERS):
+        W = w[off:off + out * inn].view(out, inn); off += out * inn
+        b = w[off:off + out]; off += out
+        x = x @ W.t() + b
+        if i < len(LAYERS) - 1:
+            x = torch.relu(x)
+    t = torch.sigmoid(x)[:, 1]
+    return {"max": float(t.max()), "share_above_0.5": float((t > 0.5).float().mean()), "share_above_0.8": float((t > 0.8).float().mean()),
+            "share_above_0.9": float((t > 0.9).float().mean()), "share_above_0.99": float((t > 0.99).float().mean())}
+
+
 def fill_missing_pile_groups(harvest, counts, min_piles, seed, max_missing=2, keys=None):
     """Brick-type groups Orient could not fill (the gate of a briefly fitted T-value can miss the orientations one brick type settles in)
     start GraspSim from settled piles instead - the states GraspSim generates for itself when it is given none (piles.generate_piles) - as
@@ -495,6 +554,56 @@ def block_assembly_chain_learned(num_envs=1024, grasp_epochs=1500, insert_epochs
     out = {"stage0_insert_policy_and_tvalue(untimed)": ist, "grasp_policy(untimed)": gst, "insert_policy_refit(untimed)": rst, "chain": res,
            "stand_ins": ["Orient plays its random initialisation under T-value gate %s (reference: a trained Orient policy under 0.99)" % res["orient"]["tvalue_gate"]]
            + (["settled piles for Orient's brick-type groups %s" % res["orient"]["settled_stand_in_groups"]] if res["orient"].get("settled_stand_in_groups") else [])}
+    return out, hand
+
+
+def block_assembly_chain_closed(num_envs=1024, insert_epochs=1500, grasp_epochs=1500, insert_refit_epochs=4000, orient_epochs=600, seed=22, workdir=None,
+                                min_grasp_states=100, max_grasp_steps=16000, orient_gates=(0.99,), refit_harvest_per_type=100):
+    """The chain with EVERY stage on a learned policy and the transition value refitted to the policy that actually ends the chain
+    (round 6; scripts/evaluation.py:111-119 on the output of one forward + backward pass of scripts/bi_optimization.py:110-124):
+      stage 0  BlockAssemblyInsertSim trains from synthetic grasp states; GraspInsertTValue is fitted to its outcomes (as the learned chain);
+      stage g  a GraspSim policy is trained under that value's gate 0.8 (GS:1406);
+      stage r  the grasp policy is played from settled piles until every brick-type group has `refit_harvest_per_type` harvested states
+               (round 5 took 64 and the chain itself handed on 32 states in all: VERDICT r5 item 5c), the insert policy is fine-tuned on them AND
+               the transition value is REFITTED to the fine-tuned policy's outcomes (the value the backward legs of the loop hand to GraspSim
+               and Orient, bi_optimization.py:121-124);
+      stage o  a BlockAssemblyOrient policy is TRAINED under the refitted value (round 5: random initialisation);
+      chain    Orient (trained; gate ladder `orient_gates`, default the reference's 0.99 alone) -> GraspSim (trained, gate 0.8, until every group
+               has `min_grasp_states` states) -> InsertSim (fine-tuned).
+    Returns (statistics, hand-off tensors; the caller closes hand["insert_task"].sim)."""
+    import tempfile
+    workdir = workdir or tempfile.mkdtemp(prefix="sdx_chain_closed_")
+    tv0, ipath, ist = prepare_tvalue_and_insert_policy(num_envs, insert_epochs, seed=seed, save_to=os.path.join(workdir, "insert"))
+    if tv0 is None:
+        raise RuntimeError("stage 0 logged too few insert outcomes of a class for a transition value: %s" % ist)
+    gpath, gtask, gst = train_grasp_policy(num_envs, grasp_epochs, seed=seed, save_to=os.path.join(workdir, "grasp"), tvalue_state=tv0)
+    gtask.sim.close()
+    g0, st0 = main_rlgames("BlockAssemblyGraspSim", num_envs, policy_path=gpath, tvalue_state=tv0, steps=160, seed=seed + 1,
+                           until=lambda t: int(t.sim.HARVEST_COUNT.min()) >= refit_harvest_per_type, max_steps=max_grasp_steps,
+                           task_kwargs={"harvest_tvalue_gate": 0.8})
+    cnt0 = g0.sim.HARVEST_COUNT.cpu().tolist()
+    if min(cnt0) == 0:
+        g0.sim.close()
+        raise RuntimeError("the grasp policy harvested no state for a brick-type group under gate 0.8 in %d steps per env: %s" % (st0["steps_per_env"], cnt0))
+    s0 = g0.grasp_terminal_states()
+    g0.sim.close()
+    tv1, ipath1, rst = prepare_tvalue_and_insert_policy(num_envs, insert_refit_epochs, seed=seed, save_to=os.path.join(workdir, "insert_refit"),
+                                                        grasp_states=s0, restore=ipath, synthetic_fallback=False, fit=True)
+    rst["grasp_states_harvested_per_type(settled piles, gate 0.8, %d steps per env)" % st0["steps_per_env"]] = cnt0
+    tv = tv1 if tv1 is not None else tv0
+    tvs = {"stage0": tvalue_over_random_orientations(tv0), "refitted": tvalue_over_random_orientations(tv1) if tv1 is not None else None,
+           "used_by_the_chain": "refitted to the fine-tuned insert policy" if tv1 is not None else "stage 0 (the refit was skipped: %s)" % rst.get("tvalue_fit")}
+    opath, ost = train_orient_policy(num_envs, orient_epochs, tv, gate=orient_gates[0], seed=seed, save_to=os.path.join(workdir, "orient"))
+    res, hand = block_assembly_chain(num_envs, tv, policies={"orient": opath, "grasp": gpath, "insert": ipath1}, synthetic_fallback=False, orient_fallback=True,
+                                     orient_tvalue_gate=tuple(orient_gates), grasp_tvalue_gate=0.8, stage_steps={"grasp": 160},
+                                     min_grasp_states=min_grasp_states, max_grasp_steps=max_grasp_steps, seed=seed)
+    stand_ins = []
+    if res["orient"]["tvalue_gate"] != 0.99:
+        stand_ins.append("Orient's gate %s instead of 0.99 (the ladder's first rung that harvested)" % res["orient"]["tvalue_gate"])
+    if res["orient"].get("settled_stand_in_groups"):
+        stand_ins.append("settled piles for Orient's brick-type groups %s" % res["orient"]["settled_stand_in_groups"])
+    out = {"stage0_insert_policy_and_tvalue(untimed)": ist, "grasp_policy(untimed)": gst, "insert_policy_refit_and_tvalue_refit(untimed)": rst,
+           "orient_policy(untimed)": ost, "tvalue_over_200000_random_orientations": tvs, "chain": res, "stand_ins": stand_ins}
     return out, hand
 
 

@@ -35,6 +35,18 @@ def main():
     assert agent.multi_gpu and agent.rank == rank and agent.rank_size == int(os.environ["WORLD_SIZE"])
     assert agent._collectives().host_staged
     first = {k: agent.ppo.t[k].cpu().numpy().copy() for k in ("AC_PARAMS", "CV_PARAMS")}
+    # everything the update phase of the LAST epoch starts from, taken between its rollout and its update: the test replays the two
+    # ranks' updates in ONE process (collectives emulated by tensor copies) and expects the same parameters bit for bit
+    DATASET = ("AC_PARAMS", "CV_PARAMS", "MB_OBS", "MB_STATES", "MB_ACTIONS", "MB_MUS", "MB_SIGMAS", "MB_NEGLOGP", "MB_VALUES", "RETURNS", "ADVANTAGES",
+               "CV_RMS_MEAN", "CV_RMS_VAR", "STATS", "AC_ADAM_M", "AC_ADAM_V", "CV_ADAM_M", "CV_ADAM_V")
+    snap = {}
+    upd = agent._update_multi_gpu
+
+    def snapshotting_update():
+        torch.cuda.synchronize()
+        snap.update({"pre_" + k: agent.ppo.t[k].cpu().numpy().copy() for k in DATASET})
+        upd()
+    agent._update_multi_gpu = snapshotting_update
     import time
     t0 = time.time()
     for _ in range(epochs):
@@ -45,7 +57,7 @@ def main():
     c = agent.ppo.ctrl()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ac0=first["AC_PARAMS"], cv0=first["CV_PARAMS"],
              ac=agent.ppo.t["AC_PARAMS"].cpu().numpy(), cv=agent.ppo.t["CV_PARAMS"].cpu().numpy(), obs=agent.ppo.t["MB_OBS"].cpu().numpy(),
-             lr=np.float64(agent.last_lr), ac_t=np.int64(int(c.ac_t)), factor_path=np.int64("FACTORS" in agent.ppo.t and minibatch <= 8))
+             lr=np.float64(agent.last_lr), ac_t=np.int64(int(c.ac_t)), factor_path=np.int64("FACTORS" in agent.ppo.t and minibatch <= 8), **snap)
     dist.barrier()
     agent.ppo.close()
     task.sim.close()

@@ -64,5 +64,40 @@ print("large-minibatch variant:", {k: v.get(k) for k in ("value", "minibatch", "
 print("cpu_baseline:", json.dumps(d.get("cpu_baseline"))[:300])
 PY
   ;;
+sweep)   # training runs: $1 = name of the output, $2 = run list "mb:lr:seed:epochs,...", $3 = per-run time box (s)
+  timeout 3400 python tools/train_sweep.py --runs "$2" --out $O/$1.json --max-seconds ${3:-100000} 2> $O/$1.err | cut -c1-600; tail -2 $O/$1.err | cut -c1-300
+  ;;
+profiles)   # the round's evidence: bench lines, kernel trace of the bench command, FETCH / WRITE of its kernels, k_physics counters + phase clocks
+  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
+  timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-large-minibatch > $O/bench_protocol.json 2>> $O/bench.err; echo "protocol rc $?"
+  SDX_FORCE_MULTI_RANK=1 timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-large-minibatch > $O/bench_forced_multi_rank_world1.json 2>> $O/bench.err; echo "forced multi-rank rc $?"
+  pass() { name=$1; shift; timeout -k 5 240 rocprofv3 "$@" > $O/prof_$name.log 2>&1; echo "$name rc=$?"; }
+  summ() { db=$(find $O/prof_$1 -name "*_results.db" | head -1); if [ -n "$db" ]; then python tools/rocpd_summary.py $2 $db $O/$3; else echo "no db for $1"; tail -3 $O/prof_$1.log; fi; rm -rf $O/prof_$1; }
+  SHORT="--steps 1 --warmup 1 --no-cpu-baseline --no-large-minibatch"
+  pass stats --kernel-trace --stats -d $O/prof_stats -o r6 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  summ stats stats bench_kernel_stats.csv
+  pass bfetch --pmc FETCH_SIZE -d $O/prof_bfetch -o r6 -- python bench.py $SHORT
+  summ bfetch pmc bench_pmc_fetch.csv
+  pass bwrite --pmc WRITE_SIZE -d $O/prof_bwrite -o r6 -- python bench.py $SHORT
+  summ bwrite pmc bench_pmc_write.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    pass k$c --pmc $c -d $O/prof_k$c -o r6 -- python tools/time_physics.py 1024 8
+    summ k$c pmc kphysics_pmc_$c.csv
+  done
+  pass ksq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU -d $O/prof_ksq -o r6 -- python tools/time_physics.py 1024 8
+  summ ksq pmc kphysics_pmc_sq.csv
+  pass klds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU -d $O/prof_klds -o r6 -- python tools/time_physics.py 1024 8
+  summ klds pmc kphysics_pmc_lds.csv
+  timeout 150 python tools/time_physics.py 1024 24 > $O/kphysics_time_n1024.json 2>/dev/null; digest $O/kphysics_time_n1024.json
+  for e in 0 1; do SDX_LIB_PATH=$PWD/seqdex_amd/lib/libseqdex_prof.so SDX_DEBUG_ENV=$e timeout 150 python tools/time_physics.py 1024 24 > $O/kphysics_phase_clock_env$e.json 2>/dev/null; done
+  SDX_LIB_PATH=$PWD/seqdex_amd/lib/libseqdex_prof.so timeout 300 python tools/ablate_physics.py 1024 24 > $O/kphysics_ablation.json 2>/dev/null
+  head -6 $O/bench_kernel_stats.csv | cut -c1-120
+  grep -E "k_update_persistent|k_physics" $O/bench_pmc_fetch.csv $O/bench_pmc_write.csv | cut -c1-200
+  grep -h "k_physics" $O/kphysics_pmc_*.csv | grep 524288 | cut -c1-200
+  ;;
+chain_closed)   # the all-learned chain over seeds: $1 = output name, rest = arguments of tools/chain_closed.py
+  name=$1; shift
+  timeout 3400 python tools/chain_closed.py "$@" --out $O/$name.json 2> $O/$name.err | grep -v "^Setting\|amdgpu" | cut -c1-1500; tail -3 $O/$name.err | cut -c1-400
+  ;;
 *) echo "unknown job $job"; exit 2 ;;
 esac
