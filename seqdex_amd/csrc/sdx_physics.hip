@@ -45,6 +45,41 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
   } while (0)
 
+// Barrier among the waves that hold threads 0 .. nthreads-1 only (whole waves; every one of them calls it): a wave announces itself on an
+// LDS counter once its LDS writes have completed and waits until `target` arrivals have been counted.  The counter is monotonic - the
+// caller passes (waves) x (number of calls so far) - and the LDS executes the operations of a CU in issue order, so a wave that has seen
+// the count reads what the others wrote before they signalled.  Used where a few waves have a dependent stage of their own while the rest
+// of the block is busy with independent work (solver loop: link gather -> robot section beside the brick gather); the waves of a
+// workgroup are resident together, so the wait cannot deadlock.
+#ifdef HIPEMU
+#define WAVES_BARRIER(ctr, target, nthreads) hipemu::group_barrier(nthreads)
+#else
+__device__ __forceinline__ void waves_barrier(int* ctr, int target) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+#define WAVES_BARRIER(ctr, target, nthreads) waves_barrier((ctr), (target))
+#endif
+// One wave tells the others that its LDS results up to here are complete (flag = a value that only grows); the others wait for it.
+#ifdef HIPEMU
+// (the emulator runs wave 0 up to its next workgroup barrier before any other wave: the flag is always set when a waiter looks)
+#define WAVE_SIGNAL(flag, value) (*(flag) = (value))
+#define WAVES_WAIT(flag, value) do { if (*(flag) < (value)) __builtin_trap(); } while (0)
+#else
+__device__ __forceinline__ void wave_signal(int* flag, int value) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void waves_wait(int* flag, int value) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < value) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+#define WAVE_SIGNAL(flag, value) wave_signal((flag), (value))
+#define WAVES_WAIT(flag, value) waves_wait((flag), (value))
+#endif
+
 __constant__ float c_samp[SDX_NSAMP][3] = {
     {1, 1, 1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1},
     {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
@@ -91,6 +126,8 @@ struct PhysLds {
   float Qc[NL][12];     // per iteration: generalised impulse the contacts of link k apply to the s-th dof of its path (<= 11 dofs)
   uint32_t desc[ND];    // bit k: link k lies below dof j
   int nc, np, overflow, seg_brick, rebuilt, nrob;
+  int rsync;            // arrivals at the robot waves' own barrier (solver loop), monotonic within a solve
+  int fkflag;           // substep whose forward kinematics wave 0 has finished (the other waves' broadphase of the robot boxes waits for it)
   int eoff[NF + NL + 1], efill[NF + NL];
   int wsum[16];
   // contacts: geometry in LDS for the whole solve
@@ -107,6 +144,7 @@ struct PhysLds {
 #define S_SP0(S) (reinterpret_cast<uint32_t*>(&(S).cp[0][0]))                        // box pair: box a | sub a << 7 | box b << 11 | sub b << 19
 #define S_SP1(S) (reinterpret_cast<uint32_t*>(&(S).cn[0][0]))                        // ... its identity: rank of the body pair << 9 | index of the box pair inside it
 #define S_OFF(S) (reinterpret_cast<int*>(&(S).cn[0][0]) + MAXSP)                     // body pair -> first candidate box pair (exclusive prefix sum)
+#define S_BMASK(S) (reinterpret_cast<uint32_t*>(&(S).cp[0][0]))                       // broadphase hits of lane tid's candidates (bit = trip), NT words; zero between substeps
 #define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[0][0]))                  // unsorted CSR entries (solver set-up)
 #define S_EBODY2(S) (reinterpret_cast<unsigned char*>(&(S).P[1][0]))                 // ... and the body each one belongs to
 static_assert(ND * HP <= MAXC, "L^-1 must fit one row");
@@ -123,6 +161,14 @@ struct Box { f3 c; f4 q; f3 h; };
 #define PSTAMP(i) do { if (threadIdx.x == 0 && e == B.dbg_env && sub == 0) B.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #define SSTAMP(i) do { if (threadIdx.x == 0 && dbg) dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #define SCOUNT(i, v) do { if (threadIdx.x == 0 && dbg) dbg[i] = (long long)(v); } while (0)
+// per-lane measurements of the first solver pass of the debug env: maximum over the block's lanes (slots 55..62 hold maxima since sdx_create)
+#ifdef SDX_LANE_CLOCK   // (its global atomics distort the phase stamps of the passes they measure: a build of its own, make prof VFLAGS=-DSDX_LANE_CLOCK)
+#define LCLOCK(var) const long long var = (long long)__builtin_readcyclecounter()
+#define LMAX(i, v) do { if (dbg) atomicMax(reinterpret_cast<unsigned long long*>(&dbg[i]), (unsigned long long)(v)); } while (0)
+#else
+#define LCLOCK(var) ((void)0)
+#define LMAX(i, v) ((void)0)
+#endif
 // timing ablations of the profiling build (tools/ablate_physics.py): bits of SDX_T_DEBUG[63], read once per workgroup.  A set bit REMOVES a
 // piece of work (the results are then meaningless; the tool restores the state before every launch): 1 the gather loop of [D], 2 the body of
 // [AC], 4 all solver iterations but one, 8 the robot section, 16 the sample classification (no contacts), 32 the broadphase (no pairs),
@@ -132,6 +178,8 @@ struct Box { f3 c; f4 q; f3 h; };
 #define PSTAMP(i) ((void)0)
 #define SSTAMP(i) ((void)0)
 #define SCOUNT(i, v) ((void)0)
+#define LCLOCK(var) ((void)0)
+#define LMAX(i, v) ((void)0)
 #define ABL(bit) 0
 #endif
 
@@ -658,6 +706,10 @@ __device__ __forceinline__ void tri_index(int idx, int* i, int* j) {   // idx ->
 }
 
 // ---------------------------------------------------------------- B: H = M + implicit PD terms, Hinv (once per step)
+// (defined with the broadphase below) part 0 / 1 of the candidate enumeration, tested by the lanes of waves 1.. while wave 0 is busy alone
+template <int NT>
+__device__ __forceinline__ void broad_mask_part(const SdxConst* C, PhysLds& S, int tid, int part);
+
 template <int NT>
 __device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int tid, float h, long long* dbg) {
   const sdx_scene_desc& sc = C->sc;
@@ -748,6 +800,8 @@ __device__ __forceinline__ void mass_matrix(const SdxConst* C, PhysLds& S, int t
 #pragma unroll
       for (int i = 0; i < ND; ++i) S_T(S)[i][c] = t[i];
     }
+  } else {
+    broad_mask_part<NT>(C, S, tid, 1);   // the robot boxes' candidates (their poses are this substep's: FK is done) beside the factorisation
   }
   __syncthreads();
   SSTAMP(36);
@@ -846,28 +900,32 @@ __device__ __forceinline__ bool candidate(const PhysLds& S, int idx, int n1, int
   return box_sdf_val(rc - ld3(S.stc[st]), ld3(S.sth[st])) <= rr0 + off;
 }
 
+// part 0: candidates [0, n1 + n2) - bricks against static bodies and against each other, which need nothing of this substep's robot
+// state; part 1: [n1 + n2, ntot) - the robot boxes, after the forward kinematics.  Lanes 64.. of the block share a part's candidates
+// (stride NT - 64) and set bit idx / NT of word idx % NT for a hit (integer atomics on a word that is zero between substeps).
+template <int NT>
+__device__ __forceinline__ void broad_mask_part(const SdxConst* C, PhysLds& S, int tid, int part) {
+  const sdx_scene_desc& sc = C->sc;
+  constexpr int ns = SDX_MAX_STATIC, per = NF + SDX_MAX_STATIC;
+  constexpr int n1 = NF * ns, n2 = NF * (NF - 1) / 2;
+  const int ntot = n1 + n2 + sc.n_rbox * per;
+  const int lo = part == 0 ? 0 : n1 + n2, hi = part == 0 ? n1 + n2 : ntot;
+#pragma unroll 1
+  for (int idx = lo + tid - 64; idx < hi; idx += NT - 64)
+    if (candidate(S, idx, n1, n2, ns, per, sc.n_static, sc.contact_offset)) atomicOr(&S_BMASK(S)[idx % NT], 1u << (idx / NT));
+}
+
 template <int NT>
 __device__ __forceinline__ void collide(const SdxConst* C, PhysLds& S, int tid, long long* dbg, int abl_bits) {
   const sdx_scene_desc& sc = C->sc;
   const float off = sc.contact_offset;
   constexpr int ns = SDX_MAX_STATIC, per = NF + SDX_MAX_STATIC;
-  const int ns_used = sc.n_static;
-  // ---- broadphase over BODY pairs: lane tid tests candidates tid, tid + NT, ...; hits as a bit mask; ONE block scan places them (lane-major order)
+  // ---- broadphase over BODY pairs: lane tid owns candidates tid, tid + NT, ... (ntot <= 16 NT: sdx_create checks); hits as a bit mask; ONE block scan places them (lane-major order)
   constexpr int n1 = NF * ns, n2 = NF * (NF - 1) / 2;
-  const int n3 = sc.n_rbox * per, ntot = n1 + n2 + n3;   // ntot <= 16 NT (sdx_create checks)
-  // Two passes (round 6; one loop over candidate() cost 20 k cycles per substep: ~12 trips per lane, every one as long as its slowest lane's
-  // oriented-box tests).  Pass 1, unrolled: the FIRST stage of candidate() for each of the lane's candidates - a sphere test on two
-  // 16-byte rows (brick / robot box against brick) or the axis-aligned box test of a static body - with the loads of several trips in
-  // flight; the trip's regime is a compile-time constant for all but two of the 16 trips.  Pass 2: candidate() itself, only for the trips
-  // that passed.  The mask is the one the single loop produced: pass 1 never rejects what candidate() accepts (same expressions, plus a
-  // relative slack of 1e-5 against a differently contracted product).
-  uint32_t mask = 0;
-  if (!ABL(32)) {
-    int it = 0;
-    for (int idx = tid; idx < ntot; idx += NT, ++it) {
-      if (candidate(S, idx, n1, n2, ns, per, ns_used, off)) mask |= 1u << it;
-    }
-  }
+  // (round 6) the candidate tests themselves have run BEFORE this function, on the lanes of waves 1..7 while wave 0 was alone with the
+  // forward kinematics, the factorisation and the drive (broad_mask_part; 19 k cycles per substep when they ran here): the hits of lane
+  // tid's candidates tid, tid + NT, ... are the bits of S_BMASK[tid] - the same mask, whoever computed it
+  const uint32_t mask = ABL(32) ? 0u : S_BMASK(S)[tid];
   SSTAMP(32);
   int np;
   {
@@ -1513,6 +1571,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     S.acount[0][i] = i < NF ? S.ecount[i] : (i == NF ? nrob : 0);
     S.acount[1][i] = 0;
   }
+  if (tid == 0) S.rsync = 0;
   __syncthreads();   // every lane has read what it needs of v / w in the body table (warm-start gate above)
   // body table -> (u, w): u = v - w x x.  Link rows too (their twists are those of the drive phase until the robot section rewrites them)
   for (int i = tid; i < NBODY; i += NT) st3(S.bv[i], ld3(S.bv[i]) - cross(ld3(S.bw[i]), ld3(S.bp[i])));
@@ -1534,12 +1593,14 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     for (int r = 0; r < 3; ++r) { SDX_OPAQUE(lam[q][r]); SDX_OPAQUE(wA[q][r]); SDX_OPAQUE(wB[q][r]); }
   }
   SDX_OPAQUE(gbeg); SDX_OPAQUE(gend); SDX_OPAQUE(tjp);
-  for (int it = (WARM && nold > 0) ? -1 : 0; it < (ABL(4) ? 1 : sc.solver_iters); ++it) {   // it = -1: only the gather of the warm-start impulses
+  const int it0 = (WARM && nold > 0) ? -1 : 0;
+  for (int it = it0; it < (ABL(4) ? 1 : sc.solver_iters); ++it) {   // it = -1: only the gather of the warm-start impulses
 #ifdef SDX_PHASE_CLOCK
     if (it == 1) dbg = nullptr;
 #endif
     SSTAMP(18);
     const int cur = it & 1, nxt = cur ^ 1;
+    LCLOCK(lc_ac0);
     // ---- [AC] lane = contact: relative velocity from the current body table, active flag -> counted for the NEXT iteration (integer
     // atomics), Jacobi update with the counts of the previous iteration; impulse P (on body A) to LDS, zero when inactive
 #pragma unroll
@@ -1591,8 +1652,12 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       __builtin_amdgcn_sched_barrier(0);   // one contact after the other: interleaving the three costs the loop its registers
 #endif
     }
+#ifdef SDX_LANE_CLOCK
+    { LCLOCK(lc_ac1); LMAX(55, lc_ac1 - lc_ac0); if (tid == NT - 1) LMAX(56, lc_ac1 - lc_ac0); }
+#endif
     __syncthreads();
     SSTAMP(20);
+    LCLOCK(lc_d0);
     // ---- [D] gather (LL / GL lanes per body): F = sum(+-P), M = sum(+-(p - x) x P) about the body's reference point x; each lane sums its
     // slice in ascending contact order, the partial sums are combined in a fixed order (deterministic); inactive contacts carry P = 0.
     // Bricks: w += Iw^-1 M, u += F / m - dw x x.  Links: the wrench (F, M about the link origin) is projected on the dofs of the link's
@@ -1634,6 +1699,9 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
           }
         }
       }
+#ifdef SDX_LANE_CLOCK
+      { LCLOCK(lc_d1); LMAX(57, lc_d1 - lc_d0); LMAX(58, (gend - gbeg + gstride - 1) / gstride); if (d_sub == 0) LMAX(60, S.eoff[d_body + 1] - S.eoff[d_body]); }
+#endif
       // the brick update's operands (inverse inertia, inverse mass, u, w: 13 numbers) are requested BEFORE the lane reductions and pinned
       // after them: their LDS round trip runs under the DPP adds instead of after them (every lane loads: the branch comes later)
       const int tb = d_link ? 0 : d_body;
@@ -1667,25 +1735,33 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       }
       if (td == NL * LL) { S.acount[cur][NF] = 0; }
     }
+#ifdef SDX_LANE_CLOCK
+    { LCLOCK(lc_d2); LMAX(59, lc_d2 - lc_d0); }
+#endif
     if (has_robot && !ABL(8)) {
-      // robot section, ONE stage on 8 lanes per link: every group sums the generalised impulses of all 23 dofs from the Qc rows of the
-      // touched links below each dof (3 dofs per lane), shares them inside the group through LDS (wave-synchronous), then
-      // qd += Hinv dQ for the (<= 2) path dofs of this lane and the link's twist
-      __syncthreads();
-      SSTAMP(21);
+      // robot section, ONE stage on 8 lanes per link = waves 0..2, which are also the link gather's: they meet at their OWN barrier (an LDS
+      // counter) while waves 3..7 are still gathering the bricks - the section touches nothing those read or write (Qc, qd / qdb, the link
+      // rows of the body table) - and the pass closes with the one workgroup barrier below (round 6; a workgroup barrier in front of this
+      // section made every pass of an env whose hand touches bricks brick gather + robot section long instead of the longer of the two).
+      // Every group sums the generalised impulses of all 23 dofs from the Qc rows of the touched links below each dof (3 dofs per lane),
+      // shares them inside the group lane to lane (ds_bpermute: no LDS space - the impulse rows are still being read by the brick
+      // gather), then qd += Hinv dQ for the (<= 2) path dofs of this lane and the link's twist
+      static_assert((NL * 8) % 64 == 0, "the robot section's lanes are whole waves");
       int tr = tid;
       SDX_OPAQUE(tr);
-      const int rj = tr / 8, rs = tr % 8;
       if (tr < NL * 8) {
-        float* Qg = W + rj * 24;     // this group's copy of Q (the impulse rows are free between [D] and the next [AC])
+        WAVES_BARRIER(&S.rsync, (NL * 8 / 64) * (it - it0 + 1), NL * 8);
+        SSTAMP(21);
+        const int rj = tr / 8, rs = tr % 8;
+        float qa[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int j = rs + 8 * u;
+          float acc = 0.0f;
           if (j < ND) {
             // the position of dof j in the path of a link below it = the number of dofs above j: the same for every such link
             const int slot = __popc(S.anc[j + 1] & ((1u << j) - 1u));
             uint32_t m = S.desc[j] & touched;
-            float acc = 0.0f;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {          // (independent loads: in flight together)
               const int k = m ? __ffs(m) - 1 : 0;
@@ -1697,17 +1773,30 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
               m &= m - 1;
               acc += S.Qc[k][slot];
             }
-            Qg[j] = acc;
           }
+          qa[u] = acc;
         }
-        WAVE_SYNC();
+
         const int tj0 = tjp & 0xff, tj1 = tjp >> 8;
         const int r0 = tj0 < ND ? tj0 : 0, r1 = tj1 < ND ? tj1 : 0;
         float q0 = 0.0f, q1 = 0.0f;
         const float* qsrc = qpar ? S.qdb : S.qd;
         float* qdst = qpar ? S.qd : S.qdb;
-#pragma unroll 8
-        for (int j = 0; j < ND; ++j) { const float Qj = Qg[j]; q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }   // (fully unrolled, 69 loads in flight pushed 31 registers of the WHOLE kernel into scratch)
+        const int g0 = (tr & 63) & ~7;   // first lane of this group inside its wave
+        // eight dofs per block: Q_j from lane j % 8 of the group; the scheduling barrier keeps the three blocks' loads apart (all 69 in
+        // flight pushed 31 registers of the WHOLE kernel into scratch)
+        // eight dofs per trip of a ROLLED loop (fully unrolled, 69 loads in flight pushed 31 registers of the WHOLE kernel into scratch - also
+        // with scheduling barriers between the blocks): Q_j comes from lane j % 8 of the group
+#pragma unroll 1
+        for (int u = 0; u < 3; ++u) {
+          const float qv = u == 0 ? qa[0] : (u == 1 ? qa[1] : qa[2]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int j = 8 * u + k;
+            const float Qj = __shfl(qv, g0 + k, 64);
+            if (j < ND) { q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }
+          }
+        }
         q0 = tj0 < ND ? qsrc[r0] + q0 : 0.0f;   // qd += Hinv dQ (other groups read the same source copy while the owners write the other one)
         q1 = tj1 < ND ? qsrc[r1] + q1 : 0.0f;
         if (tj0 == rj - 1) qdst[tj0] = q0;      // the link's own dof is written by the lane that holds it (exactly one per dof)
@@ -1850,6 +1939,8 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     st3(S.bv[i], ld3(s + 7));
     st3(S.bw[i], ld3(s + 10));
   }
+  for (int i = tid; i < NT; i += NT) S_BMASK(S)[i] = 0u;
+  if (tid == 0) S.fkflag = 0;
   __syncthreads();
 
   const int nsub = sc.substeps;
@@ -1864,16 +1955,21 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     const sdx_scene_desc& scl = Cs->sc;
     PSTAMP(0);
     if (sub == 0) {   // M(q) is evaluated once per step (frozen over the substeps)
+      // wave 0: forward kinematics + inertias; waves 1..7 meanwhile: the broadphase tests of the brick / brick and brick / static
+      // candidates (part 0), which depend on nothing the robot does in this substep
       if (tl < 64) fk_wave0(Cs, S, tl, true, true, e == B.dbg_env ? B.dbg : nullptr);
+      else if (!ABL(32)) broad_mask_part<NT>(Cs, S, tl, 0);
       __syncthreads();
       PSTAMP(1);
-      if (!ABL(512)) mass_matrix<NT>(Cs, S, tl, h, e == B.dbg_env ? B.dbg : nullptr);
+      if (!ABL(512)) mass_matrix<NT>(Cs, S, tl, h, e == B.dbg_env ? B.dbg : nullptr);   // (part 1 of the mask beside its wave-0 section)
+      else { if (tl >= 64) broad_mask_part<NT>(Cs, S, tl, 1); __syncthreads(); }
       PSTAMP(2);
     }
     // A + C on wave 0 (FK, implicit PD drive (P1), velocity-product bias torques, twists); the other waves: gravity on the free bricks
     if (ABL(256) && sub != 0) {
+      if (tl >= 64) { broad_mask_part<NT>(Cs, S, tl, 0); broad_mask_part<NT>(Cs, S, tl, 1); }
     } else if (tl < 64) {
-      if (sub != 0) fk_wave0(Cs, S, tl, false, true);
+      if (sub != 0) { fk_wave0(Cs, S, tl, false, true); WAVE_SIGNAL(&S.fkflag, sub); }   // (the robot boxes are placed: part 1 of the mask may start)
       if (tl < ND) {
         const float t = scl.kp[tl] * (S.tgt[tl] - S.q[tl]) - (scl.kd[tl] + h * scl.kp[tl]) * S.qd[tl];
         // velocity-product bias torque of dof tl: inertial wrenches of the links below it, projected on its axis
@@ -1909,6 +2005,12 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     } else {
       for (int i = tl - 64; i < NF; i += NT - 64) {
         S.bv[i][0] += scl.gravity[0] * h; S.bv[i][1] += scl.gravity[1] * h; S.bv[i][2] += scl.gravity[2] * h;
+      }
+      // later substeps: both parts of the broadphase mask beside wave 0's FK + drive (the first substep had them beside FK and the factorisation)
+      if (sub != 0 && !ABL(32)) {
+        broad_mask_part<NT>(Cs, S, tl, 0);
+        WAVES_WAIT(&S.fkflag, sub);
+        broad_mask_part<NT>(Cs, S, tl, 1);
       }
     }
     __syncthreads();
@@ -1946,6 +2048,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
       nq.w = q.w + 0.5f * h * dq.w;
       st4(S.bq[i], qnormalize(nq));
     }
+    for (int i = tl; i < NT; i += NT) S_BMASK(S)[i] = 0u;   // (the contact rows are dead between the solve and the next substep's collide)
     __syncthreads();
     PSTAMP(6);
   }

@@ -9,7 +9,7 @@
 namespace hipemu {
 Idx g_tid, g_bid, g_bdim, g_gdim;
 
-enum State { RUN = 0, COLL = 1, BARRIER = 2, DONE = 3 };
+enum State { RUN = 0, COLL = 1, BARRIER = 2, DONE = 3, GBARRIER = 4 };
 struct Fiber {
   void* sp = nullptr;
   char* stack = nullptr;
@@ -66,6 +66,15 @@ static void fiber_main() {
 
 void barrier() {
   g_cur->st = BARRIER;
+  yield_to_scheduler();
+}
+
+static long g_group_barriers = 0;
+extern "C" long hipemu_group_barrier_count() { return g_group_barriers; }   // threads that have passed a subset barrier (tests: was the path taken?)
+void group_barrier(int count) {
+  ++g_group_barriers;
+  g_cur->arg = count;
+  g_cur->st = GBARRIER;
   yield_to_scheduler();
 }
 
@@ -163,6 +172,15 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
             }
           }
           if (all_done) break;
+          {   // a subset barrier opens as soon as all its members have arrived (before any workgroup barrier is considered)
+            int parked = 0, want = 0;
+            for (auto& f : g_f) if (f.st == GBARRIER) { ++parked; want = f.arg; }
+            if (parked > 0 && parked >= want) {
+              for (auto& f : g_f) if (f.st == GBARRIER) f.st = RUN;
+              continue;
+            }
+            if (parked > 0) { fprintf(stderr, "hipemu: %d of %d threads reached a subset barrier and nothing else can run\n", parked, want); abort(); }
+          }
           if (!any_barrier) { fprintf(stderr, "hipemu: block (%u,%u,%u) cannot make progress\n", bx, by, bz); abort(); }
           for (auto& f : g_f) if (f.st == BARRIER) f.st = RUN;
         }

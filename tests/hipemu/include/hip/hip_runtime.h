@@ -64,6 +64,9 @@ struct Idx { unsigned x, y, z; };
 extern Idx g_tid, g_bid, g_bdim, g_gdim;   // refreshed by the scheduler every time a fiber is resumed
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void barrier();
+// barrier among a SUBSET of the block's threads (the kernel's spin-wait on an LDS counter between some of its waves): a thread parks until
+// `count` threads of the block are parked here
+void group_barrier(int count);
 enum { K_BALLOT = 0, K_SHFL = 1, K_SHFL_XOR = 2, K_SHFL_DOWN = 3, K_SHFL_UP = 4, K_WAVE_SYNC = 5, K_DPP = 6 };
 unsigned long long collective(int kind, uint32_t value, int arg, const void* site);
 }  // namespace hipemu

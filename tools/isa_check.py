@@ -12,7 +12,7 @@ SRC = os.path.join(ROOT, "seqdex_amd", "csrc", "sdx_physics.hip")
 KERN = "_Z9k_physicsILi512EEvPK8SdxConst6SdxBuf"
 
 src = open(SRC).read().split("\n")
-lo = next(i for i, l in enumerate(src) if "for (int it = (WARM && nold > 0) ? -1 : 0;" in l) + 1
+lo = next(i for i, l in enumerate(src) if "for (int it = it0;" in l) + 1
 hi = next(i for i, l in enumerate(src) if "SSTAMP(22);" in l and i > lo) + 1
 with tempfile.TemporaryDirectory() as td:
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-gline-tables-only",

@@ -50,4 +50,7 @@ print(json.dumps({"debug_env": denv, "debug_env_contacts": int(nc[denv]), "debug
                   "env_steps_per_s": n / (ms * 1e-3), "contacts_mean": float(nc.mean()), "contacts_max": int(nc.max()),
                   "counts_env_substep0": {"body_pairs_after_mask": int(d[48]), "after_bounding_sat": int(d[49]), "candidate_box_pairs": int(d[50]),
                                           "box_pairs_classified": int(d[51]), "contacts": int(d[52]), "csr_entries": int(d[53]), "robot_entries": int(d[54])},
-                  "phase_cycles_env0_substep0": {k: int(v) for k, v in ph.items()}}))
+                  "phase_cycles_env0_substep0": {k: int(v) for k, v in ph.items()},
+                  # maxima over the block's lanes in the first solver passes of the debug env (profiling build; since sdx_create)
+                  "lane_max_first_passes": {"AC_cycles_slowest_lane": int(d[55]), "AC_cycles_last_lane": int(d[56]), "D_loop_cycles_slowest_lane": int(d[57]),
+                                            "D_entries_per_lane_max": int(d[58]), "D_cycles_slowest_lane_to_barrier": int(d[59]), "csr_degree_max": int(d[60])}}))
