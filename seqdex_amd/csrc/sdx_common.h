@@ -88,6 +88,7 @@ struct SdxBuf {
 #define SDX_RCP(x) (1.0f / (x))
 #define SDX_SQRT_FAST(x) sqrtf(x)
 #define SDX_READLANE(x, lane) __shfl((x), (lane), 64)
+#define SDX_READLANE_I(x, lane) __shfl((x), (lane), 64)
 #define SDX_UNIFORM(x) (x)
 #define SDX_WAIT_VMCNT0() ((void)0)
 #define SDX_LDS_BARRIER() __syncthreads()
@@ -118,6 +119,7 @@ struct SdxBuf {
 #define SDX_RCP(x) __builtin_amdgcn_rcpf(x)   // v_rcp_f32, 1 ulp: the solver's step lengths do not need IEEE division (12 instructions)
 // value of x in a lane known at compile time (v_readlane_b32: the result is wave-uniform, no LDS crossbar); every lane of the wave must be active
 #define SDX_READLANE(x, lane) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (lane)))
+#define SDX_READLANE_I(x, lane) __builtin_amdgcn_readlane((x), (lane))   // the same for an integer
 #define SDX_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // a wave-uniform integer the compiler could not prove uniform -> scalar register
 #endif
 

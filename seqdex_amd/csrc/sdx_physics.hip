@@ -127,6 +127,7 @@ struct PhysLds {
   uint32_t desc[ND];    // bit k: link k lies below dof j
   int nc, np, overflow, seg_brick, rebuilt, nrob;
   int rsync;            // arrivals at the robot waves' own barrier (solver loop), monotonic within a solve
+  uint32_t gtab[NF];    // brick gather lanes of this solve: first lane | lanes << 9 (solve(): the balanced gather's row packing)
   int fkflag;           // substep whose forward kinematics wave 0 has finished (the other waves' broadphase of the robot boxes waits for it)
   int eoff[NF + NL + 1], efill[NF + NL];
   int wsum[16];
@@ -145,6 +146,7 @@ struct PhysLds {
 #define S_SP1(S) (reinterpret_cast<uint32_t*>(&(S).cn[0][0]))                        // ... its identity: rank of the body pair << 9 | index of the box pair inside it
 #define S_OFF(S) (reinterpret_cast<int*>(&(S).cn[0][0]) + MAXSP)                     // body pair -> first candidate box pair (exclusive prefix sum)
 #define S_BMASK(S) (reinterpret_cast<uint32_t*>(&(S).cp[0][0]))                       // broadphase hits of lane tid's candidates (bit = trip), NT words; zero between substeps
+#define S_LANEMAP(S) (reinterpret_cast<unsigned short*>(&(S).P[2][0]))                // solver set-up: lane -> (brick, lane of the brick) of the balanced gather, [NT]
 #define S_ENT2(S) (reinterpret_cast<unsigned short*>(&(S).P[0][0]))                  // unsorted CSR entries (solver set-up)
 #define S_EBODY2(S) (reinterpret_cast<unsigned char*>(&(S).P[1][0]))                 // ... and the body each one belongs to
 static_assert(ND * HP <= MAXC, "L^-1 must fit one row");
@@ -1328,9 +1330,52 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     if (i0 < NB) S.eoff[i0] = excl;
     if (i1 < NB) S.eoff[i1] = excl + c0;
     if (i1 == NB - 1 || i0 == NB - 1) S.eoff[NB] = incl;
+  } else if (tid < 128) {
+    // ---- balanced brick gather (round 6): wave 1, beside the prefix sum.  The per-pass gather [D] used to give every brick 4 lanes: the
+    // brick with the longest list (40 - 60 sides in a settled pile, 19 on average) kept its lanes for 3 - 4 trips while most quads idled -
+    // 4 - 5 k of the pass's 9 k cycles.  Now a brick with n sides gets L = 1, 2, 4, 8 or 16 CONSECUTIVE lanes - the power of two at or
+    // above ceil(n / K) - each summing a contiguous slice of ceil(n / L) <= K sides; the slices meet in a segmented row scan (DPP).
+    // Layout = counting sort by size, largest first: every brick then starts at a multiple of its size and never straddles a 16-lane
+    // row.  K is the smallest of 4, 6, 8, 12, ... 96 whose layout fits the brick lanes (all 512 when the hand touches nothing, else
+    // those of waves 3..7); lane t holds bricks t and t + 64.
+    constexpr int GKT = 10;
+    static_assert(NF <= 128, "two bricks per lane of wave 1");
+    const int t = tid - 64;
+    const bool robot = __ballot(t < NL && S.ecount[NF + (t < NL ? t : 0)] > 0) != 0ull;
+    const int nlanes = robot ? NT - NL * 8 : NT, base = robot ? NL * 8 : 0;
+    const int n0 = S.ecount[t < NF ? t : 0], n1 = t + 64 < NF ? S.ecount[t + 64 < NF ? t + 64 : 0] : 0;
+    const uint64_t lt = t == 0 ? 0ull : (~0ull >> (64 - t));
+    int P0 = 0, P1 = 0, start0 = 0, start1 = 0;
+#pragma unroll 1
+    for (int tk = 0; tk < GKT; ++tk) {
+      const int K = (4 + 2 * (tk & 1)) << (tk >> 1), Kmul = (65536 + K - 1) / K;   // ceil(n / K) = ((n + K - 1) * Kmul) >> 16 for n < 2048
+      int L0 = ((n0 + K - 1) * Kmul) >> 16, L1 = ((n1 + K - 1) * Kmul) >> 16;
+      // size class: 0 (no sides), else the power of two >= min(L, 16)
+      P0 = L0 == 0 ? 0 : (L0 > 8 ? 16 : (L0 > 4 ? 8 : (L0 > 2 ? 4 : L0)));
+      P1 = L1 == 0 ? 0 : (L1 > 8 ? 16 : (L1 > 4 ? 8 : (L1 > 2 ? 4 : L1)));
+      int run = 0;   // lanes of the classes placed so far (wave-uniform)
+      start0 = start1 = 0;
+#pragma unroll
+      for (int c = 16; c >= 1; c >>= 1) {
+        const uint64_t b0 = __ballot(P0 == c), b1 = __ballot(P1 == c);
+        const int c0 = __popcll(b0);
+        if (P0 == c) start0 = run + c * __popcll(b0 & lt);
+        if (P1 == c) start1 = run + c * (c0 + __popcll(b1 & lt));
+        run += c * (c0 + __popcll(b1));
+      }
+      if (run <= nlanes) break;   // (K = 96 always fits: at most 16 bricks can have more than 96 sides)
+    }
+    if (t < NF) S.gtab[t] = (uint32_t)(start0 + base) | ((uint32_t)P0 << 9);
+    if (t + 64 < NF) S.gtab[t + 64] = (uint32_t)(start1 + base) | ((uint32_t)P1 << 9);
   }
+  S_LANEMAP(S)[tid] = 0;   // (wave 0 and 1 after their work: the row of the old warm-start keys is free since the barrier above)
   __syncthreads();
   SSTAMP(25);
+  if (tid < NF) {   // lane -> (brick, lane of the brick, last lane?) of the chosen packing
+    const uint32_t w = S.gtab[tid];
+    const int start = w & 511, L = w >> 9;
+    for (int j = 0; j < L; ++j) S_LANEMAP(S)[start + j] = (unsigned short)(0x8000 | tid | (j << 7) | ((j == L - 1) << 11));
+  }
 #pragma unroll
   for (int q = 0; q < CPT; ++q) {
     const int c = tid + q * NT;
@@ -1344,6 +1389,20 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
   SSTAMP(26);
   const int rbeg = S.eoff[NF], nrob = S.eoff[NB] - rbeg;   // the robot's sides: entries [rbeg, rbeg + nrob), grouped by link
   const bool has_robot = nrob > 0;                          // block-uniform
+  // this lane's slice of a brick's list (balanced gather): brick | lane of the brick << 7 | last lane << 11 | first entry << 12 | entries << 24;
+  // 0 = none.  (Read here: the row that holds the lane map is rewritten by the link-inertia stages below.)
+  uint32_t cdesc = 0;
+  {
+    const uint32_t lm = S_LANEMAP(S)[tid];
+    if (lm & 0x8000u) {
+      const int b = lm & 0x7f, j = (lm >> 7) & 15;
+      const int L = (int)(S.gtab[b] >> 9), n = S.ecount[b];
+      const int c = (n + L - 1) / L;                      // entries per lane of this brick
+      int cnt = n - j * c;
+      cnt = cnt < 0 ? 0 : (cnt > c ? c : cnt);
+      cdesc = (lm & 0xfffu) | ((uint32_t)(S.eoff[b] + j * c) << 12) | ((uint32_t)cnt << 24);
+    }
+  }
   if (tid == 0) S.nrob = nrob;
   SCOUNT(52, nc); SCOUNT(53, S.eoff[NB]); SCOUNT(54, nrob);
   // rank pass: entry -> position = number of entries of the same body with a smaller contact index (a contact touches a body at
@@ -1522,8 +1581,9 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     }
   }
   SSTAMP(30);
-  // gather lanes: LL = 8 per link first (tid = 8 * link + sub: the same lanes run the robot section), then GL = 4 per brick; lane sub sums
-  // entries sub, sub + stride, ... of its body's list
+  // gather lanes.  Links: LL = 8 per link (tid = 8 * link + sub: the same lanes run the robot section; only when the hand touches something),
+  // lane sub sums entries sub, sub + 8, ... of its link's list.  Bricks: the slice of cdesc (balanced gather, above) - kept in gbeg.
+  // (The old fixed map - GL = 4 lanes per brick after the link lanes - still decides which lane computes a brick's bK below.)
   constexpr int LL = 8;
 #ifndef SDX_GU
 #define SDX_GU 4
@@ -1549,6 +1609,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       S.bK[gbody][5] = i0 * ex.y * ex.z + i1 * ey.y * ey.z + i2 * ez.y * ez.z;
     }
   }
+  if (!(has_robot && llane)) { gbeg = (int)cdesc; gend = (int)(((cdesc >> 12) & 0xfffu) + (cdesc >> 24)); }
   // robot section lanes (8 per link): the rs-th and (rs + 8)-th dof on the path base -> link rj (ND = none)
   int tjp = ND | (ND << 8);
   {
@@ -1664,10 +1725,12 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
     // path right away (8 lanes, <= 2 dofs each) -> Qc for the robot section below.
     int td = tid;
     SDX_OPAQUE(td);   // lane coordinates re-derived per iteration instead of living in registers across the loop
-    const bool d_link = td < NL * LL;
-    const int d_body = d_link ? NF + td / LL : (td - NL * LL) / GL, d_sub = d_link ? td % LL : (td - NL * LL) % GL;
-    const int gstride = d_link ? LL : GL;
-    if (d_link || d_body < NF) {
+    const bool d_link = has_robot && td < NL * LL;   // waves 0..2 of an env whose hand touches something: link lanes; every other lane is a brick lane
+    const uint32_t cd = (uint32_t)gbeg;              // (brick lanes: the slice descriptor)
+    const int d_body = d_link ? NF + td / LL : (int)(cd & 0x7fu), d_sub = d_link ? td % LL : 0;
+    const int gstride = d_link ? LL : 1;
+    const int ibeg = d_link ? gbeg : (int)((cd >> 12) & 0xfffu);
+    {
       float acc[6] = {0, 0, 0, 0, 0, 0};
       const f3 x = ld3(S.bp[d_body]);
       // four entries per trip (the index loads, then the payloads, in flight together); not unrolled further: the decoded
@@ -1675,7 +1738,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       // two entries at a time: index loads pinned in front of the 12 payload loads, those in front of the arithmetic (four dependent LDS
       // round trips per trip of four entries instead of eight; all four at once - SDX_D_BATCH - spills inside the loop)
 #pragma unroll 1
-      for (int i = gbeg; i < (ABL(1) ? gbeg : gend); i += GU * gstride) {
+      for (int i = ibeg; i < (ABL(1) ? ibeg : gend); i += GU * gstride) {
 #pragma unroll
         for (int h2 = 0; h2 < GU; h2 += 2) {
           const int i0 = i + h2 * gstride, i1 = i0 + gstride;
@@ -1700,7 +1763,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
         }
       }
 #ifdef SDX_LANE_CLOCK
-      { LCLOCK(lc_d1); LMAX(57, lc_d1 - lc_d0); LMAX(58, (gend - gbeg + gstride - 1) / gstride); if (d_sub == 0) LMAX(60, S.eoff[d_body + 1] - S.eoff[d_body]); }
+      { LCLOCK(lc_d1); LMAX(57, lc_d1 - lc_d0); LMAX(58, (gend - ibeg + gstride - 1) / gstride); }
 #endif
       // the brick update's operands (inverse inertia, inverse mass, u, w: 13 numbers) are requested BEFORE the lane reductions and pinned
       // after them: their LDS round trip runs under the DPP adds instead of after them (every lane loads: the branch comes later)
@@ -1709,13 +1772,30 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
 #pragma unroll
       for (int r = 0; r < 6; ++r) K_[r] = S.bK[tb][r];
       f3 u_ = ld3(S.bv[tb]), w_ = ld3(S.bw[tb]);
+      if (d_link) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        acc[r] = sum4(acc[r]);
-        if (d_link) acc[r] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r]), 0x141, 0xF, 0xF, true));
+        for (int r = 0; r < 6; ++r) {
+          acc[r] = sum4(acc[r]);
+          acc[r] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r]), 0x141, 0xF, 0xF, true));
+        }
+      } else {
+        // the slices of a brick sit on consecutive lanes of one 16-lane row: inclusive segmented scan (row_shr 1, 2, 4, 8; lane `so` of the
+        // brick adds the value `sh` lanes back while that lane still belongs to the brick), after which the brick's LAST lane holds the
+        // sums - slices in ascending contact order, combined in the scan's fixed tree (deterministic)
+        const int so = (int)((cd >> 7) & 15u);
+#define SDX_SEG_STEP(sh)                                                                                                  \
+        {                                                                                                                 \
+          const bool take = so >= (sh);                                                                                   \
+          _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                                 \
+            const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r]), 0x110 + (sh), 0xF, 0xF, true)); \
+            acc[r] += take ? t : 0.0f;                                                                                    \
+          }                                                                                                               \
+        }
+        SDX_SEG_STEP(1) SDX_SEG_STEP(2) SDX_SEG_STEP(4) SDX_SEG_STEP(8)
+#undef SDX_SEG_STEP
       }
       if (!d_link) {
-        if (d_sub == 0) {
+        if ((cd >> 11) & 1u) {
           SDX_PIN4(K_); SDX_PIN1(K_[4]); SDX_PIN1(K_[5]); SDX_PIN1(imb_); SDX_PIN3(u_); SDX_PIN3(w_);
           const float* K = K_;
           const f3 dw = F3(K[0] * acc[3] + K[3] * acc[4] + K[4] * acc[5], K[3] * acc[3] + K[1] * acc[4] + K[5] * acc[5],
@@ -1724,7 +1804,7 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
           st3(S.bw[d_body], w_ + dw);
           S.acount[cur][d_body] = 0;   // read by [AC] before the barrier above; it is the set [AC] of the next iteration counts into
         }
-      } else if (has_robot) {
+      } else {
         const int k = d_body - NF;
         const int tj0 = tjp & 0xff, tj1 = tjp >> 8;
         const f3 F = F3(acc[0], acc[1], acc[2]), M = F3(acc[3], acc[4], acc[5]);
@@ -1750,6 +1830,14 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
       int tr = tid;
       SDX_OPAQUE(tr);
       if (tr < NL * 8) {
+        // (requested before the waves meet: row `lane` of Hinv as six 16-byte loads and the joint velocity it belongs to)
+        const int li = tr & 63, ri = li < ND ? li : 0;
+        const float* qsrc = qpar ? S.qdb : S.qd;
+        float* qdst = qpar ? S.qd : S.qdb;
+        f4v arow[HP / 4];
+#pragma unroll
+        for (int k4 = 0; k4 < HP / 4; ++k4) arow[k4] = *reinterpret_cast<const f4v*>(&S.A[ri][4 * k4]);
+        const float qi = qsrc[li < ND ? li : ND];   // (qd[ND] = 0)
         WAVES_BARRIER(&S.rsync, (NL * 8 / 64) * (it - it0 + 1), NL * 8);
         SSTAMP(21);
         const int rj = tr / 8, rs = tr % 8;
@@ -1776,31 +1864,20 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
           }
           qa[u] = acc;
         }
-
-        const int tj0 = tjp & 0xff, tj1 = tjp >> 8;
-        const int r0 = tj0 < ND ? tj0 : 0, r1 = tj1 < ND ? tj1 : 0;
-        float q0 = 0.0f, q1 = 0.0f;
-        const float* qsrc = qpar ? S.qdb : S.qd;
-        float* qdst = qpar ? S.qd : S.qdb;
-        const int g0 = (tr & 63) & ~7;   // first lane of this group inside its wave
-        // eight dofs per block: Q_j from lane j % 8 of the group; the scheduling barrier keeps the three blocks' loads apart (all 69 in
-        // flight pushed 31 registers of the WHOLE kernel into scratch)
-        // eight dofs per trip of a ROLLED loop (fully unrolled, 69 loads in flight pushed 31 registers of the WHOLE kernel into scratch - also
-        // with scheduling barriers between the blocks): Q_j comes from lane j % 8 of the group
-#pragma unroll 1
-        for (int u = 0; u < 3; ++u) {
-          const float qv = u == 0 ? qa[0] : (u == 1 ? qa[1] : qa[2]);
+        // qd += Hinv dQ, ONCE per wave: lane i < 23 multiplies row i of Hinv with Q, whose entry j every 8-lane group holds in lane j % 8
+        // (v_readlane from the wave's first group: no LDS).  Round 5 had every lane multiply the rows of its (<= 2) path dofs: 46 + 23 LDS
+        // loads per lane in three dependent batches; now 6 + 2.
+        float dq = 0.0f;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int j = 8 * u + k;
-            const float Qj = __shfl(qv, g0 + k, 64);
-            if (j < ND) { q0 += S.A[r0][j] * Qj; q1 += S.A[r1][j] * Qj; }
-          }
+        for (int j = 0; j < ND; ++j) {
+          const f4v a4 = arow[j >> 2];
+          const float aij = (j & 3) == 0 ? a4.x : ((j & 3) == 1 ? a4.y : ((j & 3) == 2 ? a4.z : a4.w));
+          dq += aij * SDX_READLANE(qa[j >> 3], j & 7);
         }
-        q0 = tj0 < ND ? qsrc[r0] + q0 : 0.0f;   // qd += Hinv dQ (other groups read the same source copy while the owners write the other one)
-        q1 = tj1 < ND ? qsrc[r1] + q1 : 0.0f;
-        if (tj0 == rj - 1) qdst[tj0] = q0;      // the link's own dof is written by the lane that holds it (exactly one per dof)
-        if (tj1 == rj - 1) qdst[tj1] = q1;
+        const float qn = li < ND ? qi + dq : 0.0f;
+        if (tr < ND) qdst[tr] = qn;               // the other copy: groups still read the source copy of this pass
+        const int tj0 = tjp & 0xff, tj1 = tjp >> 8;
+        const float q0 = __shfl(qn, tj0, 64), q1 = __shfl(qn, tj1, 64);   // (tj = ND, "no dof": lane ND of the wave holds 0)
         const f3 pk = ld3(S.bp[NF + rj]);
         const f3 a0 = ld3(S.la[tj0 + 1]) * q0, a1 = ld3(S.la[tj1 + 1]) * q1;
         f3 w = a0 + a1;
@@ -2053,28 +2130,32 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     PSTAMP(6);
   }
 
-  // ---- outputs (refresh_* of GS:1091-1095)
-  if (tid < 64) fk_wave0(C, S, tid, false, false);
+  // ---- outputs (refresh_* of GS:1091-1095): wave 0 refreshes the kinematics at the integrated joint positions; the brick rows, the contact
+  // forces and the step's statistics depend on none of that and are written by waves 1..7 meanwhile
+  float* rb_e = B.rb + (size_t)e * SDX_BODIES * 13;
+  if (tid < 64) {
+    fk_wave0(C, S, tid, false, false);
+  } else {
+    for (int i = tid - 64; i < NF * 13; i += NT - 64) {
+      const int k = i / 13, c = i % 13;
+      float v;
+      if (c < 3) {
+        const f3 o = ld3(S.bp[k]) - qrot(ld4(S.bq[k]), ld3(sc.brick_com[sc.brick_type[k]]));
+        v = c == 0 ? o.x : c == 1 ? o.y : o.z;
+      } else if (c < 7) v = S.bq[k][c - 3];
+      else if (c < 10) v = S.bv[k][c - 7];
+      else v = S.bw[k][c - 10];
+      root_e[SDX_ACTOR_BRICK0 * 13 + i] = v;
+      rb_e[SDX_BODY_BRICK0 * 13 + i] = v;
+    }
+    for (int i = tid - 64; i < NL * 3; i += NT - 64) B.contact[(size_t)e * SDX_BODIES * 3 + i] = (&S.cf[0][0])[i] * (1.0f / h);   // net impulse of the last substep / h
+  }
   __syncthreads();
   if (tid < ND) {
     B.dof[((size_t)e * ND + tid) * 2] = S.q[tid];
     B.dof[((size_t)e * ND + tid) * 2 + 1] = S.qd[tid];
   }
   write_kinematics<NT>(C, S, B, e, tid);
-  float* rb_e = B.rb + (size_t)e * SDX_BODIES * 13;
-  for (int i = tid; i < NF * 13; i += NT) {
-    const int k = i / 13, c = i % 13;
-    float v;
-    if (c < 3) {
-      const f3 o = ld3(S.bp[k]) - qrot(ld4(S.bq[k]), ld3(sc.brick_com[sc.brick_type[k]]));
-      v = c == 0 ? o.x : c == 1 ? o.y : o.z;
-    } else if (c < 7) v = S.bq[k][c - 3];
-    else if (c < 10) v = S.bv[k][c - 7];
-    else v = S.bw[k][c - 10];
-    root_e[SDX_ACTOR_BRICK0 * 13 + i] = v;
-    rb_e[SDX_BODY_BRICK0 * 13 + i] = v;
-  }
-  for (int i = tid; i < NL * 3; i += NT) B.contact[(size_t)e * SDX_BODIES * 3 + i] = (&S.cf[0][0])[i] * (1.0f / h);   // net impulse of the last substep / h
   if (tid == 0) {
     B.ncontacts[e] = S.nc + S.overflow;
     if (B.cost) B.cost[e] = (S.nrob > 0 ? 0x10000 : 0) | S.nc;   // what the last substep looked like: the next launch's order

@@ -117,6 +117,11 @@ static void resolve_wave(int lo, int hi) {
         if (f.arg >= 0 && f.arg <= 0xff) src = (lane & ~3) | ((f.arg >> (2 * (lane & 3))) & 3);   // quad_perm
         else if (f.arg == 0x141) src = (lane & ~7) | (7 - (lane & 7));                          // row_half_mirror
         else if (f.arg == 0x140) src = (lane & ~15) | (15 - (lane & 15));                       // row_mirror
+        else if (f.arg > 0x110 && f.arg <= 0x11f) {                                             // row_shr:n, bound_ctrl (old = 0): no source lane inside the row -> 0
+          const int sh = f.arg - 0x110;
+          if ((lane & 15) < sh) { f.result = 0; continue; }
+          src = lane - sh;
+        }
         else { fprintf(stderr, "hipemu: dpp control 0x%x not emulated\n", f.arg); abort(); }
       }
       f.result = (src >= 0 && src < 64 && ((mask >> src) & 1ull)) ? g_f[lo + src].value : f.value;
