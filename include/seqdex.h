@@ -98,7 +98,7 @@ typedef enum {
   SDX_T_SUCCESS_BUF = 25,/* i64 [N]         extras["success_buf"]                GS:459                  */
   SDX_T_PILE_CHOICE = 26,/* i32 [N]         saved-pile index drawn at the last reset of each env  GS:1510 */
   SDX_T_NCONTACTS = 27,  /* i32 [N]         contact points generated in the last substep (diagnostic)    */
-  SDX_T_DEBUG = 28,      /* i64 [64]        phase time stamps (s_memtime) of env 0 in the last k_physics (profiling aid) */
+  SDX_T_DEBUG = 28,      /* i64 [64 + 2N]   profiling build only: [0, 64) phase time stamps (s_memtime) of env SDX_DEBUG_ENV in the last k_physics, then (entry, exit) stamps of every env */
   SDX_T_HARVEST_HAND = 29, /* f32 [8,5001,23,2] saved_grasp_hand_ternimal_states per brick-type group   GS:391-417 */
   SDX_T_HARVEST_OBJ = 30,  /* f32 [8,5001,13]   saved_grasp_object_ternimal_states                       GS:391-417 */
   SDX_T_HARVEST_COUNT = 31,/* i32 [8]           terminal states harvested so far (ring index = count % 5001) GS:1417,1440 */

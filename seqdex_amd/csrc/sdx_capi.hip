@@ -162,7 +162,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(cscratch, 4);   // (contact rows now live in LDS / registers)
   ALLOC(stat, 4);
   ALLOC(step_count, 1);
-  ALLOC(dbg, 64);
+  ALLOC(dbg, 64 + 2 * (size_t)N);
   { const char* de = getenv("SDX_DEBUG_ENV"); B.dbg_env = de ? atoi(de) : 0; }
   ALLOC(harvest_hand, (size_t)8 * SDX_HARVEST_SLOTS * SDX_NDOF * 2);
   ALLOC(harvest_obj, (size_t)8 * SDX_HARVEST_SLOTS * 13);
@@ -223,7 +223,7 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   set_tensor(h, SDX_T_SUCCESS_BUF, B.success_buf, SDX_I64, {N});
   set_tensor(h, SDX_T_PILE_CHOICE, B.pile_choice, SDX_I32, {N});
   set_tensor(h, SDX_T_NCONTACTS, B.ncontacts, SDX_I32, {N});
-  set_tensor(h, SDX_T_DEBUG, B.dbg, SDX_I64, {64});
+  set_tensor(h, SDX_T_DEBUG, B.dbg, SDX_I64, {64 + 2 * (int64_t)N});
   set_tensor(h, SDX_T_HARVEST_HAND, B.harvest_hand, SDX_F32, {8, SDX_HARVEST_SLOTS, SDX_NDOF, 2});
   set_tensor(h, SDX_T_HARVEST_OBJ, B.harvest_obj, SDX_F32, {8, SDX_HARVEST_SLOTS, 13});
   set_tensor(h, SDX_T_HARVEST_COUNT, B.harvest_count, SDX_I32, {8});

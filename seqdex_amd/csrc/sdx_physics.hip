@@ -1685,12 +1685,19 @@ __device__ __forceinline__ void solve(const SdxConst* C, PhysLds& S, int tid, fl
           // (the four body rows in flight together: the plain expression loads side A, waits, then side B into the same registers)
           f3 ua = ld3v(S.bv[a]), wa = ld3v(S.bw[a]), ub = ld3v(S.bv[b]), wb = ld3v(S.bw[b]);
           SDX_PIN3x4(ua, wa, ub, wb);
+#ifdef EXP_EXTRA_ROWS   // sensitivity probe: the four body rows a second time (results unused)
+          { f3 xa = ld3v(S.bv[b]), xb = ld3v(S.bw[b]), xc = ld3v(S.bv[a]), xd = ld3v(S.bw[a]); SDX_PIN3x4(xa, xb, xc, xd); }
+#endif
           const f3 vr = (ua + cross(wa, p)) - (ub + cross(wb, p));
           const float vn = dot(vr, n);
           const float lam0 = lam[q][0], lam1 = lam[q][1], lam2 = lam[q][2];
           if (lam0 > 0.0f || vn < vtgt[q]) {
             if (a != BODY_W) atomicAdd(&S.acount[nxt][sa], 1);
             if (b != BODY_W) atomicAdd(&S.acount[nxt][sb], 1);
+#ifdef EXP_EXTRA_ATOMICS   // sensitivity probe: the same two atomics again on a dead array
+            if (a != BODY_W) atomicAdd(&S.efill[sa], 1);
+            if (b != BODY_W) atomicAdd(&S.efill[sb], 1);
+#endif
             const int ca = S.acount[cur][sa], cb = S.acount[cur][sb];
             const float na = a != BODY_W ? (float)(ca > 1 ? ca : 1) : 0.0f;
             const float nb = b != BODY_W ? (float)(cb > 1 ? cb : 1) : 0.0f;
@@ -2001,20 +2008,35 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
   constexpr int abl_bits = 0;
 #endif
 
-  // ---- load per-env state (coalesced rows) into LDS
-  load_constants<NT>(C, S, e, tid);
-  if (tid < ND) {
-    S.q[tid] = B.dof[((size_t)e * ND + tid) * 2];
-    S.qd[tid] = B.dof[((size_t)e * ND + tid) * 2 + 1];
-    S.tgt[tid] = B.targets[(size_t)e * ND + tid];
+  // this env's cycle count decides its place in the NEXT launch's order (k_order below): the clock is read by thread 0 at entry and exit
+  const long long t_in = (long long)__builtin_readcyclecounter();
+#ifdef SDX_PHASE_CLOCK
+  if (threadIdx.x == 0) {
+    B.dbg[64 + 2 * e] = t_in;                 // (entry, exit) of every env
+    if (e == B.dbg_env) B.dbg[13] = t_in;     // kernel entry of the debug env
   }
-  for (int i = tid; i < NF; i += NT) {
-    const float* s = root_e + (SDX_ACTOR_BRICK0 + i) * 13;
-    const f4 q = qnormalize(ld4(s + 3));
-    st4(S.bq[i], q);
-    st3(S.bp[i], ld3(s) + qrot(q, ld3(sc.brick_com[sc.brick_type[i]])));
-    st3(S.bv[i], ld3(s + 7));
-    st3(S.bw[i], ld3(s + 10));
+#endif
+  // ---- load per-env state (coalesced rows) into LDS.  The state rows are requested first and stored last: their HBM / L2 round trips run
+  // beside the (dependent) loads of the scene constants instead of after them
+  static_assert(NF <= NT, "one brick per lane");
+  float r_q = 0.0f, r_qd = 0.0f, r_tg = 0.0f;
+  if (tid < ND) {
+    r_q = B.dof[((size_t)e * ND + tid) * 2];
+    r_qd = B.dof[((size_t)e * ND + tid) * 2 + 1];
+    r_tg = B.targets[(size_t)e * ND + tid];
+  }
+  const float* srow = root_e + (SDX_ACTOR_BRICK0 + (tid < NF ? tid : 0)) * 13;
+  const f3 r_p = ld3(srow), r_v = ld3(srow + 7), r_w = ld3(srow + 10);
+  const f4 r_o = ld4(srow + 3);
+  const f3 r_com = ld3(sc.brick_com[sc.brick_type[tid < NF ? tid : 0]]);
+  load_constants<NT>(C, S, e, tid);
+  if (tid < ND) { S.q[tid] = r_q; S.qd[tid] = r_qd; S.tgt[tid] = r_tg; }
+  if (tid < NF) {
+    const f4 q = qnormalize(r_o);
+    st4(S.bq[tid], q);
+    st3(S.bp[tid], r_p + qrot(q, r_com));
+    st3(S.bv[tid], r_v);
+    st3(S.bw[tid], r_w);
   }
   for (int i = tid; i < NT; i += NT) S_BMASK(S)[i] = 0u;
   if (tid == 0) S.fkflag = 0;
@@ -2130,6 +2152,9 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
     PSTAMP(6);
   }
 
+#ifdef SDX_PHASE_CLOCK
+  if (threadIdx.x == 0 && e == B.dbg_env) B.dbg[15] = (long long)__builtin_readcyclecounter();   // end of the last substep
+#endif
   // ---- outputs (refresh_* of GS:1091-1095): wave 0 refreshes the kinematics at the integrated joint positions; the brick rows, the contact
   // forces and the step's statistics depend on none of that and are written by waves 1..7 meanwhile
   float* rb_e = B.rb + (size_t)e * SDX_BODIES * 13;
@@ -2158,32 +2183,44 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void k_physics(const SdxConst* __
   write_kinematics<NT>(C, S, B, e, tid);
   if (tid == 0) {
     B.ncontacts[e] = S.nc + S.overflow;
-    if (B.cost) B.cost[e] = (S.nrob > 0 ? 0x10000 : 0) | S.nc;   // what the last substep looked like: the next launch's order
+    // what this step cost: the next launch's order.  Round 6: the measured cycles of the env (units of 4096) instead of (hand touches
+    // something, contact count), whose correlation with the cycles was 0.5 - a fifth of the launch was slots waiting for the slowest pair
+    if (B.cost) B.cost[e] = (int)(((long long)__builtin_readcyclecounter() - t_in) >> 12);
   }
+#ifdef SDX_PHASE_CLOCK
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long t_out = (long long)__builtin_readcyclecounter();
+    B.dbg[64 + 2 * e + 1] = t_out;
+    if (e == B.dbg_env) B.dbg[14] = t_out;    // all outputs issued
+  }
+#endif
 }
 
-// ---- launch order of the next step: envs whose last step had robot contacts first (their solver iterations carry the robot section:
-// 685 k against 511 k cycles per step), then by contact count, in 64 buckets.  With 2 workgroups per CU and N = 1024 every CU slot runs
-// two envs back to back; in env order two slow ones can meet on one slot (makespan 2 x slow), longest-first pairs slow with fast.
-// The order inside a bucket is whatever the atomics give: it cannot change any result (envs are independent).
+// ---- launch order of the next step: the envs by the cycles their last step took (k_physics measures them), longest first, in 256 buckets of
+// 4096 cycles.  With 2 workgroups per CU and N = 1024 every CU slot runs two envs back to back; in env order two slow ones can meet on one
+// slot (makespan 2 x slow), longest-first pairs the slowest with the fastest.  (Rounds 3-5 sorted by "hand touches something" and the contact
+// count; round 6 measured a correlation of 0.5 between that key and the cycles: env 589 k cycles on average, 505 k / 656 k at the 10th / 90th
+// percentile, 854 k the slowest - and the launch took 1.42 M cycles where the slots' average load was 1.18 M.)
+// The order inside a bucket is whatever the atomics give, and the buckets depend on clocks: neither can change any result (envs are independent).
 __global__ __launch_bounds__(1024) void k_order(SdxBuf B) {
-  __shared__ int hist[64], base[64];
+  __shared__ int hist[256], base[256];
   const int tid = threadIdx.x;
-  if (tid < 64) hist[tid] = 0;
+  if (tid < 256) hist[tid] = 0;
   __syncthreads();
   for (int e = tid; e < B.N; e += 1024) {
-    const int c = B.cost[e], nc = c & 0xffff;
-    atomicAdd(&hist[(c >> 16 ? 32 : 0) + (nc / 48 < 31 ? nc / 48 : 31)], 1);
+    const int c = B.cost[e];
+    atomicAdd(&hist[c < 0 ? 0 : (c > 255 ? 255 : c)], 1);
   }
   __syncthreads();
   if (tid == 0) {
     int run = 0;
-    for (int k = 63; k >= 0; --k) { base[k] = run; run += hist[k]; }
+    for (int k = 255; k >= 0; --k) { base[k] = run; run += hist[k]; }
   }
   __syncthreads();
   for (int e = tid; e < B.N; e += 1024) {
-    const int c = B.cost[e], nc = c & 0xffff;
-    B.order[atomicAdd(&base[(c >> 16 ? 32 : 0) + (nc / 48 < 31 ? nc / 48 : 31)], 1)] = e;
+    const int c = B.cost[e];
+    B.order[atomicAdd(&base[c < 0 ? 0 : (c > 255 ? 255 : c)], 1)] = e;
   }
 }
 
