@@ -470,7 +470,8 @@ def block_assembly_chain(num_envs=512, tvalue_state=None, policies=None, control
                                  task_kwargs={"initial_piles": piles, "harvest_tvalue_gate": gate})
         cnt = grasp.sim.HARVEST_COUNT.cpu().numpy()
         gtried.append({"tvalue_gate": gate, "grasp_states_harvested_per_type": cnt.tolist()})
-        if int((cnt > 0).sum()) >= 3 or gi + 1 == len(gladder):
+        # (next rung: fewer than three groups harvested - or, when no stand-in states are allowed, any group without a state)
+        if (int((cnt > 0).sum()) >= 3 and (synthetic_fallback or cnt.min() > 0)) or gi + 1 == len(gladder):
             break
         gprobe += st["wall_s"]
         grasp.sim.close()
@@ -558,7 +559,7 @@ def block_assembly_chain_learned(num_envs=1024, grasp_epochs=1500, insert_epochs
 
 
 def block_assembly_chain_closed(num_envs=1024, insert_epochs=1500, grasp_epochs=1500, insert_refit_epochs=4000, orient_epochs=600, seed=22, workdir=None,
-                                min_grasp_states=100, max_grasp_steps=16000, orient_gates=(0.99,), refit_harvest_per_type=100):
+                                min_grasp_states=100, max_grasp_steps=16000, orient_gates=(0.99,), refit_harvest_per_type=100, grasp_gates=(0.8,)):
     """The chain with EVERY stage on a learned policy and the transition value refitted to the policy that actually ends the chain
     (round 6; scripts/evaluation.py:111-119 on the output of one forward + backward pass of scripts/bi_optimization.py:110-124):
       stage 0  BlockAssemblyInsertSim trains from synthetic grasp states; GraspInsertTValue is fitted to its outcomes (as the learned chain);
@@ -578,26 +579,40 @@ def block_assembly_chain_closed(num_envs=1024, insert_epochs=1500, grasp_epochs=
         raise RuntimeError("stage 0 logged too few insert outcomes of a class for a transition value: %s" % ist)
     gpath, gtask, gst = train_grasp_policy(num_envs, grasp_epochs, seed=seed, save_to=os.path.join(workdir, "grasp"), tvalue_state=tv0)
     gtask.sim.close()
-    g0, st0 = main_rlgames("BlockAssemblyGraspSim", num_envs, policy_path=gpath, tvalue_state=tv0, steps=160, seed=seed + 1,
-                           until=lambda t: int(t.sim.HARVEST_COUNT.min()) >= refit_harvest_per_type, max_steps=max_grasp_steps,
-                           task_kwargs={"harvest_tvalue_gate": 0.8})
-    cnt0 = g0.sim.HARVEST_COUNT.cpu().tolist()
+    # the harvest gate: GS:1406's 0.8 first; `grasp_gates` may continue with lower rungs for the seeds whose stage-0 value rates every
+    # grasp of some brick type below 0.8 (two of three seeds in profiles/r6_chain_closed_seeds_22_23_24_first_attempt.json) - a rung
+    # below 0.8 is reported as a stand-in
+    tried0 = []
+    for gi, gate0 in enumerate(grasp_gates):
+        g0, st0 = main_rlgames("BlockAssemblyGraspSim", num_envs, policy_path=gpath, tvalue_state=tv0, steps=160, seed=seed + 1,
+                               until=lambda t: int(t.sim.HARVEST_COUNT.min()) >= refit_harvest_per_type, max_steps=max_grasp_steps,
+                               task_kwargs={"harvest_tvalue_gate": gate0})
+        cnt0 = g0.sim.HARVEST_COUNT.cpu().tolist()
+        tried0.append({"tvalue_gate": gate0, "grasp_states_harvested_per_type": cnt0, "steps_per_env": st0["steps_per_env"]})
+        if min(cnt0) > 0 or gi + 1 == len(grasp_gates):
+            break
+        g0.sim.close()
     if min(cnt0) == 0:
         g0.sim.close()
-        raise RuntimeError("the grasp policy harvested no state for a brick-type group under gate 0.8 in %d steps per env: %s" % (st0["steps_per_env"], cnt0))
+        raise RuntimeError("the grasp policy harvested no state for a brick-type group under the gates %s in %d steps per env: %s" % (list(grasp_gates), st0["steps_per_env"], cnt0))
     s0 = g0.grasp_terminal_states()
     g0.sim.close()
     tv1, ipath1, rst = prepare_tvalue_and_insert_policy(num_envs, insert_refit_epochs, seed=seed, save_to=os.path.join(workdir, "insert_refit"),
                                                         grasp_states=s0, restore=ipath, synthetic_fallback=False, fit=True)
-    rst["grasp_states_harvested_per_type(settled piles, gate 0.8, %d steps per env)" % st0["steps_per_env"]] = cnt0
+    rst["grasp_states_harvested_per_type(settled piles, gate %s, %d steps per env)" % (gate0, st0["steps_per_env"])] = cnt0
+    rst["refit_harvest_gates_tried"] = tried0
     tv = tv1 if tv1 is not None else tv0
     tvs = {"stage0": tvalue_over_random_orientations(tv0), "refitted": tvalue_over_random_orientations(tv1) if tv1 is not None else None,
            "used_by_the_chain": "refitted to the fine-tuned insert policy" if tv1 is not None else "stage 0 (the refit was skipped: %s)" % rst.get("tvalue_fit")}
     opath, ost = train_orient_policy(num_envs, orient_epochs, tv, gate=orient_gates[0], seed=seed, save_to=os.path.join(workdir, "orient"))
     res, hand = block_assembly_chain(num_envs, tv, policies={"orient": opath, "grasp": gpath, "insert": ipath1}, synthetic_fallback=False, orient_fallback=True,
-                                     orient_tvalue_gate=tuple(orient_gates), grasp_tvalue_gate=0.8, stage_steps={"grasp": 160},
+                                     orient_tvalue_gate=tuple(orient_gates), grasp_tvalue_gate=tuple(grasp_gates), stage_steps={"grasp": 160},
                                      min_grasp_states=min_grasp_states, max_grasp_steps=max_grasp_steps, seed=seed)
     stand_ins = []
+    if gate0 != 0.8:
+        stand_ins.append("refit harvest of grasp states under gate %s instead of 0.8 (GS:1406)" % gate0)
+    if res["grasp"]["tvalue_gate"] != 0.8:
+        stand_ins.append("the chain's GraspSim stage under gate %s instead of 0.8 (GS:1406)" % res["grasp"]["tvalue_gate"])
     if res["orient"]["tvalue_gate"] != 0.99:
         stand_ins.append("Orient's gate %s instead of 0.99 (the ladder's first rung that harvested)" % res["orient"]["tvalue_gate"])
     if res["orient"].get("settled_stand_in_groups"):

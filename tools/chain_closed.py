@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--refit-epochs", type=int, default=4000)
     ap.add_argument("--orient-epochs", type=int, default=600)
     ap.add_argument("--gates", default="0.99,0.9,0.8,0.5")
+    ap.add_argument("--grasp-gates", default="0.8,0.65,0.5", help="gate ladder of the grasp harvests (GS:1406 ships 0.8; a lower rung is reported as a stand-in)")
     ap.add_argument("--min-grasp-states", type=int, default=100)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -33,7 +34,8 @@ def main():
         t0 = time.time()
         try:
             out, hand = block_assembly_chain_closed(a.n, a.insert_epochs, a.grasp_epochs, a.refit_epochs, a.orient_epochs, seed=seed,
-                                                    min_grasp_states=a.min_grasp_states, orient_gates=tuple(float(g) for g in a.gates.split(",")))
+                                                    min_grasp_states=a.min_grasp_states, orient_gates=tuple(float(g) for g in a.gates.split(",")),
+                                                    grasp_gates=tuple(float(g) for g in a.grasp_gates.split(",")))
             hand["insert_task"].sim.close()
             out["seed"], out["total_wall_s"] = seed, time.time() - t0
         except Exception as ex:       # a seed whose pipeline breaks is a result too
