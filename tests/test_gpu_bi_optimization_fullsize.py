@@ -19,7 +19,11 @@ pytestmark = pytest.mark.gpu
 def test_bi_optimization_round_at_4096_envs_with_the_bf16_policy(tmp_path):
     from seqdex_amd.scripts.bi_optimization import CONFIG5_GRASP_MINIBATCH, one_round_at_size
     t0 = time.time()
-    res, paths, tv = one_round_at_size(4096, True, workdir=str(tmp_path), grasp_minibatch=CONFIG5_GRASP_MINIBATCH)
+    # round 6: InsertSim's legs long enough to insert (600 + 400 epochs, 43 s; 48 + 32 gave one insertion and a skipped
+    # refit), so that ALL THREE refits of the round are performed; tools/biopt_long.py runs rounds at 1 500 + 800 epochs
+    # (profiles/r6_config5_biopt_*: 72 % of the second round's backward InsertSim episodes insert)
+    res, paths, tv = one_round_at_size(4096, True, workdir=str(tmp_path), grasp_minibatch=CONFIG5_GRASP_MINIBATCH,
+                                       stage_epochs={"insert": 600, "insert_backward": 400})
     wall = time.time() - t0
     print(json.dumps({k: v for k, v in res.items() if k not in ("runs", "handoffs")}))
     if os.environ.get("SDX_TEST_ARTIFACTS"):                      # the builder's GPU calls keep the full report (profiles/r4_config5_*)
@@ -68,7 +72,7 @@ def test_bi_optimization_round_at_4096_envs_with_the_bf16_policy(tmp_path):
             assert sf[0] <= 100 or sf[1] == 0, h                       # skipped only for the trainer's own reason
         else:
             assert h["finite"] and sf[0] > 100 and sf[1] > 0, h
-    assert any(not h["empty"] for h in fits), fits
+    assert all(not h["empty"] for h in fits), fits                    # all three refits performed (bi_optimization.py:121-124)
     assert not fits[1]["empty"] and fits[1]["outcomes_by"] == "the fine-tuned grasp policy", fits[1]   # the grasp leg's fit ran on the policy's own outcomes
     first = next(i for i, h in enumerate(fits) if not h["empty"])
     assert all(runs[5 + j]["tvalue_given"] for j in range(first, 2)), [r["tvalue_given"] for r in runs]   # every later leg carried the fitted value
@@ -76,7 +80,7 @@ def test_bi_optimization_round_at_4096_envs_with_the_bf16_policy(tmp_path):
     for k in ("search", "orient", "grasp", "insert"):
         ck = torch.load(paths[k], map_location="cpu", weights_only=False)
         assert "a2c_network.mu.weight" in ck["model"] and all(bool(torch.isfinite(v).all()) for v in ck["model"].values())
-    assert wall < 240.0, "one round took %.1f s" % wall
+    assert wall < 300.0, "one round took %.1f s" % wall
 
 
 def test_insert_stage_bf16_update_stays_with_the_fp32_update_at_4096_envs():

@@ -46,7 +46,8 @@ d = json.loads([l for l in open("$O/bench_mb$MB.json") if l.startswith("{")][0])
 print("value %.0f ms/step %.2f update_path %s" % (d["value"], d["ms_per_step"], d.get("update_path")), json.dumps(d.get("roofline_update"))[:600])
 PY
   timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $O/prof -o r6 -- python bench.py --minibatch $MB --steps 2 --warmup 1 --no-cpu-baseline "$@" > $O/prof.log 2>&1; echo "prof rc $?"
-  db=$(find $O/prof -name "*_results.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py stats $db $O/kernel_stats_mb$MB.csv; rm -rf $O/prof
+  db=$(find $O/prof -name "*_results.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py stats $db $O/kernel_stats_mb$MB.csv && python tools/rocpd_summary.py bygrid $db $O/kernel_bygrid_mb$MB.csv; rm -rf $O/prof
+  grep -i "gemm\|reduce\|adam\|stage\|heads\|sqnorm\|fin" $O/kernel_bygrid_mb$MB.csv | head -40 | cut -c1-150
   head -40 $O/kernel_stats_mb$MB.csv | cut -c1-150
   ;;
 ppo_tests)   # PPO parity tests on the device (-k "$1" optional)
@@ -98,6 +99,10 @@ profiles)   # the round's evidence: bench lines, kernel trace of the bench comma
 chain_closed)   # the all-learned chain over seeds: $1 = output name, rest = arguments of tools/chain_closed.py
   name=$1; shift
   timeout 3400 python tools/chain_closed.py "$@" --out $O/$name.json 2> $O/$name.err | grep -v "^Setting\|amdgpu" | cut -c1-1500; tail -3 $O/$name.err | cut -c1-400
+  ;;
+biopt_long)   # bi-optimisation rounds at a length that inserts: $1 = output name, rest = arguments of tools/biopt_long.py
+  name=$1; shift
+  timeout 3400 python tools/biopt_long.py "$@" --out $O/$name.json 2> $O/$name.err | grep -v "^Setting\|amdgpu\|^fps step" | cut -c1-400 | tail -60; tail -3 $O/$name.err | cut -c1-400
   ;;
 *) echo "unknown job $job"; exit 2 ;;
 esac
