@@ -310,9 +310,11 @@ def main():
                  "bound": "hbm", "achieved": phys_bytes / (phys_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "avg_launch_ms": phys_ms, "algorithmic_bytes_per_launch": phys_bytes,
                  "warm_start_cache_bytes_per_launch": cache_bytes,
-                 "bound_actual": "latency: barrier-separated LDS-resident phases (VALU issue about 1/3 busy with 66 % of the lanes active, bank conflicts "
-                                 "32 % of the LDS-active cycles, waves parked 65 % of their cycles; profiles/r5_kphysics_pmc_{sq,lds}.csv); the working set "
-                                 "never leaves LDS, so the HBM roofline is nominal",
+                 "bound_actual": "the working set never leaves LDS, so the HBM roofline is nominal.  Round 6 (DESIGN.md section 4a, profiles/r6_kphysics_*): "
+                                 "the launch's 512 workgroup slots are about 97 % busy (every env is stamped in the profiling build: sum of env cycles / 512 "
+                                 "slots = 1.17 M cycles against a launch of 0.578 ms at about 2.05 GHz), so the average env's 586 k cycles are what counts; "
+                                 "inside the solver loop the CU is LDS-throughput-bound (four more row loads per contact: +5.7 % of the kernel), elsewhere it "
+                                 "waits: barrier-separated LDS-resident phases, serial FK / factorisation on one wave (the broadphase tests now run beside them)",
                  "contacts_per_env_mean": nc_mean, "contacts_per_env_max": int(sim.NCONTACTS.max().item()),
                  "contact_capacity_per_env": 1536, "contacts_per_env_max_since_create": cstats[0],
                  "env_substeps_over_capacity_since_create": cstats[1], "env_substeps_rebuilt_without_speculative_contacts": cstats[2],
