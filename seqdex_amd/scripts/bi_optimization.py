@@ -22,7 +22,7 @@ from ..tvalue_trainer import TValue_Trainer, flat_from_state_dict
 
 
 def main_rlgames(task, num_envs, use_t_value=False, policy_path="", max_iterations=0, task_kwargs=None, tvalue_state=None, keep=False,
-                 minibatch_size=0, mixed_precision=False, report=None, leg=""):
+                 minibatch_size=0, mixed_precision=False, report=None, leg="", seed=None):
     """one training run of `task` (bi_optimization.py:36-104).  Returns (checkpoint path, task object or None).  use_t_value marks the
     backward-pass runs whose purpose is the task's success / failure datasets (they are always logged on the device here).
     mixed_precision: rl_games' `mixed_precision` key for this run (BASELINE.json configs[4] "bf16 policy": bf16 MFMA operands with fp32
@@ -34,6 +34,8 @@ def main_rlgames(task, num_envs, use_t_value=False, policy_path="", max_iteratio
         argv.append("--max_iterations=%d" % max_iterations)
     if policy_path:
         argv.append("--checkpoint=%s" % policy_path)
+    if seed is not None:
+        argv.append("--seed=%d" % seed)       # (the launcher's own flag; default 22, TR:62-65)
     args = get_args(argv)
     args.use_t_value = use_t_value
     task_obj, env, agent, logdir, rank = build(args, task_kwargs, minibatch_size, {"mixed_precision": bool(mixed_precision)})
@@ -100,7 +102,7 @@ def _handoff(report, name, tensor_or_none, fallback):
 
 def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, insert_minibatch=0, mixed_precision=False, report=None,
                    stage_epochs=None, search_envs=128, orient_backward_envs=128, grasp_harvest_stand_in=False, gates=None, gates_after_fit=None,
-                   grasp_minibatch=0):
+                   grasp_minibatch=0, seed=None):
     """insert_minibatch: override of the insert schedule's minibatch_size 4096 for runs with fewer than 512 envs.
     grasp_minibatch: override of the grasp schedule's minibatch_size 4 (both GraspSim legs): on this engine the shipped 4-row minibatches
     with the adaptive LR do not learn to lift within thousands of epochs, 2 048-row minibatches do within hundreds.
@@ -118,7 +120,7 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
     tv = None
     paths = {}
     se = lambda k: int((stage_epochs or {}).get(k, (stage_epochs or {}).get(k.split("_")[0], epochs)))
-    mp = dict(mixed_precision=mixed_precision, report=report)
+    mp = dict(mixed_precision=mixed_precision, report=report, **({} if seed is None else {"seed": seed}))
 
     def gate_kw():
         g = (gates_after_fit if tv is not None else gates) or {}

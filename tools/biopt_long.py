@@ -23,6 +23,7 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--num_envs", type=int, default=4096)
     ap.add_argument("--tvalue_rollout", type=int, default=3000)
+    ap.add_argument("--seed", type=int, default=None, help="the launcher's --seed for every training run (default: its 22) and the seed of the final chain")
     ap.add_argument("--epochs", default="search=20,orient=20,orient_backward=100,grasp=1200,grasp_backward=300,insert=1500,insert_backward=800")
     ap.add_argument("--chain_envs", type=int, default=1024, help="after the rounds: play Orient -> GraspSim -> InsertSim once from the final checkpoints under "
                     "the final transition value, gates as ladders that START at the reference's 0.99 / 0.8 (0 = skip)")
@@ -39,7 +40,7 @@ if __name__ == "__main__":
     try:
         paths, tv = block_assembly(rounds=a.rounds, num_envs=a.num_envs, tvalue_rollout=a.tvalue_rollout, mixed_precision=True, report=report,
                                    stage_epochs=stage_epochs, grasp_harvest_stand_in=True, gates={"orient": 0.0, "grasp": 0.0},
-                                   gates_after_fit={"orient": 0.5, "grasp": 0.28}, grasp_minibatch=2048)
+                                   gates_after_fit={"orient": 0.5, "grasp": 0.28}, grasp_minibatch=2048, seed=a.seed)
     except Exception as ex:          # a round that breaks is a result too: what ran is in the report
         err = "%s: %s" % (type(ex).__name__, str(ex)[:600])
     finally:
@@ -52,7 +53,7 @@ if __name__ == "__main__":
         try:
             res, hand = block_assembly_chain(a.chain_envs, tv, policies={k: os.path.join(tmp, v) for k, v in paths.items() if k in ("orient", "grasp", "insert")},
                                              synthetic_fallback=False, orient_fallback=True, orient_tvalue_gate=(0.99, 0.9, 0.8, 0.5),
-                                             grasp_tvalue_gate=(0.8, 0.65, 0.5), stage_steps={"grasp": 160}, min_grasp_states=100, max_grasp_steps=16000, seed=22)
+                                             grasp_tvalue_gate=(0.8, 0.65, 0.5), stage_steps={"grasp": 160}, min_grasp_states=100, max_grasp_steps=16000, seed=22 if a.seed is None else a.seed)
             hand["insert_task"].sim.close()
             chain = res
             chain["stand_ins"] = [x for x in (None if res["orient"]["tvalue_gate"] == 0.99 else "Orient's gate %s instead of 0.99" % res["orient"]["tvalue_gate"],
@@ -63,7 +64,7 @@ if __name__ == "__main__":
     runs = [r for r in report if "task" in r]
     hand = [r for r in report if "handoff" in r]
     fits = [h for h in hand if h["handoff"].startswith("T-value fitted")]
-    out = {"config": "bi-optimisation, %d rounds at %d envs (Search 128, backward Orient 128), mixed_precision, GraspSim minibatch 2048" % (a.rounds, a.num_envs),
+    out = {"config": "bi-optimisation, %d rounds at %d envs (Search 128, backward Orient 128), mixed_precision, GraspSim minibatch 2048, seed %s" % (a.rounds, a.num_envs, a.seed if a.seed is not None else "22 (the launcher's default)"),
            "stage_epochs": stage_epochs, "tvalue_fit_iterations": a.tvalue_rollout, "wall_s": time.time() - t0, "error": err,
            "env_steps": sum(r["env_steps"] for r in runs), "training_wall_s": sum(r["wall_s"] for r in runs),
            "tvalue_refits_performed": [h["handoff"] for h in fits if h.get("source") == "harvested"], "tvalue_refits_skipped": [h["handoff"] for h in fits if h.get("source") != "harvested"],
