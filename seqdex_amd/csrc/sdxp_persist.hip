@@ -73,7 +73,10 @@ struct PLds {
   float dy2[3][MB][U2];
   float dy1[3][MB][U1];
   // Gram matrices (MB x MB) of the factors of the minibatch currently held: inputs gx[net][layer 0..3], gradients gd[net][layer 0..2]
-  float gx[3][4][16], gd[3][3][16], bsq[3][3];   // bsq: |sum_s dY_s|^2 (bias gradients) per net and trunk layer
+  // (round 6: the gradient factors' Grams never leave the reduction that forms them - layer 0's meets G_x0 on the producing CU, layers 1 / 2
+  // meet theirs at the end of the dY0 shadow - so only the inputs' Grams and one partial squared norm per network are kept)
+  float gx[3][4][16];
+  float n2rest[4];           // per network: sum over trunk layers 1, 2 of <G_dY, G_x> + their bias terms + the heads' terms (n2h): everything but layer 0
   float part[64 * 4];        // block_sum results
   float fpart[3 * MB * NWV];  // cross-wave partial dot products of the forward passes
   float red[4 * NWV][64];    // block_sum: one row per (wave, DPP row)
@@ -109,7 +112,7 @@ typedef unsigned long long u64;
 // published a phase ahead, gathered row- and column-wise by different consumers) keeps its 8-byte words.
 // Layout of D.ll: 16-byte words LQ_* first, then the 8-byte head words at LL_HW (u64 index).
 constexpr unsigned LQ_X1 = 0, LQ_X2 = LQ_X1 + MB * U0, LQ_X3 = LQ_X2 + MB * U1, LQ_DY1 = LQ_X3 + MB * U2, LQ_DY0 = LQ_DY1 + MB * U1,
-                   LQ_G0 = LQ_DY0 + MB * U0, LQ_END = LQ_G0 + 16 * NWG;   // LQ_G0: [10 Gram entries (lower triangle)][CU], the 3 nets per word
+                   LQ_G0 = LQ_DY0 + MB * U0, LQ_END = LQ_G0 + 16 * NWG;   // LQ_G0: [CU]: the CU's share of layer 0's squared gradient norm, the 3 nets per word (round 6; rounds 4-5: 10 Gram entries per CU)
 constexpr size_t LL_HW = 2 * (size_t)LQ_END, LL_END = LL_HW + (ACT + 2) * U2;
 static_assert(LL_END <= SDXP_LL_WORDS, "exchange buffer too small");
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -447,63 +450,27 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     }
     // ================================================================== phase A: gradient norm, Adam of layer 0, forward L0
     if (pending) {
-      // squared-norm Gram of dY0: every CU published the 4x4 Gram of ITS four columns per net (30 numbers) at the end of the
-      // previous step; thread (entry v, lane c16 of its 16-lane row) adds the shares of CUs c16, c16 + 16, ..., a DPP row reduction does the rest
-      {
-        // thread (entry e = tid / 32 of the lower triangle, lane c32 of its half-wave): the three networks' shares of CUs c32, c32 + 32, ...;
-        // every CU adds the same numbers in the same order, so the replicated control state stays bit-identical across CUs
-        const int e = tid >> 5, c32 = tid & 31;
-        float t[3] = {0.0f, 0.0f, 0.0f};
-        if (e < 10) {
-          float w0[8], w1[8], w2[8];
-          if (!lq_gather<8>(LQ, LQ_G0 + (unsigned)e * NWG + c32, 32, tag_prev, w0, w1, w2, failflag)) S.fail = 1;
+      // Squared gradient norm -> clip scale, WITHOUT a workgroup barrier or an LDS pass on the step's dependent chain (round 6).  Every CU
+      // published ONE word at the end of the previous step: its four columns' share of <G_dY0, G_x0> + |sum_s dY0_s|^2 for the three
+      // networks (rounds 4-5: the 10 entries of its Gram; 320 threads gathered 2 560 words, reduced them through LDS and wave 0 ran the
+      // control block between two barriers: 2.2 us from the top of the step to the first Adam instruction).  Every WAVE now gathers the
+      // 256 words itself - CUs lane, lane + 64, ... - and adds them in one fixed order (pair sums, then the DPP tree of wave_sum), so all
+      // waves of all CUs hold bit-identical scalars and walk into Adam of layer 0 as their own words arrive.  What does not depend on dY0
+      // - the other layers' and the heads' terms (S.n2rest), the bias corrections and the learning-rate scalars (S.scal[2..5]) - was
+      // prepared in the shadows of the previous step.
+      float w0[4], w1[4], w2[4];
+      if (!lq_gather<4>(LQ, LQ_G0 + lane, 64, tag_prev, w0, w1, w2, failflag)) S.fail = 1;
+      float n2[3];
+      n2[0] = (w0[0] + w0[1]) + (w0[2] + w0[3]); n2[1] = (w1[0] + w1[1]) + (w1[2] + w1[3]); n2[2] = (w2[0] + w2[1]) + (w2[2] + w2[3]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { t[0] += w0[j]; t[1] += w1[j]; t[2] += w2[j]; }
-        }
+      for (int net = 0; net < 3; ++net) n2[net] = wave_sum(n2[net]);     // three independent DPP chains
 #pragma unroll
-        for (int net = 0; net < 3; ++net) {
-          float x = t[net];
-          x = dpp_add<0xB1, 0xF>(x); x = dpp_add<0x4E, 0xF>(x); x = dpp_add<0x141, 0xF>(x); x = dpp_add<0x140, 0xF>(x);   // 16-lane row sums
-          x = dpp_add<0x142, 0xA>(x);                                                                                       // + the other row of the half-wave (valid in lanes 16..31, 48..63)
-          t[net] = x;
-        }
-        if (e < 10 && c32 == 31) {                                 // e = hi (hi + 1) / 2 + lo
-          const int hi = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), lo = e - hi * (hi + 1) / 2;
-#pragma unroll
-          for (int net = 0; net < 3; ++net) { S.gd[net][0][hi * 4 + lo] = t[net]; S.gd[net][0][lo * 4 + hi] = t[net]; }
-        }
-        __syncthreads();
-      }
-      if (wave == 0) {   // control block: |g|^2 = sum over layers of <Gd, Gx> + bias terms (+ heads, kept in n2h), then the step scalars
-        float t = 0.0f;
-        if (lane < 48) {
-          const int net = lane >> 4, i = lane & 15;
-#pragma unroll
-          for (int l = 0; l < 3; ++l) t += S.gd[net][l][i] * S.gx[net][l][i];
-          t += S.gd[net][0][i];   // layer-0 bias term |sum_s dY0_s|^2 = sum of all entries of the Gram
-        }
-        t = dpp_add<0xB1, 0xF>(t); t = dpp_add<0x4E, 0xF>(t); t = dpp_add<0x141, 0xF>(t); t = dpp_add<0x140, 0xF>(t);   // 16-lane row sums
-        float n2[3];
-        n2[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 0));
-        n2[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 16));
-        n2[2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 32));
-        if (lane == 0) {
-          PLds::Ctl& C = S.ctl;
-#pragma unroll
-          for (int net = 0; net < 3; ++net) n2[net] += C.n2h[net] + S.bsq[net][1] + S.bsq[net][2];
-          C.ac_gn = sqrtf(n2[0] + n2[1]); C.cv_gn = sqrtf(n2[2]);
-          S.scal[0] = D.truncate_grads ? fminf(1.0f, D.grad_norm / (C.ac_gn + 1e-6f)) : 1.0f;
-          S.scal[1] = D.truncate_grads ? fminf(1.0f, D.grad_norm / (C.cv_gn + 1e-6f)) : 1.0f;
-          // Adam step counters / bias corrections
-          C.ac_t += 1; C.cv_t += 1;
-          C.ac_b1 *= 0.9; C.ac_b2 *= 0.999; C.cv_b1 *= 0.9; C.cv_b2 *= 0.999;
-          S.scal[2] = C.ac_lr_applied / (float)(1.0 - C.ac_b1); S.scal[3] = 1.0f / sqrtf((float)(1.0 - C.ac_b2));
-          S.scal[4] = C.cv_lr / (float)(1.0 - C.cv_b1); S.scal[5] = 1.0f / sqrtf((float)(1.0 - C.cv_b2));
-        }
-      }
-      __syncthreads();
+      for (int net = 0; net < 3; ++net) n2[net] += S.n2rest[net];
+      const float ac_gn = sqrtf(n2[0] + n2[1]), cv_gn = sqrtf(n2[2]);
+      const float gs_ac = D.truncate_grads ? fminf(1.0f, D.grad_norm / (ac_gn + 1e-6f)) : 1.0f;
+      const float gs_cv = D.truncate_grads ? fminf(1.0f, D.grad_norm / (cv_gn + 1e-6f)) : 1.0f;
+      if (tid == 0) { S.ctl.ac_gn = ac_gn; S.ctl.cv_gn = cv_gn; S.scal[0] = gs_ac; S.scal[1] = gs_cv; }   // for the shadows' Adam phases (behind the next barrier)
       TS(0)
-      const float gs_ac = S.scal[0], gs_cv = S.scal[1];
       const float ac_lr_bc1 = S.scal[2], ac_isq = S.scal[3], cv_lr_bc1 = S.scal[4], cv_isq = S.scal[5];
       float dep = 0.0f;   // last weight written by the Adam sequence below (ordering token, see opaque())
       // ---- layer 0 rows
@@ -1125,6 +1092,16 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         if (kl > 2.0f * D.kl_threshold) C.ac_lr = fmaxf(C.ac_lr / 1.5f, 1e-6f);
         if (kl < 0.5f * D.kl_threshold) C.ac_lr = fminf(C.ac_lr * 1.5f, 1e-2f);
       }
+      if constexpr (!SINGLE) {
+        // Adam step counters / bias corrections of the optimiser step that applies THIS minibatch's gradient (phase A of the next
+        // iteration): nothing here depends on the gradient, so it left the chain (round 6; the double-precision powers and the two
+        // divisions sat between the norm and the first Adam instruction).  S.scal[2..5] were last read by the Adam shadows of this
+        // iteration, which every wave finished before the barrier in front of phase C
+        C.ac_t += 1; C.cv_t += 1;
+        C.ac_b1 *= 0.9; C.ac_b2 *= 0.999; C.cv_b1 *= 0.9; C.cv_b2 *= 0.999;
+        S.scal[2] = C.ac_lr_applied / (float)(1.0 - C.ac_b1); S.scal[3] = 1.0f / sqrtf((float)(1.0 - C.ac_b2));
+        S.scal[4] = C.cv_lr / (float)(1.0 - C.cv_b1); S.scal[5] = 1.0f / sqrtf((float)(1.0 - C.cv_b2));
+      }
     }
     if constexpr (!SINGLE) {
       float p[33];
@@ -1197,18 +1174,27 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tid < 10) {
-          const int e = tid;
-          const int hi = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), lo = e - hi * (hi + 1) / 2;
-          float gsum[3];
+        if (wave == 0) {
+          // lane (a, b) < 16: entry (a, b) of the CU's 4x4 Gram of dY0 (its four columns) times (G_x0[a][b] + 1): the weight-gradient term
+          // <G_dY0, G_x0> and the bias term |sum_s dY0_s|^2 = sum of all entries of the Gram; a DPP row sum, ONE word per CU
+          float t[3] = {0.0f, 0.0f, 0.0f};
+          if (lane < 16) {
+            const int hi = lane >> 2, lo = lane & 3;
+#pragma unroll
+            for (int net = 0; net < 3; ++net) {
+              float gg = 0.0f;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) gg += S.dyown[net][hi][c] * S.dyown[net][lo][c];
+              t[net] = gg * S.gx[net][0][lane] + gg;
+            }
+          }
 #pragma unroll
           for (int net = 0; net < 3; ++net) {
-            float t = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) t += S.dyown[net][hi][c] * S.dyown[net][lo][c];
-            gsum[net] = t;
+            float x = t[net];
+            x = dpp_add<0xB1, 0xF>(x); x = dpp_add<0x4E, 0xF>(x); x = dpp_add<0x141, 0xF>(x); x = dpp_add<0x140, 0xF>(x);   // 16-lane row sums
+            t[net] = x;
           }
-          lq_store(LQ, LQ_G0 + (unsigned)e * NWG + g, gsum[0], gsum[1], gsum[2], tag);
+          if (lane == 0) lq_store(LQ, LQ_G0 + g, t[0], t[1], t[2], tag);
         }
       }
     }
@@ -1257,26 +1243,40 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       return;
     }
     if constexpr (!SINGLE)
-    {   // ---- (shadow of dY0) Grams of dY1 and dY2
-      float p[33];
+    {   // ---- (shadow of dY0) Grams of dY1 and dY2 through ONE block reduction (round 6; two of them, four barriers, were 2.55 us - longer than
+        // the edge they shadow), then the part of the squared gradient norm that does not wait for dY0: out[0..29] = [dY1: net][10],
+        // out[32..61] = [dY2: net][10].  The bias terms |sum_s dY_s|^2 are the sums of all entries of the same Grams (as layer 0's always was)
+      float ua[8], ub[8];
+      {
+        float p[30];
 #pragma unroll
-      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
+        for (int i = 0; i < 30; ++i) p[i] = 0.0f;
 #pragma unroll
-      for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.dy1[net][0][tid], S.dy1[net][1][tid], S.dy1[net][2][tid], S.dy1[net][3][tid]);
-      block_sum<33>(S, p, S.part, tid, wave, lane);
-      if (tid < 48) S.gd[tid >> 4][1][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-      else if (tid >= 64 && tid < 67) S.bsq[tid - 64][1] = S.part[(tid - 64) * 11 + 10];
-      // ... and of dY2 (moved here from the dY1 shadow to balance the two)
-#pragma unroll
-      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
-      if (tid < U2) {
-#pragma unroll
-        for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.dy2[net][0][tid], S.dy2[net][1][tid], S.dy2[net][2][tid], S.dy2[net][3][tid]);
+        for (int net = 0; net < 3; ++net) gram_acc10(&p[net * 10], S.dy1[net][0][tid], S.dy1[net][1][tid], S.dy1[net][2][tid], S.dy1[net][3][tid]);
+        row_butterfly<30>(p, ua, lane);
       }
-      block_sum<33>(S, p, S.part, tid, wave, lane);
-      if (tid < 48) S.gd[tid >> 4][2][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-      else if (tid >= 64 && tid < 67) S.bsq[tid - 64][2] = S.part[(tid - 64) * 11 + 10];
-      else if (tid >= 128 && tid < 128 + 3 * MB) { const int net = (tid - 128) / MB, s = (tid - 128) % MB; S.dyown[net][s][6] = S.dy2[net][s][g]; }
+      rows_store<8>(S, ua, 0, wave, lane);
+      {
+        float p[30];
+#pragma unroll
+        for (int i = 0; i < 30; ++i) p[i] = 0.0f;
+        if (tid < U2) {
+#pragma unroll
+          for (int net = 0; net < 3; ++net) gram_acc10(&p[net * 10], S.dy2[net][0][tid], S.dy2[net][1][tid], S.dy2[net][2][tid], S.dy2[net][3][tid]);
+        }
+        row_butterfly<30>(p, ub, lane);
+      }
+      rows_store<8>(S, ub, 32, wave, lane);
+      rows_reduce(S, 64, S.part, tid);
+      if (wave == 1) {   // lane (net, i) < 48: entry i of both Grams against (G_x + 1); a DPP row sum per network; + the heads' terms
+        float t = 0.0f;
+        if (lane < 48) {
+          const int net = lane >> 4, i = lane & 15;
+          t = S.part[net * 10 + tri16(i)] * (S.gx[net][1][i] + 1.0f) + S.part[32 + net * 10 + tri16(i)] * (S.gx[net][2][i] + 1.0f);
+        }
+        t = dpp_add<0xB1, 0xF>(t); t = dpp_add<0x4E, 0xF>(t); t = dpp_add<0x141, 0xF>(t); t = dpp_add<0x140, 0xF>(t);   // 16-lane row sums
+        if (lane < 48 && (lane & 15) == 0) S.n2rest[lane >> 4] = t + S.ctl.n2h[lane >> 4];
+      } else if (tid >= 128 && tid < 128 + 3 * MB) { const int net = (tid - 128) / MB, s = (tid - 128) % MB; S.dyown[net][s][6] = S.dy2[net][s][g]; }
     }
     TS(18)
     pending = true;

@@ -53,6 +53,18 @@ PY
 ppo_tests)   # PPO parity tests on the device (-k "$1" optional)
   timeout 1200 python -m pytest tests/test_gpu_ppo_parity.py -q -m gpu -x ${1:+-k "$1"} 2>&1 | tail -15 > $O/tests.txt; tail -8 $O/tests.txt
   ;;
+persist)   # the persistent update kernel: its oracle / determinism / fault tests, phase clock of CU 0, short bench line ($1 = tag of the output files)
+  tagp=${1:-head}
+  timeout 900 python -m pytest tests/test_gpu_ppo_parity.py tests/test_gpu_fullsize_properties.py -q -m gpu -x -k "update_matches_autograd_adam or persistent or narrow_padded or explicit_gradient_path" 2>&1 | tail -8 > $O/tests_$tagp.txt; tail -4 $O/tests_$tagp.txt
+  SDXP_PERSIST_STAMPS=1 timeout 200 python tools/prof_persist.py 1024 > $O/phase_clock_$tagp.txt 2> /dev/null; cat $O/phase_clock_$tagp.txt
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-large-minibatch > $O/bench_$tagp.json 2> $O/bench_$tagp.err; echo "bench rc $?"
+  python - <<PY
+import json
+d = json.loads([l for l in open("$O/bench_$tagp.json") if l.startswith("{")][0])
+r = d.get("roofline_update") or d.get("roofline") or {}
+print("value %.0f ms/step %.2f" % (d["value"], d["ms_per_step"]), json.dumps(r)[:500])
+PY
+  ;;
 bench)   # the default bench line (+ args)
   timeout 600 python bench.py "$@" > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
   python - <<PY
