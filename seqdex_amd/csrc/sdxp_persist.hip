@@ -205,6 +205,17 @@ __device__ __forceinline__ bool ll_gather(const u64* p, size_t stride, unsigned 
     }
   }
 }
+// the same without the scheduling fence (elements whose gradients already sit in registers: the sqrt / rcp chains of neighbours may interleave)
+__device__ __forceinline__ void adam1f(float& w, float g, float& m, float& v, float lr_bc1, float isq_bc2) {
+  m = 0.9f * m + 0.1f * g;
+  v = 0.999f * v + 0.001f * g * g;
+  w -= lr_bc1 * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * isq_bc2 + 1e-8f);
+}
+#ifdef SDXP_ADAM0_FREE
+#define ADAM0 adam1f
+#else
+#define ADAM0 adam1
+#endif
 // accumulate the 4x4 Gram (lower triangle, 10 terms) and |sum|^2 of (a, b, c, d)
 __device__ __forceinline__ void gram_acc(float* p, float a, float b, float c, float d) {
   p[0] += a * a; p[1] += b * a; p[2] += b * b; p[3] += c * a; p[4] += c * b; p[5] += c * c;
@@ -423,10 +434,58 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     C.n2h[0] = C.n2h[1] = C.n2h[2] = 0.0f;   // head + logstd contributions to the squared gradient norm of the held minibatch
   }
   bool pending = false;
+  // layer-0 gradient elements of this lane (sum_s dY0_s[row] x0_s[k], before the clip scale), formed in the dY0 shadow of the step that
+  // produced them - the LDS round trips of the rebuild are off the chain, Adam of layer 0 runs on registers (round 6)
+  float g0a[I0A], g0c[I0A], g0v[I0V];
+#pragma unroll
+  for (int i = 0; i < I0A; ++i) { g0a[i] = 0.0f; g0c[i] = 0.0f; }
+#pragma unroll
+  for (int i = 0; i < I0V; ++i) g0v[i] = 0.0f;
+  // columns of the layer-0 input image past obs_dim stay zero for the whole launch (the row loads below never touch them)
+  for (int i = tid; i < MB * OBS; i += NTH) (&S.obs[0][0])[i] = 0.0f;
   __syncthreads();
 
+    // This step's layer-0 inputs (dataset rows mb*MB .. +MB) go STRAIGHT into LDS (global_load_lds_dword: lane tid of a wave fetches element
+  // wave 64 + lane of a row, the wave's 64 dwords land behind one wave-uniform LDS address; no VGPR round trip, no ds_write, no barrier in
+  // front of the copy).  The old rows were last read by the dY0 shadow (the layer-0 gradient rebuild), which every wave finished before the
+  // barrier at the top of the step; the loads fly under the norm gather and Adam of layer 0 and are waited for in front of forward L0.
+  auto load_rows = [&](int mb_, int me_) {
+    // row pointers are wave-uniform (scalar registers), the lane adds its 32-bit offset: ONE address VGPR for the twelve loads (twelve 64-bit
+    // per-lane pointers formed up front were 24 VGPRs - the kernel has none to spare - and spilled the first looks of the x2 / dY1 words)
+    // (the "+s" asm keeps each pointer in a scalar register pair and in place: hoisted out of the step loop as per-lane 64-bit values they
+    // cost VGPR pairs for the whole step)
+    auto uni = [](const float* q) -> const float* { unsigned long long a = (unsigned long long)q; asm volatile("" : "+s"(a)); return (const float*)a; };
+    const float* o = uni(obs_rows(D, mb_));
+    const float* c = uni(cvx_rows(D, mb_, me_));
+    const unsigned odim = D.obs_dim;
+    if (odim == OBS) {
+      // full-width observations: the MB rows are contiguous in the dataset AND in LDS (S.obs, then S.cvx): 960 pieces of 16 bytes, two
+      // global_load_lds_dwordx4 per lane (twelve dword loads with their exec masks and M0 writes cost phase A 0.4 us of issue)
+      static_assert(offsetof(PLds, cvx) == sizeof(float) * MB * OBS && (MB * OBS) % 4 == 0 && (MB * ST) % 4 == 0, "obs and cvx images are adjacent 16-byte runs");
+      constexpr int PO = MB * OBS / 4, PA = PO + MB * ST / 4;
+      char* l0 = reinterpret_cast<char*>(&S.obs[0][0]);
+#pragma unroll
+      for (int j = 0; j < (PA + NTH - 1) / NTH; ++j) {
+        const int pc = tid + NTH * j;
+        if (pc < PA) {
+          const float* src = pc < PO ? o + 4 * pc : c + 4 * (pc - PO);
+          __builtin_amdgcn_global_load_lds(SDX_AS_GLOBAL(src), SDX_AS_LDS(l0 + (wave + NWV * j) * 1024), 16, 0, 0);
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int s = 0; s < MB; ++s) {
+      const float* orow = uni(o + s * odim);
+      const float* crow = uni(c + s * ST);
+      if ((unsigned)tid < odim) __builtin_amdgcn_global_load_lds(SDX_AS_GLOBAL(orow + (unsigned)tid), SDX_AS_LDS(&S.obs[s][wave * 64]), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(SDX_AS_GLOBAL(crow + (unsigned)tid), SDX_AS_LDS(&S.cvx[s][wave * 64]), 4, 0, 0);
+      if (tid + NTH < ST) __builtin_amdgcn_global_load_lds(SDX_AS_GLOBAL(crow + NTH + (unsigned)tid), SDX_AS_LDS(&S.cvx[s][NTH]), 4, 0, 0);
+    }
+  };
+  if (total_steps > 0) load_rows(SINGLE ? gctl->mb_index : 0, SINGLE ? gctl->mini_epoch : 0);   // rows of the first minibatch
   for (int step = 0; step <= total_steps; ++step) {
-    __syncthreads();
+    SDX_LDS_BARRIER();   // LDS only: the next step's row loads (requested in the dY0 shadow) stay in flight across it
     if (S.fail) return;   // an exchange word never arrived (not all CUs resident?): the host sees *failflag and reports it
     if (fault && g == NWG - 1 && step == 3) return;   // SDXP_PERSIST_FAULT=1 (tests): one CU goes silent, the others must time out
     refresh();
@@ -435,19 +494,6 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     // tag of everything this step produces / of what the previous step produced.  tag_base advances from launch to launch (the
     // exchange buffer is never cleared), so a word left over from an earlier launch can never match
     const unsigned tag = tag_base + (unsigned)step + 1u, tag_prev = tag_base + (unsigned)step;
-    // prefetch this step's layer-0 inputs (dataset rows mb*MB .. +MB; lane k holds element k of the MB samples): the HBM latency
-    // hides behind the norm / Adam work below
-    float pf_o[MB], pf_c[2][MB];
-    {
-      const float* o = obs_rows(D, last ? 0 : mbi);
-      const float* c = cvx_rows(D, last ? 0 : mbi, last ? 0 : mini_epoch);
-#pragma unroll
-      for (int s = 0; s < MB; ++s) {
-        pf_o[s] = tid < D.obs_dim ? o[s * D.obs_dim + tid] : 0.0f;
-        pf_c[0][s] = c[s * ST + tid];
-        pf_c[1][s] = tid + NTH < ST ? c[s * ST + tid + NTH] : 0.0f;
-      }
-    }
     // ================================================================== phase A: gradient norm, Adam of layer 0, forward L0
     if (pending) {
       // Squared gradient norm -> clip scale, WITHOUT a workgroup barrier or an LDS pass on the step's dependent chain (round 6).  Every CU
@@ -472,34 +518,14 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       if (tid == 0) { S.ctl.ac_gn = ac_gn; S.ctl.cv_gn = cv_gn; S.scal[0] = gs_ac; S.scal[1] = gs_cv; }   // for the shadows' Adam phases (behind the next barrier)
       TS(0)
       const float ac_lr_bc1 = S.scal[2], ac_isq = S.scal[3], cv_lr_bc1 = S.scal[4], cv_isq = S.scal[5];
-      float dep = 0.0f;   // last weight written by the Adam sequence below (ordering token, see opaque())
-      // ---- layer 0 rows
-      {
-        float da[MB], dc[MB], dvv[MB];
+      // ---- layer 0 rows: gradient elements from registers (g0a / g0c / g0v, dY0 shadow of the previous iteration), scaled by the clip factor
 #pragma unroll
-        for (int s = 0; s < MB; ++s) { da[s] = S.dyown[0][s][r0w] * gs_ac; dc[s] = S.dyown[1][s][r0w] * gs_ac; dvv[s] = S.dyown[2][s][r0w] * gs_cv; }
-#pragma unroll
-        for (int i = 0; i < I0A; ++i) {
-          const int kk = opaque(lane + 64 * i, dep), k = h0 * H0A + kk;
-          if (kk < H0A && k < D.obs_dim) {
-            float ga = 0.0f, gc = 0.0f;
-#pragma unroll
-            for (int s = 0; s < MB; ++s) { const float x = S.obs[s][k]; ga += da[s] * x; gc += dc[s] * x; }
-            adam1(w0a[i], ga, m0a[i], v0a[i], ac_lr_bc1, ac_isq); dep = w0a[i];
-            adam1(w0c[i], gc, m0c[i], v0c[i], ac_lr_bc1, ac_isq); dep = w0c[i];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < I0V; ++i) {
-          const int kk = opaque(lane + 64 * i, dep), k = h0 * H0V + kk;
-          if (kk < H0V) {
-            float gv = 0.0f;
-#pragma unroll
-            for (int s = 0; s < MB; ++s) gv += dvv[s] * S.cvx[s][k];
-            adam1(w0v[i], gv, m0v[i], v0v[i], cv_lr_bc1, cv_isq); dep = w0v[i];
-          }
-        }
+      for (int i = 0; i < I0A; ++i) {
+        ADAM0(w0a[i], g0a[i] * gs_ac, m0a[i], v0a[i], ac_lr_bc1, ac_isq);
+        ADAM0(w0c[i], g0c[i] * gs_ac, m0c[i], v0c[i], ac_lr_bc1, ac_isq);
       }
+#pragma unroll
+      for (int i = 0; i < I0V; ++i) ADAM0(w0v[i], g0v[i] * gs_cv, m0v[i], v0v[i], cv_lr_bc1, cv_isq);
       if (tid < 12) {   // layer-0 biases (bias gradient = sum_s dY_s[row])
         const int net = tid / 4;
         float gg = 0.0f;
@@ -508,17 +534,11 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         adam1(b, gg * (net == 2 ? gs_cv : gs_ac), bm, bv, net == 2 ? cv_lr_bc1 : ac_lr_bc1, net == 2 ? cv_isq : ac_isq);
         S.bias[tid] = b; S.bias_m[tid] = bm; S.bias_v[tid] = bv;
       }
-      __syncthreads();   // every wave is done with the old S.obs / S.cvx
       TS(1)
     }
     if (!last) {
-      // ---- this step's layer-0 inputs to LDS, forward L0 of the owned rows (two half-row waves per row, combined through LDS)
-#pragma unroll
-      for (int s = 0; s < MB; ++s) {
-        if (tid < OBS) S.obs[s][tid] = pf_o[s];   // columns past obs_dim hold zeros (pf_o is masked)
-        S.cvx[s][tid] = pf_c[0][s];
-        if (tid + NTH < ST) S.cvx[s][tid + NTH] = pf_c[1][s];
-      }
+      // ---- forward L0 of the owned rows (two half-row waves per row, combined through LDS) once this step's rows have landed
+      SDX_WAIT_VMCNT0();
       __syncthreads();
       float pa[MB], pc[MB], pv[MB];
 #pragma unroll
@@ -558,13 +578,13 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
       TS(2)
       if constexpr (!SINGLE) {
-      // ---- in the shadow of the x1 exchange: Gram of the layer-0 inputs (from the prefetch registers)
+      // ---- in the shadow of the x1 exchange: Gram of the layer-0 inputs
       float p[22];
 #pragma unroll
       for (int i = 0; i < 22; ++i) p[i] = 0.0f;
-      gram_acc(&p[0], pf_o[0], pf_o[1], pf_o[2], pf_o[3]);
-      gram_acc(&p[11], pf_c[0][0], pf_c[0][1], pf_c[0][2], pf_c[0][3]);
-      gram_acc(&p[11], pf_c[1][0], pf_c[1][1], pf_c[1][2], pf_c[1][3]);
+      if (tid < OBS) gram_acc(&p[0], S.obs[0][tid], S.obs[1][tid], S.obs[2][tid], S.obs[3][tid]);
+      gram_acc(&p[11], S.cvx[0][tid], S.cvx[1][tid], S.cvx[2][tid], S.cvx[3][tid]);
+      if (tid + NTH < ST) gram_acc(&p[11], S.cvx[0][tid + NTH], S.cvx[1][tid + NTH], S.cvx[2][tid + NTH], S.cvx[3][tid + NTH]);
       block_sum<22>(S, p, S.part, tid, wave, lane);
       if (tid < 16) { const float v = S.part[tri16(tid)]; S.gx[0][0][tid] = v; S.gx[1][0][tid] = v; }
       else if (tid >= 64 && tid < 80) S.gx[2][0][tid - 64] = S.part[11 + tri16(tid - 64)];
@@ -1267,7 +1287,42 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         row_butterfly<30>(p, ub, lane);
       }
       rows_store<8>(S, ub, 32, wave, lane);
-      rows_reduce(S, 64, S.part, tid);
+      SDX_LDS_BARRIER();          // (rows_reduce, opened up: the stage between its two barriers occupies 64 threads ...)
+      if (tid < 64) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4 * NWV; ++w) t += S.red[w][tid];
+        S.part[tid] = t;
+      }
+      // ... so this lane's layer-0 gradient elements are formed here, by every wave (dyown[.][.][0..3] were published by the barrier above;
+      // S.obs / S.cvx still hold this minibatch): 4 + 5 batches of four independent LDS loads instead of 13 dependent round trips on the chain
+      {
+        float da[MB], dc[MB], dvv[MB];
+#pragma unroll
+        for (int s = 0; s < MB; ++s) { da[s] = S.dyown[0][s][r0w]; dc[s] = S.dyown[1][s][r0w]; dvv[s] = S.dyown[2][s][r0w]; }
+#pragma unroll
+        for (int i = 0; i < I0A; ++i) {
+          const int kk = lane + 64 * i, k = h0 * H0A + kk;
+          const bool ok = kk < H0A && k < D.obs_dim;
+          const int kc = ok ? k : 0;
+          float ga = 0.0f, gc = 0.0f;
+#pragma unroll
+          for (int s = 0; s < MB; ++s) { const float x = S.obs[s][kc]; ga += da[s] * x; gc += dc[s] * x; }
+          g0a[i] = ok ? ga : 0.0f; g0c[i] = ok ? gc : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < I0V; ++i) {
+          const int kk = lane + 64 * i, k = h0 * H0V + kk;
+          const bool ok = kk < H0V;
+          const int kc = ok ? k : 0;
+          float gv = 0.0f;
+#pragma unroll
+          for (int s = 0; s < MB; ++s) gv += dvv[s] * S.cvx[s][kc];
+          g0v[i] = ok ? gv : 0.0f;
+        }
+      }
+      SDX_LDS_BARRIER();
+      if (step + 1 < total_steps) { const bool wrap = mbi + 1 >= D.num_minibatches; load_rows(wrap ? 0 : mbi + 1, mini_epoch + (wrap ? 1 : 0)); }
       if (wave == 1) {   // lane (net, i) < 48: entry i of both Grams against (G_x + 1); a DPP row sum per network; + the heads' terms
         float t = 0.0f;
         if (lane < 48) {

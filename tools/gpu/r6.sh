@@ -57,6 +57,9 @@ persist)   # the persistent update kernel: its oracle / determinism / fault test
   tagp=${1:-head}
   timeout 900 python -m pytest tests/test_gpu_ppo_parity.py tests/test_gpu_fullsize_properties.py -q -m gpu -x -k "update_matches_autograd_adam or persistent or narrow_padded or explicit_gradient_path" 2>&1 | tail -8 > $O/tests_$tagp.txt; tail -4 $O/tests_$tagp.txt
   SDXP_PERSIST_STAMPS=1 timeout 200 python tools/prof_persist.py 1024 > $O/phase_clock_$tagp.txt 2> /dev/null; cat $O/phase_clock_$tagp.txt
+  shift; for v in "$@"; do   # further libraries (seqdex_amd/lib/libseqdex_<v>.so): phase clock only
+    SDX_LIB_PATH=$PWD/seqdex_amd/lib/libseqdex_$v.so SDXP_PERSIST_STAMPS=1 timeout 200 python tools/prof_persist.py 1024 > $O/phase_clock_${tagp}_$v.txt 2> /dev/null; echo "== $v"; cat $O/phase_clock_${tagp}_$v.txt
+  done
   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-large-minibatch > $O/bench_$tagp.json 2> $O/bench_$tagp.err; echo "bench rc $?"
   python - <<PY
 import json
