@@ -76,6 +76,7 @@ struct PLds {
   // (round 6: the gradient factors' Grams never leave the reduction that forms them - layer 0's meets G_x0 on the producing CU, layers 1 / 2
   // meet theirs at the end of the dY0 shadow - so only the inputs' Grams and one partial squared norm per network are kept)
   float gx[3][4][16];
+  float gd2[3][16];          // Gram of dY2 (formed in the dY1 shadow beside the Gram of x3, used at the end of the dY0 shadow)
   float n2rest[4];           // per network: sum over trunk layers 1, 2 of <G_dY, G_x> + their bias terms + the heads' terms (n2h): everything but layer 0
   float part[64 * 4];        // block_sum results
   float fpart[3 * MB * NWV];  // cross-wave partial dot products of the forward passes
@@ -90,7 +91,7 @@ struct PLds {
   // control state machine, owned by thread 0 of every CU (every CU runs it on identical inputs, so the copies stay identical)
   struct Ctl {
     double ac_b1, ac_b2, cv_b1, cv_b2;
-    float ac_lr, ac_lr_applied, cv_lr, sum_a, sum_c, sum_b, sum_kl, sum_cv, sum_ent, last_kl, ac_gn, cv_gn, n2h[3];
+    float ac_lr, ac_lr_applied, cv_lr, sum_a, sum_c, sum_b, sum_kl, sum_cv, sum_ent, last_kl, ac_gn, cv_gn;
     int ac_t, cv_t;
   } ctl;
   int fail;
@@ -431,7 +432,6 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     C.ac_lr = gctl->ac_lr; C.ac_lr_applied = C.ac_lr; C.cv_lr = gctl->cv_lr; C.ac_t = gctl->ac_t; C.cv_t = gctl->cv_t;
     C.ac_b1 = gctl->ac_b1pow; C.ac_b2 = gctl->ac_b2pow; C.cv_b1 = gctl->cv_b1pow; C.cv_b2 = gctl->cv_b2pow;
     C.sum_a = C.sum_c = C.sum_b = C.sum_kl = C.sum_cv = C.sum_ent = C.last_kl = C.ac_gn = C.cv_gn = 0.0f;
-    C.n2h[0] = C.n2h[1] = C.n2h[2] = 0.0f;   // head + logstd contributions to the squared gradient norm of the held minibatch
   }
   bool pending = false;
   // layer-0 gradient elements of this lane (sum_s dY0_s[row] x0_s[k], before the clip scale), formed in the dY0 shadow of the step that
@@ -1124,13 +1124,14 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
     }
     if constexpr (!SINGLE) {
-      float p[33];
+      // Round 6: the Gram of x3 (waves 0..3, unit = tid) and the Gram of dY2 (waves 4..7, unit = tid - 256; it used to wait for the dY0 shadow, whose
+      // block reduction is on the chain since the norm edge shrank) go through ONE pass: columns 0..29 / 32..61, each summed over its 16 rows.
+      // The heads' terms are only STORED here (S.part[128..], [192..]); the serial sums that closed this shadow (16 + 23 dependent LDS reads on
+      // three threads, about 1 us after the reduction) are lanes of the DPP sum at the end of the dY0 shadow now.
+      float p[30];
 #pragma unroll
-      for (int i = 0; i < 33; ++i) p[i] = 0.0f;
-      if (tid < U2) {
-#pragma unroll
-        for (int net = 0; net < 3; ++net) gram_acc(&p[net * 11], S.x3[net][0][tid], S.x3[net][1][tid], S.x3[net][2][tid], S.x3[net][3][tid]);
-      } else if (tid >= 256 && tid < 256 + 48) {       // thread (net, a, b): the heads' gradient product that multiplies G_x3[a][b]
+      for (int i = 0; i < 30; ++i) p[i] = 0.0f;
+      if (tid >= 256 && tid < 256 + 48) {              // thread (net, a, b): the heads' gradient product that multiplies G_x3[a][b]
         const int t = tid - 256, net = t / 16, a = (t / 4) % 4, b = t % 4;
         float dd = 0.0f;
         if (net == 0) { for (int j = 0; j < A; ++j) dd += S.dmu[a][j] * S.dmu[b][j]; }
@@ -1142,15 +1143,32 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         if (j < A) { float sb = 0; for (int a = 0; a < MB; ++a) sb += S.dmu[a][j]; t = sb * sb + S.dls[j] * S.dls[j]; }
         S.part[192 + j] = t;
       }
-      block_sum<33>(S, p, S.part, tid, wave, lane);    // (its barriers also publish S.part[128 ..] above)
-      if (tid < 48) S.gx[tid >> 4][3][tid & 15] = S.part[(tid >> 4) * 11 + tri16(tid & 15)];
-      else if (tid >= 64 && tid < 67) {                // squared-norm contributions of the heads and logstd
-        const int net = tid - 64;
-        float acc = 0.0f;
-        for (int i = 0; i < 16; ++i) acc += S.part[128 + net * 16 + i] * S.part[net * 11 + tri16(i)];
-        if (net == 0) { for (int j = 0; j < A; ++j) acc += S.part[192 + j]; }
-        else { float sb = 0; for (int a = 0; a < MB; ++a) sb += S.dv[net - 1][a]; acc += sb * sb; }
-        S.ctl.n2h[net] = acc;
+      if (tid < U2) {
+#pragma unroll
+        for (int net = 0; net < 3; ++net) gram_acc10(&p[net * 10], S.x3[net][0][tid], S.x3[net][1][tid], S.x3[net][2][tid], S.x3[net][3][tid]);
+      } else {
+        const int k = tid - U2;
+#pragma unroll
+        for (int net = 0; net < 3; ++net) gram_acc10(&p[net * 10], S.dy2[net][0][k], S.dy2[net][1][k], S.dy2[net][2][k], S.dy2[net][3][k]);
+      }
+      {
+        float u[8];
+        row_butterfly<30>(p, u, lane);
+        rows_store<8>(S, u, tid < U2 ? 0 : 32, wave, lane);
+      }
+      SDX_LDS_BARRIER();
+      if (tid < 64) {                                  // column tid: rows of waves 0..3 (x3) or 4..7 (dY2)
+        const int r0 = tid < 32 ? 0 : 2 * NWV;
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 2 * NWV; ++w) t += S.red[r0 + w][tid];
+        const int c = tid & 31, net = c / 10, e = c - net * 10;
+        // entry e of the lower triangle -> both (hi, lo) and (lo, hi) of the 4x4 matrix
+        const int hi = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), lo = e - hi * (hi + 1) / 2;
+        if (c < 30) {
+          float* dst = tid < 32 ? S.gx[net][3] : S.gd2[net];
+          dst[hi * 4 + lo] = t; dst[lo * 4 + hi] = t;
+        }
       }
       // first look at this lane's dY1 words (the polling gather of phase E takes over if a producer is late)
       lq_peek<4>(LQ, LQ_DY1 + tid, NTH, pdy1); pdy1_issued = true;
@@ -1263,32 +1281,19 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       return;
     }
     if constexpr (!SINGLE)
-    {   // ---- (shadow of dY0) Grams of dY1 and dY2 through ONE block reduction (round 6; two of them, four barriers, were 2.55 us - longer than
-        // the edge they shadow), then the part of the squared gradient norm that does not wait for dY0: out[0..29] = [dY1: net][10],
-        // out[32..61] = [dY2: net][10].  The bias terms |sum_s dY_s|^2 are the sums of all entries of the same Grams (as layer 0's always was)
-      float ua[8], ub[8];
+    {   // ---- (shadow of dY0; on the step's chain since the norm edge shrank to one word per CU) Gram of dY1 - the Gram of dY2 moved into the dY1
+        // shadow (round 6) -, this lane's layer-0 gradient elements, the next step's rows, and the part of the squared norm that does not wait for dY0
       {
-        float p[30];
+        float p[30], ua[8];
 #pragma unroll
         for (int i = 0; i < 30; ++i) p[i] = 0.0f;
 #pragma unroll
         for (int net = 0; net < 3; ++net) gram_acc10(&p[net * 10], S.dy1[net][0][tid], S.dy1[net][1][tid], S.dy1[net][2][tid], S.dy1[net][3][tid]);
         row_butterfly<30>(p, ua, lane);
+        rows_store<8>(S, ua, 0, wave, lane);
       }
-      rows_store<8>(S, ua, 0, wave, lane);
-      {
-        float p[30];
-#pragma unroll
-        for (int i = 0; i < 30; ++i) p[i] = 0.0f;
-        if (tid < U2) {
-#pragma unroll
-          for (int net = 0; net < 3; ++net) gram_acc10(&p[net * 10], S.dy2[net][0][tid], S.dy2[net][1][tid], S.dy2[net][2][tid], S.dy2[net][3][tid]);
-        }
-        row_butterfly<30>(p, ub, lane);
-      }
-      rows_store<8>(S, ub, 32, wave, lane);
-      SDX_LDS_BARRIER();          // (rows_reduce, opened up: the stage between its two barriers occupies 64 threads ...)
-      if (tid < 64) {
+      SDX_LDS_BARRIER();          // (rows_reduce, opened up: the stage between its two barriers occupies 32 threads ...)
+      if (tid < 32) {
         float t = 0.0f;
 #pragma unroll
         for (int w = 0; w < 4 * NWV; ++w) t += S.red[w][tid];
@@ -1323,14 +1328,19 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       }
       SDX_LDS_BARRIER();
       if (step + 1 < total_steps) { const bool wrap = mbi + 1 >= D.num_minibatches; load_rows(wrap ? 0 : mbi + 1, mini_epoch + (wrap ? 1 : 0)); }
-      if (wave == 1) {   // lane (net, i) < 48: entry i of both Grams against (G_x + 1); a DPP row sum per network; + the heads' terms
+      if (wave == 1) {
+        // lane (net, i) < 48: entry i of the Grams of dY1 / dY2 against (G_x1 / G_x2 + 1) - weight and bias gradients of trunk layers 1, 2 -, of the
+        // Gram of x3 against the heads' gradient products (S.part[128..], dY1 shadow), + the head-bias / logstd terms (32 entries over the 16 lanes
+        // of net 0; |sum_s dV_s|^2 on lane 0 of nets 1, 2); a DPP row sum per network
         float t = 0.0f;
         if (lane < 48) {
           const int net = lane >> 4, i = lane & 15;
-          t = S.part[net * 10 + tri16(i)] * (S.gx[net][1][i] + 1.0f) + S.part[32 + net * 10 + tri16(i)] * (S.gx[net][2][i] + 1.0f);
+          t = S.part[net * 10 + tri16(i)] * (S.gx[net][1][i] + 1.0f) + S.gd2[net][i] * (S.gx[net][2][i] + 1.0f) + S.gx[net][3][i] * S.part[128 + net * 16 + i];
+          if (net == 0) t += S.part[192 + i] + S.part[208 + i];
+          else if (i == 0) { float sb = 0.0f; for (int a = 0; a < MB; ++a) sb += S.dv[net - 1][a]; t += sb * sb; }
         }
         t = dpp_add<0xB1, 0xF>(t); t = dpp_add<0x4E, 0xF>(t); t = dpp_add<0x141, 0xF>(t); t = dpp_add<0x140, 0xF>(t);   // 16-lane row sums
-        if (lane < 48 && (lane & 15) == 0) S.n2rest[lane >> 4] = t + S.ctl.n2h[lane >> 4];
+        if (lane < 48 && (lane & 15) == 0) S.n2rest[lane >> 4] = t;
       } else if (tid >= 128 && tid < 128 + 3 * MB) { const int net = (tid - 128) / MB, s = (tid - 128) % MB; S.dyown[net][s][6] = S.dy2[net][s][g]; }
     }
     TS(18)
