@@ -29,6 +29,7 @@ void sdxpk_pad_obs(const SdxpDev*, const float*, hipStream_t);
 int sdxpk_backward_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_grads_from_factors(const SdxpDev*, int, hipStream_t);
 int sdxpk_apply_factors(const SdxpDev*, int, hipStream_t);
+int sdxpk_apply_factors_fused(const SdxpDev*, int, unsigned*, hipStream_t);
 int sdxpk_update_persistent(const SdxpDev*, int, unsigned*, hipStream_t);
 int sdxpk_fwd_bwd_persistent(const SdxpDev*, unsigned*, hipStream_t);
 int sdxpk_prenorm(const SdxpDev*, int, hipStream_t);
@@ -54,9 +55,10 @@ struct sdxp_agent {
   hipGraphExec_t graph_exec = nullptr;
   int graph_chunk = 0;
   bool use_persist = false;      // persistent register-resident update kernel (sdxp_persist.hip)
-  unsigned* bar_dev = nullptr;   // [64] grid-barrier counter (+ fail flag at [32])
+  unsigned* bar_dev = nullptr;   // [64] grid-barrier counter (+ fail flags at [32] persistent kernels, [34] one-launch apply; [36] its launch counter = tag of its exchange words)
   bool last_was_step = false;    // the most recent persistent launch was a single forward/backward (no restore possible on failure)
   bool use_persist_step = false; // multi-rank path: forward/backward of one minibatch as one persistent-style launch
+  bool use_fused_apply = false;  // multi-rank path: gradient rebuild + norm + clip + Adam + control block as one launch (SDXP_APPLY_IMPL=fused; default: three launches)
   unsigned* fail_host = nullptr; // pinned mirror of the fail flag, refreshed after every persistent update
   // what a persistent update touches before it can fail (old mu/sigma rows, running mean/std, control block): saved at the start
   // of the call so that sdxp_update_status can put it back and the caller can repeat the epoch on the hipGraph path
@@ -212,7 +214,7 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     D.foff.dh = o; o += MB * 34; D.foff.dls = o; o += 32; D.foff.kl = o; o += 1;
     D.foff.total = (o + 63) / 64 * 64;
     D.world = cfg->world_size > 0 ? cfg->world_size : 1;
-    PAL(D.fact, D.foff.total); PAL(D.fact_all, (size_t)D.foff.total * D.world); PAL(D.sqn_part, 4096);   // 2 x SDXP_SQN_STRIDE (sdxp_kernels.hip)
+    PAL(D.fact, D.foff.total); PAL(D.fact_all, (size_t)D.foff.total * D.world); PAL(D.sqn_part, 16384);   // 2 x SDXP_SQN_STRIDE partials, then (SDXP_TW_OFF) the tagged 16-byte words of the one-launch apply (sdxp_kernels.hip)
   }
   if (h->big) {   // activations and pre-activation gradients of one large minibatch, split partials of the weight gradients
     SdxpBigWs& w = h->bigws;
@@ -298,6 +300,8 @@ extern "C" int sdxp_create(const sdxp_config* cfg, int32_t device, uint64_t seed
     h->use_persist = supported && !(impl && std::string(impl) == "graph");
     const char* simpl = getenv("SDXP_STEP_IMPL");   // multi-rank path: "kernels" forces the multi-kernel forward/backward
     h->use_persist_step = supported && !(simpl && std::string(simpl) == "kernels");
+    const char* aimpl = getenv("SDXP_APPLY_IMPL");  // multi-rank path: "fused" = the one-launch apply (opt-in: its grid-wide meeting needs every workgroup resident, i.e. the GPU to itself)
+    h->use_fused_apply = aimpl && std::string(aimpl) == "fused";
     PCHK(h, hipHostMalloc((void**)&h->fail_host, sizeof(unsigned), hipHostMallocDefault));
     *h->fail_host = 0;
   }
@@ -581,6 +585,10 @@ extern "C" int sdxp_grads_from_factors(sdxp_handle h, void* stream) {
 // sdxp_grads_from_factors + sdxp_apply(0, -INFINITY) + sdxp_apply(1) in four launches (the multi-rank step is launch-latency bound)
 extern "C" int sdxp_apply_factors(sdxp_handle h, void* stream) {
   if (!h) return SDX_ERR_INVALID;
+  if (h->use_fused_apply) {   // one launch with a grid-wide ticket; -1: shape or occupancy does not allow it on this device
+    if (sdxpk_apply_factors_fused(&h->D, h->cfg.minibatch, h->bar_dev, (hipStream_t)stream) == 0) return plaunch_ok(h, "sdxp_apply_factors(fused)");
+    h->use_fused_apply = false;
+  }
   sdxpk_apply_factors(&h->D, h->cfg.minibatch, (hipStream_t)stream);
   return plaunch_ok(h, "sdxp_apply_factors");
 }
@@ -601,12 +609,23 @@ extern "C" int sdxp_update_status(sdxp_handle h, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   PCHK(h, hipStreamSynchronize(st));
   if (!h->fail_host) return SDX_OK;
+  if (h->use_fused_apply) {   // the one-launch apply gave up at its ticket: from that step on nothing was applied
+    PCHK(h, hipMemcpy(h->fail_host, h->bar_dev + 34, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (*h->fail_host) {
+      *h->fail_host = 0;
+      h->use_fused_apply = false;
+      PCHK(h, hipMemset(h->bar_dev + 34, 0, sizeof(unsigned)));
+      h->err = "sdxp_apply_factors: the one-launch apply timed out at its grid-wide meeting (not all workgroups resident?); optimiser steps of "
+               "this epoch were skipped from that launch on; this handle now uses the three-launch apply - restore a checkpoint";
+      return SDX_ERR_STATE;
+    }
+  }
   PCHK(h, hipMemcpy(h->fail_host, h->bar_dev + 32, sizeof(unsigned), hipMemcpyDeviceToHost));
   if (!*h->fail_host) return SDX_OK;
   if (h->last_was_step) {   // multi-rank path: a forward/backward launch gave up; its factors were garbage and may have been applied
     *h->fail_host = 0;
     h->use_persist_step = false;
-    PCHK(h, hipMemset(h->bar_dev, 0, 256));
+    PCHK(h, hipMemset(h->bar_dev, 0, 36 * sizeof(unsigned)));
     {   // tags of the failed launch must never be handed out again
       SdxpCtrl c;
       PCHK(h, hipMemcpy(&c, h->D.ctrl, sizeof(c), hipMemcpyDeviceToHost));
@@ -621,7 +640,7 @@ extern "C" int sdxp_update_status(sdxp_handle h, void* stream) {
   *h->fail_host = 0;
   h->use_persist = false;
   const size_t ra = (size_t)h->D.N * h->D.horizon * h->D.act_dim * sizeof(float), sd = (size_t)h->D.state_dim * sizeof(double);
-  PCHK(h, hipMemsetAsync(h->bar_dev, 0, 256, st));
+  PCHK(h, hipMemsetAsync(h->bar_dev, 0, 36 * sizeof(unsigned), st));
   PCHK(h, hipMemcpyAsync(h->D.mb_mus, h->mus_bak, ra, hipMemcpyDeviceToDevice, st));
   PCHK(h, hipMemcpyAsync(h->D.mb_sigmas, h->sig_bak, ra, hipMemcpyDeviceToDevice, st));
   PCHK(h, hipMemcpyAsync(h->D.rms_mean, h->rms_bak, sd, hipMemcpyDeviceToDevice, st));

@@ -1160,6 +1160,8 @@ __global__ __launch_bounds__(256) void k_pack_factors(SdxpDev D) {
 // block-level sum of the squared-gradient contributions of this workgroup, written (no atomics) to the slot of this workgroup:
 // part[slot] for the actor-critic buffer, part[SDXP_SQN_STRIDE + slot] for the central value.  Every thread of the 256 calls it.
 #define SDXP_SQN_STRIDE 2048
+#define SDXP_TW_OFF 4096    // D.sqn_part + SDXP_TW_OFF: 16-byte tagged words of the one-launch apply: [SDXP_SQN_STRIDE] workgroups, then [64] groups
+typedef unsigned int tw_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void write_sqn_partials(float ss_ac, float ss_cv, float* part, int slot) {
   __shared__ float s_sq[2][4];
   const int tid = threadIdx.x;
@@ -1500,6 +1502,17 @@ __global__ __launch_bounds__(256) void k_adam2(SdxpDev D) {
     M[i] = m; V[i] = v;
   }
 }
+// adam1 with every rounding spelled out (no compiler-chosen contraction): k_adam3 and the one-launch apply (k_apply_factors_fused) inline it
+// in different surroundings, where hipcc picked different fused multiply-adds for `0.9 m + 0.1 g` (first moments one ulp apart after one
+// step); written this way the two forms of the apply are bit-identical (tests/test_gpu_fullsize_properties.py).
+__device__ __forceinline__ float adam1x(float w, float g, float& m, float& v, float lr_bc1, float isq_bc2) {
+#pragma clang fp contract(off)
+  m = __builtin_fmaf(0.1f, g, 0.9f * m);
+  v = __builtin_fmaf(0.001f * g, g, 0.999f * v);
+  const float den = __builtin_fmaf(sqrtf(v), isq_bc2, 1e-8f);
+  const float q = (lr_bc1 * m) / den;
+  return w - q;
+}
 // k_adam2 with the squared norms taken from the per-workgroup partials that k_grad_all_w left in sqn_part (nparts slots per buffer):
 // every block folds them in the same fixed order -> the same clip scale in every block and on every rank
 __global__ __launch_bounds__(256) void k_adam3(SdxpDev D, int nparts) {
@@ -1531,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_adam3(SdxpDev D, int nparts) {
   const float lr_bc1 = lr / bc1, isq_bc2 = 1.0f / sqrtf(bc2);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float m = M[i], v = V[i];
-    P[i] = adam1(P[i], G[i] * inv_w * clip, m, v, lr_bc1, isq_bc2);
+    P[i] = adam1x(P[i], G[i] * inv_w * clip, m, v, lr_bc1, isq_bc2);
     M[i] = m; V[i] = v;
   }
 }
@@ -1554,6 +1567,275 @@ static void launch_apply_factors(const SdxpDev* D, hipStream_t st) {
   hipLaunchKernelGGL(k_grad_all_w<MB>, dim3(nb), dim3(256), (size_t)MB * Kmax * sizeof(float), st, *D, 1);
   hipLaunchKernelGGL(k_adam3, dim3(512, 2), dim3(256), 0, st, *D, nb);
   hipLaunchKernelGGL(k_apply_fin2, dim3(1), dim3(1), 0, st, *D);
+}
+// ---- the apply phase of the multi-rank step as ONE launch (round 6).  The three-launch form above rebuilds the summed
+// gradient (k_grad_all_w: 13.4 MB written), reads it back beside weights and moments (k_adam3) and advances the control block from a
+// single thread (k_apply_fin2): three dependent graph nodes of 7-10 us each.  Here every workgroup keeps the gradient elements it rebuilt
+// in registers, publishes its share of the squared norm, meets the other workgroups at ONE grid-wide ticket (all of them are resident: the
+// host checks the occupancy before it picks this form), folds the published shares in the fixed order of k_adam3 - the same clip scale
+// in every workgroup and on every rank - and sends its elements through Adam.  The flat gradient is never materialised (only the KL word
+// is); workgroup 0 advances the control block behind the ticket (every workgroup read what it needs of it BEFORE it arrived).
+// Exchange discipline (MI355X guide, cross-XCD hand-off): shares and KL word leave as write-through (sc1) stores, the producer drains its
+// stores (vmcnt(0)) before the relaxed agent-scope ticket increment, consumers read them with agent-scope loads after the ticket completes.
+// A workgroup that waits too long raises the fail flag (bar[34]) and every later launch returns at once: sdxp_update_status reports it
+// and the handle goes back to the three-launch form.
+template <int MB>
+__global__ __launch_bounds__(256, 6) void k_apply_factors_fused(SdxpDev D, unsigned* __restrict__ gen, unsigned* __restrict__ failflag) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float s_sq[2][4], s_n2[2];
+  __shared__ int s_ok;
+  __shared__ unsigned s_gen;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  SdxpCtrl* ctl = D.ctrl;
+  if (tid == 0) { s_ok = __hip_atomic_load(failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; s_gen = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __syncthreads();
+  const unsigned tag_gen = s_gen;   // launches of this handle so far (device counter: launches replayed from a hipGraph see it grow); workgroup 0 advances it behind the meeting
+  if (!s_ok) return;   // an earlier launch timed out at its ticket: nothing is applied until the host has looked (sdxp_update_status)
+  // ---- what this launch needs of the control block (read before the ticket: workgroup 0 advances the block behind it)
+  const float inv_w = 1.0f / (float)ctl->world;
+  const int t_ac = ctl->ac_t + 1, t_cv = ctl->cv_t + 1;
+  const float lr_ac = ctl->ac_lr, lr_cv = ctl->cv_lr;
+  const float ac_lr_bc1 = lr_ac / (1.0f - powf(0.9f, (float)t_ac)), ac_isq = 1.0f / sqrtf(1.0f - powf(0.999f, (float)t_ac));
+  const float cv_lr_bc1 = lr_cv / (1.0f - powf(0.9f, (float)t_cv)), cv_isq = 1.0f / sqrtf(1.0f - powf(0.999f, (float)t_cv));
+  // ---- the job of this workgroup (the map of k_grad_all_w): four rows of a trunk layer of one network, or a slice of the heads
+  const int nb0 = 3 * ((D.units[0] + 3) / 4), nb1 = 3 * ((D.units[1] + 3) / 4), nb2 = 3 * ((D.units[2] + 3) / 4);
+  int b = blockIdx.x, l = -1;
+  if (b < nb0) l = 0;
+  else if (b < nb0 + nb1) { l = 1; b -= nb0; }
+  else if (b < nb0 + nb1 + nb2) { l = 2; b -= nb0 + nb1; }
+  else b -= nb0 + nb1 + nb2;
+  const int W = D.world;
+  const float sc = 1.0f / (float)W;
+  float g[16], sb = 0.0f, ss_ac = 0.0f, ss_cv = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) g[j] = 0.0f;
+  // layer job
+  int net = 0, n = 0, K = 0;
+  size_t woff = 0, boff = 0;
+  bool valid = false;
+  // heads job: at most one element per thread (main slice, or - last heads block - a bias / logstd entry)
+  float gh = 0.0f;
+  int h_which = -1;     // 0: actor-critic buffer, 1: central value, -1: none
+  size_t h_idx = 0;
+  if (l >= 0) {
+    const int Nl = D.units[l];
+    const int blocks_per_net = (Nl + 3) / 4;
+    net = b / blocks_per_net; n = (b % blocks_per_net) * 4 + wave;
+    K = (l == 0) ? (net == 2 ? D.state_dim : D.obs_dim) : D.units[l - 1];
+    woff = net == 0 ? D.off.a_w[l] : net == 1 ? D.off.c_w[l] : D.coff.w[l];
+    boff = net == 0 ? D.off.a_b[l] : net == 1 ? D.off.c_b[l] : D.coff.b[l];
+    valid = n < Nl;
+    for (int r = 0; r < W; ++r) {      // ascending rank order on every rank: identical sums everywhere (grad_layer_w_body's arithmetic)
+      const float* F = D.fact_all + (size_t)r * D.foff.total;
+      const float* gx = F + D.foff.x[net][l];
+      for (int i = tid; i < MB * K; i += 256) sm[i] = gx[i];
+      __syncthreads();
+      if (valid) {
+        float dyn[MB];
+#pragma unroll
+        for (int s = 0; s < MB; ++s) { dyn[s] = F[D.foff.dy[net][l] + s * Nl + n]; sb += dyn[s]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = lane + 64 * j;
+          if (k < K) {
+#pragma unroll
+            for (int s = 0; s < MB; ++s) g[j] += dyn[s] * sm[s * K + k];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float ss = 0.0f;
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { const int k = lane + 64 * j; if (k < K) ss += (g[j] * sc) * (g[j] * sc); }
+      if (lane == 0) ss += (sb * sc) * (sb * sc);
+    }
+    if (net == 2) ss_cv = ss; else ss_ac = ss;
+  } else {
+    const int hb = b, nhb = (int)gridDim.x - (nb0 + nb1 + nb2);
+    const int U = D.units[2], A = D.act_dim;
+    const size_t T = D.foff.total;
+    const int i = hb * 256 + tid;
+    if (i < (A + 2) * U) {
+      const int row = i / U, k = i % U;
+      const int hnet = row < A ? 0 : (row == A ? 1 : 2);
+      for (int r = 0; r < W; ++r) {
+        const float* F = D.fact_all + r * T;
+        const float* dh = F + D.foff.dh;
+        const float* h = F + D.foff.h[hnet];
+        for (int s = 0; s < MB; ++s) gh += (row < A ? dh[s * 34 + row] : dh[s * 34 + 32 + (row - A)]) * h[s * U + k];
+      }
+      if (row < A) { h_which = 0; h_idx = D.off.mu_w + (size_t)row * U + k; }
+      else if (row == A) { h_which = 0; h_idx = D.off.v_w + k; }
+      else { h_which = 1; h_idx = D.coff.v_w + k; }
+      if (row <= A) ss_ac += (gh * sc) * (gh * sc); else ss_cv += (gh * sc) * (gh * sc);
+    }
+    if (hb == nhb - 1) {   // the tails: head biases, logstd, the ranks' KL sum
+      if (tid < A + 2) {
+        for (int r = 0; r < W; ++r) {
+          const float* dh = D.fact_all + r * T + D.foff.dh;
+          for (int s = 0; s < MB; ++s) gh += tid < A ? dh[s * 34 + tid] : dh[s * 34 + 32 + (tid - A)];
+        }
+        if (tid < A) { h_which = 0; h_idx = D.off.mu_b + tid; }
+        else if (tid == A) { h_which = 0; h_idx = D.off.v_b; }
+        else { h_which = 1; h_idx = D.coff.v_b; }
+        if (tid <= A) ss_ac += (gh * sc) * (gh * sc); else ss_cv += (gh * sc) * (gh * sc);
+      }
+      if (tid >= 64 && tid < 64 + A) {
+        for (int r = 0; r < W; ++r) gh += D.fact_all[r * T + D.foff.dls + (tid - 64)];
+        h_which = 0; h_idx = D.off.logstd + (tid - 64);
+        ss_ac += (gh * sc) * (gh * sc);
+      }
+      if (tid == 128) {   // SUM of the ranks' minibatch KL, where the LR rule (and sdxp_apply(0, -INFINITY)) looks for it
+        float kl = 0.0f;
+        for (int r = 0; r < W; ++r) kl += D.fact_all[r * T + D.foff.kl];
+        __hip_atomic_store(&D.ac_g[D.g_tail], kl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // ---- this workgroup's shares of the two squared norms (write_sqn_partials' order), then the grid-wide meeting: NO atomics.
+  // (First versions: one device-scope counter - 1 380 arrivals served one after the other at the memory side: 105 us per optimiser step
+  // against 68 with three launches; 64 counters: 87 us, the kernel alone 46.5 us against 7.8 + 18.4 + 4.7 for the three.)  The meeting is
+  // two hops of tagged 16-byte words, the persistent kernel's exchange discipline (write-through store, polling agent-scope loads, the
+  // tag - spread and folded with the payload so that a torn word is polled again - in the last dword), laid out so that the sums are
+  // k_adam3's to the bit: every workgroup publishes (share_ac, share_cv); workgroup w < 4 plays wave w of k_adam3's fold - lane l adds
+  // the shares 64 w + l + 256 k in ascending k, then wave_sum - and publishes that wave's sum; every workgroup gathers the four sums
+  // and adds them as (s0 + s1) + (s2 + s3).
+  ss_ac = wave_sum(ss_ac); ss_cv = wave_sum(ss_cv);
+  if (lane == 0) { s_sq[0][wave] = ss_ac; s_sq[1][wave] = ss_cv; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the KL word of thread 128 has left before the barrier that precedes this workgroup's word
+  __syncthreads();
+  if (wave == 0) {
+    const __amdgpu_buffer_rsrc_t Q = __builtin_amdgcn_make_buffer_rsrc(D.sqn_part + SDXP_TW_OFF, 0, (SDXP_SQN_STRIDE + 64) * 16, 0x00020000);
+    const unsigned nwg = gridDim.x;
+    const unsigned tagm = (tag_gen + 1u) * 0x9E3779B1u;
+    int ok = 1;
+    auto put = [&](unsigned idx, float x, float y) {
+      tw_u32x4 w; w.x = __float_as_uint(x); w.y = __float_as_uint(y); w.z = 0u; w.w = tagm ^ w.x ^ w.y;
+      __builtin_amdgcn_raw_buffer_store_b128(w, Q, idx * 16u, 0, 16);
+    };
+    // wave-uniform retry until every word idx0 + i * stride < limit carries this launch's tag; x / y: the words' payloads added in ascending i
+    auto gather_sum = [&](unsigned idx0, unsigned stride, unsigned limit, float& x, float& y) {
+      unsigned spins = 0;
+      for (;;) {
+        tw_u32x4 w[SDXP_SQN_STRIDE / 256];
+#pragma unroll
+        for (int i = 0; i < SDXP_SQN_STRIDE / 256; ++i) { const unsigned idx = idx0 + i * stride; w[i] = __builtin_amdgcn_raw_buffer_load_b128(Q, (idx < limit ? idx : idx0) * 16u, 0, 16); }
+        bool good = true;
+        x = 0.0f; y = 0.0f;
+#pragma unroll
+        for (int i = 0; i < SDXP_SQN_STRIDE / 256; ++i) {
+          const bool act = idx0 + i * stride < limit;
+          good = good && (!act || (w[i].w ^ w[i].x ^ w[i].y ^ w[i].z) == tagm);
+          if (act) { x += __uint_as_float(w[i].x); y += __uint_as_float(w[i].y); }
+        }
+        if (__builtin_amdgcn_ballot_w64(!good) == 0) return;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0) {
+          const unsigned f = __hip_atomic_load(failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (spins > (1u << 20) || __builtin_amdgcn_readfirstlane(f) != 0) {
+            if (lane == 0) __hip_atomic_store(failflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            return;
+          }
+        }
+      }
+    };
+    if (lane == 0) put(blockIdx.x, (s_sq[0][0] + s_sq[0][1]) + (s_sq[0][2] + s_sq[0][3]), (s_sq[1][0] + s_sq[1][1]) + (s_sq[1][2] + s_sq[1][3]));
+    if (blockIdx.x < 4) {   // wave blockIdx.x of k_adam3's fold
+      float x, y;
+      const unsigned t = 64u * blockIdx.x + lane;
+      gather_sum(t < nwg ? t : 0u, 256u, t < nwg ? nwg : 0u, x, y);
+      x = wave_sum(x); y = wave_sum(y);
+      if (ok && lane == 0) put(SDXP_SQN_STRIDE + blockIdx.x, x, y);
+    }
+    float x = 0.0f, y = 0.0f;
+    if (ok) gather_sum(SDXP_SQN_STRIDE + (lane < 4 ? lane : 0), 64u, SDXP_SQN_STRIDE + 4u, x, y);   // (one word per lane: 0.0f + the sum, exact)
+    const float x0 = lane0(x), y0 = lane0(y);
+    const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 1)), y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), 1));
+    const float x2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 2)), y2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), 2));
+    const float x3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 3)), y3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), 3));
+    if (lane == 0) { s_ok = ok; s_n2[0] = (x0 + x1) + (x2 + x3); s_n2[1] = (y0 + y1) + (y2 + y3); }
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  const float n2_ac = s_n2[0], n2_cv = s_n2[1];
+  const float clip_ac = D.truncate_grads ? fminf(1.0f, D.grad_norm / (sqrtf(n2_ac) + 1e-6f)) : 1.0f;
+  const float clip_cv = D.truncate_grads ? fminf(1.0f, D.grad_norm / (sqrtf(n2_cv) + 1e-6f)) : 1.0f;
+  // ---- Adam of the elements this workgroup holds (k_adam3's arithmetic: adam1x(P, G * inv_w * clip, ...))
+  if (l >= 0) {
+    if (valid) {
+      float* P = net == 2 ? D.cv : D.ac; float* M = net == 2 ? D.cv_m : D.ac_m; float* V = net == 2 ? D.cv_v : D.ac_v;
+      const float clip = net == 2 ? clip_cv : clip_ac, lr_bc1 = net == 2 ? cv_lr_bc1 : ac_lr_bc1, isq = net == 2 ? cv_isq : ac_isq;
+      const size_t row0 = woff + (size_t)n * K;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {   // eight columns per pass: their 24 loads in flight together, 80 VGPRs without a spill
+        if (512 * hf >= K) break;
+        float p[8], m[8], v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kk = lane + 64 * (8 * hf + j);
+          const int k = kk < K ? kk : K - 1;    // clamped address instead of a branch around the load
+          p[j] = P[row0 + k]; m[j] = M[row0 + k]; v[j] = V[row0 + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = lane + 64 * (8 * hf + j);
+          if (k < K) {
+            P[row0 + k] = adam1x(p[j], g[8 * hf + j] * inv_w * clip, m[j], v[j], lr_bc1, isq);
+            M[row0 + k] = m[j]; V[row0 + k] = v[j];
+          }
+        }
+      }
+      if (lane == 0) {
+        float bm = M[boff + n], bv = V[boff + n];
+        P[boff + n] = adam1x(P[boff + n], sb * inv_w * clip, bm, bv, lr_bc1, isq);
+        M[boff + n] = bm; V[boff + n] = bv;
+      }
+    }
+  } else if (h_which >= 0) {
+    float* P = h_which ? D.cv : D.ac; float* M = h_which ? D.cv_m : D.ac_m; float* V = h_which ? D.cv_v : D.ac_v;
+    float hm = M[h_idx], hv = V[h_idx];
+    P[h_idx] = adam1x(P[h_idx], gh * inv_w * (h_which ? clip_cv : clip_ac), hm, hv, h_which ? cv_lr_bc1 : ac_lr_bc1, h_which ? cv_isq : ac_isq);
+    M[h_idx] = hm; V[h_idx] = hv;
+  }
+  // ---- k_apply_fin2's work, behind the ticket
+  if (blockIdx.x == 0 && tid == 0) {
+    __hip_atomic_store(gen, tag_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctl->gn2_ac = n2_ac; ctl->gn2_cv = n2_cv;
+    ctl->cv_t += 1; ctl->cv_b1pow *= 0.9; ctl->cv_b2pow *= 0.999; ctl->cv_gnorm = sqrtf(n2_cv);
+    ctl->ac_t += 1; ctl->ac_b1pow *= 0.9; ctl->ac_b2pow *= 0.999; ctl->ac_gnorm = sqrtf(n2_ac);
+    const float kl = __hip_atomic_load(&D.ac_g[D.g_tail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (float)ctl->world;
+    if (D.adaptive_lr) {
+      if (kl > 2.0f * D.kl_threshold) ctl->ac_lr = fmaxf(ctl->ac_lr / 1.5f, 1e-6f);
+      if (kl < 0.5f * D.kl_threshold) ctl->ac_lr = fminf(ctl->ac_lr * 1.5f, 1e-2f);
+    }
+  }
+}
+// 1 when every workgroup of the one-launch apply can be resident at once on this device (its grid-wide ticket needs that); decided once per MB
+template <int MB>
+static int apply_fused_fits(const SdxpDev* D, int nb, size_t lds) {
+  static int fits = -1;
+  if (fits < 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    fits = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_apply_factors_fused<MB>, 256, lds) == hipSuccess)
+      fits = (long long)per_cu * prop.multiProcessorCount >= nb ? 1 : 0;
+  }
+  return fits;
+}
+extern "C" int sdxpk_apply_factors_fused(const SdxpDev* D, int mb_size, unsigned* bar, hipStream_t st) {
+  const int nhb = ((D->act_dim + 2) * D->units[2] + 255) / 256 + 1;
+  const int nb = 3 * ((D->units[0] + 3) / 4) + 3 * ((D->units[1] + 3) / 4) + 3 * ((D->units[2] + 3) / 4) + nhb;
+  const int Kmax = D->units[0] > D->state_dim ? D->units[0] : D->state_dim;
+  if (nb > SDXP_SQN_STRIDE || Kmax > 1024 || D->obs_dim > 1024) return -1;
+#define C_(M) { const size_t lds = (size_t)M * Kmax * sizeof(float); if (!apply_fused_fits<M>(D, nb, lds)) return -1; \
+                hipLaunchKernelGGL(k_apply_factors_fused<M>, dim3(nb), dim3(256), lds, st, *D, bar + 36, bar + 34); }
+  switch (mb_size) { case 2: C_(2) return 0; case 4: C_(4) return 0; default: return -1; }
+#undef C_
 }
 // clip_grad_norm_ + Adam + LR schedule on the flat gradients already sitting in ac_g / cv_g (KL word in ac_g[g_tail])
 extern "C" void sdxpk_apply_flat(const SdxpDev* D, hipStream_t st) {

@@ -242,6 +242,52 @@ def test_factor_exchange_equals_gradient_allreduce_world2_emulated():
             ag.close()
 
 
+def test_one_launch_apply_equals_three_launch_apply_bit_for_bit():
+    """the apply phase of the multi-rank step as ONE launch (k_apply_factors_fused: gradient rebuild in registers, grid-wide ticket, the
+    squared-norm shares folded in k_adam3's order, Adam, control block; SDXP_APPLY_IMPL=fused) against the default three-launch form on the
+    same factors of two emulated ranks: parameters, both Adam moments, counters, gradient norms and the learning rate must be bit-identical
+    after every one of 64 optimiser steps' worth of launches (checked at the end: a single differing bit would spread)."""
+    n, world = 16, 2
+    B = _filled_agent_w(n, 5, 4, world)                   # rank 0, three launches (the default)
+    os.environ["SDXP_APPLY_IMPL"] = "fused"
+    try:
+        A = _filled_agent_w(n, 5, 4, world)               # rank 0 again, one-launch apply
+        C = _filled_agent_w(n, 5, 6, world)               # rank 1 (another dataset), one-launch apply
+    finally:
+        del os.environ["SDXP_APPLY_IMPL"]
+    try:
+        for ag in (A, B, C):
+            ag.backward_factors(-1)
+        for ep in range(2):
+            for mb in range(n * 8 // 4):
+                for ag in (A, B, C):
+                    ag.backward_factors(mb)
+                np.testing.assert_array_equal(A.t["FACTORS"].cpu().numpy(), B.t["FACTORS"].cpu().numpy())
+                f = torch.stack([A.t["FACTORS"], C.t["FACTORS"]])
+                for ag in (A, B, C):
+                    ag.t["FACTORS_ALL"].copy_(f)
+                    ag.apply_factors()
+        for ag in (A, B, C):
+            ag.update_status()
+        ca, cb, cc = A.ctrl(), B.ctrl(), C.ctrl()
+        assert ca.ac_t == cb.ac_t == cc.ac_t == 2 * (n * 8 // 4) and ca.cv_t == cb.cv_t
+        for k in ("ac_lr", "ac_gnorm", "cv_gnorm", "gn2_ac", "gn2_cv", "ac_b1pow", "cv_b2pow"):
+            assert getattr(ca, k) == getattr(cb, k) == getattr(cc, k), k
+        assert ca.ac_gnorm > 0.0 and ca.cv_gnorm > 0.0
+        moved = False
+        for k in ("AC_PARAMS", "CV_PARAMS", "AC_ADAM_M", "AC_ADAM_V", "CV_ADAM_M", "CV_ADAM_V"):
+            if k not in A.t:
+                continue
+            a = A.t[k].cpu().numpy()
+            np.testing.assert_array_equal(a, B.t[k].cpu().numpy(), err_msg=k)      # one launch == three launches
+            np.testing.assert_array_equal(a, C.t[k].cpu().numpy(), err_msg=k)      # the two ranks in lock step
+            moved = moved or bool(np.abs(a).max() > 0)
+        assert moved
+    finally:
+        for ag in (A, B, C):
+            ag.close()
+
+
 def test_persistent_kernel_failure_falls_back_to_graph_path():
     """fault injection (SDXP_PERSIST_FAULT=1: one CU of the persistent kernel goes silent at step 3): every other CU must time out
     instead of hanging, nothing of the epoch may be applied, the touched inputs must be restored, and update_checked() must

@@ -53,6 +53,33 @@ PY
 ppo_tests)   # PPO parity tests on the device (-k "$1" optional)
   timeout 1200 python -m pytest tests/test_gpu_ppo_parity.py -q -m gpu -x ${1:+-k "$1"} 2>&1 | tail -15 > $O/tests.txt; tail -8 $O/tests.txt
   ;;
+pclock)   # phase clock of the persistent update kernel only ($1 = tag, further args = variant libraries)
+  tagp=${1:-head}; shift
+  SDXP_PERSIST_STAMPS=1 timeout 200 python tools/prof_persist.py 1024 > $O/phase_clock_$tagp.txt 2> /dev/null; cat $O/phase_clock_$tagp.txt
+  for v in "$@"; do
+    SDX_LIB_PATH=$PWD/seqdex_amd/lib/libseqdex_$v.so SDXP_PERSIST_STAMPS=1 timeout 200 python tools/prof_persist.py 1024 > $O/phase_clock_${tagp}_$v.txt 2> /dev/null; echo "== $v"; cat $O/phase_clock_${tagp}_$v.txt
+  done
+  ;;
+multirank)   # the multi-rank optimiser step on one GPU: its tests, then the forced world-1 bench line with the one-launch and the three-launch apply ($1 = tag)
+  tagp=${1:-head}
+  timeout 900 python -m pytest tests/test_gpu_fullsize_properties.py tests/test_gpu_two_ranks_one_gpu.py -q -m gpu -x -k "one_launch_apply or factor_exchange or rccl_world1 or two_processes" 2>&1 | tail -60 > $O/tests_$tagp.txt; tail -4 $O/tests_$tagp.txt
+  SDXP_APPLY_IMPL=fused SDX_FORCE_MULTI_RANK=1 timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-large-minibatch > $O/bench_fused_$tagp.json 2> $O/bench_fused_$tagp.err; echo "fused rc $?"
+  SDX_FORCE_MULTI_RANK=1 timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-large-minibatch > $O/bench_three_$tagp.json 2> $O/bench_three_$tagp.err; echo "three-launch rc $?"
+  for t in fused three; do python -c "
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][0])
+print(sys.argv[2], 'value %.0f ms/step %.2f' % (d['value'], d['ms_per_step']), 'update_path', d.get('update_path'), json.dumps(d.get('roofline_update') or d.get('roofline'))[:300])
+" $O/bench_${t}_$tagp.json $t; done
+  if [ -n "$2" ]; then   # $2 = trace: kernel durations of both forms (rocprofv3 kernel trace of a one-epoch run)
+    for t in fused three; do
+      if [ $t = fused ]; then export SDXP_APPLY_IMPL=fused; else unset SDXP_APPLY_IMPL; fi
+      SDX_FORCE_MULTI_RANK=1 timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $O/prof_$t -o r6 -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-large-minibatch > $O/prof_$t.log 2>&1; echo "prof $t rc $?"
+      db=$(find $O/prof_$t -name "*_results.db" | head -1); [ -n "$db" ] && python tools/rocpd_summary.py stats $db $O/kernel_stats_${t}_$tagp.csv; rm -rf $O/prof_$t
+      head -8 $O/kernel_stats_${t}_$tagp.csv | cut -c1-160
+    done
+    unset SDXP_APPLY_IMPL
+  fi
+  ;;
 persist)   # the persistent update kernel: its oracle / determinism / fault tests, phase clock of CU 0, short bench line ($1 = tag of the output files)
   tagp=${1:-head}
   timeout 900 python -m pytest tests/test_gpu_ppo_parity.py tests/test_gpu_fullsize_properties.py -q -m gpu -x -k "update_matches_autograd_adam or persistent or narrow_padded or explicit_gradient_path" 2>&1 | tail -8 > $O/tests_$tagp.txt; tail -4 $O/tests_$tagp.txt
