@@ -49,7 +49,8 @@ extern "C" {
 #define SDX_NUM_ACTIONS 23  /* GS:211                                                                        */
 #define SDX_OBS_FRAME 132
 #define SDX_STATE_FRAME 188
-#define SDX_PILE_HARVEST_SLOTS 512 /* Orient's ring of pile states per brick-type group (the reference keeps 10 000: OR:1485)     */
+#define SDX_PILE_HARVEST_SLOTS 512 /* Orient's ring of pile states per brick-type group; SDX_PILE_SLOTS=10000 in the environment of
+                                       sdx_create gives the reference's length (OR:1485: 10 000 = 549 MB)                          */
 #define SDX_TV_LOG_SLOTS 1048576 /* rows of each T-value dataset ring (success / failure): large enough that the runs of the chain
                                   * never wrap it (a wrapped ring's surviving rows depend on the order the slots were claimed in)      */
 #define SDX_HARVEST_SLOTS 5001 /* ring of grasp terminal states per brick-type group (GS:1440: index wraps after 5000) */

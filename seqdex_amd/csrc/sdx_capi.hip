@@ -174,6 +174,11 @@ extern "C" int sdx_create(const sdx_scene_desc* scene, int32_t num_envs, int32_t
   ALLOC(tv_key, (size_t)2 * SDX_TV_LOG_SLOTS);
   ALLOC(harvest_key, (size_t)8 * SDX_HARVEST_SLOTS);
   B.pile_slots = (scene->task_kind == 1 || scene->task_kind == 3) ? SDX_PILE_HARVEST_SLOTS : 1;   // Orient and Search harvest piles
+  if (B.pile_slots > 1) {   // SDX_PILE_SLOTS=10000: the reference's ring length (OR:1485; 549 MB of the 288 GB); default SDX_PILE_HARVEST_SLOTS
+    const char* ps = getenv("SDX_PILE_SLOTS");
+    const long v = ps ? atol(ps) : 0;
+    if (v >= 16 && v <= 10000) B.pile_slots = (int32_t)v;
+  }
   ALLOC(pile_harvest, (size_t)8 * B.pile_slots * SDX_NBRICK * 13);
   ALLOC(pile_harvest_count, 8);
   ALLOC(pile_key, (size_t)8 * B.pile_slots);

@@ -9,7 +9,7 @@ Same robot, bin and brick pile as BlockAssemblyGraspSim; what the Orient task ch
   * finger drives kp 20 / effort 0.7 (OR:596-597), target brick 50 x heavier (OR:977);
   * reset with the two scripted 50-step pre-grasp phases (OR:1427-1461, 1655-1695) - inside sdx_step, on the device.
   * terminal-state harvesting (OR:1463-1488): finished episodes that leave the target brick reachable hand their whole brick pile on
-    (`pile_terminal_states()` -> `BlockAssemblyGraspSim(initial_piles=...)`), ring of 512 per brick-type group (reference: 10 000).
+    (`pile_terminal_states()` -> `BlockAssemblyGraspSim(initial_piles=...)`), ring of 512 per brick-type group (SDX_PILE_SLOTS=10000 in the environment: the reference's 10 000).
 Not reproduced: the 36-brick floor of this scene (the GraspSim slab is used), the density 2000 of the fixed
 bricks (they are static here anyway).
 """

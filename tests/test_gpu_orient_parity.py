@@ -138,6 +138,35 @@ def test_orient_task_end_to_end_with_scripted_reset(scene):
     assert 0.0 < float(rew.mean()) <= 1.0                        # exp(-...) reward
 
 
+def test_pile_ring_takes_the_reference_length_from_the_environment():
+    """OR:1485 keeps 10 000 piles per brick-type group; the default ring here is SDX_PILE_HARVEST_SLOTS = 512, SDX_PILE_SLOTS in the
+    environment of sdx_create selects the length (549 MB at 10 000).  The ring and its key tensor follow, appends still land in it."""
+    import yaml
+    from seqdex_amd import _abi
+    from seqdex_amd.tasks.block_assembly_orient import BlockAssemblyOrient
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root_dir, "seqdex_amd/cfg/allegro_hand_block_assembly_orient.yaml")))
+    n = 16
+    cfg["env"]["numEnvs"] = n
+    os.environ["SDX_PILE_SLOTS"] = "10000"
+    try:
+        task = BlockAssemblyOrient(cfg, device_type="cuda", device_id=0, headless=True, seed=4, piles_per_type=2)
+    finally:
+        del os.environ["SDX_PILE_SLOTS"]
+    assert tuple(task.sim.PILE_HARVEST.shape) == (8, 10000, 132, 13) and tuple(task.sim.PILE_HARVEST_KEYS.shape) == (8, 10000)
+    flat = np.zeros(_abi.TV_PARAMS, np.float32)
+    flat[-1] = 20.0                                   # the 0.99 gate accepts every state
+    task.sim.set_tvalue_weights(flat)
+    g = torch.Generator().manual_seed(0)
+    for t in range(77):
+        task.step(((torch.rand(n, 23, generator=g) * 2 - 1) * 0.1).cuda())
+    torch.cuda.synchronize()
+    pc = task.sim.PILE_HARVEST_COUNT.cpu().numpy()
+    assert pc.sum() >= n // 2
+    piles = task.pile_terminal_states()
+    assert piles is not None and piles.shape[1] == int(pc.min()) and np.isfinite(piles.cpu().numpy()).all()
+
+
 def test_orient_harvests_pile_states_for_grasp_sim(scene):
     """OR:1463-1488: at a reset event (after the first one) every env whose episode ended with the hand withdrawn, the target brick in
     the bin half and an accepting T-value stores its whole brick pile in the ring of its brick-type group and logs a T-value success;
