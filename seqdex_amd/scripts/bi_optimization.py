@@ -228,7 +228,10 @@ def block_assembly(rounds=10, num_envs=512, epochs=0, tvalue_rollout=10000, inse
 CONFIG5_EPOCHS = {"search": 20, "orient": 10, "grasp": 20, "insert": 48, "insert_backward": 32}
 # round 5: the grasp stage long enough, and on minibatches large enough, for the policy to LEARN to lift: its own
 # terminal states go to InsertSim and its own outcomes to the transition-value fit - no scripted stand-in
-CONFIG5_LEARNED_EPOCHS = dict(CONFIG5_EPOCHS, grasp=400, grasp_backward=100)
+# orient_backward: the backward Orient leg plays 128 envs (bi_optimization.py:124); at the forward leg's 10 epochs it finishes 128 episodes in all,
+# and the transition-value trainer holds out 100 success rows - whether the last refit of a round happened then hung on a 78 % success share
+# (round 6: a rounding change in the persistent update moved it to 23 % and the refit was skipped).  60 epochs = ~770 episodes, +2 s
+CONFIG5_LEARNED_EPOCHS = dict(CONFIG5_EPOCHS, grasp=400, grasp_backward=100, orient_backward=60)
 CONFIG5_GRASP_MINIBATCH = 2048
 
 

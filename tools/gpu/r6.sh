@@ -147,7 +147,7 @@ biopt_long)   # bi-optimisation rounds at a length that inserts: $1 = output nam
   timeout 3400 python tools/biopt_long.py "$@" --out $O/$name.json 2> $O/$name.err | grep -v "^Setting\|amdgpu\|^fps step" | cut -c1-400 | tail -60; tail -3 $O/$name.err | cut -c1-400
   ;;
 suite)   # the whole -m gpu suite as the driver runs it, then smoke()
-  timeout 3000 python -m pytest tests/ -x -q -m gpu --durations=15 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -60 > $O/gputests.txt; grep -E "passed|failed|error" $O/gputests.txt | tail -3
+  timeout 3000 python -m pytest tests/ -q -m gpu --durations=15 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -60 > $O/gputests.txt; grep -E "passed|failed|error" $O/gputests.txt | tail -3
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
   ;;
 *) echo "unknown job $job"; exit 2 ;;
