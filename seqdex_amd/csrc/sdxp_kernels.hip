@@ -196,6 +196,144 @@ __global__ __launch_bounds__(256 * KS) void k_linear_mfma(LinBatch lb) {
       }
   }
 }
+// ---- the same product with the operands staged by LDS-DMA (round 6).  k_linear_mfma above moves every 16-byte piece
+// global -> VGPR -> (normalise / zero) -> four ds_write_b32 into a padded [row][33] image and reads it back one dword at a time: per 32-wide
+// chunk a wave issues 2 loads, 8 LDS stores and 16 LDS loads around its 8 MFMAs, in three barrier-separated phases (read, multiply, stage), and
+// a chunk takes ~0.9 us where its multiplies need 0.5 (2 waves per SIMD).  Here the pieces go straight into LDS (global_load_lds_dwordx4: no
+// staging registers, no LDS stores, no stage phase), into an XOR-swizzled image of 16-byte slots - slot(row, q) = 8 row + (q ^ ((row >> 1) & 7)),
+// the swizzle applied on the SOURCE address since the DMA writes base + 16 lane - that ds_read_b128 reads without bank conflicts in its four
+// 16-lane groups; a lane gets four k values per read, so a wave issues 4 LDS loads per chunk instead of 16 (the k order inside a chunk is
+// permuted - lanes 0-31 take piece 2t, lanes 32-63 piece 2t + 1 of the k group - identically for both operands).  NBUF image pairs rotate:
+// wait (counted vmcnt) for chunk c, LDS-only barrier, request chunk c + NBUF - 1 into the pair everybody finished reading before that barrier,
+// read, multiply.  The normalisation of a first layer's input is applied to the A operand after the read (same arithmetic: (x - mean) / sd,
+// clamp); pieces past K of the last chunk are zeroed in LDS by the lanes that would have loaded them.  ALL LDS of the kernel is one array (a
+// second __shared__ object makes hipcc wait vmcnt(0) in front of every ds_read of a DMA pipeline).
+// Measured (tools/time_linear.py, profiles/r6_linear_layers_lds_dma.txt): 28.2 / 29.0 / 17.1 us for the three layers against 30.5 / 29.4 / 17.0 with
+// k_linear_mfma's best shape - the staging was NOT what these layers wait for.  What the two kernels share is what is left: the 17.1 us of the
+// 16-chunk last layer and the 29.0 us of the 32-chunk middle layer (one workgroup per CU both) put a chunk at 0.74 us - its 16 multiplies per SIMD
+// need 0.5 us at the ~2.05 GHz these kernels run at - and the launch with its prologue (first pieces from HBM) and epilogue (k-group sum, stores)
+// at 5.2 us, three times per sdxp_act.  sdxp_act as a whole did not move (92 us either way), so the launcher keeps shape 3; this kernel is shape
+// 7 (SDXP_LINEAR_TILE=7), held to float64 with every other shape by tests/test_gpu_linear_kernel.py.  A fourth image pair (72 KB of LDS: the
+// tables then sit above 64 KB) gave wrong sums in normalised launches - LDS addresses above 64 KB through inline-asm ds_read - and 1 % in time: dropped.
+// LDS reads of the DMA pipeline as inline asm: hipcc's wait-count pass treats every ds_read it can see as a possible reader of every LDS-DMA
+// in flight and puts s_waitcnt vmcnt(0) in front of it (seen in the first build of this kernel: the chunk requested a line earlier was waited
+// for at once, the pipeline was serial).  What it cannot see it does not wait for; the waits are spelled out (lds_wait4 / lds_wait8).
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v_t lds_read128(unsigned byte_addr) {
+  f4v_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
+__device__ __forceinline__ void lds_wait4(f4v_t& a, f4v_t& b, f4v_t& c, f4v_t& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+template <int KS, int NBUF>
+__global__ __launch_bounds__(256 * KS) void k_linear_glds(LinBatch lb) {
+  static_assert(KS == 2 && NBUF == 3, "512 threads move one 16-byte piece of each operand tile per chunk; everything stays below 64 KB of LDS");
+  constexpr int GK = 32, TILE = 64 * 8 * 4, OPER = NBUF * 2 * TILE, RED = (KS - 1) * 4 * 16 * 64, NTAB = SDXP_NORM_K + GK;
+  static_assert(RED <= OPER, "the k-group reduction reuses the operand images");
+  __shared__ __attribute__((aligned(16))) float lds[OPER + 2 * NTAB];
+  float* nmu = lds + OPER;
+  float* nsd = nmu + NTAB;
+  const LinArgs& g = lb.a[blockIdx.z];
+  const int tid = threadIdx.x, wave8 = tid >> 6, wave = wave8 & 3, kg = tid >> 8, lane = tid & 63;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int M = g.M, N = g.N, K = g.K;
+  if (m0 >= M || n0 >= N) return;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const bool norm = g.nmean != nullptr;
+  if (norm) {   // ordinary loads: finished (the barrier below) before the first DMA is requested
+    for (int k = tid; k < NTAB; k += 256 * KS) { nmu[k] = k < K ? (float)g.nmean[k] : 0.0f; nsd[k] = k < K ? sqrtf((float)g.nvar[k] + 1e-5f) : 1.0f; }
+    __syncthreads();
+  }
+  // loader coordinates: slot tid of an image = (row tid / 8, position tid % 8) holds piece q = position ^ swizzle(row) of that row
+  const int lrow = tid >> 3, lq = (tid & 7) ^ ((lrow >> 1) & 7);
+  const float* pa = g.X + (size_t)(m0 + lrow < M ? m0 + lrow : M - 1) * K + 4 * lq;
+  const float* pb = g.W + (size_t)(n0 + lrow < N ? n0 + lrow : N - 1) * K + 4 * lq;
+  const int nchunk = (K + GK - 1) / GK;
+  auto request = [&](int c, int buf) {
+    float* da = lds + buf * 2 * TILE + wave8 * 256;   // this wave's 64 slots of the A image (wave-uniform: the DMA adds 16 lane)
+    float* db = da + TILE;
+    if (c * GK + 4 * lq < K) {
+      __builtin_amdgcn_global_load_lds(SDX_AS_GLOBAL(pa + c * GK), SDX_AS_LDS(da), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(SDX_AS_GLOBAL(pb + c * GK), SDX_AS_LDS(db), 16, 0, 0);
+    } else {                                        // past K (last chunk only): zeros, by the lanes whose pieces these are
+      *reinterpret_cast<float4*>(da + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      *reinterpret_cast<float4*>(db + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  // reader coordinates
+  const int ra = wm + (lane & 31), rb = wn + (lane & 31), hf = lane >> 5;
+  const int sa = ra * 8, xa = (ra >> 1) & 7, sb = rb * 8, xb = (rb >> 1) & 7;
+  const unsigned lds_base = (unsigned)(uintptr_t)SDX_AS_LDS(lds);   // byte offset of the array inside the workgroup's LDS
+#pragma unroll
+  for (int c = 0; c < NBUF - 1; ++c)
+    if (c < nchunk) request(c, c);
+  int buf = 0, nbuf = NBUF - 1;                     // image pair of chunk c / of chunk c + NBUF - 1
+  for (int c = 0; c < nchunk; ++c) {
+    // chunk c has landed in this wave's slots once at most NBUF - 2 younger chunks (two DMAs each) are still outstanding
+    if (c + NBUF - 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NBUF - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SDX_LDS_BARRIER();
+    if (c + NBUF - 1 < nchunk) request(c + NBUF - 1, nbuf);
+    const unsigned A = lds_base + (unsigned)buf * (2 * TILE * 4), B = A + TILE * 4;
+    f4v_t av[2], bv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int q = 4 * kg + 2 * t + hf;
+      av[t] = lds_read128(A + 16u * (unsigned)(sa + (q ^ xa)));
+      bv[t] = lds_read128(B + 16u * (unsigned)(sb + (q ^ xb)));
+    }
+    if (norm) {
+      f4v_t mu[2], sd[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const unsigned k = (unsigned)(c * GK + 4 * (4 * kg + 2 * t + hf));
+        mu[t] = lds_read128(lds_base + 4u * (OPER + k));
+        sd[t] = lds_read128(lds_base + 4u * (OPER + NTAB + k));
+      }
+      lds_wait4(mu[0], mu[1], sd[0], sd[1]);
+      lds_wait4(av[0], av[1], bv[0], bv[1]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[t][i] = clampf((av[t][i] - mu[t][i]) / sd[t][i], -5.0f, 5.0f);
+    } else {
+      lds_wait4(av[0], av[1], bv[0], bv[1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][i], bv[t][i], acc, 0, 0, 0);
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
+  }
+  // sum of the k groups, in group order (the operand images are reused)
+  SDX_LDS_BARRIER();
+  {
+    float* red = lds + wave * 16 * 64;
+    if (kg == 1)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[i * 64 + lane] = acc[i];
+    SDX_LDS_BARRIER();
+    if (kg != 0) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += red[i * 64 + lane];
+  }
+  const int col = n0 + wn + (lane & 31);
+  if (col < N) {
+    const float bias = g.b[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < M) {
+        const float v = acc[r] + bias;
+        g.Y[(size_t)row * N + col] = g.elu ? elu(v) : v;
+      }
+    }
+  }
+}
 template <int WTM, int KS, int GKc>
 static void launch_linear_as(const LinBatch& lb, int count, int M, int Nx, hipStream_t st) {
   hipLaunchKernelGGL((k_linear_mfma<WTM, KS, GKc>), dim3((Nx + GT - 1) / GT, (M + WTM * GT - 1) / (WTM * GT), count), dim3(256 * KS), 0, st, lb);
@@ -219,6 +357,7 @@ static void launch_linear(const LinBatch& lb, int count, int M, int Nx, hipStrea
     case 4: launch_linear_as<1, 2, 64>(lb, count, M, Nx, st); break;
     case 5: launch_linear_as<1, 4, 64>(lb, count, M, Nx, st); break;
     case 6: launch_linear_as<1, 1, 64>(lb, count, M, Nx, st); break;
+    case 7: hipLaunchKernelGGL((k_linear_glds<2, 3>), dim3((Nx + GT - 1) / GT, (M + GT - 1) / GT, count), dim3(512), 0, st, lb); break;
     default: launch_linear_as<1, 1, 32>(lb, count, M, Nx, st); break;
   }
 }

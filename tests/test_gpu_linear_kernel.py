@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [1, 2, 3, 4, 5, 6]
+SHAPES = [1, 2, 3, 4, 5, 6, 7]      # 7: k_linear_glds (operands staged by LDS-DMA)
 CASES = [(1024, 1024, 396), (1024, 1024, 564), (1024, 512, 1024), (1024, 256, 512), (100, 2, 128), (65, 70, 36), (3, 1, 4), (130, 129, 68), (4096, 512, 1024)]
 
 

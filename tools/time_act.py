@@ -20,8 +20,8 @@ lib.sdxpk_linear_force_shape.argtypes = [C.c_int]
 obs = torch.randn(n, 396, device="cuda").clamp(-5, 5)
 st = torch.randn(n, 564, device="cuda").clamp(-5, 5)
 names = {0: "automatic", 1: "64x64, chunks of 32", 2: "128x64, chunks of 32", 3: "64x64, 2 k groups, chunks of 32", 4: "64x64, 2 k groups, chunks of 64",
-         5: "64x64, 4 k groups, chunks of 64", 6: "64x64, chunks of 64"}
-for shape in (0, 1, 3, 4, 2, 5, 6):
+         5: "64x64, 4 k groups, chunks of 64", 6: "64x64, chunks of 64", 7: "64x64, LDS-DMA staging, 3 image pairs"}
+for shape in ([int(a) for a in sys.argv[2:]] or (0, 1, 3, 4, 2, 5, 6, 7)):
     lib.sdxpk_linear_force_shape(shape)
     for _ in range(5):
         ppo.act(0, obs, st)
