@@ -209,22 +209,12 @@ __global__ __launch_bounds__(256 * KS) void k_linear_mfma(LinBatch lb) {
 // clamp); pieces past K of the last chunk are zeroed in LDS by the lanes that would have loaded them.  ALL LDS of the kernel is one array (a
 // second __shared__ object makes hipcc wait vmcnt(0) in front of every ds_read of a DMA pipeline).
 // Measured (tools/time_linear.py, profiles/r6_linear_layers_lds_dma.txt): 28.2 / 29.0 / 17.1 us for the three layers against 30.5 / 29.4 / 17.0 with
-// k_linear_mfma's best shape - the staging was NOT what these layers wait for.  What the two kernels share is what is left: the 17.1 us of the
-// 16-chunk last layer and the 29.0 us of the 32-chunk middle layer (one workgroup per CU both) put a chunk at 0.74 us - its 16 multiplies per SIMD
-// need 0.5 us at the ~2.05 GHz these kernels run at - and the launch with its prologue (first pieces from HBM) and epilogue (k-group sum, stores)
-// at 5.2 us, three times per sdxp_act.  sdxp_act as a whole did not move (92 us either way), so the launcher keeps shape 3; this kernel is shape
-// 7 (SDXP_LINEAR_TILE=7), held to float64 with every other shape by tests/test_gpu_linear_kernel.py.  A fourth image pair (72 KB of LDS: the
-// tables then sit above 64 KB) gave wrong sums in normalised launches - LDS addresses above 64 KB through inline-asm ds_read - and 1 % in time: dropped.
-// LDS reads of the DMA pipeline as inline asm: hipcc's wait-count pass treats every ds_read it can see as a possible reader of every LDS-DMA
-// in flight and puts s_waitcnt vmcnt(0) in front of it (seen in the first build of this kernel: the chunk requested a line earlier was waited
-// for at once, the pipeline was serial).  What it cannot see it does not wait for; the waits are spelled out (lds_wait4 / lds_wait8).
-typedef float f4v_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f4v_t lds_read128(unsigned byte_addr) {
-  f4v_t v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
-  return v;
-}
-__device__ __forceinline__ void lds_wait4(f4v_t& a, f4v_t& b, f4v_t& c, f4v_t& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+// k_linear_mfma's best shape, and the same again (28.9 / 28.6 / 16.9) with the next chunk's LDS reads requested under this chunk's multiplies
+// (the form below).  Neither the staging nor the LDS reads are what these layers wait for: a chunk costs 0.74 us = its 16 multiplies per SIMD at
+// 68 % of the nominal fp32 matrix rate, the ceiling the large GEMMs of sdx_gemm_nt.h also sit at; a launch costs 5.2 us beyond its chunks, three
+// times per sdxp_act.  sdxp_act as a whole did not move, so the launcher keeps shape 3; this kernel is shape 7
+// (SDXP_LINEAR_TILE=7), held to float64 with every other shape by tests/test_gpu_linear_kernel.py.  A fourth image pair (72 KB of LDS: the tables
+// then sit above 64 KB) gave wrong sums in normalised launches - LDS addresses above 64 KB through inline-asm ds_read - and 1 % in time: dropped.
 template <int KS, int NBUF>
 __global__ __launch_bounds__(256 * KS) void k_linear_glds(LinBatch lb) {
   static_assert(KS == 2 && NBUF == 3, "512 threads move one 16-byte piece of each operand tile per chunk; everything stays below 64 KB of LDS");
@@ -267,47 +257,63 @@ __global__ __launch_bounds__(256 * KS) void k_linear_glds(LinBatch lb) {
   const int ra = wm + (lane & 31), rb = wn + (lane & 31), hf = lane >> 5;
   const int sa = ra * 8, xa = (ra >> 1) & 7, sb = rb * 8, xb = (rb >> 1) & 7;
   const unsigned lds_base = (unsigned)(uintptr_t)SDX_AS_LDS(lds);   // byte offset of the array inside the workgroup's LDS
-#pragma unroll
-  for (int c = 0; c < NBUF - 1; ++c)
-    if (c < nchunk) request(c, c);
-  int buf = 0, nbuf = NBUF - 1;                     // image pair of chunk c / of chunk c + NBUF - 1
-  for (int c = 0; c < nchunk; ++c) {
-    // chunk c has landed in this wave's slots once at most NBUF - 2 younger chunks (two DMAs each) are still outstanding
-    if (c + NBUF - 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NBUF - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SDX_LDS_BARRIER();
-    if (c + NBUF - 1 < nchunk) request(c + NBUF - 1, nbuf);
+  struct Frag { f4v_t a[2], b[2], mu[2], sd[2]; };
+  auto read_chunk = [&](int c, int buf, Frag& f) {   // requests only: the LDS-only barrier of the next trip completes them
     const unsigned A = lds_base + (unsigned)buf * (2 * TILE * 4), B = A + TILE * 4;
-    f4v_t av[2], bv[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int q = 4 * kg + 2 * t + hf;
-      av[t] = lds_read128(A + 16u * (unsigned)(sa + (q ^ xa)));
-      bv[t] = lds_read128(B + 16u * (unsigned)(sb + (q ^ xb)));
-    }
-    if (norm) {
-      f4v_t mu[2], sd[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const unsigned k = (unsigned)(c * GK + 4 * (4 * kg + 2 * t + hf));
-        mu[t] = lds_read128(lds_base + 4u * (OPER + k));
-        sd[t] = lds_read128(lds_base + 4u * (OPER + NTAB + k));
+      f.a[t] = lds_read128(A + 16u * (unsigned)(sa + (q ^ xa)));
+      f.b[t] = lds_read128(B + 16u * (unsigned)(sb + (q ^ xb)));
+      if (norm) {
+        const unsigned k = (unsigned)(c * GK + 4 * q);
+        f.mu[t] = lds_read128(lds_base + 4u * (OPER + k));
+        f.sd[t] = lds_read128(lds_base + 4u * (OPER + NTAB + k));
       }
-      lds_wait4(mu[0], mu[1], sd[0], sd[1]);
-      lds_wait4(av[0], av[1], bv[0], bv[1]);
+    }
+  };
+  // One trip = chunk c out of registers (its LDS reads were requested a trip ago and ran under the previous chunk's multiplies):
+  //   wait (counted) until chunk c + 1 has landed, LDS-only barrier (everybody's reads of chunk c are complete: its image pair is free, and
+  //   everybody's pieces of chunk c + 1 are there), request chunk c + NBUF into the freed pair, request the LDS reads of chunk c + 1, multiply chunk c.
+  auto trip = [&](int c, int buf, Frag& cur, Frag& nxt) {
+    if (c + 1 < nchunk) {
+      if (c + NBUF - 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NBUF - 2)) : "memory");   // chunks c + 2 .. c + NBUF - 1 may still fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    SDX_LDS_BARRIER();
+    lds_wait4(cur.a[0], cur.a[1], cur.b[0], cur.b[1]);            // (already complete: ties the registers to the wait for the compiler)
+    if (norm) lds_wait4(cur.mu[0], cur.mu[1], cur.sd[0], cur.sd[1]);
+    if (c + NBUF < nchunk) request(c + NBUF, buf);
+    if (c + 1 < nchunk) read_chunk(c + 1, buf + 1 == NBUF ? 0 : buf + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);                              // the reads are issued in front of the dependent multiplies, not behind them
+    if (norm) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[t][i] = clampf((av[t][i] - mu[t][i]) / sd[t][i], -5.0f, 5.0f);
-    } else {
-      lds_wait4(av[0], av[1], bv[0], bv[1]);
+        for (int i = 0; i < 4; ++i) cur.a[t][i] = clampf((cur.a[t][i] - cur.mu[t][i]) / cur.sd[t][i], -5.0f, 5.0f);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][i], bv[t][i], acc, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t][i], cur.b[t][i], acc, 0, 0, 0);
+  };
+#pragma unroll
+  for (int c = 0; c < NBUF; ++c)
+    if (c < nchunk) request(c, c);
+  Frag f0, f1;
+  // chunk 0: landed once at most NBUF - 1 younger chunks are outstanding
+  if (nchunk >= NBUF) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NBUF - 1)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SDX_LDS_BARRIER();
+  read_chunk(0, 0, f0);
+  int buf = 0;
+  for (int c = 0; c < nchunk; c += 2) {
+    trip(c, buf, f0, f1);
     buf = buf + 1 == NBUF ? 0 : buf + 1;
-    nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
+    if (c + 1 < nchunk) {
+      trip(c + 1, buf, f1, f0);
+      buf = buf + 1 == NBUF ? 0 : buf + 1;
+    }
   }
   // sum of the k groups, in group order (the operand images are reused)
   SDX_LDS_BARRIER();
