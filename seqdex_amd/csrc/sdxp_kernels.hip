@@ -215,6 +215,16 @@ __global__ __launch_bounds__(256 * KS) void k_linear_mfma(LinBatch lb) {
 // times per sdxp_act.  sdxp_act as a whole did not move, so the launcher keeps shape 3; this kernel is shape 7
 // (SDXP_LINEAR_TILE=7), held to float64 with every other shape by tests/test_gpu_linear_kernel.py.  A fourth image pair (72 KB of LDS: the tables
 // then sit above 64 KB) gave wrong sums in normalised launches - LDS addresses above 64 KB through inline-asm ds_read - and 1 % in time: dropped.
+// LDS reads of the DMA pipeline as inline asm: hipcc's wait-count pass treats every ds_read it can see as a possible reader of every LDS-DMA
+// in flight and puts s_waitcnt vmcnt(0) in front of it (seen in the first build of this kernel: the chunk requested a line earlier was waited
+// for at once, the pipeline was serial).  What it cannot see it does not wait for; the waits are spelled out (lds_wait4).
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v_t lds_read128(unsigned byte_addr) {
+  f4v_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
+__device__ __forceinline__ void lds_wait4(f4v_t& a, f4v_t& b, f4v_t& c, f4v_t& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 template <int KS, int NBUF>
 __global__ __launch_bounds__(256 * KS) void k_linear_glds(LinBatch lb) {
   static_assert(KS == 2 && NBUF == 3, "512 threads move one 16-byte piece of each operand tile per chunk; everything stays below 64 KB of LDS");
