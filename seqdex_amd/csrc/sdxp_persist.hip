@@ -212,11 +212,15 @@ __device__ __forceinline__ void adam1f(float& w, float g, float& m, float& v, fl
   v = 0.999f * v + 0.001f * g * g;
   w -= lr_bc1 * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * isq_bc2 + 1e-8f);
 }
-#ifdef SDXP_ADAM0_FREE
-#define ADAM0 adam1f
-#else
-#define ADAM0 adam1
-#endif
+// layer 0 (the only Adam on the step's dependent chain): the moments arrive PRE-SCALED by 0.9 / 0.999 - done in the dY0 shadow, where the
+// element's gradient is formed - so that behind the clip scale an element is 7 VALU + sqrt + rcp instead of 11 (round 6)
+__device__ __forceinline__ void adam1p(float& w, float g, float& m9, float& v999, float lr_bc1, float isq_bc2) {
+  m9 = __builtin_fmaf(0.1f, g, m9);
+  v999 = __builtin_fmaf(0.001f * g, g, v999);
+  w -= lr_bc1 * m9 * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v999) * isq_bc2 + 1e-8f);
+  __builtin_amdgcn_sched_barrier(0);
+}
+#define ADAM0 adam1p
 // accumulate the 4x4 Gram (lower triangle, 10 terms) and |sum|^2 of (a, b, c, d)
 __device__ __forceinline__ void gram_acc(float* p, float a, float b, float c, float d) {
   p[0] += a * a; p[1] += b * a; p[2] += b * b; p[3] += c * a; p[4] += c * b; p[5] += c * c;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     he = HPC * g + t; hrow = he >> 8; hk = he & (U2 - 1);
   };
   refresh();
-#define TS(i) if (stamps && g == 0 && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); S.tacc[i] += t_ - S.tlast; S.tlast = t_; }
+#define TS(i) if (stamps && g == (stamps >> 8) && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); S.tacc[i] += t_ - S.tlast; S.tlast = t_; }
   if (tid < 32) S.tacc[tid] = 0;
   if (tid == 0) S.fail = 0;
   if (tid == 0) S.tlast = __builtin_amdgcn_s_memtime();
@@ -484,6 +488,12 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     }
   };
   if (total_steps > 0) load_rows(SINGLE ? gctl->mb_index : 0, SINGLE ? gctl->mini_epoch : 0);   // rows of the first minibatch
+  // first look at the gradient-norm words (round 6): every CU published its word at the end of phase E, 1.6 us before the top of the next
+  // step, so the words are there when the dY0 shadow ends - what the gather at the top of the step paid for was its own round trip
+  // (0.9 us of the 1.2: all 256 CUs show the same 1.2 us, there is no late producer).  The loads are requested behind the shadow's second
+  // barrier and taken at the top of the next step; a miss falls back to the polling gather.
+  u32x4 pg0[4];
+  bool pg0_issued = false;
   for (int step = 0; step <= total_steps; ++step) {
     SDX_LDS_BARRIER();   // LDS only: the next step's row loads (requested in the dY0 shadow) stay in flight across it
     if (S.fail) return;   // an exchange word never arrived (not all CUs resident?): the host sees *failflag and reports it
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       // - the other layers' and the heads' terms (S.n2rest), the bias corrections and the learning-rate scalars (S.scal[2..5]) - was
       // prepared in the shadows of the previous step.
       float w0[4], w1[4], w2[4];
-      if (!lq_gather<4>(LQ, LQ_G0 + lane, 64, tag_prev, w0, w1, w2, failflag)) S.fail = 1;
+      if (!(pg0_issued && lq_take<4>(pg0, tag_prev, w0, w1, w2)) && !lq_gather<4>(LQ, LQ_G0 + lane, 64, tag_prev, w0, w1, w2, failflag)) S.fail = 1;
       float n2[3];
       n2[0] = (w0[0] + w0[1]) + (w0[2] + w0[3]); n2[1] = (w1[0] + w1[1]) + (w1[2] + w1[3]); n2[2] = (w2[0] + w2[1]) + (w2[2] + w2[3]);
 #pragma unroll
@@ -1109,8 +1119,12 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       C.last_kl = kl;
       C.ac_lr_applied = C.ac_lr;   // the optimiser step of THIS minibatch uses the current lr; the schedule moves it afterwards
       if (D.adaptive_lr) {         // legacy schedule: after every minibatch (PS:306-312)
-        if (kl > 2.0f * D.kl_threshold) C.ac_lr = fmaxf(C.ac_lr / 1.5f, 1e-6f);
-        if (kl < 0.5f * D.kl_threshold) C.ac_lr = fminf(C.ac_lr * 1.5f, 1e-2f);
+        // (the two thresholds are formed HERE from an opaque copy: hoisted out of the step loop they cost two registers for the whole launch,
+        // and with the first look at the norm words in flight one of them was spilled and reloaded - a scratch load and a vmcnt(0) - in this shadow)
+        float klt = D.kl_threshold;
+        SDX_OPAQUE(klt);
+        if (kl > 2.0f * klt) C.ac_lr = fmaxf(C.ac_lr / 1.5f, 1e-6f);
+        if (kl < 0.5f * klt) C.ac_lr = fminf(C.ac_lr * 1.5f, 1e-2f);
       }
       if constexpr (!SINGLE) {
         // Adam step counters / bias corrections of the optimiser step that applies THIS minibatch's gradient (phase A of the next
@@ -1293,6 +1307,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
         rows_store<8>(S, ua, 0, wave, lane);
       }
       SDX_LDS_BARRIER();          // (rows_reduce, opened up: the stage between its two barriers occupies 32 threads ...)
+      lq_peek<4>(LQ, LQ_G0 + lane, 64, pg0); pg0_issued = true;   // (0.7 us into the shadow: the words left their CUs 0.7 + 2.0 (phase E) us ago; the round trip ends with the shadow)
       if (tid < 32) {
         float t = 0.0f;
 #pragma unroll
@@ -1314,6 +1329,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 #pragma unroll
           for (int s = 0; s < MB; ++s) { const float x = S.obs[s][kc]; ga += da[s] * x; gc += dc[s] * x; }
           g0a[i] = ok ? ga : 0.0f; g0c[i] = ok ? gc : 0.0f;
+          m0a[i] *= 0.9f; v0a[i] *= 0.999f; m0c[i] *= 0.9f; v0c[i] *= 0.999f;   // (adam1p: off the chain)
         }
 #pragma unroll
         for (int i = 0; i < I0V; ++i) {
@@ -1324,6 +1340,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
 #pragma unroll
           for (int s = 0; s < MB; ++s) gv += dvv[s] * S.cvx[s][kc];
           g0v[i] = ok ? gv : 0.0f;
+          m0v[i] *= 0.9f; v0v[i] *= 0.999f;
         }
       }
       SDX_LDS_BARRIER();
@@ -1347,7 +1364,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     pending = true;
   }
 
-  if (stamps && g == 0 && tid < 32) D.dbg[tid] = S.tacc[tid];
+  if (stamps && g == (stamps >> 8) && tid < 32) D.dbg[tid] = S.tacc[tid];
   // ------------------------------------------------------------------ epilogue: resident parameters back to HBM
   refresh();
 #pragma unroll
@@ -1425,7 +1442,9 @@ extern "C" int sdxpk_persist_supported(const SdxpDev* D, int minibatch, int n_cu
 }
 extern "C" int sdxpk_update_persistent(const SdxpDev* D, int total_steps, unsigned* failflag, hipStream_t st) {
   static bool attr = false;
-  static const int stamps = (getenv("SDXP_PERSIST_STAMPS") && getenv("SDXP_PERSIST_STAMPS")[0] == '1') ? 1 : 0;
+  // SDXP_PERSIST_STAMPS=1: phase clock of CU 0; SDXP_PERSIST_STAMP_CU=<g> picks another CU (bits 8.. of the kernel's flag)
+  static const int stamps = (getenv("SDXP_PERSIST_STAMPS") && getenv("SDXP_PERSIST_STAMPS")[0] == '1')
+                                ? (1 | ((getenv("SDXP_PERSIST_STAMP_CU") ? (atoi(getenv("SDXP_PERSIST_STAMP_CU")) & 255) : 0) << 8)) : 0;
   const char* fe = getenv("SDXP_PERSIST_FAULT");   // read per call: the failure-path test sets and clears it
   const int fault = (fe && fe[0] == '1') ? 1 : 0;
   if (!attr) {
