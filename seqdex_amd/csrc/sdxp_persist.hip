@@ -212,6 +212,8 @@ __device__ __forceinline__ void adam1f(float& w, float g, float& m, float& v, fl
   v = 0.999f * v + 0.001f * g * g;
   w -= lr_bc1 * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * isq_bc2 + 1e-8f);
 }
+#define SDX_PIN4X(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define SDX_PIN3X(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 // layer 0 (the only Adam on the step's dependent chain): the moments arrive PRE-SCALED by 0.9 / 0.999 - done in the dY0 shadow, where the
 // element's gradient is formed - so that behind the clip scale an element is 7 VALU + sqrt + rcp instead of 11 (round 6)
 __device__ __forceinline__ void adam1p(float& w, float g, float& m9, float& v999, float lr_bc1, float isq_bc2) {
@@ -514,20 +516,24 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       // waves of all CUs hold bit-identical scalars and walk into Adam of layer 0 as their own words arrive.  What does not depend on dY0
       // - the other layers' and the heads' terms (S.n2rest), the bias corrections and the learning-rate scalars (S.scal[2..5]) - was
       // prepared in the shadows of the previous step.
+      // (what the scalars below need from LDS is requested in front of the norm words' take: one LDS round trip less behind the DPP sums)
+      float nr0 = S.n2rest[0], nr1 = S.n2rest[1], nr2 = S.n2rest[2];
+      float ac_lr_bc1 = S.scal[2], ac_isq = S.scal[3], cv_lr_bc1 = S.scal[4], cv_isq = S.scal[5];
       float w0[4], w1[4], w2[4];
       if (!(pg0_issued && lq_take<4>(pg0, tag_prev, w0, w1, w2)) && !lq_gather<4>(LQ, LQ_G0 + lane, 64, tag_prev, w0, w1, w2, failflag)) S.fail = 1;
       float n2[3];
       n2[0] = (w0[0] + w0[1]) + (w0[2] + w0[3]); n2[1] = (w1[0] + w1[1]) + (w1[2] + w1[3]); n2[2] = (w2[0] + w2[1]) + (w2[2] + w2[3]);
 #pragma unroll
       for (int net = 0; net < 3; ++net) n2[net] = wave_sum(n2[net]);     // three independent DPP chains
-#pragma unroll
-      for (int net = 0; net < 3; ++net) n2[net] += S.n2rest[net];
-      const float ac_gn = sqrtf(n2[0] + n2[1]), cv_gn = sqrtf(n2[2]);
-      const float gs_ac = D.truncate_grads ? fminf(1.0f, D.grad_norm / (ac_gn + 1e-6f)) : 1.0f;
-      const float gs_cv = D.truncate_grads ? fminf(1.0f, D.grad_norm / (cv_gn + 1e-6f)) : 1.0f;
+      SDX_PIN4X(nr0, nr1, nr2, ac_lr_bc1); SDX_PIN3X(ac_isq, cv_lr_bc1, cv_isq);   // (used from here on; requested above)
+      n2[0] += nr0; n2[1] += nr1; n2[2] += nr2;
+      // v_sqrt_f32 / v_rcp_f32 (1 ulp each, as in the Adam arithmetic) instead of the IEEE sequences: these four sit between the last word of the
+      // norm and the first Adam instruction of every lane
+      const float ac_gn = __builtin_amdgcn_sqrtf(n2[0] + n2[1]), cv_gn = __builtin_amdgcn_sqrtf(n2[2]);
+      const float gs_ac = D.truncate_grads ? fminf(1.0f, D.grad_norm * __builtin_amdgcn_rcpf(ac_gn + 1e-6f)) : 1.0f;
+      const float gs_cv = D.truncate_grads ? fminf(1.0f, D.grad_norm * __builtin_amdgcn_rcpf(cv_gn + 1e-6f)) : 1.0f;
       if (tid == 0) { S.ctl.ac_gn = ac_gn; S.ctl.cv_gn = cv_gn; S.scal[0] = gs_ac; S.scal[1] = gs_cv; }   // for the shadows' Adam phases (behind the next barrier)
       TS(0)
-      const float ac_lr_bc1 = S.scal[2], ac_isq = S.scal[3], cv_lr_bc1 = S.scal[4], cv_isq = S.scal[5];
       // ---- layer 0 rows: gradient elements from registers (g0a / g0c / g0v, dY0 shadow of the previous iteration), scaled by the clip factor
 #pragma unroll
       for (int i = 0; i < I0A; ++i) {
