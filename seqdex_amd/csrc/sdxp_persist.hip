@@ -82,7 +82,7 @@ struct PLds {
   float fpart[3 * MB * NWV];  // cross-wave partial dot products of the forward passes
   float red[4 * NWV][64];    // block_sum: one row per (wave, DPP row)
   float mu[MB][32], dmu[MB][32], z[MB][32], act[MB][32], omu[MB][32], osg[MB][32];
-  float val[2][MB], dv[2][MB], gnlp[MB], ls[32], dls[32], stat[MB][8];
+  float val[2][MB], dv[2][MB], gnlp[MB], ls[32], sgm[32], dls[32], stat[MB][8];   // sgm = exp(ls): formed with ls in the x3 shadow (round 6), not three times in the loss phase
   // biases of the owned rows and their Adam moments, one thread per slot: [0..11] L0 (net*4 + row), [12..17] L1 (12 + net*2 + row),
   // [18..20] L2 (18 + net), [21..45] heads (21 + row, replicated on every CU); logstd lives in the static bank s_b2
   float bias[64], bias_m[64], bias_v[64];
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
     TS(8)
     // (this minibatch's actions and old (mu, sigma) go to LDS before the Grams: three registers fewer across the 60-value reduction)
     if (tid < MB * 32) { S.act[tid / 32][tid % 32] = pf_act; S.omu[tid / 32][tid % 32] = pf_omu; S.osg[tid / 32][tid % 32] = pf_osg; }
-    if (tid >= 128 && tid < 128 + 32) S.ls[tid - 128] = (tid - 128 < A) ? s_b2[0][tid - 128] : 0.0f;
+    if (tid >= 128 && tid < 128 + 32) { const float l_ = (tid - 128 < A) ? s_b2[0][tid - 128] : 0.0f; S.ls[tid - 128] = l_; S.sgm[tid - 128] = expf(l_); }
     if constexpr (!SINGLE)
     {   // ---- (shadow of x3) Grams of x2 and x1 (S.x1 stays valid until the next step's gather).  Two butterflies, ONE pass through LDS
         // and its two barriers: out[0..29] = [x2: net][10], out[32..61] = [x1: net][10]
@@ -995,10 +995,10 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       if (tid < MB * 32) {
         const int s = tid / 32, a = tid % 32;
         // z of (sample s, action a): formed by the thread that uses it here; S.z is only for the dmu / dlogstd lanes after the barrier below
-        const float zz = (a < A) ? (S.act[s][a] - S.mu[s][a]) / expf(S.ls[a]) : 0.0f;
+        const float zz = (a < A) ? (S.act[s][a] - S.mu[s][a]) / S.sgm[a] : 0.0f;
         S.z[s][a] = zz;
         if (a < A) {
-          const float ls = S.ls[a], sg = expf(ls), mu = S.mu[s][a];
+          const float ls = S.ls[a], sg = S.sgm[a], mu = S.mu[s][a];
           r_nlp = 0.5f * zz * zz + ls;
           const float omu = S.omu[s][a], osg = S.osg[s][a];
           r_kl = logf(osg / sg + 1e-5f) + (sg * sg + (omu - mu) * (omu - mu)) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(NTH, 2) void k_update_persistent(SdxpDev D, int tot
       const int s = tid / 32, a = tid % 32;
       float dmu = 0.0f;
       if (a < A) {
-        const float sg = expf(S.ls[a]), mu = S.mu[s][a];
+        const float sg = S.sgm[a], mu = S.mu[s][a];
         const float hi = fmaxf(mu - 1.1f, 0.0f), lo = fminf(mu + 1.1f, 0.0f);
         dmu = S.gnlp[s] * (-(S.z[s][a] / sg)) * invM + D.bounds_coef * (2.0f * hi + 2.0f * lo) * invM;
         if (g == 0) { __hip_atomic_store(&D.mb_mus[(r0 + s) * A + a], mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&D.mb_sigmas[(r0 + s) * A + a], sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // update_mu_sigma (RC:1358)
