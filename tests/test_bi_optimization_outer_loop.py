@@ -110,7 +110,7 @@ def test_grasp_minibatch_override_reaches_both_grasp_legs_and_nothing_else(monke
     bo, runs, fits, *_ = _patch(monkeypatch)
     bo.block_assembly(rounds=1, num_envs=4096, grasp_minibatch=bo.CONFIG5_GRASP_MINIBATCH, stage_epochs=bo.CONFIG5_LEARNED_EPOCHS)
     assert [r["minibatch_size"] for r in runs] == [0, 0, 2048, 0, 0, 2048, 0]
-    assert [r["epochs"] for r in runs] == [20, 10, 400, 48, 32, 100, 10]
+    assert [r["epochs"] for r in runs] == [20, 10, 400, 48, 32, 100, 60]      # (backward Orient leg: 60 since round 6, CONFIG5_LEARNED_EPOCHS)
     runs.clear()
     bo.block_assembly(rounds=1, num_envs=4096, stage_epochs=bo.CONFIG5_EPOCHS)
     assert [r["minibatch_size"] for r in runs] == [0] * 7 and [r["epochs"] for r in runs] == [20, 10, 20, 48, 32, 20, 10]
